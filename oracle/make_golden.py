@@ -1,0 +1,262 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python (imported from
+/root/reference, authoring container only) on seeded synthetic scenes.
+
+    python -m oracle.make_golden            # writes tests/golden/*.npz
+
+A fixture holds inputs (seeds, pixel coordinates, the CPU RNG draws the reference consumed)
+and the reference's outputs; scenes are regenerated from their seed by
+spurfies_amd.synthetic.make_scene and guarded by a checksum stored in the fixture.
+Large tensors (weight / latent gradients) are stored as norms plus fixed probe entries.
+
+The kNN op underneath the reference run is oracle/voxel_grid.py (upstream torch_knnquery is
+absent, so that stage is pinned only to the build's frozen spec — "parity unpinned").
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim  # noqa: E402
+from spurfies_amd import synthetic as syn  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+N_PROBE = 512
+
+
+def scene_checksum(scene) -> np.ndarray:
+    st = scene["state"]
+    return np.asarray([float(np.asarray(st[k], np.float64).sum()) for k in sorted(st)], np.float64)
+
+
+def probes(name: str, t: torch.Tensor):
+    """Compact pin of a big tensor: [sum, abs-sum, l2] + N_PROBE entries at fixed indices."""
+    flat = t.detach().reshape(-1).double()
+    g = np.random.default_rng(abs(hash(name)) % (2 ** 31) if False else sum(map(ord, name)))
+    idx = g.integers(0, flat.numel(), size=min(N_PROBE, flat.numel()))
+    stats = np.asarray([flat.sum().item(), flat.abs().sum().item(), flat.norm().item()])
+    return {f"{name}.stats": stats, f"{name}.idx": idx.astype(np.int64), f"{name}.val": flat[idx].numpy().astype(np.float32)}
+
+
+class DrawRecorder:
+    """Record the CPU-generator draws the reference makes (ray_sampler.py:55,514,550,562)."""
+
+    def __init__(self):
+        self.draws = {}
+        self._orig = (torch.rand, torch.randperm, torch.randint)
+
+    def __enter__(self):
+        rec = self
+
+        def rand(*a, **k):
+            v = rec._orig[0](*a, **k)
+            shape = tuple(v.shape)
+            key = "uniform_rand" if (len(shape) == 2 and shape[1] == 128) else "cdf_rand"
+            rec.draws.setdefault(key, v.clone().numpy())
+            return v
+
+        def randperm(*a, **k):
+            v = rec._orig[1](*a, **k)
+            rec.draws.setdefault("extra_perm", v.clone().numpy())
+            return v
+
+        def randint(*a, **k):
+            v = rec._orig[2](*a, **k)
+            rec.draws.setdefault("eik_idx", v.clone().numpy())
+            return v
+
+        torch.rand, torch.randperm, torch.randint = rand, randperm, randint
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randperm, torch.randint = self._orig
+
+
+def make_inputs(scene, n_rays, view, seed):
+    g = torch.Generator().manual_seed(seed)
+    uv = syn.make_pixels(n_rays, g)
+    rgb_gt = torch.rand((n_rays, 3), generator=g).numpy()
+    mask_gt = (torch.rand((n_rays,), generator=g) > 0.2).float().numpy()
+    inp = {"intrinsics": torch.from_numpy(scene["intrinsics"])[None], "uv": torch.from_numpy(uv)[None],
+           "pose": torch.from_numpy(scene["poses"][view])[None], "local_data": None, "iter_step": 0}
+    return inp, uv, rgb_gt, mask_gt
+
+
+def reference_loss():
+    ref_shim.enter_reference()
+    if "helpers.help" not in sys.modules:  # loss.py:6 imports a logger from helpers/help.py (needs omegaconf/GPUtil)
+        pkg = types.ModuleType("helpers")
+        hm = types.ModuleType("helpers.help")
+        hm.logger = ref_shim._Anything()
+        pkg.help = hm
+        sys.modules["helpers"], sys.modules["helpers.help"] = pkg, hm
+    from spurfies.model.loss import VolSDFLoss
+
+    return VolSDFLoss("torch.nn.L1Loss", local_weight=0.5, pseudo_weight=0.5, eikonal_weight=0.001,
+                      rgb_weight=1.0, tv_weight=0.01)  # config/ours.yaml:15-20
+
+
+def golden_train_step(name, n_points, n_rays, view, seed, cam_radius=2.2):
+    scene = syn.make_scene(n_points, seed=seed)
+    if cam_radius != 2.2:
+        scene["intrinsics"], scene["poses"] = syn.make_cameras(ring_radius=cam_radius)
+    model, ref_mod = ref_shim.build_reference_model(scene)
+    model.train()
+    inp, uv, rgb_gt, mask_gt = make_inputs(scene, n_rays, view, seed + 100)
+    loss_fn = reference_loss()
+    captured = {}
+    orig_query = ref_mod.query
+
+    def query_spy(grid, inputs, k, r, sr):
+        res = orig_query(grid, inputs, k, r, sr)
+        if sr > 1:
+            captured["points"] = inputs.detach().clone()
+            captured["neighbor_idx"] = res[0].clone()
+            captured["mask"] = res[2].clone()
+            captured["ray_mask"] = res[3].clone()
+        return res
+
+    ref_mod.query = query_spy
+    orig_get_sdf, orig_get_color = model.get_sdf, model.get_color
+
+    def sdf_spy(*a, **k):
+        captured["agg_sdf"] = orig_get_sdf(*a, **k)
+        return captured["agg_sdf"]
+
+    def color_spy(*a, **k):
+        captured["colors"] = orig_get_color(*a, **k)
+        return captured["colors"]
+
+    model.get_sdf, model.get_color = sdf_spy, color_spy
+    torch.manual_seed(seed + 7)
+    with DrawRecorder() as rec:
+        out = model(inp, fast=1)
+    ref_mod.query = orig_query
+    gt = {"rgb": torch.from_numpy(rgb_gt)[None], "mask": torch.from_numpy(mask_gt)[None, :, None].repeat(1, 1, 3)}
+    losses = loss_fn(out, gt)
+    model.zero_grad()
+    losses["loss"].backward()
+    fx = {"meta.n_points": n_points, "meta.n_rays": n_rays, "meta.view": view, "meta.seed": seed,
+          "meta.cam_radius": cam_radius, "meta.checksum": scene_checksum(scene),
+          "in.uv": uv, "in.rgb_gt": rgb_gt, "in.mask_gt": mask_gt}
+    fx.update({f"draw.{k}": v for k, v in rec.draws.items()})
+    for k in ("rgb_values", "depth_values", "depth_vals", "weights", "xyz", "pseudo_pts_loss", "tv_loss", "grad_theta"):
+        fx[f"out.{k}"] = out[k].detach().numpy()
+    for k in ("points", "neighbor_idx", "mask", "ray_mask", "agg_sdf", "colors"):
+        fx[f"stage.{k}"] = captured[k].detach().numpy()
+    fx["stage.neighbor_idx"] = fx["stage.neighbor_idx"].astype(np.int32)
+    for k, v in losses.items():
+        fx[f"loss.{k}"] = np.float64(v.item())
+    for pname, p in model.named_parameters():
+        if p.requires_grad:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            fx.update(probes(f"grad.{pname}", g))
+    fx["meta.knn_calls"] = np.asarray([c[1] for c in model._voxel_grid_neural.calls], np.int64)
+    np.savez_compressed(os.path.join(OUT, name), **fx)
+    print(name, "rays valid", int(captured["ray_mask"].sum()), "P", captured["neighbor_idx"].shape[0],
+          "loss", losses["loss"].item(), "pseudo", out["pseudo_pts_loss"].item())
+
+
+def golden_eval_step(name, n_points, n_rays, view, seed):
+    scene = syn.make_scene(n_points, seed=seed)
+    model, ref_mod = ref_shim.build_reference_model(scene, near=0.5)
+    model.eval()
+    inp, uv, _, _ = make_inputs(scene, n_rays, view, seed + 100)
+    n_calls = []
+    orig = model.sdf_importance
+
+    def spy(x):
+        n_calls.append(int(x.shape[0]))
+        return orig(x)
+
+    model.sdf_importance = spy
+    torch.manual_seed(seed + 7)
+    with DrawRecorder() as rec:
+        out = model(inp, fast=-1)
+    fx = {"meta.n_points": n_points, "meta.n_rays": n_rays, "meta.view": view, "meta.seed": seed,
+          "meta.checksum": scene_checksum(scene), "in.uv": uv, "meta.sampler_calls": np.asarray(n_calls, np.int64)}
+    fx.update({f"draw.{k}": v for k, v in rec.draws.items()})
+    for k in ("rgb_values", "depth_values", "depth_vals", "weights", "xyz", "normal_map", "pseudo_pts_loss", "tv_loss"):
+        fx[f"out.{k}"] = out[k].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, name), **fx)
+    print(name, "sampler calls", n_calls)
+
+
+def golden_sdf_eval(name, n_points, seed, res=20):
+    scene = syn.make_scene(n_points, seed=seed)
+    model, _ = ref_shim.build_reference_model(scene)
+    model.eval()
+    b = scene["base_radius"] * 1.3
+    ax = torch.linspace(-b, b, res)
+    x = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    with torch.no_grad():
+        sdf = model.get_sdf_eval(x)
+    fx = {"meta.n_points": n_points, "meta.seed": seed, "meta.checksum": scene_checksum(scene),
+          "in.x": x.numpy(), "out.sdf": sdf.numpy()}
+    np.savez_compressed(os.path.join(OUT, name), **fx)
+    print(name, "valid", int((sdf != 1000).sum()), "of", len(sdf))
+
+
+def golden_knn(name, seed):
+    """Frozen-spec kNN vectors (UNPINNED vs upstream torch_knnquery — generated by
+    oracle/voxel_grid.py, cross-checked against its brute-force twin) incl. the edge cases of
+    SURVEY.md §8(c) G1: empty rays, > SR hits, duplicate distances, points outside `ranges`."""
+    from oracle.voxel_grid import VoxelGridOracle, brute_force_knn
+
+    rng = np.random.default_rng(seed)
+    pts, _, base = syn.make_cloud(3000, seed=seed)
+    pts = np.concatenate([pts, pts[:40] + np.float32(0.0),            # exact duplicates -> equal distances
+                          rng.uniform(1.05, 1.4, size=(25, 3)).astype(np.float32),   # outside ranges -> dropped
+                          np.asarray([[0.9, 0.9, 0.9], [0.9, 0.9, 0.925]], np.float32)])
+    grid = VoxelGridOracle((0.025,) * 3, (3,) * 3, (3,) * 3, 26, 20000, (-1, -1, -1, 1, 1, 1))
+    grid.set_pointset(pts)
+    fx = {"in.pts": pts, "meta.origin": grid.origin, "meta.dims": grid.dims, "meta.cell": grid.cell}
+    cases = {}
+    # D=1 point-wise (sampler / get_sdf_eval shape): random positions near and far from the surface
+    d = rng.standard_normal((4000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    x1 = (d * (base * rng.uniform(0.6, 1.4, size=(4000, 1)))).astype(np.float32)
+    x1[:64] = pts[:64]                                                   # exactly on points (dist 0)
+    x1[64:96] = ((pts[100:132] + pts[101:133]) * np.float32(0.5))          # midpoints: tie candidates
+    cases["d1"] = (x1[:, None, :], 8, 2, 1)
+    # rays through the object: D=98 with SR=80, and D=128 with a small SR so that > SR hits occur
+    o = np.asarray([2.0, 0.3, 0.2], np.float32)
+    tgt = rng.uniform(-0.9, 0.9, size=(96, 3)).astype(np.float32) * np.float32(base)
+    tgt[:8] = np.asarray([0.0, 0.0, 5.0], np.float32)                    # rays that miss everything
+    dirs = tgt - o
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    for nm, D, SR, k in (("d98", 98, 80, 8), ("d128", 128, 6, 4)):
+        z = np.sort(rng.uniform(0.5, 3.5, size=(96, D)).astype(np.float32), axis=1)
+        z[:, D // 2 :] = np.sort(rng.uniform(1.0, 2.6, size=(96, D - D // 2)).astype(np.float32), axis=1)
+        z = np.sort(z, axis=1)
+        cases[nm] = ((o[None, None] + z[..., None] * dirs[:, None]).astype(np.float32), k, 2, SR)
+    for nm, (x, k, r, SR) in cases.items():
+        pidx, loc, slot_sample, ray_valid = grid.query_dense(x, k, r, SR)
+        sel = slot_sample >= 0
+        rr, ss = np.nonzero(sel)
+        bf = brute_force_knn(pts, x[rr, slot_sample[rr, ss]], k, grid.radius(r), grid.ranges)
+        assert np.array_equal(bf, pidx[rr, ss]), nm
+        fx.update({f"{nm}.x": x, f"{nm}.k": k, f"{nm}.r": r, f"{nm}.sr": SR, f"{nm}.pidx": pidx, f"{nm}.loc": loc,
+                   f"{nm}.slot_sample": slot_sample, f"{nm}.ray_valid": ray_valid})
+        print(name, nm, "hits", int(sel.sum()), "valid rays", int(ray_valid.sum()), "pairs", int((pidx >= 0).sum()))
+    np.savez_compressed(os.path.join(OUT, name), **fx)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    golden_knn("knn_spec.npz", seed=3)
+    golden_train_step("step_train_r128.npz", n_points=6000, n_rays=128, view=0, seed=0)
+    golden_train_step("step_train_far.npz", n_points=3000, n_rays=96, view=1, seed=1, cam_radius=1.6)
+    golden_eval_step("step_eval_r24.npz", n_points=6000, n_rays=24, view=2, seed=2)
+    golden_sdf_eval("sdf_eval_grid.npz", n_points=6000, seed=0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,42 @@
+"""Shared test helpers: rebuild a golden fixture's scene and compare compact pins."""
+import os
+
+import numpy as np
+import torch
+
+from spurfies_amd import synthetic as syn
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def scene_of(fx):
+    scene = syn.make_scene(int(fx["meta.n_points"]), seed=int(fx["meta.seed"]))
+    if "meta.cam_radius" in fx and float(fx["meta.cam_radius"]) != 2.2:
+        scene["intrinsics"], scene["poses"] = syn.make_cameras(ring_radius=float(fx["meta.cam_radius"]))
+    st = scene["state"]
+    chk = np.asarray([float(np.asarray(st[k], np.float64).sum()) for k in sorted(st)], np.float64)
+    np.testing.assert_allclose(chk, fx["meta.checksum"], rtol=0, atol=0, err_msg="synthetic scene drifted from the golden's")
+    return scene
+
+
+def inputs_of(fx, scene, device="cpu"):
+    return {"intrinsics": torch.from_numpy(scene["intrinsics"])[None].to(device),
+            "uv": torch.from_numpy(fx["in.uv"])[None].to(device),
+            "pose": torch.from_numpy(scene["poses"][int(fx["meta.view"])])[None].to(device),
+            "local_data": None, "iter_step": 0}
+
+
+def draws_of(fx):
+    return {k[len("draw."):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("draw.")}
+
+
+def check_probes(fx, name, t, rtol, atol):
+    flat = t.detach().reshape(-1).double().cpu()
+    idx = torch.from_numpy(fx[f"{name}.idx"])
+    np.testing.assert_allclose(flat[idx].numpy(), fx[f"{name}.val"], rtol=rtol, atol=atol, err_msg=name)
+    stats = fx[f"{name}.stats"]
+    np.testing.assert_allclose(flat.norm().item(), stats[2], rtol=max(rtol, 1e-4), atol=atol, err_msg=name + " l2")
