@@ -1,0 +1,146 @@
+/*
+ * spurfies_hip.h — C ABI of libspurfies_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the per-ray volumetric-rendering hot path of kevinYitshak/spurfies.
+ * Every entry point replaces a reference interface, cited as <file>:<line> relative to the
+ * reference tree.  The reference binds its native op from Python (torch_knnquery, a CUDA
+ * extension); this library is bound the same way, through ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types in signatures.
+ *   - Every data pointer is a DEVICE pointer owned by the caller (a torch tensor's data_ptr());
+ *     the library never frees or retains them beyond the call, except spf_grid_build, which
+ *     copies what it needs into tables owned by the opaque spf_grid handle.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it; no call synchronises the device unless it says so.
+ *   - Return value: 0 on success, negative SPF_E* code otherwise; text in spf_last_error()
+ *     (thread-local).  No exceptions cross the ABI.
+ *   - All floating-point data is float32 (the reference forces fp32, spurfies/train.py:23-24),
+ *     indices are int32.
+ */
+#ifndef SPURFIES_HIP_H
+#define SPURFIES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPF_OK 0
+#define SPF_EINVAL (-22)
+#define SPF_ENOMEM (-12)
+#define SPF_EHIP (-5)
+
+#define SPF_ABI_VERSION 1
+#define SPF_KMAX 8          /* neighbours per point (config/vol/dtu_pn.yaml:27, k: 8) */
+#define SPF_GEO_DIM 32      /* geometry latent width = feature_vector_size/2 (pointneus_disent.py:172) */
+#define SPF_COL_DIM 64      /* colour latent width  = feature_vector_size   (pointneus_disent.py:161) */
+#define SPF_HID 256         /* MLP width (pointneus_disent.py:76-107) */
+#define SPF_TILE_PTS 8      /* points per MLP tile (8 points x 8 neighbours = 64 MFMA rows) */
+
+int spf_abi_version(void);
+const char* spf_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Voxel grid  — replaces torch_knnquery.VoxelGrid
+ *   ctor          spurfies/model/pointneus_disent.py:45-62
+ *   set_pointset  spurfies/model/pointneus_disent.py:252-260,353-361,427-435,522-530,627-635
+ *   query         spurfies/model/utils.py:93-95,118-120
+ * Specification (frozen by this build; upstream source absent): see DESIGN.md §kNN.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct spf_grid spf_grid;
+
+typedef struct spf_grid_config {
+    float voxel_size[3];           /* (0.025, 0.025, 0.025) */
+    int32_t voxel_scale[3];        /* (3, 3, 3)  -> cell = voxel_size * voxel_scale */
+    int32_t kernel_size[3];        /* (3, 3, 3)  -> occupancy dilation box */
+    int32_t max_points_per_voxel;  /* accepted for signature parity; all points are kept */
+    int32_t max_occ_voxels;        /* accepted for signature parity; all cells are kept */
+    float ranges[6];               /* (xmin, ymin, zmin, xmax, ymax, zmax) */
+} spf_grid_config;
+
+typedef struct spf_grid_info {
+    float origin[3];
+    float cell[3];
+    int32_t dims[3];
+    int32_t n_points;     /* points handed to spf_grid_build */
+    int32_t n_in_range;   /* points inside `ranges` (the others are never returned) */
+    int32_t n_occupied;   /* occupied cells */
+} spf_grid_info;
+
+int spf_grid_create(const spf_grid_config* cfg, spf_grid** out);
+void spf_grid_destroy(spf_grid* g);
+
+/* VoxelGrid.set_pointset.  points: [n,3].  Builds the cell table (counting sort) and the
+ * dilated-occupancy bitmask.  Synchronises `stream` once (the bounding box sizes the tables).
+ * The reference rebuilds the grid 3-4x per step for a constant cloud; callers of this library
+ * build once per cloud. */
+int spf_grid_build(spf_grid* g, const float* points, int32_t n, void* stream);
+int spf_grid_get_info(const spf_grid* g, spf_grid_info* out);
+
+/* VoxelGrid.query, dense (uncompacted) form.  raypos: [R,D,3].
+ *   pidx        [R,SR,k] int32   neighbours sorted by (dist2, index), -1 padded
+ *   loc         [R,SR,3] float   position of the sample feeding each slot (0 where unused)
+ *   slot_sample [R,SR]   int32   sample index (0..D-1) feeding the slot, -1 = unused slot
+ *   slot_valid  [R,SR]   uint8   1 iff the slot has >= 1 neighbour ("valid point", utils.py:98-101)
+ *   ray_valid   [R]      uint8   1 iff some slot of the ray is valid (the op's ray_mask)
+ * radius_limit_scale multiplies max(voxel_size_x, voxel_size_y) as upstream does.  k <= SPF_KMAX. */
+int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D, int32_t k,
+                   float radius_limit_scale, int32_t SR, int32_t* pidx, float* loc,
+                   int32_t* slot_sample, uint8_t* slot_valid, uint8_t* ray_valid, void* stream);
+
+/* Device-side compaction of valid points (replaces the masked_select host syncs of
+ * spurfies/model/utils.py:107-112 and mask_to_batch_ray_idx :172-183).
+ *   point_slot [R*SR] int32  flat slot id (r*SR+s) of the p-th valid point, ray-major order
+ *   slot_point [R*SR] int32  inverse map, -1 for slots that are not valid points
+ *   n_points   [1]    int32  number of valid points P (stays on the device)
+ * scratch: >= R+1 int32. */
+int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t* point_slot,
+                       int32_t* slot_point, int32_t* n_points, int32_t* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused geometry path — replaces get_keypoint_data + compute_weights + get_sdf (+ the value of
+ * get_gradients): spurfies/model/utils.py:140-170, spurfies/model/pointneus_disent.py:241-247,
+ * 300-323; the same code inlined in sdf_importance :386-418, pseudo_sdf :460-493,
+ * get_sdf_eval :284-296.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Number of floats of the packed F_geometry/T weight image. */
+int64_t spf_geo_packed_floats(void);
+
+/* Pack nn.Linear weights ([out,in] row-major, as state_dict holds them) of
+ * F_geometry.{0,2,4,6,8} and T.0 into the MFMA fragment order the kernels stream.
+ * The last Linear of F_geometry and T are folded (no activation sits between them,
+ * pointneus_disent.py:95-98): v = T.W * F8.W, c = T.W * F8.b + T.b. */
+int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float* b2,
+                 const float* w4, const float* b4, const float* w6, const float* b6,
+                 const float* w8, const float* b8, const float* wT, const float* bT,
+                 float* packed, void* stream);
+
+/* One launch evaluates every valid point p < *n_points (a DEVICE int32; max_points sizes the
+ * launch; NULL = exactly max_points).  All per-point arrays are addressed by ROW:
+ * row = point_slot[p] (the flat slot id r*SR+s written by spf_compact_points), or row = p when
+ * point_slot is NULL.  Inputs: x[row,3] positions, nbr[row,k] int32 neighbours (-1 pad),
+ * tables pts[N,3], feat_geo[N,32], the packed weight image, rbf = conf.rbf (45).  Outputs (rows
+ * of invalid points are left untouched, so callers pre-fill e.g. sdf with 1000):
+ *   sdf   [rows]        RBF-weighted mean of the per-neighbour SDF
+ *   wn    [rows,8]      normalised RBF weights w_j / sum_j w_j (0 for padding); may be NULL
+ *   grad  [rows,3]      d sdf / d x  (NULL: skip the Jacobian sweep — sampler / eval mode)
+ *   jac   [rows,8,32]   d sdf_j / d latent_j per pair (NULL iff grad is NULL) */
+int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slot, const int32_t* n_points,
+                    int32_t max_points, int32_t k, const float* pts, const float* feat_geo,
+                    const float* packed, float rbf, float* sdf, float* wn, float* grad, float* jac,
+                    void* stream);
+
+/* Backward of the weighted mean w.r.t. the geometry latents (same row addressing):
+ *   g_feat_geo[nbr[row,j], :] += g_sdf[row] * wn[row,j] * jac[row,j,:]   (float atomics)
+ * (F_geometry / T are frozen in the reference's training, train.py:151-154.) */
+int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* jac, const int32_t* nbr,
+                             const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
+                             int32_t k, float* g_feat_geo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPURFIES_HIP_H */

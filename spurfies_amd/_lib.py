@@ -1,0 +1,85 @@
+"""ctypes binding of libspurfies_hip.so (the C ABI declared in include/spurfies_hip.h).
+
+The product path fails loudly when the HIP library is missing: there is no CPU or PyTorch
+fallback for any kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libspurfies_hip.so")
+
+
+class GridConfig(C.Structure):
+    _fields_ = [("voxel_size", C.c_float * 3), ("voxel_scale", C.c_int32 * 3), ("kernel_size", C.c_int32 * 3),
+                ("max_points_per_voxel", C.c_int32), ("max_occ_voxels", C.c_int32), ("ranges", C.c_float * 6)]
+
+
+class GridInfo(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("cell", C.c_float * 3), ("dims", C.c_int32 * 3),
+                ("n_points", C.c_int32), ("n_in_range", C.c_int32), ("n_occupied", C.c_int32)]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_F = C.c_float
+
+# name -> (restype, argtypes): exactly the entry points of include/spurfies_hip.h
+SIGNATURES = {
+    "spf_abi_version": (C.c_int, []),
+    "spf_last_error": (C.c_char_p, []),
+    "spf_grid_create": (C.c_int, [C.POINTER(GridConfig), C.POINTER(_P)]),
+    "spf_grid_destroy": (None, [_P]),
+    "spf_grid_build": (C.c_int, [_P, _P, _I, _P]),
+    "spf_grid_get_info": (C.c_int, [_P, C.POINTER(GridInfo)]),
+    "spf_grid_query": (C.c_int, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
+    "spf_compact_points": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P]),
+    "spf_geo_packed_floats": (C.c_int64, []),
+    "spf_geo_pack": (C.c_int, [_P] * 14),
+    "spf_geo_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+class SpurfiesHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SpurfiesHipError(
+                f"{LIB_PATH} is missing: build it with `python -m spurfies_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no fallback path.")
+        import torch  # noqa: F401  (loads torch's libamdhip64 first so both share one HIP runtime)
+
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = lib().spf_last_error()
+        raise SpurfiesHipError(f"{what} failed ({code}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,447 @@
+// Fused geometry path (K4 of DESIGN.md): gather 32-d geometry latents + relative positions of a
+// point's <= 8 neighbours, RBF weights, F_geometry + T on the fp32 matrix cores, the input-Jacobian
+// sweep, and the RBF-weighted mean per point — one kernel, activations never leave the CU.
+//
+// Replaces, for every caller, the reference's
+//   get_keypoint_data  spurfies/model/utils.py:140-170       (table concat + index_select + masked_select)
+//   compute_weights    spurfies/model/pointneus_disent.py:241-247
+//   get_sdf            spurfies/model/pointneus_disent.py:300-313 (5+1 cuBLAS GEMMs, index_add_)
+//   get_gradients      spurfies/model/pointneus_disent.py:315-323 (autograd double-backward graph)
+// and the inlined copies in sdf_importance :386-418, pseudo_sdf :460-493, get_sdf_eval :284-296.
+//
+// Shape of the work: one tile = 8 points x 8 neighbour slots = 64 rows.  Four waves per workgroup;
+// wave w owns output columns [64w, 64w+64) of every 256-wide layer as 2x2 tiles of
+// v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).  The A operand (activations,
+// [64][256] fp32, row stride 260 floats so ds_read_b128 is conflict-free) lives in LDS; the B operand
+// (weights) streams from L2 in a fragment order packed once by spf_geo_pack, 1 KiB per wave-load.
+//
+// Math (LeakyReLU slope 0.01 = nn.LeakyReLU default):
+//   h1 = W0 [g | x_pi] + b0, a1 = lrelu(h1), ..., a4 = lrelu(W6 a3 + b6)
+//   sdf_j = T (W8 a4 + b8) + bT = v . a4 + c,  v = T W8, c = T b8 + bT   (no activation between
+//           F_geometry's last Linear and T, pointneus_disent.py:95-98, so they fold exactly in R)
+//   d sdf_j / d in = (((v * D4) W6 * D3) W4 * D2) W2 * D1) W0,  D_l = lrelu'(h_l) in {1, 0.01}
+//   sdf(p) = sum_j w_j sdf_j / sum_j w_j,  w_j = exp(-(rbf * max(|x_pi|, 1e-12))^2)  (detached)
+//   d sdf / d x(p) = sum_j (w_j / norm) d sdf_j / d x_pi
+#include "common.h"
+
+namespace {
+
+using namespace spf;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LDA = 260;     // LDS row stride in floats (1040 B: 16-B aligned, breaks the 256-B bank period)
+constexpr int K_IN = 35;     // 32 latent + 3 x_pi
+constexpr int T_IN = 5;      // ceil(35/8) k-steps of 8 for the first layer
+constexpr int T_HID = 32;    // 256/8
+
+// packed image layout (floats)
+constexpr int SZ_FW1 = 4 * T_IN * 2 * 64 * 4;
+constexpr int SZ_HH = 4 * T_HID * 2 * 64 * 4;
+constexpr int SZ_JW = 2 * T_HID * 64 * 4;
+constexpr int OFF_FW1 = 0;
+constexpr int OFF_FW2 = OFF_FW1 + SZ_FW1;
+constexpr int OFF_FW3 = OFF_FW2 + SZ_HH;
+constexpr int OFF_FW4 = OFF_FW3 + SZ_HH;
+constexpr int OFF_BW4 = OFF_FW4 + SZ_HH;  // d/d a3 = g_h4 * W6
+constexpr int OFF_BW3 = OFF_BW4 + SZ_HH;  // W4
+constexpr int OFF_BW2 = OFF_BW3 + SZ_HH;  // W2
+constexpr int OFF_JW1 = OFF_BW2 + SZ_HH;  // W0 (256 -> 35, padded to 64)
+constexpr int OFF_B1 = OFF_JW1 + SZ_JW;
+constexpr int OFF_B2 = OFF_B1 + 256;
+constexpr int OFF_B3 = OFF_B2 + 256;
+constexpr int OFF_B4 = OFF_B3 + 256;
+constexpr int OFF_V5 = OFF_B4 + 256;
+constexpr int OFF_C = OFF_V5 + 256;
+constexpr int PACKED_FLOATS = OFF_C + 4;
+
+// LDS carve (floats)
+constexpr int L_X = 0;
+constexpr int L_W = L_X + 64 * LDA;   // rbf weight per row
+constexpr int L_S = L_W + 64;         // per-row sdf
+constexpr int L_JX = L_S + 64;        // per-row d sdf_j / d x_pi (3)
+constexpr int L_NORM = L_JX + 192;    // per-point sum of weights
+constexpr int L_SROW = L_NORM + 8;    // per-point output row (int bits), -1 beyond the last point
+constexpr int L_TOTAL = L_SROW + 8;
+
+__device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// acc[mt][nt] += X[mt*32.., :] * B  for this wave's 64 output columns.  wp: [T][2][64] float4.
+template <int T>
+__device__ __forceinline__ void gemm_rows64(const float* X, const f32x4* wp, int lane, f32x16 (&acc)[2][2]) {
+    const int i = lane & 31, h = lane >> 5;
+    const float* a0p = X + i * LDA + 4 * h;
+    const float* a1p = a0p + 32 * LDA;
+    const f32x4* bp = wp + lane;
+    f32x4 b0 = bp[0], b1 = bp[64];
+#pragma unroll 4
+    for (int t = 0; t < T; ++t) {
+        f32x4 nb0 = b0, nb1 = b1;
+        if (t + 1 < T) {
+            nb0 = bp[(t + 1) * 128];
+            nb1 = bp[(t + 1) * 128 + 64];
+        }
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + 8 * t);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 8 * t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        }
+        b0 = nb0;
+        b1 = nb1;
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+}
+
+// forward epilogue: + bias, record sign bits, LeakyReLU, write this wave's 64x64 block back to X
+__device__ __forceinline__ void fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave,
+                                             int lane, uint32_t (&mask)[2]) {
+    const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+    const float bv[2] = {bias[c0], bias[c0 + 32]};
+    mask[0] = mask[1] = 0u;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[m][n][r] + bv[n];
+                const bool pos = v > 0.f;
+                mask[m] |= (pos ? 1u : 0u) << (n * 16 + r);
+                v = pos ? v : v * 0.01f;
+                X[(m * 32 + row_of(r, h)) * LDA + c0 + 32 * n] = v;
+            }
+}
+
+// backward epilogue: g_h = g_a * lrelu'(h)
+__device__ __forceinline__ void bwd_epilogue(float* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mask)[2]) {
+    const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool pos = (mask[m] >> (n * 16 + r)) & 1u;
+                const float v = acc[m][n][r];
+                X[(m * 32 + row_of(r, h)) * LDA + c0 + 32 * n] = pos ? v : v * 0.01f;
+            }
+}
+
+template <bool WITH_JAC>
+__global__ void __launch_bounds__(256, 2)
+geo_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
+                   const int32_t* __restrict__ n_points_dev, int max_points, int k, const float* __restrict__ pts,
+                   const float* __restrict__ feat_geo, const float* packed, float rbf, float* __restrict__ sdf,
+                   float* __restrict__ wn, float* __restrict__ grad, float* __restrict__ jac) {
+    __shared__ __attribute__((aligned(16))) float smem[L_TOTAL];
+    float* X = smem + L_X;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    const int ntiles = (P + SPF_TILE_PTS - 1) / SPF_TILE_PTS;
+    const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- gather: thread = (row, quarter of the 32-d latent) ---------------------------------
+        {
+            const int row = tid >> 2, q = tid & 3;
+            const int p = tile * SPF_TILE_PTS + (row >> 3), j = row & 7;
+            int idx = -1, srow = 0;
+            if (p < P) {
+                srow = point_slot ? point_slot[p] : p;
+                if (j < k) idx = nbr[(size_t)srow * k + j];
+            }
+            f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0;
+            if (idx >= 0) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(feat_geo + (size_t)idx * SPF_GEO_DIM + q * 8);
+                f0 = src[0];
+                f1 = src[1];
+            }
+            *reinterpret_cast<f32x4*>(X + row * LDA + q * 8) = f0;
+            *reinterpret_cast<f32x4*>(X + row * LDA + q * 8 + 4) = f1;
+            if (q == 0) {
+                float dx = 0.f, dy = 0.f, dz = 0.f, w = 0.f;
+                if (idx >= 0) {
+                    dx = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
+                    dy = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
+                    dz = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
+                    float dist = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
+                    float s = dist * rbf;
+                    w = expf(-(s * s));
+                }
+                *reinterpret_cast<f32x4*>(X + row * LDA + 32) = f32x4{dx, dy, dz, 0.f};
+                *reinterpret_cast<f32x4*>(X + row * LDA + 36) = f32x4{0.f, 0.f, 0.f, 0.f};
+                smem[L_W + row] = w;
+                if (j == 0) smem[L_SROW + (row >> 3)] = __int_as_float(p < P ? srow : -1);
+            }
+        }
+        __syncthreads();
+        if (tid < SPF_TILE_PTS) {
+            float nrm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nrm += smem[L_W + tid * 8 + j];
+            smem[L_NORM + tid] = nrm;
+        }
+
+        f32x16 acc[2][2];
+        uint32_t m1[2], m2[2], m3[2], m4[2];
+        // ---- forward: 35 -> 256 -> 256 -> 256 -> 256 -------------------------------------------
+        zero_acc(acc);
+        gemm_rows64<T_IN>(X, pk4 + (OFF_FW1 / 4) + wave * (T_IN * 128), lane, acc);
+        __syncthreads();
+        fwd_epilogue(X, acc, packed + OFF_B1, wave, lane, m1);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID>(X, pk4 + (OFF_FW2 / 4) + wave * (T_HID * 128), lane, acc);
+        __syncthreads();
+        fwd_epilogue(X, acc, packed + OFF_B2, wave, lane, m2);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID>(X, pk4 + (OFF_FW3 / 4) + wave * (T_HID * 128), lane, acc);
+        __syncthreads();
+        fwd_epilogue(X, acc, packed + OFF_B3, wave, lane, m3);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID>(X, pk4 + (OFF_FW4 / 4) + wave * (T_HID * 128), lane, acc);
+        __syncthreads();
+        fwd_epilogue(X, acc, packed + OFF_B4, wave, lane, m4);
+        __syncthreads();
+
+        // ---- sdf_j = v . a4 + c : 4 threads per row, interleaved float4 chunks ------------------
+        {
+            const int row = tid >> 2, q = tid & 3;
+            const f32x4* v4 = pk4 + OFF_V5 / 4;
+            float s = 0.f;
+#pragma unroll
+            for (int mth = 0; mth < 16; ++mth) {
+                const int c4 = q + 4 * mth;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(X + row * LDA + 4 * c4);
+                const f32x4 v = v4[c4];
+                s += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
+            }
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if (q == 0) smem[L_S + row] = s + packed[OFF_C];
+        }
+        __syncthreads();
+        if (tid < SPF_TILE_PTS) {
+            const int srow = __float_as_int(smem[L_SROW + tid]);
+            if (srow >= 0) {
+                const float nrm = smem[L_NORM + tid];
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a += smem[L_W + tid * 8 + j] * smem[L_S + tid * 8 + j];
+                sdf[srow] = a / nrm;
+                if (wn) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wn[(size_t)srow * 8 + j] = smem[L_W + tid * 8 + j] / nrm;
+                }
+            }
+        }
+
+        if (WITH_JAC) {
+            // ---- Jacobian sweep: g_h4 = v * D4 ; g_a3 = g_h4 W6 ; ... ; J = g_h1 W0 --------------
+            {
+                const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+                const float vv[2] = {packed[OFF_V5 + c0], packed[OFF_V5 + c0 + 32]};
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const bool pos = (m4[m] >> (n * 16 + r)) & 1u;
+                            X[(m * 32 + row_of(r, h)) * LDA + c0 + 32 * n] = pos ? vv[n] : vv[n] * 0.01f;
+                        }
+            }
+            __syncthreads();
+            zero_acc(acc);
+            gemm_rows64<T_HID>(X, pk4 + (OFF_BW4 / 4) + wave * (T_HID * 128), lane, acc);
+            __syncthreads();
+            bwd_epilogue(X, acc, wave, lane, m3);
+            __syncthreads();
+            zero_acc(acc);
+            gemm_rows64<T_HID>(X, pk4 + (OFF_BW3 / 4) + wave * (T_HID * 128), lane, acc);
+            __syncthreads();
+            bwd_epilogue(X, acc, wave, lane, m2);
+            __syncthreads();
+            zero_acc(acc);
+            gemm_rows64<T_HID>(X, pk4 + (OFF_BW2 / 4) + wave * (T_HID * 128), lane, acc);
+            __syncthreads();
+            bwd_epilogue(X, acc, wave, lane, m1);
+            __syncthreads();
+            // last step 256 -> 35 (padded 64): wave = (row half mt, column half nt), one 32x32 tile each
+            {
+                const int mt = wave >> 1, nt = wave & 1, i = lane & 31, h = lane >> 5;
+                f32x16 aj;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) aj[r] = 0.f;
+                const float* ap = X + (mt * 32 + i) * LDA + 4 * h;
+                const f32x4* bp = pk4 + (OFF_JW1 / 4) + nt * (T_HID * 64) + lane;
+#pragma unroll 4
+                for (int t = 0; t < T_HID; ++t) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * t);
+                    const f32x4 b = bp[t * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) aj = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], aj, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + row_of(r, h);
+                    if (nt == 0) {
+                        const int srow = __float_as_int(smem[L_SROW + (row >> 3)]);
+                        if (srow >= 0) jac[((size_t)srow * 8 + (row & 7)) * SPF_GEO_DIM + i] = aj[r];
+                    } else if (i < 3) {
+                        smem[L_JX + row * 3 + i] = aj[r];
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < SPF_TILE_PTS * 3) {
+                const int pl = tid / 3, c = tid % 3;
+                const int srow = __float_as_int(smem[L_SROW + pl]);
+                if (srow >= 0) {
+                    const float inv = 1.0f / smem[L_NORM + pl];
+                    float g = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g += (smem[L_W + pl * 8 + j] * inv) * smem[L_JX + (pl * 8 + j) * 3 + c];
+                    grad[(size_t)srow * 3 + c] = g;
+                }
+            }
+        }
+        __syncthreads();  // smem is reused by the next tile
+    }
+}
+
+__global__ void geo_backward_latents_kernel(const float* __restrict__ g_sdf, const float* __restrict__ wn,
+                                            const float* __restrict__ jac, const int32_t* __restrict__ nbr,
+                                            const int32_t* __restrict__ point_slot, const int32_t* __restrict__ n_points_dev,
+                                            int max_points, int k, float* __restrict__ g_feat) {
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    const long long npair = (long long)P * 8;
+    const int c = threadIdx.x & 31;
+    for (long long pair = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; pair < npair;
+         pair += ((long long)gridDim.x * blockDim.x) >> 5) {
+        const int p = (int)(pair >> 3), j = (int)(pair & 7);
+        if (j >= k) continue;
+        const int srow = point_slot ? point_slot[p] : p;
+        const int idx = nbr[(size_t)srow * k + j];
+        if (idx < 0) continue;
+        const float coef = g_sdf[srow] * wn[(size_t)srow * 8 + j];
+        if (coef != 0.f) atomicAdd(&g_feat[(size_t)idx * SPF_GEO_DIM + c], coef * jac[((size_t)srow * 8 + j) * SPF_GEO_DIM + c]);
+    }
+}
+
+struct PackArgs {
+    const float *w0, *b0, *w2, *b2, *w4, *b4, *w6, *b6, *w8, *b8, *wT, *bT;
+};
+
+__global__ void geo_pack_kernel(PackArgs a, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= PACKED_FLOATS) return;
+    float val = 0.f;
+    if (e < OFF_JW1) {
+        // [wave][t][nt][lane][j] fragments; forward layers read W[n][k], backward layers W[k][n]
+        int region, local;
+        if (e < OFF_FW2) { region = 0; local = e; }
+        else { region = 1 + (e - OFF_FW2) / SZ_HH; local = (e - OFF_FW2) % SZ_HH; }
+        const int T = region == 0 ? T_IN : T_HID;
+        const int j = local & 3, ln = (local >> 2) & 63, nt = (local >> 8) & 1;
+        const int t = (local >> 9) % T, w = (local >> 9) / T;
+        const int n = 64 * w + 32 * nt + (ln & 31), kk = 8 * t + 4 * (ln >> 5) + j;
+        switch (region) {
+            case 0: val = kk < K_IN ? a.w0[n * K_IN + kk] : 0.f; break;
+            case 1: val = a.w2[n * 256 + kk]; break;
+            case 2: val = a.w4[n * 256 + kk]; break;
+            case 3: val = a.w6[n * 256 + kk]; break;
+            case 4: val = a.w6[kk * 256 + n]; break;  // g_a3[i] = sum_o g_h4[o] W6[o][i]
+            case 5: val = a.w4[kk * 256 + n]; break;
+            default: val = a.w2[kk * 256 + n]; break;
+        }
+    } else if (e < OFF_B1) {
+        const int local = e - OFF_JW1;
+        const int j = local & 3, ln = (local >> 2) & 63, t = (local >> 8) & 31, nt = (local >> 13) & 1;
+        const int n = 32 * nt + (ln & 31), kk = 8 * t + 4 * (ln >> 5) + j;
+        val = n < K_IN ? a.w0[kk * K_IN + n] : 0.f;
+    } else if (e < OFF_V5) {
+        const int local = e - OFF_B1, l = local >> 8, i = local & 255;
+        val = (l == 0 ? a.b0 : l == 1 ? a.b2 : l == 2 ? a.b4 : a.b6)[i];
+    } else if (e < OFF_C) {
+        const int i = e - OFF_V5;
+        float s = 0.f;
+        for (int o = 0; o < 256; ++o) s += a.wT[o] * a.w8[o * 256 + i];
+        val = s;
+    } else if (e == OFF_C) {
+        float s = 0.f;
+        for (int o = 0; o < 256; ++o) s += a.wT[o] * a.b8[o];
+        val = s + a.bT[0];
+    }
+    out[e] = val;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t spf_geo_packed_floats(void) { return PACKED_FLOATS; }
+
+int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
+                 const float* w6, const float* b6, const float* w8, const float* b8, const float* wT, const float* bT,
+                 float* packed, void* stream) {
+    if (!w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !w6 || !b6 || !w8 || !b8 || !wT || !bT || !packed)
+        return spf::fail(SPF_EINVAL, "spf_geo_pack: null pointer");
+    PackArgs a{w0, b0, w2, b2, w4, b4, w6, b6, w8, b8, wT, bT};
+    geo_pack_kernel<<<spf::div_up(PACKED_FLOATS, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
+    SPF_LAUNCH_CHECK("geo_pack_kernel");
+    return SPF_OK;
+}
+
+int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slot, const int32_t* n_points,
+                    int32_t max_points, int32_t k, const float* pts, const float* feat_geo, const float* packed, float rbf,
+                    float* sdf, float* wn, float* grad, float* jac, void* stream) {
+    if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_geo_forward: bad sizes (max_points=%d k=%d)", max_points, k);
+    if (max_points == 0) return SPF_OK;
+    if (!x || !nbr || !pts || !feat_geo || !packed || !sdf) return spf::fail(SPF_EINVAL, "spf_geo_forward: null pointer");
+    if ((grad == nullptr) != (jac == nullptr)) return spf::fail(SPF_EINVAL, "spf_geo_forward: grad and jac must be given together");
+    if (grad && !wn) return spf::fail(SPF_EINVAL, "spf_geo_forward: wn is required with grad/jac");
+    const int tiles = spf::div_up(max_points, SPF_TILE_PTS);
+    const int blocks = tiles < 512 ? tiles : 512;  // 2 workgroups per CU x 256 CUs, tiles are strided over them
+    if (grad)
+        geo_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, point_slot, n_points, max_points, k, pts, feat_geo,
+                                                                          packed, rbf, sdf, wn, grad, jac);
+    else
+        geo_forward_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, point_slot, n_points, max_points, k, pts, feat_geo,
+                                                                           packed, rbf, sdf, wn, nullptr, nullptr);
+    SPF_LAUNCH_CHECK("geo_forward_kernel");
+    return SPF_OK;
+}
+
+int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* jac, const int32_t* nbr,
+                             const int32_t* point_slot, const int32_t* n_points, int32_t max_points, int32_t k,
+                             float* g_feat_geo, void* stream) {
+    if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: bad sizes");
+    if (max_points == 0) return SPF_OK;
+    if (!g_sdf || !wn || !jac || !nbr || !g_feat_geo) return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: null pointer");
+    long long threads = (long long)max_points * 8 * 32;
+    int blocks = spf::div_up(threads, 256);
+    if (blocks > 8192) blocks = 8192;
+    geo_backward_latents_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_sdf, wn, jac, nbr, point_slot, n_points, max_points, k,
+                                                                         g_feat_geo);
+    SPF_LAUNCH_CHECK("geo_backward_latents_kernel");
+    return SPF_OK;
+}
+
+}  // extern "C"

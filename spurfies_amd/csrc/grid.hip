@@ -1,0 +1,534 @@
+// Voxel-grid kNN for the neural point cloud (K1-K3 of DESIGN.md).
+//
+// Replaces torch_knnquery.VoxelGrid (reference call sites: pointneus_disent.py:45-62, 252-260,
+// 353-361, 427-435, 627-635; utils.py:93-95, 118-120).  Not a translation of the upstream CUDA
+// extension (its source is absent): a static counting-sorted cell table is built ONCE per cloud
+// and queries are wave-cooperative (ballot + popcount slot compaction, register top-k).
+//
+// Float arithmetic that decides indices (cell of a point, dist2) is written without FMA
+// contraction (the library is built with -ffp-contract=off) so that it matches the frozen
+// specification bit for bit.
+#include <stdarg.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <new>
+
+#include "common.h"
+
+namespace spf {
+
+char* err_buf() {
+    static thread_local char buf[512];
+    return buf;
+}
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace spf
+
+struct spf_grid {
+    spf_grid_config cfg;
+    float cell[3];
+    float origin[3];
+    int32_t dims[3];
+    int32_t ncell;
+    int32_t n_points, n_in, n_occ;
+    int32_t* cell_start;  // [ncell+1]
+    float4* sorted;       // [n_in] xyz + original index (bit pattern in .w), grouped by cell
+    uint32_t* dil;        // [(ncell+63)/64*2] dilated-occupancy bitmask
+    int32_t* cursor;      // [ncell] scratch
+    uint32_t* stats;      // [8] device scratch: min xyz, max xyz (ordered-uint), n_in, n_occ
+};
+
+namespace {
+
+using namespace spf;
+
+struct GridDev {
+    float ox, oy, oz;
+    float cx, cy, cz;
+    int dx, dy, dz;
+    const int32_t* cell_start;
+    const float4* sorted;
+    const uint32_t* dil;
+};
+
+__device__ __forceinline__ uint32_t ord_enc(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+inline float ord_dec(uint32_t u) {
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+__global__ void bbox_kernel(const float* __restrict__ pts, int n, float lx, float ly, float lz, float hx,
+                            float hy, float hz, uint32_t* stats) {
+    uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    int cnt = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        bool in = x >= lx && x <= hx && y >= ly && y <= hy && z >= lz && z <= hz;
+        if (in) {
+            uint32_t e[3] = {ord_enc(x), ord_enc(y), ord_enc(z)};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = min(mn[a], e[a]);
+                mx[a] = max(mx[a], e[a]);
+            }
+            ++cnt;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], off));
+            mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], off));
+        }
+        cnt += __shfl_xor(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&stats[a], mn[a]);
+            atomicMax(&stats[3 + a], mx[a]);
+        }
+        atomicAdd(&stats[6], (uint32_t)cnt);
+    }
+}
+
+// cell of a position; returns false when outside the grid (also for NaN)
+__device__ __forceinline__ bool cell_of(const GridDev& g, float x, float y, float z, int& cx, int& cy, int& cz) {
+    float qx = (x - g.ox) / g.cx, qy = (y - g.oy) / g.cy, qz = (z - g.oz) / g.cz;
+    bool in = qx >= 0.f && qx < (float)g.dx && qy >= 0.f && qy < (float)g.dy && qz >= 0.f && qz < (float)g.dz;
+    cx = (int)floorf(qx);
+    cy = (int)floorf(qy);
+    cz = (int)floorf(qz);
+    return in;
+}
+
+__device__ __forceinline__ int point_cell(const GridDev& g, float x, float y, float z) {
+    int cx = (int)floorf((x - g.ox) / g.cx), cy = (int)floorf((y - g.oy) / g.cy), cz = (int)floorf((z - g.oz) / g.cz);
+    cx = min(max(cx, 0), g.dx - 1);
+    cy = min(max(cy, 0), g.dy - 1);
+    cz = min(max(cz, 0), g.dz - 1);
+    return (cx * g.dy + cy) * g.dz + cz;
+}
+
+__global__ void count_kernel(const float* __restrict__ pts, int n, GridDev g, float lx, float ly, float lz,
+                             float hx, float hy, float hz, int32_t* counts /* = cell_start + 1 */) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    if (!(x >= lx && x <= hx && y >= ly && y <= hy && z >= lz && z <= hz)) return;
+    atomicAdd(&counts[point_cell(g, x, y, z)], 1);
+}
+
+// in-place inclusive scan of a[0..n) by ONE block of 1024 threads (a[0] is 0 on entry for the
+// cell table, which makes a = exclusive starts); also copies a[i] to copy[i] for i < n-1.
+__global__ void __launch_bounds__(1024) scan_kernel(int32_t* a, int n, int32_t* copy) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + tid;
+        int v = i < n ? a[i] : 0;
+        int s = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(s, off);
+            if (lane >= off) s += t;
+        }
+        if (lane == 63) wsum[wid] = s;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        int carry = carry_s;
+        int incl = carry + woff + s;
+        if (i < n) {
+            a[i] = incl;
+            if (copy && i < n - 1) copy[i] = incl;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = incl;
+        __syncthreads();
+    }
+}
+
+__global__ void fill_kernel(const float* __restrict__ pts, int n, GridDev g, float lx, float ly, float lz,
+                            float hx, float hy, float hz, int32_t* cursor, float4* sorted) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    if (!(x >= lx && x <= hx && y >= ly && y <= hy && z >= lz && z <= hz)) return;
+    int pos = atomicAdd(&cursor[point_cell(g, x, y, z)], 1);
+    sorted[pos] = make_float4(x, y, z, __int_as_float(i));
+}
+
+// one thread per cell: dilated occupancy = any occupied cell in the kernel box; 64 cells -> one ballot
+__global__ void dilate_kernel(GridDev g, int ncell, int hkx, int hky, int hkz, uint32_t* dil, uint32_t* stats) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    bool occ = false, self = false;
+    if (c < ncell) {
+        int cz = c % g.dz, cy = (c / g.dz) % g.dy, cx = c / (g.dz * g.dy);
+        self = g.cell_start[c + 1] > g.cell_start[c];
+        for (int ax = max(cx - hkx, 0); ax <= min(cx + hkx, g.dx - 1); ++ax)
+            for (int ay = max(cy - hky, 0); ay <= min(cy + hky, g.dy - 1); ++ay) {
+                int lo = (ax * g.dy + ay) * g.dz + max(cz - hkz, 0);
+                int hi = (ax * g.dy + ay) * g.dz + min(cz + hkz, g.dz - 1);
+                occ |= g.cell_start[hi + 1] > g.cell_start[lo];
+            }
+    }
+    unsigned long long b = __ballot(occ), bs = __ballot(self);
+    if ((threadIdx.x & 63) == 0 && c < ncell) {
+        int w = c >> 5;  // c is a multiple of 64 here
+        dil[w] = (uint32_t)b;
+        dil[w + 1] = (uint32_t)(b >> 32);
+        if (bs) atomicAdd(&stats[7], (uint32_t)__popcll(bs));
+    }
+}
+
+__device__ __forceinline__ bool dil_hit(const GridDev& g, float x, float y, float z) {
+    int cx, cy, cz;
+    if (!cell_of(g, x, y, z, cx, cy, cz)) return false;
+    int lin = (cx * g.dy + cy) * g.dz + cz;
+    return (g.dil[lin >> 5] >> (lin & 31)) & 1u;
+}
+
+// ---- slot assignment ------------------------------------------------------------------------
+// D > 1: one wave per ray; samples are tested 64 at a time, hits get consecutive slots.
+__global__ void __launch_bounds__(256) hit_slots_kernel(const float* __restrict__ raypos, int R, int D, int SR,
+                                                        GridDev g, int32_t* __restrict__ slot_sample) {
+    const int lane = threadIdx.x & 63;
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= R) return;
+    int count = 0;
+    for (int base = 0; base < D && count < SR; base += 64) {
+        int d = base + lane;
+        bool hit = false;
+        if (d < D) {
+            const float* p = raypos + ((size_t)r * D + d) * 3;
+            hit = dil_hit(g, p[0], p[1], p[2]);
+        }
+        unsigned long long b = __ballot(hit);
+        int slot = count + __popcll(b & ((1ull << lane) - 1ull));
+        if (hit && slot < SR) slot_sample[(size_t)r * SR + slot] = d;
+        count += __popcll(b);
+    }
+    for (int s = min(count, SR) + lane; s < SR; s += 64) slot_sample[(size_t)r * SR + s] = -1;
+}
+
+// D == 1 (sampler / get_sdf_eval / pseudo / tv shape): one thread per point
+__global__ void point_slots_kernel(const float* __restrict__ raypos, int R, int SR, GridDev g,
+                                   int32_t* __restrict__ slot_sample) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* p = raypos + (size_t)r * 3;
+    bool hit = dil_hit(g, p[0], p[1], p[2]);
+    slot_sample[(size_t)r * SR] = hit ? 0 : -1;
+    for (int s = 1; s < SR; ++s) slot_sample[(size_t)r * SR + s] = -1;
+}
+
+// ---- k nearest within radius ----------------------------------------------------------------
+// One thread per slot.  Exact top-8 by (dist2, index) kept sorted in registers; candidates come
+// from the 3x3 (x,y) columns of cells around the sample, each column's 3 z-cells being ONE
+// contiguous run of the sorted table (z is the fastest cell axis).
+__global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ raypos, int R, int D, int SR, int k,
+                                                  float rad2, GridDev g, int hkx, int hky, int hkz,
+                                                  const int32_t* __restrict__ slot_sample, int32_t* __restrict__ pidx,
+                                                  float* __restrict__ loc, uint8_t* __restrict__ slot_valid) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)R * SR) return;
+    int samp = slot_sample[gid];
+    float bd[SPF_KMAX];
+    int bi[SPF_KMAX];
+#pragma unroll
+    for (int t = 0; t < SPF_KMAX; ++t) {
+        bd[t] = FLT_MAX;
+        bi[t] = 0x7fffffff;
+    }
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (samp >= 0) {
+        size_t r = gid / SR;
+        const float* p = raypos + (r * D + samp) * 3;
+        x = p[0];
+        y = p[1];
+        z = p[2];
+        int cx, cy, cz;
+        cell_of(g, x, y, z, cx, cy, cz);  // a slot's sample is always inside the grid
+        for (int ax = max(cx - hkx, 0); ax <= min(cx + hkx, g.dx - 1); ++ax)
+            for (int ay = max(cy - hky, 0); ay <= min(cy + hky, g.dy - 1); ++ay) {
+                int col = (ax * g.dy + ay) * g.dz;
+                int s = g.cell_start[col + max(cz - hkz, 0)];
+                int e = g.cell_start[col + min(cz + hkz, g.dz - 1) + 1];
+                for (int j = s; j < e; ++j) {
+                    float4 q = g.sorted[j];
+                    float dx = x - q.x, dy = y - q.y, dz = z - q.z;
+                    float d2 = (dx * dx + dy * dy) + dz * dz;
+                    int id = __float_as_int(q.w);
+                    if (d2 <= rad2 && (d2 < bd[SPF_KMAX - 1] || (d2 == bd[SPF_KMAX - 1] && id < bi[SPF_KMAX - 1]))) {
+                        bd[SPF_KMAX - 1] = d2;
+                        bi[SPF_KMAX - 1] = id;
+#pragma unroll
+                        for (int t = SPF_KMAX - 1; t > 0; --t) {
+                            bool sw = bd[t] < bd[t - 1] || (bd[t] == bd[t - 1] && bi[t] < bi[t - 1]);
+                            float td = sw ? bd[t - 1] : bd[t];
+                            int ti = sw ? bi[t - 1] : bi[t];
+                            bd[t - 1] = sw ? bd[t] : bd[t - 1];
+                            bi[t - 1] = sw ? bi[t] : bi[t - 1];
+                            bd[t] = td;
+                            bi[t] = ti;
+                        }
+                    }
+                }
+            }
+    }
+    int32_t* o = pidx + gid * k;
+#pragma unroll
+    for (int t = 0; t < SPF_KMAX; ++t)
+        if (t < k) o[t] = (bd[t] == FLT_MAX) ? -1 : bi[t];
+    loc[gid * 3] = x;
+    loc[gid * 3 + 1] = y;
+    loc[gid * 3 + 2] = z;
+    slot_valid[gid] = bd[0] != FLT_MAX;
+}
+
+__global__ void ray_valid_kernel(const uint8_t* __restrict__ slot_valid, int R, int SR, uint8_t* __restrict__ ray_valid) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    uint8_t any = 0;
+    for (int s = 0; s < SR; ++s) any |= slot_valid[(size_t)r * SR + s];
+    ray_valid[r] = any;
+}
+
+// ---- compaction of valid points (single block; R per-ray counts -> exclusive scan -> lists) ----
+__global__ void __launch_bounds__(1024) compact_kernel(const uint8_t* __restrict__ slot_valid, int R, int SR,
+                                                       int32_t* __restrict__ point_slot, int32_t* __restrict__ slot_point,
+                                                       int32_t* __restrict__ n_points) {
+    __shared__ int32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int chunk = (R + 1023) / 1024;
+    const int r0 = min(tid * chunk, R), r1 = min(r0 + chunk, R);
+    int cnt = 0;
+    for (size_t i = (size_t)r0 * SR; i < (size_t)r1 * SR; ++i) cnt += slot_valid[i];
+    int s = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(s, off);
+        if (lane >= off) s += t;
+    }
+    if (lane == 63) wsum[wid] = s;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wid) woff += wsum[w];
+        total += wsum[w];
+    }
+    int p = woff + s - cnt;
+    for (size_t i = (size_t)r0 * SR; i < (size_t)r1 * SR; ++i) {
+        if (slot_valid[i]) {
+            point_slot[p] = (int32_t)i;
+            slot_point[i] = p++;
+        } else {
+            slot_point[i] = -1;
+        }
+    }
+    if (tid == 0) *n_points = total;
+}
+
+GridDev dev_view(const spf_grid* g) {
+    GridDev d;
+    d.ox = g->origin[0], d.oy = g->origin[1], d.oz = g->origin[2];
+    d.cx = g->cell[0], d.cy = g->cell[1], d.cz = g->cell[2];
+    d.dx = g->dims[0], d.dy = g->dims[1], d.dz = g->dims[2];
+    d.cell_start = g->cell_start;
+    d.sorted = g->sorted;
+    d.dil = g->dil;
+    return d;
+}
+
+void free_tables(spf_grid* g) {
+    if (g->cell_start) (void)hipFree(g->cell_start);
+    if (g->sorted) (void)hipFree(g->sorted);
+    if (g->dil) (void)hipFree(g->dil);
+    if (g->cursor) (void)hipFree(g->cursor);
+    g->cell_start = nullptr;
+    g->sorted = nullptr;
+    g->dil = nullptr;
+    g->cursor = nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spf_abi_version(void) { return SPF_ABI_VERSION; }
+const char* spf_last_error(void) { return spf::err_buf(); }
+
+int spf_grid_create(const spf_grid_config* cfg, spf_grid** out) {
+    if (!cfg || !out) return spf::fail(SPF_EINVAL, "spf_grid_create: null argument");
+    for (int a = 0; a < 3; ++a) {
+        if (!(cfg->voxel_size[a] > 0.f) || cfg->voxel_scale[a] < 1 || cfg->kernel_size[a] < 1 || (cfg->kernel_size[a] & 1) == 0)
+            return spf::fail(SPF_EINVAL, "spf_grid_create: voxel_size>0, voxel_scale>=1, odd kernel_size>=1 required");
+        if (!(cfg->ranges[a] < cfg->ranges[a + 3])) return spf::fail(SPF_EINVAL, "spf_grid_create: empty ranges");
+    }
+    spf_grid* g = new (std::nothrow) spf_grid();
+    if (!g) return spf::fail(SPF_ENOMEM, "spf_grid_create: out of host memory");
+    memset(g, 0, sizeof(*g));
+    g->cfg = *cfg;
+    for (int a = 0; a < 3; ++a) g->cell[a] = (float)((double)cfg->voxel_size[a] * (double)cfg->voxel_scale[a]);
+    *out = g;
+    return SPF_OK;
+}
+
+void spf_grid_destroy(spf_grid* g) {
+    if (!g) return;
+    free_tables(g);
+    if (g->stats) (void)hipFree(g->stats);
+    delete g;
+}
+
+int spf_grid_build(spf_grid* g, const float* points, int32_t n, void* stream_) {
+    if (!g || (!points && n > 0) || n < 0) return spf::fail(SPF_EINVAL, "spf_grid_build: bad arguments");
+    hipStream_t stream = (hipStream_t)stream_;
+    const float* rg = g->cfg.ranges;
+    if (!g->stats) SPF_HIP_CHECK(hipMalloc(&g->stats, 8 * sizeof(uint32_t)));
+    uint32_t init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+    SPF_HIP_CHECK(hipMemcpyAsync(g->stats, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    if (n > 0) {
+        int blocks = std::min(spf::div_up(n, 256), 1024);
+        bbox_kernel<<<blocks, 256, 0, stream>>>(points, n, rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], g->stats);
+        SPF_LAUNCH_CHECK("bbox_kernel");
+    }
+    uint32_t host[8];
+    SPF_HIP_CHECK(hipMemcpyAsync(host, g->stats, sizeof(host), hipMemcpyDeviceToHost, stream));
+    SPF_HIP_CHECK(hipStreamSynchronize(stream));
+    free_tables(g);
+    g->n_points = n;
+    g->n_in = (int32_t)host[6];
+    g->n_occ = 0;
+    if (g->n_in == 0) {
+        g->dims[0] = g->dims[1] = g->dims[2] = 0;
+        g->ncell = 0;
+        g->origin[0] = g->origin[1] = g->origin[2] = 0.f;
+        return SPF_OK;
+    }
+    long long ncell = 1;
+    for (int a = 0; a < 3; ++a) {
+        float half = (float)g->cfg.kernel_size[a] / 2.0f;
+        float pad = g->cell[a] * half;
+        float mn = ord_dec(host[a]), mx = ord_dec(host[3 + a]);
+        float org = mn - pad;
+        float top = mx + pad;
+        float ext = top - org;
+        float q = ext / g->cell[a];
+        int d = (int)ceilf(q);
+        g->origin[a] = org;
+        g->dims[a] = d < 1 ? 1 : d;
+        ncell *= g->dims[a];
+    }
+    if (ncell > (1ll << 30)) return spf::fail(SPF_EINVAL, "spf_grid_build: grid too large (%lld cells)", ncell);
+    g->ncell = (int32_t)ncell;
+    size_t dil_words = (size_t)((ncell + 63) / 64) * 2;
+    SPF_HIP_CHECK(hipMalloc(&g->cell_start, (size_t)(ncell + 1) * sizeof(int32_t)));
+    SPF_HIP_CHECK(hipMalloc(&g->cursor, (size_t)ncell * sizeof(int32_t)));
+    SPF_HIP_CHECK(hipMalloc(&g->sorted, (size_t)g->n_in * sizeof(float4)));
+    SPF_HIP_CHECK(hipMalloc(&g->dil, dil_words * sizeof(uint32_t)));
+    SPF_HIP_CHECK(hipMemsetAsync(g->cell_start, 0, (size_t)(ncell + 1) * sizeof(int32_t), stream));
+    GridDev d = dev_view(g);
+    count_kernel<<<spf::div_up(n, 256), 256, 0, stream>>>(points, n, d, rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], g->cell_start + 1);
+    SPF_LAUNCH_CHECK("count_kernel");
+    scan_kernel<<<1, 1024, 0, stream>>>(g->cell_start, (int)(ncell + 1), g->cursor);
+    SPF_LAUNCH_CHECK("scan_kernel");
+    fill_kernel<<<spf::div_up(n, 256), 256, 0, stream>>>(points, n, d, rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], g->cursor, g->sorted);
+    SPF_LAUNCH_CHECK("fill_kernel");
+    dilate_kernel<<<spf::div_up(ncell, 256), 256, 0, stream>>>(d, (int)ncell, g->cfg.kernel_size[0] / 2, g->cfg.kernel_size[1] / 2,
+                                                             g->cfg.kernel_size[2] / 2, g->dil, g->stats);
+    SPF_LAUNCH_CHECK("dilate_kernel");
+    SPF_HIP_CHECK(hipMemcpyAsync(host, g->stats, sizeof(host), hipMemcpyDeviceToHost, stream));
+    SPF_HIP_CHECK(hipStreamSynchronize(stream));
+    g->n_occ = (int32_t)host[7];
+    return SPF_OK;
+}
+
+int spf_grid_get_info(const spf_grid* g, spf_grid_info* out) {
+    if (!g || !out) return spf::fail(SPF_EINVAL, "spf_grid_get_info: null argument");
+    for (int a = 0; a < 3; ++a) {
+        out->origin[a] = g->origin[a];
+        out->cell[a] = g->cell[a];
+        out->dims[a] = g->dims[a];
+    }
+    out->n_points = g->n_points;
+    out->n_in_range = g->n_in;
+    out->n_occupied = g->n_occ;
+    return SPF_OK;
+}
+
+int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D, int32_t k, float radius_limit_scale,
+                   int32_t SR, int32_t* pidx, float* loc, int32_t* slot_sample, uint8_t* slot_valid, uint8_t* ray_valid,
+                   void* stream_) {
+    if (!g) return spf::fail(SPF_EINVAL, "spf_grid_query: null grid");
+    if (R < 0 || D < 1 || SR < 1 || k < 1 || k > SPF_KMAX)
+        return spf::fail(SPF_EINVAL, "spf_grid_query: need R>=0, D>=1, SR>=1, 1<=k<=%d (got R=%d D=%d SR=%d k=%d)", SPF_KMAX, R, D, SR, k);
+    if (R == 0) return SPF_OK;
+    if (!raypos || !pidx || !loc || !slot_sample || !slot_valid || !ray_valid)
+        return spf::fail(SPF_EINVAL, "spf_grid_query: null buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t nslot = (size_t)R * SR;
+    if (g->n_in == 0) {  // built on an empty / fully out-of-range cloud: nothing is ever hit
+        SPF_HIP_CHECK(hipMemsetAsync(pidx, 0xff, nslot * k * sizeof(int32_t), stream));
+        SPF_HIP_CHECK(hipMemsetAsync(loc, 0, nslot * 3 * sizeof(float), stream));
+        SPF_HIP_CHECK(hipMemsetAsync(slot_sample, 0xff, nslot * sizeof(int32_t), stream));
+        SPF_HIP_CHECK(hipMemsetAsync(slot_valid, 0, nslot, stream));
+        SPF_HIP_CHECK(hipMemsetAsync(ray_valid, 0, (size_t)R, stream));
+        return SPF_OK;
+    }
+    float vmax = g->cfg.voxel_size[0] > g->cfg.voxel_size[1] ? g->cfg.voxel_size[0] : g->cfg.voxel_size[1];
+    float rad = (float)((double)radius_limit_scale * (double)vmax);
+    float rad2 = rad * rad;
+    GridDev d = dev_view(g);
+    if (D == 1) {
+        point_slots_kernel<<<spf::div_up(R, 256), 256, 0, stream>>>(raypos, R, SR, d, slot_sample);
+        SPF_LAUNCH_CHECK("point_slots_kernel");
+    } else {
+        hit_slots_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, stream>>>(raypos, R, D, SR, d, slot_sample);
+        SPF_LAUNCH_CHECK("hit_slots_kernel");
+    }
+    knn_kernel<<<spf::div_up((long long)nslot, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
+                                                                       g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
+                                                                       slot_sample, pidx, loc, slot_valid);
+    SPF_LAUNCH_CHECK("knn_kernel");
+    ray_valid_kernel<<<spf::div_up(R, 256), 256, 0, stream>>>(slot_valid, R, SR, ray_valid);
+    SPF_LAUNCH_CHECK("ray_valid_kernel");
+    return SPF_OK;
+}
+
+int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t* point_slot, int32_t* slot_point,
+                       int32_t* n_points, int32_t* scratch, void* stream_) {
+    (void)scratch;
+    if (R < 0 || SR < 1) return spf::fail(SPF_EINVAL, "spf_compact_points: bad sizes");
+    if (!n_points) return spf::fail(SPF_EINVAL, "spf_compact_points: null n_points");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (R == 0) {
+        SPF_HIP_CHECK(hipMemsetAsync(n_points, 0, sizeof(int32_t), stream));
+        return SPF_OK;
+    }
+    if (!slot_valid || !point_slot || !slot_point) return spf::fail(SPF_EINVAL, "spf_compact_points: null buffer");
+    compact_kernel<<<1, 1024, 0, stream>>>(slot_valid, R, SR, point_slot, slot_point, n_points);
+    SPF_LAUNCH_CHECK("compact_kernel");
+    return SPF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+"""torch-facing wrappers of the C ABI (tensor allocation + autograd glue only; every
+arithmetic stage is a HIP kernel in libspurfies_hip.so)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+SDF_FILL = 1000.0  # pointneus_disent.py:271,371,445,703
+
+
+def compact_points(slot_valid):
+    """slot_valid uint8 [R,SR] -> (point_slot i32 [R*SR], slot_point i32 [R*SR], n_points i32 [1]); no host sync."""
+    R, SR = slot_valid.shape
+    dev = slot_valid.device
+    point_slot = torch.empty((R * SR,), dtype=torch.int32, device=dev)
+    slot_point = torch.empty((R * SR,), dtype=torch.int32, device=dev)
+    n_points = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_compact_points(_lib.ptr(slot_valid), R, SR, _lib.ptr(point_slot), _lib.ptr(slot_point),
+                                                 _lib.ptr(n_points), None, _lib.stream_ptr()), "spf_compact_points")
+    return point_slot, slot_point, n_points
+
+
+def pack_geometry_weights(state: dict) -> torch.Tensor:
+    """state: {'F_geometry.0.weight', ..., 'T.0.bias'} CUDA float32 tensors -> packed image."""
+    names = ["F_geometry.0", "F_geometry.2", "F_geometry.4", "F_geometry.6", "F_geometry.8", "T.0"]
+    args = []
+    for n in names:
+        w, b = state[n + ".weight"], state[n + ".bias"]
+        args += [w.detach().contiguous().float(), b.detach().contiguous().float()]
+    dev = args[0].device
+    packed = torch.empty((int(_lib.lib().spf_geo_packed_floats()),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_geo_pack(*[_lib.ptr(a) for a in args], _lib.ptr(packed), _lib.stream_ptr()), "spf_geo_pack")
+    return packed
+
+
+def geo_forward(x, nbr, point_slot, n_points, pts, feat_geo, packed, rbf, with_grad, sdf_out=None):
+    """Rows = first dim of x / nbr.  Returns dict(sdf [rows] (1000 where not a valid point), wn [rows,8],
+    grad [rows,3] | None, jac [rows,8,32] | None)."""
+    rows, k = nbr.shape[0], nbr.shape[1]
+    dev = x.device
+    sdf = sdf_out if sdf_out is not None else torch.full((rows,), SDF_FILL, dtype=torch.float32, device=dev)
+    wn = torch.zeros((rows, 8), dtype=torch.float32, device=dev)
+    grad = torch.zeros((rows, 3), dtype=torch.float32, device=dev) if with_grad else None
+    jac = torch.empty((rows, 8, 32), dtype=torch.float32, device=dev) if with_grad else None
+    max_points = rows if point_slot is None else min(rows, point_slot.shape[0])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_geo_forward(_lib.ptr(x), _lib.ptr(nbr), _lib.ptr(point_slot), _lib.ptr(n_points), max_points, k,
+                                              _lib.ptr(pts), _lib.ptr(feat_geo), _lib.ptr(packed), float(rbf), _lib.ptr(sdf),
+                                              _lib.ptr(wn), _lib.ptr(grad), _lib.ptr(jac), _lib.stream_ptr()), "spf_geo_forward")
+    return {"sdf": sdf, "wn": wn, "grad": grad, "jac": jac}
+
+
+def geo_backward_latents(g_sdf, wn, jac, nbr, point_slot, n_points, g_feat_geo):
+    rows, k = nbr.shape[0], nbr.shape[1]
+    max_points = rows if point_slot is None else min(rows, point_slot.shape[0])
+    with torch.cuda.device(g_sdf.device):
+        _lib.check(_lib.lib().spf_geo_backward_latents(_lib.ptr(g_sdf), _lib.ptr(wn), _lib.ptr(jac), _lib.ptr(nbr), _lib.ptr(point_slot),
+                                                       _lib.ptr(n_points), max_points, k, _lib.ptr(g_feat_geo), _lib.stream_ptr()),
+                   "spf_geo_backward_latents")
+    return g_feat_geo
+
+
+class GeoSDF(torch.autograd.Function):
+    """sdf(x; geometry latents) through the fused kernel.  Differentiable w.r.t. x (d sdf/d x is
+    the kernel's `grad` output — RBF weights are detached in the reference, pointneus_disent.py:242)
+    and w.r.t. the geometry latent table (scalar-output MLP: d sdf_j/d latent_j = Jacobian row)."""
+
+    @staticmethod
+    def forward(ctx, x, feat_geo, nbr, point_slot, n_points, pts, packed, rbf):
+        res = geo_forward(x.detach(), nbr, point_slot, n_points, pts, feat_geo.detach(), packed, rbf, with_grad=True)
+        ctx.save_for_backward(res["wn"], res["jac"], res["grad"], nbr, point_slot, n_points)
+        ctx.n_table = feat_geo.shape[0]
+        ctx.mark_non_differentiable(res["grad"])
+        return res["sdf"], res["grad"]
+
+    @staticmethod
+    def backward(ctx, g_sdf, _g_grad):
+        wn, jac, grad, nbr, point_slot, n_points = ctx.saved_tensors
+        g_sdf = g_sdf.contiguous()
+        g_x = g_feat = None
+        if ctx.needs_input_grad[0]:
+            g_x = g_sdf.unsqueeze(-1) * grad
+        if ctx.needs_input_grad[1]:
+            g_feat = torch.zeros((ctx.n_table, 32), dtype=torch.float32, device=g_sdf.device)
+            geo_backward_latents(g_sdf, wn, jac, nbr, point_slot, n_points, g_feat)
+        return g_x, g_feat, None, None, None, None, None, None

@@ -1,0 +1,113 @@
+"""GPU parity: HIP voxel-grid kNN (through the C ABI) vs the frozen-spec oracle — bit exact."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid(ranges=(-1, -1, -1, 1, 1, 1)):
+    from spurfies_amd.torch_knnquery import VoxelGrid
+
+    return VoxelGrid((0.025,) * 3, (3,) * 3, (3,) * 3, 26, 20000, ranges)
+
+
+def test_knn_matches_golden_spec():
+    fx = load_golden("knn_spec.npz")
+    g = _grid()
+    pts = torch.from_numpy(fx["in.pts"]).cuda()
+    g.set_pointset(pts.unsqueeze(0), torch.full((1,), len(pts), dtype=torch.int32, device="cuda"))
+    info = g.info()
+    assert tuple(info["dims"]) == tuple(int(v) for v in fx["meta.dims"])
+    assert np.array_equal(np.asarray(info["origin"], np.float32), fx["meta.origin"])
+    assert info["n_in_range"] == len(pts) - 27 + 2
+    for nm in ("d1", "d98", "d128"):
+        x = torch.from_numpy(fx[f"{nm}.x"]).cuda()
+        k, r, sr = int(fx[f"{nm}.k"]), float(fx[f"{nm}.r"]), int(fx[f"{nm}.sr"])
+        d = g.query_dense(x, k, r, sr)
+        assert np.array_equal(d["slot_sample"].cpu().numpy(), fx[f"{nm}.slot_sample"]), nm
+        assert np.array_equal(d["pidx"].cpu().numpy(), fx[f"{nm}.pidx"]), nm
+        assert np.array_equal(d["loc"].cpu().numpy(), fx[f"{nm}.loc"]), nm
+        assert np.array_equal(d["ray_valid"].cpu().numpy().astype(bool), fx[f"{nm}.ray_valid"]), nm
+        assert np.array_equal(d["slot_valid"].cpu().numpy().astype(bool), (fx[f"{nm}.pidx"] >= 0).any(-1)), nm
+        # the op's own (compacted) return convention: dtypes and shapes of utils.py:93-113
+        pidx, loc, mask = g.query(x.unsqueeze(0), k, r, sr)
+        rv = fx[f"{nm}.ray_valid"]
+        assert pidx.dtype == torch.int32 and loc.dtype == torch.float32 and mask.dtype == torch.int8
+        assert tuple(pidx.shape) == (1, int(rv.sum()), sr, k) and tuple(mask.shape) == (1, len(rv))
+        assert np.array_equal(pidx[0].cpu().numpy(), fx[f"{nm}.pidx"][rv])
+
+
+def test_compaction_lists():
+    from spurfies_amd import ops
+
+    rng = np.random.default_rng(0)
+    for R, SR in ((1024, 80), (131072, 1), (7, 3), (1, 1)):
+        sv = (rng.uniform(size=(R, SR)) < 0.3).astype(np.uint8)
+        point_slot, slot_point, n = ops.compact_points(torch.from_numpy(sv).cuda())
+        want = np.nonzero(sv.reshape(-1))[0]
+        assert int(n.item()) == len(want)
+        assert np.array_equal(point_slot.cpu().numpy()[: len(want)], want)
+        inv = np.full(R * SR, -1, np.int64)
+        inv[want] = np.arange(len(want))
+        assert np.array_equal(slot_point.cpu().numpy(), inv)
+
+
+def test_knn_full_size_against_oracle_subset():
+    """BASELINE config 5 shape (dense cloud, range +-2, 4096 rays x 98 samples): every slot of a
+    random subset of rays equals the oracle; plus size-independent properties on all rays."""
+    from oracle.voxel_grid import VoxelGridOracle
+    from spurfies_amd import synthetic as syn
+
+    pts, _, base = syn.make_cloud(200000, spacing=0.0125, seed=5)
+    ranges = (-2, -2, -2, 2, 2, 2)
+    g = _grid(ranges)
+    tp = torch.from_numpy(pts).cuda()
+    g.set_pointset(tp.unsqueeze(0))
+    rng = np.random.default_rng(1)
+    R, D = 4096, 98
+    o = np.asarray([3.2, 0.4, 0.5], np.float32)
+    tgt = (rng.standard_normal((R, 3)) * 0.5 * base).astype(np.float32)
+    dirs = tgt - o
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    z = np.sort(rng.uniform(1.0, 5.5, size=(R, D)).astype(np.float32), axis=1)
+    x = (o[None, None] + z[..., None] * dirs[:, None]).astype(np.float32)
+    d = g.query_dense(torch.from_numpy(x).cuda(), 8, 2, 80)
+    pidx = d["pidx"].cpu().numpy()
+    ss = d["slot_sample"].cpu().numpy()
+    # properties: slot samples strictly increasing then -1; neighbours within radius, sorted by distance, unique
+    used = ss >= 0
+    assert (np.diff(np.where(used, ss, 10 ** 6), axis=1) > 0)[used[:, 1:]].all()
+    rr, sl, kk = np.nonzero(pidx >= 0)
+    dist = np.linalg.norm(x[rr, ss[rr, sl]].astype(np.float64) - pts[pidx[rr, sl, kk]].astype(np.float64), axis=1)
+    assert dist.max() <= 0.05 * (1 + 1e-5)
+    first_pad = (pidx < 0).argmax(-1)
+    assert ((pidx >= 0).sum(-1) == np.where((pidx < 0).any(-1), first_pad, 8)).all(), "-1 padding must be a suffix"
+    # oracle on a subset of rays
+    orc = VoxelGridOracle((0.025,) * 3, (3,) * 3, (3,) * 3, 26, 20000, ranges)
+    orc.set_pointset(pts)
+    assert tuple(g.info()["dims"]) == tuple(int(v) for v in orc.dims)
+    sub = rng.choice(R, size=48, replace=False)
+    op, ol, oss, orv = orc.query_dense(x[sub], 8, 2, 80)
+    assert np.array_equal(ss[sub], oss) and np.array_equal(pidx[sub], op)
+    assert np.array_equal(d["ray_valid"].cpu().numpy()[sub].astype(bool), orv)
+
+
+def test_knn_edge_cases():
+    g = _grid()
+    far = torch.full((10, 3), 5.0, device="cuda")          # every point outside `ranges`
+    g.set_pointset(far.unsqueeze(0))
+    d = g.query_dense(torch.zeros((4, 3, 3), device="cuda"), 8, 2, 2)
+    assert int(d["ray_valid"].sum()) == 0 and int((d["pidx"] >= 0).sum()) == 0
+    one = torch.tensor([[0.1, 0.2, 0.3]], device="cuda")   # single point; query exactly on it and just outside radius
+    g2 = _grid()
+    g2.set_pointset(one.unsqueeze(0))
+    q = torch.tensor([[[0.1, 0.2, 0.3]], [[0.1, 0.2, 0.3501]], [[0.1, 0.2, 0.3499]], [[float("nan"), 0.0, 0.0]]], device="cuda")
+    d = g2.query_dense(q, 8, 2, 1)
+    assert d["pidx"][:, 0, 0].tolist() == [0, -1, 0, -1]
+    empty = g2.query_dense(torch.zeros((0, 5, 3), device="cuda"), 8, 2, 4)
+    assert empty["pidx"].shape == (0, 4, 8)
+    with pytest.raises(Exception):
+        g2.query_dense(q, 9, 2, 1)  # k > SPF_KMAX is refused loudly
