@@ -76,7 +76,8 @@ def test_latent_gradient_matches_oracle():
     sdf_o, valid_o = P.sdf_at_points(xo, ogrid, st, cfg)
     (sdf_o * coef.cpu())[valid_o].sum().backward()
     go = st["neural_feats_geometry"].grad
-    np.testing.assert_allclose(feat.grad.cpu().numpy(), go.numpy(), rtol=5e-4, atol=1e-6 * float(go.abs().max()) + 1e-8)
+    # float atomics: summation order differs run to run -> absolute tolerance relative to the largest entry
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), go.numpy(), rtol=5e-4, atol=5e-5 * float(go.abs().max()))
     np.testing.assert_allclose(xt.grad.cpu().numpy(), xo.grad.numpy(), rtol=5e-4, atol=2e-5)
 
 
