@@ -1,0 +1,29 @@
+"""Laplace-CDF density with the reference's interface (spurfies/model/density.py:5-30)."""
+import torch
+import torch.nn as nn
+
+
+class Density(nn.Module):
+    def __init__(self, params_init={}):
+        super().__init__()
+        for name, value in dict(params_init).items():
+            setattr(self, name, nn.Parameter(torch.tensor(float(value))))
+
+    def forward(self, sdf, beta=None):
+        return self.density_func(sdf, beta=beta)
+
+
+class LaplaceDensity(Density):
+    """sigma = (1/beta) * (0.5 + 0.5 * sign(s) * expm1(-|s|/beta)),  beta = |beta_param| + beta_min."""
+
+    def __init__(self, params_init={}, beta_min=0.0001):
+        super().__init__(params_init=params_init)
+        self.register_buffer("beta_min", torch.tensor(float(beta_min)), persistent=False)
+
+    def density_func(self, sdf, beta=None):
+        if beta is None:
+            beta = self.get_beta()
+        return (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+    def get_beta(self):
+        return self.beta.abs() + self.beta_min

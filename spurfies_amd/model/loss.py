@@ -1,0 +1,50 @@
+"""VolSDFLoss with the reference's constructor and forward contract (spurfies/model/loss.py:19-101).
+
+`forward(model_outputs, ground_truth)`; ground_truth = {'rgb': [1,R,3], 'mask': [1,R,3]}.
+For ray-sharded multi-GPU steps `denominators` carries the GLOBAL counts so that the sum of the
+ranks' losses equals the single-GPU batch loss exactly (spurfies_amd/dist.py)."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..utils.general import get_class
+
+
+class VolSDFLoss(nn.Module):
+    def __init__(self, rgb_loss, local_weight, pseudo_weight, eikonal_weight, rgb_weight=1.0, tv_weight=0.0):
+        super().__init__()
+        self.local_weight = local_weight
+        self.pseudo_weight = pseudo_weight
+        self.eikonal_weight = eikonal_weight
+        self.rgb_weight = rgb_weight
+        self.tv_weight = tv_weight
+        self.rgb_loss = get_class(rgb_loss)(reduction="mean") if isinstance(rgb_loss, str) else rgb_loss
+        self.iter_step = 0
+
+    def get_rgb_loss(self, rgb_values, rgb_gt, model_outputs=None, t=0):
+        return self.rgb_loss(rgb_values, rgb_gt.reshape(-1, 3))
+
+    def get_eikonal_loss(self, grad_theta):
+        return ((grad_theta.norm(2, dim=1) - 1) ** 2).mean()
+
+    def forward(self, model_outputs, ground_truth):
+        dev = model_outputs["rgb_values"].device
+        rgb_gt = ground_truth["rgb"].to(dev)
+        mask_gt = ground_truth["mask"].to(dev)
+        zero = torch.tensor(0.0, device=dev)
+        out = {"rgb_loss": self.get_rgb_loss(model_outputs["rgb_values"], rgb_gt)}
+        g = model_outputs.get("grad_theta")
+        out["eikonal_loss"] = self.get_eikonal_loss(g) if g is not None else zero
+        out["tv_loss"] = model_outputs["tv_loss"] if ("tv_loss" in model_outputs and self.tv_weight > 0) else zero
+        if "weights" in model_outputs:
+            wsum = model_outputs["weights"].sum(-1, keepdim=True)
+            out["mask_loss"] = F.binary_cross_entropy(wsum.clip(1e-3, 1.0 - 1e-3), mask_gt.squeeze()[:, 0][..., None])
+        else:
+            out["mask_loss"] = zero
+        out["local_loss"] = model_outputs.get("local_loss", zero)
+        out["pseudo_loss"] = model_outputs["pseudo_pts_loss"] if ("pseudo_pts_loss" in model_outputs and self.pseudo_weight > 0) else zero
+        out["loss"] = (self.rgb_weight * out["rgb_loss"] + self.eikonal_weight * out["eikonal_loss"]
+                       + self.tv_weight * out["tv_loss"] + self.local_weight * out["local_loss"]
+                       + self.pseudo_weight * out["pseudo_loss"] + out["mask_loss"])
+        self.iter_step += 1
+        return out

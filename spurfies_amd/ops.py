@@ -8,6 +8,24 @@ from . import _lib
 
 SDF_FILL = 1000.0  # pointneus_disent.py:271,371,445,703
 
+# ---- optional per-launch timing of the fused geometry kernel (bench.py roofline) -----------------
+_prof = None
+
+
+def profile_start():
+    global _prof
+    _prof = []
+
+
+def profile_stop():
+    """-> [{'ms', 'pairs', 'rows', 'with_grad'}] per spf_geo_forward launch since profile_start()."""
+    global _prof
+    rec, _prof = _prof or [], None
+    torch.cuda.synchronize()
+    return [{"ms": e0.elapsed_time(e1), "pairs": int((wn > 0).sum().item()), "rows": rows, "with_grad": wg}
+            for e0, e1, wn, rows, wg in rec]
+
+
 
 def compact_points(slot_valid):
     """slot_valid uint8 [R,SR] -> (point_slot i32 [R*SR], slot_point i32 [R*SR], n_points i32 [1]); no host sync."""
@@ -46,10 +64,16 @@ def geo_forward(x, nbr, point_slot, n_points, pts, feat_geo, packed, rbf, with_g
     grad = torch.zeros((rows, 3), dtype=torch.float32, device=dev) if with_grad else None
     jac = torch.empty((rows, 8, 32), dtype=torch.float32, device=dev) if with_grad else None
     max_points = rows if point_slot is None else min(rows, point_slot.shape[0])
+    if _prof is not None:  # HIP events on the launch stream (torch's current stream is the one passed to the kernel)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_geo_forward(_lib.ptr(x), _lib.ptr(nbr), _lib.ptr(point_slot), _lib.ptr(n_points), max_points, k,
                                               _lib.ptr(pts), _lib.ptr(feat_geo), _lib.ptr(packed), float(rbf), _lib.ptr(sdf),
                                               _lib.ptr(wn), _lib.ptr(grad), _lib.ptr(jac), _lib.stream_ptr()), "spf_geo_forward")
+    if _prof is not None:
+        e1.record()
+        _prof.append((e0, e1, wn, rows, bool(with_grad)))
     return {"sdf": sdf, "wn": wn, "grad": grad, "jac": jac}
 
 
@@ -64,20 +88,21 @@ def geo_backward_latents(g_sdf, wn, jac, nbr, point_slot, n_points, g_feat_geo):
 
 
 class GeoSDF(torch.autograd.Function):
-    """sdf(x; geometry latents) through the fused kernel.  Differentiable w.r.t. x (d sdf/d x is
-    the kernel's `grad` output — RBF weights are detached in the reference, pointneus_disent.py:242)
-    and w.r.t. the geometry latent table (scalar-output MLP: d sdf_j/d latent_j = Jacobian row)."""
+    """(sdf, d sdf/d x, normalised RBF weights) through the fused kernel.  sdf is differentiable
+    w.r.t. x (d sdf/d x is the kernel's `grad` output — RBF weights are detached in the reference,
+    pointneus_disent.py:242) and w.r.t. the geometry latent table (scalar-output MLP:
+    d sdf_j/d latent_j is the Jacobian row the forward sweep stored)."""
 
     @staticmethod
     def forward(ctx, x, feat_geo, nbr, point_slot, n_points, pts, packed, rbf):
         res = geo_forward(x.detach(), nbr, point_slot, n_points, pts, feat_geo.detach(), packed, rbf, with_grad=True)
         ctx.save_for_backward(res["wn"], res["jac"], res["grad"], nbr, point_slot, n_points)
         ctx.n_table = feat_geo.shape[0]
-        ctx.mark_non_differentiable(res["grad"])
-        return res["sdf"], res["grad"]
+        ctx.mark_non_differentiable(res["grad"], res["wn"])
+        return res["sdf"], res["grad"], res["wn"]
 
     @staticmethod
-    def backward(ctx, g_sdf, _g_grad):
+    def backward(ctx, g_sdf, _g_grad, _g_wn):
         wn, jac, grad, nbr, point_slot, n_points = ctx.saved_tensors
         g_sdf = g_sdf.contiguous()
         g_x = g_feat = None

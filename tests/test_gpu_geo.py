@@ -67,7 +67,7 @@ def test_latent_gradient_matches_oracle():
     q = grid.query_dense(xt.detach().unsqueeze(1), cfg.k, cfg.r, 1)
     point_slot, _, n_pts = ops.compact_points(q["slot_valid"])
     nbr = q["pidx"].reshape(-1, cfg.k)
-    sdf, _ = ops.GeoSDF.apply(xt, feat, nbr, point_slot, n_pts, dev["neural_pts"], packed, cfg.rbf)
+    sdf, _, _ = ops.GeoSDF.apply(xt, feat, nbr, point_slot, n_pts, dev["neural_pts"], packed, cfg.rbf)
     valid = q["slot_valid"].reshape(-1).bool()
     coef = torch.linspace(-1.0, 1.0, sdf.shape[0], device="cuda")
     (sdf * coef)[valid].sum().backward()
