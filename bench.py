@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (config/ours.yaml:14 num_pixels)")
     ap.add_argument("--points", type=int, default=10000, help="neural points (DTU-like cloud)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=512)
+    ap.add_argument("--cpu-rays", type=int, default=256)
     return ap.parse_args()
 
 
@@ -67,7 +67,7 @@ def cpu_baseline(scene, n_rays):
     from oracle import path as P
     from spurfies_amd import synthetic as syn
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 8)   # more intra-op threads only slow these small CPU ops down
     torch.set_num_threads(cores)
     st = P.load_state(scene["state"])
     cfg = P.PathConfig(ranges=tuple(scene["ranges"]))
