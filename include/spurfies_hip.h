@@ -140,6 +140,24 @@ int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* j
                              const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
                              int32_t k, float* g_feat_geo, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Latent tables
+ * ---------------------------------------------------------------------------------------- */
+
+/* dst[idx[m], :] += src[m, :] for m < M (idx < 0 skipped); c in {4, 32, 64} floats per row.
+ * Backward of the reference's index_select gathers of latent rows (spurfies/model/utils.py:158-161);
+ * float atomics (summation order not reproducible run to run). */
+int spf_scatter_add_rows(const float* src, const int32_t* idx, int64_t m, int32_t c, float* dst, void* stream);
+
+/* Total-variation regulariser of the geometry latents over the static neighbour graph
+ * (spurfies/model/utils.py:221-282): nbr[n,k] int32 (any valid index where w == 0), w[n,k] inverse-
+ * distance weights (0 = absent), norm[n] = sum_j w.  tv[i] = sum_j w_ij |f_j - f_i|_1 / norm_i
+ * (the caller takes the mean).  Backward accumulates into g_feat_geo[n,32] (float atomics). */
+int spf_tv_forward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm, int32_t n,
+                   int32_t k, float* tv, void* stream);
+int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm,
+                    const float* g_tv, int32_t n, int32_t k, float* g_feat_geo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

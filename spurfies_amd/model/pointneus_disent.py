@@ -184,9 +184,9 @@ class PointVolSDF(nn.Module):
     def _colors(self, rows, x, nbr, wn, ray_dirs, SR):
         """:325-346 on the valid points `rows` (flat slot ids).  Padded to 8 neighbours per point; padding
         carries weight 0.  [P,3]."""
-        nb = nbr[rows].clamp(min=0).long()                        # [P,8]
-        x_pi = x[rows].unsqueeze(1) - self.neural_pts[nb]         # [P,8,3]
-        fin = torch.cat([self.position_encoding(x_pi), self.neural_feats_color[nb]], dim=-1)
+        nb32 = nbr[rows].clamp(min=0)                             # [P,8] int32
+        x_pi = x[rows].unsqueeze(1) - self.neural_pts[nb32.long()]  # [P,8,3]
+        fin = torch.cat([self.position_encoding(x_pi), ops.gather_rows(self.neural_feats_color, nb32)], dim=-1)
         feat = self.F_color(fin)                                  # [P,8,256]
         agg = (wn[rows].unsqueeze(-1) * feat).sum(1)              # weights are detached (:242)
         dirs = ray_dirs[torch.div(rows, SR, rounding_mode="floor")]

@@ -69,16 +69,17 @@ class TVGraph:
         enough = (padded >= 0).sum(-1, keepdim=True) > 1
         padded = torch.where(ident & enough, torch.full_like(padded, -1), padded)
         self.valid = padded >= 0                              # [n,k]
-        self.nbr = padded.clamp(min=0)
-        dist = torch.linalg.norm(kp_pos[self.nbr] - kp_pos[:, None, :], dim=-1)
+        nbr = padded.clamp(min=0)
+        dist = torch.linalg.norm(kp_pos[nbr] - kp_pos[:, None, :], dim=-1)
         w = 1 / (dist + 1.0e-5)
-        self.w = torch.where(self.valid, w, torch.zeros_like(w))
-        self.norm = self.w.sum(-1)
+        self.w = torch.where(self.valid, w, torch.zeros_like(w)).contiguous()
+        self.norm = self.w.sum(-1).contiguous()
+        self.nbr = nbr.to(torch.int32).contiguous()
 
     def loss(self, kp_feat):
-        fdist = (kp_feat[self.nbr] - kp_feat[:, None, :]).abs().sum(-1)
-        tv = (self.w * fdist).sum(-1) / self.norm
-        return tv.mean()
+        from .. import ops
+
+        return ops.TVLoss.apply(kp_feat, self.nbr, self.w, self.norm)
 
 
 def tv_regul(voxel_grid, kp_pos, kp_feat, k, r):

@@ -112,3 +112,57 @@ class GeoSDF(torch.autograd.Function):
             g_feat = torch.zeros((ctx.n_table, 32), dtype=torch.float32, device=g_sdf.device)
             geo_backward_latents(g_sdf, wn, jac, nbr, point_slot, n_points, g_feat)
         return g_x, g_feat, None, None, None, None, None, None
+
+
+class GatherRows(torch.autograd.Function):
+    """table[idx] for a [N,C] latent table (C in {32, 64}); backward = HIP row scatter-add
+    (the reference's index_select backward, spurfies/model/utils.py:158-161)."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = table.shape
+        return table.detach()[idx.long()]
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        n, c = ctx.shape
+        g = g.contiguous().view(-1, c)
+        out = torch.zeros((n, c), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().spf_scatter_add_rows(_lib.ptr(g), _lib.ptr(idx), g.shape[0], c, _lib.ptr(out), _lib.stream_ptr()),
+                       "spf_scatter_add_rows")
+        return out, None
+
+
+def gather_rows(table, idx_i32):
+    """idx_i32: int32 tensor of any shape (all >= 0) -> table rows, shape idx.shape + [C]."""
+    flat = idx_i32.reshape(-1).contiguous()
+    return GatherRows.apply(table, flat).view(*idx_i32.shape, table.shape[1])
+
+
+class TVLoss(torch.autograd.Function):
+    """mean_i tv_i over the static neighbour graph (spurfies/model/utils.py:221-282), HIP fwd + bwd."""
+
+    @staticmethod
+    def forward(ctx, feat, nbr, w, norm):
+        n, k = nbr.shape
+        feat_c = feat.detach().contiguous()
+        tv = torch.empty((n,), dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _lib.check(_lib.lib().spf_tv_forward(_lib.ptr(feat_c), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), n, k, _lib.ptr(tv),
+                                                 _lib.stream_ptr()), "spf_tv_forward")
+        ctx.save_for_backward(feat_c, nbr, w, norm)
+        return tv.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, nbr, w, norm = ctx.saved_tensors
+        n, k = nbr.shape
+        g_tv = (g / n).expand(n).contiguous()
+        out = torch.zeros_like(feat)
+        with torch.cuda.device(feat.device):
+            _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), _lib.ptr(g_tv), n, k,
+                                                  _lib.ptr(out), _lib.stream_ptr()), "spf_tv_backward")
+        return out, None, None, None

@@ -99,3 +99,27 @@ def test_full_size_linearity_property():
     a, b = run(xt), run(xt[perm])
     assert torch.isfinite(a).all()
     assert torch.equal(a[perm], b)
+
+
+def test_tv_and_row_scatter_match_torch():
+    """TV regulariser (utils.py:221-282) and the latent-row scatter-add vs the oracle / plain torch."""
+    from spurfies_amd import ops
+    from spurfies_amd.model.utils import TVGraph
+
+    scene, st, cfg, x, dev, grid, packed = _setup(n_points=4000, n_query=10, seed=6)
+    feat = dev["neural_feats_geometry"].clone().requires_grad_(True)
+    graph = TVGraph(grid, dev["neural_pts"], cfg.k, cfg.r)
+    tv = graph.loss(feat)
+    tv.backward()
+    ogrid = P.make_grid(cfg, st["neural_pts"])
+    tv_o = P.tv_loss(ogrid, st, cfg)
+    tv_o.backward()
+    go = st["neural_feats_geometry"].grad
+    np.testing.assert_allclose(tv.item(), tv_o.item(), rtol=2e-6)
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), go.numpy(), rtol=1e-4, atol=2e-5 * float(go.abs().max()))
+    table = torch.randn((500, 64), device="cuda", requires_grad=True)
+    idx = torch.randint(0, 500, (3000, 8), device="cuda", dtype=torch.int32)
+    wgt = torch.randn((3000, 8, 64), device="cuda")
+    (ops.gather_rows(table, idx) * wgt).sum().backward()
+    ref = torch.zeros((500, 64), device="cuda").index_add_(0, idx.reshape(-1).long(), wgt.reshape(-1, 64))
+    np.testing.assert_allclose(table.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
