@@ -141,6 +141,35 @@ int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* j
                              int32_t k, float* g_feat_geo, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused colour-feature path — replaces the F_color half of get_color,
+ * spurfies/model/pointneus_disent.py:325-336 (posenc embedder.py:26-30, gather utils.py:140-170,
+ * 4 GEMMs, index_add_), and autograd's backward through it.
+ * ---------------------------------------------------------------------------------------- */
+int64_t spf_color_packed_floats(void);
+
+/* Pack F_color.{0,2,4,6} ([out,in] row-major) into forward and transposed fragment order. */
+int spf_color_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4,
+                   const float* b4, const float* w6, const float* b6, float* packed, void* stream);
+
+/* agg[p, 256] = sum_j wn[row,j] * F_color([posenc6(x[row] - pts[nbr[row,j]]) | feat_color[nbr[row,j]]])
+ * for the p-th valid point (row = point_slot[p], or p when point_slot is NULL); wn comes from
+ * spf_geo_forward.  Training mode (act0 != NULL) also stores every layer's input in compact tile order
+ * (row t = 8p + j): act0 [T,104] in the kernel's internal column order [latent 64 | posenc 39 | 0],
+ * act1..act3 [T,256]; T = 64 * ceil(P/8). */
+int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot,
+                      const int32_t* n_points, int32_t max_points, int32_t k, const float* pts,
+                      const float* feat_color, const float* packed, float* agg, float* act0, float* act1,
+                      float* act2, float* act3, void* stream);
+
+/* Data-gradient chain for g_agg[p,256] = dL/d agg: writes the pre-activation gradients G1..G4 [T,256]
+ * (weight gradients are then dW_l = G_l^T act_{l-1}, plain GEMMs) and accumulates the colour-latent
+ * gradient into g_feat_color[N,64] (float atomics). */
+int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot,
+                       const int32_t* n_points, int32_t max_points, int32_t k, const float* packed,
+                       const float* act1, const float* act2, const float* act3, float* G1, float* G2,
+                       float* G3, float* G4, float* g_feat_color, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Latent tables
  * ---------------------------------------------------------------------------------------- */
 

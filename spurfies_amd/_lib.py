@@ -40,6 +40,10 @@ SIGNATURES = {
     "spf_geo_pack": (C.c_int, [_P] * 14),
     "spf_geo_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
     "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "spf_color_packed_floats": (C.c_int64, []),
+    "spf_color_pack": (C.c_int, [_P] * 10),
+    "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_color_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_scatter_add_rows": (C.c_int, [_P, _P, C.c_int64, _I, _P, _P]),
     "spf_tv_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),

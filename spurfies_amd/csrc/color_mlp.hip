@@ -1,0 +1,388 @@
+// Fused colour-feature path (K5 of DESIGN.md): positional encoding of the relative position +
+// gather of the 64-d colour latent, F_color (103 -> 256 -> 256 -> 256 -> 256) on the fp32 matrix cores
+// and the RBF-weighted mean over a point's neighbours — forward, and the data-gradient chain of the
+// backward with the colour-latent scatter-add.
+//
+// Replaces the F_color half of get_color, spurfies/model/pointneus_disent.py:325-336
+// (positional encoding embedder.py:26-30, table gather utils.py:140-170, 4 cuBLAS GEMMs,
+// index_add_ of [pairs,256]) and autograd's backward through it.  The `R` head (:338-346) works on
+// points, not pairs, and is a separate stage.
+//
+// Same tile engine as the geometry kernel (mlp_tile.h): tile = 8 points x 8 neighbour slots = 64
+// rows, compact tile order (row = p*8 + j for the p-th valid point).
+//
+// Training mode stores each layer's input activation ([rows,104] and 3 x [rows,256]) so that
+//   * the backward kernel recovers LeakyReLU' from the sign of the stored activation, and
+//   * the weight gradients dW_l = G_l^T A_{l-1} are plain library GEMMs over [rows,256] buffers
+//     (G_l = gradient w.r.t. layer l's pre-activation, stored by the backward kernel).
+#include "mlp_tile.h"
+
+namespace {
+
+using namespace spf;
+
+constexpr int C_IN = 103;   // 39 posenc + 64 latent (pointneus_disent.py:329-330: [posenc | feat]).
+                            // Inside the kernels the columns are permuted to [latent(64) | posenc(39) | pad] so the latent
+                            // gather lands 16-B aligned in LDS; spf_color_pack applies the permutation to W0's columns,
+                            // and act0 / dW0 are in this internal order (internal k -> reference column: c_orig()).
+constexpr int C_INP = 104;  // padded to a multiple of 8
+constexpr int T_CIN = 13;
+constexpr int N_FREQ = 6;   // get_embedder(multires=6), pointneus_disent.py:70-72
+
+constexpr int SZ_CFW1 = 4 * T_CIN * 2 * 64 * 4;
+constexpr int SZ_CHH = 4 * T_HID * 2 * 64 * 4;
+constexpr int SZ_CBL = 2 * T_HID * 64 * 4;
+constexpr int CO_FW1 = 0;
+constexpr int CO_FW2 = CO_FW1 + SZ_CFW1;
+constexpr int CO_FW3 = CO_FW2 + SZ_CHH;
+constexpr int CO_FW4 = CO_FW3 + SZ_CHH;
+constexpr int CO_BW4 = CO_FW4 + SZ_CHH;
+constexpr int CO_BW3 = CO_BW4 + SZ_CHH;
+constexpr int CO_BW2 = CO_BW3 + SZ_CHH;
+constexpr int CO_BWL = CO_BW2 + SZ_CHH;   // W0[:, 39:103] (256 -> 64 latent columns)
+constexpr int CO_B1 = CO_BWL + SZ_CBL;
+constexpr int CO_B2 = CO_B1 + 256;
+constexpr int CO_B3 = CO_B2 + 256;
+constexpr int CO_B4 = CO_B3 + 256;
+constexpr int C_PACKED = CO_B4 + 256;
+
+constexpr int CL_X = 0;
+constexpr int CL_W = CL_X + 64 * LDA;
+constexpr int CL_TOTAL = CL_W + 64;
+
+// ---- pack ------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int c_orig(int k) { return k < 64 ? 39 + k : k - 64; }
+
+struct CPackArgs {
+    const float *w0, *b0, *w2, *b2, *w4, *b4, *w6, *b6;
+};
+
+__global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= C_PACKED) return;
+    float val = 0.f;
+    if (e < CO_BWL) {
+        int region, local;
+        if (e < CO_FW2) { region = 0; local = e; }
+        else { region = 1 + (e - CO_FW2) / SZ_CHH; local = (e - CO_FW2) % SZ_CHH; }
+        const int T = region == 0 ? T_CIN : T_HID;
+        const int j = local & 3, ln = (local >> 2) & 63, nt = (local >> 8) & 1;
+        const int t = (local >> 9) % T, w = (local >> 9) / T;
+        const int n = 64 * w + 32 * nt + (ln & 31), kk = 8 * t + 4 * (ln >> 5) + j;
+        switch (region) {
+            case 0: val = kk < C_IN ? a.w0[n * C_IN + c_orig(kk)] : 0.f; break;
+            case 1: val = a.w2[n * 256 + kk]; break;
+            case 2: val = a.w4[n * 256 + kk]; break;
+            case 3: val = a.w6[n * 256 + kk]; break;
+            case 4: val = a.w6[kk * 256 + n]; break;   // g_a3[i] = sum_o G4[o] W6[o][i]
+            case 5: val = a.w4[kk * 256 + n]; break;
+            default: val = a.w2[kk * 256 + n]; break;
+        }
+    } else if (e < CO_B1) {
+        const int local = e - CO_BWL;
+        const int j = local & 3, ln = (local >> 2) & 63, t = (local >> 8) & 31, nt = (local >> 13) & 1;
+        const int n = 39 + 32 * nt + (ln & 31), kk = 8 * t + 4 * (ln >> 5) + j;
+        val = a.w0[kk * C_IN + n];
+    } else {
+        const int local = e - CO_B1, l = local >> 8, i = local & 255;
+        val = (l == 0 ? a.b0 : l == 1 ? a.b2 : l == 2 ? a.b4 : a.b6)[i];
+    }
+    out[e] = val;
+}
+
+// epilogue of a hidden layer: + bias, LeakyReLU, write to X, optionally store the activation
+template <bool STORE>
+__device__ __forceinline__ void c_fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave, int lane,
+                                               float* act_g /* tile base [64][256] */) {
+    const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+    const float bv[2] = {bias[c0], bias[c0 + 32]};
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[m][n][r] + bv[n];
+                v = v > 0.f ? v : v * 0.01f;
+                const int row = m * 32 + row_of(r, h);
+                X[row * LDA + c0 + 32 * n] = v;
+                if (STORE) act_g[row * 256 + c0 + 32 * n] = v;
+            }
+}
+
+template <bool STORE>
+__global__ void __launch_bounds__(256, 2)
+color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
+                     const int32_t* __restrict__ point_slot, const int32_t* __restrict__ n_points_dev, int max_points, int k,
+                     const float* __restrict__ pts, const float* __restrict__ feat_col, const float* packed,
+                     float* __restrict__ agg, float* __restrict__ act0, float* __restrict__ act1, float* __restrict__ act2,
+                     float* __restrict__ act3) {
+    __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL];
+    float* X = smem + CL_X;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    const int ntiles = (P + SPF_TILE_PTS - 1) / SPF_TILE_PTS;
+    const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- gather: thread = (row, quarter): 16 latent floats each; quarter 0 also does posenc -----
+        {
+            const int row = tid >> 2, q = tid & 3;
+            const int p = tile * SPF_TILE_PTS + (row >> 3), j = row & 7;
+            int idx = -1, srow = 0;
+            if (p < P) {
+                srow = point_slot ? point_slot[p] : p;
+                if (j < k) idx = nbr[(size_t)srow * k + j];
+            }
+            f32x4 f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx >= 0) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(feat_col + (size_t)idx * SPF_COL_DIM + q * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) f[u] = src[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(X + row * LDA + q * 16 + 4 * u) = f[u];
+            if (q == 0) {
+                float d[3] = {0.f, 0.f, 0.f};
+                float w = 0.f;
+                if (idx >= 0) {
+                    d[0] = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
+                    d[1] = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
+                    d[2] = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
+                    w = wn[(size_t)srow * 8 + j];
+                }
+                float* e = X + row * LDA + 64;   // posenc block: internal columns 64..102
+                if (idx >= 0) {
+                    e[0] = d[0]; e[1] = d[1]; e[2] = d[2];
+                    float fr = 1.f;
+#pragma unroll
+                    for (int l = 0; l < N_FREQ; ++l) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float a = d[c] * fr;
+                            e[3 + 6 * l + c] = sinf(a);
+                            e[6 + 6 * l + c] = cosf(a);
+                        }
+                        fr *= 2.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 39; ++c) e[c] = 0.f;
+                }
+                e[39] = 0.f;                      // pad column 103
+                smem[CL_W + row] = w;
+            }
+        }
+        __syncthreads();
+        if (STORE) {  // layer-1 input [64][104] -> act0 (coalesced float4 copy out of LDS)
+            float* dst = act0 + (size_t)tile * 64 * C_INP;
+            for (int e4 = tid; e4 < 64 * (C_INP / 4); e4 += 256) {
+                const int row = e4 / (C_INP / 4), c4 = e4 % (C_INP / 4);
+                *reinterpret_cast<f32x4*>(dst + row * C_INP + 4 * c4) = *reinterpret_cast<const f32x4*>(X + row * LDA + 4 * c4);
+            }
+        }
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        gemm_rows64<T_CIN>(X, pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128), lane, acc);
+        __syncthreads();
+        c_fwd_epilogue<STORE>(X, acc, packed + CO_B1, wave, lane, STORE ? act1 + (size_t)tile * 64 * 256 : nullptr);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID>(X, pk4 + (CO_FW2 / 4) + wave * (T_HID * 128), lane, acc);
+        __syncthreads();
+        c_fwd_epilogue<STORE>(X, acc, packed + CO_B2, wave, lane, STORE ? act2 + (size_t)tile * 64 * 256 : nullptr);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID>(X, pk4 + (CO_FW3 / 4) + wave * (T_HID * 128), lane, acc);
+        __syncthreads();
+        c_fwd_epilogue<STORE>(X, acc, packed + CO_B3, wave, lane, STORE ? act3 + (size_t)tile * 64 * 256 : nullptr);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID>(X, pk4 + (CO_FW4 / 4) + wave * (T_HID * 128), lane, acc);
+        // ---- last layer has no activation: weighted mean over the 8 neighbour rows of each point ----
+        {
+            const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+            const float bv[2] = {packed[CO_B4 + c0], packed[CO_B4 + c0 + 32]};
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {       // point (g + 4m) of the tile: rows 8(g+4m) + (r&3) + 4h
+                    const int pl = g + 4 * m;
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float w = smem[CL_W + pl * 8 + u + 4 * h];
+                        s0 += w * (acc[m][0][4 * g + u] + bv[0]);
+                        s1 += w * (acc[m][1][4 * g + u] + bv[1]);
+                    }
+                    s0 += __shfl_xor(s0, 32);
+                    s1 += __shfl_xor(s1, 32);
+                    const int p = tile * SPF_TILE_PTS + pl;
+                    if (h == 0 && p < P) {
+                        agg[(size_t)p * 256 + c0] = s0;
+                        agg[(size_t)p * 256 + c0 + 32] = s1;
+                    }
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// backward epilogue: G_l = g_a * lrelu'(h_l), sign read from the stored activation; write X and G_l
+__device__ __forceinline__ void c_bwd_epilogue(float* X, const f32x16 (&acc)[2][2], int wave, int lane,
+                                               const float* __restrict__ act_g, float* __restrict__ g_out) {
+    const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m * 32 + row_of(r, h);
+                const float a = act_g[row * 256 + c0 + 32 * n];
+                float v = acc[m][n][r];
+                v = a > 0.f ? v : v * 0.01f;
+                X[row * LDA + c0 + 32 * n] = v;
+                g_out[row * 256 + c0 + 32 * n] = v;
+            }
+}
+
+__global__ void __launch_bounds__(256, 2)
+color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
+                      const int32_t* __restrict__ point_slot, const int32_t* __restrict__ n_points_dev, int max_points, int k,
+                      const float* packed, const float* __restrict__ act1, const float* __restrict__ act2,
+                      const float* __restrict__ act3, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3,
+                      float* __restrict__ G4, float* __restrict__ g_feat_col) {
+    __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL];
+    float* X = smem + CL_X;
+    int* s_idx = reinterpret_cast<int*>(smem + CL_W);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    const int ntiles = (P + SPF_TILE_PTS - 1) / SPF_TILE_PTS;
+    const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t tbase = (size_t)tile * 64 * 256;
+        // ---- G4[row] = wn[row] * g_agg[p]  (the last layer is linear; agg = sum_j wn_j f_j) ---------
+        {
+            const int row = tid >> 2, q = tid & 3;
+            const int p = tile * SPF_TILE_PTS + (row >> 3), j = row & 7;
+            float w = 0.f;
+            int idx = -1;
+            if (p < P) {
+                const int srow = point_slot ? point_slot[p] : p;
+                if (j < k) idx = nbr[(size_t)srow * k + j];
+                if (idx >= 0) w = wn[(size_t)srow * 8 + j];
+            }
+            if (q == 0) s_idx[row] = idx;
+            const f32x4* ga = reinterpret_cast<const f32x4*>(g_agg + (size_t)(p < P ? p : 0) * 256);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c4 = q + 4 * u;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (w != 0.f) {
+                    v = ga[c4];
+                    v[0] *= w; v[1] *= w; v[2] *= w; v[3] *= w;
+                }
+                *reinterpret_cast<f32x4*>(X + row * LDA + 4 * c4) = v;
+                *reinterpret_cast<f32x4*>(G4 + tbase + row * 256 + 4 * c4) = v;
+            }
+        }
+        __syncthreads();
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        gemm_rows64<T_HID>(X, pk4 + (CO_BW4 / 4) + wave * (T_HID * 128), lane, acc);
+        __syncthreads();
+        c_bwd_epilogue(X, acc, wave, lane, act3 + tbase, G3 + tbase);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID>(X, pk4 + (CO_BW3 / 4) + wave * (T_HID * 128), lane, acc);
+        __syncthreads();
+        c_bwd_epilogue(X, acc, wave, lane, act2 + tbase, G2 + tbase);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID>(X, pk4 + (CO_BW2 / 4) + wave * (T_HID * 128), lane, acc);
+        __syncthreads();
+        c_bwd_epilogue(X, acc, wave, lane, act1 + tbase, G1 + tbase);
+        __syncthreads();
+        // ---- d/d latent = G1 * W0[:, 39:103]; wave = (row half mt, latent half nt); scatter-add ------
+        {
+            const int mt = wave >> 1, nt = wave & 1, i = lane & 31, h = lane >> 5;
+            f32x16 aj;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aj[r] = 0.f;
+            const float* ap = X + (mt * 32 + i) * LDA + 4 * h;
+            const f32x4* bp = pk4 + (CO_BWL / 4) + nt * (T_HID * 64) + lane;
+#pragma unroll 4
+            for (int t = 0; t < T_HID; ++t) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * t);
+                const f32x4 b = bp[t * 64];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) aj = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b[jj], aj, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + row_of(r, h);
+                const int idx = s_idx[row];
+                if (idx >= 0) atomicAdd(&g_feat_col[(size_t)idx * SPF_COL_DIM + 32 * nt + i], aj[r]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t spf_color_packed_floats(void) { return C_PACKED; }
+
+int spf_color_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
+                   const float* w6, const float* b6, float* packed, void* stream) {
+    if (!w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !w6 || !b6 || !packed) return spf::fail(SPF_EINVAL, "spf_color_pack: null pointer");
+    CPackArgs a{w0, b0, w2, b2, w4, b4, w6, b6};
+    color_pack_kernel<<<spf::div_up(C_PACKED, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
+    SPF_LAUNCH_CHECK("color_pack_kernel");
+    return SPF_OK;
+}
+
+int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* n_points,
+                      int32_t max_points, int32_t k, const float* pts, const float* feat_color, const float* packed, float* agg,
+                      float* act0, float* act1, float* act2, float* act3, void* stream) {
+    if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_forward: bad sizes");
+    if (max_points == 0) return SPF_OK;
+    if (!x || !nbr || !wn || !pts || !feat_color || !packed || !agg) return spf::fail(SPF_EINVAL, "spf_color_forward: null pointer");
+    const bool store = act0 != nullptr;
+    if (store && (!act1 || !act2 || !act3)) return spf::fail(SPF_EINVAL, "spf_color_forward: act0..act3 must be given together");
+    const int tiles = spf::div_up(max_points, SPF_TILE_PTS);
+    const int blocks = tiles < 512 ? tiles : 512;
+    if (store)
+        color_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, n_points, max_points, k, pts,
+                                                                            feat_color, packed, agg, act0, act1, act2, act3);
+    else
+        color_forward_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, n_points, max_points, k, pts,
+                                                                             feat_color, packed, agg, nullptr, nullptr, nullptr, nullptr);
+    SPF_LAUNCH_CHECK("color_forward_kernel");
+    return SPF_OK;
+}
+
+int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* n_points,
+                       int32_t max_points, int32_t k, const float* packed, const float* act1, const float* act2, const float* act3,
+                       float* G1, float* G2, float* G3, float* G4, float* g_feat_color, void* stream) {
+    if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_backward: bad sizes");
+    if (max_points == 0) return SPF_OK;
+    if (!g_agg || !nbr || !wn || !packed || !act1 || !act2 || !act3 || !G1 || !G2 || !G3 || !G4 || !g_feat_color)
+        return spf::fail(SPF_EINVAL, "spf_color_backward: null pointer");
+    const int tiles = spf::div_up(max_points, SPF_TILE_PTS);
+    const int blocks = tiles < 512 ? tiles : 512;
+    color_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_agg, nbr, wn, point_slot, n_points, max_points, k, packed, act1,
+                                                                   act2, act3, G1, G2, G3, G4, g_feat_color);
+    SPF_LAUNCH_CHECK("color_backward_kernel");
+    return SPF_OK;
+}
+
+}  // extern "C"

@@ -22,19 +22,14 @@
 //   d sdf_j / d in = (((v * D4) W6 * D3) W4 * D2) W2 * D1) W0,  D_l = lrelu'(h_l) in {1, 0.01}
 //   sdf(p) = sum_j w_j sdf_j / sum_j w_j,  w_j = exp(-(rbf * max(|x_pi|, 1e-12))^2)  (detached)
 //   d sdf / d x(p) = sum_j (w_j / norm) d sdf_j / d x_pi
-#include "common.h"
+#include "mlp_tile.h"
 
 namespace {
 
 using namespace spf;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int LDA = 260;     // LDS row stride in floats (1040 B: 16-B aligned, breaks the 256-B bank period)
 constexpr int K_IN = 35;     // 32 latent + 3 x_pi
 constexpr int T_IN = 5;      // ceil(35/8) k-steps of 8 for the first layer
-constexpr int T_HID = 32;    // 256/8
 
 // packed image layout (floats)
 constexpr int SZ_FW1 = 4 * T_IN * 2 * 64 * 4;
@@ -64,46 +59,6 @@ constexpr int L_JX = L_S + 64;        // per-row d sdf_j / d x_pi (3)
 constexpr int L_NORM = L_JX + 192;    // per-point sum of weights
 constexpr int L_SROW = L_NORM + 8;    // per-point output row (int bits), -1 beyond the last point
 constexpr int L_TOTAL = L_SROW + 8;
-
-__device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// acc[mt][nt] += X[mt*32.., :] * B  for this wave's 64 output columns.  wp: [T][2][64] float4.
-template <int T>
-__device__ __forceinline__ void gemm_rows64(const float* X, const f32x4* wp, int lane, f32x16 (&acc)[2][2]) {
-    const int i = lane & 31, h = lane >> 5;
-    const float* a0p = X + i * LDA + 4 * h;
-    const float* a1p = a0p + 32 * LDA;
-    const f32x4* bp = wp + lane;
-    f32x4 b0 = bp[0], b1 = bp[64];
-#pragma unroll 4
-    for (int t = 0; t < T; ++t) {
-        f32x4 nb0 = b0, nb1 = b1;
-        if (t + 1 < T) {
-            nb0 = bp[(t + 1) * 128];
-            nb1 = bp[(t + 1) * 128 + 64];
-        }
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + 8 * t);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 8 * t);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
-        }
-        b0 = nb0;
-        b1 = nb1;
-    }
-}
-
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-}
 
 // forward epilogue: + bias, record sign bits, LeakyReLU, write this wave's 64x64 block back to X
 __device__ __forceinline__ void fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave,

@@ -1,0 +1,56 @@
+// Device helpers shared by the fused MLP kernels (geometry, colour): one tile = 64 rows, four waves,
+// wave w owns output columns [64w, 64w+64) as 2x2 tiles of v_mfma_f32_32x32x2_f32; A operand in LDS
+// (row stride LDA floats), B operand streamed from L2 in packed fragment order.
+#pragma once
+#include "common.h"
+
+namespace spf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LDA = 260;     // LDS row stride in floats (1040 B: 16-B aligned, breaks the 256-B bank period)
+constexpr int T_HID = 32;    // 256/8
+
+__device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// acc[mt][nt] += X[mt*32.., :] * B  for this wave's 64 output columns.  wp: [T][2][64] float4.
+template <int T>
+__device__ __forceinline__ void gemm_rows64(const float* X, const f32x4* wp, int lane, f32x16 (&acc)[2][2]) {
+    const int i = lane & 31, h = lane >> 5;
+    const float* a0p = X + i * LDA + 4 * h;
+    const float* a1p = a0p + 32 * LDA;
+    const f32x4* bp = wp + lane;
+    f32x4 b0 = bp[0], b1 = bp[64];
+#pragma unroll 4
+    for (int t = 0; t < T; ++t) {
+        f32x4 nb0 = b0, nb1 = b1;
+        if (t + 1 < T) {
+            nb0 = bp[(t + 1) * 128];
+            nb1 = bp[(t + 1) * 128 + 64];
+        }
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + 8 * t);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 8 * t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        }
+        b0 = nb0;
+        b1 = nb1;
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+}
+
+
+}  // namespace spf

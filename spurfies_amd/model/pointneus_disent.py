@@ -181,14 +181,13 @@ class PointVolSDF(nn.Module):
         transmittance = torch.exp(-torch.cumsum(shifted, dim=-1))
         return alpha * transmittance
 
-    def _colors(self, rows, x, nbr, wn, ray_dirs, SR):
-        """:325-346 on the valid points `rows` (flat slot ids).  Padded to 8 neighbours per point; padding
-        carries weight 0.  [P,3]."""
-        nb32 = nbr[rows].clamp(min=0)                             # [P,8] int32
-        x_pi = x[rows].unsqueeze(1) - self.neural_pts[nb32.long()]  # [P,8,3]
-        fin = torch.cat([self.position_encoding(x_pi), ops.gather_rows(self.neural_feats_color, nb32)], dim=-1)
-        feat = self.F_color(fin)                                  # [P,8,256]
-        agg = (wn[rows].unsqueeze(-1) * feat).sum(1)              # weights are detached (:242)
+    def _colors(self, rows, x, nbr, wn, point_slot, n_points, ray_dirs, SR):
+        """:325-346 on the P valid points (`rows` = their flat slot ids).  F_color + the RBF-weighted mean are
+        the fused HIP kernels; the small per-point `R` head stays a PyTorch module.  [P,3]."""
+        fc = self.F_color
+        agg = ops.ColorAgg.apply(self.neural_feats_color, fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight,
+                                 fc[4].bias, fc[6].weight, fc[6].bias, x, nbr, wn, point_slot, n_points, self.neural_pts,
+                                 rows.shape[0])
         dirs = ray_dirs[torch.div(rows, SR, rounding_mode="floor")]
         return self.R(torch.cat([self.view_encoding(dirs), agg], dim=-1))
 
@@ -232,7 +231,7 @@ class PointVolSDF(nn.Module):
         self.stats = {"valid_points": P, "rays": R}
         colors = torch.zeros((R * SR, 3), device=dev)
         if P > 0:
-            colors = colors.index_put((rows,), self._colors(rows, x, nbr, wn, ray_dirs, SR))
+            colors = colors.index_put((rows,), self._colors(rows, x, nbr, wn, point_slot, n_points, ray_dirs, SR))
         colors = colors.view(R, SR, 3)
 
         # ---- density + compositing (:714-723, 765-795) -----------------------------------------

@@ -166,3 +166,72 @@ class TVLoss(torch.autograd.Function):
             _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), _lib.ptr(g_tv), n, k,
                                                   _lib.ptr(out), _lib.stream_ptr()), "spf_tv_backward")
         return out, None, None, None
+
+
+# ---- fused colour-feature path ------------------------------------------------------------------
+_C_ORIG = None
+
+
+def _color_col_perm(device):
+    """internal column k of the colour kernels -> reference column (spf_color_pack's c_orig)."""
+    global _C_ORIG
+    if _C_ORIG is None or _C_ORIG.device != device:
+        k = torch.arange(103, device=device)
+        _C_ORIG = torch.where(k < 64, 39 + k, k - 64)
+    return _C_ORIG
+
+
+def pack_color_weights(ws):
+    """ws: [w0, b0, w2, b2, w4, b4, w6, b6] of F_color -> packed image."""
+    args = [t.detach().contiguous().float() for t in ws]
+    dev = args[0].device
+    packed = torch.empty((int(_lib.lib().spf_color_packed_floats()),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_color_pack(*[_lib.ptr(a) for a in args], _lib.ptr(packed), _lib.stream_ptr()), "spf_color_pack")
+    return packed
+
+
+class ColorAgg(torch.autograd.Function):
+    """agg[p,256] = sum_j wn_j F_color([posenc6(x_pi) | colour latent]) for the P valid points
+    (pointneus_disent.py:325-336).  Forward and the data-gradient chain are HIP kernels; the weight
+    gradients are library GEMMs over the activation / pre-activation-gradient buffers the kernels store."""
+
+    @staticmethod
+    def forward(ctx, feat_col, w0, b0, w2, b2, w4, b4, w6, b6, x, nbr, wn, point_slot, n_points, pts, n_valid):
+        dev = x.device
+        P = int(n_valid)
+        k = nbr.shape[1]
+        rows = 64 * ((P + 7) // 8)
+        packed = pack_color_weights([w0, b0, w2, b2, w4, b4, w6, b6])
+        agg = torch.empty((P, 256), dtype=torch.float32, device=dev)
+        train = any(ctx.needs_input_grad[:9])
+        acts = [torch.empty((rows, 104), dtype=torch.float32, device=dev)] + \
+               [torch.empty((rows, 256), dtype=torch.float32, device=dev) for _ in range(3)] if train else [None] * 4
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_color_forward(_lib.ptr(x), _lib.ptr(nbr), _lib.ptr(wn), _lib.ptr(point_slot), _lib.ptr(n_points), P, k,
+                                                    _lib.ptr(pts), _lib.ptr(feat_col.detach()), _lib.ptr(packed), _lib.ptr(agg),
+                                                    *[_lib.ptr(a) for a in acts], _lib.stream_ptr()), "spf_color_forward")
+        if train:
+            ctx.save_for_backward(nbr, wn, point_slot, n_points, packed, *acts)
+            ctx.P, ctx.n_table = P, feat_col.shape[0]
+        return agg
+
+    @staticmethod
+    def backward(ctx, g_agg):
+        nbr, wn, point_slot, n_points, packed, act0, act1, act2, act3 = ctx.saved_tensors
+        dev = g_agg.device
+        P, k = ctx.P, nbr.shape[1]
+        rows = act1.shape[0]
+        G = [torch.empty((rows, 256), dtype=torch.float32, device=dev) for _ in range(4)]
+        g_feat = torch.zeros((ctx.n_table, 64), dtype=torch.float32, device=dev)
+        g_agg = g_agg.contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg), _lib.ptr(nbr), _lib.ptr(wn), _lib.ptr(point_slot), _lib.ptr(n_points), P, k,
+                                                     _lib.ptr(packed), _lib.ptr(act1), _lib.ptr(act2), _lib.ptr(act3),
+                                                     *[_lib.ptr(g) for g in G], _lib.ptr(g_feat), _lib.stream_ptr()), "spf_color_backward")
+        G1, G2, G3, G4 = G
+        dw0_int = G1.t() @ act0                                    # [256,104] in the kernels' internal column order
+        dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
+        dw0[:, _color_col_perm(dev)] = dw0_int[:, :103]
+        grads = (g_feat, dw0, G1.sum(0), G2.t() @ act1, G2.sum(0), G3.t() @ act2, G3.sum(0), G4.t() @ act3, G4.sum(0))
+        return grads + (None,) * 7

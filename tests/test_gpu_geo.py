@@ -106,7 +106,7 @@ def test_tv_and_row_scatter_match_torch():
     from spurfies_amd import ops
     from spurfies_amd.model.utils import TVGraph
 
-    scene, st, cfg, x, dev, grid, packed = _setup(n_points=4000, n_query=10, seed=6)
+    scene, st, cfg, x, dev, grid, packed = _setup(n_points=4000, n_query=100, seed=6)
     feat = dev["neural_feats_geometry"].clone().requires_grad_(True)
     graph = TVGraph(grid, dev["neural_pts"], cfg.k, cfg.r)
     tv = graph.loss(feat)
@@ -123,3 +123,41 @@ def test_tv_and_row_scatter_match_torch():
     (ops.gather_rows(table, idx) * wgt).sum().backward()
     ref = torch.zeros((500, 64), device="cuda").index_add_(0, idx.reshape(-1).long(), wgt.reshape(-1, 64))
     np.testing.assert_allclose(table.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_color_agg_forward_backward_match_oracle():
+    """Fused F_color + weighted mean (pointneus_disent.py:325-336) vs torch-CPU autograd: agg, colour-latent
+    gradient, F_color weight / bias gradients."""
+    from spurfies_amd import ops
+
+    scene, st, cfg, x, dev, grid, packed = _setup(n_points=5000, n_query=2500, seed=8)
+    xt = torch.from_numpy(x).cuda()
+    q = grid.query_dense(xt.unsqueeze(1), cfg.k, cfg.r, 1)
+    point_slot, _, n_pts = ops.compact_points(q["slot_valid"])
+    nbr = q["pidx"].reshape(-1, cfg.k)
+    geo = ops.geo_forward(xt, nbr, point_slot, n_pts, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
+    P_ = int(n_pts.item())
+    names = [f"F_color.{i}.{n}" for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+    params = [dev[n].clone().requires_grad_(True) for n in names]
+    table = dev["neural_feats_color"].clone().requires_grad_(True)
+    agg = ops.ColorAgg.apply(table, *params, xt, nbr, geo["wn"], point_slot, n_pts, dev["neural_pts"], P_)
+    coef = torch.randn((P_, 256), generator=torch.Generator().manual_seed(0)).cuda()
+    (agg * coef).sum().backward()
+    # oracle
+    ogrid = P.make_grid(cfg, st["neural_pts"])
+    nb, _, mask, _ = P.knn_query(ogrid, torch.from_numpy(x).unsqueeze(1), cfg.k, cfg.r, 1)
+    valid = nb >= 0
+    rows = P.pair_index(valid)
+    pos, fc, fg = P.gather_pairs(nb, valid, st)
+    x_pi = torch.from_numpy(x)[mask.reshape(-1)][rows] - pos
+    w, norm = P.rbf_weights(x_pi, rows, nb.shape[0], cfg.rbf)
+    feat = P.mlp(torch.cat([P.posenc(x_pi, 6), fc], -1), st, "F_color")
+    agg_o = torch.zeros(nb.shape[0], 256).index_add_(0, rows, w.unsqueeze(-1) * feat) / norm.unsqueeze(-1)
+    (agg_o * coef.cpu()).sum().backward()
+    assert agg_o.shape[0] == P_
+    np.testing.assert_allclose(agg.detach().cpu().numpy(), agg_o.detach().numpy(), rtol=2e-4, atol=2e-5)
+    go = st["neural_feats_color"].grad
+    np.testing.assert_allclose(table.grad.cpu().numpy(), go.numpy(), rtol=2e-3, atol=1e-4 * float(go.abs().max()))
+    for n, p_ in zip(names, params):
+        g = st[n].grad
+        np.testing.assert_allclose(p_.grad.cpu().numpy(), g.numpy(), rtol=2e-3, atol=2e-4 * float(g.abs().max()), err_msg=n)
