@@ -170,6 +170,33 @@ int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, 
                        float* G3, float* G4, float* g_feat_color, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-ray compositing — replaces filter_points (spurfies/model/pointneus_disent.py:207-239),
+ * LaplaceDensity (spurfies/model/density.py:16-30), volume_rendering (:894-908) and the composites
+ * (:765-795), forward and backward.  All arrays are dense [R,SR] (invalid slots masked).
+ * ---------------------------------------------------------------------------------------- */
+
+/* loc [R,SR,3] slot sample positions (spf_grid_query), slot_valid [R,SR], cam_loc / ray_dirs [R,3] ->
+ *   z [R,SR]       t = nanmean_xyz((loc - o)/d) at valid slots, 0 elsewhere
+ *   deltas [R,SR]  max(z[s+1] - z[s], 0) with z[SR] := 0; 0 at invalid slots
+ *   x [R*SR,3]     o + z d  (the shading points handed to the MLP kernels) */
+int spf_filter_points(const float* loc, const uint8_t* slot_valid, const float* cam_loc, const float* ray_dirs,
+                      int32_t R, int32_t SR, float* z, float* deltas, float* x, void* stream);
+
+/* sigma = Laplace(sdf; *beta) at valid slots, E = delta sigma, w = (1 - e^-E) exp(-sum_{i<j} E_i);
+ * rgb = sum w c, depth = sum w z / (sum w + 1e-8), dist = sum w z / (sum w + 1e-10), acc = sum w.
+ * colors [R,SR,3] must be 0 at invalid slots; beta is a DEVICE scalar (|beta_param| + beta_min). */
+int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas,
+                       const float* colors, const float* beta, int32_t R, int32_t SR, float* weights,
+                       float* rgb, float* depth, float* dist, float* acc, void* stream);
+
+/* Gradients of a scalar loss given g_weights [R,SR] (may be NULL), g_rgb [R,3], g_depth [R] (may be
+ * NULL), g_dist [R] (may be NULL): g_sdf [R,SR], g_colors [R,SR,3], and g_beta[0] += dL/d beta. */
+int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas,
+                        const float* colors, const float* beta, const float* weights, const float* g_weights,
+                        const float* g_rgb, const float* g_depth, const float* g_dist, int32_t R, int32_t SR,
+                        float* g_sdf, float* g_colors, float* g_beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Latent tables
  * ---------------------------------------------------------------------------------------- */
 

@@ -213,12 +213,8 @@ class PointVolSDF(nn.Module):
         point_slot, _, n_points = ops.compact_points(q["slot_valid"])
         nbr = q["pidx"].view(R * SR, k)
 
-        # ---- filter_points (:207-239) on dense rows --------------------------------------------
-        t = ((q["loc"] - cam_loc.unsqueeze(1)) / ray_dirs.unsqueeze(1)).nanmean(dim=-1)          # [R,SR]
-        z_slots = torch.where(valid, t, torch.zeros_like(t))
-        z_pad = torch.cat([z_slots, torch.zeros(R, 1, device=dev)], dim=1)
-        deltas = torch.where(valid, z_pad[:, 1:] - z_pad[:, :-1], torch.zeros_like(t)).clamp(min=0)
-        x = (cam_loc.unsqueeze(1) + z_slots.unsqueeze(-1) * ray_dirs.unsqueeze(1)).view(R * SR, 3).detach()
+        # ---- filter_points (:207-239) on dense rows (HIP) ---------------------------------------
+        z_slots, deltas, x = ops.filter_points(q["loc"], q["slot_valid"], cam_loc.detach(), ray_dirs.detach())
 
         # ---- geometry: sdf, d sdf/d x, normalised RBF weights (HIP) -----------------------------
         sdf_flat, gradients, wn = ops.GeoSDF.apply(x, self.neural_feats_geometry, nbr, point_slot, n_points, self.neural_pts,
@@ -234,13 +230,8 @@ class PointVolSDF(nn.Module):
             colors = colors.index_put((rows,), self._colors(rows, x, nbr, wn, point_slot, n_points, ray_dirs, SR))
         colors = colors.view(R, SR, 3)
 
-        # ---- density + compositing (:714-723, 765-795) -----------------------------------------
-        dens = torch.where(valid, self.density(sdf), torch.zeros_like(sdf))
-        weights = self.volume_rendering(deltas, dens)             # [R,SR]
-        wsum = weights.sum(-1, keepdim=True)
-        dist_map = torch.sum(weights / (wsum + 1e-10) * z_slots, -1)
-        rgb = torch.sum(weights.unsqueeze(-1) * colors, 1)
-        depth = torch.sum(weights * z_slots, 1, keepdim=True) / (wsum + 1e-8)
+        # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------
+        weights, rgb, depth, dist_map, _ = ops.Render.apply(sdf, colors, self.density.get_beta(), q["slot_valid"], z_slots, deltas)
         depth = torch.where(ray_mask[:, None], depth, torch.ones_like(depth))
         far_fill = float(conf.ray_sampler.far)
         depth_vals = torch.where(ray_mask[:, None], z_slots * depth_scale, torch.full_like(z_slots, far_fill))

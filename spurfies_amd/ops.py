@@ -235,3 +235,65 @@ class ColorAgg(torch.autograd.Function):
         dw0[:, _color_col_perm(dev)] = dw0_int[:, :103]
         grads = (g_feat, dw0, G1.sum(0), G2.t() @ act1, G2.sum(0), G3.t() @ act2, G3.sum(0), G4.t() @ act3, G4.sum(0))
         return grads + (None,) * 7
+
+
+# ---- per-ray compositing --------------------------------------------------------------------------
+def filter_points(loc, slot_valid, cam_loc, ray_dirs):
+    """pointneus_disent.py:207-239 on dense rows -> (z [R,SR], deltas [R,SR], x [R*SR,3]); no autograd (inputs are detached)."""
+    R, SR = slot_valid.shape
+    dev = loc.device
+    z = torch.empty((R, SR), dtype=torch.float32, device=dev)
+    deltas = torch.empty((R, SR), dtype=torch.float32, device=dev)
+    x = torch.empty((R * SR, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_filter_points(_lib.ptr(loc.contiguous()), _lib.ptr(slot_valid), _lib.ptr(cam_loc.contiguous()),
+                                                _lib.ptr(ray_dirs.contiguous()), R, SR, _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(x),
+                                                _lib.stream_ptr()), "spf_filter_points")
+    return z, deltas, x
+
+
+class Render(torch.autograd.Function):
+    """(weights [R,SR], rgb [R,3], depth [R,1], dist_map [R], acc [R,1]) from sdf [R,SR], colors [R,SR,3] and the
+    effective beta (a 0-dim tensor); differentiable w.r.t. all three."""
+
+    @staticmethod
+    def forward(ctx, sdf, colors, beta, slot_valid, z, deltas):
+        R, SR = sdf.shape
+        dev = sdf.device
+        sdf_c, col_c = sdf.detach().contiguous(), colors.detach().contiguous()
+        beta_c = beta.detach().reshape(1).contiguous()
+        weights = torch.empty((R, SR), dtype=torch.float32, device=dev)
+        rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        dist = torch.empty((R,), dtype=torch.float32, device=dev)
+        acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_render_forward(_lib.ptr(sdf_c), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(col_c),
+                                                     _lib.ptr(beta_c), R, SR, _lib.ptr(weights), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(dist),
+                                                     _lib.ptr(acc), _lib.stream_ptr()), "spf_render_forward")
+        ctx.save_for_backward(sdf_c, col_c, beta_c, slot_valid, z, deltas, weights)
+        return weights, rgb, depth, dist, acc
+
+    @staticmethod
+    def backward(ctx, g_w, g_rgb, g_depth, g_dist, g_acc):
+        sdf, colors, beta, slot_valid, z, deltas, weights = ctx.saved_tensors
+        R, SR = sdf.shape
+        dev = sdf.device
+        gw = None
+        if g_w is not None:
+            gw = g_w
+        if g_acc is not None:  # acc = sum_j w_j
+            gw = g_acc.expand(R, SR) if gw is None else gw + g_acc
+        gw = None if gw is None else gw.contiguous()
+        g_rgb = torch.zeros((R, 3), device=dev) if g_rgb is None else g_rgb.contiguous()
+        g_depth = None if g_depth is None else g_depth.contiguous()
+        g_dist = None if g_dist is None else g_dist.contiguous()
+        g_sdf = torch.empty((R, SR), dtype=torch.float32, device=dev)
+        g_col = torch.empty((R, SR, 3), dtype=torch.float32, device=dev)
+        g_beta = torch.zeros((1,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_render_backward(_lib.ptr(sdf), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(colors),
+                                                      _lib.ptr(beta), _lib.ptr(weights), _lib.ptr(gw), _lib.ptr(g_rgb), _lib.ptr(g_depth),
+                                                      _lib.ptr(g_dist), R, SR, _lib.ptr(g_sdf), _lib.ptr(g_col), _lib.ptr(g_beta),
+                                                      _lib.stream_ptr()), "spf_render_backward")
+        return g_sdf, g_col, g_beta.reshape(()), None, None, None
