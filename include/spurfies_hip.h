@@ -170,6 +170,35 @@ int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, 
                        float* G3, float* G4, float* g_feat_color, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * VolSDF error-bounded sampler — replaces UniformSampler.get_z_vals (spurfies/model/ray_sampler.py:33-59),
+ * ErrorBoundSampler_pn.get_z_vals (:377-574) and get_error_bound (:576-588).  The random numbers are
+ * drawn by the host from the CPU generator, as the reference does, and passed in.
+ * ---------------------------------------------------------------------------------------- */
+
+/* z[r,i] = near (1 - tlin[i]) + far tlin[i]; with t_rand [R,n] (training) stratified inside the
+ * mid-point intervals.  Also writes points[r,i,:] = cam_loc[r] + z ray_dirs[r]. */
+int spf_sampler_uniform(const float* tlin, const float* t_rand, const float* cam_loc, const float* ray_dirs,
+                        int32_t R, int32_t n, float near, float far, float* z, float* points, void* stream);
+
+/* One refinement iteration on sorted z [R,n] with sdf [R,n] (1000 where a sample has no neighbour):
+ * d* per interval, beta by bisection from beta_in [R] (NULL: the Lemma-2 bound sqrt(bound_coef * sum dz^2)),
+ * beta0 a DEVICE scalar, then N samples by inverting the CDF of
+ *   more == 0: the rendering weights + 1e-5           (final sample set, :491-503)
+ *   more != 0: the per-interval error bound + add_tiny (:470-489), and z_merged [R,n+N] =
+ *              sort(cat(z, samples)) with merged_idx [R,n+N] indexing into cat(z, samples).
+ * u: [N] (u_per_ray == 0) or [R,N].  N may be 0 (beta only).  beta_out [R]. */
+int spf_sampler_iter(const float* z, const float* sdf, const float* beta_in, const float* beta0, int32_t R,
+                     int32_t n, float eps, float bound_coef, int32_t beta_iters, int32_t more, float add_tiny,
+                     const float* u, int32_t u_per_ray, int32_t N, float* samples, float* beta_out,
+                     float* z_merged, int32_t* merged_idx, void* stream);
+
+/* z_out [R,Ns+2+Ne] = sort(cat(z_samples [R,Ns], near, far, z_vals[:, sel])) and the main-pass points
+ * points[r,i,:] = cam_loc[r] + z_out ray_dirs[r]  (:535-559). */
+int spf_sampler_finish(const float* z_samples, int32_t Ns, const float* z_vals, int32_t n, const int32_t* sel,
+                       int32_t Ne, float near, float far, const float* cam_loc, const float* ray_dirs, int32_t R,
+                       float* z_out, float* points, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-ray compositing — replaces filter_points (spurfies/model/pointneus_disent.py:207-239),
  * LaplaceDensity (spurfies/model/density.py:16-30), volume_rendering (:894-908) and the composites
  * (:765-795), forward and backward.  All arrays are dense [R,SR] (invalid slots masked).

@@ -1,0 +1,316 @@
+// VolSDF error-bounded sampler (K7 of DESIGN.md): one wavefront per ray, every per-ray cumulative sum a
+// wave prefix-sum over a blocked register layout, CDF inversion by binary search in LDS.
+//
+// Replaces the ~150 elementwise / cumsum / gather / sort launches per call of
+//   UniformSampler.get_z_vals        spurfies/model/ray_sampler.py:33-59
+//   ErrorBoundSampler_pn.get_z_vals  spurfies/model/ray_sampler.py:377-574
+//   ErrorBoundSampler_pn.get_error_bound  :576-588
+// The SDF evaluations between the stages (model.sdf_importance, :403) are the kNN + geometry kernels; the
+// random numbers are drawn by the host from the CPU generator exactly as the reference does and handed in.
+#include <cfloat>
+
+#include "common.h"
+
+namespace {
+using namespace spf;
+
+__device__ __forceinline__ float sigma_laplace(float s, float beta) {
+    const float sg = s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f);
+    return (1.f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+}
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wexcl(float v, int lane) {  // exclusive scan of one value per lane
+    float s = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(s, off);
+        if (lane >= off) s += t;
+    }
+    return s - v;
+}
+
+// ---- stage 0: stratified uniform samples + their 3-D points ---------------------------------------
+__global__ void uniform_kernel(const float* __restrict__ tlin, const float* __restrict__ t_rand, const float* __restrict__ cam_loc,
+                               const float* __restrict__ ray_dirs, int R, int n, float near, float far, float* __restrict__ z_out,
+                               float* __restrict__ points) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)R * n) return;
+    const int r = (int)(gid / n), i = (int)(gid % n);
+    auto zl = [&](int k) { return near * (1.0f - tlin[k]) + far * tlin[k]; };
+    float z = zl(i);
+    if (t_rand) {
+        const float up = i + 1 < n ? 0.5f * (zl(i + 1) + z) : z;
+        const float lo = i > 0 ? 0.5f * (z + zl(i - 1)) : z;
+        z = lo + (up - lo) * t_rand[gid];
+    }
+    z_out[gid] = z;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) points[gid * 3 + c] = cam_loc[3 * r + c] + z * ray_dirs[3 * r + c];
+}
+
+// ---- stage 1: d*, beta bisection, weights, pdf/cdf, inverse CDF (+ merge when another iteration follows) ----
+template <int E>
+__global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restrict__ z_in, const float* __restrict__ sdf_in,
+                                                           const float* __restrict__ beta_in, const float* __restrict__ beta0_p, int R, int n,
+                                                           float eps, float bound_coef, int beta_iters, int more, float add_tiny,
+                                                           const float* __restrict__ u, int u_per_ray, int N, float* __restrict__ samples,
+                                                           float* __restrict__ beta_out, float* __restrict__ z_merged,
+                                                           int32_t* __restrict__ merged_idx) {
+    constexpr int NMAX = 64 * E;
+    __shared__ float smem[4 * (3 * NMAX + 128)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    const bool active = r < R;
+    float* zs = smem + wave * (3 * NMAX + 128);
+    float* ds = zs + NMAX;
+    float* cdf = ds + NMAX;
+    float* sm = cdf + NMAX;  // [128] new samples (merge)
+    if (active)
+        for (int k = lane; k < n; k += 64) {
+            zs[k] = z_in[(size_t)r * n + k];
+            ds[k] = sdf_in[(size_t)r * n + k];
+        }
+    __syncthreads();
+    const float beta0 = *beta0_p;
+    float a[E], dst[E], sd[E];
+    float sumsq = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane * E + e;
+        a[e] = 0.f;
+        dst[e] = 0.f;
+        sd[e] = 0.f;
+        if (active && i < n) sd[e] = ds[i];
+        if (active && i < n - 1) {
+            const float d0 = ds[i], d1 = ds[i + 1];
+            const float aa = zs[i + 1] - zs[i], b = fabsf(d0), c = fabsf(d1);
+            a[e] = aa;
+            sumsq += aa * aa;
+            const bool first = aa * aa + b * b <= c * c, second = aa * aa + c * c <= b * b;
+            float v = 0.f;
+            if (!first && !second && (b + c - aa > 0.f)) {
+                const float s = (aa + b + c) / 2.0f;
+                v = (2.0f * sqrtf(s * (s - aa) * (s - b) * (s - c))) / aa;
+            }
+            if (first) v = b;
+            if (second) v = c;
+            const float s0 = d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f), s1 = d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f);
+            dst[e] = (s1 * s0 == 1.f) ? v : 0.f;
+        }
+    }
+    // error bound of ray_sampler.py:576-588 for one beta (uniform over the wave)
+    auto errbound = [&](float beta, float* T_out, float* EI_out) {
+        float ep_inc[E], fe_exc[E];
+        float run_ep = 0.f, run_fe = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            float ep = 0.f, fe = 0.f;
+            if (i < n - 1) {
+                ep = expf(-dst[e] / beta) * (a[e] * a[e]) / (4.f * (beta * beta));
+                fe = a[e] * sigma_laplace(sd[e], beta);
+            }
+            run_ep += ep;
+            ep_inc[e] = run_ep;
+            fe_exc[e] = run_fe;
+            run_fe += fe;
+        }
+        const float off_ep = wexcl(run_ep, lane), off_fe = wexcl(run_fe, lane);
+        float mx = -FLT_MAX;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            const float ei = off_ep + ep_inc[e], tr = expf(-(off_fe + fe_exc[e]));
+            if (T_out) {
+                T_out[e] = tr;
+                EI_out[e] = ei;
+            }
+            if (i < n - 1) mx = fmaxf(mx, (fminf(expf(ei), 1.0e6f) - 1.0f) * tr);
+        }
+        return wmax(mx);
+    };
+    float beta = beta_in ? (active ? beta_in[r] : 1.f) : sqrtf(bound_coef * wsum(sumsq));
+    if (errbound(beta0, nullptr, nullptr) <= eps) beta = beta0;
+    float bmin = beta0, bmax = beta;
+    for (int it = 0; it < beta_iters; ++it) {
+        const float mid = (bmin + bmax) / 2.0f;
+        const float err = errbound(mid, nullptr, nullptr);
+        if (err <= eps) bmax = mid;
+        if (err > eps) bmin = mid;
+    }
+    beta = bmax;
+    if (active && lane == 0) beta_out[r] = beta;
+
+    // ---- pdf over the n-1 intervals with the final beta -------------------------------------------
+    float p[E];
+    if (more) {  // proportional to the current error bound (:470-489)
+        float T[E], EI[E];
+        errbound(beta, T, EI);
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[e] = (lane * E + e < n - 1) ? (fminf(expf(EI[e]), 1.0e6f) - 1.0f) * T[e] + add_tiny : 0.f;
+    } else {     // proportional to the rendering weights (:447-464, 491-503)
+        float fe[E], run = 0.f, ex[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            fe[e] = 0.f;
+            if (i < n) fe[e] = (i < n - 1 ? a[e] : 1e10f) * sigma_laplace(sd[e], beta);
+            ex[e] = run;
+            run += fe[e];
+        }
+        const float off = wexcl(run, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float w = (1.f - expf(-fe[e])) * expf(-(off + ex[e]));
+            p[e] = (lane * E + e < n - 1) ? w + 1e-5f : 0.f;
+        }
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) tot += p[e];
+    tot = wsum(tot);
+    {
+        float run = 0.f, ex[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            p[e] = p[e] / tot;
+            ex[e] = run;
+            run += p[e];
+        }
+        const float off = wexcl(run, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            if (i < n) cdf[i] = off + ex[e];   // cdf[k] = sum_{i<k} pdf_i, cdf[0] = 0
+        }
+    }
+    __syncthreads();
+    // ---- inverse CDF (:517-529) ------------------------------------------------------------------
+    if (active)
+        for (int m = lane; m < N; m += 64) {
+            const float uu = u_per_ray ? u[(size_t)r * N + m] : u[m];
+            int lo = 0, hi = n;
+            while (lo < hi) {           // searchsorted(right=True): number of cdf entries <= uu
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+            }
+            const int below = max(lo - 1, 0), above = min(lo, n - 1);
+            float denom = cdf[above] - cdf[below];
+            if (denom < 1e-5f) denom = 1.f;
+            const float t = (uu - cdf[below]) / denom;
+            const float s = zs[below] + t * (zs[above] - zs[below]);
+            samples[(size_t)r * N + m] = s;
+            if (more) sm[m] = s;
+        }
+    if (more) {  // z_new = sort(cat(z, samples)) as a merge of two sorted lists (:532-533)
+        __syncthreads();
+        if (active) {
+            for (int i = lane; i < n; i += 64) {
+                const float v = zs[i];
+                int lo = 0, hi = N;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (sm[mid] < v) lo = mid + 1; else hi = mid; }
+                z_merged[(size_t)r * (n + N) + i + lo] = v;
+                merged_idx[(size_t)r * (n + N) + i + lo] = i;
+            }
+            for (int m = lane; m < N; m += 64) {
+                const float v = sm[m];
+                int lo = 0, hi = n;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (zs[mid] <= v) lo = mid + 1; else hi = mid; }
+                z_merged[(size_t)r * (n + N) + m + lo] = v;
+                merged_idx[(size_t)r * (n + N) + m + lo] = n + m;
+            }
+        }
+    }
+}
+
+// ---- stage 2: z_final = sort([z_samples | near | far | z_vals[:, sel]]) and the main-pass points (:535-559) ----
+__global__ void __launch_bounds__(256) sampler_finish_kernel(const float* __restrict__ z_samples, int Ns, const float* __restrict__ z_vals,
+                                                             int n, const int32_t* __restrict__ sel, int Ne, float near, float far,
+                                                             const float* __restrict__ cam_loc, const float* __restrict__ ray_dirs, int R,
+                                                             float* __restrict__ z_out, float* __restrict__ points) {
+    __shared__ float smem[4 * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    const bool active = r < R;
+    const int M = Ns + 2 + Ne;
+    float* c = smem + wave * 256;
+    if (active)
+        for (int q = lane; q < M; q += 64) {
+            float v;
+            if (q < Ns) v = z_samples[(size_t)r * Ns + q];
+            else if (q == Ns) v = near;
+            else if (q == Ns + 1) v = far;
+            else v = z_vals[(size_t)r * n + sel[q - Ns - 2]];
+            c[q] = v;
+        }
+    __syncthreads();
+    if (!active) return;
+    for (int q = lane; q < M; q += 64) {
+        const float v = c[q];
+        int rank = 0;
+        for (int pth = 0; pth < M; ++pth) {
+            const float w = c[pth];
+            rank += (w < v) || (w == v && pth < q);
+        }
+        const size_t o = (size_t)r * M + rank;
+        z_out[o] = v;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) points[o * 3 + k] = cam_loc[3 * r + k] + v * ray_dirs[3 * r + k];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int spf_sampler_uniform(const float* tlin, const float* t_rand, const float* cam_loc, const float* ray_dirs, int32_t R, int32_t n,
+                        float near, float far, float* z, float* points, void* stream) {
+    if (R < 0 || n < 1) return spf::fail(SPF_EINVAL, "spf_sampler_uniform: bad sizes");
+    if (R == 0) return SPF_OK;
+    if (!tlin || !cam_loc || !ray_dirs || !z || !points) return spf::fail(SPF_EINVAL, "spf_sampler_uniform: null pointer");
+    uniform_kernel<<<spf::div_up((long long)R * n, 256), 256, 0, (hipStream_t)stream>>>(tlin, t_rand, cam_loc, ray_dirs, R, n, near, far, z, points);
+    SPF_LAUNCH_CHECK("uniform_kernel");
+    return SPF_OK;
+}
+
+int spf_sampler_iter(const float* z, const float* sdf, const float* beta_in, const float* beta0, int32_t R, int32_t n, float eps,
+                     float bound_coef, int32_t beta_iters, int32_t more, float add_tiny, const float* u, int32_t u_per_ray, int32_t N,
+                     float* samples, float* beta_out, float* z_merged, int32_t* merged_idx, void* stream) {
+    if (R < 0 || n < 2 || n > 640 || N < 0 || (more && (N < 1 || N > 128))) return spf::fail(SPF_EINVAL, "spf_sampler_iter: need 2<=n<=640, N>=0 (1..128 when merging)");
+    if (R == 0) return SPF_OK;
+    if (!z || !sdf || !beta0 || !beta_out || (N > 0 && (!u || !samples)) || (more && (!z_merged || !merged_idx)))
+        return spf::fail(SPF_EINVAL, "spf_sampler_iter: null pointer");
+    const int blocks = spf::div_up(R, 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 128)
+        sampler_iter_kernel<2><<<blocks, 256, 0, s>>>(z, sdf, beta_in, beta0, R, n, eps, bound_coef, beta_iters, more, add_tiny, u, u_per_ray, N,
+                                                       samples, beta_out, z_merged, merged_idx);
+    else
+        sampler_iter_kernel<10><<<blocks, 256, 0, s>>>(z, sdf, beta_in, beta0, R, n, eps, bound_coef, beta_iters, more, add_tiny, u, u_per_ray, N,
+                                                        samples, beta_out, z_merged, merged_idx);
+    SPF_LAUNCH_CHECK("sampler_iter_kernel");
+    return SPF_OK;
+}
+
+int spf_sampler_finish(const float* z_samples, int32_t Ns, const float* z_vals, int32_t n, const int32_t* sel, int32_t Ne, float near,
+                       float far, const float* cam_loc, const float* ray_dirs, int32_t R, float* z_out, float* points, void* stream) {
+    if (R < 0 || Ns < 0 || Ne < 0 || Ns + 2 + Ne > 256) return spf::fail(SPF_EINVAL, "spf_sampler_finish: need Ns + 2 + Ne <= 256");
+    if (R == 0) return SPF_OK;
+    if (!z_samples || !z_vals || (Ne > 0 && !sel) || !cam_loc || !ray_dirs || !z_out || !points)
+        return spf::fail(SPF_EINVAL, "spf_sampler_finish: null pointer");
+    sampler_finish_kernel<<<spf::div_up(R, 4), 256, 0, (hipStream_t)stream>>>(z_samples, Ns, z_vals, n, sel, Ne, near, far, cam_loc, ray_dirs, R,
+                                                                              z_out, points);
+    SPF_LAUNCH_CHECK("sampler_finish_kernel");
+    return SPF_OK;
+}
+
+}  // extern "C"

@@ -170,7 +170,7 @@ class PointVolSDF(nn.Module):
         ray_dirs = ray_dirs.reshape(-1, 3)
         cam_loc = cam_loc.unsqueeze(1).repeat(1, ray_dirs.shape[0], 1).reshape(-1, 3)
         z_vals, _ = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, model, fast, iter_step)
-        points = cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)
+        points = self.ray_sampler.last_points                     # o + z d, written by the sampler's finish kernel
         return points, z_vals, cam_loc, ray_dirs
 
     def volume_rendering(self, deltas, density):

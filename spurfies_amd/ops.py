@@ -230,11 +230,21 @@ class ColorAgg(torch.autograd.Function):
                                                      _lib.ptr(packed), _lib.ptr(act1), _lib.ptr(act2), _lib.ptr(act3),
                                                      *[_lib.ptr(g) for g in G], _lib.ptr(g_feat), _lib.stream_ptr()), "spf_color_backward")
         G1, G2, G3, G4 = G
-        dw0_int = G1.t() @ act0                                    # [256,104] in the kernels' internal column order
+        dw0_int = _wgrad(G1, act0)                                 # [256,104] in the kernels' internal column order
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
         dw0[:, _color_col_perm(dev)] = dw0_int[:, :103]
-        grads = (g_feat, dw0, G1.sum(0), G2.t() @ act1, G2.sum(0), G3.t() @ act2, G3.sum(0), G4.t() @ act3, G4.sum(0))
+        grads = (g_feat, dw0, G1.sum(0), _wgrad(G2, act1), G2.sum(0), _wgrad(G3, act2), G3.sum(0), _wgrad(G4, act3), G4.sum(0))
         return grads + (None,) * 7
+
+
+def _wgrad(G, A, split=32):
+    """dW = G^T A for [rows,256] x [rows,C] with rows ~ 4e5: a K-huge, tiny-MN GEMM.  A single library GEMM fills
+    only a few workgroups; batching over `split` row blocks (rows is a multiple of 64) fills the chip
+    (measured 0.43 ms vs 1.06 ms on MI355X, tools/wgrad_bench.py)."""
+    rows = G.shape[0]
+    if rows % split or rows < 64 * split:
+        return G.t() @ A
+    return torch.bmm(G.view(split, rows // split, G.shape[1]).transpose(1, 2), A.view(split, rows // split, A.shape[1])).sum(0)
 
 
 # ---- per-ray compositing --------------------------------------------------------------------------
@@ -297,3 +307,45 @@ class Render(torch.autograd.Function):
                                                       _lib.ptr(g_dist), R, SR, _lib.ptr(g_sdf), _lib.ptr(g_col), _lib.ptr(g_beta),
                                                       _lib.stream_ptr()), "spf_render_backward")
         return g_sdf, g_col, g_beta.reshape(()), None, None, None
+
+
+# ---- sampler stages ---------------------------------------------------------------------------------
+def sampler_uniform(tlin, t_rand, cam_loc, ray_dirs, near, far):
+    R, n = cam_loc.shape[0], tlin.shape[0]
+    dev = cam_loc.device
+    z = torch.empty((R, n), dtype=torch.float32, device=dev)
+    pts = torch.empty((R, n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_sampler_uniform(_lib.ptr(tlin), _lib.ptr(t_rand), _lib.ptr(cam_loc), _lib.ptr(ray_dirs), R, n, float(near),
+                                                  float(far), _lib.ptr(z), _lib.ptr(pts), _lib.stream_ptr()), "spf_sampler_uniform")
+    return z, pts
+
+
+def sampler_iter(z, sdf, beta_in, beta0, eps, bound_coef, beta_iters, more, add_tiny, u, N):
+    """-> (samples [R,N] | None, beta [R], z_merged [R,n+N] | None, merged_idx [R,n+N] | None)."""
+    R, n = z.shape
+    dev = z.device
+    samples = torch.empty((R, N), dtype=torch.float32, device=dev) if N > 0 else None
+    beta = torch.empty((R,), dtype=torch.float32, device=dev)
+    zm = torch.empty((R, n + N), dtype=torch.float32, device=dev) if more else None
+    mi = torch.empty((R, n + N), dtype=torch.int32, device=dev) if more else None
+    per_ray = 1 if (u is not None and u.dim() == 2) else 0
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_sampler_iter(_lib.ptr(z), _lib.ptr(sdf), _lib.ptr(beta_in), _lib.ptr(beta0), R, n, float(eps), float(bound_coef),
+                                               int(beta_iters), int(bool(more)), float(add_tiny), _lib.ptr(u), per_ray, N, _lib.ptr(samples),
+                                               _lib.ptr(beta), _lib.ptr(zm), _lib.ptr(mi), _lib.stream_ptr()), "spf_sampler_iter")
+    return samples, beta, zm, mi
+
+
+def sampler_finish(z_samples, z_vals, sel, near, far, cam_loc, ray_dirs):
+    R, Ns = z_samples.shape
+    n, Ne = z_vals.shape[1], (0 if sel is None else sel.shape[0])
+    dev = z_samples.device
+    M = Ns + 2 + Ne
+    z_out = torch.empty((R, M), dtype=torch.float32, device=dev)
+    pts = torch.empty((R, M, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_sampler_finish(_lib.ptr(z_samples), Ns, _lib.ptr(z_vals), n, _lib.ptr(sel), Ne, float(near), float(far),
+                                                 _lib.ptr(cam_loc), _lib.ptr(ray_dirs), R, _lib.ptr(z_out), _lib.ptr(pts), _lib.stream_ptr()),
+                   "spf_sampler_finish")
+    return z_out, pts
