@@ -23,11 +23,15 @@ __device__ __forceinline__ float wsum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
+// torch.max propagates NaN (rays that miss everything carry NaN samples in the reference too); fmaxf would drop it
+__device__ __forceinline__ float nanmax(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
 __device__ __forceinline__ float wmax(float v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    for (int off = 32; off > 0; off >>= 1) v = nanmax(v, __shfl_xor(v, off));
     return v;
 }
+// ordering key: NaN sorts last, as torch.sort does
+__device__ __forceinline__ float okey(float v) { return v != v ? __builtin_inff() : v; }
 __device__ __forceinline__ float wexcl(float v, int lane) {  // exclusive scan of one value per lane
     float s = v;
 #pragma unroll
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
                 T_out[e] = tr;
                 EI_out[e] = ei;
             }
-            if (i < n - 1) mx = fmaxf(mx, (fminf(expf(ei), 1.0e6f) - 1.0f) * tr);
+            if (i < n - 1) mx = nanmax(mx, (fminf(expf(ei), 1.0e6f) - 1.0f) * tr);
         }
         return wmax(mx);
     };
@@ -215,16 +219,16 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
         __syncthreads();
         if (active) {
             for (int i = lane; i < n; i += 64) {
-                const float v = zs[i];
+                const float v = zs[i], kv = okey(v);
                 int lo = 0, hi = N;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (sm[mid] < v) lo = mid + 1; else hi = mid; }
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (okey(sm[mid]) < kv) lo = mid + 1; else hi = mid; }
                 z_merged[(size_t)r * (n + N) + i + lo] = v;
                 merged_idx[(size_t)r * (n + N) + i + lo] = i;
             }
             for (int m = lane; m < N; m += 64) {
-                const float v = sm[m];
+                const float v = sm[m], kv = okey(v);
                 int lo = 0, hi = n;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (zs[mid] <= v) lo = mid + 1; else hi = mid; }
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (okey(zs[mid]) <= kv) lo = mid + 1; else hi = mid; }
                 z_merged[(size_t)r * (n + N) + m + lo] = v;
                 merged_idx[(size_t)r * (n + N) + m + lo] = n + m;
             }
@@ -255,11 +259,11 @@ __global__ void __launch_bounds__(256) sampler_finish_kernel(const float* __rest
     __syncthreads();
     if (!active) return;
     for (int q = lane; q < M; q += 64) {
-        const float v = c[q];
+        const float v = c[q], kv = okey(v);
         int rank = 0;
         for (int pth = 0; pth < M; ++pth) {
-            const float w = c[pth];
-            rank += (w < v) || (w == v && pth < q);
+            const float w = okey(c[pth]);
+            rank += (w < kv) || (w == kv && pth < q);
         }
         const size_t o = (size_t)r * M + rank;
         z_out[o] = v;

@@ -56,6 +56,7 @@ def test_sampler_matches_oracle(training, fast):
     g = torch.Generator().manual_seed(3)
     cam = torch.tensor([2.0, 0.2, 0.1]).repeat(R, 1)
     tgt = torch.randn((R, 3), generator=g) * 0.35
+    tgt[:6] = torch.tensor([0.0, 0.0, 9.0])     # rays that miss everything: NaN samples in eval, as in the reference
     dirs = torch.nn.functional.normalize(tgt - cam, dim=-1)
     draws = {}
     torch.manual_seed(11)
@@ -66,8 +67,9 @@ def test_sampler_matches_oracle(training, fast):
     z_g, _ = sampler.get_z_vals(dirs.cuda(), cam.cuda(), _FakeModel(training), fast=fast)
     assert sampler.last_iters == trace["iters"]
     zg = z_g.cpu().numpy()
-    assert zg.shape == (R, 98) and (np.diff(zg, axis=1) >= 0).all()
+    assert zg.shape == (R, 98) and (np.diff(zg[6:], axis=1) >= 0).all()
     # a ray whose bisection lands within rounding of eps may pick the neighbouring beta: compare per ray
-    close = np.isclose(zg, z_o.numpy(), rtol=2e-4, atol=2e-4).all(axis=1)
+    close = np.isclose(zg, z_o.numpy(), rtol=2e-4, atol=2e-4, equal_nan=True).all(axis=1)
     assert close.mean() > 0.97, f"only {close.mean():.3f} of the rays agree"
-    np.testing.assert_allclose(sampler.last_points.cpu().numpy(), (cam[:, None] + z_g.cpu()[..., None] * dirs[:, None]).numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sampler.last_points.cpu().numpy(), (cam[:, None] + z_g.cpu()[..., None] * dirs[:, None]).numpy(), rtol=1e-6, atol=1e-6,
+                               equal_nan=True)
