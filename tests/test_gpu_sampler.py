@@ -67,7 +67,9 @@ def test_sampler_matches_oracle(training, fast):
     z_g, _ = sampler.get_z_vals(dirs.cuda(), cam.cuda(), _FakeModel(training), fast=fast)
     assert sampler.last_iters == trace["iters"]
     zg = z_g.cpu().numpy()
-    assert zg.shape == (R, 98) and (np.diff(zg[6:], axis=1) >= 0).all()
+    finite = np.isfinite(zg).all(axis=1)      # rays that never enter the SDF shell carry NaN samples in eval (reference too)
+    assert zg.shape == (R, 98) and (np.diff(zg[finite], axis=1) >= 0).all() and finite.mean() > 0.3
+    assert np.array_equal(finite, np.isfinite(z_o.numpy()).all(axis=1))
     # a ray whose bisection lands within rounding of eps may pick the neighbouring beta: compare per ray
     close = np.isclose(zg, z_o.numpy(), rtol=2e-4, atol=2e-4, equal_nan=True).all(axis=1)
     assert close.mean() > 0.97, f"only {close.mean():.3f} of the rays agree"
