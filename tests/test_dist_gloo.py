@@ -1,0 +1,106 @@
+"""CPU, world_size 2 over gloo: ray sharding + count-normalised losses + one flat-buffer all-reduce
+reproduce the single-process batch loss and gradients exactly."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from spurfies_amd import dist as sdist
+from spurfies_amd.model.loss import VolSDFLoss
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _loss_mod():
+    return VolSDFLoss("torch.nn.L1Loss", local_weight=0.5, pseudo_weight=0.5, eikonal_weight=0.001, rgb_weight=1.0, tv_weight=0.01)
+
+
+def _toy_params():
+    g = torch.Generator().manual_seed(0)
+    return [torch.randn((6, 3), generator=g).requires_grad_(True), torch.randn((6, 5), generator=g).requires_grad_(True),
+            torch.randn((4,), generator=g).requires_grad_(True)]
+
+
+def _toy_forward(params, feats, n_pts_per_ray):
+    """A differentiable stand-in for PointVolSDF.forward with the same output keys and data-dependent counts."""
+    a, b, c = params
+    rgb = torch.sigmoid(feats @ a)
+    weights = torch.softmax(feats @ b, -1) * 0.9
+    g = (feats.repeat_interleave(n_pts_per_ray, 0)[:, :3] * c[:3]) + c[3]
+    valid = feats[:, 0] > 0
+    sd = (feats @ a).sum(-1)
+    return {"rgb_values": rgb, "weights": weights, "grad_theta": g, "tv_loss": (c ** 2).sum(), "local_loss": torch.tensor(0.0),
+            "pseudo_sum": torch.where(valid, sd.abs(), torch.zeros_like(sd)).sum(), "pseudo_count": valid.sum(),
+            "pseudo_pts_loss": torch.where(valid, sd.abs(), torch.zeros_like(sd)).sum() / valid.sum().clamp(min=1)}
+
+
+def _data(R=64):
+    g = torch.Generator().manual_seed(1)
+    feats = torch.randn((R, 6), generator=g)
+    n_pts = torch.randint(1, 5, (R,), generator=g)
+    rgb_gt = torch.rand((R, 3), generator=g)
+    mask = (torch.rand((R,), generator=g) > 0.3).float()
+    return feats, n_pts, rgb_gt, mask
+
+
+def _worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params = _toy_params()
+        flat = sdist.FlatGrads(params)
+        feats, n_pts, rgb_gt, mask = _data()
+        sel = sdist.shard_rays(feats.shape[0])
+        assert sel.tolist() == list(range(rank, feats.shape[0], world))
+        out = _toy_forward(params, feats[sel], n_pts[sel])
+        gt = {"rgb": rgb_gt[sel][None], "mask": mask[sel][None, :, None].repeat(1, 1, 3)}
+        losses = sdist.sharded_loss(_loss_mod(), out, gt)
+        flat.zero_()
+        losses["loss"].backward()
+        total = losses["loss"].detach().clone()
+        sdist.all_reduce_sum(total)
+        sdist.all_reduce_sum(flat.buffer)
+        out_q.put((rank, total.item(), flat.buffer.clone().numpy(), [p.grad.data_ptr() == flat.buffer.data_ptr() + 4 * o for p, o in
+                                                                      zip(params, np.cumsum([0] + [p.numel() for p in params[:-1]]))]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, whole batch, the reference's own loss normalisation
+    params = _toy_params()
+    feats, n_pts, rgb_gt, mask = _data()
+    out = _toy_forward(params, feats, n_pts)
+    losses = _loss_mod()(out, {"rgb": rgb_gt[None], "mask": mask[None, :, None].repeat(1, 1, 3)})
+    losses["loss"].backward()
+    want = np.concatenate([p.grad.reshape(-1).numpy() for p in params])
+    for rank, total, buf, views_ok in res:
+        assert all(views_ok), "every parameter's .grad must be a view into the flat buffer"
+        np.testing.assert_allclose(total, losses["loss"].item(), rtol=1e-6)
+        np.testing.assert_allclose(buf, want, rtol=2e-5, atol=1e-7)
+
+
+def test_single_process_helpers():
+    assert sdist.world_size() == 1 and sdist.rank() == 0
+    assert sdist.shard_rays(5).tolist() == [0, 1, 2, 3, 4]
+    t = torch.ones(3)
+    assert sdist.all_reduce_sum(t) is t
