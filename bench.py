@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (config/ours.yaml:14 num_pixels)")
     ap.add_argument("--points", type=int, default=10000, help="neural points (DTU-like cloud)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=256)
+    ap.add_argument("--cpu-rays", type=int, default=1024)
     return ap.parse_args()
 
 
@@ -136,12 +136,20 @@ def main():
     # dominant kernel: geo_forward_kernel<true> of the main pass (the largest with-Jacobian launch per step)
     main = [p for p in prof if p["with_grad"] and p["rows"] >= args.rays * 2]
     roof = None
+    traffic = None   # HBM bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process)
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec["config"] == {"points": args.points, "rays": args.rays}:
+            hit = [v for k, v in rec["kernels"].items() if "geo_forward_kernel<true>" in k]
+            traffic = hit[0]["hbm_bytes_max_corrected"] if hit else None
     if main:
         ms = sum(p["ms"] for p in main)
         pairs = sum(p["pairs"] for p in main)
         ach = pairs * (F_FWD + F_JAC) / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None, "kernel": "geo_forward_kernel<true>", "launches": len(main), "avg_ms": ms / len(main),
+                "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                if traffic else None, "kernel": "geo_forward_kernel<true>", "launches": len(main), "avg_ms": ms / len(main),
                 "pairs_per_launch": pairs / len(main)}
     res = {
         "metric": "ray-samples/sec (kNN+SDF+render, train step)", "value": SAMPLES_PER_RAY * rays_total * args.steps / dt,
