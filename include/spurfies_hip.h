@@ -153,21 +153,26 @@ int spf_color_pack(const float* w0, const float* b0, const float* w2, const floa
 
 /* agg[p, 256] = sum_j wn[row,j] * F_color([posenc6(x[row] - pts[nbr[row,j]]) | feat_color[nbr[row,j]]])
  * for the p-th valid point (row = point_slot[p], or p when point_slot is NULL); wn comes from
- * spf_geo_forward.  Training mode (act0 != NULL) also stores every layer's input in compact tile order
- * (row t = 8p + j): act0 [T,104] in the kernel's internal column order [latent 64 | posenc 39 | 0],
- * act1..act3 [T,256]; T = 64 * ceil(P/8). */
+ * spf_geo_forward.  Training mode (act0 != NULL) also writes, in compact tile order (row t = 8p + j,
+ * T = 64 * ceil(P/8) rows):
+ *   act0 [T,104]   layer-1 input in the kernel's internal column order [latent 64 | posenc 39 | 0]
+ *   act1, act2 [T,256]  inputs of layers 2 and 3 (operands of their weight-gradient GEMMs)
+ *   agg3 [P8,256]  sum_j wn_j a3_j, the RBF-weighted mean of the last hidden activation (P8 = 8*ceil(P/8)):
+ *                  the last layer is linear, so its weight gradient is g_agg^T agg3 (K = P, not 8P)
+ *   masks [T/64, 3, 512] uint32  LeakyReLU sign bits of layers 1..3 in accumulator order */
 int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot,
                       const int32_t* n_points, int32_t max_points, int32_t k, const float* pts,
                       const float* feat_color, const float* packed, float* agg, float* act0, float* act1,
-                      float* act2, float* act3, void* stream);
+                      float* act2, float* agg3, uint32_t* masks, void* stream);
 
-/* Data-gradient chain for g_agg[p,256] = dL/d agg: writes the pre-activation gradients G1..G4 [T,256]
- * (weight gradients are then dW_l = G_l^T act_{l-1}, plain GEMMs) and accumulates the colour-latent
- * gradient into g_feat_color[N,64] (float atomics). */
+/* Data-gradient chain for g_agg[p,256] = dL/d agg: writes the pre-activation gradients G1..G3 [T,256]
+ * (weight gradients of layers 1..3 are then dW_l = G_l^T act_{l-1}, plain GEMMs), adds their column sums
+ * to g_bias [3,256] (bias gradients of layers 1..3) and accumulates the colour-latent gradient into
+ * g_feat_color[N,64] (float atomics). */
 int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot,
                        const int32_t* n_points, int32_t max_points, int32_t k, const float* packed,
-                       const float* act1, const float* act2, const float* act3, float* G1, float* G2,
-                       float* G3, float* G4, float* g_feat_color, void* stream);
+                       const uint32_t* masks, float* G1, float* G2, float* G3, float* g_bias,
+                       float* g_feat_color, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * VolSDF error-bounded sampler — replaces UniformSampler.get_z_vals (spurfies/model/ray_sampler.py:33-59),

@@ -90,24 +90,51 @@ __global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
     out[e] = val;
 }
 
-// epilogue of a hidden layer: + bias, LeakyReLU, write to X, optionally store the activation
+// epilogue of a hidden layer: + bias, LeakyReLU, write to X.  Training mode also records the sign bits
+// (one uint32 per lane and row half: bit n*16+r, the same lane/register position the backward kernel's
+// accumulators have), optionally streams the activation to HBM (input of the next layer's wgrad GEMM) and
+// optionally reduces it over each point's 8 rows with the RBF weights (agg3, see spf_color_backward).
 template <bool STORE>
 __device__ __forceinline__ void c_fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave, int lane,
-                                               float* act_g /* tile base [64][256] */) {
+                                               float* act_g /* tile base [64][256] or null */, uint32_t* mask_g /* [4][2][64] or null */,
+                                               const float* s_w, float* agg_g /* [8][256] tile base or null */, int pts_left) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
     const float bv[2] = {bias[c0], bias[c0 + 32]};
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+        uint32_t bits = 0u;
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int g = 0; g < 4; ++g) {
+            float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[m][n][r] + bv[n];
-                v = v > 0.f ? v : v * 0.01f;
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * g + u;
                 const int row = m * 32 + row_of(r, h);
-                X[row * LDA + c0 + 32 * n] = v;
-                if (STORE) act_g[row * 256 + c0 + 32 * n] = v;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    float v = acc[m][n][r] + bv[n];
+                    const bool pos = v > 0.f;
+                    bits |= (pos ? 1u : 0u) << (n * 16 + r);
+                    v = pos ? v : v * 0.01f;
+                    X[row * LDA + c0 + 32 * n] = v;
+                    if (STORE && act_g) act_g[row * 256 + c0 + 32 * n] = v;
+                    if (STORE && agg_g) {
+                        const float w = s_w[(g + 4 * m) * 8 + u + 4 * h];
+                        if (n == 0) s0 += w * v; else s1 += w * v;
+                    }
+                }
             }
+            if (STORE && agg_g) {
+                s0 += __shfl_xor(s0, 32);
+                s1 += __shfl_xor(s1, 32);
+                if (h == 0 && g + 4 * m < pts_left) {
+                    agg_g[(g + 4 * m) * 256 + c0] = s0;
+                    agg_g[(g + 4 * m) * 256 + c0 + 32] = s1;
+                }
+            }
+        }
+        if (STORE && mask_g) mask_g[(wave * 2 + m) * 64 + lane] = bits;
+    }
 }
 
 template <bool STORE>
@@ -116,7 +143,7 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
                      const int32_t* __restrict__ point_slot, const int32_t* __restrict__ n_points_dev, int max_points, int k,
                      const float* __restrict__ pts, const float* __restrict__ feat_col, const float* packed,
                      float* __restrict__ agg, float* __restrict__ act0, float* __restrict__ act1, float* __restrict__ act2,
-                     float* __restrict__ act3) {
+                     float* __restrict__ agg3, uint32_t* __restrict__ masks) {
     __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL];
     float* X = smem + CL_X;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -188,17 +215,21 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         zero_acc(acc);
         gemm_rows64<T_CIN>(X, pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128), lane, acc);
         __syncthreads();
-        c_fwd_epilogue<STORE>(X, acc, packed + CO_B1, wave, lane, STORE ? act1 + (size_t)tile * 64 * 256 : nullptr);
+        const int pts_left = P - tile * SPF_TILE_PTS;
+        uint32_t* mk = STORE ? masks + (size_t)tile * 3 * 512 : nullptr;   // [layer 3][wave 4][m 2][lane 64]
+        c_fwd_epilogue<STORE>(X, acc, packed + CO_B1, wave, lane, STORE ? act1 + (size_t)tile * 64 * 256 : nullptr, mk, smem + CL_W, nullptr, pts_left);
         __syncthreads();
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_FW2 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_fwd_epilogue<STORE>(X, acc, packed + CO_B2, wave, lane, STORE ? act2 + (size_t)tile * 64 * 256 : nullptr);
+        c_fwd_epilogue<STORE>(X, acc, packed + CO_B2, wave, lane, STORE ? act2 + (size_t)tile * 64 * 256 : nullptr, STORE ? mk + 512 : nullptr,
+                              smem + CL_W, nullptr, pts_left);
         __syncthreads();
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_FW3 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_fwd_epilogue<STORE>(X, acc, packed + CO_B3, wave, lane, STORE ? act3 + (size_t)tile * 64 * 256 : nullptr);
+        c_fwd_epilogue<STORE>(X, acc, packed + CO_B3, wave, lane, nullptr, STORE ? mk + 1024 : nullptr, smem + CL_W,
+                              STORE ? agg3 + (size_t)tile * SPF_TILE_PTS * 256 : nullptr, pts_left);
         __syncthreads();
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_FW4 / 4) + wave * (T_HID * 128), lane, acc);
@@ -231,31 +262,40 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
     }
 }
 
-// backward epilogue: G_l = g_a * lrelu'(h_l), sign read from the stored activation; write X and G_l
+// backward epilogue: G_l = g_a * lrelu'(h_l) with the sign bits the forward recorded; write X and G_l (operand of the
+// wgrad GEMM) and add this tile's column sums to the bias gradient (256 floats per layer per tile, 128-B atomics)
 __device__ __forceinline__ void c_bwd_epilogue(float* X, const f32x16 (&acc)[2][2], int wave, int lane,
-                                               const float* __restrict__ act_g, float* __restrict__ g_out) {
+                                               const uint32_t* __restrict__ mask_g, float* __restrict__ g_out,
+                                               float* __restrict__ g_bias) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+    float cs[2] = {0.f, 0.f};
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+        const uint32_t bits = mask_g[(wave * 2 + m) * 64 + lane];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m * 32 + row_of(r, h);
-                const float a = act_g[row * 256 + c0 + 32 * n];
                 float v = acc[m][n][r];
-                v = a > 0.f ? v : v * 0.01f;
+                v = ((bits >> (n * 16 + r)) & 1u) ? v : v * 0.01f;
                 X[row * LDA + c0 + 32 * n] = v;
                 g_out[row * 256 + c0 + 32 * n] = v;
+                cs[n] += v;
             }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const float t = cs[n] + __shfl_xor(cs[n], 32);
+        if (h == 0) atomicAdd(&g_bias[c0 + 32 * n], t);
+    }
 }
 
 __global__ void __launch_bounds__(256, 2)
 color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
                       const int32_t* __restrict__ point_slot, const int32_t* __restrict__ n_points_dev, int max_points, int k,
-                      const float* packed, const float* __restrict__ act1, const float* __restrict__ act2,
-                      const float* __restrict__ act3, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3,
-                      float* __restrict__ G4, float* __restrict__ g_feat_col) {
+                      const float* packed, const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2,
+                      float* __restrict__ G3, float* __restrict__ g_bias /* [3][256]: layers 1..3 */, float* __restrict__ g_feat_col) {
     __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL];
     float* X = smem + CL_X;
     int* s_idx = reinterpret_cast<int*>(smem + CL_W);
@@ -289,7 +329,6 @@ color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict
                     v[0] *= w; v[1] *= w; v[2] *= w; v[3] *= w;
                 }
                 *reinterpret_cast<f32x4*>(X + row * LDA + 4 * c4) = v;
-                *reinterpret_cast<f32x4*>(G4 + tbase + row * 256 + 4 * c4) = v;
             }
         }
         __syncthreads();
@@ -297,17 +336,18 @@ color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_BW4 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, act3 + tbase, G3 + tbase);
+        const uint32_t* mk = masks + (size_t)tile * 3 * 512;
+        c_bwd_epilogue(X, acc, wave, lane, mk + 1024, G3 + tbase, g_bias + 512);
         __syncthreads();
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_BW3 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, act2 + tbase, G2 + tbase);
+        c_bwd_epilogue(X, acc, wave, lane, mk + 512, G2 + tbase, g_bias + 256);
         __syncthreads();
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_BW2 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, act1 + tbase, G1 + tbase);
+        c_bwd_epilogue(X, acc, wave, lane, mk, G1 + tbase, g_bias);
         __syncthreads();
         // ---- d/d latent = G1 * W0[:, 39:103]; wave = (row half mt, latent half nt); scatter-add ------
         {
@@ -352,35 +392,35 @@ int spf_color_pack(const float* w0, const float* b0, const float* w2, const floa
 
 int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* n_points,
                       int32_t max_points, int32_t k, const float* pts, const float* feat_color, const float* packed, float* agg,
-                      float* act0, float* act1, float* act2, float* act3, void* stream) {
+                      float* act0, float* act1, float* act2, float* agg3, uint32_t* masks, void* stream) {
     if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_forward: bad sizes");
     if (max_points == 0) return SPF_OK;
     if (!x || !nbr || !wn || !pts || !feat_color || !packed || !agg) return spf::fail(SPF_EINVAL, "spf_color_forward: null pointer");
     const bool store = act0 != nullptr;
-    if (store && (!act1 || !act2 || !act3)) return spf::fail(SPF_EINVAL, "spf_color_forward: act0..act3 must be given together");
+    if (store && (!act1 || !act2 || !agg3 || !masks)) return spf::fail(SPF_EINVAL, "spf_color_forward: training buffers must be given together");
     const int tiles = spf::div_up(max_points, SPF_TILE_PTS);
     const int blocks = tiles < 512 ? tiles : 512;
     if (store)
         color_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, n_points, max_points, k, pts,
-                                                                            feat_color, packed, agg, act0, act1, act2, act3);
+                                                                            feat_color, packed, agg, act0, act1, act2, agg3, masks);
     else
         color_forward_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, n_points, max_points, k, pts,
-                                                                             feat_color, packed, agg, nullptr, nullptr, nullptr, nullptr);
+                                                                             feat_color, packed, agg, nullptr, nullptr, nullptr, nullptr, nullptr);
     SPF_LAUNCH_CHECK("color_forward_kernel");
     return SPF_OK;
 }
 
 int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* n_points,
-                       int32_t max_points, int32_t k, const float* packed, const float* act1, const float* act2, const float* act3,
-                       float* G1, float* G2, float* G3, float* G4, float* g_feat_color, void* stream) {
+                       int32_t max_points, int32_t k, const float* packed, const uint32_t* masks, float* G1, float* G2, float* G3,
+                       float* g_bias, float* g_feat_color, void* stream) {
     if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_backward: bad sizes");
     if (max_points == 0) return SPF_OK;
-    if (!g_agg || !nbr || !wn || !packed || !act1 || !act2 || !act3 || !G1 || !G2 || !G3 || !G4 || !g_feat_color)
+    if (!g_agg || !nbr || !wn || !packed || !masks || !G1 || !G2 || !G3 || !g_bias || !g_feat_color)
         return spf::fail(SPF_EINVAL, "spf_color_backward: null pointer");
     const int tiles = spf::div_up(max_points, SPF_TILE_PTS);
     const int blocks = tiles < 512 ? tiles : 512;
-    color_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_agg, nbr, wn, point_slot, n_points, max_points, k, packed, act1,
-                                                                   act2, act3, G1, G2, G3, G4, g_feat_color);
+    color_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_agg, nbr, wn, point_slot, n_points, max_points, k, packed, masks, G1, G2,
+                                                                   G3, g_bias, g_feat_color);
     SPF_LAUNCH_CHECK("color_backward_kernel");
     return SPF_OK;
 }

@@ -313,39 +313,75 @@ __global__ void ray_valid_kernel(const uint8_t* __restrict__ slot_valid, int R, 
     ray_valid[r] = any;
 }
 
-// ---- compaction of valid points (single block; R per-ray counts -> exclusive scan -> lists) ----
-__global__ void __launch_bounds__(1024) compact_kernel(const uint8_t* __restrict__ slot_valid, int R, int SR,
-                                                       int32_t* __restrict__ point_slot, int32_t* __restrict__ slot_point,
-                                                       int32_t* __restrict__ n_points) {
-    __shared__ int32_t wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int chunk = (R + 1023) / 1024;
-    const int r0 = min(tid * chunk, R), r1 = min(r0 + chunk, R);
-    int cnt = 0;
-    for (size_t i = (size_t)r0 * SR; i < (size_t)r1 * SR; ++i) cnt += slot_valid[i];
-    int s = cnt;
+// ---- compaction of valid points: ordered (ray-major) lists without a host round trip ------------------
+// Two launches over chunks of 2048 slots (8 consecutive slots per thread): per-chunk counts, then every
+// chunk sums the counts before it (<= a few hundred values) and writes its slice.
+constexpr int CMP_PER_THREAD = 8;
+constexpr int CMP_CHUNK = 256 * CMP_PER_THREAD;
+
+__device__ __forceinline__ int block_excl_scan_256(int v, int& total, int32_t* wsum /* [4] */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int s = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(s, off);
+        const int t = __shfl_up(s, off);
         if (lane >= off) s += t;
     }
     if (lane == 63) wsum[wid] = s;
     __syncthreads();
-    int woff = 0, total = 0;
-    for (int w = 0; w < 16; ++w) {
+    int woff = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
         if (w < wid) woff += wsum[w];
         total += wsum[w];
     }
-    int p = woff + s - cnt;
-    for (size_t i = (size_t)r0 * SR; i < (size_t)r1 * SR; ++i) {
-        if (slot_valid[i]) {
-            point_slot[p] = (int32_t)i;
-            slot_point[i] = p++;
-        } else {
-            slot_point[i] = -1;
-        }
+    return woff + s - v;
+}
+
+__global__ void __launch_bounds__(256) compact_count_kernel(const uint8_t* __restrict__ slot_valid, long long nslot,
+                                                            int32_t* __restrict__ chunk_counts) {
+    __shared__ int32_t wsum[4];
+    const long long base = (long long)blockIdx.x * CMP_CHUNK + (long long)threadIdx.x * CMP_PER_THREAD;
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u)
+        if (base + u < nslot) cnt += slot_valid[base + u] != 0;
+    int total;
+    block_excl_scan_256(cnt, total, wsum);
+    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) compact_write_kernel(const uint8_t* __restrict__ slot_valid, long long nslot,
+                                                            const int32_t* __restrict__ chunk_counts, int32_t* __restrict__ point_slot,
+                                                            int32_t* __restrict__ slot_point, int32_t* __restrict__ n_points) {
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t wsum2[4];
+    int before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += chunk_counts[b];
+    int chunk_base;
+    block_excl_scan_256(before, chunk_base, wsum2);   // total over the block = sum of all earlier chunks
+    const long long base = (long long)blockIdx.x * CMP_CHUNK + (long long)threadIdx.x * CMP_PER_THREAD;
+    int cnt = 0;
+    uint8_t v[CMP_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u) {
+        v[u] = (base + u < nslot) ? slot_valid[base + u] : 0;
+        cnt += v[u] != 0;
     }
-    if (tid == 0) *n_points = total;
+    int total;
+    int p = chunk_base + block_excl_scan_256(cnt, total, wsum);
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u)
+        if (base + u < nslot) {
+            if (v[u]) {
+                point_slot[p] = (int32_t)(base + u);
+                slot_point[base + u] = p++;
+            } else {
+                slot_point[base + u] = -1;
+            }
+        }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_points = chunk_base + total;
 }
 
 GridDev dev_view(const spf_grid* g) {
@@ -517,7 +553,6 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
 
 int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t* point_slot, int32_t* slot_point,
                        int32_t* n_points, int32_t* scratch, void* stream_) {
-    (void)scratch;
     if (R < 0 || SR < 1) return spf::fail(SPF_EINVAL, "spf_compact_points: bad sizes");
     if (!n_points) return spf::fail(SPF_EINVAL, "spf_compact_points: null n_points");
     hipStream_t stream = (hipStream_t)stream_;
@@ -525,9 +560,14 @@ int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t
         SPF_HIP_CHECK(hipMemsetAsync(n_points, 0, sizeof(int32_t), stream));
         return SPF_OK;
     }
-    if (!slot_valid || !point_slot || !slot_point) return spf::fail(SPF_EINVAL, "spf_compact_points: null buffer");
-    compact_kernel<<<1, 1024, 0, stream>>>(slot_valid, R, SR, point_slot, slot_point, n_points);
-    SPF_LAUNCH_CHECK("compact_kernel");
+    if (!slot_valid || !point_slot || !slot_point || !scratch) return spf::fail(SPF_EINVAL, "spf_compact_points: null buffer");
+    const long long nslot = (long long)R * SR;
+    const int chunks = spf::div_up(nslot, CMP_CHUNK);
+    if (chunks > R + 1) return spf::fail(SPF_EINVAL, "spf_compact_points: scratch (R+1 ints) too small for %d chunks", chunks);
+    compact_count_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nslot, scratch);
+    SPF_LAUNCH_CHECK("compact_count_kernel");
+    compact_write_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nslot, scratch, point_slot, slot_point, n_points);
+    SPF_LAUNCH_CHECK("compact_write_kernel");
     return SPF_OK;
 }
 

@@ -34,9 +34,10 @@ def compact_points(slot_valid):
     point_slot = torch.empty((R * SR,), dtype=torch.int32, device=dev)
     slot_point = torch.empty((R * SR,), dtype=torch.int32, device=dev)
     n_points = torch.empty((1,), dtype=torch.int32, device=dev)
+    scratch = torch.empty((R + 1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_compact_points(_lib.ptr(slot_valid), R, SR, _lib.ptr(point_slot), _lib.ptr(slot_point),
-                                                 _lib.ptr(n_points), None, _lib.stream_ptr()), "spf_compact_points")
+                                                 _lib.ptr(n_points), _lib.ptr(scratch), _lib.stream_ptr()), "spf_compact_points")
     return point_slot, slot_point, n_points
 
 
@@ -194,46 +195,53 @@ def pack_color_weights(ws):
 class ColorAgg(torch.autograd.Function):
     """agg[p,256] = sum_j wn_j F_color([posenc6(x_pi) | colour latent]) for the P valid points
     (pointneus_disent.py:325-336).  Forward and the data-gradient chain are HIP kernels; the weight
-    gradients are library GEMMs over the activation / pre-activation-gradient buffers the kernels store."""
+    gradients are library GEMMs over the activation / pre-activation-gradient buffers the kernels store
+    (the last, linear layer through its rank structure: dW6 = g_agg^T (sum_j wn_j a3_j), K = P)."""
 
     @staticmethod
     def forward(ctx, feat_col, w0, b0, w2, b2, w4, b4, w6, b6, x, nbr, wn, point_slot, n_points, pts, n_valid):
         dev = x.device
         P = int(n_valid)
         k = nbr.shape[1]
-        rows = 64 * ((P + 7) // 8)
+        tiles = (P + 7) // 8
+        rows = 64 * tiles
         packed = pack_color_weights([w0, b0, w2, b2, w4, b4, w6, b6])
         agg = torch.empty((P, 256), dtype=torch.float32, device=dev)
         train = any(ctx.needs_input_grad[:9])
-        acts = [torch.empty((rows, 104), dtype=torch.float32, device=dev)] + \
-               [torch.empty((rows, 256), dtype=torch.float32, device=dev) for _ in range(3)] if train else [None] * 4
+        if train:
+            bufs = [torch.empty((rows, 104), dtype=torch.float32, device=dev), torch.empty((rows, 256), dtype=torch.float32, device=dev),
+                    torch.empty((rows, 256), dtype=torch.float32, device=dev), torch.empty((tiles * 8, 256), dtype=torch.float32, device=dev),
+                    torch.empty((tiles, 3, 512), dtype=torch.int32, device=dev)]
+        else:
+            bufs = [None] * 5
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_color_forward(_lib.ptr(x), _lib.ptr(nbr), _lib.ptr(wn), _lib.ptr(point_slot), _lib.ptr(n_points), P, k,
                                                     _lib.ptr(pts), _lib.ptr(feat_col.detach()), _lib.ptr(packed), _lib.ptr(agg),
-                                                    *[_lib.ptr(a) for a in acts], _lib.stream_ptr()), "spf_color_forward")
+                                                    *[_lib.ptr(a) for a in bufs], _lib.stream_ptr()), "spf_color_forward")
         if train:
-            ctx.save_for_backward(nbr, wn, point_slot, n_points, packed, *acts)
+            ctx.save_for_backward(nbr, wn, point_slot, n_points, packed, *bufs)
             ctx.P, ctx.n_table = P, feat_col.shape[0]
         return agg
 
     @staticmethod
     def backward(ctx, g_agg):
-        nbr, wn, point_slot, n_points, packed, act0, act1, act2, act3 = ctx.saved_tensors
+        nbr, wn, point_slot, n_points, packed, act0, act1, act2, agg3, masks = ctx.saved_tensors
         dev = g_agg.device
         P, k = ctx.P, nbr.shape[1]
         rows = act1.shape[0]
-        G = [torch.empty((rows, 256), dtype=torch.float32, device=dev) for _ in range(4)]
+        G1, G2, G3 = (torch.empty((rows, 256), dtype=torch.float32, device=dev) for _ in range(3))
+        g_bias = torch.zeros((3, 256), dtype=torch.float32, device=dev)
         g_feat = torch.zeros((ctx.n_table, 64), dtype=torch.float32, device=dev)
         g_agg = g_agg.contiguous()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg), _lib.ptr(nbr), _lib.ptr(wn), _lib.ptr(point_slot), _lib.ptr(n_points), P, k,
-                                                     _lib.ptr(packed), _lib.ptr(act1), _lib.ptr(act2), _lib.ptr(act3),
-                                                     *[_lib.ptr(g) for g in G], _lib.ptr(g_feat), _lib.stream_ptr()), "spf_color_backward")
-        G1, G2, G3, G4 = G
+                                                     _lib.ptr(packed), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_bias),
+                                                     _lib.ptr(g_feat), _lib.stream_ptr()), "spf_color_backward")
         dw0_int = _wgrad(G1, act0)                                 # [256,104] in the kernels' internal column order
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
         dw0[:, _color_col_perm(dev)] = dw0_int[:, :103]
-        grads = (g_feat, dw0, G1.sum(0), _wgrad(G2, act1), G2.sum(0), _wgrad(G3, act2), G3.sum(0), _wgrad(G4, act3), G4.sum(0))
+        dw6 = g_agg.t() @ agg3[:P]                                 # last layer: rank structure, K = P
+        grads = (g_feat, dw0, g_bias[0], _wgrad(G2, act1), g_bias[1], _wgrad(G3, act2), g_bias[2], dw6, g_agg.sum(0))
         return grads + (None,) * 7
 
 
