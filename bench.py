@@ -91,11 +91,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("SPF_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only for single-GPU smoke tests
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from spurfies_amd import ops, synthetic as syn
     from spurfies_amd.conf import default_model_conf
