@@ -99,6 +99,15 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
 int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t* point_slot,
                        int32_t* slot_point, int32_t* n_points, int32_t* scratch, void* stream);
 
+/* Pair list over the valid points (replaces mask_to_batch_ray_idx, spurfies/model/utils.py:172-183): the rows
+ * of the MLP kernels are the valid (point, neighbour) pairs, grouped by point, WITHOUT padding.
+ *   pair_off   [max_points+1] int32  exclusive scan of the per-point neighbour counts (pair_off[P] = n_pairs)
+ *   pair_point [max_points*k] int32  compact point id of each pair
+ *   n_pairs    [1] int32 (device);   scratch: >= max_points/2048 + 2 int32 */
+int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
+                    int32_t k, int32_t* pair_off, int32_t* pair_point, int32_t* n_pairs, int32_t* scratch,
+                    void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused geometry path — replaces get_keypoint_data + compute_weights + get_sdf (+ the value of
  * get_gradients): spurfies/model/utils.py:140-170, spurfies/model/pointneus_disent.py:241-247,
@@ -118,27 +127,30 @@ int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float*
                  const float* w8, const float* b8, const float* wT, const float* bT,
                  float* packed, void* stream);
 
-/* One launch evaluates every valid point p < *n_points (a DEVICE int32; max_points sizes the
- * launch; NULL = exactly max_points).  All per-point arrays are addressed by ROW:
- * row = point_slot[p] (the flat slot id r*SR+s written by spf_compact_points), or row = p when
- * point_slot is NULL.  Inputs: x[row,3] positions, nbr[row,k] int32 neighbours (-1 pad),
- * tables pts[N,3], feat_geo[N,32], the packed weight image, rbf = conf.rbf (45).  Outputs (rows
- * of invalid points are left untouched, so callers pre-fill e.g. sdf with 1000):
- *   sdf   [rows]        RBF-weighted mean of the per-neighbour SDF
- *   wn    [rows,8]      normalised RBF weights w_j / sum_j w_j (0 for padding); may be NULL
- *   grad  [rows,3]      d sdf / d x  (NULL: skip the Jacobian sweep — sampler / eval mode)
- *   jac   [rows,8,32]   d sdf_j / d latent_j per pair (NULL iff grad is NULL) */
-int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slot, const int32_t* n_points,
-                    int32_t max_points, int32_t k, const float* pts, const float* feat_geo,
-                    const float* packed, float rbf, float* sdf, float* wn, float* grad, float* jac,
-                    void* stream);
+/* Evaluates every valid pair q < *n_pairs (tiles of 64 pairs) and reduces per point p < *n_points
+ * (both DEVICE int32; max_points / max_pairs size the launches).  Per-point arrays are addressed by ROW:
+ * row = point_slot[p] (the flat slot id r*SR+s written by spf_compact_points), or row = p when point_slot
+ * is NULL; per-pair arrays by the compact pair id q (spf_build_pairs).  Inputs: x[row,3] positions,
+ * nbr[row,k] int32 neighbours (-1 pad), tables pts[N,3], feat_geo[N,32], the packed weight image,
+ * rbf = conf.rbf (45).  Outputs (rows of invalid points are left untouched: pre-fill sdf with 1000):
+ *   sdf   [rows]         RBF-weighted mean of the per-neighbour SDF
+ *   grad  [rows,3]       d sdf / d x  (NULL: skip the Jacobian sweep — sampler / eval mode)
+ *   wn    [max_pairs]    normalised RBF weight of each pair, w_j / sum_j w_j (may be NULL when grad is NULL)
+ *   jac   [max_pairs,32] d sdf_j / d latent_j per pair (NULL iff grad is NULL)
+ *   pair_tmp [max_pairs,5] scratch */
+int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slot, const int32_t* pair_off,
+                    const int32_t* pair_point, const int32_t* n_points, const int32_t* n_pairs,
+                    int32_t max_points, int32_t max_pairs, int32_t k, const float* pts, const float* feat_geo,
+                    const float* packed, float rbf, float* sdf, float* grad, float* wn, float* jac,
+                    float* pair_tmp, void* stream);
 
-/* Backward of the weighted mean w.r.t. the geometry latents (same row addressing):
- *   g_feat_geo[nbr[row,j], :] += g_sdf[row] * wn[row,j] * jac[row,j,:]   (float atomics)
+/* Backward of the weighted mean w.r.t. the geometry latents:
+ *   g_feat_geo[nbr(q), :] += g_sdf[row(q)] * wn[q] * jac[q,:]   (float atomics)
  * (F_geometry / T are frozen in the reference's training, train.py:151-154.) */
 int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* jac, const int32_t* nbr,
-                             const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
-                             int32_t k, float* g_feat_geo, void* stream);
+                             const int32_t* point_slot, const int32_t* pair_off, const int32_t* pair_point,
+                             const int32_t* n_pairs, int32_t max_pairs, int32_t k, float* g_feat_geo,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused colour-feature path — replaces the F_color half of get_color,
@@ -151,28 +163,28 @@ int64_t spf_color_packed_floats(void);
 int spf_color_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4,
                    const float* b4, const float* w6, const float* b6, float* packed, void* stream);
 
-/* agg[p, 256] = sum_j wn[row,j] * F_color([posenc6(x[row] - pts[nbr[row,j]]) | feat_color[nbr[row,j]]])
- * for the p-th valid point (row = point_slot[p], or p when point_slot is NULL); wn comes from
- * spf_geo_forward.  Training mode (act0 != NULL) also writes, in compact tile order (row t = 8p + j,
- * T = 64 * ceil(P/8) rows):
+/* agg[p, 256] += sum_j wn[q] * F_color([posenc6(x[row] - pts[nbr]) | feat_color[nbr]]) over the pairs q of the
+ * p-th valid point (pair lists from spf_build_pairs, wn from spf_geo_forward); agg must be ZEROED by the caller
+ * (a point whose pairs straddle two 64-pair tiles receives two commutative atomic adds).  Training mode
+ * (act0 != NULL) also writes, per pair row q (T = 64 * ceil(n_pairs/64) rows):
  *   act0 [T,104]   layer-1 input in the kernel's internal column order [latent 64 | posenc 39 | 0]
  *   act1, act2 [T,256]  inputs of layers 2 and 3 (operands of their weight-gradient GEMMs)
- *   agg3 [P8,256]  sum_j wn_j a3_j, the RBF-weighted mean of the last hidden activation (P8 = 8*ceil(P/8)):
- *                  the last layer is linear, so its weight gradient is g_agg^T agg3 (K = P, not 8P)
+ *   agg3 [P,256]   += sum_j wn_j a3_j (ZEROED by the caller): the last layer is linear, so its weight gradient
+ *                  is g_agg^T agg3 (K = P, not n_pairs)
  *   masks [T/64, 3, 512] uint32  LeakyReLU sign bits of layers 1..3 in accumulator order */
 int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot,
-                      const int32_t* n_points, int32_t max_points, int32_t k, const float* pts,
-                      const float* feat_color, const float* packed, float* agg, float* act0, float* act1,
-                      float* act2, float* agg3, uint32_t* masks, void* stream);
+                      const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs,
+                      int32_t k, const float* pts, const float* feat_color, const float* packed, float* agg,
+                      float* act0, float* act1, float* act2, float* agg3, uint32_t* masks, void* stream);
 
 /* Data-gradient chain for g_agg[p,256] = dL/d agg: writes the pre-activation gradients G1..G3 [T,256]
  * (weight gradients of layers 1..3 are then dW_l = G_l^T act_{l-1}, plain GEMMs), adds their column sums
  * to g_bias [3,256] (bias gradients of layers 1..3) and accumulates the colour-latent gradient into
  * g_feat_color[N,64] (float atomics). */
 int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot,
-                       const int32_t* n_points, int32_t max_points, int32_t k, const float* packed,
-                       const uint32_t* masks, float* G1, float* G2, float* G3, float* g_bias,
-                       float* g_feat_color, void* stream);
+                       const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs,
+                       int32_t k, const float* packed, const uint32_t* masks, float* G1, float* G2, float* G3,
+                       float* g_bias, float* g_feat_color, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * VolSDF error-bounded sampler — replaces UniformSampler.get_z_vals (spurfies/model/ray_sampler.py:33-59),

@@ -47,8 +47,27 @@ constexpr int CO_B4 = CO_B3 + 256;
 constexpr int C_PACKED = CO_B4 + 256;
 
 constexpr int CL_X = 0;
-constexpr int CL_W = CL_X + 64 * LDA;
-constexpr int CL_TOTAL = CL_W + 64;
+constexpr int CL_W = CL_X + 64 * LDA;   // per-row normalised RBF weight
+constexpr int CL_P = CL_W + 64;         // per-row compact point id (int bits), -1 for padding rows
+constexpr int CL_TOTAL = CL_P + 64;
+
+// out[p, c] += sum over the tile's rows of point p of w_row * X[row][c]; thread = column.  Rows of a point are
+// consecutive (pairs are grouped by point); a point straddling two tiles receives two atomic adds (commutative,
+// so the result does not depend on their order).
+__device__ __forceinline__ void seg_reduce_rows(const float* X, const float* s_w, const int* s_p, int c, float* __restrict__ out) {
+    int cur = s_p[0];
+    float a = 0.f;
+    for (int row = 0; row < 64; ++row) {
+        const int p = s_p[row];
+        if (p != cur) {
+            if (cur >= 0) atomicAdd(&out[(size_t)cur * 256 + c], a);
+            cur = p;
+            a = 0.f;
+        }
+        a += s_w[row] * X[row * LDA + c];
+    }
+    if (cur >= 0) atomicAdd(&out[(size_t)cur * 256 + c], a);
+}
 
 // ---- pack ------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ int c_orig(int k) { return k < 64 ? 39 + k : k - 64; }
@@ -90,96 +109,80 @@ __global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
     out[e] = val;
 }
 
-// epilogue of a hidden layer: + bias, LeakyReLU, write to X.  Training mode also records the sign bits
-// (one uint32 per lane and row half: bit n*16+r, the same lane/register position the backward kernel's
-// accumulators have), optionally streams the activation to HBM (input of the next layer's wgrad GEMM) and
-// optionally reduces it over each point's 8 rows with the RBF weights (agg3, see spf_color_backward).
-template <bool STORE>
+// epilogue of a layer: + bias, (LeakyReLU), write to X.  Training mode also records the sign bits (one uint32 per
+// lane and row half: bit n*16+r, the same lane/register position the backward kernel's accumulators have) and
+// optionally streams the activation to HBM (input of the next layer's wgrad GEMM).
+template <bool STORE, bool ACT>
 __device__ __forceinline__ void c_fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave, int lane,
-                                               float* act_g /* tile base [64][256] or null */, uint32_t* mask_g /* [4][2][64] or null */,
-                                               const float* s_w, float* agg_g /* [8][256] tile base or null */, int pts_left) {
+                                               float* act_g /* tile base [64][256] or null */, uint32_t* mask_g /* [4][2][64] or null */) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
     const float bv[2] = {bias[c0], bias[c0 + 32]};
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         uint32_t bits = 0u;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float s0 = 0.f, s1 = 0.f;
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = 4 * g + u;
-                const int row = m * 32 + row_of(r, h);
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    float v = acc[m][n][r] + bv[n];
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[m][n][r] + bv[n];
+                if (ACT) {
                     const bool pos = v > 0.f;
                     bits |= (pos ? 1u : 0u) << (n * 16 + r);
                     v = pos ? v : v * 0.01f;
-                    X[row * LDA + c0 + 32 * n] = v;
-                    if (STORE && act_g) act_g[row * 256 + c0 + 32 * n] = v;
-                    if (STORE && agg_g) {
-                        const float w = s_w[(g + 4 * m) * 8 + u + 4 * h];
-                        if (n == 0) s0 += w * v; else s1 += w * v;
-                    }
                 }
+                const int row = m * 32 + row_of(r, h);
+                X[row * LDA + c0 + 32 * n] = v;
+                if (STORE && act_g) act_g[row * 256 + c0 + 32 * n] = v;
             }
-            if (STORE && agg_g) {
-                s0 += __shfl_xor(s0, 32);
-                s1 += __shfl_xor(s1, 32);
-                if (h == 0 && g + 4 * m < pts_left) {
-                    agg_g[(g + 4 * m) * 256 + c0] = s0;
-                    agg_g[(g + 4 * m) * 256 + c0 + 32] = s1;
-                }
-            }
-        }
-        if (STORE && mask_g) mask_g[(wave * 2 + m) * 64 + lane] = bits;
+        if (STORE && ACT && mask_g) mask_g[(wave * 2 + m) * 64 + lane] = bits;
     }
 }
 
 template <bool STORE>
 __global__ void __launch_bounds__(256, 2)
 color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
-                     const int32_t* __restrict__ point_slot, const int32_t* __restrict__ n_points_dev, int max_points, int k,
-                     const float* __restrict__ pts, const float* __restrict__ feat_col, const float* packed,
-                     float* __restrict__ agg, float* __restrict__ act0, float* __restrict__ act1, float* __restrict__ act2,
-                     float* __restrict__ agg3, uint32_t* __restrict__ masks) {
+                     const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
+                     const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k, const float* __restrict__ pts,
+                     const float* __restrict__ feat_col, const float* packed, float* __restrict__ agg, float* __restrict__ act0,
+                     float* __restrict__ act1, float* __restrict__ act2, float* __restrict__ agg3, uint32_t* __restrict__ masks) {
     __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL];
     float* X = smem + CL_X;
+    int* s_p = reinterpret_cast<int*>(smem + CL_P);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
-    const int ntiles = (P + SPF_TILE_PTS - 1) / SPF_TILE_PTS;
+    const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
+    const int ntiles = (NP + 63) / 64;
     const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ---- gather: thread = (row, quarter): 16 latent floats each; quarter 0 also does posenc -----
         {
-            const int row = tid >> 2, q = tid & 3;
-            const int p = tile * SPF_TILE_PTS + (row >> 3), j = row & 7;
-            int idx = -1, srow = 0;
-            if (p < P) {
+            const int row = tid >> 2, q4 = tid & 3;
+            const int q = tile * 64 + row;
+            int idx = -1, srow = 0, p = -1;
+            if (q < NP) {
+                p = pair_point[q];
                 srow = point_slot ? point_slot[p] : p;
-                if (j < k) idx = nbr[(size_t)srow * k + j];
+                idx = nbr[(size_t)srow * k + (q - pair_off[p])];
             }
             f32x4 f[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) f[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (idx >= 0) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(feat_col + (size_t)idx * SPF_COL_DIM + q * 16);
+                const f32x4* src = reinterpret_cast<const f32x4*>(feat_col + (size_t)idx * SPF_COL_DIM + q4 * 16);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) f[u] = src[u];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(X + row * LDA + q * 16 + 4 * u) = f[u];
-            if (q == 0) {
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(X + row * LDA + q4 * 16 + 4 * u) = f[u];
+            if (q4 == 0) {
                 float d[3] = {0.f, 0.f, 0.f};
                 float w = 0.f;
                 if (idx >= 0) {
                     d[0] = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
                     d[1] = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
                     d[2] = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
-                    w = wn[(size_t)srow * 8 + j];
+                    w = wn[q];
                 }
                 float* e = X + row * LDA + 64;   // posenc block: internal columns 64..102
                 if (idx >= 0) {
@@ -201,6 +204,7 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
                 }
                 e[39] = 0.f;                      // pad column 103
                 smem[CL_W + row] = w;
+                s_p[row] = idx >= 0 ? p : -1;
             }
         }
         __syncthreads();
@@ -211,53 +215,30 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
                 *reinterpret_cast<f32x4*>(dst + row * C_INP + 4 * c4) = *reinterpret_cast<const f32x4*>(X + row * LDA + 4 * c4);
             }
         }
+        uint32_t* mk = STORE ? masks + (size_t)tile * 3 * 512 : nullptr;   // [layer 3][wave 4][m 2][lane 64]
         f32x16 acc[2][2];
         zero_acc(acc);
         gemm_rows64<T_CIN>(X, pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128), lane, acc);
         __syncthreads();
-        const int pts_left = P - tile * SPF_TILE_PTS;
-        uint32_t* mk = STORE ? masks + (size_t)tile * 3 * 512 : nullptr;   // [layer 3][wave 4][m 2][lane 64]
-        c_fwd_epilogue<STORE>(X, acc, packed + CO_B1, wave, lane, STORE ? act1 + (size_t)tile * 64 * 256 : nullptr, mk, smem + CL_W, nullptr, pts_left);
+        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B1, wave, lane, STORE ? act1 + (size_t)tile * 64 * 256 : nullptr, mk);
         __syncthreads();
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_FW2 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_fwd_epilogue<STORE>(X, acc, packed + CO_B2, wave, lane, STORE ? act2 + (size_t)tile * 64 * 256 : nullptr, STORE ? mk + 512 : nullptr,
-                              smem + CL_W, nullptr, pts_left);
+        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B2, wave, lane, STORE ? act2 + (size_t)tile * 64 * 256 : nullptr, STORE ? mk + 512 : nullptr);
         __syncthreads();
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_FW3 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_fwd_epilogue<STORE>(X, acc, packed + CO_B3, wave, lane, nullptr, STORE ? mk + 1024 : nullptr, smem + CL_W,
-                              STORE ? agg3 + (size_t)tile * SPF_TILE_PTS * 256 : nullptr, pts_left);
+        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B3, wave, lane, nullptr, STORE ? mk + 1024 : nullptr);
         __syncthreads();
+        if (STORE) seg_reduce_rows(X, smem + CL_W, s_p, tid, agg3);   // agg3[p] = sum_j wn_j a3_j (rank structure of the last layer's wgrad)
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_FW4 / 4) + wave * (T_HID * 128), lane, acc);
-        // ---- last layer has no activation: weighted mean over the 8 neighbour rows of each point ----
-        {
-            const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
-            const float bv[2] = {packed[CO_B4 + c0], packed[CO_B4 + c0 + 32]};
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {       // point (g + 4m) of the tile: rows 8(g+4m) + (r&3) + 4h
-                    const int pl = g + 4 * m;
-                    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float w = smem[CL_W + pl * 8 + u + 4 * h];
-                        s0 += w * (acc[m][0][4 * g + u] + bv[0]);
-                        s1 += w * (acc[m][1][4 * g + u] + bv[1]);
-                    }
-                    s0 += __shfl_xor(s0, 32);
-                    s1 += __shfl_xor(s1, 32);
-                    const int p = tile * SPF_TILE_PTS + pl;
-                    if (h == 0 && p < P) {
-                        agg[(size_t)p * 256 + c0] = s0;
-                        agg[(size_t)p * 256 + c0 + 32] = s1;
-                    }
-                }
-        }
+        __syncthreads();
+        c_fwd_epilogue<false, false>(X, acc, packed + CO_B4, wave, lane, nullptr, nullptr);   // last layer: no activation
+        __syncthreads();
+        seg_reduce_rows(X, smem + CL_W, s_p, tid, agg);               // agg[p] = sum_j wn_j F_color(.)_j
         __syncthreads();
     }
 }
@@ -293,36 +274,38 @@ __device__ __forceinline__ void c_bwd_epilogue(float* X, const f32x16 (&acc)[2][
 
 __global__ void __launch_bounds__(256, 2)
 color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
-                      const int32_t* __restrict__ point_slot, const int32_t* __restrict__ n_points_dev, int max_points, int k,
-                      const float* packed, const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2,
-                      float* __restrict__ G3, float* __restrict__ g_bias /* [3][256]: layers 1..3 */, float* __restrict__ g_feat_col) {
+                      const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
+                      const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k, const float* packed,
+                      const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3,
+                      float* __restrict__ g_bias /* [3][256]: layers 1..3 */, float* __restrict__ g_feat_col) {
     __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL];
     float* X = smem + CL_X;
     int* s_idx = reinterpret_cast<int*>(smem + CL_W);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
-    const int ntiles = (P + SPF_TILE_PTS - 1) / SPF_TILE_PTS;
+    const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
+    const int ntiles = (NP + 63) / 64;
     const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const size_t tbase = (size_t)tile * 64 * 256;
         // ---- G4[row] = wn[row] * g_agg[p]  (the last layer is linear; agg = sum_j wn_j f_j) ---------
         {
-            const int row = tid >> 2, q = tid & 3;
-            const int p = tile * SPF_TILE_PTS + (row >> 3), j = row & 7;
+            const int row = tid >> 2, q4 = tid & 3;
+            const int q = tile * 64 + row;
             float w = 0.f;
-            int idx = -1;
-            if (p < P) {
+            int idx = -1, p = 0;
+            if (q < NP) {
+                p = pair_point[q];
                 const int srow = point_slot ? point_slot[p] : p;
-                if (j < k) idx = nbr[(size_t)srow * k + j];
-                if (idx >= 0) w = wn[(size_t)srow * 8 + j];
+                idx = nbr[(size_t)srow * k + (q - pair_off[p])];
+                w = wn[q];
             }
-            if (q == 0) s_idx[row] = idx;
-            const f32x4* ga = reinterpret_cast<const f32x4*>(g_agg + (size_t)(p < P ? p : 0) * 256);
+            if (q4 == 0) s_idx[row] = idx;
+            const f32x4* ga = reinterpret_cast<const f32x4*>(g_agg + (size_t)p * 256);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int c4 = q + 4 * u;
+                const int c4 = q4 + 4 * u;
                 f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (w != 0.f) {
                     v = ga[c4];
@@ -333,10 +316,10 @@ color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict
         }
         __syncthreads();
         f32x16 acc[2][2];
+        const uint32_t* mk = masks + (size_t)tile * 3 * 512;
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_BW4 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        const uint32_t* mk = masks + (size_t)tile * 3 * 512;
         c_bwd_epilogue(X, acc, wave, lane, mk + 1024, G3 + tbase, g_bias + 512);
         __syncthreads();
         zero_acc(acc);
@@ -390,37 +373,39 @@ int spf_color_pack(const float* w0, const float* b0, const float* w2, const floa
     return SPF_OK;
 }
 
-int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* n_points,
-                      int32_t max_points, int32_t k, const float* pts, const float* feat_color, const float* packed, float* agg,
-                      float* act0, float* act1, float* act2, float* agg3, uint32_t* masks, void* stream) {
-    if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_forward: bad sizes");
-    if (max_points == 0) return SPF_OK;
-    if (!x || !nbr || !wn || !pts || !feat_color || !packed || !agg) return spf::fail(SPF_EINVAL, "spf_color_forward: null pointer");
+int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* pair_off,
+                      const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* pts,
+                      const float* feat_color, const float* packed, float* agg, float* act0, float* act1, float* act2, float* agg3,
+                      uint32_t* masks, void* stream) {
+    if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_forward: bad sizes");
+    if (max_pairs == 0) return SPF_OK;
+    if (!x || !nbr || !wn || !pair_off || !pair_point || !pts || !feat_color || !packed || !agg)
+        return spf::fail(SPF_EINVAL, "spf_color_forward: null pointer");
     const bool store = act0 != nullptr;
     if (store && (!act1 || !act2 || !agg3 || !masks)) return spf::fail(SPF_EINVAL, "spf_color_forward: training buffers must be given together");
-    const int tiles = spf::div_up(max_points, SPF_TILE_PTS);
+    const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
     if (store)
-        color_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, n_points, max_points, k, pts,
+        color_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts,
                                                                             feat_color, packed, agg, act0, act1, act2, agg3, masks);
     else
-        color_forward_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, n_points, max_points, k, pts,
-                                                                             feat_color, packed, agg, nullptr, nullptr, nullptr, nullptr, nullptr);
+        color_forward_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k,
+                                                                             pts, feat_color, packed, agg, nullptr, nullptr, nullptr, nullptr, nullptr);
     SPF_LAUNCH_CHECK("color_forward_kernel");
     return SPF_OK;
 }
 
-int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* n_points,
-                       int32_t max_points, int32_t k, const float* packed, const uint32_t* masks, float* G1, float* G2, float* G3,
-                       float* g_bias, float* g_feat_color, void* stream) {
-    if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_backward: bad sizes");
-    if (max_points == 0) return SPF_OK;
-    if (!g_agg || !nbr || !wn || !packed || !masks || !G1 || !G2 || !G3 || !g_bias || !g_feat_color)
+int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* pair_off,
+                       const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* packed,
+                       const uint32_t* masks, float* G1, float* G2, float* G3, float* g_bias, float* g_feat_color, void* stream) {
+    if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_backward: bad sizes");
+    if (max_pairs == 0) return SPF_OK;
+    if (!g_agg || !nbr || !wn || !pair_off || !pair_point || !packed || !masks || !G1 || !G2 || !G3 || !g_bias || !g_feat_color)
         return spf::fail(SPF_EINVAL, "spf_color_backward: null pointer");
-    const int tiles = spf::div_up(max_points, SPF_TILE_PTS);
+    const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
-    color_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_agg, nbr, wn, point_slot, n_points, max_points, k, packed, masks, G1, G2,
-                                                                   G3, g_bias, g_feat_color);
+    color_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_agg, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
+                                                                   masks, G1, G2, G3, g_bias, g_feat_color);
     SPF_LAUNCH_CHECK("color_backward_kernel");
     return SPF_OK;
 }

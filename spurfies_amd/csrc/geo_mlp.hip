@@ -51,14 +51,12 @@ constexpr int OFF_V5 = OFF_B4 + 256;
 constexpr int OFF_C = OFF_V5 + 256;
 constexpr int PACKED_FLOATS = OFF_C + 4;
 
-// LDS carve (floats)
+// LDS: the activation tile only
 constexpr int L_X = 0;
-constexpr int L_W = L_X + 64 * LDA;   // rbf weight per row
-constexpr int L_S = L_W + 64;         // per-row sdf
-constexpr int L_JX = L_S + 64;        // per-row d sdf_j / d x_pi (3)
-constexpr int L_NORM = L_JX + 192;    // per-point sum of weights
-constexpr int L_SROW = L_NORM + 8;    // per-point output row (int bits), -1 beyond the last point
-constexpr int L_TOTAL = L_SROW + 8;
+constexpr int L_TOTAL = 64 * LDA;
+
+// per-pair scratch written by the MLP kernel and consumed by the point reduction: [w, sdf_j, dsdf_j/dx (3)]
+constexpr int PT_STRIDE = 5;
 
 // forward epilogue: + bias, record sign bits, LeakyReLU, write this wave's 64x64 block back to X
 __device__ __forceinline__ void fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave,
@@ -95,61 +93,57 @@ __device__ __forceinline__ void bwd_epilogue(float* X, const f32x16 (&acc)[2][2]
             }
 }
 
+// One tile = 64 consecutive VALID pairs (rows), whatever points they belong to: no padding rows except in
+// the last tile.  Per pair the kernel leaves [w_j, sdf_j, d sdf_j/d x] in pair_tmp and (WITH_JAC) the
+// latent Jacobian row in jac; geo_point_reduce_kernel then forms the per-point weighted means.
 template <bool WITH_JAC>
 __global__ void __launch_bounds__(256, 2)
-geo_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
-                   const int32_t* __restrict__ n_points_dev, int max_points, int k, const float* __restrict__ pts,
-                   const float* __restrict__ feat_geo, const float* packed, float rbf, float* __restrict__ sdf,
-                   float* __restrict__ wn, float* __restrict__ grad, float* __restrict__ jac) {
+geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
+                 const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
+                 int max_pairs, int k, const float* __restrict__ pts, const float* __restrict__ feat_geo, const float* packed,
+                 float rbf, float* __restrict__ pair_tmp, float* __restrict__ jac) {
     __shared__ __attribute__((aligned(16))) float smem[L_TOTAL];
     float* X = smem + L_X;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
-    const int ntiles = (P + SPF_TILE_PTS - 1) / SPF_TILE_PTS;
+    const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
+    const int ntiles = (NP + 63) / 64;
     const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ---- gather: thread = (row, quarter of the 32-d latent) ---------------------------------
         {
-            const int row = tid >> 2, q = tid & 3;
-            const int p = tile * SPF_TILE_PTS + (row >> 3), j = row & 7;
+            const int row = tid >> 2, q4 = tid & 3;
+            const int q = tile * 64 + row;
             int idx = -1, srow = 0;
-            if (p < P) {
+            if (q < NP) {
+                const int p = pair_point[q];
                 srow = point_slot ? point_slot[p] : p;
-                if (j < k) idx = nbr[(size_t)srow * k + j];
+                idx = nbr[(size_t)srow * k + (q - pair_off[p])];
             }
             f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0;
             if (idx >= 0) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(feat_geo + (size_t)idx * SPF_GEO_DIM + q * 8);
+                const f32x4* src = reinterpret_cast<const f32x4*>(feat_geo + (size_t)idx * SPF_GEO_DIM + q4 * 8);
                 f0 = src[0];
                 f1 = src[1];
             }
-            *reinterpret_cast<f32x4*>(X + row * LDA + q * 8) = f0;
-            *reinterpret_cast<f32x4*>(X + row * LDA + q * 8 + 4) = f1;
-            if (q == 0) {
-                float dx = 0.f, dy = 0.f, dz = 0.f, w = 0.f;
+            *reinterpret_cast<f32x4*>(X + row * LDA + q4 * 8) = f0;
+            *reinterpret_cast<f32x4*>(X + row * LDA + q4 * 8 + 4) = f1;
+            if (q4 == 0) {
+                float dx = 0.f, dy = 0.f, dz = 0.f;
                 if (idx >= 0) {
                     dx = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
                     dy = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
                     dz = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
-                    float dist = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
-                    float s = dist * rbf;
-                    w = expf(-(s * s));
+                    const float dist = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
+                    const float sc = dist * rbf;
+                    pair_tmp[(size_t)q * PT_STRIDE] = expf(-(sc * sc));
                 }
                 *reinterpret_cast<f32x4*>(X + row * LDA + 32) = f32x4{dx, dy, dz, 0.f};
                 *reinterpret_cast<f32x4*>(X + row * LDA + 36) = f32x4{0.f, 0.f, 0.f, 0.f};
-                smem[L_W + row] = w;
-                if (j == 0) smem[L_SROW + (row >> 3)] = __int_as_float(p < P ? srow : -1);
             }
         }
         __syncthreads();
-        if (tid < SPF_TILE_PTS) {
-            float nrm = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) nrm += smem[L_W + tid * 8 + j];
-            smem[L_NORM + tid] = nrm;
-        }
 
         f32x16 acc[2][2];
         uint32_t m1[2], m2[2], m3[2], m4[2];
@@ -177,37 +171,24 @@ geo_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
 
         // ---- sdf_j = v . a4 + c : 4 threads per row, interleaved float4 chunks ------------------
         {
-            const int row = tid >> 2, q = tid & 3;
+            const int row = tid >> 2, q4 = tid & 3;
             const f32x4* v4 = pk4 + OFF_V5 / 4;
             float s = 0.f;
 #pragma unroll
             for (int mth = 0; mth < 16; ++mth) {
-                const int c4 = q + 4 * mth;
+                const int c4 = q4 + 4 * mth;
                 const f32x4 a = *reinterpret_cast<const f32x4*>(X + row * LDA + 4 * c4);
                 const f32x4 v = v4[c4];
                 s += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
             }
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
-            if (q == 0) smem[L_S + row] = s + packed[OFF_C];
-        }
-        __syncthreads();
-        if (tid < SPF_TILE_PTS) {
-            const int srow = __float_as_int(smem[L_SROW + tid]);
-            if (srow >= 0) {
-                const float nrm = smem[L_NORM + tid];
-                float a = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a += smem[L_W + tid * 8 + j] * smem[L_S + tid * 8 + j];
-                sdf[srow] = a / nrm;
-                if (wn) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) wn[(size_t)srow * 8 + j] = smem[L_W + tid * 8 + j] / nrm;
-                }
-            }
+            const int q = tile * 64 + row;
+            if (q4 == 0 && q < NP) pair_tmp[(size_t)q * PT_STRIDE + 1] = s + packed[OFF_C];
         }
 
         if (WITH_JAC) {
+            __syncthreads();
             // ---- Jacobian sweep: g_h4 = v * D4 ; g_a3 = g_h4 W6 ; ... ; J = g_h1 W0 --------------
             {
                 const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
@@ -253,27 +234,14 @@ geo_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
 #pragma unroll
                     for (int j = 0; j < 4; ++j) aj = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], aj, 0, 0, 0);
                 }
+                const int qb = tile * 64 + mt * 32 + 4 * h;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = mt * 32 + row_of(r, h);
-                    if (nt == 0) {
-                        const int srow = __float_as_int(smem[L_SROW + (row >> 3)]);
-                        if (srow >= 0) jac[((size_t)srow * 8 + (row & 7)) * SPF_GEO_DIM + i] = aj[r];
-                    } else if (i < 3) {
-                        smem[L_JX + row * 3 + i] = aj[r];
+                    const int q = qb + (r & 3) + 8 * (r >> 2);
+                    if (q < NP) {
+                        if (nt == 0) jac[(size_t)q * SPF_GEO_DIM + i] = aj[r];
+                        else if (i < 3) pair_tmp[(size_t)q * PT_STRIDE + 2 + i] = aj[r];
                     }
-                }
-            }
-            __syncthreads();
-            if (tid < SPF_TILE_PTS * 3) {
-                const int pl = tid / 3, c = tid % 3;
-                const int srow = __float_as_int(smem[L_SROW + pl]);
-                if (srow >= 0) {
-                    const float inv = 1.0f / smem[L_NORM + pl];
-                    float g = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) g += (smem[L_W + pl * 8 + j] * inv) * smem[L_JX + (pl * 8 + j) * 3 + c];
-                    grad[(size_t)srow * 3 + c] = g;
                 }
             }
         }
@@ -281,22 +249,55 @@ geo_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
     }
 }
 
+// per point: norm = sum_j w_j ; sdf = sum_j w_j sdf_j / norm ; wn_j = w_j / norm ; grad = sum_j wn_j d sdf_j/dx
+__global__ void geo_point_reduce_kernel(const float* __restrict__ pair_tmp, const int32_t* __restrict__ pair_off,
+                                        const int32_t* __restrict__ point_slot, const int32_t* __restrict__ n_points_dev, int max_points,
+                                        float* __restrict__ sdf, float* __restrict__ grad, float* __restrict__ wn) {
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int q0 = pair_off[p], q1 = pair_off[p + 1];
+    const int srow = point_slot ? point_slot[p] : p;
+    float nrm = 0.f, a = 0.f;
+    for (int q = q0; q < q1; ++q) {
+        const float w = pair_tmp[(size_t)q * PT_STRIDE];
+        nrm += w;
+        a += w * pair_tmp[(size_t)q * PT_STRIDE + 1];
+    }
+    sdf[srow] = a / nrm;
+    const float inv = 1.0f / nrm;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int q = q0; q < q1; ++q) {
+        const float w = pair_tmp[(size_t)q * PT_STRIDE];
+        if (wn) wn[q] = w / nrm;
+        if (grad) {
+            const float wi = w * inv;
+            g0 += wi * pair_tmp[(size_t)q * PT_STRIDE + 2];
+            g1 += wi * pair_tmp[(size_t)q * PT_STRIDE + 3];
+            g2 += wi * pair_tmp[(size_t)q * PT_STRIDE + 4];
+        }
+    }
+    if (grad) {
+        grad[(size_t)srow * 3] = g0;
+        grad[(size_t)srow * 3 + 1] = g1;
+        grad[(size_t)srow * 3 + 2] = g2;
+    }
+}
+
+// g_feat[nbr(q)] += g_sdf[row(q)] * wn[q] * jac[q, :]   — 32 lanes per pair, two 128-B atomic segments per wave
 __global__ void geo_backward_latents_kernel(const float* __restrict__ g_sdf, const float* __restrict__ wn,
                                             const float* __restrict__ jac, const int32_t* __restrict__ nbr,
-                                            const int32_t* __restrict__ point_slot, const int32_t* __restrict__ n_points_dev,
-                                            int max_points, int k, float* __restrict__ g_feat) {
-    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
-    const long long npair = (long long)P * 8;
+                                            const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off,
+                                            const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
+                                            int max_pairs, int k, float* __restrict__ g_feat) {
+    const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
     const int c = threadIdx.x & 31;
-    for (long long pair = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; pair < npair;
-         pair += ((long long)gridDim.x * blockDim.x) >> 5) {
-        const int p = (int)(pair >> 3), j = (int)(pair & 7);
-        if (j >= k) continue;
+    for (long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; q < NP; q += ((long long)gridDim.x * blockDim.x) >> 5) {
+        const int p = pair_point[q];
         const int srow = point_slot ? point_slot[p] : p;
-        const int idx = nbr[(size_t)srow * k + j];
-        if (idx < 0) continue;
-        const float coef = g_sdf[srow] * wn[(size_t)srow * 8 + j];
-        if (coef != 0.f) atomicAdd(&g_feat[(size_t)idx * SPF_GEO_DIM + c], coef * jac[((size_t)srow * 8 + j) * SPF_GEO_DIM + c]);
+        const int idx = nbr[(size_t)srow * k + ((int)q - pair_off[p])];
+        const float coef = g_sdf[srow] * wn[q];
+        if (coef != 0.f) atomicAdd(&g_feat[(size_t)idx * SPF_GEO_DIM + c], coef * jac[(size_t)q * SPF_GEO_DIM + c]);
     }
 }
 
@@ -364,37 +365,44 @@ int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float*
     return SPF_OK;
 }
 
-int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slot, const int32_t* n_points,
-                    int32_t max_points, int32_t k, const float* pts, const float* feat_geo, const float* packed, float rbf,
-                    float* sdf, float* wn, float* grad, float* jac, void* stream) {
-    if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_geo_forward: bad sizes (max_points=%d k=%d)", max_points, k);
-    if (max_points == 0) return SPF_OK;
-    if (!x || !nbr || !pts || !feat_geo || !packed || !sdf) return spf::fail(SPF_EINVAL, "spf_geo_forward: null pointer");
+int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slot, const int32_t* pair_off, const int32_t* pair_point,
+                    const int32_t* n_points, const int32_t* n_pairs, int32_t max_points, int32_t max_pairs, int32_t k, const float* pts,
+                    const float* feat_geo, const float* packed, float rbf, float* sdf, float* grad, float* wn, float* jac,
+                    float* pair_tmp, void* stream) {
+    if (max_points < 0 || max_pairs < 0 || k < 1 || k > SPF_KMAX)
+        return spf::fail(SPF_EINVAL, "spf_geo_forward: bad sizes (max_points=%d max_pairs=%d k=%d)", max_points, max_pairs, k);
+    if (max_points == 0 || max_pairs == 0) return SPF_OK;
+    if (!x || !nbr || !pair_off || !pair_point || !pts || !feat_geo || !packed || !sdf || !pair_tmp)
+        return spf::fail(SPF_EINVAL, "spf_geo_forward: null pointer");
     if ((grad == nullptr) != (jac == nullptr)) return spf::fail(SPF_EINVAL, "spf_geo_forward: grad and jac must be given together");
     if (grad && !wn) return spf::fail(SPF_EINVAL, "spf_geo_forward: wn is required with grad/jac");
-    const int tiles = spf::div_up(max_points, SPF_TILE_PTS);
+    const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;  // 2 workgroups per CU x 256 CUs, tiles are strided over them
+    hipStream_t s = (hipStream_t)stream;
     if (grad)
-        geo_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, point_slot, n_points, max_points, k, pts, feat_geo,
-                                                                          packed, rbf, sdf, wn, grad, jac);
+        geo_pairs_kernel<true><<<blocks, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
+                                                      pair_tmp, jac);
     else
-        geo_forward_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, point_slot, n_points, max_points, k, pts, feat_geo,
-                                                                           packed, rbf, sdf, wn, nullptr, nullptr);
-    SPF_LAUNCH_CHECK("geo_forward_kernel");
+        geo_pairs_kernel<false><<<blocks, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
+                                                       rbf, pair_tmp, nullptr);
+    SPF_LAUNCH_CHECK("geo_pairs_kernel");
+    geo_point_reduce_kernel<<<spf::div_up(max_points, 256), 256, 0, s>>>(pair_tmp, pair_off, point_slot, n_points, max_points, sdf, grad, wn);
+    SPF_LAUNCH_CHECK("geo_point_reduce_kernel");
     return SPF_OK;
 }
 
-int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* jac, const int32_t* nbr,
-                             const int32_t* point_slot, const int32_t* n_points, int32_t max_points, int32_t k,
+int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* jac, const int32_t* nbr, const int32_t* point_slot,
+                             const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k,
                              float* g_feat_geo, void* stream) {
-    if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: bad sizes");
-    if (max_points == 0) return SPF_OK;
-    if (!g_sdf || !wn || !jac || !nbr || !g_feat_geo) return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: null pointer");
-    long long threads = (long long)max_points * 8 * 32;
+    if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: bad sizes");
+    if (max_pairs == 0) return SPF_OK;
+    if (!g_sdf || !wn || !jac || !nbr || !pair_off || !pair_point || !g_feat_geo)
+        return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: null pointer");
+    long long threads = (long long)max_pairs * 32;
     int blocks = spf::div_up(threads, 256);
     if (blocks > 8192) blocks = 8192;
-    geo_backward_latents_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_sdf, wn, jac, nbr, point_slot, n_points, max_points, k,
-                                                                         g_feat_geo);
+    geo_backward_latents_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_sdf, wn, jac, nbr, point_slot, pair_off, pair_point, n_pairs,
+                                                                         max_pairs, k, g_feat_geo);
     SPF_LAUNCH_CHECK("geo_backward_latents_kernel");
     return SPF_OK;
 }

@@ -384,6 +384,65 @@ __global__ void __launch_bounds__(256) compact_write_kernel(const uint8_t* __res
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_points = chunk_base + total;
 }
 
+// ---- pair list: rows of the MLP kernels are the VALID (point, neighbour) pairs, grouped by point ---------
+// (the reference's mask_to_batch_ray_idx, utils.py:172-183).  pair_off = exclusive scan of the per-point
+// neighbour counts; same two-launch chunked scan as the point compaction.
+__device__ __forceinline__ int nbr_count(const int32_t* __restrict__ row, int k) {
+    int c = 0;
+    for (int j = 0; j < k; ++j) c += row[j] >= 0;   // -1 padding is a suffix
+    return c;
+}
+
+__global__ void __launch_bounds__(256) pairs_count_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
+                                                          const int32_t* __restrict__ n_points, int max_points, int k,
+                                                          int32_t* __restrict__ chunk_counts) {
+    __shared__ int32_t wsum[4];
+    const int P = n_points ? min(*n_points, max_points) : max_points;
+    const int base = blockIdx.x * CMP_CHUNK + threadIdx.x * CMP_PER_THREAD;
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u) {
+        const int p = base + u;
+        if (p < P) cnt += nbr_count(nbr + (size_t)(point_slot ? point_slot[p] : p) * k, k);
+    }
+    int total;
+    block_excl_scan_256(cnt, total, wsum);
+    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) pairs_write_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
+                                                          const int32_t* __restrict__ n_points, int max_points, int k,
+                                                          const int32_t* __restrict__ chunk_counts, int32_t* __restrict__ pair_off,
+                                                          int32_t* __restrict__ pair_point, int32_t* __restrict__ n_pairs) {
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t wsum2[4];
+    const int P = n_points ? min(*n_points, max_points) : max_points;
+    int before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += chunk_counts[b];
+    int chunk_base;
+    block_excl_scan_256(before, chunk_base, wsum2);
+    const int base = blockIdx.x * CMP_CHUNK + threadIdx.x * CMP_PER_THREAD;
+    int c[CMP_PER_THREAD], cnt = 0;
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u) {
+        const int p = base + u;
+        c[u] = p < P ? nbr_count(nbr + (size_t)(point_slot ? point_slot[p] : p) * k, k) : 0;
+        cnt += c[u];
+    }
+    int total;
+    int q = chunk_base + block_excl_scan_256(cnt, total, wsum);
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u) {
+        const int p = base + u;
+        if (p <= P) {
+            pair_off[p] = q;              // p == P closes the list
+            if (p == P) *n_pairs = q;
+        }
+        for (int j = 0; j < c[u]; ++j) pair_point[q + j] = p;
+        q += c[u];
+    }
+}
+
 GridDev dev_view(const spf_grid* g) {
     GridDev d;
     d.ox = g->origin[0], d.oy = g->origin[1], d.oz = g->origin[2];
@@ -568,6 +627,19 @@ int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t
     SPF_LAUNCH_CHECK("compact_count_kernel");
     compact_write_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nslot, scratch, point_slot, slot_point, n_points);
     SPF_LAUNCH_CHECK("compact_write_kernel");
+    return SPF_OK;
+}
+
+int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t* n_points, int32_t max_points, int32_t k,
+                    int32_t* pair_off, int32_t* pair_point, int32_t* n_pairs, int32_t* scratch, void* stream_) {
+    if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_build_pairs: bad sizes");
+    if (!nbr || !pair_off || !pair_point || !n_pairs || !scratch) return spf::fail(SPF_EINVAL, "spf_build_pairs: null buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int chunks = spf::div_up((long long)max_points + 1, CMP_CHUNK);   // +1: the closing entry pair_off[P]
+    pairs_count_kernel<<<chunks, 256, 0, stream>>>(nbr, point_slot, n_points, max_points, k, scratch);
+    SPF_LAUNCH_CHECK("pairs_count_kernel");
+    pairs_write_kernel<<<chunks, 256, 0, stream>>>(nbr, point_slot, n_points, max_points, k, scratch, pair_off, pair_point, n_pairs);
+    SPF_LAUNCH_CHECK("pairs_write_kernel");
     return SPF_OK;
 }
 

@@ -133,20 +133,19 @@ class PointVolSDF(nn.Module):
 
     # ------------------------------------------------------------------ geometry at free points
     def _sdf_points(self, x, with_grad):
-        """x [M,3] -> dict(sdf [M] (1000 where no neighbour), valid u8 [M], nbr, point_slot, n_points, ...); no sync."""
+        """x [M,3] -> dict(sdf [M] (1000 where no neighbour), grad, valid u8 [M], pairs); no host sync."""
         grid = self._grid()
         x = x.contiguous()
         q = grid.query_dense(x.detach().unsqueeze(1), self.conf.k, self.conf.r, 1)
         point_slot, _, n_points = ops.compact_points(q["slot_valid"])
-        nbr = q["pidx"].view(-1, self.conf.k)
+        pl = ops.PairList(q["pidx"].view(-1, self.conf.k), point_slot, n_points)
         if with_grad:
-            sdf, grad, _ = ops.GeoSDF.apply(x, self.neural_feats_geometry, nbr, point_slot, n_points, self.neural_pts,
-                                            self._packed(), float(self.conf.rbf))
+            sdf, grad, _ = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(self.conf.rbf))
         else:
-            res = ops.geo_forward(x.detach(), nbr, point_slot, n_points, self.neural_pts, self.neural_feats_geometry.detach(),
-                                  self._packed(), float(self.conf.rbf), with_grad=False)
+            res = ops.geo_forward(x.detach(), pl, self.neural_pts, self.neural_feats_geometry.detach(), self._packed(),
+                                  float(self.conf.rbf), with_grad=False)
             sdf, grad = res["sdf"], None
-        return {"sdf": sdf, "grad": grad, "valid": q["slot_valid"].view(-1), "n_points": n_points}
+        return {"sdf": sdf, "grad": grad, "valid": q["slot_valid"].view(-1), "pairs": pl}
 
     def sdf_importance(self, inputs):
         """:348-421 — SDF at sampler points, 1000 where a point has no neighbour (callers wrap in no_grad)."""
@@ -181,13 +180,12 @@ class PointVolSDF(nn.Module):
         transmittance = torch.exp(-torch.cumsum(shifted, dim=-1))
         return alpha * transmittance
 
-    def _colors(self, rows, x, nbr, wn, point_slot, n_points, ray_dirs, SR):
+    def _colors(self, rows, x, wn, pl, n_pairs, ray_dirs, SR):
         """:325-346 on the P valid points (`rows` = their flat slot ids).  F_color + the RBF-weighted mean are
         the fused HIP kernels; the small per-point `R` head stays a PyTorch module.  [P,3]."""
         fc = self.F_color
         agg = ops.ColorAgg.apply(self.neural_feats_color, fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight,
-                                 fc[4].bias, fc[6].weight, fc[6].bias, x, nbr, wn, point_slot, n_points, self.neural_pts,
-                                 rows.shape[0])
+                                 fc[4].bias, fc[6].weight, fc[6].bias, x, wn, pl, self.neural_pts, rows.shape[0], n_pairs)
         dirs = ray_dirs[torch.div(rows, SR, rounding_mode="floor")]
         return self.R(torch.cat([self.view_encoding(dirs), agg], dim=-1))
 
@@ -211,23 +209,22 @@ class PointVolSDF(nn.Module):
         valid = q["slot_valid"].bool()                            # [R,SR]  == reference `mask`
         ray_mask = q["ray_valid"].bool()                          # [R]
         point_slot, _, n_points = ops.compact_points(q["slot_valid"])
-        nbr = q["pidx"].view(R * SR, k)
+        pl = ops.PairList(q["pidx"].view(R * SR, k), point_slot, n_points)
 
         # ---- filter_points (:207-239) on dense rows (HIP) ---------------------------------------
         z_slots, deltas, x = ops.filter_points(q["loc"], q["slot_valid"], cam_loc.detach(), ray_dirs.detach())
 
         # ---- geometry: sdf, d sdf/d x, normalised RBF weights (HIP) -----------------------------
-        sdf_flat, gradients, wn = ops.GeoSDF.apply(x, self.neural_feats_geometry, nbr, point_slot, n_points, self.neural_pts,
-                                                   self._packed(), float(conf.rbf))
+        sdf_flat, gradients, wn = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(conf.rbf))
         sdf = sdf_flat.view(R, SR)                                # gradients: [R*SR,3], zero rows where not a point
 
         # ---- colours (PyTorch ops on the P valid points; one host sync for P) -------------------
-        P = int(n_points.item())
+        P, n_pairs = pl.host_counts()
         rows = point_slot[:P].long()
-        self.stats = {"valid_points": P, "rays": R}
+        self.stats = {"valid_points": P, "pairs": n_pairs, "rays": R}
         colors = torch.zeros((R * SR, 3), device=dev)
         if P > 0:
-            colors = colors.index_put((rows,), self._colors(rows, x, nbr, wn, point_slot, n_points, ray_dirs, SR))
+            colors = colors.index_put((rows,), self._colors(rows, x, wn, pl, n_pairs, ray_dirs, SR))
         colors = colors.view(R, SR, 3)
 
         # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------

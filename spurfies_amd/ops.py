@@ -22,8 +22,8 @@ def profile_stop():
     global _prof
     rec, _prof = _prof or [], None
     torch.cuda.synchronize()
-    return [{"ms": e0.elapsed_time(e1), "pairs": int((wn > 0).sum().item()), "rows": rows, "with_grad": wg}
-            for e0, e1, wn, rows, wg in rec]
+    return [{"ms": e0.elapsed_time(e1), "pairs": int(npairs.item()), "rows": rows, "with_grad": wg}
+            for e0, e1, npairs, rows, wg in rec]
 
 
 
@@ -41,6 +41,36 @@ def compact_points(slot_valid):
     return point_slot, slot_point, n_points
 
 
+class PairList:
+    """Device-side lists of the valid points and of their (point, neighbour) pairs — the rows of the MLP kernels
+    (utils.py:96-113, 172-183 without the masked_select host syncs).  `counts` = [n_points, n_pairs] on the device."""
+
+    def __init__(self, nbr, point_slot, n_points):
+        rows, k = nbr.shape
+        dev = nbr.device
+        self.nbr, self.point_slot, self.k = nbr, point_slot, k
+        self.max_points = rows if point_slot is None else min(rows, point_slot.shape[0])
+        self.max_pairs = self.max_points * k
+        self.counts = torch.empty((2,), dtype=torch.int32, device=dev)
+        if n_points is None:
+            self.counts[0] = self.max_points
+        else:
+            self.counts[:1].copy_(n_points)
+        self.n_points, self.n_pairs = self.counts[:1], self.counts[1:]
+        self.pair_off = torch.empty((self.max_points + 1,), dtype=torch.int32, device=dev)
+        self.pair_point = torch.empty((self.max_pairs,), dtype=torch.int32, device=dev)
+        scratch = torch.empty((self.max_points // 2048 + 2,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_build_pairs(_lib.ptr(nbr), _lib.ptr(point_slot), _lib.ptr(self.n_points), self.max_points, k,
+                                                  _lib.ptr(self.pair_off), _lib.ptr(self.pair_point), _lib.ptr(self.n_pairs),
+                                                  _lib.ptr(scratch), _lib.stream_ptr()), "spf_build_pairs")
+
+    def host_counts(self):
+        """(P, n_pairs) on the host — ONE synchronising copy."""
+        c = self.counts.tolist()
+        return int(c[0]), int(c[1])
+
+
 def pack_geometry_weights(state: dict) -> torch.Tensor:
     """state: {'F_geometry.0.weight', ..., 'T.0.bias'} CUDA float32 tensors -> packed image."""
     names = ["F_geometry.0", "F_geometry.2", "F_geometry.4", "F_geometry.6", "F_geometry.8", "T.0"]
@@ -55,64 +85,64 @@ def pack_geometry_weights(state: dict) -> torch.Tensor:
     return packed
 
 
-def geo_forward(x, nbr, point_slot, n_points, pts, feat_geo, packed, rbf, with_grad, sdf_out=None):
-    """Rows = first dim of x / nbr.  Returns dict(sdf [rows] (1000 where not a valid point), wn [rows,8],
-    grad [rows,3] | None, jac [rows,8,32] | None)."""
-    rows, k = nbr.shape[0], nbr.shape[1]
+def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_out=None):
+    """Rows = first dim of x / nbr.  Returns dict(sdf [rows] (1000 where not a valid point), grad [rows,3] | None,
+    wn [max_pairs], jac [max_pairs,32] | None)."""
+    rows = pl.nbr.shape[0]
     dev = x.device
     sdf = sdf_out if sdf_out is not None else torch.full((rows,), SDF_FILL, dtype=torch.float32, device=dev)
-    wn = torch.zeros((rows, 8), dtype=torch.float32, device=dev)
+    wn = torch.empty((pl.max_pairs,), dtype=torch.float32, device=dev)
     grad = torch.zeros((rows, 3), dtype=torch.float32, device=dev) if with_grad else None
-    jac = torch.empty((rows, 8, 32), dtype=torch.float32, device=dev) if with_grad else None
-    max_points = rows if point_slot is None else min(rows, point_slot.shape[0])
+    jac = torch.empty((pl.max_pairs, 32), dtype=torch.float32, device=dev) if with_grad else None
+    tmp = torch.empty((pl.max_pairs, 5), dtype=torch.float32, device=dev)
     if _prof is not None:  # HIP events on the launch stream (torch's current stream is the one passed to the kernel)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().spf_geo_forward(_lib.ptr(x), _lib.ptr(nbr), _lib.ptr(point_slot), _lib.ptr(n_points), max_points, k,
-                                              _lib.ptr(pts), _lib.ptr(feat_geo), _lib.ptr(packed), float(rbf), _lib.ptr(sdf),
-                                              _lib.ptr(wn), _lib.ptr(grad), _lib.ptr(jac), _lib.stream_ptr()), "spf_geo_forward")
+        _lib.check(_lib.lib().spf_geo_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off), _lib.ptr(pl.pair_point),
+                                              _lib.ptr(pl.n_points), _lib.ptr(pl.n_pairs), pl.max_points, pl.max_pairs, pl.k, _lib.ptr(pts),
+                                              _lib.ptr(feat_geo), _lib.ptr(packed), float(rbf), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(wn),
+                                              _lib.ptr(jac), _lib.ptr(tmp), _lib.stream_ptr()), "spf_geo_forward")
     if _prof is not None:
         e1.record()
-        _prof.append((e0, e1, wn, rows, bool(with_grad)))
+        _prof.append((e0, e1, pl.n_pairs, rows, bool(with_grad)))
     return {"sdf": sdf, "wn": wn, "grad": grad, "jac": jac}
 
 
-def geo_backward_latents(g_sdf, wn, jac, nbr, point_slot, n_points, g_feat_geo):
-    rows, k = nbr.shape[0], nbr.shape[1]
-    max_points = rows if point_slot is None else min(rows, point_slot.shape[0])
+def geo_backward_latents(g_sdf, wn, jac, pl: "PairList", g_feat_geo):
     with torch.cuda.device(g_sdf.device):
-        _lib.check(_lib.lib().spf_geo_backward_latents(_lib.ptr(g_sdf), _lib.ptr(wn), _lib.ptr(jac), _lib.ptr(nbr), _lib.ptr(point_slot),
-                                                       _lib.ptr(n_points), max_points, k, _lib.ptr(g_feat_geo), _lib.stream_ptr()),
-                   "spf_geo_backward_latents")
+        _lib.check(_lib.lib().spf_geo_backward_latents(_lib.ptr(g_sdf), _lib.ptr(wn), _lib.ptr(jac), _lib.ptr(pl.nbr), _lib.ptr(pl.point_slot),
+                                                       _lib.ptr(pl.pair_off), _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), pl.max_pairs, pl.k,
+                                                       _lib.ptr(g_feat_geo), _lib.stream_ptr()), "spf_geo_backward_latents")
     return g_feat_geo
 
 
 class GeoSDF(torch.autograd.Function):
-    """(sdf, d sdf/d x, normalised RBF weights) through the fused kernel.  sdf is differentiable
+    """(sdf, d sdf/d x, normalised RBF weights per pair) through the fused kernel.  sdf is differentiable
     w.r.t. x (d sdf/d x is the kernel's `grad` output — RBF weights are detached in the reference,
     pointneus_disent.py:242) and w.r.t. the geometry latent table (scalar-output MLP:
     d sdf_j/d latent_j is the Jacobian row the forward sweep stored)."""
 
     @staticmethod
-    def forward(ctx, x, feat_geo, nbr, point_slot, n_points, pts, packed, rbf):
-        res = geo_forward(x.detach(), nbr, point_slot, n_points, pts, feat_geo.detach(), packed, rbf, with_grad=True)
-        ctx.save_for_backward(res["wn"], res["jac"], res["grad"], nbr, point_slot, n_points)
+    def forward(ctx, x, feat_geo, pl, pts, packed, rbf):
+        res = geo_forward(x.detach(), pl, pts, feat_geo.detach(), packed, rbf, with_grad=True)
+        ctx.save_for_backward(res["wn"], res["jac"], res["grad"])
+        ctx.pl = pl
         ctx.n_table = feat_geo.shape[0]
         ctx.mark_non_differentiable(res["grad"], res["wn"])
         return res["sdf"], res["grad"], res["wn"]
 
     @staticmethod
     def backward(ctx, g_sdf, _g_grad, _g_wn):
-        wn, jac, grad, nbr, point_slot, n_points = ctx.saved_tensors
+        wn, jac, grad = ctx.saved_tensors
         g_sdf = g_sdf.contiguous()
         g_x = g_feat = None
         if ctx.needs_input_grad[0]:
             g_x = g_sdf.unsqueeze(-1) * grad
         if ctx.needs_input_grad[1]:
             g_feat = torch.zeros((ctx.n_table, 32), dtype=torch.float32, device=g_sdf.device)
-            geo_backward_latents(g_sdf, wn, jac, nbr, point_slot, n_points, g_feat)
-        return g_x, g_feat, None, None, None, None, None, None
+            geo_backward_latents(g_sdf, wn, jac, ctx.pl, g_feat)
+        return g_x, g_feat, None, None, None, None
 
 
 class GatherRows(torch.autograd.Function):
@@ -199,50 +229,51 @@ class ColorAgg(torch.autograd.Function):
     (the last, linear layer through its rank structure: dW6 = g_agg^T (sum_j wn_j a3_j), K = P)."""
 
     @staticmethod
-    def forward(ctx, feat_col, w0, b0, w2, b2, w4, b4, w6, b6, x, nbr, wn, point_slot, n_points, pts, n_valid):
+    def forward(ctx, feat_col, w0, b0, w2, b2, w4, b4, w6, b6, x, wn, pl, pts, n_valid, n_pairs):
         dev = x.device
-        P = int(n_valid)
-        k = nbr.shape[1]
-        tiles = (P + 7) // 8
+        P, NP = int(n_valid), int(n_pairs)
+        tiles = (NP + 63) // 64
         rows = 64 * tiles
         packed = pack_color_weights([w0, b0, w2, b2, w4, b4, w6, b6])
-        agg = torch.empty((P, 256), dtype=torch.float32, device=dev)
+        agg = torch.zeros((P, 256), dtype=torch.float32, device=dev)
         train = any(ctx.needs_input_grad[:9])
         if train:
             bufs = [torch.empty((rows, 104), dtype=torch.float32, device=dev), torch.empty((rows, 256), dtype=torch.float32, device=dev),
-                    torch.empty((rows, 256), dtype=torch.float32, device=dev), torch.empty((tiles * 8, 256), dtype=torch.float32, device=dev),
+                    torch.empty((rows, 256), dtype=torch.float32, device=dev), torch.zeros((P, 256), dtype=torch.float32, device=dev),
                     torch.empty((tiles, 3, 512), dtype=torch.int32, device=dev)]
         else:
             bufs = [None] * 5
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().spf_color_forward(_lib.ptr(x), _lib.ptr(nbr), _lib.ptr(wn), _lib.ptr(point_slot), _lib.ptr(n_points), P, k,
-                                                    _lib.ptr(pts), _lib.ptr(feat_col.detach()), _lib.ptr(packed), _lib.ptr(agg),
+            _lib.check(_lib.lib().spf_color_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
+                                                    _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), NP, pl.k, _lib.ptr(pts),
+                                                    _lib.ptr(feat_col.detach()), _lib.ptr(packed), _lib.ptr(agg),
                                                     *[_lib.ptr(a) for a in bufs], _lib.stream_ptr()), "spf_color_forward")
         if train:
-            ctx.save_for_backward(nbr, wn, point_slot, n_points, packed, *bufs)
-            ctx.P, ctx.n_table = P, feat_col.shape[0]
+            ctx.save_for_backward(wn, packed, *bufs)
+            ctx.pl, ctx.NP, ctx.n_table = pl, NP, feat_col.shape[0]
         return agg
 
     @staticmethod
     def backward(ctx, g_agg):
-        nbr, wn, point_slot, n_points, packed, act0, act1, act2, agg3, masks = ctx.saved_tensors
+        wn, packed, act0, act1, act2, agg3, masks = ctx.saved_tensors
+        pl = ctx.pl
         dev = g_agg.device
-        P, k = ctx.P, nbr.shape[1]
         rows = act1.shape[0]
         G1, G2, G3 = (torch.empty((rows, 256), dtype=torch.float32, device=dev) for _ in range(3))
         g_bias = torch.zeros((3, 256), dtype=torch.float32, device=dev)
         g_feat = torch.zeros((ctx.n_table, 64), dtype=torch.float32, device=dev)
         g_agg = g_agg.contiguous()
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg), _lib.ptr(nbr), _lib.ptr(wn), _lib.ptr(point_slot), _lib.ptr(n_points), P, k,
-                                                     _lib.ptr(packed), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_bias),
-                                                     _lib.ptr(g_feat), _lib.stream_ptr()), "spf_color_backward")
+            _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
+                                                     _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), ctx.NP, pl.k, _lib.ptr(packed), _lib.ptr(masks),
+                                                     _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_bias), _lib.ptr(g_feat),
+                                                     _lib.stream_ptr()), "spf_color_backward")
         dw0_int = _wgrad(G1, act0)                                 # [256,104] in the kernels' internal column order
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
         dw0[:, _color_col_perm(dev)] = dw0_int[:, :103]
-        dw6 = g_agg.t() @ agg3[:P]                                 # last layer: rank structure, K = P
+        dw6 = g_agg.t() @ agg3                                     # last layer: rank structure, K = P
         grads = (g_feat, dw0, g_bias[0], _wgrad(G2, act1), g_bias[1], _wgrad(G3, act2), g_bias[2], dw6, g_agg.sum(0))
-        return grads + (None,) * 7
+        return grads + (None,) * 6
 
 
 def _wgrad(G, A, split=32):
@@ -250,7 +281,9 @@ def _wgrad(G, A, split=32):
     only a few workgroups; batching over `split` row blocks (rows is a multiple of 64) fills the chip
     (measured 0.43 ms vs 1.06 ms on MI355X, tools/wgrad_bench.py)."""
     rows = G.shape[0]
-    if rows % split or rows < 64 * split:
+    while split > 1 and rows % split:
+        split //= 2
+    if rows < 64 * split or split == 1:
         return G.t() @ A
     return torch.bmm(G.view(split, rows // split, G.shape[1]).transpose(1, 2), A.view(split, rows // split, A.shape[1])).sum(0)
 

@@ -49,7 +49,7 @@ def test_argument_validation_without_gpu(lib):
     cfg.kernel_size[:] = (3, 3, 3)
     assert lib.spf_grid_create(ctypes.byref(cfg), ctypes.byref(h)) == 0 and h.value
     assert lib.spf_grid_query(h, None, 4, 3, 9, 2.0, 2, None, None, None, None, None, None) == -22   # k > SPF_KMAX
-    assert lib.spf_geo_forward(None, None, None, None, 8, 8, None, None, None, 45.0, None, None, None, None, None) == -22
+    assert lib.spf_geo_forward(None, None, None, None, None, None, None, 8, 64, 9, None, None, None, 45.0, None, None, None, None, None, None) == -22
     assert lib.spf_render_forward(None, None, None, None, None, None, 4, 1000, None, None, None, None, None, None) == -22
     lib.spf_grid_destroy(h)
 

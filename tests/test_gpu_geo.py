@@ -40,8 +40,8 @@ def test_sdf_forward_and_gradient_match_oracle():
     xt = torch.from_numpy(x).cuda()
     q = grid.query_dense(xt.unsqueeze(1), cfg.k, cfg.r, 1)
     point_slot, slot_point, n_pts = ops.compact_points(q["slot_valid"])
-    nbr = q["pidx"].reshape(-1, cfg.k)
-    res = ops.geo_forward(xt, nbr, point_slot, n_pts, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
+    pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), point_slot, n_pts)
+    res = ops.geo_forward(xt, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
     # oracle: same points, torch CPU autograd
     ogrid = P.make_grid(cfg, st["neural_pts"])
     xo = torch.from_numpy(x).requires_grad_(True)
@@ -54,8 +54,14 @@ def test_sdf_forward_and_gradient_match_oracle():
     np.testing.assert_allclose(res["grad"].cpu().numpy()[v], g_o.numpy()[v], rtol=2e-4, atol=2e-5)
     assert float(res["grad"].cpu()[~valid_o].abs().max()) == 0.0
     # forward-only launch (sampler / eval mode) gives the same sdf bit for bit
-    res2 = ops.geo_forward(xt, nbr, point_slot, n_pts, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=False)
+    res2 = ops.geo_forward(xt, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=False)
     assert torch.equal(res2["sdf"], res["sdf"])
+    # pair bookkeeping (utils.py:172-183): counts and the exclusive scan
+    P_, NP_ = pl.host_counts()
+    nb = q["pidx"].reshape(-1, cfg.k)[point_slot[:P_].long()]
+    cnt = (nb >= 0).sum(1)
+    assert NP_ == int(cnt.sum()) and torch.equal(pl.pair_off[: P_ + 1].long().cpu(), torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0).cpu()]))
+    assert torch.equal(pl.pair_point[:NP_].long().cpu(), torch.repeat_interleave(torch.arange(P_), cnt.cpu()))
 
 
 def test_latent_gradient_matches_oracle():
@@ -66,8 +72,8 @@ def test_latent_gradient_matches_oracle():
     feat = dev["neural_feats_geometry"].clone().requires_grad_(True)
     q = grid.query_dense(xt.detach().unsqueeze(1), cfg.k, cfg.r, 1)
     point_slot, _, n_pts = ops.compact_points(q["slot_valid"])
-    nbr = q["pidx"].reshape(-1, cfg.k)
-    sdf, _, _ = ops.GeoSDF.apply(xt, feat, nbr, point_slot, n_pts, dev["neural_pts"], packed, cfg.rbf)
+    pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), point_slot, n_pts)
+    sdf, _, _ = ops.GeoSDF.apply(xt, feat, pl, dev["neural_pts"], packed, cfg.rbf)
     valid = q["slot_valid"].reshape(-1).bool()
     coef = torch.linspace(-1.0, 1.0, sdf.shape[0], device="cuda")
     (sdf * coef)[valid].sum().backward()
@@ -93,11 +99,12 @@ def test_full_size_linearity_property():
     def run(xx):
         q = grid.query_dense(xx.unsqueeze(1), cfg.k, cfg.r, 1)
         ps, _, n = ops.compact_points(q["slot_valid"])
-        return ops.geo_forward(xx, q["pidx"].reshape(-1, cfg.k), ps, n, dev["neural_pts"], dev["neural_feats_geometry"], packed,
-                               cfg.rbf, with_grad=False)["sdf"]
+        pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), ps, n)
+        return ops.geo_forward(xx, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=False)["sdf"]
 
     a, b = run(xt), run(xt[perm])
     assert torch.isfinite(a).all()
+    # a pair's SDF does not depend on which tile it lands in; the per-point mean is a fixed-order sum
     assert torch.equal(a[perm], b)
 
 
@@ -134,13 +141,13 @@ def test_color_agg_forward_backward_match_oracle():
     xt = torch.from_numpy(x).cuda()
     q = grid.query_dense(xt.unsqueeze(1), cfg.k, cfg.r, 1)
     point_slot, _, n_pts = ops.compact_points(q["slot_valid"])
-    nbr = q["pidx"].reshape(-1, cfg.k)
-    geo = ops.geo_forward(xt, nbr, point_slot, n_pts, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
-    P_ = int(n_pts.item())
+    pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), point_slot, n_pts)
+    geo = ops.geo_forward(xt, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
+    P_, NP_ = pl.host_counts()
     names = [f"F_color.{i}.{n}" for i in (0, 2, 4, 6) for n in ("weight", "bias")]
     params = [dev[n].clone().requires_grad_(True) for n in names]
     table = dev["neural_feats_color"].clone().requires_grad_(True)
-    agg = ops.ColorAgg.apply(table, *params, xt, nbr, geo["wn"], point_slot, n_pts, dev["neural_pts"], P_)
+    agg = ops.ColorAgg.apply(table, *params, xt, geo["wn"], pl, dev["neural_pts"], P_, NP_)
     coef = torch.randn((P_, 256), generator=torch.Generator().manual_seed(0)).cuda()
     (agg * coef).sum().backward()
     # oracle

@@ -41,17 +41,18 @@ def main():
         x = torch.from_numpy((pts[rng.integers(0, len(pts), n_q)] + rng.normal(0, 0.015, size=(n_q, 3))).astype(np.float32)).cuda()
         q = grid.query_dense(x.unsqueeze(1), 8, 2, 1)
         ps, _, n = ops.compact_points(q["slot_valid"])
-        P = int(n.item())
         nbr = q["pidx"].reshape(-1, 8)
-        pairs = int((nbr >= 0).sum().item())
+        pl = ops.PairList(nbr, ps, n)
+        P, pairs = pl.host_counts()
         t_knn = timeit(lambda: grid.query_dense(x.unsqueeze(1), 8, 2, 1))
         t_cmp = timeit(lambda: ops.compact_points(q["slot_valid"]))
-        t_f = timeit(lambda: ops.geo_forward(x, nbr, ps, n, dev["neural_pts"], dev["neural_feats_geometry"], packed, 45.0, False))
-        t_j = timeit(lambda: ops.geo_forward(x, nbr, ps, n, dev["neural_pts"], dev["neural_feats_geometry"], packed, 45.0, True))
+        t_pl = timeit(lambda: ops.PairList(nbr, ps, n))
+        t_f = timeit(lambda: ops.geo_forward(x, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, 45.0, False))
+        t_j = timeit(lambda: ops.geo_forward(x, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, 45.0, True))
         # algorithmic flops per padded row (8 per point): fwd 2*(35*256+3*256*256+256); jac adds 2*(3*256*256+256*35)
         f_fwd = 2.0 * (35 * 256 + 3 * 256 * 256 + 256)
         f_jac = 2.0 * (3 * 256 * 256 + 256 * 35)
-        out[n_q] = dict(P=P, pairs=pairs, knn_ms=t_knn, compact_ms=t_cmp, geo_fwd_ms=t_f, geo_fwd_jac_ms=t_j,
+        out[n_q] = dict(P=P, pairs=pairs, knn_ms=t_knn, compact_ms=t_cmp, pairs_ms=t_pl, geo_fwd_ms=t_f, geo_fwd_jac_ms=t_j,
                         fwd_tflops_pairs=pairs * f_fwd / t_f / 1e9, jac_tflops_pairs=pairs * (f_fwd + f_jac) / t_j / 1e9,
                         fwd_tflops_rows=P * 8 * f_fwd / t_f / 1e9)
         print(n_q, json.dumps(out[n_q]))
