@@ -138,7 +138,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # dominant kernel: geo_forward_kernel<true> of the main pass (the largest with-Jacobian launch per step)
+    # dominant kernel: geo_pairs_kernel<true> of the main pass (the largest with-Jacobian launch per step)
     main = [p for p in prof if p["with_grad"] and p["rows"] >= args.rays * 2]
     roof = None
     traffic = None   # HBM bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process)
@@ -146,7 +146,7 @@ def main():
     if os.path.exists(pmc):
         rec = json.load(open(pmc))
         if rec["config"] == {"points": args.points, "rays": args.rays}:
-            hit = [v for k, v in rec["kernels"].items() if "geo_forward_kernel<true>" in k]
+            hit = [v for k, v in rec["kernels"].items() if "geo_pairs_kernel<true>" in k]
             traffic = hit[0]["hbm_bytes_max_corrected"] if hit else None
     if main:
         ms = sum(p["ms"] for p in main)
@@ -154,7 +154,7 @@ def main():
         ach = pairs * (F_FWD + F_JAC) / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-                if traffic else None, "kernel": "geo_forward_kernel<true>", "launches": len(main), "avg_ms": ms / len(main),
+                if traffic else None, "kernel": "geo_pairs_kernel<true> (+ geo_point_reduce_kernel, < 1 % of the launch)", "launches": len(main), "avg_ms": ms / len(main),
                 "pairs_per_launch": pairs / len(main)}
     res = {
         "metric": "ray-samples/sec (kNN+SDF+render, train step)", "value": SAMPLES_PER_RAY * rays_total * args.steps / dt,

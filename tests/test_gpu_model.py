@@ -97,3 +97,43 @@ def test_state_dict_keys_match_reference_contract():
     want |= {f"F_geometry.{i}.{n}" for i in (0, 2, 4, 6, 8) for n in ("weight", "bias")}
     want |= {f"T.0.{n}" for n in ("weight", "bias")} | {f"R.{i}.{n}" for i in (0, 2, 4) for n in ("weight", "bias")}
     assert set(model.state_dict().keys()) == want
+
+
+def test_three_optimisation_steps_track_the_oracle():
+    """SURVEY.md §8(c) G6 (+ Adam): three full steps (forward, loss, backward, clip 1.0, Adam lr 5e-4, cosine schedule) on
+    the GPU stay on the trajectory of the oracle driven by the same optimiser recipe on the CPU."""
+    from oracle import path as P
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.train import TrainStep
+
+    scene = syn.make_scene(2500, seed=9)
+    model = build_model(scene)
+    step = TrainStep(model)
+    st = P.load_state(scene["state"])
+    cfg = P.PathConfig(ranges=tuple(scene["ranges"]))
+    grid = P.make_grid(cfg, st["neural_pts"])
+    names = [k for k, v in st.items() if v.requires_grad]
+    opt = torch.optim.Adam([{"params": [], "lr": 1e-2}, {"params": [st[k] for k in names], "lr": 5e-4}])
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=100_000, eta_min=3e-4)
+    g = torch.Generator().manual_seed(77)
+    K = torch.from_numpy(scene["intrinsics"])[None]
+    for it in range(3):
+        uv = torch.from_numpy(syn.make_pixels(48, g))[None]
+        pose = torch.from_numpy(scene["poses"][it % 3])[None]
+        rgb, mask = torch.rand((48, 3), generator=g), (torch.rand((48,), generator=g) > 0.2).float()
+        torch.manual_seed(100 + it)
+        losses, _ = step({"intrinsics": K.cuda(), "uv": uv.cuda(), "pose": pose.cuda(), "local_data": None},
+                         {"rgb": rgb[None].cuda(), "mask": mask[None, :, None].repeat(1, 1, 3).cuda()})
+        torch.manual_seed(100 + it)
+        _, olosses, _ = P.train_step_grads({"intrinsics": K, "uv": uv, "pose": pose}, rgb, mask, st, cfg, grid=grid)
+        torch.nn.utils.clip_grad_norm_([st[k] for k in names], 1.0)
+        opt.step()
+        sched.step()
+        np.testing.assert_allclose(losses["loss"].item(), olosses["loss"].item(), rtol=3e-3, err_msg=f"step {it}")
+    sd = model.state_dict()
+    for k in names:
+        a, b = sd[k].detach().cpu().numpy(), st[k].detach().numpy()
+        moved = np.abs(b - np.asarray(scene["state"][k])).max()
+        assert moved > 0, k
+        # after 3 Adam steps every touched entry moved by ~3*lr; the two trajectories must agree far below that
+        np.testing.assert_allclose(a, b, rtol=0, atol=0.1 * moved + 1e-7, err_msg=k)
