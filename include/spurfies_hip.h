@@ -187,6 +187,28 @@ int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, 
                        float* g_bias, float* g_feat_color, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Radiance head R — replaces the second half of get_color, spurfies/model/pointneus_disent.py:338-346
+ * (view encoding with multires 3, concat, R: 277 -> 256 -> 256 -> 3, sigmoid) and its backward.
+ * Rows are the valid POINTS (tiles of 64).
+ * ---------------------------------------------------------------------------------------- */
+int64_t spf_rhead_packed_floats(void);
+int spf_rhead_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4,
+                   const float* b4, float* packed, void* stream);
+
+/* colors[row,3] = sigmoid(R([direnc3(ray_dirs[row / SR]) | agg[p]])) for the p-th valid point, row = point_slot[p]
+ * (rows of invalid points untouched: pre-fill with 0).  Training mode (direnc != NULL) stores, per point
+ * (T = 64*ceil(P/64) rows): direnc [T,24] (21 + 3 zeros), act1, act2 [T,256], masks [T/64,2,512]. */
+int spf_rhead_forward(const float* agg, const float* ray_dirs, const int32_t* point_slot, const int32_t* n_points,
+                      int32_t max_points, int32_t SR, const float* packed, float* colors, float* direnc,
+                      float* act1, float* act2, uint32_t* masks, void* stream);
+
+/* Given g_colors[row,3]: writes G1, G2 [T,256] (pre-activation gradients; dW_l = G_l^T act_{l-1} are plain GEMMs),
+ * g_agg [T,256] (rows >= P are scratch), and adds into g_small [1283] = [db0 (256) | db2 (256) | dW4 (3x256) | db4 (3)] (ZEROED by the caller). */
+int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t* point_slot, const int32_t* n_points,
+                       int32_t max_points, const float* packed, const float* act2, const uint32_t* masks,
+                       float* G1, float* G2, float* g_agg, float* g_small, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * VolSDF error-bounded sampler — replaces UniformSampler.get_z_vals (spurfies/model/ray_sampler.py:33-59),
  * ErrorBoundSampler_pn.get_z_vals (:377-574) and get_error_bound (:576-588).  The random numbers are
  * drawn by the host from the CPU generator, as the reference does, and passed in.

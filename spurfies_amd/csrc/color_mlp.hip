@@ -152,9 +152,11 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
     const int ntiles = (NP + 63) / 64;
-    const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+    const float* packed0 = packed;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const float* packed = launder(packed0);
+        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
         // ---- gather: thread = (row, quarter): 16 latent floats each; quarter 0 also does posenc -----
         {
             const int row = tid >> 2, q4 = tid & 3;
@@ -285,9 +287,11 @@ color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
     const int ntiles = (NP + 63) / 64;
-    const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+    const float* packed0 = packed;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const float* packed = launder(packed0);
+        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
         const size_t tbase = (size_t)tile * 64 * 256;
         // ---- G4[row] = wn[row] * g_agg[p]  (the last layer is linear; agg = sum_j wn_j f_j) ---------
         {

@@ -108,9 +108,11 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
     const int ntiles = (NP + 63) / 64;
-    const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+    const float* packed0 = packed;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const float* packed = launder(packed0);
+        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
         // ---- gather: thread = (row, quarter of the 32-d latent) ---------------------------------
         {
             const int row = tid >> 2, q4 = tid & 3;

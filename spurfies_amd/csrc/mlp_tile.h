@@ -12,14 +12,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDA = 260;     // LDS row stride in floats (1040 B: 16-B aligned, breaks the 256-B bank period)
 constexpr int T_HID = 32;    // 256/8
 
+// Re-materialise a (wave-uniform) pointer inside the persistent tile loop: keeps hipcc from hoisting the loop-invariant
+// weight / bias loads of one tile iteration out of the loop and parking them in > 100 VGPRs (spills).
+template <typename T>
+__device__ __forceinline__ const T* launder(const T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 __device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// acc[mt][nt] += X[mt*32.., :] * B  for this wave's 64 output columns.  wp: [T][2][64] float4.
-template <int T>
+// acc[mt][nt] += X[mt*32.., :] * B  for this wave's 64 output columns.  wp: [T][2][64] float4.  LD = LDS row stride.
+template <int T, int LD = LDA>
 __device__ __forceinline__ void gemm_rows64(const float* X, const f32x4* wp, int lane, f32x16 (&acc)[2][2]) {
     const int i = lane & 31, h = lane >> 5;
-    const float* a0p = X + i * LDA + 4 * h;
-    const float* a1p = a0p + 32 * LDA;
+    const float* a0p = X + i * LD + 4 * h;
+    const float* a1p = a0p + 32 * LD;
     const f32x4* bp = wp + lane;
     f32x4 b0 = bp[0], b1 = bp[64];
 #pragma unroll 4

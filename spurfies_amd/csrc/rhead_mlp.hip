@@ -1,0 +1,375 @@
+// Radiance head `R` (K5b of DESIGN.md): per valid POINT, [dir-enc3(ray dir) | agg] (277) -> 256 -> 256 -> 3 -> sigmoid,
+// forward and the data-gradient chain of the backward, on the fp32 matrix cores.
+//
+// Replaces the second half of get_color, spurfies/model/pointneus_disent.py:338-346 (view encoding
+// embedder.py:26-30 with multires 3, torch.concat, three cuBLAS GEMMs, sigmoid) and autograd's backward.
+//
+// Tile = 64 consecutive valid points (rows).  Internal column order is [agg (256) | dir-enc (21) | pad] so that the
+// agg rows load 16-B aligned; spf_rhead_pack folds the permutation into the packed first-layer weights.
+// Weight gradients of the two wide layers are library GEMMs over stored [P,256] buffers (G_l^T act_{l-1}); the
+// 3 x 256 last layer's and all bias gradients are accumulated in-kernel.
+#include "mlp_tile.h"
+
+namespace {
+using namespace spf;
+
+constexpr int R_IN = 277;      // 21 dir-enc + 256 agg (pointneus_disent.py:343-344: [encoded_dir | agg])
+constexpr int T_RIN = 35;
+constexpr int LDR = 284;       // LDS row stride (1136 B): 284 mod 64 = 28 -> ds_read_b128 conflict-free
+constexpr int DIR_FREQ = 3;    // get_embedder(multires=3), pointneus_disent.py:73-75
+
+constexpr int SZ_RFW1 = 4 * T_RIN * 2 * 64 * 4;
+constexpr int SZ_RHH = 4 * T_HID * 2 * 64 * 4;
+constexpr int RO_FW1 = 0;
+constexpr int RO_FW2 = RO_FW1 + SZ_RFW1;
+constexpr int RO_BW2 = RO_FW2 + SZ_RHH;    // g_a1 = G2 * W2
+constexpr int RO_BWA = RO_BW2 + SZ_RHH;    // g_agg = G1 * W1[:, 21:277]
+constexpr int RO_B1 = RO_BWA + SZ_RHH;
+constexpr int RO_B2 = RO_B1 + 256;
+constexpr int RO_W3 = RO_B2 + 256;         // [3][256]
+constexpr int RO_B3 = RO_W3 + 768;         // [3] (+1 pad)
+constexpr int R_PACKED = RO_B3 + 4;
+
+constexpr int RL_X = 0;
+constexpr int RL_G3 = RL_X + 64 * LDR;     // [64][4] per-row dL/d(pre-sigmoid)
+constexpr int RL_ROW = RL_G3 + 256;        // [64] slot row of each point (int bits), -1 = padding
+constexpr int RL_TOTAL = RL_ROW + 64;
+
+__host__ __device__ __forceinline__ int r_orig(int k) { return k < 256 ? 21 + k : k - 256; }  // internal column -> reference column
+
+struct RPackArgs {
+    const float *w0, *b0, *w2, *b2, *w4, *b4;
+};
+
+__global__ void rhead_pack_kernel(RPackArgs a, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R_PACKED) return;
+    float val = 0.f;
+    if (e < RO_B1) {
+        int region, local;
+        if (e < RO_FW2) { region = 0; local = e; }
+        else { region = 1 + (e - RO_FW2) / SZ_RHH; local = (e - RO_FW2) % SZ_RHH; }
+        const int T = region == 0 ? T_RIN : T_HID;
+        const int j = local & 3, ln = (local >> 2) & 63, nt = (local >> 8) & 1;
+        const int t = (local >> 9) % T, w = (local >> 9) / T;
+        const int n = 64 * w + 32 * nt + (ln & 31), kk = 8 * t + 4 * (ln >> 5) + j;
+        switch (region) {
+            case 0: val = kk < R_IN ? a.w0[n * R_IN + r_orig(kk)] : 0.f; break;
+            case 1: val = a.w2[n * 256 + kk]; break;
+            case 2: val = a.w2[kk * 256 + n]; break;            // g_a1[i] = sum_o G2[o] W2[o][i]
+            default: val = a.w0[kk * R_IN + 21 + n]; break;     // g_agg[i] = sum_o G1[o] W0[o][21 + i]
+        }
+    } else if (e < RO_W3) {
+        const int local = e - RO_B1;
+        val = (local < 256 ? a.b0 : a.b2)[local & 255];
+    } else if (e < RO_B3) {
+        val = a.w4[e - RO_W3];
+    } else if (e < RO_B3 + 3) {
+        val = a.b4[e - RO_B3];
+    }
+    out[e] = val;
+}
+
+template <bool STORE>
+__device__ __forceinline__ void r_fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave, int lane,
+                                               float* act_g, uint32_t* mask_g) {
+    const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+    const float bv[2] = {bias[c0], bias[c0 + 32]};
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[m][n][r] + bv[n];
+                const bool pos = v > 0.f;
+                bits |= (pos ? 1u : 0u) << (n * 16 + r);
+                v = pos ? v : v * 0.01f;
+                const int row = m * 32 + row_of(r, h);
+                X[row * LDR + c0 + 32 * n] = v;
+                if (STORE) act_g[row * 256 + c0 + 32 * n] = v;
+            }
+        if (STORE) mask_g[(wave * 2 + m) * 64 + lane] = bits;
+    }
+}
+
+template <bool STORE>
+__global__ void __launch_bounds__(256, 2)
+rhead_forward_kernel(const float* __restrict__ agg, const float* __restrict__ ray_dirs, const int32_t* __restrict__ point_slot,
+                     const int32_t* __restrict__ n_points_dev, int max_points, int SR, const float* packed, float* __restrict__ colors,
+                     float* __restrict__ direnc, float* __restrict__ act1, float* __restrict__ act2, uint32_t* __restrict__ masks) {
+    __shared__ __attribute__((aligned(16))) float smem[RL_TOTAL];
+    float* X = smem + RL_X;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    const int ntiles = (P + 63) / 64;
+    const float* packed0 = packed;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const float* packed = launder(packed0);
+        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+        {   // gather: thread = (row, quarter): 64 agg floats each; quarter 0 also encodes the view direction
+            const int row = tid >> 2, q4 = tid & 3;
+            const int p = tile * 64 + row;
+            const bool ok = p < P;
+            const f32x4* src = reinterpret_cast<const f32x4*>(agg + (size_t)(ok ? p : 0) * 256 + q4 * 64);
+#pragma unroll 4
+            for (int u = 0; u < 16; ++u) {
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) v = src[u];
+                *reinterpret_cast<f32x4*>(X + row * LDR + q4 * 64 + 4 * u) = v;
+            }
+            if (q4 == 0) {
+                float* e = X + row * LDR + 256;
+                int srow = -1;
+                if (ok) {
+                    srow = point_slot ? point_slot[p] : p;
+                    const float* dv = ray_dirs + (size_t)(srow / SR) * 3;
+                    const float d[3] = {dv[0], dv[1], dv[2]};
+                    e[0] = d[0]; e[1] = d[1]; e[2] = d[2];
+                    float fr = 1.f;
+#pragma unroll
+                    for (int l = 0; l < DIR_FREQ; ++l) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float a = d[c] * fr;
+                            e[3 + 6 * l + c] = sinf(a);
+                            e[6 + 6 * l + c] = cosf(a);
+                        }
+                        fr *= 2.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 21; ++c) e[c] = 0.f;
+                }
+                e[21] = 0.f; e[22] = 0.f; e[23] = 0.f;
+                if (STORE) {
+#pragma unroll
+                    for (int c4 = 0; c4 < 6; ++c4)
+                        *reinterpret_cast<f32x4*>(direnc + (size_t)(tile * 64 + row) * 24 + 4 * c4) = *reinterpret_cast<const f32x4*>(e + 4 * c4);
+                }
+                reinterpret_cast<int*>(smem + RL_ROW)[row] = srow;
+            }
+        }
+        __syncthreads();
+        const size_t tb = (size_t)tile * 64 * 256;
+        uint32_t* mk = STORE ? masks + (size_t)tile * 2 * 512 : nullptr;
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        gemm_rows64<T_RIN, LDR>(X, pk4 + (RO_FW1 / 4) + wave * (T_RIN * 128), lane, acc);
+        __syncthreads();
+        r_fwd_epilogue<STORE>(X, acc, packed + RO_B1, wave, lane, STORE ? act1 + tb : nullptr, mk);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID, LDR>(X, pk4 + (RO_FW2 / 4) + wave * (T_HID * 128), lane, acc);
+        __syncthreads();
+        r_fwd_epilogue<STORE>(X, acc, packed + RO_B2, wave, lane, STORE ? act2 + tb : nullptr, STORE ? mk + 512 : nullptr);
+        __syncthreads();
+        {   // 256 -> 3 + sigmoid: 4 threads per row, interleaved float4 chunks
+            const int row = tid >> 2, q4 = tid & 3;
+            const f32x4* w3 = pk4 + RO_W3 / 4;
+            float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int mth = 0; mth < 16; ++mth) {
+                const int c4 = q4 + 4 * mth;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(X + row * LDR + 4 * c4);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 v = w3[c * 64 + c4];
+                    s[c] += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
+                }
+            }
+            const int srow = reinterpret_cast<const int*>(smem + RL_ROW)[row];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                s[c] += __shfl_xor(s[c], 1);
+                s[c] += __shfl_xor(s[c], 2);
+                if (q4 == 0 && srow >= 0) colors[(size_t)srow * 3 + c] = 1.f / (1.f + expf(-(s[c] + packed[RO_B3 + c])));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// backward epilogue: G_l = g_a * lrelu'(h_l); write X and G_l, add the column sums to the bias gradient
+__device__ __forceinline__ void r_bwd_epilogue(float* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t* __restrict__ mask_g,
+                                               float* __restrict__ g_out, float* __restrict__ g_bias) {
+    const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+    float cs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const uint32_t bits = mask_g[(wave * 2 + m) * 64 + lane];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m * 32 + row_of(r, h);
+                float v = acc[m][n][r];
+                v = ((bits >> (n * 16 + r)) & 1u) ? v : v * 0.01f;
+                X[row * LDR + c0 + 32 * n] = v;
+                g_out[row * 256 + c0 + 32 * n] = v;
+                cs[n] += v;
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const float t = cs[n] + __shfl_xor(cs[n], 32);
+        if (h == 0) atomicAdd(&g_bias[c0 + 32 * n], t);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restrict__ colors, const int32_t* __restrict__ point_slot,
+                      const int32_t* __restrict__ n_points_dev, int max_points, const float* packed, const float* __restrict__ act2,
+                      const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ g_agg,
+                      float* __restrict__ g_small /* [256 db1 | 256 db2 | 768 dW3 | 3 db3] */) {
+    __shared__ __attribute__((aligned(16))) float smem[RL_TOTAL];
+    float* X = smem + RL_X;
+    float* s_g3 = smem + RL_G3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    const int ntiles = (P + 63) / 64;
+    const float* packed0 = packed;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const float* packed = launder(packed0);
+        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+        const size_t tb = (size_t)tile * 64 * 256;
+        if (tid < 64) {   // dL/d(pre-sigmoid) = g_c * c (1 - c)
+            const int p = tile * 64 + tid;
+            float g[3] = {0.f, 0.f, 0.f};
+            if (p < P) {
+                const int srow = point_slot ? point_slot[p] : p;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float cc = colors[(size_t)srow * 3 + c];
+                    g[c] = g_colors[(size_t)srow * 3 + c] * cc * (1.f - cc);
+                }
+            }
+            s_g3[tid * 4] = g[0]; s_g3[tid * 4 + 1] = g[1]; s_g3[tid * 4 + 2] = g[2]; s_g3[tid * 4 + 3] = 0.f;
+        }
+        __syncthreads();
+        {   // dW3[c][col] += sum_rows g3[row][c] a2[row][col]; db3[c] += sum_rows g3[row][c]   (thread = column)
+            float a0 = 0.f, a1 = 0.f, a2v = 0.f;
+            const int rows_here = min(64, P - tile * 64);
+            for (int row = 0; row < rows_here; ++row) {
+                const float a = act2[tb + row * 256 + tid];
+                a0 += s_g3[row * 4] * a;
+                a1 += s_g3[row * 4 + 1] * a;
+                a2v += s_g3[row * 4 + 2] * a;
+            }
+            atomicAdd(&g_small[512 + tid], a0);
+            atomicAdd(&g_small[512 + 256 + tid], a1);
+            atomicAdd(&g_small[512 + 512 + tid], a2v);
+            if (tid < 3) {
+                float s = 0.f;
+                for (int row = 0; row < 64; ++row) s += s_g3[row * 4 + tid];
+                atomicAdd(&g_small[1280 + tid], s);
+            }
+        }
+        const uint32_t* mk = masks + (size_t)tile * 2 * 512;
+        {   // G2 = (g3 W3) * lrelu'(h2), formed directly in accumulator layout
+            const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+            float w3[2][3];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) w3[n][c] = packed[RO_W3 + c * 256 + c0 + 32 * n];
+            float cs[2] = {0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const uint32_t bits = mk[512 + (wave * 2 + m) * 64 + lane];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m * 32 + row_of(r, h);
+                        float v = s_g3[row * 4] * w3[n][0] + s_g3[row * 4 + 1] * w3[n][1] + s_g3[row * 4 + 2] * w3[n][2];
+                        v = ((bits >> (n * 16 + r)) & 1u) ? v : v * 0.01f;
+                        X[row * LDR + c0 + 32 * n] = v;
+                        G2[tb + row * 256 + c0 + 32 * n] = v;
+                        cs[n] += v;
+                    }
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float t = cs[n] + __shfl_xor(cs[n], 32);
+                if (h == 0) atomicAdd(&g_small[256 + c0 + 32 * n], t);
+            }
+        }
+        __syncthreads();
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane, acc);
+        __syncthreads();
+        r_bwd_epilogue(X, acc, wave, lane, mk, G1 + tb, g_small);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BWA / 4) + wave * (T_HID * 128), lane, acc);
+        {   // g_agg[p][col]  (the buffer is padded to whole tiles: no bounds test)
+            const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+            float* ga = g_agg + tb + c0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ga[(m * 32 + row_of(r, h)) * 256 + 32 * n] = acc[m][n][r];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t spf_rhead_packed_floats(void) { return R_PACKED; }
+
+int spf_rhead_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4, float* packed,
+                   void* stream) {
+    if (!w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !packed) return spf::fail(SPF_EINVAL, "spf_rhead_pack: null pointer");
+    RPackArgs a{w0, b0, w2, b2, w4, b4};
+    rhead_pack_kernel<<<spf::div_up(R_PACKED, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
+    SPF_LAUNCH_CHECK("rhead_pack_kernel");
+    return SPF_OK;
+}
+
+int spf_rhead_forward(const float* agg, const float* ray_dirs, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
+                      int32_t SR, const float* packed, float* colors, float* direnc, float* act1, float* act2, uint32_t* masks, void* stream) {
+    if (max_points < 0 || SR < 1) return spf::fail(SPF_EINVAL, "spf_rhead_forward: bad sizes");
+    if (max_points == 0) return SPF_OK;
+    if (!agg || !ray_dirs || !packed || !colors) return spf::fail(SPF_EINVAL, "spf_rhead_forward: null pointer");
+    const bool store = direnc != nullptr;
+    if (store && (!act1 || !act2 || !masks)) return spf::fail(SPF_EINVAL, "spf_rhead_forward: training buffers must be given together");
+    const int tiles = spf::div_up(max_points, 64);
+    const int blocks = tiles < 512 ? tiles : 512;
+    if (store)
+        rhead_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(agg, ray_dirs, point_slot, n_points, max_points, SR, packed, colors, direnc,
+                                                                            act1, act2, masks);
+    else
+        rhead_forward_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(agg, ray_dirs, point_slot, n_points, max_points, SR, packed, colors,
+                                                                             nullptr, nullptr, nullptr, nullptr);
+    SPF_LAUNCH_CHECK("rhead_forward_kernel");
+    return SPF_OK;
+}
+
+int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
+                       const float* packed, const float* act2, const uint32_t* masks, float* G1, float* G2, float* g_agg, float* g_small,
+                       void* stream) {
+    if (max_points < 0) return spf::fail(SPF_EINVAL, "spf_rhead_backward: bad sizes");
+    if (max_points == 0) return SPF_OK;
+    if (!g_colors || !colors || !packed || !act2 || !masks || !G1 || !G2 || !g_agg || !g_small)
+        return spf::fail(SPF_EINVAL, "spf_rhead_backward: null pointer");
+    const int tiles = spf::div_up(max_points, 64);
+    const int blocks = tiles < 512 ? tiles : 512;
+    rhead_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_colors, colors, point_slot, n_points, max_points, packed, act2, masks, G1, G2,
+                                                                   g_agg, g_small);
+    SPF_LAUNCH_CHECK("rhead_backward_kernel");
+    return SPF_OK;
+}
+
+}  // extern "C"

@@ -180,14 +180,14 @@ class PointVolSDF(nn.Module):
         transmittance = torch.exp(-torch.cumsum(shifted, dim=-1))
         return alpha * transmittance
 
-    def _colors(self, rows, x, wn, pl, n_pairs, ray_dirs, SR):
-        """:325-346 on the P valid points (`rows` = their flat slot ids).  F_color + the RBF-weighted mean are
-        the fused HIP kernels; the small per-point `R` head stays a PyTorch module.  [P,3]."""
-        fc = self.F_color
+    def _colors(self, n_valid, x, wn, pl, n_pairs, ray_dirs, SR):
+        """:325-346 — colours of the P valid points, written at their slot rows of a dense [R*SR,3] array (0 elsewhere).
+        F_color + RBF-weighted mean and the R head are fused HIP kernels (spf_color_*, spf_rhead_*)."""
+        fc, rh = self.F_color, self.R
         agg = ops.ColorAgg.apply(self.neural_feats_color, fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight,
-                                 fc[4].bias, fc[6].weight, fc[6].bias, x, wn, pl, self.neural_pts, rows.shape[0], n_pairs)
-        dirs = ray_dirs[torch.div(rows, SR, rounding_mode="floor")]
-        return self.R(torch.cat([self.view_encoding(dirs), agg], dim=-1))
+                                 fc[4].bias, fc[6].weight, fc[6].bias, x, wn, pl, self.neural_pts, n_valid, n_pairs)
+        return ops.RHead.apply(agg, rh[0].weight, rh[0].bias, rh[2].weight, rh[2].bias, rh[4].weight, rh[4].bias,
+                               ray_dirs.detach().contiguous(), pl.point_slot, pl.n_points, SR, x.shape[0])
 
     # ------------------------------------------------------------------ forward (:614-892)
     def forward(self, input, fast=-1):
@@ -222,9 +222,7 @@ class PointVolSDF(nn.Module):
         P, n_pairs = pl.host_counts()
         rows = point_slot[:P].long()
         self.stats = {"valid_points": P, "pairs": n_pairs, "rays": R}
-        colors = torch.zeros((R * SR, 3), device=dev)
-        if P > 0:
-            colors = colors.index_put((rows,), self._colors(rows, x, wn, pl, n_pairs, ray_dirs, SR))
+        colors = self._colors(P, x, wn, pl, n_pairs, ray_dirs, SR) if P > 0 else torch.zeros((R * SR, 3), device=dev)
         colors = colors.view(R, SR, 3)
 
         # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------

@@ -390,3 +390,62 @@ def sampler_finish(z_samples, z_vals, sel, near, far, cam_loc, ray_dirs):
                                                  _lib.ptr(cam_loc), _lib.ptr(ray_dirs), R, _lib.ptr(z_out), _lib.ptr(pts), _lib.stream_ptr()),
                    "spf_sampler_finish")
     return z_out, pts
+
+
+# ---- radiance head R -------------------------------------------------------------------------------
+def pack_rhead_weights(ws):
+    args = [t.detach().contiguous().float() for t in ws]
+    dev = args[0].device
+    packed = torch.empty((int(_lib.lib().spf_rhead_packed_floats()),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_rhead_pack(*[_lib.ptr(a) for a in args], _lib.ptr(packed), _lib.stream_ptr()), "spf_rhead_pack")
+    return packed
+
+
+class RHead(torch.autograd.Function):
+    """colors [rows,3] = sigmoid(R([direnc3(ray dir) | agg])) on the P valid points (pointneus_disent.py:338-346), written
+    at the points' slot rows (0 elsewhere).  Forward and the data-gradient chain are HIP kernels; the two wide layers'
+    weight gradients are library GEMMs over [P,256] buffers."""
+
+    @staticmethod
+    def forward(ctx, agg, w0, b0, w2, b2, w4, b4, ray_dirs, point_slot, n_points, SR, n_rows):
+        dev = agg.device
+        P = agg.shape[0]
+        tiles = (P + 63) // 64
+        T = 64 * tiles
+        packed = pack_rhead_weights([w0, b0, w2, b2, w4, b4])
+        colors = torch.zeros((n_rows, 3), dtype=torch.float32, device=dev)
+        train = any(ctx.needs_input_grad[:7])
+        if train:
+            bufs = [torch.empty((T, 24), dtype=torch.float32, device=dev), torch.empty((T, 256), dtype=torch.float32, device=dev),
+                    torch.empty((T, 256), dtype=torch.float32, device=dev), torch.empty((tiles, 2, 512), dtype=torch.int32, device=dev)]
+        else:
+            bufs = [None] * 4
+        agg_c = agg.detach().contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_rhead_forward(_lib.ptr(agg_c), _lib.ptr(ray_dirs), _lib.ptr(point_slot), _lib.ptr(n_points), P, int(SR),
+                                                    _lib.ptr(packed), _lib.ptr(colors), *[_lib.ptr(b) for b in bufs], _lib.stream_ptr()),
+                       "spf_rhead_forward")
+        if train:
+            ctx.save_for_backward(agg_c, colors, point_slot, n_points, packed, *bufs)
+        return colors
+
+    @staticmethod
+    def backward(ctx, g_colors):
+        agg, colors, point_slot, n_points, packed, direnc, act1, act2, masks = ctx.saved_tensors
+        dev = g_colors.device
+        P, T = agg.shape[0], act1.shape[0]
+        G1 = torch.empty((T, 256), dtype=torch.float32, device=dev)
+        G2 = torch.empty((T, 256), dtype=torch.float32, device=dev)
+        g_agg = torch.empty((T, 256), dtype=torch.float32, device=dev)
+        g_small = torch.zeros((1283,), dtype=torch.float32, device=dev)
+        g_colors = g_colors.contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_rhead_backward(_lib.ptr(g_colors), _lib.ptr(colors), _lib.ptr(point_slot), _lib.ptr(n_points), P, _lib.ptr(packed),
+                                                     _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_small),
+                                                     _lib.stream_ptr()), "spf_rhead_backward")
+        G1p, G2p = G1[:P], G2[:P]
+        dw0 = torch.cat([G1p.t() @ direnc[:P, :21], G1p.t() @ agg], dim=1)        # reference column order [dir-enc | agg]
+        dw2 = G2p.t() @ act1[:P]
+        return (g_agg[:P], dw0, g_small[:256], dw2, g_small[256:512], g_small[512:1280].view(3, 256), g_small[1280:1283],
+                None, None, None, None, None)

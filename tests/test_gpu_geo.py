@@ -168,3 +168,35 @@ def test_color_agg_forward_backward_match_oracle():
     for n, p_ in zip(names, params):
         g = st[n].grad
         np.testing.assert_allclose(p_.grad.cpu().numpy(), g.numpy(), rtol=2e-3, atol=2e-4 * float(g.abs().max()), err_msg=n)
+
+
+def test_rhead_forward_backward_match_torch():
+    """Fused R head (pointneus_disent.py:338-346) vs the oracle's torch ops: colours, d/d agg, weight and bias gradients."""
+    from spurfies_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    P_, R, SR = 1000, 40, 80
+    st = P.load_state(syn.make_mlp_weights(seed=3))
+    names = [f"R.{i}.{n}" for i in (0, 2, 4) for n in ("weight", "bias")]
+    params = [st[n].detach().cuda().requires_grad_(True) for n in names]
+    agg = (torch.randn((P_, 256), generator=g) * 0.5)
+    dirs = torch.nn.functional.normalize(torch.randn((R, 3), generator=g), dim=-1)
+    slots = torch.sort(torch.randperm(R * SR, generator=g)[:P_])[0].to(torch.int32)
+    coef = torch.randn((P_, 3), generator=g)
+    agg_g = agg.cuda().requires_grad_(True)
+    n_pts = torch.tensor([P_], dtype=torch.int32, device="cuda")
+    colors = ops.RHead.apply(agg_g, *params, dirs.cuda(), slots.cuda(), n_pts, SR, R * SR)
+    (colors[slots.long().cuda()] * coef.cuda()).sum().backward()
+    # oracle ops on the CPU
+    agg_o = agg.clone().requires_grad_(True)
+    for n in names:
+        st[n].requires_grad_(True)
+    d_pts = dirs[torch.div(slots.long(), SR, rounding_mode="floor")]
+    col_o = torch.sigmoid(P.mlp(torch.cat([P.posenc(d_pts, 3), agg_o], -1), st, "R"))
+    (col_o * coef).sum().backward()
+    np.testing.assert_allclose(colors[slots.long().cuda()].detach().cpu().numpy(), col_o.detach().numpy(), rtol=2e-5, atol=2e-6)
+    assert float(colors.detach().abs().sum()) == pytest.approx(float(colors[slots.long().cuda()].detach().abs().sum()))
+    np.testing.assert_allclose(agg_g.grad.cpu().numpy(), agg_o.grad.numpy(), rtol=5e-4, atol=1e-6)
+    for n, p_ in zip(names, params):
+        gr = st[n].grad
+        np.testing.assert_allclose(p_.grad.cpu().numpy(), gr.numpy(), rtol=2e-3, atol=2e-4 * float(gr.abs().max()), err_msg=n)
