@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (config/ours.yaml:14 num_pixels)")
     ap.add_argument("--points", type=int, default=10000, help="neural points (DTU-like cloud)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync", action="store_true", help="default (reference-shaped) step with one host read-back per step")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     return ap.parse_args()
 
@@ -113,7 +114,7 @@ def main():
     conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
     model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
     model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
-    step = TrainStep(model)
+    step = TrainStep(model, sync_free=not args.sync)
     rays_total = args.rays * world
     batches = make_batches(scene, args.warmup + args.steps, rays_total, rank, world, device)
 
@@ -163,7 +164,8 @@ def main():
         "config": {"workload": f"DTU scan24-shaped synthetic scene: {args.points} neural points, {args.rays} rays/GPU/step x "
                                f"(128 sampler + 98 main) samples, fast=1 optimisation step (fwd+bwd+clip+Adam)",
                    "rays_per_gpu": args.rays, "neural_points": args.points, "k": 8, "max_shading_pts": 80,
-                   "parallelism": f"ray-sharded dp{world}", "valid_points_last_step": model.stats.get("valid_points")},
+                   "parallelism": f"ray-sharded dp{world}", "valid_points_last_step": model.stats.get("valid_points", int(model.stats["counts"][0].item()) if "counts" in model.stats else None),
+                   "host_syncs_per_step": 1 if args.sync else 0},
         "roofline": roof,
         "loss_last": float(losses["loss"].item()),
     }

@@ -265,6 +265,16 @@ int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float
                         float* g_sdf, float* g_colors, float* g_beta, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Weight-gradient GEMM with a device-side row count — replaces autograd's AddmmBackward GEMMs for the
+ * nn.Linear layers of F_color / R (spurfies/model/pointneus_disent.py:76-107).
+ *   dW[256, 0:C] (leading dimension ldw) += G[0:rows, 256]^T * A[0:rows, 0:C] (leading dimension lda),
+ * rows = min(*n_rows, max_rows) read on the device (NULL: max_rows).  C in {256 | multiple of 4 <= 128 | <= 32};
+ * workspace: spf_wgrad_workspace_floats(C) floats (per-workgroup partial slabs, summed in a fixed order). */
+int64_t spf_wgrad_workspace_floats(int32_t C);
+int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows,
+              float* dW, int32_t ldw, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Latent tables
  * ---------------------------------------------------------------------------------------- */
 

@@ -68,14 +68,18 @@ def sharded_loss(loss_mod, out, ground_truth, group=None):
     mask_gt = ground_truth["mask"].to(dev).squeeze()[:, 0][..., None]
     R_loc = out["rgb_values"].shape[0]
     g = out.get("grad_theta")
-    P_loc = 0 if g is None else g.shape[0]
+    if "eikonal_sum" in out:                     # sync-free mode: sum and count were formed on the device
+        eik_sum, P_loc = out["eikonal_sum"], out["point_count"].float()
+    else:
+        eik_sum = ((g.norm(2, dim=1) - 1) ** 2).sum() if g is not None else torch.tensor(0.0, device=dev)
+        P_loc = torch.tensor(float(0 if g is None else g.shape[0]), device=dev)
     pseudo_cnt = out.get("pseudo_count", torch.tensor(1.0, device=dev))
-    counts = torch.stack([torch.tensor(float(R_loc), device=dev), torch.tensor(float(P_loc), device=dev), pseudo_cnt.float()])
+    counts = torch.stack([torch.tensor(float(R_loc), device=dev), P_loc, pseudo_cnt.float()])
     all_reduce_sum(counts, group)
     R_tot, P_tot, ps_tot = counts[0], counts[1].clamp(min=1), counts[2]
     zero = torch.tensor(0.0, device=dev)
     res = {"rgb_loss": (out["rgb_values"] - rgb_gt).abs().sum() / (3.0 * R_tot)}
-    res["eikonal_loss"] = ((g.norm(2, dim=1) - 1) ** 2).sum() / P_tot if g is not None else zero
+    res["eikonal_loss"] = eik_sum / P_tot
     res["tv_loss"] = out["tv_loss"] / G if loss_mod.tv_weight > 0 else zero
     wsum = out["weights"].sum(-1, keepdim=True).clip(1e-3, 1.0 - 1e-3)
     res["mask_loss"] = F.binary_cross_entropy(wsum, mask_gt, reduction="sum") / R_tot

@@ -34,7 +34,10 @@ class VolSDFLoss(nn.Module):
         zero = torch.tensor(0.0, device=dev)
         out = {"rgb_loss": self.get_rgb_loss(model_outputs["rgb_values"], rgb_gt)}
         g = model_outputs.get("grad_theta")
-        out["eikonal_loss"] = self.get_eikonal_loss(g) if g is not None else zero
+        if "eikonal_value" in model_outputs:        # sync-free mode: the model formed the mean on the device
+            out["eikonal_loss"] = model_outputs["eikonal_value"].reshape(())
+        else:
+            out["eikonal_loss"] = self.get_eikonal_loss(g) if g is not None else zero
         out["tv_loss"] = model_outputs["tv_loss"] if ("tv_loss" in model_outputs and self.tv_weight > 0) else zero
         if "weights" in model_outputs:
             wsum = model_outputs["weights"].sum(-1, keepdim=True)

@@ -69,6 +69,7 @@ class PointVolSDF(nn.Module):
         self._packed_key = None
         self._tv_graph = None
         self.stats = {}
+        self.sync_free = False   # training only: static shapes, no host synchronisation (spurfies_amd/train.py sets it)
 
     # ------------------------------------------------------------------ initialisation (:116-205)
     @staticmethod
@@ -181,13 +182,17 @@ class PointVolSDF(nn.Module):
         return alpha * transmittance
 
     def _colors(self, n_valid, x, wn, pl, n_pairs, ray_dirs, SR):
+        """n_valid / n_pairs = None selects the sync-free (worst-case buffers, device-side counts) mode."""
+        return self._colors_impl(n_valid, x, wn, pl, n_pairs, ray_dirs, SR)
+
+    def _colors_impl(self, n_valid, x, wn, pl, n_pairs, ray_dirs, SR):
         """:325-346 — colours of the P valid points, written at their slot rows of a dense [R*SR,3] array (0 elsewhere).
         F_color + RBF-weighted mean and the R head are fused HIP kernels (spf_color_*, spf_rhead_*)."""
         fc, rh = self.F_color, self.R
         agg = ops.ColorAgg.apply(self.neural_feats_color, fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight,
                                  fc[4].bias, fc[6].weight, fc[6].bias, x, wn, pl, self.neural_pts, n_valid, n_pairs)
         return ops.RHead.apply(agg, rh[0].weight, rh[0].bias, rh[2].weight, rh[2].bias, rh[4].weight, rh[4].bias,
-                               ray_dirs.detach().contiguous(), pl.point_slot, pl.n_points, SR, x.shape[0])
+                               ray_dirs.detach().contiguous(), pl.point_slot, pl.n_points, SR, x.shape[0], n_valid is None)
 
     # ------------------------------------------------------------------ forward (:614-892)
     def forward(self, input, fast=-1):
@@ -219,10 +224,16 @@ class PointVolSDF(nn.Module):
         sdf = sdf_flat.view(R, SR)                                # gradients: [R*SR,3], zero rows where not a point
 
         # ---- colours (PyTorch ops on the P valid points; one host sync for P) -------------------
-        P, n_pairs = pl.host_counts()
-        rows = point_slot[:P].long()
-        self.stats = {"valid_points": P, "pairs": n_pairs, "rays": R}
-        colors = self._colors(P, x, wn, pl, n_pairs, ray_dirs, SR) if P > 0 else torch.zeros((R * SR, 3), device=dev)
+        static = self.sync_free and self.training
+        if static:       # no host round trip: worst-case buffers, counts stay on the device
+            P, n_pairs, rows = 1, None, None
+            self.stats = {"rays": R, "counts": pl.counts}
+            colors = self._colors(None, x, wn, pl, None, ray_dirs, SR)
+        else:
+            P, n_pairs = pl.host_counts()
+            rows = point_slot[:P].long()
+            self.stats = {"valid_points": P, "pairs": n_pairs, "rays": R}
+            colors = self._colors(P, x, wn, pl, n_pairs, ray_dirs, SR) if P > 0 else torch.zeros((R * SR, 3), device=dev)
         colors = colors.view(R, SR, 3)
 
         # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------
@@ -255,6 +266,14 @@ class PointVolSDF(nn.Module):
             g = gradients.view(R, SR, 3)
             nrm = torch.where(valid.unsqueeze(-1), g / g.norm(2, -1, keepdim=True), torch.zeros(1, device=dev))
             output["normal_map"] = torch.sum(weights.unsqueeze(-1) * nrm, 1).detach()
+        elif static:
+            # mean over the valid points of (|d sdf/dx| - 1)^2 (loss.py:47-49), formed on the device; its gradient w.r.t. every
+            # trainable tensor is exactly zero, so it is a value only
+            gn = gradients.view(R, SR, 3).norm(2, dim=-1)
+            output["eikonal_sum"] = torch.where(valid, (gn - 1) ** 2, torch.zeros_like(gn)).sum()
+            output["point_count"] = pl.n_points[0]
+            output["eikonal_value"] = output["eikonal_sum"] / pl.n_points[0].clamp(min=1)
+            output["grad_theta"] = None
         else:
             output["grad_theta"] = gradients[rows] if P > 0 else None
         return output

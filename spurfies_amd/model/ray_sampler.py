@@ -66,6 +66,8 @@ class ErrorBoundSampler_pn(RaySampler):
         self.add_tiny = add_tiny
         self.last_iters = 0
         self.last_points = None
+        self.draws = None   # sync-free / graph mode: {'t_rand' [R,128], 'u' [R,N_samples], 'sel' int32 [N_extra]} device tensors the
+        #                     caller fills from the CPU generator (same calls, same order) before every step
         # Lemma-2 constant exactly as the reference forms it in float32 (ray_sampler.py:389)
         self._bound_coef = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
         self._lin = {}
@@ -88,7 +90,11 @@ class ErrorBoundSampler_pn(RaySampler):
         max_total_iters = fast if fast >= 0 else self.max_total_iters
         beta0 = model.density.get_beta().detach().reshape(1).contiguous()
         n0 = self.N_samples_eval
-        t_rand = torch.rand((R, n0)).to(dev) if model.training else None      # CPU generator, as the reference (:55)
+        ext = self.draws if (self.draws is not None and model.training) else None
+        if ext is not None:
+            t_rand = ext["t_rand"]
+        else:
+            t_rand = torch.rand((R, n0)).to(dev) if model.training else None  # CPU generator, as the reference (:55)
         z_vals, points = ops.sampler_uniform(self._linspace(n0, dev), t_rand, cam_loc, ray_dirs, self.near, self.far)
         samples, samples_idx, sdf, beta = z_vals, None, None, None
         total_iters, not_converge = 0, True
@@ -113,7 +119,10 @@ class ErrorBoundSampler_pn(RaySampler):
                 N, u = self.N_samples_eval, self._linspace(self.N_samples_eval, dev)
             else:
                 N = self.N_samples
-                u = self._linspace(N, dev) if not model.training else torch.rand([R, N]).to(dev).contiguous()
+                if not model.training:
+                    u = self._linspace(N, dev)
+                else:
+                    u = ext["u"] if ext is not None else torch.rand([R, N]).to(dev).contiguous()
             samples, beta, zm, mi = ops.sampler_iter(z_vals, sdf, beta, beta0, self.eps, self._bound_coef, iters_left, more, self.add_tiny, u, N)
             if more:
                 z_vals, samples_idx = zm, mi.long()
@@ -122,14 +131,17 @@ class ErrorBoundSampler_pn(RaySampler):
         if total_iters == 0:                                     # fast=0: the reference then takes `samples = z_vals`
             samples = z_vals
         if self.N_samples_extra > 0:
-            if model.training:
-                sel = torch.randperm(z_vals.shape[1])[: self.N_samples_extra]
+            if ext is not None:
+                sel = ext["sel"]
+            elif model.training:
+                sel = torch.randperm(z_vals.shape[1])[: self.N_samples_extra].to(torch.int32).to(dev)
             else:
-                sel = torch.linspace(0, z_vals.shape[1] - 1, self.N_samples_extra).long()
-            sel = sel.to(torch.int32).to(dev)
+                sel = torch.linspace(0, z_vals.shape[1] - 1, self.N_samples_extra).long().to(torch.int32).to(dev)
         else:
             sel = None
         z_out, self.last_points = ops.sampler_finish(samples.contiguous(), z_vals, sel, self.near, self.far, cam_loc, ray_dirs)
+        if ext is not None:
+            return z_out, None                                            # the caller drew (and dropped) the eikonal index
         idx = torch.randint(z_out.shape[-1], (z_out.shape[0],)).to(dev)   # consumes the generator like :562
         z_samples_eik = torch.gather(z_out, 1, idx.unsqueeze(-1))
         return z_out, z_samples_eik

@@ -230,8 +230,11 @@ class ColorAgg(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feat_col, w0, b0, w2, b2, w4, b4, w6, b6, x, wn, pl, pts, n_valid, n_pairs):
+        """n_valid / n_pairs: host ints (buffers sized exactly), or None = sync-free mode: worst-case buffers, every
+        kernel (incl. the wgrad GEMMs) reads the counts from device memory."""
         dev = x.device
-        P, NP = int(n_valid), int(n_pairs)
+        ctx.static = n_valid is None
+        P, NP = (pl.max_points, pl.max_pairs) if ctx.static else (int(n_valid), int(n_pairs))
         tiles = (NP + 63) // 64
         rows = 64 * tiles
         packed = pack_color_weights([w0, b0, w2, b2, w4, b4, w6, b6])
@@ -268,12 +271,29 @@ class ColorAgg(torch.autograd.Function):
                                                      _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), ctx.NP, pl.k, _lib.ptr(packed), _lib.ptr(masks),
                                                      _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_bias), _lib.ptr(g_feat),
                                                      _lib.stream_ptr()), "spf_color_backward")
-        dw0_int = _wgrad(G1, act0)                                 # [256,104] in the kernels' internal column order
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
-        dw0[:, _color_col_perm(dev)] = dw0_int[:, :103]
-        dw6 = g_agg.t() @ agg3                                     # last layer: rank structure, K = P
-        grads = (g_feat, dw0, g_bias[0], _wgrad(G2, act1), g_bias[1], _wgrad(G3, act2), g_bias[2], dw6, g_agg.sum(0))
+        if ctx.static:   # row counts stay on the device
+            dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs)[:, :103]
+            dw2, dw4 = wgrad(G2, act1, pl.n_pairs), wgrad(G3, act2, pl.n_pairs)
+            dw6 = wgrad(g_agg, agg3, pl.n_points)
+            db6 = wgrad(g_agg, _ones_col(g_agg.shape[0], dev), pl.n_points, C=1)[:, 0]
+        else:
+            dw0[:, _color_col_perm(dev)] = _wgrad(G1, act0)[:, :103]   # [256,104] comes in the kernels' internal column order
+            dw2, dw4 = _wgrad(G2, act1), _wgrad(G3, act2)
+            dw6 = g_agg.t() @ agg3                                 # last layer: rank structure, K = P
+            db6 = g_agg.sum(0)
+        grads = (g_feat, dw0, g_bias[0], dw2, g_bias[1], dw4, g_bias[2], dw6, db6)
         return grads + (None,) * 6
+
+
+_ones = {}
+
+
+def _ones_col(n, dev):
+    key = (dev.index, n)
+    if key not in _ones:
+        _ones[key] = torch.ones((n, 4), dtype=torch.float32, device=dev)
+    return _ones[key]
 
 
 def _wgrad(G, A, split=32):
@@ -408,8 +428,10 @@ class RHead(torch.autograd.Function):
     weight gradients are library GEMMs over [P,256] buffers."""
 
     @staticmethod
-    def forward(ctx, agg, w0, b0, w2, b2, w4, b4, ray_dirs, point_slot, n_points, SR, n_rows):
+    def forward(ctx, agg, w0, b0, w2, b2, w4, b4, ray_dirs, point_slot, n_points, SR, n_rows, static=False):
+        """agg has exactly P rows (host-known), or — static=True — worst-case rows with the count read on the device."""
         dev = agg.device
+        ctx.static = static
         P = agg.shape[0]
         tiles = (P + 63) // 64
         T = 64 * tiles
@@ -444,8 +466,34 @@ class RHead(torch.autograd.Function):
             _lib.check(_lib.lib().spf_rhead_backward(_lib.ptr(g_colors), _lib.ptr(colors), _lib.ptr(point_slot), _lib.ptr(n_points), P, _lib.ptr(packed),
                                                      _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_small),
                                                      _lib.stream_ptr()), "spf_rhead_backward")
-        G1p, G2p = G1[:P], G2[:P]
-        dw0 = torch.cat([G1p.t() @ direnc[:P, :21], G1p.t() @ agg], dim=1)        # reference column order [dir-enc | agg]
-        dw2 = G2p.t() @ act1[:P]
+        if ctx.static:
+            dw0 = torch.zeros((256, 277), dtype=torch.float32, device=dev)        # reference column order [dir-enc | agg]
+            wgrad(G1, direnc, n_points, C=21, out=dw0)
+            wgrad(G1, agg, n_points, out=dw0[:, 21:])
+            dw2 = wgrad(G2, act1, n_points)
+        else:
+            G1p, G2p = G1[:P], G2[:P]
+            dw0 = torch.cat([G1p.t() @ direnc[:P, :21], G1p.t() @ agg], dim=1)
+            dw2 = G2p.t() @ act1[:P]
         return (g_agg[:P], dw0, g_small[:256], dw2, g_small[256:512], g_small[512:1280].view(3, 256), g_small[1280:1283],
-                None, None, None, None, None)
+                None, None, None, None, None, None)
+
+
+_wgrad_ws = {}
+
+
+def wgrad(G, A, n_rows, C=None, out=None, ldw=None):
+    """out[256, :C] += G[:rows]^T A[:rows, :C] with the row count `n_rows` (int32 device tensor or None) read on the device."""
+    dev = G.device
+    C = A.shape[1] if C is None else C
+    if out is None:
+        out = torch.zeros((256, C), dtype=torch.float32, device=dev)
+    ldw = out.stride(0) if ldw is None else ldw
+    nws = int(_lib.lib().spf_wgrad_workspace_floats(C))
+    key = (dev.index, nws)
+    if key not in _wgrad_ws:
+        _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_wgrad(_lib.ptr(G), _lib.ptr(A), A.stride(0), C, _lib.ptr(n_rows), min(G.shape[0], A.shape[0]), _lib.ptr(out), ldw,
+                                        _lib.ptr(_wgrad_ws[key]), _lib.stream_ptr()), "spf_wgrad")
+    return out

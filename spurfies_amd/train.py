@@ -20,8 +20,13 @@ def default_loss() -> VolSDFLoss:
 
 
 class TrainStep:
-    def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None):
+    def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False):
+        """sync_free: static shapes and device-side counts everywhere — no host synchronisation inside the step (the
+        default path reads [P, n_pairs] back once per step to size the colour buffers exactly)."""
         self.model = model
+        self.sync_free = sync_free
+        model.sync_free = sync_free
+        self._draws = None
         self.loss = loss or default_loss()
         model.freeze_prior()                                    # train.py:151-154
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -39,6 +44,8 @@ class TrainStep:
         self.model.train()
         model_input = dict(model_input)
         model_input["iter_step"] = self.iter_step
+        if self.sync_free:
+            self._refresh_draws(model_input["uv"].shape[1], model_input["uv"].device)
         out = self.model(model_input, fast=1)
         if self.world > 1:
             losses = sdist.sharded_loss(self.loss, out, ground_truth, self.group)
@@ -57,3 +64,21 @@ class TrainStep:
         self.scheduler.step()
         self.iter_step += 1
         return losses, out
+
+    def _refresh_draws(self, R, dev):
+        """The reference draws its random numbers from the CPU generator and moves them (ray_sampler.py:55,514,550,562); in
+        sync-free mode the same calls are issued here, in the same order, into persistent device buffers the sampler reads."""
+        s = self.model.ray_sampler
+        n0, N, Ne, M = s.N_samples_eval, s.N_samples, s.N_samples_extra, s.N_samples + 2 + s.N_samples_extra
+        if self._draws is None or self._draws["t_rand"].shape[0] != R:
+            self._draws = {"t_rand": torch.empty((R, n0), device=dev), "u": torch.empty((R, N), device=dev),
+                           "sel": torch.empty((Ne,), dtype=torch.int32, device=dev)}
+            self._pinned = {"t_rand": torch.empty((R, n0)).pin_memory(), "u": torch.empty((R, N)).pin_memory(),
+                            "sel": torch.empty((Ne,), dtype=torch.int32).pin_memory()}
+        torch.rand((R, n0), out=self._pinned["t_rand"])
+        torch.rand((R, N), out=self._pinned["u"])
+        self._pinned["sel"].copy_(torch.randperm(n0)[:Ne])
+        torch.randint(M, (R,))                       # the unused eikonal index (:562) — keeps the generator in step
+        for k, v in self._draws.items():
+            v.copy_(self._pinned[k], non_blocking=True)
+        s.draws = self._draws

@@ -137,3 +137,30 @@ def test_three_optimisation_steps_track_the_oracle():
         assert moved > 0, k
         # after 3 Adam steps every touched entry moved by ~3*lr; the two trajectories must agree far below that
         np.testing.assert_allclose(a, b, rtol=0, atol=0.1 * moved + 1e-7, err_msg=k)
+
+
+def test_sync_free_step_equals_default_step():
+    """The static-shape / device-side-count path (no host synchronisation) reproduces the default step: same loss, same
+    gradients (up to float-atomic order) and the same CPU-generator consumption."""
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.train import TrainStep
+
+    scene = syn.make_scene(3000, seed=12)
+    g = torch.Generator().manual_seed(3)
+    uv = torch.from_numpy(syn.make_pixels(96, g))[None].cuda()
+    K, pose = torch.from_numpy(scene["intrinsics"])[None].cuda(), torch.from_numpy(scene["poses"][2])[None].cuda()
+    gt = {"rgb": torch.rand((96, 3), generator=g)[None].cuda(), "mask": (torch.rand((96,), generator=g) > 0.2).float()[None, :, None].repeat(1, 1, 3).cuda()}
+    res = []
+    for sync_free in (False, True):
+        model = build_model(scene)
+        step = TrainStep(model, sync_free=sync_free)
+        torch.manual_seed(5)
+        losses, out = step({"intrinsics": K, "uv": uv, "pose": pose, "local_data": None}, gt)
+        after = torch.rand(1).item()              # generator state after the step
+        res.append((losses, step.flat.buffer.clone(), after, out))
+    (l0, g0, a0, o0), (l1, g1, a1, o1) = res
+    assert a0 == a1
+    for k in l0:
+        np.testing.assert_allclose(l1[k].item(), l0[k].item(), rtol=1e-5, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(o1["rgb_values"].detach().cpu().numpy(), o0["rgb_values"].detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=2e-3, atol=2e-5 * float(g0.abs().max()))
