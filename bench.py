@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--points", type=int, default=10000, help="neural points (DTU-like cloud)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync", action="store_true", help="default (reference-shaped) step with one host read-back per step")
+    ap.add_argument("--no-graph", action="store_true", help="sync-free step, launches issued eagerly instead of one hipGraph replay")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     return ap.parse_args()
 
@@ -114,7 +115,8 @@ def main():
     conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
     model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
     model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
-    step = TrainStep(model, sync_free=not args.sync)
+    use_graph = not args.sync and not args.no_graph and world == 1
+    step = TrainStep(model, sync_free=not args.sync, use_graph=use_graph)
     rays_total = args.rays * world
     batches = make_batches(scene, args.warmup + args.steps, rays_total, rank, world, device)
 
@@ -126,13 +128,22 @@ def main():
     torch.manual_seed(1 + rank * 0)   # identical CPU draws on every rank (stratified jitter is per ray anyway)
     for i in range(args.warmup):
         step(*batches[i])
-    ops.profile_start()
+    if not use_graph:
+        ops.profile_start()          # HIP events around every spf_geo_forward launch of the timed region
     sync()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         losses, out = step(*batches[i])
     sync()
     dt = time.perf_counter() - t0
+    loss_last = float(losses["loss"].item())
+    if use_graph:
+        # events cannot be placed inside a hipGraph replay: time the dominant kernel over eager forward+backward passes of
+        # the SAME batches right after the timed region (same kernels, same inputs; no optimiser step)
+        ops.profile_start()
+        for i in range(args.warmup, args.warmup + args.steps):
+            step._forward_backward(dict(batches[i][0]), batches[i][1])
+        sync()
     prof = ops.profile_stop()
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
@@ -155,7 +166,9 @@ def main():
         ach = pairs * (F_FWD + F_JAC) / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-                if traffic else None, "kernel": "geo_pairs_kernel<true> (+ geo_point_reduce_kernel, < 1 % of the launch)", "launches": len(main), "avg_ms": ms / len(main),
+                if traffic else None, "kernel": "geo_pairs_kernel<true> (+ geo_point_reduce_kernel, < 1 % of the launch)",
+                "timing": ("HIP events over eager passes of the timed batches, right after the timed region (events cannot sit inside a "
+                           "hipGraph replay)") if use_graph else "HIP events over the timed region", "launches": len(main), "avg_ms": ms / len(main),
                 "pairs_per_launch": pairs / len(main)}
     res = {
         "metric": "ray-samples/sec (kNN+SDF+render, train step)", "value": SAMPLES_PER_RAY * rays_total * args.steps / dt,
@@ -165,9 +178,10 @@ def main():
                                f"(128 sampler + 98 main) samples, fast=1 optimisation step (fwd+bwd+clip+Adam)",
                    "rays_per_gpu": args.rays, "neural_points": args.points, "k": 8, "max_shading_pts": 80,
                    "parallelism": f"ray-sharded dp{world}", "valid_points_last_step": model.stats.get("valid_points", int(model.stats["counts"][0].item()) if "counts" in model.stats else None),
-                   "host_syncs_per_step": 1 if args.sync else 0},
+                   "host_syncs_per_step": 1 if args.sync else 0,
+                   "launch": "hipGraph replay (fwd+loss+bwd) + eager clip/Adam" if use_graph else "eager"},
         "roofline": roof,
-        "loss_last": float(losses["loss"].item()),
+        "loss_last": loss_last,
     }
     if rank == 0:
         res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(scene, args.cpu_rays)

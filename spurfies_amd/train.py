@@ -20,11 +20,16 @@ def default_loss() -> VolSDFLoss:
 
 
 class TrainStep:
-    def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False):
+    def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False, use_graph=False):
         """sync_free: static shapes and device-side counts everywhere — no host synchronisation inside the step (the
-        default path reads [P, n_pairs] back once per step to size the colour buffers exactly)."""
+        default path reads [P, n_pairs] back once per step to size the colour buffers exactly).
+        use_graph (implies sync_free): forward + loss + backward (~230 kernel launches) are captured once into a hipGraph
+        and replayed; the gradient all-reduce, clipping and Adam stay eager."""
         self.model = model
+        sync_free = sync_free or use_graph
         self.sync_free = sync_free
+        self.use_graph = use_graph
+        self._graph = None
         model.sync_free = sync_free
         self._draws = None
         self.loss = loss or default_loss()
@@ -40,19 +45,12 @@ class TrainStep:
         self.skipped = 0
 
     def __call__(self, model_input, ground_truth):
-        """model_input: {'intrinsics','uv','pose','local_data'} for THIS rank's rays; returns the loss dict."""
+        """model_input: {'intrinsics','uv','pose','local_data'} for THIS rank's rays; returns (loss dict, model outputs)."""
         self.model.train()
-        model_input = dict(model_input)
-        model_input["iter_step"] = self.iter_step
-        if self.sync_free:
-            self._refresh_draws(model_input["uv"].shape[1], model_input["uv"].device)
-        out = self.model(model_input, fast=1)
-        if self.world > 1:
-            losses = sdist.sharded_loss(self.loss, out, ground_truth, self.group)
+        if self.use_graph:
+            losses, out = self._graphed_forward_backward(model_input, ground_truth)
         else:
-            losses = self.loss(out, ground_truth)
-        self.flat.zero_()
-        losses["loss"].backward()
+            losses, out = self._forward_backward(model_input, ground_truth)
         if self.world > 1:
             sdist.all_reduce_sum(self.flat.buffer, self.group)
         if self.grad_clip:
@@ -64,6 +62,56 @@ class TrainStep:
         self.scheduler.step()
         self.iter_step += 1
         return losses, out
+
+    def _forward_backward(self, model_input, ground_truth):
+        model_input = dict(model_input)
+        model_input["iter_step"] = self.iter_step
+        if self.sync_free:
+            self._refresh_draws(model_input["uv"].shape[1], model_input["uv"].device)
+        out = self.model(model_input, fast=1)
+        if self.world > 1:
+            losses = sdist.sharded_loss(self.loss, out, ground_truth, self.group)
+        else:
+            losses = self.loss(out, ground_truth)
+        self.flat.zero_()
+        losses["loss"].backward()
+        return losses, out
+
+    # ------------------------------------------------------------------ hipGraph path
+    def _graphed_forward_backward(self, model_input, ground_truth):
+        dev = model_input["uv"].device
+        keys_in = ("intrinsics", "uv", "pose")
+        if self._graph is None or self._static_in["uv"].shape != model_input["uv"].shape:
+            if self.world > 1:
+                raise NotImplementedError("use_graph with ray sharding: the count all-reduce inside the loss is not captured yet")
+            self._static_in = {k: model_input[k].clone() for k in keys_in}
+            self._static_gt = {k: ground_truth[k].to(dev).clone() for k in ("rgb", "mask")}
+            # warm-up on a side stream (builds the cell table, TV graph, workspaces, allocator pools) without touching the
+            # training trajectory: parameters are restored afterwards and no optimiser step is taken
+            rng = torch.get_rng_state()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._forward_backward(dict(self._static_in, local_data=None), self._static_gt)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.set_rng_state(rng)
+            self._refresh_draws(model_input["uv"].shape[1], dev)      # allocates the persistent draw buffers
+            torch.set_rng_state(rng)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
+                losses = self.loss(out, self._static_gt)
+                self.flat.zero_()
+                losses["loss"].backward()
+            self._static_out = (losses, out)
+        for k in keys_in:
+            self._static_in[k].copy_(model_input[k], non_blocking=True)
+        for k in ("rgb", "mask"):
+            self._static_gt[k].copy_(ground_truth[k], non_blocking=True)
+        self._refresh_draws(model_input["uv"].shape[1], dev)
+        self._graph.replay()
+        return self._static_out
 
     def _refresh_draws(self, R, dev):
         """The reference draws its random numbers from the CPU generator and moves them (ray_sampler.py:55,514,550,562); in

@@ -164,3 +164,30 @@ def test_sync_free_step_equals_default_step():
         np.testing.assert_allclose(l1[k].item(), l0[k].item(), rtol=1e-5, atol=1e-7, err_msg=k)
     np.testing.assert_allclose(o1["rgb_values"].detach().cpu().numpy(), o0["rgb_values"].detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=2e-3, atol=2e-5 * float(g0.abs().max()))
+
+
+def test_graphed_step_tracks_eager_step():
+    """hipGraph replay of forward + loss + backward gives the same three-step trajectory as eager launches."""
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.train import TrainStep
+
+    scene = syn.make_scene(3000, seed=13)
+    g = torch.Generator().manual_seed(4)
+    K = torch.from_numpy(scene["intrinsics"])[None].cuda()
+    batches = []
+    for it in range(3):
+        uv = torch.from_numpy(syn.make_pixels(64, g))[None].cuda()
+        pose = torch.from_numpy(scene["poses"][it])[None].cuda()
+        gt = {"rgb": torch.rand((64, 3), generator=g)[None].cuda(), "mask": (torch.rand((64,), generator=g) > 0.2).float()[None, :, None].repeat(1, 1, 3).cuda()}
+        batches.append(({"intrinsics": K, "uv": uv, "pose": pose, "local_data": None}, gt))
+    traj = []
+    for use_graph in (False, True):
+        model = build_model(scene)
+        step = TrainStep(model, sync_free=True, use_graph=use_graph)
+        torch.manual_seed(9)
+        ls = [step(*b)[0]["loss"].item() for b in batches]
+        traj.append((ls, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (l0, s0), (l1, s1) = traj
+    np.testing.assert_allclose(l1, l0, rtol=2e-5)
+    for k in s0:
+        np.testing.assert_allclose(s1[k].cpu().numpy(), s0[k].cpu().numpy(), rtol=0, atol=2e-5, err_msg=k)
