@@ -71,13 +71,13 @@ def sharded_loss(loss_mod, out, ground_truth, group=None):
     if "eikonal_sum" in out:                     # sync-free mode: sum and count were formed on the device
         eik_sum, P_loc = out["eikonal_sum"], out["point_count"].float()
     else:
-        eik_sum = ((g.norm(2, dim=1) - 1) ** 2).sum() if g is not None else torch.tensor(0.0, device=dev)
-        P_loc = torch.tensor(float(0 if g is None else g.shape[0]), device=dev)
-    pseudo_cnt = out.get("pseudo_count", torch.tensor(1.0, device=dev))
-    counts = torch.stack([torch.tensor(float(R_loc), device=dev), P_loc, pseudo_cnt.float()])
+        eik_sum = ((g.norm(2, dim=1) - 1) ** 2).sum() if g is not None else torch.zeros((), device=dev)
+        P_loc = torch.full((), float(0 if g is None else g.shape[0]), device=dev)
+    pseudo_cnt = out.get("pseudo_count", torch.ones((), device=dev))
+    counts = torch.stack([torch.full((), float(R_loc), device=dev), P_loc, pseudo_cnt.float()])
     all_reduce_sum(counts, group)
     R_tot, P_tot, ps_tot = counts[0], counts[1].clamp(min=1), counts[2]
-    zero = torch.tensor(0.0, device=dev)
+    zero = torch.zeros((), device=dev)
     res = {"rgb_loss": (out["rgb_values"] - rgb_gt).abs().sum() / (3.0 * R_tot)}
     res["eikonal_loss"] = eik_sum / P_tot
     res["tv_loss"] = out["tv_loss"] / G if loss_mod.tv_weight > 0 else zero

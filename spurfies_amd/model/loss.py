@@ -31,7 +31,7 @@ class VolSDFLoss(nn.Module):
         dev = model_outputs["rgb_values"].device
         rgb_gt = ground_truth["rgb"].to(dev)
         mask_gt = ground_truth["mask"].to(dev)
-        zero = torch.tensor(0.0, device=dev)
+        zero = torch.zeros((), device=dev)
         out = {"rgb_loss": self.get_rgb_loss(model_outputs["rgb_values"], rgb_gt)}
         g = model_outputs.get("grad_theta")
         if "eikonal_value" in model_outputs:        # sync-free mode: the model formed the mean on the device

@@ -244,7 +244,7 @@ class PointVolSDF(nn.Module):
         xyz = torch.where(valid.unsqueeze(-1), x.view(R, SR, 3), torch.zeros(1, device=dev))
 
         # ---- pseudo-point loss (:765-780) --------------------------------------------------------
-        pseudo_pts_loss = torch.tensor(0.0, device=dev)
+        pseudo_pts_loss = torch.zeros((), device=dev)
         pseudo_sum, pseudo_cnt = pseudo_pts_loss, pseudo_pts_loss
         if P > 0:
             pts_rendered = cam_loc + ray_dirs * dist_map[:, None]
@@ -257,7 +257,7 @@ class PointVolSDF(nn.Module):
             pseudo_pts_loss = torch.where(cnt > 0, l1, torch.full_like(l1, SDF_FILL))
 
         output = {"rgb_values": rgb, "depth_values": depth, "depth_vals": depth_vals, "weights": weights, "xyz": xyz,
-                  "local_loss": torch.tensor(0.0, device=dev), "pseudo_pts_loss": pseudo_pts_loss,
+                  "local_loss": torch.zeros((), device=dev), "pseudo_pts_loss": pseudo_pts_loss,
                   "pseudo_sum": pseudo_sum, "pseudo_count": pseudo_cnt}  # sums + counts for ray-sharded steps (dist.py)
         if self._tv_graph is None:
             self._tv_graph = TVGraph(grid, self.neural_pts, k, conf.r)
