@@ -6,27 +6,120 @@
 // keeps the whole optimisation step free of host synchronisation (and capturable in a hipGraph).
 //
 // K-huge / MN-tiny shape: every workgroup owns a slice of the rows and the FULL 256 x C output in accumulators
-// (one wave per SIMD, 2 x NT tiles of v_mfma_f32_32x32x2_f32 = up to 256 VGPRs), streams G and A straight from HBM
-// (each element read once; per row pair a wave issues one float2 + NT/4 float4 loads for 2*NT MFMAs) and leaves its
-// partial in a slab; a second tiny kernel sums the slabs in a fixed order (bitwise reproducible) into dW.
+// (one wave per SIMD, 2 x NT tiles of v_mfma_f32_32x32x2_f32 = up to 256 accumulator registers), streams G and A from HBM
+// exactly once through a double-buffered LDS stage and leaves its partial in a slab; a second tiny kernel sums the slabs
+// in a fixed order (bitwise reproducible) into dW.
 #include "mlp_tile.h"
 
 namespace {
 using namespace spf;
 
-// Operand maps (chosen so that every load is a wide, fully coalesced one):
-//   A operand (G^T): tile m, lane (o_l = lane & 31)  <->  output row o = 64 wave + 2 o_l + m   (one float2 load per row)
-//   B operand (A):   tile t, lane (c_i = lane & 31)  <->  column     i = NT c_i + t            (NT/4 float4 loads per row)
-// Each workgroup writes its partial [256][32 NT] in that native accumulator order to a slab; wgrad_reduce_kernel
-// sums the slabs of the active workgroups in a fixed order (deterministic) and adds the result to dW.
+// Operand maps:
+//   A operand (G^T): tile m, lane (o_l = lane & 31)  <->  output row o = 64 wave + 2 o_l + m
+//   B operand (A):   tile t, lane (c_i = lane & 31)  <->  column i = col_of<NT>(c_i, t)
+// col_of keeps every lane's LDS read a conflict-free 16-B access: NT = 8 -> 4 c_i + t (t < 4), 128 + 4 c_i + t - 4 (t >= 4);
+// NT = 4 -> 4 c_i + t; NT = 1 -> c_i.
+template <int NT>
+__host__ __device__ __forceinline__ int col_of(int ci, int t) {
+    return NT == 8 ? (t < 4 ? 4 * ci + t : 128 + 4 * ci + (t - 4)) : (NT == 4 ? 4 * ci + t : ci);
+}
+
+// NT in {4, 8}: the four waves of a workgroup need the SAME rows of A and different 64-column slices of G, so the rows are
+// staged once per workgroup through LDS (16 rows per stage, double buffered, one barrier per 128 MFMAs per wave) instead of
+// being pulled four times through the CU's vector-memory path, which is what bounded the direct-load form (~10 B/clk/CU).
 template <int NT>
 __global__ void __launch_bounds__(256, 1)
-wgrad_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
-             int max_rows, float* __restrict__ slab) {
+wgrad_lds_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
+                 int max_rows, float* __restrict__ slab) {
+    constexpr int U = 8, ROWS = 2 * U, CA = 32 * NT;            // rows per stage, staged A width
+    constexpr int G4 = ROWS * 64 / 256, A4 = ROWS * (CA / 4) / 256;   // float4 per thread per stage
+    __shared__ __attribute__((aligned(16))) float sG[2][ROWS][256];
+    __shared__ __attribute__((aligned(16))) float sA[2][ROWS][CA];
+    const int tid = threadIdx.x, lane = tid & 63, ci = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
+    int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    chunk += chunk & 1;
+    const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, n);
+    if (r0 >= r1) return;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+    f32x4 rg[G4], ra[A4];
+    auto gload = [&](int base) {
+#pragma unroll
+        for (int v = 0; v < G4; ++v) {
+            const int e = tid + 256 * v, row = base + e / 64, c4 = e % 64;
+            rg[v] = row < r1 ? *reinterpret_cast<const f32x4*>(G + (size_t)row * 256 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int v = 0; v < A4; ++v) {
+            const int e = tid + 256 * v, row = base + e / (CA / 4), c4 = e % (CA / 4);
+            ra[v] = (row < r1 && 4 * c4 < C) ? *reinterpret_cast<const f32x4*>(A + (size_t)row * lda + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int v = 0; v < G4; ++v) {
+            const int e = tid + 256 * v;
+            *reinterpret_cast<f32x4*>(&sG[buf][e / 64][4 * (e % 64)]) = rg[v];
+        }
+#pragma unroll
+        for (int v = 0; v < A4; ++v) {
+            const int e = tid + 256 * v;
+            *reinterpret_cast<f32x4*>(&sA[buf][e / (CA / 4)][4 * (e % (CA / 4))]) = ra[v];
+        }
+    };
+    gload(r0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int base = r0; base < r1; base += ROWS) {
+        const bool more = base + ROWS < r1;
+        if (more) gload(base + ROWS);               // next stage in flight while this one is consumed
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float2 a = *reinterpret_cast<const float2*>(&sG[buf][2 * u + h][64 * wave + 2 * ci]);
+            float b[NT];
+#pragma unroll
+            for (int v = 0; v < NT / 4; ++v) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(&sA[buf][2 * u + h][128 * v + 4 * ci]);
+                b[4 * v] = x4[0]; b[4 * v + 1] = x4[1]; b[4 * v + 2] = x4[2]; b[4 * v + 3] = x4[3];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t], acc[1][t], 0, 0, 0);
+            }
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* out = slab + ((size_t)blockIdx.x * 4 + wave) * (2 * NT * 16 * 64) + lane;   // slab[block][wave][m][t][reg][lane]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[((m * NT + t) * 16 + r) * 64] = acc[m][t][r];
+}
+
+// NT = 8 (C = 256): the LDS-staged form needs > 512 registers with this compiler (256 accumulators + staging); the direct form
+// keeps the accumulators in AGPRs (70 VGPR + 256 AGPR, no spill) and is bounded by the CU's vector-memory path instead
+// (every wave pulls the same A rows): ~90 TFLOP/s.
+__global__ void __launch_bounds__(256, 1)
+wgrad_wide_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
+                  int max_rows, float* __restrict__ slab) {
+    constexpr int NT = 8, U = 6;
     const int lane = threadIdx.x & 63, ci = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
-    int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;   // even-sized row slices: a k-pair never straddles two workgroups
+    int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
     chunk += chunk & 1;
     const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, n);
     if (r0 >= r1) return;
@@ -38,34 +131,23 @@ wgrad_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
     const float* gp = G + 64 * wave + 2 * ci;
-    const bool bok = NT * ci < C;            // C is a multiple of NT for every caller (256 / 104 / 21 with NT 8 / 4 / 1)
-    constexpr int U = (NT == 8) ? 6 : 8;     // row pairs per software-pipeline stage
-    float2 a[U], an[U];
-    float b[U][NT], bn[U][NT];
-    auto load = [&](int base, float2 (&fa)[U], float (&fb)[U][NT]) {
+    for (int base = r0; base < r1; base += 2 * U) {
+        float2 a[U];
+        float b[U][NT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int row = base + 2 * u + h;
             const bool ok = row < r1;
             const size_t rr = ok ? (size_t)row : (size_t)r0;
-            fa[u] = *reinterpret_cast<const float2*>(gp + rr * 256);
-            if (!ok) fa[u] = make_float2(0.f, 0.f);
-            const float* ap = A + rr * lda + NT * ci;
-            if (NT >= 4) {
+            a[u] = *reinterpret_cast<const float2*>(gp + rr * 256);
+            if (!ok) a[u] = make_float2(0.f, 0.f);
 #pragma unroll
-                for (int v = 0; v < NT / 4; ++v) {
-                    f32x4 x4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ok && bok) x4 = *reinterpret_cast<const f32x4*>(ap + 4 * v);
-                    fb[u][4 * v] = x4[0]; fb[u][4 * v + 1] = x4[1]; fb[u][4 * v + 2] = x4[2]; fb[u][4 * v + 3] = x4[3];
-                }
-            } else {
-                fb[u][0] = (ok && bok) ? ap[0] : 0.f;
+            for (int v = 0; v < 2; ++v) {
+                f32x4 x4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok && 128 * v + 4 * ci < C) x4 = *reinterpret_cast<const f32x4*>(A + rr * lda + 128 * v + 4 * ci);
+                b[u][4 * v] = x4[0]; b[u][4 * v + 1] = x4[1]; b[u][4 * v + 2] = x4[2]; b[u][4 * v + 3] = x4[3];
             }
         }
-    };
-    load(r0, a, b);
-    for (int base = r0; base < r1; base += 2 * U) {
-        load(base + 2 * U, an, bn);          // next stage's operands are in flight while this stage's MFMAs issue
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -73,14 +155,7 @@ wgrad_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, 
                 acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u][t], acc[0][t], 0, 0, 0);
                 acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u][t], acc[1][t], 0, 0, 0);
             }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            a[u] = an[u];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) b[u][t] = bn[u][t];
-        }
     }
-    // slab[block][wave][m][t][reg][lane]
     float* out = slab + ((size_t)blockIdx.x * 4 + wave) * (2 * NT * 16 * 64) + lane;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -88,6 +163,50 @@ wgrad_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, 
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) out[((m * NT + t) * 16 + r) * 64] = acc[m][t][r];
+}
+
+// NT = 1 (C <= 32: the 21 view-encoding columns, a ones column for a bias gradient): direct loads, nothing to share
+__global__ void __launch_bounds__(256, 1)
+wgrad_narrow_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
+                    int max_rows, float* __restrict__ slab) {
+    const int lane = threadIdx.x & 63, ci = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
+    int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    chunk += chunk & 1;
+    const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, n);
+    if (r0 >= r1) return;
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const float* gp = G + 64 * wave + 2 * ci;
+    const bool bok = ci < C;
+    constexpr int U = 8;
+    for (int base = r0; base < r1; base += 2 * U) {
+        float2 a[U];
+        float b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = base + 2 * u + h;
+            const bool ok = row < r1;
+            const size_t rr = ok ? (size_t)row : (size_t)r0;
+            a[u] = *reinterpret_cast<const float2*>(gp + rr * 256);
+            if (!ok) a[u] = make_float2(0.f, 0.f);
+            b[u] = (ok && bok) ? A[rr * lda + ci] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u], acc[1], 0, 0, 0);
+        }
+    }
+    float* out = slab + ((size_t)blockIdx.x * 4 + wave) * (2 * 16 * 64) + lane;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(m * 16 + r) * 64] = acc[m][r];
 }
 
 template <int NT>
@@ -104,7 +223,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk_lau
     const int lane = e & 63, r = (e >> 6) & 15, mt = (e >> 10) % (2 * NT), wave = (e >> 10) / (2 * NT);
     const int m = mt / NT, t = mt % NT;
     const int o = 64 * wave + 2 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) + m;
-    const int i = NT * (lane & 31) + t;
+    const int i = col_of<NT>(lane & 31, t);
     if (i >= C) return;
     float s = 0.f;
     for (int b = 0; b < active; ++b) s += slab[(size_t)b * PER + e];
@@ -123,19 +242,19 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     if (max_rows == 0) return SPF_OK;
     if (!G || !A || !dW || !workspace) return spf::fail(SPF_EINVAL, "spf_wgrad: null pointer");
     const int NT = C > 128 ? 8 : (C > 32 ? 4 : 1);
-    if (C % NT || (NT >= 4 && (lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad: C must be a multiple of %d and lda of 4 (C=%d lda=%d)", NT, C, lda);
+    if (NT >= 4 && ((C % 4) || (lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad: C and lda must be multiples of 4 for C > 32 (C=%d lda=%d)", C, lda);
     hipStream_t s = (hipStream_t)stream;
     int blocks = spf::div_up(max_rows, 512);
     if (blocks > 256) blocks = 256;   // one workgroup per CU, one wave per SIMD
     const int per = 4 * 2 * NT * 16 * 64;
     if (NT == 8) {
-        wgrad_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_wide_kernel<<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         wgrad_reduce_kernel<8><<<spf::div_up(per, 256), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     } else if (NT == 4) {
-        wgrad_kernel<4><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_lds_kernel<4><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         wgrad_reduce_kernel<4><<<spf::div_up(per, 256), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     } else {
-        wgrad_kernel<1><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_narrow_kernel<<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         wgrad_reduce_kernel<1><<<spf::div_up(per, 256), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     }
     SPF_LAUNCH_CHECK("wgrad_kernel");

@@ -191,3 +191,36 @@ def test_graphed_step_tracks_eager_step():
     np.testing.assert_allclose(l1, l0, rtol=2e-5)
     for k in s0:
         np.testing.assert_allclose(s1[k].cpu().numpy(), s0[k].cpu().numpy(), rtol=0, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("n_points,spacing,n_rays", [(50000, 0.025, 1024), (200000, 0.0125, 4096)])
+def test_large_configs_run_and_paths_agree(n_points, spacing, n_rays):
+    """BASELINE configs 3 and 5 shapes (garden-like 5e4 points in the +-2 grid; dense 2e5-point cloud with 4096-ray batches):
+    the step runs at full size, every output is finite and physically bounded, and the two independent execution paths
+    (exact-size buffers + library GEMMs vs worst-case buffers + device-side counts) agree."""
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.train import TrainStep
+
+    scene = syn.make_scene(n_points, seed=21, spacing=spacing)
+    assert tuple(scene["ranges"])[0] == -2.0
+    scene["intrinsics"], scene["poses"] = syn.make_cameras(ring_radius=4.0)
+    g = torch.Generator().manual_seed(6)
+    uv = torch.from_numpy(syn.make_pixels(n_rays, g))[None].cuda()
+    K, pose = torch.from_numpy(scene["intrinsics"])[None].cuda(), torch.from_numpy(scene["poses"][0])[None].cuda()
+    gt = {"rgb": torch.rand((n_rays, 3), generator=g)[None].cuda(), "mask": torch.ones((1, n_rays, 3)).cuda()}
+    res = []
+    for sync_free in (False, True):
+        model = build_model(scene)
+        step = TrainStep(model, sync_free=sync_free)
+        torch.manual_seed(2)
+        losses, out = step({"intrinsics": K, "uv": uv, "pose": pose, "local_data": None}, gt)
+        res.append((losses["loss"].item(), step.flat.buffer.clone(), out))
+        w = out["weights"].detach()
+        assert torch.isfinite(w).all() and float(w.min()) >= 0.0 and float(w.sum(-1).max()) <= 1.0 + 1e-5
+        assert torch.isfinite(out["rgb_values"]).all() and float(out["rgb_values"].max()) <= 1.0 + 1e-5
+        assert torch.isfinite(step.flat.buffer).all()
+        if not sync_free:
+            assert model.stats["valid_points"] > 20 * n_rays, "the rays must actually hit the cloud"
+    (l0, g0, _), (l1, g1, _) = res
+    np.testing.assert_allclose(l1, l0, rtol=1e-5)
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=5e-3, atol=5e-5 * float(g0.abs().max()))
