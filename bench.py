@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (config/ours.yaml:14 num_pixels)")
     ap.add_argument("--points", type=int, default=10000, help="neural points (DTU-like cloud)")
+    ap.add_argument("--spacing", type=float, default=0.025, help="nearest-neighbour spacing of the synthetic cloud (0.0125 = dense stress cloud)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync", action="store_true", help="default (reference-shaped) step with one host read-back per step")
     ap.add_argument("--no-graph", action="store_true", help="sync-free step, launches issued eagerly instead of one hipGraph replay")
@@ -110,7 +111,7 @@ def main():
     from spurfies_amd.train import TrainStep
 
     torch.manual_seed(0)
-    scene = syn.make_scene(args.points, seed=0)
+    scene = syn.make_scene(args.points, seed=0, spacing=args.spacing)
     st = scene["state"]
     conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
     model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
