@@ -40,7 +40,8 @@ class Conf(dict):
         return bool(self._lookup(k, default))
 
     def get_list(self, k, default=None):
-        return list(self._lookup(k, default))
+        v = self._lookup(k, default)
+        return None if v is None else list(v)
 
     def get_string(self, k, default=None):
         return self._lookup(k, default)

@@ -130,3 +130,199 @@ class TrainStep:
         for k, v in self._draws.items():
             v.copy_(self._pinned[k], non_blocking=True)
         s.draws = self._draws
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# VolOpt: the reference's trainer object (spurfies/train.py:20-564) around TrainStep — "next" row N1 of SURVEY.md §8(f)
+# ---------------------------------------------------------------------------------------------------------------
+import os
+from datetime import datetime
+
+from .conf import Conf, default_model_conf
+from .utils import general as utils
+from .utils import rend_util
+
+
+class SyntheticDataset(torch.utils.data.Dataset):
+    """Stand-in for spurfies/datasets/dtu.py:DTUDataset (images / cameras come from an unavailable download): same item layout
+    `(idx, sample, ground_truth)`, `collate_fn`, `change_sampling_idx`, `total_pixels`, `img_res`."""
+
+    def __init__(self, scene, img_res=(576, 768), n_views=3, seed=0):
+        from . import synthetic as syn
+
+        self.img_res = list(img_res)
+        self.total_pixels = img_res[0] * img_res[1]
+        self.scale_factor = 1.0
+        self.n_images = n_views
+        self.intrinsics = torch.from_numpy(scene["intrinsics"])
+        self.poses = torch.from_numpy(scene["poses"][:n_views])
+        g = torch.Generator().manual_seed(seed)
+        ys, xs = torch.meshgrid(torch.arange(img_res[0]), torch.arange(img_res[1]), indexing="ij")
+        self.uv = torch.stack([xs, ys], -1).reshape(-1, 2).float()
+        base = torch.stack([xs / img_res[1], ys / img_res[0], 0.5 + 0 * xs], -1).reshape(-1, 3).float()
+        self.rgb = [(base * (0.6 + 0.4 * torch.rand(3, generator=g))).clamp(0, 1) for _ in range(n_views)]
+        cx, cy = syn.CX, syn.CY
+        self.mask = [(((self.uv[:, 0] - cx) ** 2 + (self.uv[:, 1] - cy) ** 2) < (0.45 * img_res[0]) ** 2).float() for _ in range(n_views)]
+        self.sampling_idx = None
+
+    def __len__(self):
+        return self.n_images
+
+    def change_sampling_idx(self, sampling_size):
+        """datasets/dtu.py:360-364."""
+        self.sampling_idx = None if sampling_size == -1 else torch.randperm(self.total_pixels)[:sampling_size]
+
+    def __getitem__(self, idx):
+        sample = {"uv": self.uv, "intrinsics": self.intrinsics, "pose": self.poses[idx], "local_data": None}
+        gt = {"rgb": self.rgb[idx], "mask": self.mask[idx][:, None].repeat(1, 3)}
+        if self.sampling_idx is not None:
+            sample["uv"] = self.uv[self.sampling_idx]
+            gt = {"rgb": self.rgb[idx][self.sampling_idx], "mask": gt["mask"][self.sampling_idx]}
+        return idx, sample, gt
+
+    @staticmethod
+    def collate_fn(batch):
+        idx, samples, gts = zip(*batch)
+        stack = lambda ds: {k: (None if ds[0][k] is None else torch.stack([d[k] for d in ds])) for k in ds[0]}
+        return torch.as_tensor(idx), stack(samples), stack(gts)
+
+
+class VolOpt:
+    """Trainer with the reference's surface (spurfies/train.py): `VolOpt(args=..., batch_size=1, is_continue=False,
+    timestamp='latest', checkpoint='latest', scan='scan24')`, `.gen_dataset(stg)`, `.stg`, `.run(opt_stepN) -> epoch`,
+    `.train_step(batch)`, `.render_step(batch)`, `.save_checkpoints(epoch)`, `.load_from_dir(dir, checkpoint)`, and the same
+    checkpoint files (`checkpoints/ModelParameters/{latest,<epoch>}.pth` = {epoch, model_state_dict, iter_step},
+    `checkpoints/OptimizerParameters/*.pth` = {epoch, optimizer_state_dict}).  Dataset and cloud are injectable because the
+    reference's data is a separate download; hydra / OmegaConf / TensorBoard are not required."""
+
+    def __init__(self, **kwargs):
+        torch.set_default_dtype(torch.float32)
+        args = kwargs.get("args") or Conf()
+        self.hparams = args
+        self.conf = Conf(args.get("vol", {})) if isinstance(args, dict) else Conf()
+        self.batch_size = kwargs.get("batch_size", 1)
+        self.exps_folder_name = args.get("exps_folder", "exps_vsdf") if isinstance(args, dict) else "exps_vsdf"
+        scan = kwargs.get("scan", "scan24")
+        self.data_dir = self.conf.get_string("dataset.data_dir", "dtu")
+        self.scan_id = int(scan[4:]) if (self.data_dir == "dtu" and str(scan).startswith("scan")) else scan
+        self.expname = self.conf.get_string("train.expname", "ours") + f"_{self.scan_id}"
+        root = kwargs.get("root", "./")
+        self.expdir = os.path.join(root, self.exps_folder_name, self.expname)
+        is_continue, timestamp = kwargs.get("is_continue", False), kwargs.get("timestamp", "latest")
+        if is_continue and timestamp == "latest":
+            stamps = sorted(os.listdir(self.expdir)) if os.path.exists(self.expdir) else []
+            is_continue, timestamp = (True, stamps[-1]) if stamps else (False, None)
+        self.timestamp = "{:%Y_%m_%d_%H_%M_%S}".format(datetime.now())
+        self.plots_dir = os.path.join(self.expdir, self.timestamp, "plots")
+        self.checkpoints_path = os.path.join(self.expdir, self.timestamp, "checkpoints")
+        self.model_params_subdir, self.optimizer_params_subdir = "ModelParameters", "OptimizerParameters"
+        for d in (self.plots_dir, os.path.join(self.checkpoints_path, self.model_params_subdir),
+                  os.path.join(self.checkpoints_path, self.optimizer_params_subdir)):
+            os.makedirs(d, exist_ok=True)
+
+        device = kwargs.get("device", "cuda")
+        self.scene = kwargs.get("scene")
+        self.train_dataset = kwargs.get("dataset")
+        model_conf = self.conf.get_config("model") or default_model_conf()
+        model_cls = utils.get_class(self.conf.get_string("train.model_class", "spurfies_amd.model.pointneus_disent.PointVolSDF"))
+        self.model = model_cls(conf=model_conf if isinstance(model_conf, Conf) else Conf(model_conf), scan_id=self.scan_id,
+                               dataset=self.data_dir, neural_points=kwargs.get("neural_points"), device=device)
+        prior = kwargs.get("prior_state_dict")            # train.py:125-140 renames ckpt/local_prior.pt into F_geometry.* / T.0.*
+        if prior is not None:
+            self.model.load_state_dict(prior, strict=False)
+        self.num_pixels = self.conf.get_int("train.num_pixels", 1024)
+        self.checkpoint_freq = self.conf.get_int("train.checkpoint_freq", 100)
+        self.render_freq = self.conf.get_int("train.render_freq", 500)
+        self.split_n_pixels = self.conf.get_int("train.split_n_pixels", 500)
+        lw = self.conf.get_config("loss") or {}
+        loss = VolSDFLoss(lw.get("rgb_loss", "torch.nn.L1Loss"), local_weight=lw.get("local_weight", 0.5), pseudo_weight=lw.get("pseudo_weight", 0.5),
+                          eikonal_weight=lw.get("eikonal_weight", 0.001), rgb_weight=lw.get("rgb_weight", 1.0), tv_weight=lw.get("tv_weight", 0.01))
+        self.lr = self.conf.get_float("train.learning_rate", 5.0e-4)
+        grad_clip = args.get("grad_clip", True) if isinstance(args, dict) else True
+        self.step = TrainStep(self.model, loss=loss, lr=self.lr, grad_clip=grad_clip, sync_free=kwargs.get("sync_free", False),
+                              use_graph=kwargs.get("use_graph", False))
+        self.loss, self.optimizer, self.scheduler = self.step.loss, self.step.optimizer, self.step.scheduler
+        self.start_epoch, self.iter_step, self.total_step = 0, 0, 0
+        self.stg = 2
+        if is_continue:
+            self.load_from_dir(dir=os.path.join(self.expdir, timestamp), checkpoint=kwargs.get("checkpoint", "latest"))
+        self.model.hparams = self.hparams
+        self.last_losses = None
+
+    # ---- data -----------------------------------------------------------------------------------------------
+    def gen_dataset(self, stg):
+        self.stg = stg
+        if self.train_dataset is None:
+            if self.scene is None:
+                raise RuntimeError("no dataset: pass dataset=... or scene=... (the reference's DTU / MipNeRF-360 loaders need its data download)")
+            self.train_dataset = SyntheticDataset(self.scene)
+        ds = self.train_dataset
+        self.train_dataloader = torch.utils.data.DataLoader(ds, batch_size=self.batch_size, shuffle=True, collate_fn=ds.collate_fn)
+        self.eval_dataloader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, collate_fn=ds.collate_fn)
+        self.total_pixels, self.img_res, self.n_batches = ds.total_pixels, ds.img_res, len(self.train_dataloader)
+        self.ds_len = len(ds)
+
+    # ---- checkpoints (train.py:221-241, 293-328) -----------------------------------------------------------------
+    def save_checkpoints(self, epoch, latest_only=False):
+        model_blob = {"epoch": epoch, "model_state_dict": self.model.state_dict(), "iter_step": self.iter_step}
+        opt_blob = {"epoch": epoch, "optimizer_state_dict": self.optimizer.state_dict()}
+        names = ["latest"] if latest_only else ["latest", str(epoch)]
+        for n in names:
+            torch.save(model_blob, os.path.join(self.checkpoints_path, self.model_params_subdir, n + ".pth"))
+            torch.save(opt_blob, os.path.join(self.checkpoints_path, self.optimizer_params_subdir, n + ".pth"))
+
+    def load_from_dir(self, dir, checkpoint="latest"):
+        ck = os.path.join(dir, "checkpoints")
+        saved = torch.load(os.path.join(ck, "ModelParameters", str(checkpoint) + ".pth"), map_location=self.model.neural_pts.device)
+        self.model.load_state_dict(saved["model_state_dict"])
+        self.start_epoch, self.iter_step = saved["epoch"], saved["iter_step"]
+        self.step.iter_step = self.iter_step
+        data = torch.load(os.path.join(ck, "OptimizerParameters", str(checkpoint) + ".pth"), map_location=self.model.neural_pts.device)
+        self.optimizer.load_state_dict(data["optimizer_state_dict"])
+        self.step.flat.zero_()     # re-attach the flat gradient views (the reference does not save the scheduler either)
+
+    # ---- steps ---------------------------------------------------------------------------------------------------
+    def train_step(self, batch, use_mvs=False, use_depth_reg=True):
+        """train.py:330-397."""
+        indices, model_input, ground_truth = batch
+        dev = self.model.neural_pts.device
+        model_input = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in model_input.items()}
+        ground_truth = {k: v.to(dev) for k, v in ground_truth.items()}
+        self.step.iter_step = self.iter_step
+        losses, out = self.step(model_input, ground_truth)
+        self.last_losses = losses
+        self.last_psnr = rend_util.get_psnr(out["rgb_values"].detach(), ground_truth["rgb"].reshape(-1, 3))
+        self.train_dataset.change_sampling_idx(self.num_pixels)
+        self.iter_step += 1
+        self.total_step += 1
+        return losses
+
+    def render_step(self, batch, epoch=0, dataset=None, fast=-1):
+        """train.py:399-472 without the image files / TensorBoard: full-image render in `split_n_pixels` chunks."""
+        self.model.eval()
+        indices, model_input, ground_truth = batch
+        dev = self.model.neural_pts.device
+        model_input = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in model_input.items()}
+        total = model_input["uv"].shape[1]
+        res = []
+        for s in utils.split_input(model_input, total, n_pixels=self.split_n_pixels):
+            out = self.model(s, fast=fast)
+            res.append({k: out[k].detach() for k in ("rgb_values", "depth_values", "normal_map")})
+        merged = utils.merge_output(res, total, 1)
+        merged["psnr"] = rend_util.get_psnr(merged["rgb_values"], ground_truth["rgb"].to(dev).reshape(-1, 3))
+        return merged
+
+    def run(self, opt_stepN):
+        """train.py:496-546: epochs over the image loader until `opt_stepN` steps; returns the epoch reached."""
+        epoch = self.start_epoch
+        self.train_dataset.change_sampling_idx(self.num_pixels)
+        while self.iter_step < opt_stepN:
+            if self.checkpoint_freq > 0 and epoch % self.checkpoint_freq == 0 and epoch > self.start_epoch:
+                self.save_checkpoints(epoch)
+            for batch in self.train_dataloader:
+                if self.iter_step >= opt_stepN:
+                    break
+                self.train_step(batch)
+            epoch += 1
+        self.save_checkpoints(epoch)
+        return epoch
