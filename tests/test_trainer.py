@@ -49,7 +49,7 @@ def test_short_run_reduces_the_loss(tmp_path):
     for _ in range(4):
         epoch = t.run(t.iter_step + 10)
         losses.append(float(t.last_losses["rgb_loss"].item()))
-    assert t.iter_step == 40 and epoch >= 13
+    assert t.iter_step == 40 and epoch >= 4
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
     assert os.path.exists(os.path.join(t.checkpoints_path, "ModelParameters", "latest.pth"))
     batch = next(iter(t.eval_dataloader))
