@@ -52,6 +52,7 @@ def test_short_run_reduces_the_loss(tmp_path):
     assert t.iter_step == 40 and epoch >= 4
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
     assert os.path.exists(os.path.join(t.checkpoints_path, "ModelParameters", "latest.pth"))
+    t.train_dataset.change_sampling_idx(-1)                 # full image, as train.py:402 does before rendering
     batch = next(iter(t.eval_dataloader))
     idx, sample, gt = batch
     sample["uv"], gt["rgb"] = sample["uv"][:, :1500], gt["rgb"][:, :1500]
