@@ -81,7 +81,7 @@ wgrad_lds_kernel(const float* __restrict__ G, const float* __restrict__ A, int l
     for (int base = r0; base < r1; base += ROWS) {
         const bool more = base + ROWS < r1;
         if (more) gload(base + ROWS);               // next stage in flight while this one is consumed
-#pragma unroll
+#pragma unroll 2                                   // a fully unrolled stage needs > 512 registers at NT = 8 (spills)
         for (int u = 0; u < U; ++u) {
             const float2 a = *reinterpret_cast<const float2*>(&sG[buf][2 * u + h][64 * wave + 2 * ci]);
             float b[NT];
@@ -101,62 +101,6 @@ wgrad_lds_kernel(const float* __restrict__ G, const float* __restrict__ A, int l
         buf ^= 1;
     }
     float* out = slab + ((size_t)blockIdx.x * 4 + wave) * (2 * NT * 16 * 64) + lane;   // slab[block][wave][m][t][reg][lane]
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[((m * NT + t) * 16 + r) * 64] = acc[m][t][r];
-}
-
-// NT = 8 (C = 256): the LDS-staged form needs > 512 registers with this compiler (256 accumulators + staging); the direct form
-// keeps the accumulators in AGPRs (70 VGPR + 256 AGPR, no spill) and is bounded by the CU's vector-memory path instead
-// (every wave pulls the same A rows): ~90 TFLOP/s.
-__global__ void __launch_bounds__(256, 1)
-wgrad_wide_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
-                  int max_rows, float* __restrict__ slab) {
-    constexpr int NT = 8, U = 6;
-    const int lane = threadIdx.x & 63, ci = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
-    int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
-    chunk += chunk & 1;
-    const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, n);
-    if (r0 >= r1) return;
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
-    const float* gp = G + 64 * wave + 2 * ci;
-    for (int base = r0; base < r1; base += 2 * U) {
-        float2 a[U];
-        float b[U][NT];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int row = base + 2 * u + h;
-            const bool ok = row < r1;
-            const size_t rr = ok ? (size_t)row : (size_t)r0;
-            a[u] = *reinterpret_cast<const float2*>(gp + rr * 256);
-            if (!ok) a[u] = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                f32x4 x4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok && 128 * v + 4 * ci < C) x4 = *reinterpret_cast<const f32x4*>(A + rr * lda + 128 * v + 4 * ci);
-                b[u][4 * v] = x4[0]; b[u][4 * v + 1] = x4[1]; b[u][4 * v + 2] = x4[2]; b[u][4 * v + 3] = x4[3];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u][t], acc[1][t], 0, 0, 0);
-            }
-    }
-    float* out = slab + ((size_t)blockIdx.x * 4 + wave) * (2 * NT * 16 * 64) + lane;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -248,7 +192,7 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     if (blocks > 256) blocks = 256;   // one workgroup per CU, one wave per SIMD
     const int per = 4 * 2 * NT * 16 * 64;
     if (NT == 8) {
-        wgrad_wide_kernel<<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_lds_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         wgrad_reduce_kernel<8><<<spf::div_up(per, 256), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     } else if (NT == 4) {
         wgrad_lds_kernel<4><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
