@@ -22,8 +22,6 @@
 //   d sdf_j / d in = (((v * D4) W6 * D3) W4 * D2) W2 * D1) W0,  D_l = lrelu'(h_l) in {1, 0.01}
 //   sdf(p) = sum_j w_j sdf_j / sum_j w_j,  w_j = exp(-(rbf * max(|x_pi|, 1e-12))^2)  (detached)
 //   d sdf / d x(p) = sum_j (w_j / norm) d sdf_j / d x_pi
-#include <cstdlib>
-
 #include "mlp_tile.h"
 
 namespace {
@@ -253,181 +251,6 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
     }
 }
 
-// ---- ping-pong form ---------------------------------------------------------------------------------------------------
-// One 512-thread workgroup per CU works on TWO tiles at once: waves 0-3 (group A) and waves 4-7 (group B) run the same
-// phase list one slot apart, so that in every slot exactly one group is inside a GEMM phase (an MFMA stream that saturates
-// the SIMD's matrix pipe by itself) while the other does its epilogue / gather / stores.  Two workgroups of 4 waves running
-// the plain kernel fall into lockstep instead (both in GEMM, then both in their epilogues: matrix pipe 78 % busy, measured
-// with SQ_VALU_MFMA_BUSY_CYCLES).  One workgroup-wide barrier per slot; each group owns its own LDS tile.
-template <bool WITH_JAC>
-struct GeoTile {
-    // kernel arguments
-    const float* x; const int32_t* nbr; const int32_t* point_slot; const int32_t* pair_off; const int32_t* pair_point;
-    int NP, k; const float* pts; const float* feat_geo; const float* packed; float rbf; float* pair_tmp; float* jac;
-    // per-wave state
-    float* X; int tile, w, lane, tid;      // w = wave within the group (0..3), tid = thread within the group (0..255)
-    f32x16 acc[2][2];
-    uint32_t m1[2], m2[2], m3[2], m4[2];
-
-    template <int PH>
-    __device__ __forceinline__ void phase() {
-        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
-        if constexpr (PH == 0) gather();
-        else if constexpr (PH == 1) { zero_acc(acc); gemm_rows64_pf<T_IN>(X, pk4 + (OFF_FW1 / 4) + w * (T_IN * 128), lane, acc); }
-        else if constexpr (PH == 2) fwd_epilogue(X, acc, packed + OFF_B1, w, lane, m1);
-        else if constexpr (PH == 3) { zero_acc(acc); gemm_rows64_pf<T_HID>(X, pk4 + (OFF_FW2 / 4) + w * (T_HID * 128), lane, acc); }
-        else if constexpr (PH == 4) fwd_epilogue(X, acc, packed + OFF_B2, w, lane, m2);
-        else if constexpr (PH == 5) { zero_acc(acc); gemm_rows64_pf<T_HID>(X, pk4 + (OFF_FW3 / 4) + w * (T_HID * 128), lane, acc); }
-        else if constexpr (PH == 6) fwd_epilogue(X, acc, packed + OFF_B3, w, lane, m3);
-        else if constexpr (PH == 7) { zero_acc(acc); gemm_rows64_pf<T_HID>(X, pk4 + (OFF_FW4 / 4) + w * (T_HID * 128), lane, acc); }
-        else if constexpr (PH == 8) fwd_epilogue(X, acc, packed + OFF_B4, w, lane, m4);
-        else if constexpr (PH == 9) dot();
-        else if constexpr (PH == 10) seed_sweep();
-        else if constexpr (PH == 11) { zero_acc(acc); gemm_rows64_pf<T_HID>(X, pk4 + (OFF_BW4 / 4) + w * (T_HID * 128), lane, acc); }
-        else if constexpr (PH == 12) bwd_epilogue(X, acc, w, lane, m3);
-        else if constexpr (PH == 13) { zero_acc(acc); gemm_rows64_pf<T_HID>(X, pk4 + (OFF_BW3 / 4) + w * (T_HID * 128), lane, acc); }
-        else if constexpr (PH == 14) bwd_epilogue(X, acc, w, lane, m2);
-        else if constexpr (PH == 15) { zero_acc(acc); gemm_rows64_pf<T_HID>(X, pk4 + (OFF_BW2 / 4) + w * (T_HID * 128), lane, acc); }
-        else if constexpr (PH == 16) bwd_epilogue(X, acc, w, lane, m1);
-        else if constexpr (PH == 17) jacobian();
-    }
-
-    __device__ __forceinline__ void gather() {
-        const int row = tid >> 2, q4 = tid & 3;
-        const int q = tile * 64 + row;
-        int idx = -1, srow = 0;
-        if (q < NP) {
-            const int p = pair_point[q];
-            srow = point_slot ? point_slot[p] : p;
-            idx = nbr[(size_t)srow * k + (q - pair_off[p])];
-        }
-        f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0;
-        if (idx >= 0) {
-            const f32x4* src = reinterpret_cast<const f32x4*>(feat_geo + (size_t)idx * SPF_GEO_DIM + q4 * 8);
-            f0 = src[0];
-            f1 = src[1];
-        }
-        *reinterpret_cast<f32x4*>(X + row * LDA + q4 * 8) = f0;
-        *reinterpret_cast<f32x4*>(X + row * LDA + q4 * 8 + 4) = f1;
-        if (q4 == 0) {
-            float dx = 0.f, dy = 0.f, dz = 0.f;
-            if (idx >= 0) {
-                dx = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
-                dy = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
-                dz = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
-                const float dist = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
-                const float sc = dist * rbf;
-                pair_tmp[(size_t)q * PT_STRIDE] = expf(-(sc * sc));
-            }
-            *reinterpret_cast<f32x4*>(X + row * LDA + 32) = f32x4{dx, dy, dz, 0.f};
-            *reinterpret_cast<f32x4*>(X + row * LDA + 36) = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-
-    __device__ __forceinline__ void dot() {
-        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
-        const int row = tid >> 2, q4 = tid & 3;
-        const f32x4* v4 = pk4 + OFF_V5 / 4;
-        float s = 0.f;
-#pragma unroll 4
-        for (int mth = 0; mth < 16; ++mth) {
-            const int c4 = q4 + 4 * mth;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(X + row * LDA + 4 * c4);
-            const f32x4 v = v4[c4];
-            s += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
-        }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        const int q = tile * 64 + row;
-        if (q4 == 0 && q < NP) pair_tmp[(size_t)q * PT_STRIDE + 1] = s + packed[OFF_C];
-    }
-
-    __device__ __forceinline__ void seed_sweep() {   // g_h4 = v * lrelu'(h4)
-        const int c0 = w * 64 + (lane & 31), h = lane >> 5;
-        const float vv[2] = {packed[OFF_V5 + c0], packed[OFF_V5 + c0 + 32]};
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool pos = (m4[m] >> (n * 16 + r)) & 1u;
-                    X[(m * 32 + row_of(r, h)) * LDA + c0 + 32 * n] = pos ? vv[n] : vv[n] * 0.01f;
-                }
-    }
-
-    __device__ __forceinline__ void jacobian() {     // 256 -> 35 (padded 64): wave = (row half mt, column half nt)
-        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
-        const int mt = w >> 1, nt = w & 1, i = lane & 31, h = lane >> 5;
-        f32x16 aj;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) aj[r] = 0.f;
-        const float* ap = X + (mt * 32 + i) * LDA + 4 * h;
-        const f32x4* bp = pk4 + (OFF_JW1 / 4) + nt * (T_HID * 64) + lane;
-        f32x4 a = *reinterpret_cast<const f32x4*>(ap), b = bp[0];
-#pragma unroll 4
-        for (int t = 0; t < T_HID; ++t) {
-            f32x4 na = a, nb = b;
-            if (t + 1 < T_HID) {
-                na = *reinterpret_cast<const f32x4*>(ap + 8 * (t + 1));
-                nb = bp[(t + 1) * 64];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) aj = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], aj, 0, 0, 0);
-            a = na; b = nb;
-        }
-        const int qb = tile * 64 + mt * 32 + 4 * h;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = qb + (r & 3) + 8 * (r >> 2);
-            if (q < NP) {
-                if (nt == 0) jac[(size_t)q * SPF_GEO_DIM + i] = aj[r];
-                else if (i < 3) pair_tmp[(size_t)q * PT_STRIDE + 2 + i] = aj[r];
-            }
-        }
-    }
-};
-
-// slot S of the two-group schedule: group A runs phase S, group B phase S-1, then one workgroup-wide barrier
-template <int S, int NPH, class TileT>
-struct PingPong {
-    static __device__ __forceinline__ void run(TileT& T, int grp, bool live) {
-        if (grp == 0) {
-            if constexpr (S < NPH) { if (live) T.template phase<S>(); }
-        } else {
-            if constexpr (S >= 1) { if (live) T.template phase<S - 1>(); }
-        }
-        __syncthreads();
-        if constexpr (S < NPH) PingPong<S + 1, NPH, TileT>::run(T, grp, live);
-    }
-};
-
-template <bool WITH_JAC>
-__global__ void __launch_bounds__(512, 2)
-geo_pairs_pp_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
-                    const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
-                    int max_pairs, int k, const float* __restrict__ pts, const float* __restrict__ feat_geo, const float* packed, float rbf,
-                    float* __restrict__ pair_tmp, float* __restrict__ jac) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * L_TOTAL];
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);     // 0: waves 0-3, 1: waves 4-7
-    GeoTile<WITH_JAC> T;
-    T.x = x; T.nbr = nbr; T.point_slot = point_slot; T.pair_off = pair_off; T.pair_point = pair_point;
-    T.NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
-    T.k = k; T.pts = pts; T.feat_geo = feat_geo; T.rbf = rbf; T.pair_tmp = pair_tmp; T.jac = jac;
-    T.X = smem + grp * L_TOTAL;
-    T.tid = threadIdx.x & 255;
-    T.lane = threadIdx.x & 63;
-    T.w = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
-    const int ntiles = (T.NP + 63) / 64;
-    constexpr int NPH = WITH_JAC ? 18 : 10;                               // phases 0..NPH-1
-    for (int pair = blockIdx.x; 2 * pair < ntiles; pair += gridDim.x) {
-        T.packed = launder(packed);
-        T.tile = 2 * pair + grp;
-        const bool live = T.tile < ntiles;
-        PingPong<0, NPH, GeoTile<WITH_JAC>>::run(T, grp, live);
-    }
-}
-
 // per point: norm = sum_j w_j ; sdf = sum_j w_j sdf_j / norm ; wn_j = w_j / norm ; grad = sum_j wn_j d sdf_j/dx
 __global__ void geo_point_reduce_kernel(const float* __restrict__ pair_tmp, const int32_t* __restrict__ pair_off,
                                         const int32_t* __restrict__ point_slot, const int32_t* __restrict__ n_points_dev, int max_points,
@@ -557,25 +380,13 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
     if (grad && !wn) return spf::fail(SPF_EINVAL, "spf_geo_forward: wn is required with grad/jac");
     const int tiles = spf::div_up(max_pairs, 64);
     hipStream_t s = (hipStream_t)stream;
-    static const bool plain = getenv("SPF_GEO_PLAIN") != nullptr;   // A/B switch: the 4-wave kernel, 2 workgroups per CU
-    if (plain) {
-        const int blocks = tiles < 512 ? tiles : 512;
-        if (grad)
-            geo_pairs_kernel<true><<<blocks, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
-                                                          rbf, pair_tmp, jac);
-        else
-            geo_pairs_kernel<false><<<blocks, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
-                                                           rbf, pair_tmp, nullptr);
-    } else {
-        const int pairs2 = spf::div_up(tiles, 2);
-        const int blocks = pairs2 < 256 ? pairs2 : 256;                 // one 8-wave workgroup per CU, two tiles in flight each
-        if (grad)
-            geo_pairs_pp_kernel<true><<<blocks, 512, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo,
-                                                             packed, rbf, pair_tmp, jac);
-        else
-            geo_pairs_pp_kernel<false><<<blocks, 512, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo,
-                                                              packed, rbf, pair_tmp, nullptr);
-    }
+    const int blocks = tiles < 512 ? tiles : 512;  // 2 workgroups per CU x 256 CUs, tiles are strided over them
+    if (grad)
+        geo_pairs_kernel<true><<<blocks, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
+                                                      pair_tmp, jac);
+    else
+        geo_pairs_kernel<false><<<blocks, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
+                                                       rbf, pair_tmp, nullptr);
     SPF_LAUNCH_CHECK("geo_pairs_kernel");
     geo_point_reduce_kernel<<<spf::div_up(max_points, 256), 256, 0, s>>>(pair_tmp, pair_off, point_slot, n_points, max_points, sdf, grad, wn);
     SPF_LAUNCH_CHECK("geo_point_reduce_kernel");

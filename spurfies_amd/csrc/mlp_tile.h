@@ -51,36 +51,6 @@ __device__ __forceinline__ void gemm_rows64(const float* X, const f32x4* wp, int
     }
 }
 
-// Same product with BOTH operands software-pipelined one k-step ahead.  Used by the ping-pong kernels, where only one wave
-// per SIMD is inside a GEMM phase at any time, so nothing else covers the LDS-read -> MFMA latency.
-template <int T, int LD = LDA>
-__device__ __forceinline__ void gemm_rows64_pf(const float* X, const f32x4* wp, int lane, f32x16 (&acc)[2][2]) {
-    const int i = lane & 31, h = lane >> 5;
-    const float* a0p = X + i * LD + 4 * h;
-    const float* a1p = a0p + 32 * LD;
-    const f32x4* bp = wp + lane;
-    f32x4 b0 = bp[0], b1 = bp[64];
-    f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p), a1 = *reinterpret_cast<const f32x4*>(a1p);
-#pragma unroll 4
-    for (int t = 0; t < T; ++t) {
-        f32x4 nb0 = b0, nb1 = b1, na0 = a0, na1 = a1;
-        if (t + 1 < T) {
-            nb0 = bp[(t + 1) * 128];
-            nb1 = bp[(t + 1) * 128 + 64];
-            na0 = *reinterpret_cast<const f32x4*>(a0p + 8 * (t + 1));
-            na1 = *reinterpret_cast<const f32x4*>(a1p + 8 * (t + 1));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
-        }
-        b0 = nb0; b1 = nb1; a0 = na0; a1 = na1;
-    }
-}
-
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
