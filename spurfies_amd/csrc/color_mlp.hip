@@ -110,11 +110,19 @@ __global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
 }
 
 // epilogue of a layer: + bias, (LeakyReLU), write to X.  Training mode also records the sign bits (one uint32 per
-// lane and row half: bit n*16+r, the same lane/register position the backward kernel's accumulators have) and
-// optionally streams the activation to HBM (input of the next layer's wgrad GEMM).
+// lane and row half: bit n*16+r, the same lane/register position the backward kernel's accumulators have).
+// [64][256] tile: LDS -> HBM as 1-KiB wave stores (the accumulator layout would give 4-byte stores two rows at a time)
+__device__ __forceinline__ void store_tile_256(const float* X, float* __restrict__ dst, int tid) {
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const int e4 = tid + 256 * u, row = e4 >> 6, c4 = e4 & 63;
+        *reinterpret_cast<f32x4*>(dst + row * 256 + 4 * c4) = *reinterpret_cast<const f32x4*>(X + row * LDA + 4 * c4);
+    }
+}
+
 template <bool STORE, bool ACT>
 __device__ __forceinline__ void c_fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave, int lane,
-                                               float* act_g /* tile base [64][256] or null */, uint32_t* mask_g /* [4][2][64] or null */) {
+                                               uint32_t* mask_g /* [4][2][64] or null */) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
     const float bv[2] = {bias[c0], bias[c0 + 32]};
 #pragma unroll
@@ -132,7 +140,6 @@ __device__ __forceinline__ void c_fwd_epilogue(float* X, const f32x16 (&acc)[2][
                 }
                 const int row = m * 32 + row_of(r, h);
                 X[row * LDA + c0 + 32 * n] = v;
-                if (STORE && act_g) act_g[row * 256 + c0 + 32 * n] = v;
             }
         if (STORE && ACT && mask_g) mask_g[(wave * 2 + m) * 64 + lane] = bits;
     }
@@ -177,36 +184,36 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(X + row * LDA + q4 * 16 + 4 * u) = f[u];
-            if (q4 == 0) {
+            {   // positional encoding of x_pi, internal columns 64..102: the 18 (frequency, component) sin/cos pairs of a row are
+                // split over its 4 threads; thread 0 also writes the raw offset, the pad column and the row's bookkeeping
                 float d[3] = {0.f, 0.f, 0.f};
-                float w = 0.f;
                 if (idx >= 0) {
                     d[0] = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
                     d[1] = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
                     d[2] = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
-                    w = wn[q];
                 }
-                float* e = X + row * LDA + 64;   // posenc block: internal columns 64..102
-                if (idx >= 0) {
-                    e[0] = d[0]; e[1] = d[1]; e[2] = d[2];
-                    float fr = 1.f;
+                float* e = X + row * LDA + 64;
 #pragma unroll
-                    for (int l = 0; l < N_FREQ; ++l) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float a = d[c] * fr;
-                            e[3 + 6 * l + c] = sinf(a);
-                            e[6 + 6 * l + c] = cosf(a);
+                for (int jj = 0; jj < 5; ++jj) {
+                    const int j = q4 + 4 * jj;          // 0..17 -> (l, c)
+                    if (j < 3 * N_FREQ) {
+                        const int l = j / 3, c = j % 3;
+                        float sv = 0.f, cv = 0.f;
+                        if (idx >= 0) {
+                            const float a = d[c] * (float)(1 << l);
+                            sv = sinf(a);
+                            cv = cosf(a);
                         }
-                        fr *= 2.f;
+                        e[3 + 6 * l + c] = sv;
+                        e[6 + 6 * l + c] = cv;
                     }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 39; ++c) e[c] = 0.f;
                 }
-                e[39] = 0.f;                      // pad column 103
-                smem[CL_W + row] = w;
-                s_p[row] = idx >= 0 ? p : -1;
+                if (q4 == 0) {
+                    e[0] = d[0]; e[1] = d[1]; e[2] = d[2];
+                    e[39] = 0.f;                      // pad column 103
+                    smem[CL_W + row] = idx >= 0 ? wn[q] : 0.f;
+                    s_p[row] = idx >= 0 ? p : -1;
+                }
             }
         }
         __syncthreads();
@@ -222,23 +229,25 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         zero_acc(acc);
         gemm_rows64<T_CIN>(X, pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128), lane, acc);
         __syncthreads();
-        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B1, wave, lane, STORE ? act1 + (size_t)tile * 64 * 256 : nullptr, mk);
+        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B1, wave, lane, mk);
         __syncthreads();
+        if (STORE) store_tile_256(X, act1 + (size_t)tile * 64 * 256, tid);
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_FW2 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B2, wave, lane, STORE ? act2 + (size_t)tile * 64 * 256 : nullptr, STORE ? mk + 512 : nullptr);
+        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B2, wave, lane, STORE ? mk + 512 : nullptr);
         __syncthreads();
+        if (STORE) store_tile_256(X, act2 + (size_t)tile * 64 * 256, tid);
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_FW3 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B3, wave, lane, nullptr, STORE ? mk + 1024 : nullptr);
+        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B3, wave, lane, STORE ? mk + 1024 : nullptr);
         __syncthreads();
         if (STORE) seg_reduce_rows(X, smem + CL_W, s_p, tid, agg3);   // agg3[p] = sum_j wn_j a3_j (rank structure of the last layer's wgrad)
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_FW4 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_fwd_epilogue<false, false>(X, acc, packed + CO_B4, wave, lane, nullptr, nullptr);   // last layer: no activation
+        c_fwd_epilogue<false, false>(X, acc, packed + CO_B4, wave, lane, nullptr);   // last layer: no activation
         __syncthreads();
         seg_reduce_rows(X, smem + CL_W, s_p, tid, agg);               // agg[p] = sum_j wn_j F_color(.)_j
         __syncthreads();
@@ -248,8 +257,7 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
 // backward epilogue: G_l = g_a * lrelu'(h_l) with the sign bits the forward recorded; write X and G_l (operand of the
 // wgrad GEMM) and add this tile's column sums to the bias gradient (256 floats per layer per tile, 128-B atomics)
 __device__ __forceinline__ void c_bwd_epilogue(float* X, const f32x16 (&acc)[2][2], int wave, int lane,
-                                               const uint32_t* __restrict__ mask_g, float* __restrict__ g_out,
-                                               float* __restrict__ g_bias) {
+                                               const uint32_t* __restrict__ mask_g, float* __restrict__ g_bias) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
     float cs[2] = {0.f, 0.f};
 #pragma unroll
@@ -263,7 +271,6 @@ __device__ __forceinline__ void c_bwd_epilogue(float* X, const f32x16 (&acc)[2][
                 float v = acc[m][n][r];
                 v = ((bits >> (n * 16 + r)) & 1u) ? v : v * 0.01f;
                 X[row * LDA + c0 + 32 * n] = v;
-                g_out[row * 256 + c0 + 32 * n] = v;
                 cs[n] += v;
             }
     }
@@ -324,18 +331,21 @@ color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_BW4 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, mk + 1024, G3 + tbase, g_bias + 512);
+        c_bwd_epilogue(X, acc, wave, lane, mk + 1024, g_bias + 512);
         __syncthreads();
+        store_tile_256(X, G3 + tbase, tid);
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_BW3 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, mk + 512, G2 + tbase, g_bias + 256);
+        c_bwd_epilogue(X, acc, wave, lane, mk + 512, g_bias + 256);
         __syncthreads();
+        store_tile_256(X, G2 + tbase, tid);
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_BW2 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, mk, G1 + tbase, g_bias);
+        c_bwd_epilogue(X, acc, wave, lane, mk, g_bias);
         __syncthreads();
+        store_tile_256(X, G1 + tbase, tid);
         // ---- d/d latent = G1 * W0[:, 39:103]; wave = (row half mt, latent half nt); scatter-add ------
         {
             const int mt = wave >> 1, nt = wave & 1, i = lane & 31, h = lane >> 5;
