@@ -109,6 +109,91 @@ wgrad_lds_kernel(const float* __restrict__ G, const float* __restrict__ A, int l
             for (int r = 0; r < 16; ++r) out[((m * NT + t) * 16 + r) * 64] = acc[m][t][r];
 }
 
+// C = 256 with LDS-DMA staging: every stage (16 rows of G and of A, 32 KB) is written into LDS by `global_load_lds_dwordx4`
+// (one wave instruction = one 1 KB row, no staging registers), three buffers deep, so that one stage is always in flight
+// ACROSS the barrier: counted `s_waitcnt vmcnt(8)` + raw `s_barrier`, never `__syncthreads()` (which would drain the DMA).
+// With register staging the next stage's HBM latency (~2 us under load) was exposed behind a 1.7 us compute phase.
+// The DMA is issued from inline asm on purpose: for the builtin, hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the
+// first LDS read that follows ANY pending LDS-DMA, which drains the stage that is meant to stay in flight.  M0 carries the
+// wave-uniform LDS destination; lane l's 16 bytes land at dst + 16 l.
+typedef __attribute__((address_space(3))) float* lptr_t;
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_row) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)lds_row);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+__global__ void __launch_bounds__(256, 1)
+wgrad_dma_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, const int32_t* __restrict__ n_rows_dev,
+                 int max_rows, float* __restrict__ slab) {
+    constexpr int NT = 8, U = 8, ROWS = 2 * U, NB = 3;
+    __shared__ __attribute__((aligned(16))) float sm[NB][2][ROWS][256];     // [buffer][G | A][row][col]   96 KB, one object
+    const int tid = threadIdx.x, lane = tid & 63, ci = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
+    int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    chunk += chunk & 1;
+    const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, n);
+    if (r0 >= r1) return;
+    const int nst = (r1 - r0 + ROWS - 1) / ROWS;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+    // wave w fills rows 4w..4w+3 of both halves: 8 DMA instructions per wave per stage.  Rows past r1 re-read row r1-1
+    // (finite data) and are cancelled on the G operand below.
+    auto issue = [&](int st) {
+        const int buf = st % NB, base = r0 + st * ROWS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = 4 * wave + j, row = min(base + lr, r1 - 1);
+            glds16(G + (size_t)row * 256 + 4 * lane, &sm[buf][0][lr][0]);
+            glds16(A + (size_t)row * lda + 4 * lane, &sm[buf][1][lr][0]);
+        }
+    };
+    issue(0);
+    if (nst > 1) issue(1);
+    for (int st = 0; st < nst; ++st) {
+        if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // stage st landed, st+1 may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                          // ... for every wave's share of it
+        if (st + 2 < nst) issue(st + 2);                                       // into the buffer read in iteration st-1
+        const int buf = st % NB, left = r1 - (r0 + st * ROWS);
+        // operands of step u+1 are read from LDS before the 16 MFMAs of step u are issued (explicit register double buffer)
+        float2 a[2];
+        f32x4 b4[2][2];
+        auto rd = [&](int u, int k) {
+            a[k] = *reinterpret_cast<const float2*>(&sm[buf][0][2 * u + h][64 * wave + 2 * ci]);
+            if (2 * u + h >= left) a[k] = float2{0.f, 0.f};
+            b4[k][0] = *reinterpret_cast<const f32x4*>(&sm[buf][1][2 * u + h][4 * ci]);
+            b4[k][1] = *reinterpret_cast<const f32x4*>(&sm[buf][1][2 * u + h][128 + 4 * ci]);
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = u & 1;
+            if (u + 1 < U) rd(u + 1, k ^ 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k].x, b4[k][t >> 2][t & 3], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k].y, b4[k][t >> 2][t & 3], acc[1][t], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // this stage's LDS reads retired before the next barrier
+    }
+    float* out = slab + ((size_t)blockIdx.x * 4 + wave) * (2 * NT * 16 * 64) + lane;   // slab[block][wave][m][t][reg][lane]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[((m * NT + t) * 16 + r) * 64] = acc[m][t][r];
+}
+
 // NT = 1 (C <= 32: the 21 view-encoding columns, a ones column for a bias gradient): direct loads, nothing to share
 __global__ void __launch_bounds__(256, 1)
 wgrad_narrow_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
@@ -169,14 +254,25 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk_lau
     const int o = 64 * wave + 2 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) + m;
     const int i = col_of<NT>(lane & 31, t);
     if (i >= C) return;
-    float s = 0.f;
-    for (int b = 0; b < active; ++b) s += slab[(size_t)b * PER + e];
-    dW[(size_t)o * ldw + i] += s;
+    // blockIdx.y takes every gridDim.y-th slab (a serial walk over all 256 slabs is latency-bound: ~60 us whatever the width)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int step = gridDim.y;
+    int b = blockIdx.y;
+    for (; b + 3 * step < active; b += 4 * step) {
+        s0 += slab[(size_t)b * PER + e];
+        s1 += slab[(size_t)(b + step) * PER + e];
+        s2 += slab[(size_t)(b + 2 * step) * PER + e];
+        s3 += slab[(size_t)(b + 3 * step) * PER + e];
+    }
+    for (; b < active; b += step) s0 += slab[(size_t)b * PER + e];
+    atomicAdd(&dW[(size_t)o * ldw + i], (s0 + s1) + (s2 + s3));
 }
 
 }  // namespace
 
 extern "C" {
+
+static constexpr int RSPLIT = 16;
 
 int64_t spf_wgrad_workspace_floats(int32_t C) { return (int64_t)256 * 256 * (C > 128 ? 256 : (C > 32 ? 128 : 32)); }
 
@@ -192,14 +288,15 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     if (blocks > 256) blocks = 256;   // one workgroup per CU, one wave per SIMD
     const int per = 4 * 2 * NT * 16 * 64;
     if (NT == 8) {
-        wgrad_lds_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
-        wgrad_reduce_kernel<8><<<spf::div_up(per, 256), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
+        if (C == 256) wgrad_dma_kernel<<<blocks, 256, 0, s>>>(G, A, lda, n_rows, max_rows, workspace);
+        else wgrad_lds_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     } else if (NT == 4) {
         wgrad_lds_kernel<4><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
-        wgrad_reduce_kernel<4><<<spf::div_up(per, 256), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
+        wgrad_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     } else {
         wgrad_narrow_kernel<<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
-        wgrad_reduce_kernel<1><<<spf::div_up(per, 256), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
+        wgrad_reduce_kernel<1><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     }
     SPF_LAUNCH_CHECK("wgrad_kernel");
     return SPF_OK;
