@@ -292,6 +292,49 @@ int spf_tv_forward(const float* feat_geo, const int32_t* nbr, const float* w, co
 int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm,
                     const float* g_tv, int32_t n, int32_t k, float* g_feat_geo, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Ray set-up of one view
+ * ---------------------------------------------------------------------------------------- */
+
+/* uv [R,2] pixel coordinates, pose [4,4] camera-to-world (row-major), intrinsics [k_stride,k_stride] (3 or 4) ->
+ *   ray_dirs [R,3]    unit world-space directions  normalize(R_cw lift(uv) + t - t)
+ *   cam_loc [R,3]     the camera centre repeated per ray
+ *   depth_scale [R]   z of the camera-space unit direction (the model's `depth_scale`)
+ * Replaces rend_util.get_camera_params + lift (spurfies/utils/rend_util.py:60-95,143-156) as called twice per forward
+ * at spurfies/model/pointneus_disent.py:640-650 (batch of one view, matrix poses). */
+int spf_camera_rays(const float* uv, const float* pose, const float* intrinsics, int32_t k_stride, int32_t R,
+                    float* ray_dirs, float* cam_loc, float* depth_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss terms of one optimisation step — replaces VolSDFLoss.forward (spurfies/model/loss.py:42-49,
+ * 51-101) and the pseudo-point term of spurfies/model/pointneus_disent.py:765-780.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct spf_loss_weights {
+    float rgb, eikonal, tv, local, pseudo; /* config/ours.yaml:15-20 */
+    int32_t world;                         /* ranks sharing the batch (tv / constant terms are split over them) */
+} spf_loss_weights;
+
+int64_t spf_loss_workspace_floats(void);
+
+/* rgb, rgb_gt [R,3]; acc [R] = sum_j w_j; mask_gt[r * mask_stride], r < R; grad [rows,3] + slot_valid [rows] (d sdf/dx of the shading slots;
+ * NULL skips the eikonal term) with n_points[0] = number of valid slots (device); psdf [R] SDF at the rendered points with
+ * pvalid / ray_valid [R] (NULL skips the pseudo term); tv = device scalar (NULL: 0); denom = NULL or device
+ * {R_total, P_total, pseudo_count_total} (global counts of a ray-sharded batch).
+ *   total[0]  the weighted loss;   terms[8] = {loss, rgb, eikonal, tv, mask, local, pseudo, local pseudo count}
+ *   den[4]    normalisers for spf_loss_backward.   workspace: spf_loss_workspace_floats() floats. */
+int spf_loss_forward(const float* rgb, const float* rgb_gt, const float* acc, const float* mask_gt, int32_t mask_stride,
+                     const float* grad, const uint8_t* slot_valid, int64_t rows, const int32_t* n_points, const float* psdf,
+                     const uint8_t* pvalid, const uint8_t* ray_valid, const float* tv, const float* denom, int32_t R,
+                     const spf_loss_weights* weights, float* workspace, float* total, float* terms, float* den,
+                     void* stream);
+
+/* g_total = dL/d total (device scalar) -> g_rgb [R,3], g_acc [R], g_psdf [R] (may be NULL), g_tv[0] (may be NULL).
+ * The eikonal term has no gradient w.r.t. any trainable tensor. */
+int spf_loss_backward(const float* g_total, const float* den, const spf_loss_weights* weights, const float* rgb,
+                      const float* rgb_gt, const float* acc, const float* mask_gt, int32_t mask_stride, const float* psdf,
+                      const uint8_t* pvalid, const uint8_t* ray_valid, int32_t R, float* g_rgb, float* g_acc,
+                      float* g_psdf, float* g_tv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

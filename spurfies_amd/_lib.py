@@ -27,6 +27,12 @@ _I = C.c_int32
 _F = C.c_float
 
 # name -> (restype, argtypes): exactly the entry points of include/spurfies_hip.h
+class LossWeights(C.Structure):
+    """spf_loss_weights"""
+    _fields_ = [("rgb", C.c_float), ("eikonal", C.c_float), ("tv", C.c_float), ("local", C.c_float), ("pseudo", C.c_float),
+                ("world", C.c_int32)]
+
+
 SIGNATURES = {
     "spf_abi_version": (C.c_int, []),
     "spf_last_error": (C.c_char_p, []),
@@ -60,6 +66,10 @@ SIGNATURES = {
     "spf_scatter_add_rows": (C.c_int, [_P, _P, C.c_int64, _I, _P, _P]),
     "spf_tv_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "spf_camera_rays": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "spf_loss_workspace_floats": (C.c_int64, []),
+    "spf_loss_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _I, C.POINTER(LossWeights), _P, _P, _P, _P, _P]),
+    "spf_loss_backward": (C.c_int, [_P, _P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

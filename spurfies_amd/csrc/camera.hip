@@ -1,0 +1,53 @@
+// Pixel -> ray set-up of one view (K9 of DESIGN.md).
+//
+//  spf_camera_rays   rend_util.get_camera_params + lift (spurfies/utils/rend_util.py:60-95,143-156) for the two calls
+//                    the model makes per forward (pointneus_disent.py:640-650): world-space unit directions with the
+//                    view's pose, and the z component of the camera-space unit direction (`depth_scale`).
+//                    ~45 elementwise / bmm launches of the PyTorch formulation -> one launch.
+#include "common.h"
+
+namespace {
+using namespace spf;
+
+__global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __restrict__ pose, const float* __restrict__ K, int kstride,
+                                   int R, float* __restrict__ ray_dirs, float* __restrict__ cam_loc, float* __restrict__ depth_scale) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float fx = K[0], sk = K[1], cx = K[2], fy = K[kstride + 1], cy = K[kstride + 2];
+    const float x = uv[2 * r], y = uv[2 * r + 1];
+    // lift(), z = 1, in the reference's operation order (rend_util.py:143-156)
+    const float xl = (x - cx + cy * sk / fy - sk * y / fy) / fx * 1.0f;
+    const float yl = (y - cy) / fy * 1.0f;
+    const float zl = 1.0f;
+    const float t[3] = {pose[3], pose[7], pose[11]};
+    float d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float w = (pose[4 * i] * xl + pose[4 * i + 1] * yl + pose[4 * i + 2] * zl) + t[i];   // R c + t
+        d[i] = w - t[i];                                                                           // world - cam_loc
+    }
+    const float n = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);                 // F.normalize, eps 1e-12
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ray_dirs[3 * r + i] = d[i] / n;
+        cam_loc[3 * r + i] = t[i];
+    }
+    // identity pose: direction = normalize(lifted point); depth_scale = its z
+    depth_scale[r] = zl / fmaxf(sqrtf(xl * xl + yl * yl + zl * zl), 1e-12f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int spf_camera_rays(const float* uv, const float* pose, const float* intrinsics, int32_t k_stride, int32_t R, float* ray_dirs,
+                    float* cam_loc, float* depth_scale, void* stream) {
+    if (R < 0 || (k_stride != 3 && k_stride != 4)) return spf::fail(SPF_EINVAL, "spf_camera_rays: k_stride must be 3 or 4 (got %d)", k_stride);
+    if (R == 0) return SPF_OK;
+    if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || !depth_scale) return spf::fail(SPF_EINVAL, "spf_camera_rays: null pointer");
+    camera_rays_kernel<<<spf::div_up(R, 256), 256, 0, (hipStream_t)stream>>>(uv, pose, intrinsics, k_stride, R, ray_dirs, cam_loc, depth_scale);
+    SPF_LAUNCH_CHECK("camera_rays_kernel");
+    return SPF_OK;
+}
+
+}  // extern "C"

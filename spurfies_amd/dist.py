@@ -64,15 +64,18 @@ def sharded_loss(loss_mod, out, ground_truth, group=None):
     tv depends only on replicated state, so each rank contributes tv / world."""
     dev = out["rgb_values"].device
     G = world_size(group)
+    if "_fused" in out:                          # sync-free mode: fused loss kernels with the all-reduced counts as normalisers
+        f = out["_fused"]
+        cnt = (f["pvalid"].bool() & f["ray_valid"].bool()).sum().float()
+        counts = torch.stack([torch.full((), float(out["rgb_values"].shape[0]), device=dev), f["n_points"][0].float(), cnt])
+        all_reduce_sum(counts, group)
+        return loss_mod.fused_forward(out, ground_truth, denom=counts, world=G)
     rgb_gt = ground_truth["rgb"].to(dev).reshape(-1, 3)
     mask_gt = ground_truth["mask"].to(dev).squeeze()[:, 0][..., None]
     R_loc = out["rgb_values"].shape[0]
     g = out.get("grad_theta")
-    if "eikonal_sum" in out:                     # sync-free mode: sum and count were formed on the device
-        eik_sum, P_loc = out["eikonal_sum"], out["point_count"].float()
-    else:
-        eik_sum = ((g.norm(2, dim=1) - 1) ** 2).sum() if g is not None else torch.zeros((), device=dev)
-        P_loc = torch.full((), float(0 if g is None else g.shape[0]), device=dev)
+    eik_sum = ((g.norm(2, dim=1) - 1) ** 2).sum() if g is not None else torch.zeros((), device=dev)
+    P_loc = torch.full((), float(0 if g is None else g.shape[0]), device=dev)
     pseudo_cnt = out.get("pseudo_count", torch.ones((), device=dev))
     counts = torch.stack([torch.full((), float(R_loc), device=dev), P_loc, pseudo_cnt.float()])
     all_reduce_sum(counts, group)

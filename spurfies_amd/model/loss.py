@@ -27,17 +27,37 @@ class VolSDFLoss(nn.Module):
     def get_eikonal_loss(self, grad_theta):
         return ((grad_theta.norm(2, dim=1) - 1) ** 2).mean()
 
+    def fused_forward(self, model_outputs, ground_truth, denom=None, world=1):
+        """Sync-free mode: the model handed over the renderer's raw per-ray outputs (`_fused`), and every term, the weighted
+        total and their gradients come from spf_loss_forward / spf_loss_backward (3 launches).  `denom` = device
+        {R_total, P_total, pseudo_count_total} for ray-sharded batches (spurfies_amd/dist.py)."""
+        from .. import _lib, ops
+
+        f = model_outputs["_fused"]
+        dev = model_outputs["rgb_values"].device
+        rgb_gt = ground_truth["rgb"].to(dev).reshape(-1, 3).float().contiguous()
+        mask = ground_truth["mask"].to(dev).float()
+        R = rgb_gt.shape[0]
+        mask = mask.reshape(R, -1)                      # [R,3] (the reference repeats the mask per channel) or [R,1]: column 0
+        w = _lib.LossWeights(self.rgb_weight, self.eikonal_weight, self.tv_weight, self.local_weight, self.pseudo_weight, int(world))
+        tv = model_outputs.get("tv_loss") if self.tv_weight > 0 else None
+        psdf = f["psdf"] if self.pseudo_weight > 0 else None
+        total, t = ops.FusedLoss.apply(model_outputs["rgb_values"], f["acc"], psdf, tv, f["grad"], f["slot_valid"], f["n_points"],
+                                       f["pvalid"], f["ray_valid"], rgb_gt, mask, mask.stride(0), w, denom)
+        self.iter_step += 1
+        return {"loss": total, "rgb_loss": t[1], "eikonal_loss": t[2], "tv_loss": t[3], "mask_loss": t[4], "local_loss": t[5],
+                "pseudo_loss": t[6]}
+
     def forward(self, model_outputs, ground_truth):
+        if "_fused" in model_outputs:
+            return self.fused_forward(model_outputs, ground_truth)
         dev = model_outputs["rgb_values"].device
         rgb_gt = ground_truth["rgb"].to(dev)
         mask_gt = ground_truth["mask"].to(dev)
         zero = torch.zeros((), device=dev)
         out = {"rgb_loss": self.get_rgb_loss(model_outputs["rgb_values"], rgb_gt)}
         g = model_outputs.get("grad_theta")
-        if "eikonal_value" in model_outputs:        # sync-free mode: the model formed the mean on the device
-            out["eikonal_loss"] = model_outputs["eikonal_value"].reshape(())
-        else:
-            out["eikonal_loss"] = self.get_eikonal_loss(g) if g is not None else zero
+        out["eikonal_loss"] = self.get_eikonal_loss(g) if g is not None else zero
         out["tv_loss"] = model_outputs["tv_loss"] if ("tv_loss" in model_outputs and self.tv_weight > 0) else zero
         if "weights" in model_outputs:
             wsum = model_outputs["weights"].sum(-1, keepdim=True)

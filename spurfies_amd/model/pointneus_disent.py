@@ -29,6 +29,20 @@ from .utils import TVGraph, load_neural_points
 SDF_FILL = ops.SDF_FILL
 
 
+class DistPoints(torch.autograd.Function):
+    """o + t d for the rendered depth t (pointneus_disent.py:765-767); gradient to t only (rays carry none)."""
+
+    @staticmethod
+    def forward(ctx, cam_loc, ray_dirs, dist):
+        ctx.save_for_backward(ray_dirs)
+        return torch.addcmul(cam_loc, ray_dirs, dist.unsqueeze(-1))
+
+    @staticmethod
+    def backward(ctx, g):
+        (ray_dirs,) = ctx.saved_tensors
+        return None, None, (g * ray_dirs).sum(-1)
+
+
 class PointVolSDF(nn.Module):
     def __init__(self, conf, scan_id, dataset, neural_points=None, device="cuda"):
         """`neural_points` ({'pts': [N,3], 'colors': [N,3] 0..255}) bypasses the .ply on disk
@@ -203,10 +217,16 @@ class PointVolSDF(nn.Module):
         SR, k = conf.max_shading_pts, conf.k
         grid = self._grid()
 
-        ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
-        dirs_cam, _ = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], intrinsics)
-        depth_scale = dirs_cam[0, :, 2:]
-        points, _, cam_loc, ray_dirs = self.get_importance_rays(cam_loc, ray_dirs, self, fast, iter_step)
+        rays = ops.camera_rays(uv, pose, intrinsics)               # one launch; None for multi-view batches
+        if rays is not None:
+            ray_dirs, cam_loc, depth_scale = rays
+            self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast, iter_step)
+            points = self.ray_sampler.last_points
+        else:
+            ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+            dirs_cam, _ = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], intrinsics)
+            depth_scale = dirs_cam[0, :, 2:]
+            points, _, cam_loc, ray_dirs = self.get_importance_rays(cam_loc, ray_dirs, self, fast, iter_step)
         R = ray_dirs.shape[0]
 
         # ---- kNN of the main pass, dense [R,SR] ------------------------------------------------
@@ -237,28 +257,33 @@ class PointVolSDF(nn.Module):
         colors = colors.view(R, SR, 3)
 
         # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------
-        weights, rgb, depth, dist_map, _ = ops.Render.apply(sdf, colors, self.density.get_beta(), q["slot_valid"], z_slots, deltas)
-        depth = torch.where(ray_mask[:, None], depth, torch.ones_like(depth))
-        far_fill = float(conf.ray_sampler.far)
-        depth_vals = torch.where(ray_mask[:, None], z_slots * depth_scale, torch.full_like(z_slots, far_fill))
-        xyz = torch.where(valid.unsqueeze(-1), x.view(R, SR, 3), torch.zeros(1, device=dev))
+        weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta(), q["slot_valid"], z_slots, deltas)
+        output = {"rgb_values": rgb, "weights": weights, "local_loss": torch.zeros((), device=dev)}
+        if not static:          # per-slot maps the trainer never reads in an optimisation step (plots only)
+            far_fill = float(conf.ray_sampler.far)
+            output["depth_values"] = torch.where(ray_mask[:, None], depth, torch.ones_like(depth))
+            output["depth_vals"] = torch.where(ray_mask[:, None], z_slots * depth_scale, torch.full_like(z_slots, far_fill))
+            output["xyz"] = torch.where(valid.unsqueeze(-1), x.view(R, SR, 3), torch.zeros(1, device=dev))
 
         # ---- pseudo-point loss (:765-780) --------------------------------------------------------
-        pseudo_pts_loss = torch.zeros((), device=dev)
-        pseudo_sum, pseudo_cnt = pseudo_pts_loss, pseudo_pts_loss
-        if P > 0:
-            pts_rendered = cam_loc + ray_dirs * dist_map[:, None]
-            pr = self._sdf_points(pts_rendered, with_grad=True)
-            use = pr["valid"].bool() & ray_mask
-            cnt = use.sum()
-            pseudo_sum, pseudo_cnt = torch.where(use, pr["sdf"].abs(), torch.zeros_like(pr["sdf"])).sum(), cnt
-            l1 = pseudo_sum / cnt.clamp(min=1)
-            # no rendered point has a neighbour -> the reference's constant 1000 (no gradient)
-            pseudo_pts_loss = torch.where(cnt > 0, l1, torch.full_like(l1, SDF_FILL))
-
-        output = {"rgb_values": rgb, "depth_values": depth, "depth_vals": depth_vals, "weights": weights, "xyz": xyz,
-                  "local_loss": torch.zeros((), device=dev), "pseudo_pts_loss": pseudo_pts_loss,
-                  "pseudo_sum": pseudo_sum, "pseudo_count": pseudo_cnt}  # sums + counts for ray-sharded steps (dist.py)
+        if static:
+            # SDF at the rendered points, dense [R] (1000 where no neighbour); the masked mean is formed by the loss kernels
+            pr = self._sdf_points(DistPoints.apply(cam_loc, ray_dirs, dist_map), with_grad=True)
+            output["_fused"] = {"acc": acc, "grad": gradients.detach(), "slot_valid": q["slot_valid"].view(-1), "n_points": pl.n_points,
+                                "psdf": pr["sdf"], "pvalid": pr["valid"], "ray_valid": q["ray_valid"]}
+        else:
+            pseudo_pts_loss = torch.zeros((), device=dev)
+            pseudo_sum, pseudo_cnt = pseudo_pts_loss, pseudo_pts_loss
+            if P > 0:
+                pts_rendered = cam_loc + ray_dirs * dist_map[:, None]
+                pr = self._sdf_points(pts_rendered, with_grad=True)
+                use = pr["valid"].bool() & ray_mask
+                cnt = use.sum()
+                pseudo_sum, pseudo_cnt = torch.where(use, pr["sdf"].abs(), torch.zeros_like(pr["sdf"])).sum(), cnt
+                l1 = pseudo_sum / cnt.clamp(min=1)
+                # no rendered point has a neighbour -> the reference's constant 1000 (no gradient)
+                pseudo_pts_loss = torch.where(cnt > 0, l1, torch.full_like(l1, SDF_FILL))
+            output.update({"pseudo_pts_loss": pseudo_pts_loss, "pseudo_sum": pseudo_sum, "pseudo_count": pseudo_cnt})
         if self._tv_graph is None:
             self._tv_graph = TVGraph(grid, self.neural_pts, k, conf.r)
         output["tv_loss"] = self._tv_graph.loss(self.neural_feats_geometry)
@@ -267,13 +292,7 @@ class PointVolSDF(nn.Module):
             nrm = torch.where(valid.unsqueeze(-1), g / g.norm(2, -1, keepdim=True), torch.zeros(1, device=dev))
             output["normal_map"] = torch.sum(weights.unsqueeze(-1) * nrm, 1).detach()
         elif static:
-            # mean over the valid points of (|d sdf/dx| - 1)^2 (loss.py:47-49), formed on the device; its gradient w.r.t. every
-            # trainable tensor is exactly zero, so it is a value only
-            gn = gradients.view(R, SR, 3).norm(2, dim=-1)
-            output["eikonal_sum"] = torch.where(valid, (gn - 1) ** 2, torch.zeros_like(gn)).sum()
-            output["point_count"] = pl.n_points[0]
-            output["eikonal_value"] = output["eikonal_sum"] / pl.n_points[0].clamp(min=1)
-            output["grad_theta"] = None
+            output["grad_theta"] = None      # eikonal: a value only (zero gradient), formed by the loss kernels
         else:
             output["grad_theta"] = gradients[rows] if P > 0 else None
         return output

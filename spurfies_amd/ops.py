@@ -497,3 +497,76 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None):
         _lib.check(_lib.lib().spf_wgrad(_lib.ptr(G), _lib.ptr(A), A.stride(0), C, _lib.ptr(n_rows), min(G.shape[0], A.shape[0]), _lib.ptr(out), ldw,
                                         _lib.ptr(_wgrad_ws[key]), _lib.stream_ptr()), "spf_wgrad")
     return out
+
+
+# ---- ray set-up and loss terms (one launch each instead of dozens of elementwise PyTorch kernels) ----------------
+def camera_rays(uv, pose, intrinsics):
+    """uv [1,R,2], pose [1,4,4], intrinsics [1,3|4,3|4] -> (ray_dirs [R,3], cam_loc [R,3], depth_scale [R,1]) — the two
+    rend_util.get_camera_params calls of pointneus_disent.py:640-650.  None when the batch holds several views or
+    quaternion poses (the caller then keeps the PyTorch formulation)."""
+    if uv.dim() != 3 or uv.shape[0] != 1 or pose.shape[-2:] != (4, 4) or not uv.is_cuda:
+        return None
+    R, dev = uv.shape[1], uv.device
+    uv_c = uv.detach().reshape(R, 2).float().contiguous()
+    pose_c = pose.detach().reshape(4, 4).float().contiguous()
+    K = intrinsics.detach().float()
+    ks = K.shape[-1]
+    K = K.reshape(ks, ks).contiguous()
+    dirs = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    loc = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    scale = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_camera_rays(_lib.ptr(uv_c), _lib.ptr(pose_c), _lib.ptr(K), ks, R, _lib.ptr(dirs), _lib.ptr(loc),
+                                              _lib.ptr(scale), _lib.stream_ptr()), "spf_camera_rays")
+    return dirs, loc, scale
+
+
+_loss_ws = {}
+
+
+class FusedLoss(torch.autograd.Function):
+    """(total [], terms [8]) = spf_loss_forward(...); differentiable w.r.t. rgb, acc, psdf and tv (spf_loss_backward).
+    terms = {loss, rgb, eikonal, tv, mask, local, pseudo, pseudo count} (values only)."""
+
+    @staticmethod
+    def forward(ctx, rgb, acc, psdf, tv, grad, slot_valid, n_points, pvalid, ray_valid, rgb_gt, mask_gt, mask_stride, weights, denom):
+        dev = rgb.device
+        R = rgb.shape[0]
+        rgb_c, acc_c = rgb.detach().contiguous(), acc.detach().reshape(R).contiguous()
+        psdf_c = None if psdf is None else psdf.detach().reshape(R).contiguous()
+        tv_c = None if tv is None else tv.detach().reshape(1)
+        key = str(dev)
+        if key not in _loss_ws:
+            _loss_ws[key] = torch.empty((int(_lib.lib().spf_loss_workspace_floats()),), dtype=torch.float32, device=dev)
+        total = torch.empty((), dtype=torch.float32, device=dev)
+        terms = torch.empty((8,), dtype=torch.float32, device=dev)
+        den = torch.empty((4,), dtype=torch.float32, device=dev)
+        rows = 0 if grad is None else grad.shape[0]
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_loss_forward(_lib.ptr(rgb_c), _lib.ptr(rgb_gt), _lib.ptr(acc_c), _lib.ptr(mask_gt), mask_stride,
+                                                   _lib.ptr(grad), _lib.ptr(slot_valid), rows, _lib.ptr(n_points), _lib.ptr(psdf_c),
+                                                   _lib.ptr(pvalid), _lib.ptr(ray_valid), _lib.ptr(tv_c), _lib.ptr(denom), R, weights,
+                                                   _lib.ptr(_loss_ws[key]), _lib.ptr(total), _lib.ptr(terms), _lib.ptr(den),
+                                                   _lib.stream_ptr()), "spf_loss_forward")
+        ctx.save_for_backward(rgb_c, acc_c, psdf_c, rgb_gt, mask_gt, pvalid, ray_valid, den)
+        ctx.misc = (mask_stride, weights, acc.shape, None if psdf is None else psdf.shape, tv is not None)
+        ctx.mark_non_differentiable(terms)
+        return total, terms
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        rgb, acc, psdf, rgb_gt, mask_gt, pvalid, ray_valid, den = ctx.saved_tensors
+        mask_stride, weights, acc_shape, psdf_shape, has_tv = ctx.misc
+        R, dev = rgb.shape[0], rgb.device
+        g = g_total.detach().reshape(1).contiguous()
+        g_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        g_acc = torch.empty((R,), dtype=torch.float32, device=dev)
+        g_psdf = None if psdf is None else torch.empty((R,), dtype=torch.float32, device=dev)
+        g_tv = torch.empty((1,), dtype=torch.float32, device=dev) if has_tv else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_loss_backward(_lib.ptr(g), _lib.ptr(den), weights, _lib.ptr(rgb), _lib.ptr(rgb_gt), _lib.ptr(acc),
+                                                    _lib.ptr(mask_gt), mask_stride, _lib.ptr(psdf), _lib.ptr(pvalid), _lib.ptr(ray_valid), R,
+                                                    _lib.ptr(g_rgb), _lib.ptr(g_acc), _lib.ptr(g_psdf), _lib.ptr(g_tv), _lib.stream_ptr()),
+                       "spf_loss_backward")
+        return (g_rgb, g_acc.view(acc_shape), None if g_psdf is None else g_psdf.view(psdf_shape), None if g_tv is None else g_tv.reshape(()),
+                None, None, None, None, None, None, None, None, None, None)

@@ -49,18 +49,20 @@ def _patch_draws(rank, world):
     def rand(*shape, **kw):
         shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
         if len(shp) == 2 and shp[0] == R_TOTAL // world and world > 1:
-            return orig((R_TOTAL, shp[1]), **kw)[rank::world].contiguous()
+            out = kw.pop("out", None)                 # the sync-free step draws into pinned buffers
+            mine = orig((R_TOTAL, shp[1]), **kw)[rank::world].contiguous()
+            return mine if out is None else out.copy_(mine)
         return orig(*shape, **kw)
 
     torch.rand = rand
 
 
-def _run_step(rank, world):
+def _run_step(rank, world, sync_free=False):
     from spurfies_amd import dist as sdist
     from spurfies_amd.train import TrainStep
 
     model, uv, rgb, mask, K, pose = _setup_model()
-    step = TrainStep(model)
+    step = TrainStep(model, sync_free=sync_free)
     sel = sdist.shard_rays(R_TOTAL)
     torch.manual_seed(21)
     _patch_draws(rank, world)
@@ -72,28 +74,30 @@ def _run_step(rank, world):
     return total.item(), step.flat.buffer.detach().cpu().numpy()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sync_free=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(0)
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _run_step(rank, world))
+        q.put((rank,) + _run_step(rank, world, sync_free))
     finally:
         torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_process():
+@pytest.mark.parametrize("sync_free", [False, True])
+def test_two_ranks_on_one_gpu_match_single_process(sync_free):
+    """sync_free=True exercises the fused loss kernels with all-reduced normalisers (spf_loss_forward's `denom`)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sync_free)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in range(2))
+    res = sorted(q.get(timeout=120) for _ in range(2))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    loss1, g1 = _run_step(0, 1)
+    loss1, g1 = _run_step(0, 1, sync_free)
     for _, loss2, g2 in res:
         np.testing.assert_allclose(loss2, loss1, rtol=2e-5)
         # clipped gradients (norm <= 1): identical up to float-atomic summation order
