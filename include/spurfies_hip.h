@@ -178,13 +178,13 @@ int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const
                       float* act0, float* act1, float* act2, float* agg3, uint32_t* masks, void* stream);
 
 /* Data-gradient chain for g_agg[p,256] = dL/d agg: writes the pre-activation gradients G1..G3 [T,256]
- * (weight gradients of layers 1..3 are then dW_l = G_l^T act_{l-1}, plain GEMMs), adds their column sums
- * to g_bias [3,256] (bias gradients of layers 1..3) and accumulates the colour-latent gradient into
- * g_feat_color[N,64] (float atomics). */
+ * (weight gradients of F_color.0/2/4 are then dW_l = G_l^T act_{l-1}: spf_wgrad), ADDS their column sums to
+ * g_b0, g_b2, g_b4 [256] (bias gradients of F_color.0/2/4) and ADDS the colour-latent gradient into
+ * g_feat_color[N,64] (float atomics).  The accumulating outputs may point straight into the gradient buffers. */
 int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot,
                        const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs,
                        int32_t k, const float* packed, const uint32_t* masks, float* G1, float* G2, float* G3,
-                       float* g_bias, float* g_feat_color, void* stream);
+                       float* g_b0, float* g_b2, float* g_b4, float* g_feat_color, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Radiance head R — replaces the second half of get_color, spurfies/model/pointneus_disent.py:338-346
@@ -203,10 +203,12 @@ int spf_rhead_forward(const float* agg, const float* ray_dirs, const int32_t* po
                       float* act1, float* act2, uint32_t* masks, void* stream);
 
 /* Given g_colors[row,3]: writes G1, G2 [T,256] (pre-activation gradients; dW_l = G_l^T act_{l-1} are plain GEMMs),
- * g_agg [T,256] (rows >= P are scratch), and adds into g_small [1283] = [db0 (256) | db2 (256) | dW4 (3x256) | db4 (3)] (ZEROED by the caller). */
+ * g_agg [T,256] (rows >= P are scratch), and ADDS into g_b0, g_b2 [256], g_w4 [3,256], g_b4 [3] (gradients of R.0.bias,
+ * R.2.bias, R.4.weight, R.4.bias; float atomics — the caller zeroes them or points them at its gradient buffers). */
 int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t* point_slot, const int32_t* n_points,
                        int32_t max_points, const float* packed, const float* act2, const uint32_t* masks,
-                       float* G1, float* G2, float* g_agg, float* g_small, void* stream);
+                       float* G1, float* G2, float* g_agg, float* g_b0, float* g_b2, float* g_w4, float* g_b4,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * VolSDF error-bounded sampler — replaces UniformSampler.get_z_vals (spurfies/model/ray_sampler.py:33-59),

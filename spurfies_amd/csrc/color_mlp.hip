@@ -286,7 +286,8 @@ color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict
                       const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
                       const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k, const float* packed,
                       const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3,
-                      float* __restrict__ g_bias /* [3][256]: layers 1..3 */, float* __restrict__ g_feat_col) {
+                      float* __restrict__ g_b0, float* __restrict__ g_b2, float* __restrict__ g_b4 /* bias gradients [256] of layers 0, 2, 4 */,
+                      float* __restrict__ g_feat_col) {
     __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL];
     float* X = smem + CL_X;
     int* s_idx = reinterpret_cast<int*>(smem + CL_W);
@@ -331,19 +332,19 @@ color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_BW4 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, mk + 1024, g_bias + 512);
+        c_bwd_epilogue(X, acc, wave, lane, mk + 1024, g_b4);
         __syncthreads();
         store_tile_256(X, G3 + tbase, tid);
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_BW3 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, mk + 512, g_bias + 256);
+        c_bwd_epilogue(X, acc, wave, lane, mk + 512, g_b2);
         __syncthreads();
         store_tile_256(X, G2 + tbase, tid);
         zero_acc(acc);
         gemm_rows64<T_HID>(X, pk4 + (CO_BW2 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, mk, g_bias);
+        c_bwd_epilogue(X, acc, wave, lane, mk, g_b0);
         __syncthreads();
         store_tile_256(X, G1 + tbase, tid);
         // ---- d/d latent = G1 * W0[:, 39:103]; wave = (row half mt, latent half nt); scatter-add ------
@@ -411,15 +412,16 @@ int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const
 
 int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* pair_off,
                        const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* packed,
-                       const uint32_t* masks, float* G1, float* G2, float* G3, float* g_bias, float* g_feat_color, void* stream) {
+                       const uint32_t* masks, float* G1, float* G2, float* G3, float* g_b0, float* g_b2, float* g_b4, float* g_feat_color,
+                       void* stream) {
     if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_backward: bad sizes");
     if (max_pairs == 0) return SPF_OK;
-    if (!g_agg || !nbr || !wn || !pair_off || !pair_point || !packed || !masks || !G1 || !G2 || !G3 || !g_bias || !g_feat_color)
+    if (!g_agg || !nbr || !wn || !pair_off || !pair_point || !packed || !masks || !G1 || !G2 || !G3 || !g_b0 || !g_b2 || !g_b4 || !g_feat_color)
         return spf::fail(SPF_EINVAL, "spf_color_backward: null pointer");
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
     color_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_agg, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
-                                                                   masks, G1, G2, G3, g_bias, g_feat_color);
+                                                                   masks, G1, G2, G3, g_b0, g_b2, g_b4, g_feat_color);
     SPF_LAUNCH_CHECK("color_backward_kernel");
     return SPF_OK;
 }

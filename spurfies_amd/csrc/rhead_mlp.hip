@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256, 2)
 rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restrict__ colors, const int32_t* __restrict__ point_slot,
                       const int32_t* __restrict__ n_points_dev, int max_points, const float* packed, const float* __restrict__ act2,
                       const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ g_agg,
-                      float* __restrict__ g_small /* [256 db1 | 256 db2 | 768 dW3 | 3 db3] */) {
+                      float* __restrict__ g_b0, float* __restrict__ g_b2, float* __restrict__ g_w4 /* [3,256] */, float* __restrict__ g_b4 /* [3] */) {
     __shared__ __attribute__((aligned(16))) float smem[RL_TOTAL];
     float* X = smem + RL_X;
     float* s_g3 = smem + RL_G3;
@@ -261,13 +261,13 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
                 a1 += s_g3[row * 4 + 1] * a;
                 a2v += s_g3[row * 4 + 2] * a;
             }
-            atomicAdd(&g_small[512 + tid], a0);
-            atomicAdd(&g_small[512 + 256 + tid], a1);
-            atomicAdd(&g_small[512 + 512 + tid], a2v);
+            atomicAdd(&g_w4[tid], a0);
+            atomicAdd(&g_w4[256 + tid], a1);
+            atomicAdd(&g_w4[512 + tid], a2v);
             if (tid < 3) {
                 float s = 0.f;
                 for (int row = 0; row < 64; ++row) s += s_g3[row * 4 + tid];
-                atomicAdd(&g_small[1280 + tid], s);
+                atomicAdd(&g_b4[tid], s);
             }
         }
         const uint32_t* mk = masks + (size_t)tile * 2 * 512;
@@ -297,7 +297,7 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const float t = cs[n] + __shfl_xor(cs[n], 32);
-                if (h == 0) atomicAdd(&g_small[256 + c0 + 32 * n], t);
+                if (h == 0) atomicAdd(&g_b2[c0 + 32 * n], t);
             }
         }
         __syncthreads();
@@ -305,7 +305,7 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
         zero_acc(acc);
         gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane, acc);
         __syncthreads();
-        r_bwd_epilogue(X, acc, wave, lane, mk, G1 + tb, g_small);
+        r_bwd_epilogue(X, acc, wave, lane, mk, G1 + tb, g_b0);
         __syncthreads();
         zero_acc(acc);
         gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BWA / 4) + wave * (T_HID * 128), lane, acc);
@@ -358,16 +358,16 @@ int spf_rhead_forward(const float* agg, const float* ray_dirs, const int32_t* po
 }
 
 int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
-                       const float* packed, const float* act2, const uint32_t* masks, float* G1, float* G2, float* g_agg, float* g_small,
-                       void* stream) {
+                       const float* packed, const float* act2, const uint32_t* masks, float* G1, float* G2, float* g_agg, float* g_b0,
+                       float* g_b2, float* g_w4, float* g_b4, void* stream) {
     if (max_points < 0) return spf::fail(SPF_EINVAL, "spf_rhead_backward: bad sizes");
     if (max_points == 0) return SPF_OK;
-    if (!g_colors || !colors || !packed || !act2 || !masks || !G1 || !G2 || !g_agg || !g_small)
+    if (!g_colors || !colors || !packed || !act2 || !masks || !G1 || !G2 || !g_agg || !g_b0 || !g_b2 || !g_w4 || !g_b4)
         return spf::fail(SPF_EINVAL, "spf_rhead_backward: null pointer");
     const int tiles = spf::div_up(max_points, 64);
     const int blocks = tiles < 512 ? tiles : 512;
     rhead_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_colors, colors, point_slot, n_points, max_points, packed, act2, masks, G1, G2,
-                                                                   g_agg, g_small);
+                                                                   g_agg, g_b0, g_b2, g_w4, g_b4);
     SPF_LAUNCH_CHECK("rhead_backward_kernel");
     return SPF_OK;
 }

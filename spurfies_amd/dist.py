@@ -53,6 +53,8 @@ class FlatGrads:
         for p in self.params:  # re-attach in case an optimizer / zero_grad(set_to_none) dropped the views
             if p.grad is None or p.grad.data_ptr() != self.buffer.data_ptr() + 4 * off:
                 p.grad = self.buffer[off: off + p.numel()].view_as(p)
+                if getattr(p, "_spf_grad_sink", None) is not None:
+                    p._spf_grad_sink = p.grad
             off += p.numel()
 
 

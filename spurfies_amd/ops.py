@@ -8,6 +8,20 @@ from . import _lib
 
 SDF_FILL = 1000.0  # pointneus_disent.py:271,371,445,703
 
+
+# ---- gradient sinks (sync-free steps) -----------------------------------------------------------------
+def set_grad_sinks(params, on=True):
+    """Sync-free steps: the backward kernels ADD straight into the parameters' pre-zeroed .grad buffers (views of
+    dist.FlatGrads' flat buffer) and hand autograd no gradient for them — no temporary gradient tensors, no zero fills,
+    no AccumulateGrad add per parameter.  The caller zeroes the buffers before every backward."""
+    for p in params:
+        p._spf_grad_sink = p.grad if (on and p.grad is not None) else None
+
+
+def _sink(p):
+    g = getattr(p, "_spf_grad_sink", None)
+    return g if (g is not None and g.shape == p.shape and g.is_contiguous() and g.device == p.device) else None
+
 # ---- optional per-launch timing of the fused geometry kernel (bench.py roofline) -----------------
 _prof = None
 
@@ -129,6 +143,7 @@ class GeoSDF(torch.autograd.Function):
         ctx.save_for_backward(res["wn"], res["jac"], res["grad"])
         ctx.pl = pl
         ctx.n_table = feat_geo.shape[0]
+        ctx.sink = _sink(feat_geo)
         ctx.mark_non_differentiable(res["grad"], res["wn"])
         return res["sdf"], res["grad"], res["wn"]
 
@@ -140,8 +155,11 @@ class GeoSDF(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_x = g_sdf.unsqueeze(-1) * grad
         if ctx.needs_input_grad[1]:
-            g_feat = torch.zeros((ctx.n_table, 32), dtype=torch.float32, device=g_sdf.device)
-            geo_backward_latents(g_sdf, wn, jac, ctx.pl, g_feat)
+            if ctx.sink is not None:
+                geo_backward_latents(g_sdf, wn, jac, ctx.pl, ctx.sink)
+            else:
+                g_feat = torch.zeros((ctx.n_table, 32), dtype=torch.float32, device=g_sdf.device)
+                geo_backward_latents(g_sdf, wn, jac, ctx.pl, g_feat)
         return g_x, g_feat, None, None, None, None
 
 
@@ -185,6 +203,7 @@ class TVLoss(torch.autograd.Function):
             _lib.check(_lib.lib().spf_tv_forward(_lib.ptr(feat_c), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), n, k, _lib.ptr(tv),
                                                  _lib.stream_ptr()), "spf_tv_forward")
         ctx.save_for_backward(feat_c, nbr, w, norm)
+        ctx.sink = _sink(feat)
         return tv.mean()
 
     @staticmethod
@@ -192,11 +211,11 @@ class TVLoss(torch.autograd.Function):
         feat, nbr, w, norm = ctx.saved_tensors
         n, k = nbr.shape
         g_tv = (g / n).expand(n).contiguous()
-        out = torch.zeros_like(feat)
+        out = ctx.sink if ctx.sink is not None else torch.zeros_like(feat)
         with torch.cuda.device(feat.device):
             _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), _lib.ptr(g_tv), n, k,
                                                   _lib.ptr(out), _lib.stream_ptr()), "spf_tv_backward")
-        return out, None, None, None
+        return (None if ctx.sink is not None else out), None, None, None
 
 
 # ---- fused colour-feature path ------------------------------------------------------------------
@@ -254,6 +273,8 @@ class ColorAgg(torch.autograd.Function):
         if train:
             ctx.save_for_backward(wn, packed, *bufs)
             ctx.pl, ctx.NP, ctx.n_table = pl, NP, feat_col.shape[0]
+            sinks = [_sink(t) for t in (feat_col, w0, b0, w2, b2, w4, b4, w6, b6)]
+            ctx.sinks = sinks if (ctx.static and all(s_ is not None for s_ in sinks)) else None
         return agg
 
     @staticmethod
@@ -263,14 +284,27 @@ class ColorAgg(torch.autograd.Function):
         dev = g_agg.device
         rows = act1.shape[0]
         G1, G2, G3 = (torch.empty((rows, 256), dtype=torch.float32, device=dev) for _ in range(3))
-        g_bias = torch.zeros((3, 256), dtype=torch.float32, device=dev)
-        g_feat = torch.zeros((ctx.n_table, 64), dtype=torch.float32, device=dev)
+        sk = ctx.sinks
+        if sk is not None:                       # accumulate straight into the .grad buffers (set_grad_sinks)
+            g_feat, g_b0, g_b2, g_b4 = sk[0], sk[2], sk[4], sk[6]
+        else:
+            g_bias = torch.zeros((3, 256), dtype=torch.float32, device=dev)
+            g_b0, g_b2, g_b4 = g_bias[0], g_bias[1], g_bias[2]
+            g_feat = torch.zeros((ctx.n_table, 64), dtype=torch.float32, device=dev)
         g_agg = g_agg.contiguous()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                      _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), ctx.NP, pl.k, _lib.ptr(packed), _lib.ptr(masks),
-                                                     _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_bias), _lib.ptr(g_feat),
-                                                     _lib.stream_ptr()), "spf_color_backward")
+                                                     _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_b4),
+                                                     _lib.ptr(g_feat), _lib.stream_ptr()), "spf_color_backward")
+        if sk is not None:
+            # layer 0's [256,104] comes in the kernels' internal column order: one index_add_ into the reference order
+            sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs)[:, :103])
+            wgrad(G2, act1, pl.n_pairs, out=sk[3])
+            wgrad(G3, act2, pl.n_pairs, out=sk[5])
+            wgrad(g_agg, agg3, pl.n_points, out=sk[7])
+            wgrad(g_agg, _ones_col(g_agg.shape[0], dev), pl.n_points, C=1, out=sk[8].view(256, 1), ldw=1)
+            return (None,) * 15
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
         if ctx.static:   # row counts stay on the device
             dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs)[:, :103]
@@ -282,7 +316,7 @@ class ColorAgg(torch.autograd.Function):
             dw2, dw4 = _wgrad(G2, act1), _wgrad(G3, act2)
             dw6 = g_agg.t() @ agg3                                 # last layer: rank structure, K = P
             db6 = g_agg.sum(0)
-        grads = (g_feat, dw0, g_bias[0], dw2, g_bias[1], dw4, g_bias[2], dw6, db6)
+        grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4, dw6, db6)
         return grads + (None,) * 6
 
 
@@ -450,6 +484,8 @@ class RHead(torch.autograd.Function):
                        "spf_rhead_forward")
         if train:
             ctx.save_for_backward(agg_c, colors, point_slot, n_points, packed, *bufs)
+            sinks = [_sink(t) for t in (w0, b0, w2, b2, w4, b4)]
+            ctx.sinks = sinks if (static and all(s_ is not None for s_ in sinks)) else None
         return colors
 
     @staticmethod
@@ -460,12 +496,22 @@ class RHead(torch.autograd.Function):
         G1 = torch.empty((T, 256), dtype=torch.float32, device=dev)
         G2 = torch.empty((T, 256), dtype=torch.float32, device=dev)
         g_agg = torch.empty((T, 256), dtype=torch.float32, device=dev)
-        g_small = torch.zeros((1283,), dtype=torch.float32, device=dev)
+        sk = ctx.sinks
+        if sk is not None:
+            g_b0, g_b2, g_w4, g_b4 = sk[1], sk[3], sk[4], sk[5]
+        else:
+            g_small = torch.zeros((1283,), dtype=torch.float32, device=dev)
+            g_b0, g_b2, g_w4, g_b4 = g_small[:256], g_small[256:512], g_small[512:1280].view(3, 256), g_small[1280:1283]
         g_colors = g_colors.contiguous()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_rhead_backward(_lib.ptr(g_colors), _lib.ptr(colors), _lib.ptr(point_slot), _lib.ptr(n_points), P, _lib.ptr(packed),
-                                                     _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_small),
-                                                     _lib.stream_ptr()), "spf_rhead_backward")
+                                                     _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_b0),
+                                                     _lib.ptr(g_b2), _lib.ptr(g_w4), _lib.ptr(g_b4), _lib.stream_ptr()), "spf_rhead_backward")
+        if sk is not None:
+            wgrad(G1, direnc, n_points, C=21, out=sk[0])                # reference column order [dir-enc | agg]
+            wgrad(G1, agg, n_points, out=sk[0][:, 21:], ldw=277)
+            wgrad(G2, act1, n_points, out=sk[2])
+            return (g_agg[:P],) + (None,) * 12
         if ctx.static:
             dw0 = torch.zeros((256, 277), dtype=torch.float32, device=dev)        # reference column order [dir-enc | agg]
             wgrad(G1, direnc, n_points, C=21, out=dw0)
@@ -475,8 +521,7 @@ class RHead(torch.autograd.Function):
             G1p, G2p = G1[:P], G2[:P]
             dw0 = torch.cat([G1p.t() @ direnc[:P, :21], G1p.t() @ agg], dim=1)
             dw2 = G2p.t() @ act1[:P]
-        return (g_agg[:P], dw0, g_small[:256], dw2, g_small[256:512], g_small[512:1280].view(3, 256), g_small[1280:1283],
-                None, None, None, None, None, None)
+        return (g_agg[:P], dw0, g_b0, dw2, g_b2, g_w4, g_b4, None, None, None, None, None, None)
 
 
 _wgrad_ws = {}

@@ -11,6 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import dist as sdist
+from . import ops
 from .model.loss import VolSDFLoss
 
 
@@ -36,6 +37,7 @@ class TrainStep:
         model.freeze_prior()                                    # train.py:151-154
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.flat = sdist.FlatGrads(self.params)                # .grad of every trainable tensor is a view of one buffer
+        ops.set_grad_sinks(self.params, on=sync_free)           # sync-free: backward kernels add straight into those views
         self.optimizer = torch.optim.Adam([{"params": [], "lr": 1e-2}, {"params": self.params, "lr": lr}])
         self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=100_000, eta_min=3e-4, last_epoch=-1)
         self.grad_clip = grad_clip
