@@ -337,6 +337,21 @@ int spf_loss_backward(const float* g_total, const float* den, const spf_loss_wei
                       const uint8_t* pvalid, const uint8_t* ray_valid, int32_t R, float* g_rgb, float* g_acc,
                       float* g_psdf, float* g_tv, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Parameter update — replaces the tail of the reference's train step (spurfies/train.py:359-363, 548-564):
+ * clip_grad_norm_(parameters, max_norm), the NaN / Inf gradient guard, torch.optim.Adam.step().
+ * ---------------------------------------------------------------------------------------- */
+int64_t spf_adam_workspace_floats(void);
+
+/* param, grad, exp_avg, exp_avg_sq: flat fp32 arrays of n elements (all trainable tensors back to back).
+ *   norm = |grad|_2.  Not finite: nothing is written except state[1] += 1 (the reference then "does not update").
+ *   Otherwise grad *= min(1, max_norm / (norm + 1e-6)) in place (max_norm <= 0: no clipping), t = ++state[0], and
+ *   exp_avg, exp_avg_sq, param advance as torch.optim.Adam does (no weight decay, no amsgrad).
+ * state: device float[4] = {t, skipped steps, last norm, last clip coefficient}, zero-initialised by the caller.
+ * workspace: spf_adam_workspace_floats() floats.  No host synchronisation. */
+int spf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                  double beta2, double eps, double max_norm, float* state, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ SIGNATURES = {
     "spf_tv_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "spf_camera_rays": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "spf_adam_workspace_floats": (C.c_int64, []),
+    "spf_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
     "spf_loss_workspace_floats": (C.c_int64, []),
     "spf_loss_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _I, C.POINTER(LossWeights), _P, _P, _P, _P, _P]),
     "spf_loss_backward": (C.c_int, [_P, _P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),

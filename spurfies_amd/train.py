@@ -13,6 +13,7 @@ import torch
 from . import dist as sdist
 from . import ops
 from .model.loss import VolSDFLoss
+from .optim import FlatAdam
 
 
 def default_loss() -> VolSDFLoss:
@@ -38,7 +39,7 @@ class TrainStep:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.flat = sdist.FlatGrads(self.params)                # .grad of every trainable tensor is a view of one buffer
         ops.set_grad_sinks(self.params, on=sync_free)           # sync-free: backward kernels add straight into those views
-        self.optimizer = torch.optim.Adam([{"params": [], "lr": 1e-2}, {"params": self.params, "lr": lr}])
+        self.optimizer = FlatAdam([{"params": [], "lr": 1e-2}, {"params": self.params, "lr": lr}], flat_grads=self.flat)
         self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=100_000, eta_min=3e-4, last_epoch=-1)
         self.grad_clip = grad_clip
         self.group = process_group
@@ -55,12 +56,9 @@ class TrainStep:
             losses, out = self._forward_backward(model_input, ground_truth)
         if self.world > 1:
             sdist.all_reduce_sum(self.flat.buffer, self.group)
-        if self.grad_clip:
-            torch.nn.utils.clip_grad_norm_(self.params, 1.0)
-        # train.py:548-564 — skip the update when a gradient is not finite (device-side test, no sync)
-        finite = torch.isfinite(self.flat.buffer).all()
-        self.flat.buffer.mul_(finite.to(self.flat.buffer.dtype))
-        self.optimizer.step()
+        # train.py:359-363, 548-564 — clip_grad_norm_(1.0), skip the update when a gradient is not finite, Adam: one fused
+        # device-side sequence (spurfies_amd/optim.py), no sync
+        self.optimizer.step(max_norm=1.0 if self.grad_clip else 0.0)
         self.scheduler.step()
         self.iter_step += 1
         return losses, out
