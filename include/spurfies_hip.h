@@ -155,60 +155,64 @@ int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* j
 /* ------------------------------------------------------------------------------------------
  * Fused colour-feature path — replaces the F_color half of get_color,
  * spurfies/model/pointneus_disent.py:325-336 (posenc embedder.py:26-30, gather utils.py:140-170,
- * 4 GEMMs, index_add_), and autograd's backward through it.
+ * GEMMs, index_add_), and autograd's backward through it.
+ * F_color.6 — the last layer, linear (pointneus_disent.py:76-85) — commutes with the RBF-weighted mean
+ * (sum_j wn_j (W6 a_j + b6) = W6 sum_j wn_j a_j + b6, the weights sum to 1), so this stage ends at the mean of the
+ * third activation, agg3, and the head stage below applies F_color.6 once per POINT instead of once per pair.
  * ---------------------------------------------------------------------------------------- */
 int64_t spf_color_packed_floats(void);
 
-/* Pack F_color.{0,2,4,6} ([out,in] row-major) into forward and transposed fragment order. */
+/* Pack F_color.{0,2,4} ([out,in] row-major) into forward and transposed fragment order. */
 int spf_color_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4,
-                   const float* b4, const float* w6, const float* b6, float* packed, void* stream);
+                   const float* b4, float* packed, void* stream);
 
-/* agg[p, 256] += sum_j wn[q] * F_color([posenc6(x[row] - pts[nbr]) | feat_color[nbr]]) over the pairs q of the
- * p-th valid point (pair lists from spf_build_pairs, wn from spf_geo_forward); agg must be ZEROED by the caller
- * (a point whose pairs straddle two 64-pair tiles receives two commutative atomic adds).  Training mode
- * (act0 != NULL) also writes, per pair row q (T = 64 * ceil(n_pairs/64) rows):
- *   act0 [T,104]   layer-1 input in the kernel's internal column order [latent 64 | posenc 39 | 0]
- *   act1, act2 [T,256]  inputs of layers 2 and 3 (operands of their weight-gradient GEMMs)
- *   agg3 [P,256]   += sum_j wn_j a3_j (ZEROED by the caller): the last layer is linear, so its weight gradient
- *                  is g_agg^T agg3 (K = P, not n_pairs)
- *   masks [T/64, 3, 512] uint32  LeakyReLU sign bits of layers 1..3 in accumulator order */
+/* agg3[p, 256] += sum_j wn[q] * a3_q,  a3 = lrelu(F_color.4(lrelu(F_color.2(lrelu(F_color.0([posenc6(x[row] - pts[nbr]) |
+ * feat_color[nbr]])))))) over the pairs q of the p-th valid point (pair lists from spf_build_pairs, wn from
+ * spf_geo_forward); agg3 must be ZEROED by the caller (a point whose pairs straddle two 64-pair tiles receives two
+ * commutative atomic adds).  Training mode (act0 != NULL) also writes, per pair row q (T = 64 * ceil(n_pairs/64) rows):
+ *   act0 [T,104]   layer-0 input in the kernel's internal column order [latent 64 | posenc 39 | 0]
+ *   act1, act2 [T,256]  inputs of F_color.2 and F_color.4 (operands of their weight-gradient GEMMs)
+ *   masks [T/64, 3, 512] uint32  LeakyReLU sign bits of the three layers in accumulator order */
 int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot,
                       const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs,
-                      int32_t k, const float* pts, const float* feat_color, const float* packed, float* agg,
-                      float* act0, float* act1, float* act2, float* agg3, uint32_t* masks, void* stream);
+                      int32_t k, const float* pts, const float* feat_color, const float* packed, float* agg3,
+                      float* act0, float* act1, float* act2, uint32_t* masks, void* stream);
 
-/* Data-gradient chain for g_agg[p,256] = dL/d agg: writes the pre-activation gradients G1..G3 [T,256]
+/* Data-gradient chain for g_agg3[p,256] = dL/d agg3: writes the pre-activation gradients G1..G3 [T,256]
  * (weight gradients of F_color.0/2/4 are then dW_l = G_l^T act_{l-1}: spf_wgrad), ADDS their column sums to
  * g_b0, g_b2, g_b4 [256] (bias gradients of F_color.0/2/4) and ADDS the colour-latent gradient into
  * g_feat_color[N,64] (float atomics).  The accumulating outputs may point straight into the gradient buffers. */
-int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot,
+int spf_color_backward(const float* g_agg3, const int32_t* nbr, const float* wn, const int32_t* point_slot,
                        const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs,
                        int32_t k, const float* packed, const uint32_t* masks, float* G1, float* G2, float* G3,
                        float* g_b0, float* g_b2, float* g_b4, float* g_feat_color, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Radiance head R — replaces the second half of get_color, spurfies/model/pointneus_disent.py:338-346
- * (view encoding with multires 3, concat, R: 277 -> 256 -> 256 -> 3, sigmoid) and its backward.
- * Rows are the valid POINTS (tiles of 64).
+ * Head stage, per valid POINT (tiles of 64): agg = F_color.6(agg3), then the radiance head R — replaces F_color's last
+ * layer and the second half of get_color, spurfies/model/pointneus_disent.py:333-346 (view encoding with multires 3,
+ * concat, R: 277 -> 256 -> 256 -> 3, sigmoid) and its backward.
  * ---------------------------------------------------------------------------------------- */
 int64_t spf_rhead_packed_floats(void);
-int spf_rhead_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4,
-                   const float* b4, float* packed, void* stream);
+int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const float* b0, const float* w2, const float* b2,
+                   const float* w4, const float* b4, float* packed, void* stream);
 
-/* colors[row,3] = sigmoid(R([direnc3(ray_dirs[row / SR]) | agg[p]])) for the p-th valid point, row = point_slot[p]
+/* colors[row,3] = sigmoid(R([direnc3(ray_dirs[row / SR]) | W6 agg3[p] + b6])) for the p-th valid point, row = point_slot[p]
  * (rows of invalid points untouched: pre-fill with 0).  Training mode (direnc != NULL) stores, per point
- * (T = 64*ceil(P/64) rows): direnc [T,24] (21 + 3 zeros), act1, act2 [T,256], masks [T/64,2,512]. */
-int spf_rhead_forward(const float* agg, const float* ray_dirs, const int32_t* point_slot, const int32_t* n_points,
-                      int32_t max_points, int32_t SR, const float* packed, float* colors, float* direnc,
+ * (T = 64*ceil(P/64) rows): agg [T,256] (= F_color.6's output, R.0's input), direnc [T,24] (21 + 3 zeros),
+ * act1, act2 [T,256], masks [T/64,2,512]. */
+int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* point_slot, const int32_t* n_points,
+                      int32_t max_points, int32_t SR, const float* packed, float* colors, float* agg, float* direnc,
                       float* act1, float* act2, uint32_t* masks, void* stream);
 
-/* Given g_colors[row,3]: writes G1, G2 [T,256] (pre-activation gradients; dW_l = G_l^T act_{l-1} are plain GEMMs),
- * g_agg [T,256] (rows >= P are scratch), and ADDS into g_b0, g_b2 [256], g_w4 [3,256], g_b4 [3] (gradients of R.0.bias,
- * R.2.bias, R.4.weight, R.4.bias; float atomics — the caller zeroes them or points them at its gradient buffers). */
+/* Given g_colors[row,3]: writes G1, G2 [T,256] (pre-activation gradients of R.0 / R.2; dW_l = G_l^T act_{l-1}: spf_wgrad),
+ * g_agg [T,256] = dL/d agg (F_color.6's weight gradient is g_agg^T agg3) and g_agg3 [T,256] = g_agg W6 (input of
+ * spf_color_backward); rows >= P are scratch.  ADDS into g_b6 [256] (F_color.6.bias), g_b0, g_b2 [256], g_w4 [3,256],
+ * g_b4 [3] (R.0.bias, R.2.bias, R.4.weight, R.4.bias; float atomics — the caller zeroes them or points them at its
+ * gradient buffers). */
 int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t* point_slot, const int32_t* n_points,
                        int32_t max_points, const float* packed, const float* act2, const uint32_t* masks,
-                       float* G1, float* G2, float* g_agg, float* g_b0, float* g_b2, float* g_w4, float* g_b4,
-                       void* stream);
+                       float* G1, float* G2, float* g_agg, float* g_agg3, float* g_b6, float* g_b0, float* g_b2,
+                       float* g_w4, float* g_b4, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * VolSDF error-bounded sampler — replaces UniformSampler.get_z_vals (spurfies/model/ray_sampler.py:33-59),

@@ -48,13 +48,13 @@ SIGNATURES = {
     "spf_geo_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
     "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "spf_color_packed_floats": (C.c_int64, []),
-    "spf_color_pack": (C.c_int, [_P] * 10),
-    "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_color_pack": (C.c_int, [_P] * 8),
+    "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_color_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_rhead_packed_floats": (C.c_int64, []),
-    "spf_rhead_pack": (C.c_int, [_P] * 8),
-    "spf_rhead_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "spf_rhead_backward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_rhead_pack": (C.c_int, [_P] * 10),
+    "spf_rhead_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_rhead_backward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_sampler_uniform": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
     "spf_sampler_iter": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _I, _P, _P, _P, _P, _P]),
     "spf_sampler_finish": (C.c_int, [_P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _I, _P, _P, _P]),

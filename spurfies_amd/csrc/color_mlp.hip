@@ -1,12 +1,15 @@
 // Fused colour-feature path (K5 of DESIGN.md): positional encoding of the relative position +
-// gather of the 64-d colour latent, F_color (103 -> 256 -> 256 -> 256 -> 256) on the fp32 matrix cores
-// and the RBF-weighted mean over a point's neighbours — forward, and the data-gradient chain of the
+// gather of the 64-d colour latent, the three activated layers of F_color (103 -> 256 -> 256 -> 256) on the fp32
+// matrix cores and the RBF-weighted mean over a point's neighbours — forward, and the data-gradient chain of the
 // backward with the colour-latent scatter-add.
 //
 // Replaces the F_color half of get_color, spurfies/model/pointneus_disent.py:325-336
-// (positional encoding embedder.py:26-30, table gather utils.py:140-170, 4 cuBLAS GEMMs,
-// index_add_ of [pairs,256]) and autograd's backward through it.  The `R` head (:338-346) works on
-// points, not pairs, and is a separate stage.
+// (positional encoding embedder.py:26-30, table gather utils.py:140-170, cuBLAS GEMMs,
+// index_add_ of [pairs,256]) and autograd's backward through it.  F_color's LAST layer (F_color.6) is linear
+// (pointneus_disent.py:76-85: no activation after it), so it commutes with the weighted mean:
+//     sum_j wn_j (W6 a3_j + b6) = W6 (sum_j wn_j a3_j) + b6 sum_j wn_j,     sum_j wn_j = 1;
+// this stage therefore outputs agg3[p] = sum_j wn_j a3_j and the 256x256 layer runs once per POINT (8x fewer rows)
+// at the front of the head stage (rhead_mlp.hip), together with the `R` head (:338-346).
 //
 // Same tile engine as the geometry kernel (mlp_tile.h): tile = 8 points x 8 neighbour slots = 64
 // rows, compact tile order (row = p*8 + j for the p-th valid point).
@@ -35,16 +38,13 @@ constexpr int SZ_CBL = 2 * T_HID * 64 * 4;
 constexpr int CO_FW1 = 0;
 constexpr int CO_FW2 = CO_FW1 + SZ_CFW1;
 constexpr int CO_FW3 = CO_FW2 + SZ_CHH;
-constexpr int CO_FW4 = CO_FW3 + SZ_CHH;
-constexpr int CO_BW4 = CO_FW4 + SZ_CHH;
-constexpr int CO_BW3 = CO_BW4 + SZ_CHH;
+constexpr int CO_BW3 = CO_FW3 + SZ_CHH;
 constexpr int CO_BW2 = CO_BW3 + SZ_CHH;
 constexpr int CO_BWL = CO_BW2 + SZ_CHH;   // W0[:, 39:103] (256 -> 64 latent columns)
 constexpr int CO_B1 = CO_BWL + SZ_CBL;
 constexpr int CO_B2 = CO_B1 + 256;
 constexpr int CO_B3 = CO_B2 + 256;
-constexpr int CO_B4 = CO_B3 + 256;
-constexpr int C_PACKED = CO_B4 + 256;
+constexpr int C_PACKED = CO_B3 + 256;
 
 constexpr int CL_X = 0;
 constexpr int CL_W = CL_X + 64 * LDA;   // per-row normalised RBF weight
@@ -73,7 +73,7 @@ __device__ __forceinline__ void seg_reduce_rows(const float* X, const float* s_w
 __host__ __device__ __forceinline__ int c_orig(int k) { return k < 64 ? 39 + k : k - 64; }
 
 struct CPackArgs {
-    const float *w0, *b0, *w2, *b2, *w4, *b4, *w6, *b6;
+    const float *w0, *b0, *w2, *b2, *w4, *b4;
 };
 
 __global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
@@ -92,9 +92,7 @@ __global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
             case 0: val = kk < C_IN ? a.w0[n * C_IN + c_orig(kk)] : 0.f; break;
             case 1: val = a.w2[n * 256 + kk]; break;
             case 2: val = a.w4[n * 256 + kk]; break;
-            case 3: val = a.w6[n * 256 + kk]; break;
-            case 4: val = a.w6[kk * 256 + n]; break;   // g_a3[i] = sum_o G4[o] W6[o][i]
-            case 5: val = a.w4[kk * 256 + n]; break;
+            case 3: val = a.w4[kk * 256 + n]; break;   // g_a2[i] = sum_o G3[o] W4[o][i]
             default: val = a.w2[kk * 256 + n]; break;
         }
     } else if (e < CO_B1) {
@@ -104,7 +102,7 @@ __global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
         val = a.w0[kk * C_IN + n];
     } else {
         const int local = e - CO_B1, l = local >> 8, i = local & 255;
-        val = (l == 0 ? a.b0 : l == 1 ? a.b2 : l == 2 ? a.b4 : a.b6)[i];
+        val = (l == 0 ? a.b0 : l == 1 ? a.b2 : a.b4)[i];
     }
     out[e] = val;
 }
@@ -150,8 +148,8 @@ __global__ void __launch_bounds__(256, 2)
 color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
                      const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
                      const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k, const float* __restrict__ pts,
-                     const float* __restrict__ feat_col, const float* packed, float* __restrict__ agg, float* __restrict__ act0,
-                     float* __restrict__ act1, float* __restrict__ act2, float* __restrict__ agg3, uint32_t* __restrict__ masks) {
+                     const float* __restrict__ feat_col, const float* packed, float* __restrict__ agg3, float* __restrict__ act0,
+                     float* __restrict__ act1, float* __restrict__ act2, uint32_t* __restrict__ masks) {
     __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL];
     float* X = smem + CL_X;
     int* s_p = reinterpret_cast<int*>(smem + CL_P);
@@ -243,13 +241,7 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         __syncthreads();
         c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B3, wave, lane, STORE ? mk + 1024 : nullptr);
         __syncthreads();
-        if (STORE) seg_reduce_rows(X, smem + CL_W, s_p, tid, agg3);   // agg3[p] = sum_j wn_j a3_j (rank structure of the last layer's wgrad)
-        zero_acc(acc);
-        gemm_rows64<T_HID>(X, pk4 + (CO_FW4 / 4) + wave * (T_HID * 128), lane, acc);
-        __syncthreads();
-        c_fwd_epilogue<false, false>(X, acc, packed + CO_B4, wave, lane, nullptr);   // last layer: no activation
-        __syncthreads();
-        seg_reduce_rows(X, smem + CL_W, s_p, tid, agg);               // agg[p] = sum_j wn_j F_color(.)_j
+        seg_reduce_rows(X, smem + CL_W, s_p, tid, agg3);   // agg3[p] = sum_j wn_j a3_j; the linear F_color.6 follows per point
         __syncthreads();
     }
 }
@@ -281,8 +273,34 @@ __device__ __forceinline__ void c_bwd_epilogue(float* X, const f32x16 (&acc)[2][
     }
 }
 
+// same, for a gradient tile that is already in LDS (no GEMM in front): every lane owns the (row, column) positions its
+// accumulators would have, so the in-place update needs no further synchronisation
+__device__ __forceinline__ void c_bwd_mask_inplace(float* X, int wave, int lane, const uint32_t* __restrict__ mask_g, float* __restrict__ g_bias) {
+    const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+    float cs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const uint32_t bits = mask_g[(wave * 2 + m) * 64 + lane];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* px = X + (m * 32 + row_of(r, h)) * LDA + c0 + 32 * n;
+                float v = *px;
+                v = ((bits >> (n * 16 + r)) & 1u) ? v : v * 0.01f;
+                *px = v;
+                cs[n] += v;
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const float t = cs[n] + __shfl_xor(cs[n], 32);
+        if (h == 0) atomicAdd(&g_bias[c0 + 32 * n], t);
+    }
+}
+
 __global__ void __launch_bounds__(256, 2)
-color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
+color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
                       const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
                       const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k, const float* packed,
                       const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3,
@@ -301,7 +319,7 @@ color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict
         const float* packed = launder(packed0);
         const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
         const size_t tbase = (size_t)tile * 64 * 256;
-        // ---- G4[row] = wn[row] * g_agg[p]  (the last layer is linear; agg = sum_j wn_j f_j) ---------
+        // ---- g_a3[row] = wn[row] * g_agg3[p]  (agg3 = sum_j wn_j a3_j) -------------------------------
         {
             const int row = tid >> 2, q4 = tid & 3;
             const int q = tile * 64 + row;
@@ -314,7 +332,7 @@ color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict
                 w = wn[q];
             }
             if (q4 == 0) s_idx[row] = idx;
-            const f32x4* ga = reinterpret_cast<const f32x4*>(g_agg + (size_t)p * 256);
+            const f32x4* ga = reinterpret_cast<const f32x4*>(g_agg3 + (size_t)p * 256);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int c4 = q4 + 4 * u;
@@ -329,10 +347,7 @@ color_backward_kernel(const float* __restrict__ g_agg, const int32_t* __restrict
         __syncthreads();
         f32x16 acc[2][2];
         const uint32_t* mk = masks + (size_t)tile * 3 * 512;
-        zero_acc(acc);
-        gemm_rows64<T_HID>(X, pk4 + (CO_BW4 / 4) + wave * (T_HID * 128), lane, acc);
-        __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, mk + 1024, g_b4);
+        c_bwd_mask_inplace(X, wave, lane, mk + 1024, g_b4);     // G3 = g_a3 * lrelu'(h3), in place
         __syncthreads();
         store_tile_256(X, G3 + tbase, tid);
         zero_acc(acc);
@@ -380,9 +395,9 @@ extern "C" {
 int64_t spf_color_packed_floats(void) { return C_PACKED; }
 
 int spf_color_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
-                   const float* w6, const float* b6, float* packed, void* stream) {
-    if (!w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !w6 || !b6 || !packed) return spf::fail(SPF_EINVAL, "spf_color_pack: null pointer");
-    CPackArgs a{w0, b0, w2, b2, w4, b4, w6, b6};
+                   float* packed, void* stream) {
+    if (!w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !packed) return spf::fail(SPF_EINVAL, "spf_color_pack: null pointer");
+    CPackArgs a{w0, b0, w2, b2, w4, b4};
     color_pack_kernel<<<spf::div_up(C_PACKED, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
     SPF_LAUNCH_CHECK("color_pack_kernel");
     return SPF_OK;
@@ -390,37 +405,37 @@ int spf_color_pack(const float* w0, const float* b0, const float* w2, const floa
 
 int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* pair_off,
                       const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* pts,
-                      const float* feat_color, const float* packed, float* agg, float* act0, float* act1, float* act2, float* agg3,
-                      uint32_t* masks, void* stream) {
+                      const float* feat_color, const float* packed, float* agg3, float* act0, float* act1, float* act2, uint32_t* masks,
+                      void* stream) {
     if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_forward: bad sizes");
     if (max_pairs == 0) return SPF_OK;
-    if (!x || !nbr || !wn || !pair_off || !pair_point || !pts || !feat_color || !packed || !agg)
+    if (!x || !nbr || !wn || !pair_off || !pair_point || !pts || !feat_color || !packed || !agg3)
         return spf::fail(SPF_EINVAL, "spf_color_forward: null pointer");
     const bool store = act0 != nullptr;
-    if (store && (!act1 || !act2 || !agg3 || !masks)) return spf::fail(SPF_EINVAL, "spf_color_forward: training buffers must be given together");
+    if (store && (!act1 || !act2 || !masks)) return spf::fail(SPF_EINVAL, "spf_color_forward: training buffers must be given together");
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
     if (store)
         color_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts,
-                                                                            feat_color, packed, agg, act0, act1, act2, agg3, masks);
+                                                                            feat_color, packed, agg3, act0, act1, act2, masks);
     else
         color_forward_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k,
-                                                                             pts, feat_color, packed, agg, nullptr, nullptr, nullptr, nullptr, nullptr);
+                                                                             pts, feat_color, packed, agg3, nullptr, nullptr, nullptr, nullptr);
     SPF_LAUNCH_CHECK("color_forward_kernel");
     return SPF_OK;
 }
 
-int spf_color_backward(const float* g_agg, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* pair_off,
+int spf_color_backward(const float* g_agg3, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* pair_off,
                        const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* packed,
                        const uint32_t* masks, float* G1, float* G2, float* G3, float* g_b0, float* g_b2, float* g_b4, float* g_feat_color,
                        void* stream) {
     if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_backward: bad sizes");
     if (max_pairs == 0) return SPF_OK;
-    if (!g_agg || !nbr || !wn || !pair_off || !pair_point || !packed || !masks || !G1 || !G2 || !G3 || !g_b0 || !g_b2 || !g_b4 || !g_feat_color)
+    if (!g_agg3 || !nbr || !wn || !pair_off || !pair_point || !packed || !masks || !G1 || !G2 || !G3 || !g_b0 || !g_b2 || !g_b4 || !g_feat_color)
         return spf::fail(SPF_EINVAL, "spf_color_backward: null pointer");
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
-    color_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_agg, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
+    color_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_agg3, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
                                                                    masks, G1, G2, G3, g_b0, g_b2, g_b4, g_feat_color);
     SPF_LAUNCH_CHECK("color_backward_kernel");
     return SPF_OK;

@@ -1,8 +1,10 @@
-// Radiance head `R` (K5b of DESIGN.md): per valid POINT, [dir-enc3(ray dir) | agg] (277) -> 256 -> 256 -> 3 -> sigmoid,
-// forward and the data-gradient chain of the backward, on the fp32 matrix cores.
+// Head stage (K5b of DESIGN.md), per valid POINT: agg = F_color.6(agg3) — the linear last layer of F_color, applied after
+// the RBF-weighted mean it commutes with (color_mlp.hip) — then the radiance head `R`:
+// [dir-enc3(ray dir) | agg] (277) -> 256 -> 256 -> 3 -> sigmoid; forward and the data-gradient chain of the backward,
+// on the fp32 matrix cores.
 //
-// Replaces the second half of get_color, spurfies/model/pointneus_disent.py:338-346 (view encoding
-// embedder.py:26-30 with multires 3, torch.concat, three cuBLAS GEMMs, sigmoid) and autograd's backward.
+// Replaces F_color.6 and the second half of get_color, spurfies/model/pointneus_disent.py:333-346 (view encoding
+// embedder.py:26-30 with multires 3, torch.concat, cuBLAS GEMMs, sigmoid) and autograd's backward.
 //
 // Tile = 64 consecutive valid points (rows).  Internal column order is [agg (256) | dir-enc (21) | pad] so that the
 // agg rows load 16-B aligned; spf_rhead_pack folds the permutation into the packed first-layer weights.
@@ -24,9 +26,12 @@ constexpr int RO_FW1 = 0;
 constexpr int RO_FW2 = RO_FW1 + SZ_RFW1;
 constexpr int RO_BW2 = RO_FW2 + SZ_RHH;    // g_a1 = G2 * W2
 constexpr int RO_BWA = RO_BW2 + SZ_RHH;    // g_agg = G1 * W1[:, 21:277]
-constexpr int RO_B1 = RO_BWA + SZ_RHH;
+constexpr int RO_FW6 = RO_BWA + SZ_RHH;    // agg = agg3 * W6^T      (F_color.6)
+constexpr int RO_BW6 = RO_FW6 + SZ_RHH;    // g_agg3 = g_agg * W6
+constexpr int RO_B1 = RO_BW6 + SZ_RHH;
 constexpr int RO_B2 = RO_B1 + 256;
-constexpr int RO_W3 = RO_B2 + 256;         // [3][256]
+constexpr int RO_B6 = RO_B2 + 256;
+constexpr int RO_W3 = RO_B6 + 256;         // [3][256]
 constexpr int RO_B3 = RO_W3 + 768;         // [3] (+1 pad)
 constexpr int R_PACKED = RO_B3 + 4;
 
@@ -38,7 +43,7 @@ constexpr int RL_TOTAL = RL_ROW + 64;
 __host__ __device__ __forceinline__ int r_orig(int k) { return k < 256 ? 21 + k : k - 256; }  // internal column -> reference column
 
 struct RPackArgs {
-    const float *w0, *b0, *w2, *b2, *w4, *b4;
+    const float *w6, *b6, *w0, *b0, *w2, *b2, *w4, *b4;
 };
 
 __global__ void rhead_pack_kernel(RPackArgs a, float* __restrict__ out) {
@@ -57,11 +62,13 @@ __global__ void rhead_pack_kernel(RPackArgs a, float* __restrict__ out) {
             case 0: val = kk < R_IN ? a.w0[n * R_IN + r_orig(kk)] : 0.f; break;
             case 1: val = a.w2[n * 256 + kk]; break;
             case 2: val = a.w2[kk * 256 + n]; break;            // g_a1[i] = sum_o G2[o] W2[o][i]
-            default: val = a.w0[kk * R_IN + 21 + n]; break;     // g_agg[i] = sum_o G1[o] W0[o][21 + i]
+            case 3: val = a.w0[kk * R_IN + 21 + n]; break;      // g_agg[i] = sum_o G1[o] W0[o][21 + i]
+            case 4: val = a.w6[n * 256 + kk]; break;            // agg[o] = sum_i W6[o][i] agg3[i]
+            default: val = a.w6[kk * 256 + n]; break;           // g_agg3[i] = sum_o g_agg[o] W6[o][i]
         }
     } else if (e < RO_W3) {
         const int local = e - RO_B1;
-        val = (local < 256 ? a.b0 : a.b2)[local & 255];
+        val = (local < 256 ? a.b0 : local < 512 ? a.b2 : a.b6)[local & 255];
     } else if (e < RO_B3) {
         val = a.w4[e - RO_W3];
     } else if (e < RO_B3 + 3) {
@@ -96,9 +103,10 @@ __device__ __forceinline__ void r_fwd_epilogue(float* X, const f32x16 (&acc)[2][
 
 template <bool STORE>
 __global__ void __launch_bounds__(256, 2)
-rhead_forward_kernel(const float* __restrict__ agg, const float* __restrict__ ray_dirs, const int32_t* __restrict__ point_slot,
+rhead_forward_kernel(const float* __restrict__ agg3, const float* __restrict__ ray_dirs, const int32_t* __restrict__ point_slot,
                      const int32_t* __restrict__ n_points_dev, int max_points, int SR, const float* packed, float* __restrict__ colors,
-                     float* __restrict__ direnc, float* __restrict__ act1, float* __restrict__ act2, uint32_t* __restrict__ masks) {
+                     float* __restrict__ agg, float* __restrict__ direnc, float* __restrict__ act1, float* __restrict__ act2,
+                     uint32_t* __restrict__ masks) {
     __shared__ __attribute__((aligned(16))) float smem[RL_TOTAL];
     float* X = smem + RL_X;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -110,11 +118,11 @@ rhead_forward_kernel(const float* __restrict__ agg, const float* __restrict__ ra
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const float* packed = launder(packed0);
         const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
-        {   // gather: thread = (row, quarter): 64 agg floats each; quarter 0 also encodes the view direction
+        {   // gather: thread = (row, quarter): 64 agg3 floats each; quarter 0 also encodes the view direction
             const int row = tid >> 2, q4 = tid & 3;
             const int p = tile * 64 + row;
             const bool ok = p < P;
-            const f32x4* src = reinterpret_cast<const f32x4*>(agg + (size_t)(ok ? p : 0) * 256 + q4 * 64);
+            const f32x4* src = reinterpret_cast<const f32x4*>(agg3 + (size_t)(ok ? p : 0) * 256 + q4 * 64);
 #pragma unroll 4
             for (int u = 0; u < 16; ++u) {
                 f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -157,6 +165,25 @@ rhead_forward_kernel(const float* __restrict__ agg, const float* __restrict__ ra
         const size_t tb = (size_t)tile * 64 * 256;
         uint32_t* mk = STORE ? masks + (size_t)tile * 2 * 512 : nullptr;
         f32x16 acc[2][2];
+        zero_acc(acc);
+        gemm_rows64<T_HID, LDR>(X, pk4 + (RO_FW6 / 4) + wave * (T_HID * 128), lane, acc);     // F_color.6 on the weighted mean
+        __syncthreads();
+        {   // agg = acc + b6 (linear) into columns 0..255 of X (the dir-enc columns stay); kept for R.0's weight gradient
+            const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+            const float bv[2] = {packed[RO_B6 + c0], packed[RO_B6 + c0 + 32]};
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m * 32 + row_of(r, h);
+                        const float v = acc[m][n][r] + bv[n];
+                        X[row * LDR + c0 + 32 * n] = v;
+                        if (STORE) agg[tb + row * 256 + c0 + 32 * n] = v;
+                    }
+        }
+        __syncthreads();
         zero_acc(acc);
         gemm_rows64<T_RIN, LDR>(X, pk4 + (RO_FW1 / 4) + wave * (T_RIN * 128), lane, acc);
         __syncthreads();
@@ -224,7 +251,7 @@ __global__ void __launch_bounds__(256, 2)
 rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restrict__ colors, const int32_t* __restrict__ point_slot,
                       const int32_t* __restrict__ n_points_dev, int max_points, const float* packed, const float* __restrict__ act2,
                       const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ g_agg,
-                      float* __restrict__ g_b0, float* __restrict__ g_b2, float* __restrict__ g_w4 /* [3,256] */, float* __restrict__ g_b4 /* [3] */) {
+                      float* __restrict__ g_agg3, float* __restrict__ g_b6, float* __restrict__ g_b0, float* __restrict__ g_b2, float* __restrict__ g_w4 /* [3,256] */, float* __restrict__ g_b4 /* [3] */) {
     __shared__ __attribute__((aligned(16))) float smem[RL_TOTAL];
     float* X = smem + RL_X;
     float* s_g3 = smem + RL_G3;
@@ -309,9 +336,36 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
         __syncthreads();
         zero_acc(acc);
         gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BWA / 4) + wave * (T_HID * 128), lane, acc);
-        {   // g_agg[p][col]  (the buffer is padded to whole tiles: no bounds test)
+        __syncthreads();
+        {   // g_agg[p][col] -> HBM (operand of F_color.6's weight gradient; padded to whole tiles: no bounds test) and X;
+            // its column sums are F_color.6's bias gradient
             const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
             float* ga = g_agg + tb + c0;
+            float cs[2] = {0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m * 32 + row_of(r, h);
+                        const float v = acc[m][n][r];
+                        ga[row * 256 + 32 * n] = v;
+                        X[row * LDR + c0 + 32 * n] = v;
+                        cs[n] += v;
+                    }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float t = cs[n] + __shfl_xor(cs[n], 32);
+                if (h == 0) atomicAdd(&g_b6[c0 + 32 * n], t);
+            }
+        }
+        __syncthreads();
+        zero_acc(acc);
+        gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW6 / 4) + wave * (T_HID * 128), lane, acc);     // g_agg3 = g_agg W6
+        {
+            const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+            float* ga = g_agg3 + tb + c0;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -329,45 +383,46 @@ extern "C" {
 
 int64_t spf_rhead_packed_floats(void) { return R_PACKED; }
 
-int spf_rhead_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4, float* packed,
-                   void* stream) {
-    if (!w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !packed) return spf::fail(SPF_EINVAL, "spf_rhead_pack: null pointer");
-    RPackArgs a{w0, b0, w2, b2, w4, b4};
+int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const float* b0, const float* w2, const float* b2, const float* w4,
+                   const float* b4, float* packed, void* stream) {
+    if (!w6 || !b6 || !w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !packed) return spf::fail(SPF_EINVAL, "spf_rhead_pack: null pointer");
+    RPackArgs a{w6, b6, w0, b0, w2, b2, w4, b4};
     rhead_pack_kernel<<<spf::div_up(R_PACKED, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
     SPF_LAUNCH_CHECK("rhead_pack_kernel");
     return SPF_OK;
 }
 
-int spf_rhead_forward(const float* agg, const float* ray_dirs, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
-                      int32_t SR, const float* packed, float* colors, float* direnc, float* act1, float* act2, uint32_t* masks, void* stream) {
+int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
+                      int32_t SR, const float* packed, float* colors, float* agg, float* direnc, float* act1, float* act2, uint32_t* masks,
+                      void* stream) {
     if (max_points < 0 || SR < 1) return spf::fail(SPF_EINVAL, "spf_rhead_forward: bad sizes");
     if (max_points == 0) return SPF_OK;
-    if (!agg || !ray_dirs || !packed || !colors) return spf::fail(SPF_EINVAL, "spf_rhead_forward: null pointer");
+    if (!agg3 || !ray_dirs || !packed || !colors) return spf::fail(SPF_EINVAL, "spf_rhead_forward: null pointer");
     const bool store = direnc != nullptr;
-    if (store && (!act1 || !act2 || !masks)) return spf::fail(SPF_EINVAL, "spf_rhead_forward: training buffers must be given together");
+    if (store && (!agg || !act1 || !act2 || !masks)) return spf::fail(SPF_EINVAL, "spf_rhead_forward: training buffers must be given together");
     const int tiles = spf::div_up(max_points, 64);
     const int blocks = tiles < 512 ? tiles : 512;
     if (store)
-        rhead_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(agg, ray_dirs, point_slot, n_points, max_points, SR, packed, colors, direnc,
-                                                                            act1, act2, masks);
+        rhead_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(agg3, ray_dirs, point_slot, n_points, max_points, SR, packed, colors, agg,
+                                                                            direnc, act1, act2, masks);
     else
-        rhead_forward_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(agg, ray_dirs, point_slot, n_points, max_points, SR, packed, colors,
-                                                                             nullptr, nullptr, nullptr, nullptr);
+        rhead_forward_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(agg3, ray_dirs, point_slot, n_points, max_points, SR, packed, colors,
+                                                                             nullptr, nullptr, nullptr, nullptr, nullptr);
     SPF_LAUNCH_CHECK("rhead_forward_kernel");
     return SPF_OK;
 }
 
 int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
-                       const float* packed, const float* act2, const uint32_t* masks, float* G1, float* G2, float* g_agg, float* g_b0,
-                       float* g_b2, float* g_w4, float* g_b4, void* stream) {
+                       const float* packed, const float* act2, const uint32_t* masks, float* G1, float* G2, float* g_agg, float* g_agg3,
+                       float* g_b6, float* g_b0, float* g_b2, float* g_w4, float* g_b4, void* stream) {
     if (max_points < 0) return spf::fail(SPF_EINVAL, "spf_rhead_backward: bad sizes");
     if (max_points == 0) return SPF_OK;
-    if (!g_colors || !colors || !packed || !act2 || !masks || !G1 || !G2 || !g_agg || !g_b0 || !g_b2 || !g_w4 || !g_b4)
+    if (!g_colors || !colors || !packed || !act2 || !masks || !G1 || !G2 || !g_agg || !g_agg3 || !g_b6 || !g_b0 || !g_b2 || !g_w4 || !g_b4)
         return spf::fail(SPF_EINVAL, "spf_rhead_backward: null pointer");
     const int tiles = spf::div_up(max_points, 64);
     const int blocks = tiles < 512 ? tiles : 512;
     rhead_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_colors, colors, point_slot, n_points, max_points, packed, act2, masks, G1, G2,
-                                                                   g_agg, g_b0, g_b2, g_w4, g_b4);
+                                                                   g_agg, g_agg3, g_b6, g_b0, g_b2, g_w4, g_b4);
     SPF_LAUNCH_CHECK("rhead_backward_kernel");
     return SPF_OK;
 }

@@ -201,12 +201,13 @@ class PointVolSDF(nn.Module):
 
     def _colors_impl(self, n_valid, x, wn, pl, n_pairs, ray_dirs, SR):
         """:325-346 — colours of the P valid points, written at their slot rows of a dense [R*SR,3] array (0 elsewhere).
-        F_color + RBF-weighted mean and the R head are fused HIP kernels (spf_color_*, spf_rhead_*)."""
+        F_color's activated layers + RBF-weighted mean (per pair), then F_color's linear last layer + the R head (per
+        point) are fused HIP kernels (spf_color_*, spf_rhead_*)."""
         fc, rh = self.F_color, self.R
-        agg = ops.ColorAgg.apply(self.neural_feats_color, fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight,
-                                 fc[4].bias, fc[6].weight, fc[6].bias, x, wn, pl, self.neural_pts, n_valid, n_pairs)
-        return ops.RHead.apply(agg, rh[0].weight, rh[0].bias, rh[2].weight, rh[2].bias, rh[4].weight, rh[4].bias,
-                               ray_dirs.detach().contiguous(), pl.point_slot, pl.n_points, SR, x.shape[0], n_valid is None)
+        agg3 = ops.ColorAgg.apply(self.neural_feats_color, fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight,
+                                  fc[4].bias, x, wn, pl, self.neural_pts, n_valid, n_pairs)
+        return ops.RHead.apply(agg3, fc[6].weight, fc[6].bias, rh[0].weight, rh[0].bias, rh[2].weight, rh[2].bias, rh[4].weight,
+                               rh[4].bias, ray_dirs.detach().contiguous(), pl.point_slot, pl.n_points, SR, x.shape[0], n_valid is None)
 
     # ------------------------------------------------------------------ forward (:614-892)
     def forward(self, input, fast=-1):

@@ -232,7 +232,7 @@ def _color_col_perm(device):
 
 
 def pack_color_weights(ws):
-    """ws: [w0, b0, w2, b2, w4, b4, w6, b6] of F_color -> packed image."""
+    """ws: [w0, b0, w2, b2, w4, b4] of F_color's three activated layers -> packed image."""
     args = [t.detach().contiguous().float() for t in ws]
     dev = args[0].device
     packed = torch.empty((int(_lib.lib().spf_color_packed_floats()),), dtype=torch.float32, device=dev)
@@ -242,13 +242,13 @@ def pack_color_weights(ws):
 
 
 class ColorAgg(torch.autograd.Function):
-    """agg[p,256] = sum_j wn_j F_color([posenc6(x_pi) | colour latent]) for the P valid points
-    (pointneus_disent.py:325-336).  Forward and the data-gradient chain are HIP kernels; the weight
-    gradients are library GEMMs over the activation / pre-activation-gradient buffers the kernels store
-    (the last, linear layer through its rank structure: dW6 = g_agg^T (sum_j wn_j a3_j), K = P)."""
+    """agg3[p,256] = sum_j wn_j a3_j for the P valid points, a3 = the third activation of F_color on
+    [posenc6(x_pi) | colour latent] (pointneus_disent.py:325-336).  F_color's last layer is linear and commutes with the
+    weighted mean, so it runs once per point inside `RHead`.  Forward and the data-gradient chain are HIP kernels; the
+    weight gradients are GEMMs over the activation / pre-activation-gradient buffers the kernels store."""
 
     @staticmethod
-    def forward(ctx, feat_col, w0, b0, w2, b2, w4, b4, w6, b6, x, wn, pl, pts, n_valid, n_pairs):
+    def forward(ctx, feat_col, w0, b0, w2, b2, w4, b4, x, wn, pl, pts, n_valid, n_pairs):
         """n_valid / n_pairs: host ints (buffers sized exactly), or None = sync-free mode: worst-case buffers, every
         kernel (incl. the wgrad GEMMs) reads the counts from device memory."""
         dev = x.device
@@ -256,32 +256,31 @@ class ColorAgg(torch.autograd.Function):
         P, NP = (pl.max_points, pl.max_pairs) if ctx.static else (int(n_valid), int(n_pairs))
         tiles = (NP + 63) // 64
         rows = 64 * tiles
-        packed = pack_color_weights([w0, b0, w2, b2, w4, b4, w6, b6])
-        agg = torch.zeros((P, 256), dtype=torch.float32, device=dev)
-        train = any(ctx.needs_input_grad[:9])
+        packed = pack_color_weights([w0, b0, w2, b2, w4, b4])
+        agg3 = torch.zeros((P, 256), dtype=torch.float32, device=dev)
+        train = any(ctx.needs_input_grad[:7])
         if train:
             bufs = [torch.empty((rows, 104), dtype=torch.float32, device=dev), torch.empty((rows, 256), dtype=torch.float32, device=dev),
-                    torch.empty((rows, 256), dtype=torch.float32, device=dev), torch.zeros((P, 256), dtype=torch.float32, device=dev),
-                    torch.empty((tiles, 3, 512), dtype=torch.int32, device=dev)]
+                    torch.empty((rows, 256), dtype=torch.float32, device=dev), torch.empty((tiles, 3, 512), dtype=torch.int32, device=dev)]
         else:
-            bufs = [None] * 5
+            bufs = [None] * 4
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_color_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                     _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), NP, pl.k, _lib.ptr(pts),
-                                                    _lib.ptr(feat_col.detach()), _lib.ptr(packed), _lib.ptr(agg),
+                                                    _lib.ptr(feat_col.detach()), _lib.ptr(packed), _lib.ptr(agg3),
                                                     *[_lib.ptr(a) for a in bufs], _lib.stream_ptr()), "spf_color_forward")
         if train:
             ctx.save_for_backward(wn, packed, *bufs)
             ctx.pl, ctx.NP, ctx.n_table = pl, NP, feat_col.shape[0]
-            sinks = [_sink(t) for t in (feat_col, w0, b0, w2, b2, w4, b4, w6, b6)]
+            sinks = [_sink(t) for t in (feat_col, w0, b0, w2, b2, w4, b4)]
             ctx.sinks = sinks if (ctx.static and all(s_ is not None for s_ in sinks)) else None
-        return agg
+        return agg3
 
     @staticmethod
-    def backward(ctx, g_agg):
-        wn, packed, act0, act1, act2, agg3, masks = ctx.saved_tensors
+    def backward(ctx, g_agg3):
+        wn, packed, act0, act1, act2, masks = ctx.saved_tensors
         pl = ctx.pl
-        dev = g_agg.device
+        dev = g_agg3.device
         rows = act1.shape[0]
         G1, G2, G3 = (torch.empty((rows, 256), dtype=torch.float32, device=dev) for _ in range(3))
         sk = ctx.sinks
@@ -291,9 +290,9 @@ class ColorAgg(torch.autograd.Function):
             g_bias = torch.zeros((3, 256), dtype=torch.float32, device=dev)
             g_b0, g_b2, g_b4 = g_bias[0], g_bias[1], g_bias[2]
             g_feat = torch.zeros((ctx.n_table, 64), dtype=torch.float32, device=dev)
-        g_agg = g_agg.contiguous()
+        g_agg3 = g_agg3.contiguous()
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
+            _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg3), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                      _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), ctx.NP, pl.k, _lib.ptr(packed), _lib.ptr(masks),
                                                      _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_b4),
                                                      _lib.ptr(g_feat), _lib.stream_ptr()), "spf_color_backward")
@@ -302,21 +301,15 @@ class ColorAgg(torch.autograd.Function):
             sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs)[:, :103])
             wgrad(G2, act1, pl.n_pairs, out=sk[3])
             wgrad(G3, act2, pl.n_pairs, out=sk[5])
-            wgrad(g_agg, agg3, pl.n_points, out=sk[7])
-            wgrad(g_agg, _ones_col(g_agg.shape[0], dev), pl.n_points, C=1, out=sk[8].view(256, 1), ldw=1)
-            return (None,) * 15
+            return (None,) * 13
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
         if ctx.static:   # row counts stay on the device
             dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs)[:, :103]
             dw2, dw4 = wgrad(G2, act1, pl.n_pairs), wgrad(G3, act2, pl.n_pairs)
-            dw6 = wgrad(g_agg, agg3, pl.n_points)
-            db6 = wgrad(g_agg, _ones_col(g_agg.shape[0], dev), pl.n_points, C=1)[:, 0]
         else:
             dw0[:, _color_col_perm(dev)] = _wgrad(G1, act0)[:, :103]   # [256,104] comes in the kernels' internal column order
             dw2, dw4 = _wgrad(G2, act1), _wgrad(G3, act2)
-            dw6 = g_agg.t() @ agg3                                 # last layer: rank structure, K = P
-            db6 = g_agg.sum(0)
-        grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4, dw6, db6)
+        grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4)
         return grads + (None,) * 6
 
 
@@ -448,6 +441,7 @@ def sampler_finish(z_samples, z_vals, sel, near, far, cam_loc, ray_dirs):
 
 # ---- radiance head R -------------------------------------------------------------------------------
 def pack_rhead_weights(ws):
+    """ws: [F_color.6 w, b, R.0 w, b, R.2 w, b, R.4 w, b] -> packed image of the head stage."""
     args = [t.detach().contiguous().float() for t in ws]
     dev = args[0].device
     packed = torch.empty((int(_lib.lib().spf_rhead_packed_floats()),), dtype=torch.float32, device=dev)
@@ -457,71 +451,76 @@ def pack_rhead_weights(ws):
 
 
 class RHead(torch.autograd.Function):
-    """colors [rows,3] = sigmoid(R([direnc3(ray dir) | agg])) on the P valid points (pointneus_disent.py:338-346), written
-    at the points' slot rows (0 elsewhere).  Forward and the data-gradient chain are HIP kernels; the two wide layers'
-    weight gradients are library GEMMs over [P,256] buffers."""
+    """colors [rows,3] = sigmoid(R([direnc3(ray dir) | F_color.6(agg3)])) on the P valid points (pointneus_disent.py:333-346),
+    written at the points' slot rows (0 elsewhere).  F_color's linear last layer is applied here, per point, to the
+    RBF-weighted mean `agg3` that `ColorAgg` produced.  Forward and the data-gradient chain are HIP kernels; the wide
+    layers' weight gradients are GEMMs over [P,256] buffers."""
 
     @staticmethod
-    def forward(ctx, agg, w0, b0, w2, b2, w4, b4, ray_dirs, point_slot, n_points, SR, n_rows, static=False):
-        """agg has exactly P rows (host-known), or — static=True — worst-case rows with the count read on the device."""
-        dev = agg.device
+    def forward(ctx, agg3, w6, b6, w0, b0, w2, b2, w4, b4, ray_dirs, point_slot, n_points, SR, n_rows, static=False):
+        """agg3 has exactly P rows (host-known), or — static=True — worst-case rows with the count read on the device."""
+        dev = agg3.device
         ctx.static = static
-        P = agg.shape[0]
+        P = agg3.shape[0]
         tiles = (P + 63) // 64
         T = 64 * tiles
-        packed = pack_rhead_weights([w0, b0, w2, b2, w4, b4])
+        packed = pack_rhead_weights([w6, b6, w0, b0, w2, b2, w4, b4])
         colors = torch.zeros((n_rows, 3), dtype=torch.float32, device=dev)
-        train = any(ctx.needs_input_grad[:7])
+        train = any(ctx.needs_input_grad[:9])
         if train:
-            bufs = [torch.empty((T, 24), dtype=torch.float32, device=dev), torch.empty((T, 256), dtype=torch.float32, device=dev),
-                    torch.empty((T, 256), dtype=torch.float32, device=dev), torch.empty((tiles, 2, 512), dtype=torch.int32, device=dev)]
+            bufs = [torch.empty((T, 256), dtype=torch.float32, device=dev), torch.empty((T, 24), dtype=torch.float32, device=dev),
+                    torch.empty((T, 256), dtype=torch.float32, device=dev), torch.empty((T, 256), dtype=torch.float32, device=dev),
+                    torch.empty((tiles, 2, 512), dtype=torch.int32, device=dev)]
         else:
-            bufs = [None] * 4
-        agg_c = agg.detach().contiguous()
+            bufs = [None] * 5
+        agg3_c = agg3.detach().contiguous()
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().spf_rhead_forward(_lib.ptr(agg_c), _lib.ptr(ray_dirs), _lib.ptr(point_slot), _lib.ptr(n_points), P, int(SR),
+            _lib.check(_lib.lib().spf_rhead_forward(_lib.ptr(agg3_c), _lib.ptr(ray_dirs), _lib.ptr(point_slot), _lib.ptr(n_points), P, int(SR),
                                                     _lib.ptr(packed), _lib.ptr(colors), *[_lib.ptr(b) for b in bufs], _lib.stream_ptr()),
                        "spf_rhead_forward")
         if train:
-            ctx.save_for_backward(agg_c, colors, point_slot, n_points, packed, *bufs)
-            sinks = [_sink(t) for t in (w0, b0, w2, b2, w4, b4)]
+            ctx.save_for_backward(agg3_c, colors, point_slot, n_points, packed, *bufs)
+            sinks = [_sink(t) for t in (w6, b6, w0, b0, w2, b2, w4, b4)]
             ctx.sinks = sinks if (static and all(s_ is not None for s_ in sinks)) else None
         return colors
 
     @staticmethod
     def backward(ctx, g_colors):
-        agg, colors, point_slot, n_points, packed, direnc, act1, act2, masks = ctx.saved_tensors
+        agg3, colors, point_slot, n_points, packed, agg, direnc, act1, act2, masks = ctx.saved_tensors
         dev = g_colors.device
-        P, T = agg.shape[0], act1.shape[0]
-        G1 = torch.empty((T, 256), dtype=torch.float32, device=dev)
-        G2 = torch.empty((T, 256), dtype=torch.float32, device=dev)
-        g_agg = torch.empty((T, 256), dtype=torch.float32, device=dev)
+        P, T = agg3.shape[0], act1.shape[0]
+        G1, G2, g_agg, g_agg3 = (torch.empty((T, 256), dtype=torch.float32, device=dev) for _ in range(4))
         sk = ctx.sinks
         if sk is not None:
-            g_b0, g_b2, g_w4, g_b4 = sk[1], sk[3], sk[4], sk[5]
+            g_b6, g_b0, g_b2, g_w4, g_b4 = sk[1], sk[3], sk[5], sk[6], sk[7]
         else:
-            g_small = torch.zeros((1283,), dtype=torch.float32, device=dev)
-            g_b0, g_b2, g_w4, g_b4 = g_small[:256], g_small[256:512], g_small[512:1280].view(3, 256), g_small[1280:1283]
+            g_small = torch.zeros((1539,), dtype=torch.float32, device=dev)
+            g_b6, g_b0, g_b2, g_w4, g_b4 = (g_small[:256], g_small[256:512], g_small[512:768], g_small[768:1536].view(3, 256),
+                                            g_small[1536:1539])
         g_colors = g_colors.contiguous()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_rhead_backward(_lib.ptr(g_colors), _lib.ptr(colors), _lib.ptr(point_slot), _lib.ptr(n_points), P, _lib.ptr(packed),
-                                                     _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_b0),
-                                                     _lib.ptr(g_b2), _lib.ptr(g_w4), _lib.ptr(g_b4), _lib.stream_ptr()), "spf_rhead_backward")
+                                                     _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_agg3),
+                                                     _lib.ptr(g_b6), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_w4), _lib.ptr(g_b4),
+                                                     _lib.stream_ptr()), "spf_rhead_backward")
         if sk is not None:
-            wgrad(G1, direnc, n_points, C=21, out=sk[0])                # reference column order [dir-enc | agg]
-            wgrad(G1, agg, n_points, out=sk[0][:, 21:], ldw=277)
-            wgrad(G2, act1, n_points, out=sk[2])
-            return (g_agg[:P],) + (None,) * 12
+            wgrad(g_agg, agg3, n_points, out=sk[0])                     # F_color.6: K = points, not pairs
+            wgrad(G1, direnc, n_points, C=21, out=sk[2])                # R.0, reference column order [dir-enc | agg]
+            wgrad(G1, agg, n_points, out=sk[2][:, 21:], ldw=277)
+            wgrad(G2, act1, n_points, out=sk[4])
+            return (g_agg3[:P],) + (None,) * 14
         if ctx.static:
+            dw6 = wgrad(g_agg, agg3, n_points)
             dw0 = torch.zeros((256, 277), dtype=torch.float32, device=dev)        # reference column order [dir-enc | agg]
             wgrad(G1, direnc, n_points, C=21, out=dw0)
             wgrad(G1, agg, n_points, out=dw0[:, 21:])
             dw2 = wgrad(G2, act1, n_points)
         else:
             G1p, G2p = G1[:P], G2[:P]
-            dw0 = torch.cat([G1p.t() @ direnc[:P, :21], G1p.t() @ agg], dim=1)
+            dw6 = g_agg[:P].t() @ agg3
+            dw0 = torch.cat([G1p.t() @ direnc[:P, :21], G1p.t() @ agg[:P]], dim=1)
             dw2 = G2p.t() @ act1[:P]
-        return (g_agg[:P], dw0, g_b0, dw2, g_b2, g_w4, g_b4, None, None, None, None, None, None)
+        return (g_agg3[:P], dw6, g_b6, dw0, g_b0, dw2, g_b2, g_w4, g_b4, None, None, None, None, None, None)
 
 
 _wgrad_ws = {}

@@ -132,9 +132,10 @@ def test_tv_and_row_scatter_match_torch():
     np.testing.assert_allclose(table.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
-def test_color_agg_forward_backward_match_oracle():
-    """Fused F_color + weighted mean (pointneus_disent.py:325-336) vs torch-CPU autograd: agg, colour-latent
-    gradient, F_color weight / bias gradients."""
+def test_color_path_forward_backward_match_oracle():
+    """Colour path = per-pair trunk of F_color + RBF-weighted mean (ColorAgg), then F_color's linear last layer + R head per
+    point (RHead) — against torch-CPU autograd of the reference formulation, which applies ALL of F_color per pair and
+    averages afterwards (pointneus_disent.py:325-346): agg3, colours, colour-latent gradient, every weight / bias gradient."""
     from spurfies_amd import ops
 
     scene, st, cfg, x, dev, grid, packed = _setup(n_points=5000, n_query=2500, seed=8)
@@ -144,55 +145,74 @@ def test_color_agg_forward_backward_match_oracle():
     pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), point_slot, n_pts)
     geo = ops.geo_forward(xt, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
     P_, NP_ = pl.host_counts()
-    names = [f"F_color.{i}.{n}" for i in (0, 2, 4, 6) for n in ("weight", "bias")]
-    params = [dev[n].clone().requires_grad_(True) for n in names]
+    names = [f"{m}.{i}.{n}" for m, idx in (("F_color", (0, 2, 4, 6)), ("R", (0, 2, 4))) for i in idx for n in ("weight", "bias")]
+    params = {n: dev[n].clone().requires_grad_(True) for n in names}
+    fcp = [params[f"F_color.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")]
+    hdp = [params[f"F_color.6.{n}"] for n in ("weight", "bias")] + [params[f"R.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")]
     table = dev["neural_feats_color"].clone().requires_grad_(True)
-    agg = ops.ColorAgg.apply(table, *params, xt, geo["wn"], pl, dev["neural_pts"], P_, NP_)
-    coef = torch.randn((P_, 256), generator=torch.Generator().manual_seed(0)).cuda()
-    (agg * coef).sum().backward()
-    # oracle
+    M = x.shape[0]
+    dirs = torch.nn.functional.normalize(torch.randn((M, 3), generator=torch.Generator().manual_seed(1)), dim=-1)
+    agg3 = ops.ColorAgg.apply(table, *fcp, xt, geo["wn"], pl, dev["neural_pts"], P_, NP_)
+    colors = ops.RHead.apply(agg3, *hdp, dirs.cuda(), point_slot, n_pts, 1, M)            # SR = 1: one ray direction per row
+    rows_valid = point_slot[:P_].long()
+    coef = torch.randn((P_, 3), generator=torch.Generator().manual_seed(0))
+    (colors[rows_valid] * coef.cuda()).sum().backward()
+    # oracle: the reference's order of operations
+    for n in names + ["neural_feats_color"]:
+        st[n].requires_grad_(True)
     ogrid = P.make_grid(cfg, st["neural_pts"])
     nb, _, mask, _ = P.knn_query(ogrid, torch.from_numpy(x).unsqueeze(1), cfg.k, cfg.r, 1)
     valid = nb >= 0
     rows = P.pair_index(valid)
     pos, fc, fg = P.gather_pairs(nb, valid, st)
-    x_pi = torch.from_numpy(x)[mask.reshape(-1)][rows] - pos
+    keep = mask.reshape(-1)
+    x_pi = torch.from_numpy(x)[keep][rows] - pos
     w, norm = P.rbf_weights(x_pi, rows, nb.shape[0], cfg.rbf)
-    feat = P.mlp(torch.cat([P.posenc(x_pi, 6), fc], -1), st, "F_color")
+    inp = torch.cat([P.posenc(x_pi, 6), fc], -1)
+    feat = P.mlp(inp, st, "F_color")                                                       # 4 layers, per pair
     agg_o = torch.zeros(nb.shape[0], 256).index_add_(0, rows, w.unsqueeze(-1) * feat) / norm.unsqueeze(-1)
-    (agg_o * coef.cpu()).sum().backward()
-    assert agg_o.shape[0] == P_
-    np.testing.assert_allclose(agg.detach().cpu().numpy(), agg_o.detach().numpy(), rtol=2e-4, atol=2e-5)
+    col_o = torch.sigmoid(P.mlp(torch.cat([P.posenc(dirs[keep], 3), agg_o], -1), st, "R"))
+    (col_o * coef).sum().backward()
+    assert agg_o.shape[0] == P_ and torch.equal(torch.nonzero(keep).reshape(-1), rows_valid.cpu())
+    with torch.no_grad():                                                                  # third activation, averaged
+        h = inp
+        for i in (0, 2, 4):
+            h = torch.nn.functional.leaky_relu(torch.nn.functional.linear(h, st[f"F_color.{i}.weight"], st[f"F_color.{i}.bias"]), 0.01)
+        agg3_o = torch.zeros(nb.shape[0], 256).index_add_(0, rows, w.unsqueeze(-1) * h) / norm.unsqueeze(-1)
+    np.testing.assert_allclose(agg3.detach().cpu().numpy(), agg3_o.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(colors[rows_valid].detach().cpu().numpy(), col_o.detach().numpy(), rtol=2e-5, atol=2e-6)
     go = st["neural_feats_color"].grad
     np.testing.assert_allclose(table.grad.cpu().numpy(), go.numpy(), rtol=2e-3, atol=1e-4 * float(go.abs().max()))
-    for n, p_ in zip(names, params):
+    for n in names:
         g = st[n].grad
-        np.testing.assert_allclose(p_.grad.cpu().numpy(), g.numpy(), rtol=2e-3, atol=2e-4 * float(g.abs().max()), err_msg=n)
+        np.testing.assert_allclose(params[n].grad.cpu().numpy(), g.numpy(), rtol=2e-3, atol=2e-4 * float(g.abs().max()), err_msg=n)
 
 
 def test_rhead_forward_backward_match_torch():
-    """Fused R head (pointneus_disent.py:338-346) vs the oracle's torch ops: colours, d/d agg, weight and bias gradients."""
+    """Head stage alone (F_color.6 per point + R, pointneus_disent.py:333-346) vs the oracle's torch ops: colours, d/d agg3,
+    weight and bias gradients; sparse slot rows and SR > 1."""
     from spurfies_amd import ops
 
     g = torch.Generator().manual_seed(5)
     P_, R, SR = 1000, 40, 80
     st = P.load_state(syn.make_mlp_weights(seed=3))
-    names = [f"R.{i}.{n}" for i in (0, 2, 4) for n in ("weight", "bias")]
+    names = ["F_color.6.weight", "F_color.6.bias"] + [f"R.{i}.{n}" for i in (0, 2, 4) for n in ("weight", "bias")]
     params = [st[n].detach().cuda().requires_grad_(True) for n in names]
-    agg = (torch.randn((P_, 256), generator=g) * 0.5)
+    agg3 = (torch.randn((P_, 256), generator=g) * 0.5)
     dirs = torch.nn.functional.normalize(torch.randn((R, 3), generator=g), dim=-1)
     slots = torch.sort(torch.randperm(R * SR, generator=g)[:P_])[0].to(torch.int32)
     coef = torch.randn((P_, 3), generator=g)
-    agg_g = agg.cuda().requires_grad_(True)
+    agg_g = agg3.cuda().requires_grad_(True)
     n_pts = torch.tensor([P_], dtype=torch.int32, device="cuda")
     colors = ops.RHead.apply(agg_g, *params, dirs.cuda(), slots.cuda(), n_pts, SR, R * SR)
     (colors[slots.long().cuda()] * coef.cuda()).sum().backward()
     # oracle ops on the CPU
-    agg_o = agg.clone().requires_grad_(True)
+    agg_o = agg3.clone().requires_grad_(True)
     for n in names:
         st[n].requires_grad_(True)
     d_pts = dirs[torch.div(slots.long(), SR, rounding_mode="floor")]
-    col_o = torch.sigmoid(P.mlp(torch.cat([P.posenc(d_pts, 3), agg_o], -1), st, "R"))
+    agg_full = torch.nn.functional.linear(agg_o, st["F_color.6.weight"], st["F_color.6.bias"])
+    col_o = torch.sigmoid(P.mlp(torch.cat([P.posenc(d_pts, 3), agg_full], -1), st, "R"))
     (col_o * coef).sum().backward()
     np.testing.assert_allclose(colors[slots.long().cuda()].detach().cpu().numpy(), col_o.detach().numpy(), rtol=2e-5, atol=2e-6)
     assert float(colors.detach().abs().sum()) == pytest.approx(float(colors[slots.long().cuda()].detach().abs().sum()))
