@@ -242,26 +242,34 @@ __global__ void point_slots_kernel(const float* __restrict__ raypos, int R, int 
 }
 
 // ---- k nearest within radius ----------------------------------------------------------------
-// One thread per slot.  Exact top-8 by (dist2, index) kept sorted in registers; candidates come
-// from the 3x3 (x,y) columns of cells around the sample, each column's 3 z-cells being ONE
-// contiguous run of the sorted table (z is the fastest cell axis).
+// EIGHT lanes per slot (one thread per slot is bound by the latency of ~100 dependent candidate reads: 100-170 us whether
+// the launch has 10^3 or 10^5 slots).  Candidates come from the 3x3 (x,y) columns of cells around the sample, each
+// column's 3 z-cells being ONE contiguous run of the sorted table (z is the fastest cell axis); lane s of the octet takes
+// every 8th candidate of every run and keeps its exact top-8 by (dist2, index) — one 64-bit key, dist2 >= 0 so its float
+// bits order like the value — sorted in registers; three xor-shuffle rounds of bitonic merges leave the octet's top-8 in
+// every lane.  The result is the specification's top-k whatever the scan order (keys are unique).
+__device__ __forceinline__ void cmpx(unsigned long long& a, unsigned long long& b) {
+    const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo;
+    b = hi;
+}
+
 __global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ raypos, int R, int D, int SR, int k,
                                                   float rad2, GridDev g, int hkx, int hky, int hkz,
                                                   const int32_t* __restrict__ slot_sample, int32_t* __restrict__ pidx,
                                                   float* __restrict__ loc, uint8_t* __restrict__ slot_valid) {
-    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)R * SR) return;
-    int samp = slot_sample[gid];
-    float bd[SPF_KMAX];
-    int bi[SPF_KMAX];
+    constexpr unsigned long long NONE = ~0ull;
+    const size_t t8 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gid = t8 >> 3;
+    const int sub = (int)(t8 & 7);
+    if (gid >= (size_t)R * SR) return;                       // whole octets leave together
+    const int samp = slot_sample[gid];
+    unsigned long long key[SPF_KMAX];
 #pragma unroll
-    for (int t = 0; t < SPF_KMAX; ++t) {
-        bd[t] = FLT_MAX;
-        bi[t] = 0x7fffffff;
-    }
+    for (int t = 0; t < SPF_KMAX; ++t) key[t] = NONE;
     float x = 0.f, y = 0.f, z = 0.f;
     if (samp >= 0) {
-        size_t r = gid / SR;
+        const size_t r = gid / SR;
         const float* p = raypos + (r * D + samp) * 3;
         x = p[0];
         y = p[1];
@@ -270,39 +278,51 @@ __global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ rayp
         cell_of(g, x, y, z, cx, cy, cz);  // a slot's sample is always inside the grid
         for (int ax = max(cx - hkx, 0); ax <= min(cx + hkx, g.dx - 1); ++ax)
             for (int ay = max(cy - hky, 0); ay <= min(cy + hky, g.dy - 1); ++ay) {
-                int col = (ax * g.dy + ay) * g.dz;
-                int s = g.cell_start[col + max(cz - hkz, 0)];
-                int e = g.cell_start[col + min(cz + hkz, g.dz - 1) + 1];
-                for (int j = s; j < e; ++j) {
-                    float4 q = g.sorted[j];
-                    float dx = x - q.x, dy = y - q.y, dz = z - q.z;
-                    float d2 = (dx * dx + dy * dy) + dz * dz;
-                    int id = __float_as_int(q.w);
-                    if (d2 <= rad2 && (d2 < bd[SPF_KMAX - 1] || (d2 == bd[SPF_KMAX - 1] && id < bi[SPF_KMAX - 1]))) {
-                        bd[SPF_KMAX - 1] = d2;
-                        bi[SPF_KMAX - 1] = id;
+                const int col = (ax * g.dy + ay) * g.dz;
+                const int s = g.cell_start[col + max(cz - hkz, 0)];
+                const int e = g.cell_start[col + min(cz + hkz, g.dz - 1) + 1];
+                for (int j = s + sub; j < e; j += 8) {
+                    const float4 q = g.sorted[j];
+                    const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(q.w);
+                    if (d2 <= rad2 && kk < key[SPF_KMAX - 1]) {
+                        key[SPF_KMAX - 1] = kk;
 #pragma unroll
-                        for (int t = SPF_KMAX - 1; t > 0; --t) {
-                            bool sw = bd[t] < bd[t - 1] || (bd[t] == bd[t - 1] && bi[t] < bi[t - 1]);
-                            float td = sw ? bd[t - 1] : bd[t];
-                            int ti = sw ? bi[t - 1] : bi[t];
-                            bd[t - 1] = sw ? bd[t] : bd[t - 1];
-                            bi[t - 1] = sw ? bi[t] : bi[t - 1];
-                            bd[t] = td;
-                            bi[t] = ti;
-                        }
+                        for (int t = SPF_KMAX - 1; t > 0; --t) cmpx(key[t - 1], key[t]);
                     }
                 }
             }
-    }
-    int32_t* o = pidx + gid * k;
+        // merge the octet's eight sorted lists: min(mine[t], partner[7 - t]) is a bitonic sequence holding the 8 smallest of both
 #pragma unroll
-    for (int t = 0; t < SPF_KMAX; ++t)
-        if (t < k) o[t] = (bd[t] == FLT_MAX) ? -1 : bi[t];
-    loc[gid * 3] = x;
-    loc[gid * 3 + 1] = y;
-    loc[gid * 3 + 2] = z;
-    slot_valid[gid] = bd[0] != FLT_MAX;
+        for (int m = 1; m < 8; m <<= 1) {
+            unsigned long long o[SPF_KMAX];
+#pragma unroll
+            for (int t = 0; t < SPF_KMAX; ++t) {
+                const unsigned lo = __shfl_xor((unsigned)key[SPF_KMAX - 1 - t], m);
+                const unsigned hi = __shfl_xor((unsigned)(key[SPF_KMAX - 1 - t] >> 32), m);
+                o[t] = ((unsigned long long)hi << 32) | lo;
+            }
+#pragma unroll
+            for (int t = 0; t < SPF_KMAX; ++t) key[t] = key[t] < o[t] ? key[t] : o[t];
+#pragma unroll
+            for (int j = 4; j > 0; j >>= 1)
+#pragma unroll
+                for (int t = 0; t < SPF_KMAX; ++t)
+                    if ((t & j) == 0) cmpx(key[t], key[t + j]);
+        }
+    }
+    // lane s writes neighbour s; lane 0 the slot's position and validity
+    unsigned long long mine = key[0];
+#pragma unroll
+    for (int t = 1; t < SPF_KMAX; ++t) mine = sub == t ? key[t] : mine;
+    if (sub < k) pidx[gid * k + sub] = mine == NONE ? -1 : (int32_t)(unsigned)mine;
+    if (sub == 0) {
+        loc[gid * 3] = x;
+        loc[gid * 3 + 1] = y;
+        loc[gid * 3 + 2] = z;
+        slot_valid[gid] = key[0] != NONE;
+    }
 }
 
 __global__ void ray_valid_kernel(const uint8_t* __restrict__ slot_valid, int R, int SR, uint8_t* __restrict__ ray_valid) {
@@ -601,7 +621,7 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
         hit_slots_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, stream>>>(raypos, R, D, SR, d, slot_sample);
         SPF_LAUNCH_CHECK("hit_slots_kernel");
     }
-    knn_kernel<<<spf::div_up((long long)nslot, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
+    knn_kernel<<<spf::div_up((long long)nslot * 8, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
                                                                        g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
                                                                        slot_sample, pidx, loc, slot_valid);
     SPF_LAUNCH_CHECK("knn_kernel");
