@@ -264,11 +264,13 @@ int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float*
                        float* rgb, float* depth, float* dist, float* acc, void* stream);
 
 /* Gradients of a scalar loss given g_weights [R,SR] (may be NULL), g_rgb [R,3], g_depth [R] (may be
- * NULL), g_dist [R] (may be NULL): g_sdf [R,SR], g_colors [R,SR,3], and g_beta[0] += dL/d beta. */
+ * NULL), g_dist [R] (may be NULL): g_sdf [R,SR], g_colors [R,SR,3], and g_beta[0] += dL/d beta — or, when the raw
+ * LaplaceDensity parameter is passed in beta_param (beta = |beta_param| + beta_min, spurfies/model/density.py:28-30),
+ * g_beta[0] += sign(beta_param) dL/d beta, i.e. the parameter's own gradient. */
 int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas,
                         const float* colors, const float* beta, const float* weights, const float* g_weights,
                         const float* g_rgb, const float* g_depth, const float* g_dist, int32_t R, int32_t SR,
-                        float* g_sdf, float* g_colors, float* g_beta, void* stream);
+                        float* g_sdf, float* g_colors, float* g_beta, const float* beta_param, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight-gradient GEMM with a device-side row count — replaces autograd's AddmmBackward GEMMs for the

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
                                                               const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
                                                               const float* __restrict__ g_dist, int R, int SR,
                                                               float* __restrict__ g_sdf, float* __restrict__ g_colors,
-                                                              float* __restrict__ g_beta) {
+                                                              float* __restrict__ g_beta, const float* __restrict__ beta_param) {
     const int lane = threadIdx.x & 63;
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= R) return;
@@ -207,7 +207,10 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
         }
     }
     gb = wave_sum(gb);
-    if (lane == 0 && gb != 0.f) atomicAdd(g_beta, gb);
+    if (lane == 0 && gb != 0.f) {   // beta = |beta_param| + beta_min: chain through the abs when the raw parameter is given
+        if (beta_param) gb *= *beta_param > 0.f ? 1.f : (*beta_param < 0.f ? -1.f : 0.f);
+        atomicAdd(g_beta, gb);
+    }
 }
 
 }  // namespace
@@ -240,13 +243,14 @@ int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float*
 
 int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas, const float* colors,
                         const float* beta, const float* weights, const float* g_weights, const float* g_rgb, const float* g_depth,
-                        const float* g_dist, int32_t R, int32_t SR, float* g_sdf, float* g_colors, float* g_beta, void* stream) {
+                        const float* g_dist, int32_t R, int32_t SR, float* g_sdf, float* g_colors, float* g_beta, const float* beta_param,
+                        void* stream) {
     if (R < 0 || SR < 1 || SR > 64 * MAX_CH) return spf::fail(SPF_EINVAL, "spf_render_backward: need 1 <= SR <= %d", 64 * MAX_CH);
     if (R == 0) return SPF_OK;
     if (!sdf || !slot_valid || !z || !deltas || !colors || !beta || !weights || !g_rgb || !g_sdf || !g_colors || !g_beta)
         return spf::fail(SPF_EINVAL, "spf_render_backward: null pointer");
     render_backward_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, (hipStream_t)stream>>>(
-        sdf, slot_valid, z, deltas, colors, beta, weights, g_weights, g_rgb, g_depth, g_dist, R, SR, g_sdf, g_colors, g_beta);
+        sdf, slot_valid, z, deltas, colors, beta, weights, g_weights, g_rgb, g_depth, g_dist, R, SR, g_sdf, g_colors, g_beta, beta_param);
     SPF_LAUNCH_CHECK("render_backward_kernel");
     return SPF_OK;
 }

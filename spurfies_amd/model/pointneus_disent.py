@@ -258,7 +258,11 @@ class PointVolSDF(nn.Module):
         colors = colors.view(R, SR, 3)
 
         # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------
-        weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta(), q["slot_valid"], z_slots, deltas)
+        if static and ops._sink(self.density.beta) is not None:    # beta's gradient goes straight into its .grad buffer
+            weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta().detach(), q["slot_valid"], z_slots,
+                                                                  deltas, self.density.beta)
+        else:
+            weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta(), q["slot_valid"], z_slots, deltas)
         output = {"rgb_values": rgb, "weights": weights, "local_loss": torch.zeros((), device=dev)}
         if not static:          # per-slot maps the trainer never reads in an optimisation step (plots only)
             far_fill = float(conf.ray_sampler.far)

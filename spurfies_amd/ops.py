@@ -355,7 +355,9 @@ class Render(torch.autograd.Function):
     effective beta (a 0-dim tensor); differentiable w.r.t. all three."""
 
     @staticmethod
-    def forward(ctx, sdf, colors, beta, slot_valid, z, deltas):
+    def forward(ctx, sdf, colors, beta, slot_valid, z, deltas, beta_param=None):
+        """beta_param: the raw LaplaceDensity parameter (beta = |beta_param| + beta_min was formed from it, detached) when
+        its gradient should be accumulated straight into its .grad buffer (set_grad_sinks)."""
         R, SR = sdf.shape
         dev = sdf.device
         sdf_c, col_c = sdf.detach().contiguous(), colors.detach().contiguous()
@@ -370,6 +372,10 @@ class Render(torch.autograd.Function):
                                                      _lib.ptr(beta_c), R, SR, _lib.ptr(weights), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(dist),
                                                      _lib.ptr(acc), _lib.stream_ptr()), "spf_render_forward")
         ctx.save_for_backward(sdf_c, col_c, beta_c, slot_valid, z, deltas, weights)
+        ctx.beta_param = beta_param.detach() if beta_param is not None else None
+        ctx.beta_sink = _sink(beta_param) if beta_param is not None else None
+        if beta_param is not None and ctx.beta_sink is None:
+            raise RuntimeError("Render: beta_param needs a gradient sink (ops.set_grad_sinks)")
         return weights, rgb, depth, dist, acc
 
     @staticmethod
@@ -388,13 +394,14 @@ class Render(torch.autograd.Function):
         g_dist = None if g_dist is None else g_dist.contiguous()
         g_sdf = torch.empty((R, SR), dtype=torch.float32, device=dev)
         g_col = torch.empty((R, SR, 3), dtype=torch.float32, device=dev)
-        g_beta = torch.zeros((1,), dtype=torch.float32, device=dev)
+        sink = ctx.beta_sink
+        g_beta = sink.reshape(1) if sink is not None else torch.zeros((1,), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_render_backward(_lib.ptr(sdf), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(colors),
                                                       _lib.ptr(beta), _lib.ptr(weights), _lib.ptr(gw), _lib.ptr(g_rgb), _lib.ptr(g_depth),
                                                       _lib.ptr(g_dist), R, SR, _lib.ptr(g_sdf), _lib.ptr(g_col), _lib.ptr(g_beta),
-                                                      _lib.stream_ptr()), "spf_render_backward")
-        return g_sdf, g_col, g_beta.reshape(()), None, None, None
+                                                      _lib.ptr(ctx.beta_param), _lib.stream_ptr()), "spf_render_backward")
+        return g_sdf, g_col, (None if sink is not None else g_beta.reshape(())), None, None, None, None
 
 
 # ---- sampler stages ---------------------------------------------------------------------------------
