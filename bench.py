@@ -182,7 +182,7 @@ def main():
                    "rays_per_gpu": args.rays, "neural_points": args.points, "k": 8, "max_shading_pts": 80,
                    "parallelism": f"ray-sharded dp{world}", "valid_points_last_step": model.stats.get("valid_points", int(model.stats["counts"][0].item()) if "counts" in model.stats else None),
                    "host_syncs_per_step": 1 if args.sync else 0,
-                   "launch": "hipGraph replay (fwd+loss+bwd) + eager clip/Adam" if use_graph else "eager"},
+                   "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else "eager"},
         "roofline": roof,
         "loss_last": loss_last,
     }
