@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--spacing", type=float, default=0.025, help="nearest-neighbour spacing of the synthetic cloud (0.0125 = dense stress cloud)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync", action="store_true", help="default (reference-shaped) step with one host read-back per step")
-    ap.add_argument("--no-graph", action="store_true", help="sync-free step, launches issued eagerly instead of one hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="replay forward + loss + backward as one hipGraph (measured 4 %% SLOWER than the "
+                    "eager sync-free step on MI355X: ~3 us of dependency handling per graph node x ~105 nodes; the eager launches run ahead of the GPU)")
+    ap.add_argument("--no-graph", action="store_true", help="(default since the sync-free step became GPU-bound; kept for old command lines)")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     return ap.parse_args()
 
@@ -118,7 +120,7 @@ def main():
     conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
     model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
     model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
-    use_graph = not args.sync and not args.no_graph and world == 1
+    use_graph = args.graph and not args.sync and world == 1
     step = TrainStep(model, sync_free=not args.sync, use_graph=use_graph)
     rays_total = args.rays * world
     batches = make_batches(scene, args.warmup + args.steps, rays_total, rank, world, device)
@@ -182,7 +184,7 @@ def main():
                    "rays_per_gpu": args.rays, "neural_points": args.points, "k": 8, "max_shading_pts": 80,
                    "parallelism": f"ray-sharded dp{world}", "valid_points_last_step": model.stats.get("valid_points", int(model.stats["counts"][0].item()) if "counts" in model.stats else None),
                    "host_syncs_per_step": 1 if args.sync else 0,
-                   "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else "eager"},
+                   "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~110 per step)")},
         "roofline": roof,
         "loss_last": loss_last,
     }

@@ -109,20 +109,10 @@ __global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
 
 // epilogue of a layer: + bias, (LeakyReLU), write to X.  Training mode also records the sign bits (one uint32 per
 // lane and row half: bit n*16+r, the same lane/register position the backward kernel's accumulators have).
-// [64][256] tile: LDS -> HBM as 1-KiB wave stores (the accumulator layout would give 4-byte stores two rows at a time)
-__device__ __forceinline__ void store_tile_256(const float* X, float* __restrict__ dst, int tid) {
-#pragma unroll 4
-    for (int u = 0; u < 16; ++u) {
-        const int e4 = tid + 256 * u, row = e4 >> 6, c4 = e4 & 63;
-        *reinterpret_cast<f32x4*>(dst + row * 256 + 4 * c4) = *reinterpret_cast<const f32x4*>(X + row * LDA + 4 * c4);
-    }
-}
-
 template <bool STORE, bool ACT>
-__device__ __forceinline__ void c_fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave, int lane,
+__device__ __forceinline__ void c_fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float (&bv)[2], int wave, int lane,
                                                uint32_t* mask_g /* [4][2][64] or null */) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
-    const float bv[2] = {bias[c0], bias[c0 + 32]};
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         uint32_t bits = 0u;
@@ -162,6 +152,7 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const float* packed = launder(packed0);
         const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+        const BFrag fr1 = load_bfrag(pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128), lane);     // in flight during the gather
         // ---- gather: thread = (row, quarter): 16 latent floats each; quarter 0 also does posenc -----
         {
             const int row = tid >> 2, q4 = tid & 3;
@@ -223,23 +214,31 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
             }
         }
         uint32_t* mk = STORE ? masks + (size_t)tile * 3 * 512 : nullptr;   // [layer 3][wave 4][m 2][lane 64]
+        // bias values are requested before each GEMM, the next layer's first weight fragment inside it (mlp_tile.h)
+        const int cb = wave * 64 + (lane & 31);
+        const f32x4* wfw1 = pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128);
+        const f32x4* wfw2 = pk4 + (CO_FW2 / 4) + wave * (T_HID * 128);
+        const f32x4* wfw3 = pk4 + (CO_FW3 / 4) + wave * (T_HID * 128);
+        float bv[2] = {packed[CO_B1 + cb], packed[CO_B1 + cb + 32]};
         f32x16 acc[2][2];
         zero_acc(acc);
-        gemm_rows64<T_CIN>(X, pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128), lane, acc);
+        BFrag nf = gemm_rows64<T_CIN>(X, wfw1, lane, acc, fr1, wfw2);
         __syncthreads();
-        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B1, wave, lane, mk);
+        c_fwd_epilogue<STORE, true>(X, acc, bv, wave, lane, mk);
         __syncthreads();
+        bv[0] = packed[CO_B2 + cb]; bv[1] = packed[CO_B2 + cb + 32];
         if (STORE) store_tile_256(X, act1 + (size_t)tile * 64 * 256, tid);
         zero_acc(acc);
-        gemm_rows64<T_HID>(X, pk4 + (CO_FW2 / 4) + wave * (T_HID * 128), lane, acc);
+        nf = gemm_rows64<T_HID>(X, wfw2, lane, acc, nf, wfw3);
         __syncthreads();
-        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B2, wave, lane, STORE ? mk + 512 : nullptr);
+        c_fwd_epilogue<STORE, true>(X, acc, bv, wave, lane, STORE ? mk + 512 : nullptr);
         __syncthreads();
+        bv[0] = packed[CO_B3 + cb]; bv[1] = packed[CO_B3 + cb + 32];
         if (STORE) store_tile_256(X, act2 + (size_t)tile * 64 * 256, tid);
         zero_acc(acc);
-        gemm_rows64<T_HID>(X, pk4 + (CO_FW3 / 4) + wave * (T_HID * 128), lane, acc);
+        gemm_rows64<T_HID>(X, wfw3, lane, acc, nf, nullptr);
         __syncthreads();
-        c_fwd_epilogue<STORE, true>(X, acc, packed + CO_B3, wave, lane, STORE ? mk + 1024 : nullptr);
+        c_fwd_epilogue<STORE, true>(X, acc, bv, wave, lane, STORE ? mk + 1024 : nullptr);
         __syncthreads();
         seg_reduce_rows(X, smem + CL_W, s_p, tid, agg3);   // agg3[p] = sum_j wn_j a3_j; the linear F_color.6 follows per point
         __syncthreads();
@@ -249,12 +248,12 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
 // backward epilogue: G_l = g_a * lrelu'(h_l) with the sign bits the forward recorded; write X and G_l (operand of the
 // wgrad GEMM) and add this tile's column sums to the bias gradient (256 floats per layer per tile, 128-B atomics)
 __device__ __forceinline__ void c_bwd_epilogue(float* X, const f32x16 (&acc)[2][2], int wave, int lane,
-                                               const uint32_t* __restrict__ mask_g, float* __restrict__ g_bias) {
+                                               const uint32_t (&mbits)[2], float* __restrict__ g_bias) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
     float cs[2] = {0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const uint32_t bits = mask_g[(wave * 2 + m) * 64 + lane];
+        const uint32_t bits = mbits[m];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -275,12 +274,12 @@ __device__ __forceinline__ void c_bwd_epilogue(float* X, const f32x16 (&acc)[2][
 
 // same, for a gradient tile that is already in LDS (no GEMM in front): every lane owns the (row, column) positions its
 // accumulators would have, so the in-place update needs no further synchronisation
-__device__ __forceinline__ void c_bwd_mask_inplace(float* X, int wave, int lane, const uint32_t* __restrict__ mask_g, float* __restrict__ g_bias) {
+__device__ __forceinline__ void c_bwd_mask_inplace(float* X, int wave, int lane, const uint32_t (&mbits)[2], float* __restrict__ g_bias) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
     float cs[2] = {0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const uint32_t bits = mask_g[(wave * 2 + m) * 64 + lane];
+        const uint32_t bits = mbits[m];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -319,6 +318,9 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
         const float* packed = launder(packed0);
         const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
         const size_t tbase = (size_t)tile * 64 * 256;
+        const uint32_t* mk = masks + (size_t)tile * 3 * 512;
+        const BFrag fr3 = load_bfrag(pk4 + (CO_BW3 / 4) + wave * (T_HID * 128), lane);    // in flight during the gather
+        const uint32_t mb3[2] = {mk[1024 + (wave * 2) * 64 + lane], mk[1024 + (wave * 2 + 1) * 64 + lane]};
         // ---- g_a3[row] = wn[row] * g_agg3[p]  (agg3 = sum_j wn_j a3_j) -------------------------------
         {
             const int row = tid >> 2, q4 = tid & 3;
@@ -346,20 +348,23 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
         }
         __syncthreads();
         f32x16 acc[2][2];
-        const uint32_t* mk = masks + (size_t)tile * 3 * 512;
-        c_bwd_mask_inplace(X, wave, lane, mk + 1024, g_b4);     // G3 = g_a3 * lrelu'(h3), in place
+        const f32x4* wbw3 = pk4 + (CO_BW3 / 4) + wave * (T_HID * 128);
+        const f32x4* wbw2 = pk4 + (CO_BW2 / 4) + wave * (T_HID * 128);
+        c_bwd_mask_inplace(X, wave, lane, mb3, g_b4);     // G3 = g_a3 * lrelu'(h3), in place
         __syncthreads();
         store_tile_256(X, G3 + tbase, tid);
+        uint32_t mb[2] = {mk[512 + (wave * 2) * 64 + lane], mk[512 + (wave * 2 + 1) * 64 + lane]};   // sign bits: requested before the GEMM
         zero_acc(acc);
-        gemm_rows64<T_HID>(X, pk4 + (CO_BW3 / 4) + wave * (T_HID * 128), lane, acc);
+        BFrag nf = gemm_rows64<T_HID>(X, wbw3, lane, acc, fr3, wbw2);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, mk + 512, g_b2);
+        c_bwd_epilogue(X, acc, wave, lane, mb, g_b2);
         __syncthreads();
         store_tile_256(X, G2 + tbase, tid);
+        mb[0] = mk[(wave * 2) * 64 + lane]; mb[1] = mk[(wave * 2 + 1) * 64 + lane];
         zero_acc(acc);
-        gemm_rows64<T_HID>(X, pk4 + (CO_BW2 / 4) + wave * (T_HID * 128), lane, acc);
+        gemm_rows64<T_HID>(X, wbw2, lane, acc, nf, nullptr);
         __syncthreads();
-        c_bwd_epilogue(X, acc, wave, lane, mk, g_b0);
+        c_bwd_epilogue(X, acc, wave, lane, mb, g_b0);
         __syncthreads();
         store_tile_256(X, G1 + tbase, tid);
         // ---- d/d latent = G1 * W0[:, 39:103]; wave = (row half mt, latent half nt); scatter-add ------

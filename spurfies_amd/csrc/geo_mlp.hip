@@ -59,10 +59,9 @@ constexpr int L_TOTAL = 64 * LDA;
 constexpr int PT_STRIDE = 5;
 
 // forward epilogue: + bias, record sign bits, LeakyReLU, write this wave's 64x64 block back to X
-__device__ __forceinline__ void fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave,
+__device__ __forceinline__ void fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float (&bv)[2], int wave,
                                              int lane, uint32_t (&mask)[2]) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
-    const float bv[2] = {bias[c0], bias[c0 + 32]};
     mask[0] = mask[1] = 0u;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -113,6 +112,7 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const float* packed = launder(packed0);
         const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+        const BFrag fr1 = load_bfrag(pk4 + (OFF_FW1 / 4) + wave * (T_IN * 128), lane);     // in flight during the gather
         // ---- gather: thread = (row, quarter of the 32-d latent) ---------------------------------
         {
             const int row = tid >> 2, q4 = tid & 3;
@@ -150,25 +150,40 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
         f32x16 acc[2][2];
         uint32_t m1[2], m2[2], m3[2], m4[2];
         // ---- forward: 35 -> 256 -> 256 -> 256 -> 256 -------------------------------------------
+        // each layer's bias values are requested before its GEMM and the next layer's first weight fragment inside it, so
+        // neither L2 round trip is exposed between the barriers
+        const int cb = wave * 64 + (lane & 31);
+        const f32x4* wfw1 = pk4 + (OFF_FW1 / 4) + wave * (T_IN * 128);
+        const f32x4* wfw2 = pk4 + (OFF_FW2 / 4) + wave * (T_HID * 128);
+        const f32x4* wfw3 = pk4 + (OFF_FW3 / 4) + wave * (T_HID * 128);
+        const f32x4* wfw4 = pk4 + (OFF_FW4 / 4) + wave * (T_HID * 128);
+        const f32x4* wbw4 = pk4 + (OFF_BW4 / 4) + wave * (T_HID * 128);
+        const f32x4* wbw3 = pk4 + (OFF_BW3 / 4) + wave * (T_HID * 128);
+        const f32x4* wbw2 = pk4 + (OFF_BW2 / 4) + wave * (T_HID * 128);
+        float bv[2] = {packed[OFF_B1 + cb], packed[OFF_B1 + cb + 32]};
         zero_acc(acc);
-        gemm_rows64<T_IN>(X, pk4 + (OFF_FW1 / 4) + wave * (T_IN * 128), lane, acc);
+        BFrag nf = gemm_rows64<T_IN>(X, wfw1, lane, acc, fr1, wfw2);
         __syncthreads();
-        fwd_epilogue(X, acc, packed + OFF_B1, wave, lane, m1);
+        fwd_epilogue(X, acc, bv, wave, lane, m1);
         __syncthreads();
+        bv[0] = packed[OFF_B2 + cb]; bv[1] = packed[OFF_B2 + cb + 32];
         zero_acc(acc);
-        gemm_rows64<T_HID>(X, pk4 + (OFF_FW2 / 4) + wave * (T_HID * 128), lane, acc);
+        nf = gemm_rows64<T_HID>(X, wfw2, lane, acc, nf, wfw3);
         __syncthreads();
-        fwd_epilogue(X, acc, packed + OFF_B2, wave, lane, m2);
+        fwd_epilogue(X, acc, bv, wave, lane, m2);
         __syncthreads();
+        bv[0] = packed[OFF_B3 + cb]; bv[1] = packed[OFF_B3 + cb + 32];
         zero_acc(acc);
-        gemm_rows64<T_HID>(X, pk4 + (OFF_FW3 / 4) + wave * (T_HID * 128), lane, acc);
+        nf = gemm_rows64<T_HID>(X, wfw3, lane, acc, nf, wfw4);
         __syncthreads();
-        fwd_epilogue(X, acc, packed + OFF_B3, wave, lane, m3);
+        fwd_epilogue(X, acc, bv, wave, lane, m3);
         __syncthreads();
+        bv[0] = packed[OFF_B4 + cb]; bv[1] = packed[OFF_B4 + cb + 32];
+        const float vv[2] = {packed[OFF_V5 + cb], packed[OFF_V5 + cb + 32]};       // folded last layer, used by the sweep
         zero_acc(acc);
-        gemm_rows64<T_HID>(X, pk4 + (OFF_FW4 / 4) + wave * (T_HID * 128), lane, acc);
+        nf = gemm_rows64<T_HID>(X, wfw4, lane, acc, nf, WITH_JAC ? wbw4 : nullptr);
         __syncthreads();
-        fwd_epilogue(X, acc, packed + OFF_B4, wave, lane, m4);
+        fwd_epilogue(X, acc, bv, wave, lane, m4);
         __syncthreads();
 
         // ---- sdf_j = v . a4 + c : 4 threads per row, interleaved float4 chunks ------------------
@@ -194,7 +209,6 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
             // ---- Jacobian sweep: g_h4 = v * D4 ; g_a3 = g_h4 W6 ; ... ; J = g_h1 W0 --------------
             {
                 const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
-                const float vv[2] = {packed[OFF_V5 + c0], packed[OFF_V5 + c0 + 32]};
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -207,17 +221,17 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
             }
             __syncthreads();
             zero_acc(acc);
-            gemm_rows64<T_HID>(X, pk4 + (OFF_BW4 / 4) + wave * (T_HID * 128), lane, acc);
+            nf = gemm_rows64<T_HID>(X, wbw4, lane, acc, nf, wbw3);
             __syncthreads();
             bwd_epilogue(X, acc, wave, lane, m3);
             __syncthreads();
             zero_acc(acc);
-            gemm_rows64<T_HID>(X, pk4 + (OFF_BW3 / 4) + wave * (T_HID * 128), lane, acc);
+            nf = gemm_rows64<T_HID>(X, wbw3, lane, acc, nf, wbw2);
             __syncthreads();
             bwd_epilogue(X, acc, wave, lane, m2);
             __syncthreads();
             zero_acc(acc);
-            gemm_rows64<T_HID>(X, pk4 + (OFF_BW2 / 4) + wave * (T_HID * 128), lane, acc);
+            gemm_rows64<T_HID>(X, wbw2, lane, acc, nf, nullptr);
             __syncthreads();
             bwd_epilogue(X, acc, wave, lane, m1);
             __syncthreads();

@@ -22,14 +22,30 @@ __device__ __forceinline__ const T* launder(const T* p) {
 
 __device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// First B fragment of a layer (k-step 0): fetched by the PREVIOUS layer's GEMM, four k-steps before its end, so that the
+// ~1 us L2 latency is not exposed at the start of every layer (the two workgroups of a CU run in phase and would both wait).
+struct BFrag {
+    f32x4 b0, b1;
+};
+__device__ __forceinline__ BFrag load_bfrag(const f32x4* wp, int lane) {
+    BFrag f;
+    f.b0 = wp[lane];
+    f.b1 = wp[lane + 64];
+    return f;
+}
+
 // acc[mt][nt] += X[mt*32.., :] * B  for this wave's 64 output columns.  wp: [T][2][64] float4.  LD = LDS row stride.
+// `first` = this layer's k-step-0 fragment (load_bfrag(wp)); returns the k-step-0 fragment of `next_wp` (or `first`).
 template <int T, int LD = LDA>
-__device__ __forceinline__ void gemm_rows64(const float* X, const f32x4* wp, int lane, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ BFrag gemm_rows64(const float* X, const f32x4* wp, int lane, f32x16 (&acc)[2][2], BFrag first,
+                                             const f32x4* next_wp) {
     const int i = lane & 31, h = lane >> 5;
     const float* a0p = X + i * LD + 4 * h;
     const float* a1p = a0p + 32 * LD;
     const f32x4* bp = wp + lane;
-    f32x4 b0 = bp[0], b1 = bp[64];
+    f32x4 b0 = first.b0, b1 = first.b1;
+    BFrag nxt = first;
+    constexpr int T_PRE = T > 4 ? T - 4 : 0;
 #pragma unroll 4
     for (int t = 0; t < T; ++t) {
         f32x4 nb0 = b0, nb1 = b1;
@@ -37,6 +53,7 @@ __device__ __forceinline__ void gemm_rows64(const float* X, const f32x4* wp, int
             nb0 = bp[(t + 1) * 128];
             nb1 = bp[(t + 1) * 128 + 64];
         }
+        if (t == T_PRE && next_wp) nxt = load_bfrag(next_wp, lane);
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + 8 * t);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 8 * t);
 #pragma unroll
@@ -48,6 +65,24 @@ __device__ __forceinline__ void gemm_rows64(const float* X, const f32x4* wp, int
         }
         b0 = nb0;
         b1 = nb1;
+    }
+    return nxt;
+}
+
+// stand-alone form: fetches its own first fragment (latency exposed)
+template <int T, int LD = LDA>
+__device__ __forceinline__ void gemm_rows64(const float* X, const f32x4* wp, int lane, f32x16 (&acc)[2][2]) {
+    gemm_rows64<T, LD>(X, wp, lane, acc, load_bfrag(wp, lane), nullptr);
+}
+
+// [64][256] tile: LDS -> HBM as 1-KiB wave stores (the accumulator layout would give 4-byte stores two rows at a time,
+// and 64 separately addressed stores per lane cost registers)
+template <int LD = LDA>
+__device__ __forceinline__ void store_tile_256(const float* X, float* __restrict__ dst, int tid) {
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const int e4 = tid + 256 * u, row = e4 >> 6, c4 = e4 & 63;
+        *reinterpret_cast<f32x4*>(dst + row * 256 + 4 * c4) = *reinterpret_cast<const f32x4*>(X + row * LD + 4 * c4);
     }
 }
 

@@ -78,10 +78,9 @@ __global__ void rhead_pack_kernel(RPackArgs a, float* __restrict__ out) {
 }
 
 template <bool STORE>
-__device__ __forceinline__ void r_fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float* bias, int wave, int lane,
-                                               float* act_g, uint32_t* mask_g) {
+__device__ __forceinline__ void r_fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float (&bv)[2], int wave, int lane,
+                                               uint32_t* mask_g) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
-    const float bv[2] = {bias[c0], bias[c0 + 32]};
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         uint32_t bits = 0u;
@@ -95,7 +94,6 @@ __device__ __forceinline__ void r_fwd_epilogue(float* X, const f32x16 (&acc)[2][
                 v = pos ? v : v * 0.01f;
                 const int row = m * 32 + row_of(r, h);
                 X[row * LDR + c0 + 32 * n] = v;
-                if (STORE) act_g[row * 256 + c0 + 32 * n] = v;
             }
         if (STORE) mask_g[(wave * 2 + m) * 64 + lane] = bits;
     }
@@ -118,6 +116,7 @@ rhead_forward_kernel(const float* __restrict__ agg3, const float* __restrict__ r
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const float* packed = launder(packed0);
         const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+        const BFrag fr6 = load_bfrag(pk4 + (RO_FW6 / 4) + wave * (T_HID * 128), lane);     // in flight during the gather
         {   // gather: thread = (row, quarter): 64 agg3 floats each; quarter 0 also encodes the view direction
             const int row = tid >> 2, q4 = tid & 3;
             const int p = tile * 64 + row;
@@ -165,12 +164,16 @@ rhead_forward_kernel(const float* __restrict__ agg3, const float* __restrict__ r
         const size_t tb = (size_t)tile * 64 * 256;
         uint32_t* mk = STORE ? masks + (size_t)tile * 2 * 512 : nullptr;
         f32x16 acc[2][2];
+        const int cb = wave * 64 + (lane & 31);
+        const f32x4* wfw6 = pk4 + (RO_FW6 / 4) + wave * (T_HID * 128);
+        const f32x4* wfw1 = pk4 + (RO_FW1 / 4) + wave * (T_RIN * 128);
+        const f32x4* wfw2 = pk4 + (RO_FW2 / 4) + wave * (T_HID * 128);
+        float bv[2] = {packed[RO_B6 + cb], packed[RO_B6 + cb + 32]};       // requested before the GEMM that needs them
         zero_acc(acc);
-        gemm_rows64<T_HID, LDR>(X, pk4 + (RO_FW6 / 4) + wave * (T_HID * 128), lane, acc);     // F_color.6 on the weighted mean
+        BFrag nf = gemm_rows64<T_HID, LDR>(X, wfw6, lane, acc, fr6, wfw1);     // F_color.6 on the weighted mean
         __syncthreads();
         {   // agg = acc + b6 (linear) into columns 0..255 of X (the dir-enc columns stay); kept for R.0's weight gradient
-            const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
-            const float bv[2] = {packed[RO_B6 + c0], packed[RO_B6 + c0 + 32]};
+            const int c0 = cb, h = lane >> 5;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -178,22 +181,25 @@ rhead_forward_kernel(const float* __restrict__ agg3, const float* __restrict__ r
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m * 32 + row_of(r, h);
-                        const float v = acc[m][n][r] + bv[n];
-                        X[row * LDR + c0 + 32 * n] = v;
-                        if (STORE) agg[tb + row * 256 + c0 + 32 * n] = v;
+                        X[row * LDR + c0 + 32 * n] = acc[m][n][r] + bv[n];
                     }
         }
         __syncthreads();
+        bv[0] = packed[RO_B1 + cb]; bv[1] = packed[RO_B1 + cb + 32];
+        if (STORE) store_tile_256<LDR>(X, agg + tb, tid);
         zero_acc(acc);
-        gemm_rows64<T_RIN, LDR>(X, pk4 + (RO_FW1 / 4) + wave * (T_RIN * 128), lane, acc);
+        nf = gemm_rows64<T_RIN, LDR>(X, wfw1, lane, acc, nf, wfw2);
         __syncthreads();
-        r_fwd_epilogue<STORE>(X, acc, packed + RO_B1, wave, lane, STORE ? act1 + tb : nullptr, mk);
+        r_fwd_epilogue<STORE>(X, acc, bv, wave, lane, mk);
         __syncthreads();
+        bv[0] = packed[RO_B2 + cb]; bv[1] = packed[RO_B2 + cb + 32];
+        if (STORE) store_tile_256<LDR>(X, act1 + tb, tid);
         zero_acc(acc);
-        gemm_rows64<T_HID, LDR>(X, pk4 + (RO_FW2 / 4) + wave * (T_HID * 128), lane, acc);
+        gemm_rows64<T_HID, LDR>(X, wfw2, lane, acc, nf, nullptr);
         __syncthreads();
-        r_fwd_epilogue<STORE>(X, acc, packed + RO_B2, wave, lane, STORE ? act2 + tb : nullptr, STORE ? mk + 512 : nullptr);
+        r_fwd_epilogue<STORE>(X, acc, bv, wave, lane, STORE ? mk + 512 : nullptr);
         __syncthreads();
+        if (STORE) store_tile_256<LDR>(X, act2 + tb, tid);
         {   // 256 -> 3 + sigmoid: 4 threads per row, interleaved float4 chunks
             const int row = tid >> 2, q4 = tid & 3;
             const f32x4* w3 = pk4 + RO_W3 / 4;
@@ -221,13 +227,13 @@ rhead_forward_kernel(const float* __restrict__ agg3, const float* __restrict__ r
 }
 
 // backward epilogue: G_l = g_a * lrelu'(h_l); write X and G_l, add the column sums to the bias gradient
-__device__ __forceinline__ void r_bwd_epilogue(float* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t* __restrict__ mask_g,
-                                               float* __restrict__ g_out, float* __restrict__ g_bias) {
+__device__ __forceinline__ void r_bwd_epilogue(float* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mbits)[2],
+                                               float* __restrict__ g_bias) {
     const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
     float cs[2] = {0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const uint32_t bits = mask_g[(wave * 2 + m) * 64 + lane];
+        const uint32_t bits = mbits[m];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -236,7 +242,6 @@ __device__ __forceinline__ void r_bwd_epilogue(float* X, const f32x16 (&acc)[2][
                 float v = acc[m][n][r];
                 v = ((bits >> (n * 16 + r)) & 1u) ? v : v * 0.01f;
                 X[row * LDR + c0 + 32 * n] = v;
-                g_out[row * 256 + c0 + 32 * n] = v;
                 cs[n] += v;
             }
     }
@@ -265,6 +270,7 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
         const float* packed = launder(packed0);
         const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
         const size_t tb = (size_t)tile * 64 * 256;
+        const BFrag fr2 = load_bfrag(pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane);     // in flight during the small last-layer stage
         if (tid < 64) {   // dL/d(pre-sigmoid) = g_c * c (1 - c)
             const int p = tile * 64 + tid;
             float g[3] = {0.f, 0.f, 0.f};
@@ -317,7 +323,6 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
                         float v = s_g3[row * 4] * w3[n][0] + s_g3[row * 4 + 1] * w3[n][1] + s_g3[row * 4 + 2] * w3[n][2];
                         v = ((bits >> (n * 16 + r)) & 1u) ? v : v * 0.01f;
                         X[row * LDR + c0 + 32 * n] = v;
-                        G2[tb + row * 256 + c0 + 32 * n] = v;
                         cs[n] += v;
                     }
             }
@@ -328,19 +333,23 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
             }
         }
         __syncthreads();
+        store_tile_256<LDR>(X, G2 + tb, tid);
         f32x16 acc[2][2];
+        const f32x4* wbwa = pk4 + (RO_BWA / 4) + wave * (T_HID * 128);
+        const f32x4* wbw6 = pk4 + (RO_BW6 / 4) + wave * (T_HID * 128);
+        const uint32_t mb1[2] = {mk[(wave * 2) * 64 + lane], mk[(wave * 2 + 1) * 64 + lane]};
         zero_acc(acc);
-        gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane, acc);
+        BFrag nf = gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane, acc, fr2, wbwa);
         __syncthreads();
-        r_bwd_epilogue(X, acc, wave, lane, mk, G1 + tb, g_b0);
+        r_bwd_epilogue(X, acc, wave, lane, mb1, g_b0);
         __syncthreads();
+        store_tile_256<LDR>(X, G1 + tb, tid);
         zero_acc(acc);
-        gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BWA / 4) + wave * (T_HID * 128), lane, acc);
+        nf = gemm_rows64<T_HID, LDR>(X, wbwa, lane, acc, nf, wbw6);
         __syncthreads();
         {   // g_agg[p][col] -> HBM (operand of F_color.6's weight gradient; padded to whole tiles: no bounds test) and X;
             // its column sums are F_color.6's bias gradient
             const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
-            float* ga = g_agg + tb + c0;
             float cs[2] = {0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -350,7 +359,6 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
                     for (int r = 0; r < 16; ++r) {
                         const int row = m * 32 + row_of(r, h);
                         const float v = acc[m][n][r];
-                        ga[row * 256 + 32 * n] = v;
                         X[row * LDR + c0 + 32 * n] = v;
                         cs[n] += v;
                     }
@@ -361,18 +369,21 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
             }
         }
         __syncthreads();
+        store_tile_256<LDR>(X, g_agg + tb, tid);
         zero_acc(acc);
-        gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW6 / 4) + wave * (T_HID * 128), lane, acc);     // g_agg3 = g_agg W6
+        gemm_rows64<T_HID, LDR>(X, wbw6, lane, acc, nf, nullptr);     // g_agg3 = g_agg W6
+        __syncthreads();
         {
             const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
-            float* ga = g_agg3 + tb + c0;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) ga[(m * 32 + row_of(r, h)) * 256 + 32 * n] = acc[m][n][r];
+                    for (int r = 0; r < 16; ++r) X[(m * 32 + row_of(r, h)) * LDR + c0 + 32 * n] = acc[m][n][r];
         }
+        __syncthreads();
+        store_tile_256<LDR>(X, g_agg3 + tb, tid);
         __syncthreads();
     }
 }
