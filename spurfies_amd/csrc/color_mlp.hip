@@ -148,21 +148,29 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
     const int ntiles = (NP + 63) / 64;
     const float* packed0 = packed;
+    // pair -> (point, slot row, neighbour) is a chain of three dependent reads: the NEXT tile's chain is walked one link per GEMM
+    // of the current tile (n_*), so none of it is exposed at the top of a tile
+    int n_p = -1, n_srow = 0, n_idx = -1;
+    {
+        const int q = blockIdx.x * 64 + (tid >> 2);
+        if (blockIdx.x < ntiles && q < NP) {
+            n_p = pair_point[q];
+            n_srow = point_slot ? point_slot[n_p] : n_p;
+            n_idx = nbr[(size_t)n_srow * k + (q - pair_off[n_p])];
+        }
+    }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const float* packed = launder(packed0);
         const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
         const BFrag fr1 = load_bfrag(pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128), lane);     // in flight during the gather
+        const int qn = (tile + (int)gridDim.x) * 64 + (tid >> 2);                          // this thread's row in the block's next tile
+        const bool has_next = tile + (int)gridDim.x < ntiles && qn < NP;
         // ---- gather: thread = (row, quarter): 16 latent floats each; quarter 0 also does posenc -----
         {
             const int row = tid >> 2, q4 = tid & 3;
             const int q = tile * 64 + row;
-            int idx = -1, srow = 0, p = -1;
-            if (q < NP) {
-                p = pair_point[q];
-                srow = point_slot ? point_slot[p] : p;
-                idx = nbr[(size_t)srow * k + (q - pair_off[p])];
-            }
+            const int idx = n_idx, srow = n_srow, p = n_p;
             f32x4 f[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) f[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -220,6 +228,7 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         const f32x4* wfw2 = pk4 + (CO_FW2 / 4) + wave * (T_HID * 128);
         const f32x4* wfw3 = pk4 + (CO_FW3 / 4) + wave * (T_HID * 128);
         float bv[2] = {packed[CO_B1 + cb], packed[CO_B1 + cb + 32]};
+        n_p = has_next ? pair_point[qn] : -1;
         f32x16 acc[2][2];
         zero_acc(acc);
         BFrag nf = gemm_rows64<T_CIN>(X, wfw1, lane, acc, fr1, wfw2);
@@ -227,6 +236,11 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         c_fwd_epilogue<STORE, true>(X, acc, bv, wave, lane, mk);
         __syncthreads();
         bv[0] = packed[CO_B2 + cb]; bv[1] = packed[CO_B2 + cb + 32];
+        int n_off = 0;
+        if (n_p >= 0) {
+            n_srow = point_slot ? point_slot[n_p] : n_p;
+            n_off = pair_off[n_p];
+        }
         if (STORE) store_tile_256(X, act1 + (size_t)tile * 64 * 256, tid);
         zero_acc(acc);
         nf = gemm_rows64<T_HID>(X, wfw2, lane, acc, nf, wfw3);
@@ -234,6 +248,7 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         c_fwd_epilogue<STORE, true>(X, acc, bv, wave, lane, STORE ? mk + 512 : nullptr);
         __syncthreads();
         bv[0] = packed[CO_B3 + cb]; bv[1] = packed[CO_B3 + cb + 32];
+        n_idx = n_p >= 0 ? nbr[(size_t)n_srow * k + (qn - n_off)] : -1;
         if (STORE) store_tile_256(X, act2 + (size_t)tile * 64 * 256, tid);
         zero_acc(acc);
         gemm_rows64<T_HID>(X, wfw3, lane, acc, nf, nullptr);
@@ -313,6 +328,17 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
     const int ntiles = (NP + 63) / 64;
     const float* packed0 = packed;
+    // the next tile's (point, weight) are fetched during the current tile; the neighbour index — only needed by the final
+    // latent scatter — is resolved link by link behind the current tile's GEMMs
+    int n_p = -1;
+    float n_w = 0.f;
+    {
+        const int q = blockIdx.x * 64 + (tid >> 2);
+        if (blockIdx.x < ntiles && q < NP) {
+            n_p = pair_point[q];
+            n_w = wn[q];
+        }
+    }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const float* packed = launder(packed0);
@@ -322,18 +348,12 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
         const BFrag fr3 = load_bfrag(pk4 + (CO_BW3 / 4) + wave * (T_HID * 128), lane);    // in flight during the gather
         const uint32_t mb3[2] = {mk[1024 + (wave * 2) * 64 + lane], mk[1024 + (wave * 2 + 1) * 64 + lane]};
         // ---- g_a3[row] = wn[row] * g_agg3[p]  (agg3 = sum_j wn_j a3_j) -------------------------------
+        const int qrow = tile * 64 + (tid >> 2);
+        const int p_cur = n_p;                       // fetched during the previous tile (or before the loop)
         {
             const int row = tid >> 2, q4 = tid & 3;
-            const int q = tile * 64 + row;
-            float w = 0.f;
-            int idx = -1, p = 0;
-            if (q < NP) {
-                p = pair_point[q];
-                const int srow = point_slot ? point_slot[p] : p;
-                idx = nbr[(size_t)srow * k + (q - pair_off[p])];
-                w = wn[q];
-            }
-            if (q4 == 0) s_idx[row] = idx;
+            const float w = n_w;
+            const int p = p_cur < 0 ? 0 : p_cur;
             const f32x4* ga = reinterpret_cast<const f32x4*>(g_agg3 + (size_t)p * 256);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -352,6 +372,17 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
         const f32x4* wbw2 = pk4 + (CO_BW2 / 4) + wave * (T_HID * 128);
         c_bwd_mask_inplace(X, wave, lane, mb3, g_b4);     // G3 = g_a3 * lrelu'(h3), in place
         __syncthreads();
+        int c_srow = 0, c_off = 0;
+        if (p_cur >= 0) {
+            c_srow = point_slot ? point_slot[p_cur] : p_cur;
+            c_off = pair_off[p_cur];
+        }
+        {
+            const int qn = (tile + (int)gridDim.x) * 64 + (tid >> 2);
+            const bool has_next = tile + (int)gridDim.x < ntiles && qn < NP;
+            n_p = has_next ? pair_point[qn] : -1;
+            n_w = has_next ? wn[qn] : 0.f;
+        }
         store_tile_256(X, G3 + tbase, tid);
         uint32_t mb[2] = {mk[512 + (wave * 2) * 64 + lane], mk[512 + (wave * 2 + 1) * 64 + lane]};   // sign bits: requested before the GEMM
         zero_acc(acc);
@@ -360,6 +391,7 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
         c_bwd_epilogue(X, acc, wave, lane, mb, g_b2);
         __syncthreads();
         store_tile_256(X, G2 + tbase, tid);
+        if ((tid & 3) == 0) s_idx[tid >> 2] = p_cur >= 0 ? nbr[(size_t)c_srow * k + (qrow - c_off)] : -1;   // read after two more barriers
         mb[0] = mk[(wave * 2) * 64 + lane]; mb[1] = mk[(wave * 2 + 1) * 64 + lane];
         zero_acc(acc);
         gemm_rows64<T_HID>(X, wbw2, lane, acc, nf, nullptr);

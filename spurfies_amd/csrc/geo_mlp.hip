@@ -108,21 +108,29 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
     const int ntiles = (NP + 63) / 64;
     const float* packed0 = packed;
+    // pair -> (point, slot row, neighbour) is a chain of three dependent reads: the NEXT tile's chain is walked one link per GEMM
+    // of the current tile (n_*), so none of it is exposed at the top of a tile
+    int n_p = -1, n_srow = 0, n_idx = -1;
+    {
+        const int q = blockIdx.x * 64 + (tid >> 2);
+        if (blockIdx.x < ntiles && q < NP) {
+            n_p = pair_point[q];
+            n_srow = point_slot ? point_slot[n_p] : n_p;
+            n_idx = nbr[(size_t)n_srow * k + (q - pair_off[n_p])];
+        }
+    }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const float* packed = launder(packed0);
         const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
         const BFrag fr1 = load_bfrag(pk4 + (OFF_FW1 / 4) + wave * (T_IN * 128), lane);     // in flight during the gather
+        const int qn = (tile + (int)gridDim.x) * 64 + (tid >> 2);                          // this thread's row in the block's next tile
+        const bool has_next = tile + (int)gridDim.x < ntiles && qn < NP;
         // ---- gather: thread = (row, quarter of the 32-d latent) ---------------------------------
         {
             const int row = tid >> 2, q4 = tid & 3;
             const int q = tile * 64 + row;
-            int idx = -1, srow = 0;
-            if (q < NP) {
-                const int p = pair_point[q];
-                srow = point_slot ? point_slot[p] : p;
-                idx = nbr[(size_t)srow * k + (q - pair_off[p])];
-            }
+            const int idx = n_idx, srow = n_srow;
             f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0;
             if (idx >= 0) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(feat_geo + (size_t)idx * SPF_GEO_DIM + q4 * 8);
@@ -161,18 +169,25 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
         const f32x4* wbw3 = pk4 + (OFF_BW3 / 4) + wave * (T_HID * 128);
         const f32x4* wbw2 = pk4 + (OFF_BW2 / 4) + wave * (T_HID * 128);
         float bv[2] = {packed[OFF_B1 + cb], packed[OFF_B1 + cb + 32]};
+        n_p = has_next ? pair_point[qn] : -1;
         zero_acc(acc);
         BFrag nf = gemm_rows64<T_IN>(X, wfw1, lane, acc, fr1, wfw2);
         __syncthreads();
         fwd_epilogue(X, acc, bv, wave, lane, m1);
         __syncthreads();
         bv[0] = packed[OFF_B2 + cb]; bv[1] = packed[OFF_B2 + cb + 32];
+        int n_off = 0;
+        if (n_p >= 0) {
+            n_srow = point_slot ? point_slot[n_p] : n_p;
+            n_off = pair_off[n_p];
+        }
         zero_acc(acc);
         nf = gemm_rows64<T_HID>(X, wfw2, lane, acc, nf, wfw3);
         __syncthreads();
         fwd_epilogue(X, acc, bv, wave, lane, m2);
         __syncthreads();
         bv[0] = packed[OFF_B3 + cb]; bv[1] = packed[OFF_B3 + cb + 32];
+        n_idx = n_p >= 0 ? nbr[(size_t)n_srow * k + (qn - n_off)] : -1;
         zero_acc(acc);
         nf = gemm_rows64<T_HID>(X, wfw3, lane, acc, nf, wfw4);
         __syncthreads();
