@@ -133,6 +133,26 @@ __device__ __forceinline__ void c_fwd_epilogue(float* X, const f32x16 (&acc)[2][
     }
 }
 
+// Phase timing for tools/phase_times.py (build with SPF_EXTRA_HIPCC_FLAGS=-DSPF_TIMING): thread 0 of every workgroup sums the
+// shader-clock cycles it spends between consecutive marks; never compiled into the product library.
+#ifdef SPF_TIMING
+__device__ unsigned long long spf_timing_buf[16];
+#define T_DECL unsigned long long tacc[16] = {}; unsigned long long tlast = __builtin_readcyclecounter();
+#define T_MARK(i)                                                  \
+    if (tid == 0) {                                                \
+        const unsigned long long now = __builtin_readcyclecounter(); \
+        tacc[i] += now - tlast;                                    \
+        tlast = now;                                               \
+    }
+#define T_FLUSH                                                    \
+    if (tid == 0)                                                  \
+        for (int i = 0; i < 16; ++i) atomicAdd(&spf_timing_buf[i], tacc[i]);
+#else
+#define T_DECL
+#define T_MARK(i)
+#define T_FLUSH
+#endif
+
 template <bool STORE>
 __global__ void __launch_bounds__(256, 2)
 color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
@@ -140,7 +160,11 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
                      const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k, const float* __restrict__ pts,
                      const float* __restrict__ feat_col, const float* packed, float* __restrict__ agg3, float* __restrict__ act0,
                      float* __restrict__ act1, float* __restrict__ act2, uint32_t* __restrict__ masks) {
+#ifdef SPF_SOLO
+    __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL + 8000];     // experiment: one workgroup per CU
+#else
     __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL];
+#endif
     float* X = smem + CL_X;
     int* s_p = reinterpret_cast<int*>(smem + CL_P);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -159,11 +183,13 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
             n_idx = nbr[(size_t)n_srow * k + (q - pair_off[n_p])];
         }
     }
+    T_DECL
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const float* packed = launder(packed0);
-        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+        gfp packed = launder(packed0);
+        gf4p pk4 = reinterpret_cast<gf4p>(packed);
         const BFrag fr1 = load_bfrag(pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128), lane);     // in flight during the gather
+        T_MARK(15)
         const int qn = (tile + (int)gridDim.x) * 64 + (tid >> 2);                          // this thread's row in the block's next tile
         const bool has_next = tile + (int)gridDim.x < ntiles && qn < NP;
         // ---- gather: thread = (row, quarter): 16 latent floats each; quarter 0 also does posenc -----
@@ -213,7 +239,9 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
                 }
             }
         }
+        T_MARK(0)
         __syncthreads();
+        T_MARK(1)
         if (STORE) {  // layer-1 input [64][104] -> act0 (coalesced float4 copy out of LDS)
             float* dst = act0 + (size_t)tile * 64 * C_INP;
             for (int e4 = tid; e4 < 64 * (C_INP / 4); e4 += 256) {
@@ -224,17 +252,21 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         uint32_t* mk = STORE ? masks + (size_t)tile * 3 * 512 : nullptr;   // [layer 3][wave 4][m 2][lane 64]
         // bias values are requested before each GEMM, the next layer's first weight fragment inside it (mlp_tile.h)
         const int cb = wave * 64 + (lane & 31);
-        const f32x4* wfw1 = pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128);
-        const f32x4* wfw2 = pk4 + (CO_FW2 / 4) + wave * (T_HID * 128);
-        const f32x4* wfw3 = pk4 + (CO_FW3 / 4) + wave * (T_HID * 128);
+        gf4p wfw1 = pk4 + (CO_FW1 / 4) + wave * (T_CIN * 128);
+        gf4p wfw2 = pk4 + (CO_FW2 / 4) + wave * (T_HID * 128);
+        gf4p wfw3 = pk4 + (CO_FW3 / 4) + wave * (T_HID * 128);
         float bv[2] = {packed[CO_B1 + cb], packed[CO_B1 + cb + 32]};
         n_p = has_next ? pair_point[qn] : -1;
         f32x16 acc[2][2];
         zero_acc(acc);
         BFrag nf = gemm_rows64<T_CIN>(X, wfw1, lane, acc, fr1, wfw2);
+        T_MARK(2)
         __syncthreads();
+        T_MARK(3)
         c_fwd_epilogue<STORE, true>(X, acc, bv, wave, lane, mk);
+        T_MARK(4)
         __syncthreads();
+        T_MARK(5)
         bv[0] = packed[CO_B2 + cb]; bv[1] = packed[CO_B2 + cb + 32];
         int n_off = 0;
         if (n_p >= 0) {
@@ -244,20 +276,30 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         if (STORE) store_tile_256(X, act1 + (size_t)tile * 64 * 256, tid);
         zero_acc(acc);
         nf = gemm_rows64<T_HID>(X, wfw2, lane, acc, nf, wfw3);
+        T_MARK(6)
         __syncthreads();
+        T_MARK(7)
         c_fwd_epilogue<STORE, true>(X, acc, bv, wave, lane, STORE ? mk + 512 : nullptr);
+        T_MARK(8)
         __syncthreads();
+        T_MARK(9)
         bv[0] = packed[CO_B3 + cb]; bv[1] = packed[CO_B3 + cb + 32];
         n_idx = n_p >= 0 ? nbr[(size_t)n_srow * k + (qn - n_off)] : -1;
         if (STORE) store_tile_256(X, act2 + (size_t)tile * 64 * 256, tid);
         zero_acc(acc);
         gemm_rows64<T_HID>(X, wfw3, lane, acc, nf, nullptr);
+        T_MARK(10)
         __syncthreads();
+        T_MARK(11)
         c_fwd_epilogue<STORE, true>(X, acc, bv, wave, lane, STORE ? mk + 1024 : nullptr);
         __syncthreads();
+        T_MARK(12)
         seg_reduce_rows(X, smem + CL_W, s_p, tid, agg3);   // agg3[p] = sum_j wn_j a3_j; the linear F_color.6 follows per point
+        T_MARK(13)
         __syncthreads();
+        T_MARK(14)
     }
+    T_FLUSH
 }
 
 // backward epilogue: G_l = g_a * lrelu'(h_l) with the sign bits the forward recorded; write X and G_l (operand of the
@@ -341,8 +383,8 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
     }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const float* packed = launder(packed0);
-        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+        gfp packed = launder(packed0);
+        gf4p pk4 = reinterpret_cast<gf4p>(packed);
         const size_t tbase = (size_t)tile * 64 * 256;
         const uint32_t* mk = masks + (size_t)tile * 3 * 512;
         const BFrag fr3 = load_bfrag(pk4 + (CO_BW3 / 4) + wave * (T_HID * 128), lane);    // in flight during the gather
@@ -368,8 +410,8 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
         }
         __syncthreads();
         f32x16 acc[2][2];
-        const f32x4* wbw3 = pk4 + (CO_BW3 / 4) + wave * (T_HID * 128);
-        const f32x4* wbw2 = pk4 + (CO_BW2 / 4) + wave * (T_HID * 128);
+        gf4p wbw3 = pk4 + (CO_BW3 / 4) + wave * (T_HID * 128);
+        gf4p wbw2 = pk4 + (CO_BW2 / 4) + wave * (T_HID * 128);
         c_bwd_mask_inplace(X, wave, lane, mb3, g_b4);     // G3 = g_a3 * lrelu'(h3), in place
         __syncthreads();
         int c_srow = 0, c_off = 0;
@@ -406,7 +448,7 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) aj[r] = 0.f;
             const float* ap = X + (mt * 32 + i) * LDA + 4 * h;
-            const f32x4* bp = pk4 + (CO_BWL / 4) + nt * (T_HID * 64) + lane;
+            gf4p bp = pk4 + (CO_BWL / 4) + nt * (T_HID * 64) + lane;
 #pragma unroll 4
             for (int t = 0; t < T_HID; ++t) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * t);
@@ -428,6 +470,17 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
 }  // namespace
 
 extern "C" {
+
+#ifdef SPF_TIMING
+int spf_debug_timing(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(spf_timing_buf), 16 * sizeof(unsigned long long)) != hipSuccess) return SPF_EHIP;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(spf_timing_buf), z, sizeof(z)) != hipSuccess) return SPF_EHIP;
+    }
+    return SPF_OK;
+}
+#endif
 
 int64_t spf_color_packed_floats(void) { return C_PACKED; }
 

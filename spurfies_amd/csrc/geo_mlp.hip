@@ -121,8 +121,8 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
     }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const float* packed = launder(packed0);
-        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+        gfp packed = launder(packed0);
+        gf4p pk4 = reinterpret_cast<gf4p>(packed);
         const BFrag fr1 = load_bfrag(pk4 + (OFF_FW1 / 4) + wave * (T_IN * 128), lane);     // in flight during the gather
         const int qn = (tile + (int)gridDim.x) * 64 + (tid >> 2);                          // this thread's row in the block's next tile
         const bool has_next = tile + (int)gridDim.x < ntiles && qn < NP;
@@ -161,13 +161,13 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
         // each layer's bias values are requested before its GEMM and the next layer's first weight fragment inside it, so
         // neither L2 round trip is exposed between the barriers
         const int cb = wave * 64 + (lane & 31);
-        const f32x4* wfw1 = pk4 + (OFF_FW1 / 4) + wave * (T_IN * 128);
-        const f32x4* wfw2 = pk4 + (OFF_FW2 / 4) + wave * (T_HID * 128);
-        const f32x4* wfw3 = pk4 + (OFF_FW3 / 4) + wave * (T_HID * 128);
-        const f32x4* wfw4 = pk4 + (OFF_FW4 / 4) + wave * (T_HID * 128);
-        const f32x4* wbw4 = pk4 + (OFF_BW4 / 4) + wave * (T_HID * 128);
-        const f32x4* wbw3 = pk4 + (OFF_BW3 / 4) + wave * (T_HID * 128);
-        const f32x4* wbw2 = pk4 + (OFF_BW2 / 4) + wave * (T_HID * 128);
+        gf4p wfw1 = pk4 + (OFF_FW1 / 4) + wave * (T_IN * 128);
+        gf4p wfw2 = pk4 + (OFF_FW2 / 4) + wave * (T_HID * 128);
+        gf4p wfw3 = pk4 + (OFF_FW3 / 4) + wave * (T_HID * 128);
+        gf4p wfw4 = pk4 + (OFF_FW4 / 4) + wave * (T_HID * 128);
+        gf4p wbw4 = pk4 + (OFF_BW4 / 4) + wave * (T_HID * 128);
+        gf4p wbw3 = pk4 + (OFF_BW3 / 4) + wave * (T_HID * 128);
+        gf4p wbw2 = pk4 + (OFF_BW2 / 4) + wave * (T_HID * 128);
         float bv[2] = {packed[OFF_B1 + cb], packed[OFF_B1 + cb + 32]};
         n_p = has_next ? pair_point[qn] : -1;
         zero_acc(acc);
@@ -204,7 +204,7 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
         // ---- sdf_j = v . a4 + c : 4 threads per row, interleaved float4 chunks ------------------
         {
             const int row = tid >> 2, q4 = tid & 3;
-            const f32x4* v4 = pk4 + OFF_V5 / 4;
+            gf4p v4 = pk4 + OFF_V5 / 4;
             float s = 0.f;
 #pragma unroll
             for (int mth = 0; mth < 16; ++mth) {
@@ -257,7 +257,7 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) aj[r] = 0.f;
                 const float* ap = X + (mt * 32 + i) * LDA + 4 * h;
-                const f32x4* bp = pk4 + (OFF_JW1 / 4) + nt * (T_HID * 64) + lane;
+                gf4p bp = pk4 + (OFF_JW1 / 4) + nt * (T_HID * 64) + lane;
 #pragma unroll 4
                 for (int t = 0; t < T_HID; ++t) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * t);

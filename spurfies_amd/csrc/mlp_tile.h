@@ -12,12 +12,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDA = 260;     // LDS row stride in floats (1040 B: 16-B aligned, breaks the 256-B bank period)
 constexpr int T_HID = 32;    // 256/8
 
+// Pointers into the packed weight image keep their GLOBAL address space: a generic pointer makes hipcc emit flat_load, which
+// counts on both vmcnt and lgkmcnt and forces a full `s_waitcnt vmcnt(0) lgkmcnt(0)` drain in every k-step of the GEMM loop.
+typedef const __attribute__((address_space(1))) float* gfp;
+typedef const __attribute__((address_space(1))) f32x4* gf4p;
+
 // Re-materialise a (wave-uniform) pointer inside the persistent tile loop: keeps hipcc from hoisting the loop-invariant
 // weight / bias loads of one tile iteration out of the loop and parking them in > 100 VGPRs (spills).
-template <typename T>
-__device__ __forceinline__ const T* launder(const T* p) {
+__device__ __forceinline__ gfp launder(const float* p) {
     asm volatile("" : "+s"(p));
-    return p;
+    return (gfp)p;
 }
 
 __device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -27,7 +31,7 @@ __device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >>
 struct BFrag {
     f32x4 b0, b1;
 };
-__device__ __forceinline__ BFrag load_bfrag(const f32x4* wp, int lane) {
+__device__ __forceinline__ BFrag load_bfrag(gf4p wp, int lane) {
     BFrag f;
     f.b0 = wp[lane];
     f.b1 = wp[lane + 64];
@@ -37,12 +41,11 @@ __device__ __forceinline__ BFrag load_bfrag(const f32x4* wp, int lane) {
 // acc[mt][nt] += X[mt*32.., :] * B  for this wave's 64 output columns.  wp: [T][2][64] float4.  LD = LDS row stride.
 // `first` = this layer's k-step-0 fragment (load_bfrag(wp)); returns the k-step-0 fragment of `next_wp` (or `first`).
 template <int T, int LD = LDA>
-__device__ __forceinline__ BFrag gemm_rows64(const float* X, const f32x4* wp, int lane, f32x16 (&acc)[2][2], BFrag first,
-                                             const f32x4* next_wp) {
+__device__ __forceinline__ BFrag gemm_rows64(const float* X, gf4p wp, int lane, f32x16 (&acc)[2][2], BFrag first, gf4p next_wp) {
     const int i = lane & 31, h = lane >> 5;
     const float* a0p = X + i * LD + 4 * h;
     const float* a1p = a0p + 32 * LD;
-    const f32x4* bp = wp + lane;
+    gf4p bp = wp + lane;
     f32x4 b0 = first.b0, b1 = first.b1;
     BFrag nxt = first;
     constexpr int T_PRE = T > 4 ? T - 4 : 0;
@@ -71,7 +74,7 @@ __device__ __forceinline__ BFrag gemm_rows64(const float* X, const f32x4* wp, in
 
 // stand-alone form: fetches its own first fragment (latency exposed)
 template <int T, int LD = LDA>
-__device__ __forceinline__ void gemm_rows64(const float* X, const f32x4* wp, int lane, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void gemm_rows64(const float* X, gf4p wp, int lane, f32x16 (&acc)[2][2]) {
     gemm_rows64<T, LD>(X, wp, lane, acc, load_bfrag(wp, lane), nullptr);
 }
 

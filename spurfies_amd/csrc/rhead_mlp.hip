@@ -114,8 +114,8 @@ rhead_forward_kernel(const float* __restrict__ agg3, const float* __restrict__ r
     const float* packed0 = packed;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const float* packed = launder(packed0);
-        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+        gfp packed = launder(packed0);
+        gf4p pk4 = reinterpret_cast<gf4p>(packed);
         const BFrag fr6 = load_bfrag(pk4 + (RO_FW6 / 4) + wave * (T_HID * 128), lane);     // in flight during the gather
         {   // gather: thread = (row, quarter): 64 agg3 floats each; quarter 0 also encodes the view direction
             const int row = tid >> 2, q4 = tid & 3;
@@ -165,9 +165,9 @@ rhead_forward_kernel(const float* __restrict__ agg3, const float* __restrict__ r
         uint32_t* mk = STORE ? masks + (size_t)tile * 2 * 512 : nullptr;
         f32x16 acc[2][2];
         const int cb = wave * 64 + (lane & 31);
-        const f32x4* wfw6 = pk4 + (RO_FW6 / 4) + wave * (T_HID * 128);
-        const f32x4* wfw1 = pk4 + (RO_FW1 / 4) + wave * (T_RIN * 128);
-        const f32x4* wfw2 = pk4 + (RO_FW2 / 4) + wave * (T_HID * 128);
+        gf4p wfw6 = pk4 + (RO_FW6 / 4) + wave * (T_HID * 128);
+        gf4p wfw1 = pk4 + (RO_FW1 / 4) + wave * (T_RIN * 128);
+        gf4p wfw2 = pk4 + (RO_FW2 / 4) + wave * (T_HID * 128);
         float bv[2] = {packed[RO_B6 + cb], packed[RO_B6 + cb + 32]};       // requested before the GEMM that needs them
         zero_acc(acc);
         BFrag nf = gemm_rows64<T_HID, LDR>(X, wfw6, lane, acc, fr6, wfw1);     // F_color.6 on the weighted mean
@@ -202,7 +202,7 @@ rhead_forward_kernel(const float* __restrict__ agg3, const float* __restrict__ r
         if (STORE) store_tile_256<LDR>(X, act2 + tb, tid);
         {   // 256 -> 3 + sigmoid: 4 threads per row, interleaved float4 chunks
             const int row = tid >> 2, q4 = tid & 3;
-            const f32x4* w3 = pk4 + RO_W3 / 4;
+            gf4p w3 = pk4 + RO_W3 / 4;
             float s[3] = {0.f, 0.f, 0.f};
 #pragma unroll 2
             for (int mth = 0; mth < 16; ++mth) {
@@ -267,8 +267,8 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
     const float* packed0 = packed;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const float* packed = launder(packed0);
-        const f32x4* pk4 = reinterpret_cast<const f32x4*>(packed);
+        gfp packed = launder(packed0);
+        gf4p pk4 = reinterpret_cast<gf4p>(packed);
         const size_t tb = (size_t)tile * 64 * 256;
         const BFrag fr2 = load_bfrag(pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane);     // in flight during the small last-layer stage
         if (tid < 64) {   // dL/d(pre-sigmoid) = g_c * c (1 - c)
@@ -335,8 +335,8 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
         __syncthreads();
         store_tile_256<LDR>(X, G2 + tb, tid);
         f32x16 acc[2][2];
-        const f32x4* wbwa = pk4 + (RO_BWA / 4) + wave * (T_HID * 128);
-        const f32x4* wbw6 = pk4 + (RO_BW6 / 4) + wave * (T_HID * 128);
+        gf4p wbwa = pk4 + (RO_BWA / 4) + wave * (T_HID * 128);
+        gf4p wbw6 = pk4 + (RO_BW6 / 4) + wave * (T_HID * 128);
         const uint32_t mb1[2] = {mk[(wave * 2) * 64 + lane], mk[(wave * 2 + 1) * 64 + lane]};
         zero_acc(acc);
         BFrag nf = gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane, acc, fr2, wbwa);
