@@ -46,19 +46,34 @@ __device__ __forceinline__ BFrag gemm_rows64(const float* X, gf4p wp, int lane, 
     const float* a0p = X + i * LD + 4 * h;
     const float* a1p = a0p + 32 * LD;
     gf4p bp = wp + lane;
+    // weight fragments are requested TWO k-steps ahead (a k-step is 16 MFMAs = 1024 cycles, less than a loaded L2 round trip when
+    // the wave has the matrix pipe to itself), the LDS operand one k-step ahead
     f32x4 b0 = first.b0, b1 = first.b1;
+    f32x4 c0 = b0, c1 = b1;
+    if (T > 1) {
+        c0 = bp[128];
+        c1 = bp[128 + 64];
+    }
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p);
+    f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p);
     BFrag nxt = first;
     constexpr int T_PRE = T > 4 ? T - 4 : 0;
 #pragma unroll 4
     for (int t = 0; t < T; ++t) {
-        f32x4 nb0 = b0, nb1 = b1;
-        if (t + 1 < T) {
-            nb0 = bp[(t + 1) * 128];
-            nb1 = bp[(t + 1) * 128 + 64];
+        f32x4 d0 = c0, d1 = c1;
+        if (t + 2 < T) {
+            d0 = bp[(t + 2) * 128];
+            d1 = bp[(t + 2) * 128 + 64];
         }
         if (t == T_PRE && next_wp) nxt = load_bfrag(next_wp, lane);
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + 8 * t);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 8 * t);
+        f32x4 na0 = a0, na1 = a1;
+        if (t + 1 < T) {
+            na0 = *reinterpret_cast<const f32x4*>(a0p + 8 * (t + 1));
+            na1 = *reinterpret_cast<const f32x4*>(a1p + 8 * (t + 1));
+        }
+        // pin the order [requests for later k-steps | this k-step's 16 MFMAs]: left alone, the scheduler sinks the requests
+        // to just before their use and then has to wait for the youngest load in every k-step (vmcnt(0))
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
@@ -66,8 +81,10 @@ __device__ __forceinline__ BFrag gemm_rows64(const float* X, gf4p wp, int lane, 
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
         }
-        b0 = nb0;
-        b1 = nb1;
+        __builtin_amdgcn_sched_barrier(0);
+        b0 = c0; b1 = c1;
+        c0 = d0; c1 = d1;
+        a0 = na0; a1 = na1;
     }
     return nxt;
 }
