@@ -47,27 +47,8 @@ constexpr int CO_B3 = CO_B2 + 256;
 constexpr int C_PACKED = CO_B3 + 256;
 
 constexpr int CL_X = 0;
-constexpr int CL_W = CL_X + 64 * LDA;   // per-row normalised RBF weight
-constexpr int CL_P = CL_W + 64;         // per-row compact point id (int bits), -1 for padding rows
-constexpr int CL_TOTAL = CL_P + 64;
-
-// out[p, c] += sum over the tile's rows of point p of w_row * X[row][c]; thread = column.  Rows of a point are
-// consecutive (pairs are grouped by point); a point straddling two tiles receives two atomic adds (commutative,
-// so the result does not depend on their order).
-__device__ __forceinline__ void seg_reduce_rows(const float* X, const float* s_w, const int* s_p, int c, float* __restrict__ out) {
-    int cur = s_p[0];
-    float a = 0.f;
-    for (int row = 0; row < 64; ++row) {
-        const int p = s_p[row];
-        if (p != cur) {
-            if (cur >= 0) atomicAdd(&out[(size_t)cur * 256 + c], a);
-            cur = p;
-            a = 0.f;
-        }
-        a += s_w[row] * X[row * LDA + c];
-    }
-    if (cur >= 0) atomicAdd(&out[(size_t)cur * 256 + c], a);
-}
+constexpr int CL_W = CL_X + 64 * LDA;   // forward: per row {normalised RBF weight, compact point id bits (-1 = padding)}; backward: neighbour ids
+constexpr int CL_TOTAL = CL_W + 128;
 
 // ---- pack ------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ int c_orig(int k) { return k < 64 ? 39 + k : k - 64; }
@@ -133,6 +114,53 @@ __device__ __forceinline__ void c_fwd_epilogue(float* X, const f32x16 (&acc)[2][
     }
 }
 
+// Last activated layer: + bias, LeakyReLU (sign bits recorded), and the RBF-weighted sum over each point's rows taken straight
+// from the accumulators — a lane holds two columns x 32 of the tile's 64 rows (the other 32 sit in lane ^ 32), in ascending row
+// order, and a point's rows are consecutive, so each lane runs its own segmented sum and flushes one atomic add per (point,
+// column) it has seen.  No activation tile is written, no barrier, no serial pass over 64 LDS rows per column.
+template <bool STORE>
+__device__ __forceinline__ void c_fwd_epilogue_reduce(const f32x16 (&acc)[2][2], const float (&bv)[2], int wave, int lane,
+                                                      uint32_t* mask_g, const float* s_wp /* [64][2] = {weight, point id bits} */,
+                                                      float* __restrict__ out) {
+    const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+    int cur = -1;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // keep the row bookkeeping reads from being hoisted en bloc (spills)
+            const int row = m * 32 + row_of(r, h);
+            const float2 wp = *reinterpret_cast<const float2*>(s_wp + 2 * row);
+            const int p = __float_as_int(wp.y);
+            const float w = wp.x;
+            float v0 = acc[m][0][r] + bv[0], v1 = acc[m][1][r] + bv[1];
+            const bool p0 = v0 > 0.f, p1 = v1 > 0.f;
+            bits |= (p0 ? 1u : 0u) << r;
+            bits |= (p1 ? 1u : 0u) << (16 + r);
+            v0 = p0 ? v0 : v0 * 0.01f;
+            v1 = p1 ? v1 : v1 * 0.01f;
+            if (p != cur) {
+                if (cur >= 0) {
+                    atomicAdd(&out[(size_t)cur * 256 + c0], a0);
+                    atomicAdd(&out[(size_t)cur * 256 + c0 + 32], a1);
+                }
+                cur = p;
+                a0 = 0.f;
+                a1 = 0.f;
+            }
+            a0 += w * v0;
+            a1 += w * v1;
+        }
+        if (STORE && mask_g) mask_g[(wave * 2 + m) * 64 + lane] = bits;
+    }
+    if (cur >= 0) {
+        atomicAdd(&out[(size_t)cur * 256 + c0], a0);
+        atomicAdd(&out[(size_t)cur * 256 + c0 + 32], a1);
+    }
+}
+
 // Phase timing for tools/phase_times.py (build with SPF_EXTRA_HIPCC_FLAGS=-DSPF_TIMING): thread 0 of every workgroup sums the
 // shader-clock cycles it spends between consecutive marks; never compiled into the product library.
 #ifdef SPF_TIMING
@@ -166,7 +194,6 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
     __shared__ __attribute__((aligned(16))) float smem[CL_TOTAL];
 #endif
     float* X = smem + CL_X;
-    int* s_p = reinterpret_cast<int*>(smem + CL_P);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
@@ -234,8 +261,8 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
                 if (q4 == 0) {
                     e[0] = d[0]; e[1] = d[1]; e[2] = d[2];
                     e[39] = 0.f;                      // pad column 103
-                    smem[CL_W + row] = idx >= 0 ? wn[q] : 0.f;
-                    s_p[row] = idx >= 0 ? p : -1;
+                    smem[CL_W + 2 * row] = idx >= 0 ? wn[q] : 0.f;                 // {weight, point id} per row, read by the last epilogue
+                    smem[CL_W + 2 * row + 1] = __int_as_float(idx >= 0 ? p : -1);
                 }
             }
         }
@@ -289,14 +316,10 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         zero_acc(acc);
         gemm_rows64<T_HID>(X, wfw3, lane, acc, nf, nullptr);
         T_MARK(10)
-        __syncthreads();
-        T_MARK(11)
-        c_fwd_epilogue<STORE, true>(X, acc, bv, wave, lane, STORE ? mk + 1024 : nullptr);
-        __syncthreads();
-        T_MARK(12)
-        seg_reduce_rows(X, smem + CL_W, s_p, tid, agg3);   // agg3[p] = sum_j wn_j a3_j; the linear F_color.6 follows per point
+        // agg3[p] = sum_j wn_j a3_j straight from the accumulators; the linear F_color.6 follows per point (rhead_mlp.hip)
+        c_fwd_epilogue_reduce<STORE>(acc, bv, wave, lane, STORE ? mk + 1024 : nullptr, smem + CL_W, agg3);
         T_MARK(13)
-        __syncthreads();
+        __syncthreads();       // X, s_w, s_p are rewritten by the next tile's gather
         T_MARK(14)
     }
     T_FLUSH

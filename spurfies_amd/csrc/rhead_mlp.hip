@@ -315,16 +315,18 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const uint32_t bits = mk[512 + (wave * 2 + m) * 64 + lane];
+#pragma unroll 4
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m * 32 + row_of(r, h);
+                    const f32x4 g3 = *reinterpret_cast<const f32x4*>(s_g3 + row * 4);       // one LDS read per row, both column halves
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = m * 32 + row_of(r, h);
-                        float v = s_g3[row * 4] * w3[n][0] + s_g3[row * 4 + 1] * w3[n][1] + s_g3[row * 4 + 2] * w3[n][2];
+                    for (int n = 0; n < 2; ++n) {
+                        float v = g3[0] * w3[n][0] + g3[1] * w3[n][1] + g3[2] * w3[n][2];
                         v = ((bits >> (n * 16 + r)) & 1u) ? v : v * 0.01f;
                         X[row * LDR + c0 + 32 * n] = v;
                         cs[n] += v;
                     }
+                }
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {

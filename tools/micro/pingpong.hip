@@ -1,0 +1,108 @@
+// Scheduling experiment (not part of the library): a layer = [GEMM over 32 k-steps | epilogue that rewrites the activation tile].
+//   A) two independent 4-wave workgroups per CU, each: GEMM, barrier, epilogue, barrier   (the tile engine's structure)
+//   B) one 8-wave workgroup, two 4-wave groups one stage apart: while one group runs its GEMM the other runs its epilogue;
+//      a workgroup barrier ends every stage
+// hipcc --offload-arch=gfx950 -O3 pingpong.hip -o pingpong
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4* gf4p;
+constexpr int LDA = 260;
+
+__device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ void gemm(const float* X, gf4p wp, int lane, f32x16 (&acc)[2][2]) {
+    const int i = lane & 31, h = lane >> 5;
+    const float* a0p = X + i * LDA + 4 * h;
+    const float* a1p = a0p + 32 * LDA;
+    gf4p bp = wp + lane;
+    f32x4 b0 = bp[0], b1 = bp[64], c0 = bp[128], c1 = bp[192];
+    f32x4 a0 = *(const f32x4*)a0p, a1 = *(const f32x4*)a1p;
+#pragma unroll 4
+    for (int t = 0; t < 32; ++t) {
+        f32x4 d0 = c0, d1 = c1, na0 = a0, na1 = a1;
+        if (t + 2 < 32) { d0 = bp[(t + 2) * 128]; d1 = bp[(t + 2) * 128 + 64]; }
+        if (t + 1 < 32) { na0 = *(const f32x4*)(a0p + 8 * (t + 1)); na1 = *(const f32x4*)(a1p + 8 * (t + 1)); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        b0 = c0; b1 = c1; c0 = d0; c1 = d1; a0 = na0; a1 = na1;
+    }
+}
+
+__device__ __forceinline__ void epilogue(float* X, f32x16 (&acc)[2][2], int wave, int lane) {
+    const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[m][n][r] * 1e-3f + 0.01f;
+                v = v > 0.f ? v : v * 0.01f;
+                X[(m * 32 + row_of(r, h)) * LDA + c0 + 32 * n] = v;
+                acc[m][n][r] = 0.f;
+            }
+}
+
+__global__ void __launch_bounds__(256, 2) kA(const float* w, float* out, int layers) {
+    __shared__ __attribute__((aligned(16))) float X[64 * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < 64 * LDA; e += 256) X[e] = 0.001f * (e & 127);
+    __syncthreads();
+    f32x16 acc[2][2] = {};
+    for (int l = 0; l < layers; ++l) {
+        gemm(X, (gf4p)w + ((l & 3) * 4 + wave) * (32 * 128), lane, acc);
+        __syncthreads();
+        epilogue(X, acc, wave, lane);
+        __syncthreads();
+    }
+    out[blockIdx.x * 256 + tid] = X[tid];
+}
+
+__global__ void __launch_bounds__(512, 1) kB(const float* w, float* out, int layers) {
+    __shared__ __attribute__((aligned(16))) float XX[2][64 * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, grp = wave8 >> 2, wave = wave8 & 3;
+    float* X = XX[grp];
+    for (int e = tid & 255; e < 64 * LDA; e += 256) X[e] = 0.001f * (e & 127);
+    __syncthreads();
+    f32x16 acc[2][2] = {};
+    // group 0: G E G E ...   group 1: (idle) G E G E ...: stage s -> group g runs GEMM when (s + g) is even
+    for (int s = 0; s < 2 * layers + 1; ++s) {
+        const int ls = s - grp;                // this group's own stage counter
+        if (ls >= 0 && ls < 2 * layers) {
+            if ((ls & 1) == 0) gemm(X, (gf4p)w + (((ls >> 1) & 3) * 4 + wave) * (32 * 128), lane, acc);
+            else epilogue(X, acc, wave, lane);
+        }
+        __syncthreads();
+    }
+    out[blockIdx.x * 512 + tid] = X[tid & 255];
+}
+
+int main() {
+    float *w, *out;
+    const size_t wbytes = 16ull * 32 * 128 * 16;
+    (void)hipMalloc(&w, wbytes); (void)hipMemset(w, 0, wbytes);
+    (void)hipMalloc(&out, 4096 * 512 * 4);
+    const int layers = 600;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+        float ms;
+        kA<<<512, 256>>>(w, out, layers);
+        (void)hipEventRecord(e0); kA<<<512, 256>>>(w, out, layers); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("A two 4-wave workgroups/CU, in-phase : %.3f ms  %.1f TFLOP/s\n", ms, 512.0 * layers * 64 * 256 * 256 * 2 / (ms * 1e-3) / 1e12);
+        kB<<<256, 512>>>(w, out, layers);
+        (void)hipEventRecord(e0); kB<<<256, 512>>>(w, out, layers); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("B one 8-wave workgroup, stage-shifted : %.3f ms  %.1f TFLOP/s\n", ms, 512.0 * layers * 64 * 256 * 256 * 2 / (ms * 1e-3) / 1e12);
+    }
+    return 0;
+}
