@@ -161,25 +161,52 @@ __device__ __forceinline__ void c_fwd_epilogue_reduce(const f32x16 (&acc)[2][2],
     }
 }
 
-// Phase timing for tools/phase_times.py (build with SPF_EXTRA_HIPCC_FLAGS=-DSPF_TIMING): thread 0 of every workgroup sums the
-// shader-clock cycles it spends between consecutive marks; never compiled into the product library.
-#ifdef SPF_TIMING
-__device__ unsigned long long spf_timing_buf[16];
-#define T_DECL unsigned long long tacc[16] = {}; unsigned long long tlast = __builtin_readcyclecounter();
-#define T_MARK(i)                                                  \
-    if (tid == 0) {                                                \
-        const unsigned long long now = __builtin_readcyclecounter(); \
-        tacc[i] += now - tlast;                                    \
-        tlast = now;                                               \
+// Layer-0 input of one tile: thread = (row, quarter): 16 colour-latent floats each + a share of the positional encoding of x_pi
+// (internal columns [latent 64 | posenc 39 | pad]); thread 0 of a row also writes {weight, point id} for the weighted mean.
+__device__ __forceinline__ void c_gather(float* X, float* s_wp, int ltid, int q, int idx, int srow, int p, const float* __restrict__ x,
+                                         const float* __restrict__ pts, const float* __restrict__ feat_col, const float* __restrict__ wn) {
+    const int row = ltid >> 2, q4 = ltid & 3;
+    f32x4 f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (idx >= 0) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(feat_col + (size_t)idx * SPF_COL_DIM + q4 * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f[u] = src[u];
     }
-#define T_FLUSH                                                    \
-    if (tid == 0)                                                  \
-        for (int i = 0; i < 16; ++i) atomicAdd(&spf_timing_buf[i], tacc[i]);
-#else
-#define T_DECL
-#define T_MARK(i)
-#define T_FLUSH
-#endif
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(X + row * LDA + q4 * 16 + 4 * u) = f[u];
+    // positional encoding of x_pi, internal columns 64..102: the 18 (frequency, component) sin/cos pairs of a row are split over its
+    // 4 threads; thread 0 also writes the raw offset, the pad column and the row's bookkeeping
+    float d[3] = {0.f, 0.f, 0.f};
+    if (idx >= 0) {
+        d[0] = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
+        d[1] = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
+        d[2] = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
+    }
+    float* e = X + row * LDA + 64;
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj) {
+        const int j = q4 + 4 * jj;          // 0..17 -> (l, c)
+        if (j < 3 * N_FREQ) {
+            const int l = j / 3, c = j % 3;
+            float sv = 0.f, cv = 0.f;
+            if (idx >= 0) {
+                const float a = d[c] * (float)(1 << l);
+                sv = sinf(a);
+                cv = cosf(a);
+            }
+            e[3 + 6 * l + c] = sv;
+            e[6 + 6 * l + c] = cv;
+        }
+    }
+    if (q4 == 0) {
+        e[0] = d[0]; e[1] = d[1]; e[2] = d[2];
+        e[39] = 0.f;                      // pad column 103
+        s_wp[2 * row] = idx >= 0 ? wn[q] : 0.f;
+        s_wp[2 * row + 1] = __int_as_float(idx >= 0 ? p : -1);
+    }
+}
 
 template <bool STORE>
 __global__ void __launch_bounds__(256, 2)
@@ -219,53 +246,7 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         T_MARK(15)
         const int qn = (tile + (int)gridDim.x) * 64 + (tid >> 2);                          // this thread's row in the block's next tile
         const bool has_next = tile + (int)gridDim.x < ntiles && qn < NP;
-        // ---- gather: thread = (row, quarter): 16 latent floats each; quarter 0 also does posenc -----
-        {
-            const int row = tid >> 2, q4 = tid & 3;
-            const int q = tile * 64 + row;
-            const int idx = n_idx, srow = n_srow, p = n_p;
-            f32x4 f[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) f[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx >= 0) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(feat_col + (size_t)idx * SPF_COL_DIM + q4 * 16);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) f[u] = src[u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(X + row * LDA + q4 * 16 + 4 * u) = f[u];
-            {   // positional encoding of x_pi, internal columns 64..102: the 18 (frequency, component) sin/cos pairs of a row are
-                // split over its 4 threads; thread 0 also writes the raw offset, the pad column and the row's bookkeeping
-                float d[3] = {0.f, 0.f, 0.f};
-                if (idx >= 0) {
-                    d[0] = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
-                    d[1] = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
-                    d[2] = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
-                }
-                float* e = X + row * LDA + 64;
-#pragma unroll
-                for (int jj = 0; jj < 5; ++jj) {
-                    const int j = q4 + 4 * jj;          // 0..17 -> (l, c)
-                    if (j < 3 * N_FREQ) {
-                        const int l = j / 3, c = j % 3;
-                        float sv = 0.f, cv = 0.f;
-                        if (idx >= 0) {
-                            const float a = d[c] * (float)(1 << l);
-                            sv = sinf(a);
-                            cv = cosf(a);
-                        }
-                        e[3 + 6 * l + c] = sv;
-                        e[6 + 6 * l + c] = cv;
-                    }
-                }
-                if (q4 == 0) {
-                    e[0] = d[0]; e[1] = d[1]; e[2] = d[2];
-                    e[39] = 0.f;                      // pad column 103
-                    smem[CL_W + 2 * row] = idx >= 0 ? wn[q] : 0.f;                 // {weight, point id} per row, read by the last epilogue
-                    smem[CL_W + 2 * row + 1] = __int_as_float(idx >= 0 ? p : -1);
-                }
-            }
-        }
+        c_gather(X, smem + CL_W, tid, tile * 64 + (tid >> 2), n_idx, n_srow, n_p, x, pts, feat_col, wn);
         T_MARK(0)
         __syncthreads();
         T_MARK(1)
@@ -492,18 +473,9 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
 
 }  // namespace
 
-extern "C" {
+SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_color)
 
-#ifdef SPF_TIMING
-int spf_debug_timing(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(spf_timing_buf), 16 * sizeof(unsigned long long)) != hipSuccess) return SPF_EHIP;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(spf_timing_buf), z, sizeof(z)) != hipSuccess) return SPF_EHIP;
-    }
-    return SPF_OK;
-}
-#endif
+extern "C" {
 
 int64_t spf_color_packed_floats(void) { return C_PACKED; }
 

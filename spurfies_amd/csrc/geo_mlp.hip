@@ -120,8 +120,10 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
         }
     }
 
+    T_DECL
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gfp packed = launder(packed0);
+        T_MARK(31)
         gf4p pk4 = reinterpret_cast<gf4p>(packed);
         const BFrag fr1 = load_bfrag(pk4 + (OFF_FW1 / 4) + wave * (T_IN * 128), lane);     // in flight during the gather
         const int qn = (tile + (int)gridDim.x) * 64 + (tid >> 2);                          // this thread's row in the block's next tile
@@ -153,7 +155,9 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
                 *reinterpret_cast<f32x4*>(X + row * LDA + 36) = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        T_MARK(0)
         __syncthreads();
+        T_MARK(1)
 
         f32x16 acc[2][2];
         uint32_t m1[2], m2[2], m3[2], m4[2];
@@ -172,9 +176,13 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
         n_p = has_next ? pair_point[qn] : -1;
         zero_acc(acc);
         BFrag nf = gemm_rows64<T_IN>(X, wfw1, lane, acc, fr1, wfw2);
+        T_MARK(2)
         __syncthreads();
+        T_MARK(3)
         fwd_epilogue(X, acc, bv, wave, lane, m1);
+        T_MARK(4)
         __syncthreads();
+        T_MARK(5)
         bv[0] = packed[OFF_B2 + cb]; bv[1] = packed[OFF_B2 + cb + 32];
         int n_off = 0;
         if (n_p >= 0) {
@@ -183,23 +191,35 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
         }
         zero_acc(acc);
         nf = gemm_rows64<T_HID>(X, wfw2, lane, acc, nf, wfw3);
+        T_MARK(2)
         __syncthreads();
+        T_MARK(3)
         fwd_epilogue(X, acc, bv, wave, lane, m2);
+        T_MARK(4)
         __syncthreads();
+        T_MARK(5)
         bv[0] = packed[OFF_B3 + cb]; bv[1] = packed[OFF_B3 + cb + 32];
         n_idx = n_p >= 0 ? nbr[(size_t)n_srow * k + (qn - n_off)] : -1;
         zero_acc(acc);
         nf = gemm_rows64<T_HID>(X, wfw3, lane, acc, nf, wfw4);
+        T_MARK(2)
         __syncthreads();
+        T_MARK(3)
         fwd_epilogue(X, acc, bv, wave, lane, m3);
+        T_MARK(4)
         __syncthreads();
+        T_MARK(5)
         bv[0] = packed[OFF_B4 + cb]; bv[1] = packed[OFF_B4 + cb + 32];
         const float vv[2] = {packed[OFF_V5 + cb], packed[OFF_V5 + cb + 32]};       // folded last layer, used by the sweep
         zero_acc(acc);
         nf = gemm_rows64<T_HID>(X, wfw4, lane, acc, nf, WITH_JAC ? wbw4 : nullptr);
+        T_MARK(2)
         __syncthreads();
+        T_MARK(3)
         fwd_epilogue(X, acc, bv, wave, lane, m4);
+        T_MARK(4)
         __syncthreads();
+        T_MARK(5)
 
         // ---- sdf_j = v . a4 + c : 4 threads per row, interleaved float4 chunks ------------------
         {
@@ -219,8 +239,10 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
             if (q4 == 0 && q < NP) pair_tmp[(size_t)q * PT_STRIDE + 1] = s + packed[OFF_C];
         }
 
+        T_MARK(6)
         if (WITH_JAC) {
             __syncthreads();
+            T_MARK(7)
             // ---- Jacobian sweep: g_h4 = v * D4 ; g_a3 = g_h4 W6 ; ... ; J = g_h1 W0 --------------
             {
                 const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
@@ -234,22 +256,36 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
                             X[(m * 32 + row_of(r, h)) * LDA + c0 + 32 * n] = pos ? vv[n] : vv[n] * 0.01f;
                         }
             }
+            T_MARK(8)
             __syncthreads();
+            T_MARK(9)
             zero_acc(acc);
             nf = gemm_rows64<T_HID>(X, wbw4, lane, acc, nf, wbw3);
+            T_MARK(10)
             __syncthreads();
+            T_MARK(11)
             bwd_epilogue(X, acc, wave, lane, m3);
+            T_MARK(12)
             __syncthreads();
+            T_MARK(13)
             zero_acc(acc);
             nf = gemm_rows64<T_HID>(X, wbw3, lane, acc, nf, wbw2);
+            T_MARK(10)
             __syncthreads();
+            T_MARK(11)
             bwd_epilogue(X, acc, wave, lane, m2);
+            T_MARK(12)
             __syncthreads();
+            T_MARK(13)
             zero_acc(acc);
             gemm_rows64<T_HID>(X, wbw2, lane, acc, nf, nullptr);
+            T_MARK(10)
             __syncthreads();
+            T_MARK(11)
             bwd_epilogue(X, acc, wave, lane, m1);
+            T_MARK(12)
             __syncthreads();
+            T_MARK(13)
             // last step 256 -> 35 (padded 64): wave = (row half mt, column half nt), one 32x32 tile each
             {
                 const int mt = wave >> 1, nt = wave & 1, i = lane & 31, h = lane >> 5;
@@ -276,8 +312,11 @@ geo_pairs_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, c
                 }
             }
         }
+        T_MARK(14)
         __syncthreads();  // smem is reused by the next tile
+        T_MARK(15)
     }
+    T_FLUSH
 }
 
 // per point: norm = sum_j w_j ; sdf = sum_j w_j sdf_j / norm ; wn_j = w_j / norm ; grad = sum_j wn_j d sdf_j/dx
@@ -380,6 +419,8 @@ __global__ void geo_pack_kernel(PackArgs a, float* __restrict__ out) {
 }
 
 }  // namespace
+
+SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_geo)
 
 extern "C" {
 

@@ -117,3 +117,33 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 
 
 }  // namespace spf
+
+// Phase timing for tools/phase_times.py (build with SPF_EXTRA_HIPCC_FLAGS=-DSPF_TIMING): thread 0 of every workgroup sums the
+// shader-clock cycles it spends between consecutive marks; never compiled into the product library.
+#ifdef SPF_TIMING
+static __device__ unsigned long long spf_timing_buf[32];      // one per translation unit
+#define SPF_DEFINE_TIMING_ENTRY(name)                                                                                       \
+    extern "C" int name(unsigned long long* out32, int reset) {                                                            \
+        if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(spf_timing_buf), 32 * sizeof(unsigned long long)) != hipSuccess) return -5; \
+        if (reset) {                                                                                                        \
+            unsigned long long z[32] = {};                                                                                  \
+            if (hipMemcpyToSymbol(HIP_SYMBOL(spf_timing_buf), z, sizeof(z)) != hipSuccess) return -5;                       \
+        }                                                                                                                   \
+        return 0;                                                                                                           \
+    }
+#define T_DECL unsigned long long tacc[32] = {}; unsigned long long tlast = __builtin_readcyclecounter();
+#define T_MARK(i)                                                    \
+    if (tid == 0) {                                                  \
+        const unsigned long long now = __builtin_readcyclecounter(); \
+        tacc[i] += now - tlast;                                      \
+        tlast = now;                                                 \
+    }
+#define T_FLUSH                                                      \
+    if (tid == 0)                                                    \
+        for (int i = 0; i < 32; ++i) atomicAdd(&spf_timing_buf[i], tacc[i]);
+#else
+#define T_DECL
+#define T_MARK(i)
+#define T_FLUSH
+#define SPF_DEFINE_TIMING_ENTRY(name)
+#endif

@@ -7,7 +7,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) f32x4* gf4p;
 
 template <int MODE>   // 0: registers only, 1: + LDS operand reads, 2: + global weight reads, 3: both
-__global__ void __launch_bounds__(256) k(const float* w, float* out, int iters, unsigned long long* cyc) {
+__global__ void __launch_bounds__(256, 2) k(const float* w, float* out, int iters, unsigned long long* cyc) {
     __shared__ __attribute__((aligned(16))) float X[64 * 260];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < 64 * 260; e += 256) X[e] = 0.001f * (e & 127);

@@ -1,22 +1,35 @@
-"""Where a workgroup of color_forward_kernel spends its cycles (needs a -DSPF_TIMING build:
-   SPF_EXTRA_HIPCC_FLAGS=-DSPF_TIMING python -m spurfies_amd.build --force)."""
+"""Where a workgroup of the MLP kernels spends its cycles (needs a -DSPF_TIMING build:
+   SPF_EXTRA_HIPCC_FLAGS=-DSPF_TIMING python -m spurfies_amd.build --force; add -DSPF_SOLO for one workgroup per CU in the colour trunk)."""
 import ctypes
 import sys
 sys.path.insert(0, ".")
 import torch  # noqa: E402
-from spurfies_amd import _lib  # noqa: E402
-import tools.color_bench as cb  # noqa: E402,F401  (runs the kernels)
+from spurfies_amd import _lib, ops  # noqa: E402
+import tools.color_bench as cb  # noqa: E402  (sets up main-pass-shaped inputs and runs the kernels once)
 
 lib = _lib.lib()
-buf = (ctypes.c_ulonglong * 16)()
-lib.spf_debug_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
-lib.spf_debug_timing(buf, 1)
-for _ in range(5):
-    cb.fwd_train()
-torch.cuda.synchronize()
-lib.spf_debug_timing(buf, 1)
-names = ["gather", "sync", "act0 store + GEMM1", "sync", "epilogue1", "sync", "act1 store + GEMM2", "sync", "epilogue2", "sync",
-         "act2 store + GEMM3", "sync", "epilogue3 + sync", "seg reduce", "sync", "tile prologue"]
-tot = sum(buf)
-for n, v in zip(names, buf):
-    print(f"{n:22s} {100.0 * v / tot:6.2f} %")
+buf = (ctypes.c_ulonglong * 32)()
+
+
+def report(entry, fn, names):
+    f = getattr(lib, entry)
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    f(buf, 1)
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    f(buf, 1)
+    tot = sum(buf)
+    print(entry)
+    for i, n in names.items():
+        print(f"  {n:34s} {100.0 * buf[i] / tot:6.2f} %")
+
+
+report("spf_debug_timing_color", cb.fwd_train,
+       {15: "tile prologue", 0: "gather", 1: "sync", 2: "act0 store + GEMM1", 3: "sync", 4: "epilogue1", 5: "sync", 6: "act1 store + GEMM2",
+        7: "sync", 8: "epilogue2", 9: "sync", 10: "act2 store + GEMM3", 13: "epilogue3 + weighted mean", 14: "sync"})
+report("spf_debug_timing_geo",
+       lambda: ops.geo_forward(cb.x, cb.pl, cb.dev["neural_pts"], cb.dev["neural_feats_geometry"], cb.packed, 45.0, with_grad=True),
+       {31: "tile prologue", 0: "gather", 1: "sync", 2: "4 forward GEMMs", 3: "syncs after GEMM", 4: "4 forward epilogues", 5: "syncs after epilogue",
+        6: "sdf dot", 7: "sync", 8: "Jacobian seed", 9: "sync", 10: "3 backward GEMMs", 11: "syncs after GEMM", 12: "3 backward epilogues",
+        13: "syncs after epilogue", 14: "input-Jacobian GEMM + stores", 15: "sync"})
