@@ -92,6 +92,67 @@ __global__ void __launch_bounds__(512, 1) kB(const float* w, float* out, int lay
     out[blockIdx.x * 512 + tid] = X[tid & 255];
 }
 
+// D) structure A with the MFMA operands swapped (C^T = W X^T): a lane then holds 4 CONSECUTIVE output features of one row per
+//    register quad, so the epilogue rewrites the tile with 16 ds_write_b128 per lane instead of 64 ds_write_b32
+__device__ __forceinline__ void gemm_t(const float* X, gf4p wp, int lane, f32x16 (&acc)[2][2]) {
+    const int i = lane & 31, h = lane >> 5;
+    const float* a0p = X + i * LDA + 4 * h;
+    const float* a1p = a0p + 32 * LDA;
+    gf4p bp = wp + lane;
+    f32x4 b0 = bp[0], b1 = bp[64], c0 = bp[128], c1 = bp[192];
+    f32x4 a0 = *(const f32x4*)a0p, a1 = *(const f32x4*)a1p;
+#pragma unroll 4
+    for (int t = 0; t < 32; ++t) {
+        f32x4 d0 = c0, d1 = c1, na0 = a0, na1 = a1;
+        if (t + 2 < 32) { d0 = bp[(t + 2) * 128]; d1 = bp[(t + 2) * 128 + 64]; }
+        if (t + 1 < 32) { na0 = *(const f32x4*)(a0p + 8 * (t + 1)); na1 = *(const f32x4*)(a1p + 8 * (t + 1)); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {     // acc[m][n]: rows = features 32n.., columns = data rows 32m..
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[j], a0[j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[j], a0[j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[j], a1[j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[j], a1[j], acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        b0 = c0; b1 = c1; c0 = d0; c1 = d1; a0 = na0; a1 = na1;
+    }
+}
+
+__device__ __forceinline__ void epilogue_t(float* X, f32x16 (&acc)[2][2], int wave, int lane) {
+    const int row_l = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[m][n][4 * g + e] * 1e-3f + 0.01f;
+                    v[e] = t > 0.f ? t : t * 0.01f;
+                    acc[m][n][4 * g + e] = 0.f;
+                }
+                *(f32x4*)(X + (m * 32 + row_l) * LDA + wave * 64 + 32 * n + 8 * g + 4 * h) = v;
+            }
+}
+
+__global__ void __launch_bounds__(256, 2) kD(const float* w, float* out, int layers) {
+    __shared__ __attribute__((aligned(16))) float X[64 * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < 64 * LDA; e += 256) X[e] = 0.001f * (e & 127);
+    __syncthreads();
+    f32x16 acc[2][2] = {};
+    for (int l = 0; l < layers; ++l) {
+        gemm_t(X, (gf4p)w + ((l & 3) * 4 + wave) * (32 * 128), lane, acc);
+        __syncthreads();
+        epilogue_t(X, acc, wave, lane);
+        __syncthreads();
+    }
+    out[blockIdx.x * 256 + tid] = X[tid] + acc[0][0][0];
+}
+
 // C) one 8-wave workgroup, both groups on the same layer at the same time; the layer's weight fragments are streamed ONCE per
 //    workgroup into a 3-slot LDS ring by LDS-DMA (wave w of group 0 fetches the fragments both wave w's use) and read from there
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst_wave_base) {
@@ -171,6 +232,10 @@ int main() {
         (void)hipEventRecord(e0); kB<<<256, 512>>>(w, out, layers); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);
         printf("B one 8-wave workgroup, stage-shifted : %.3f ms  %.1f TFLOP/s\n", ms, 512.0 * layers * 64 * 256 * 256 * 2 / (ms * 1e-3) / 1e12);
+        kD<<<512, 256>>>(w, out, layers);
+        (void)hipEventRecord(e0); kD<<<512, 256>>>(w, out, layers); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("D structure A, transposed product + 16-byte tile rewrites : %.3f ms  %.1f TFLOP/s\n", ms, 512.0 * layers * 64 * 256 * 256 * 2 / (ms * 1e-3) / 1e12);
         kC<<<256, 512>>>(w, out, layers);
         (void)hipEventRecord(e0); kC<<<256, 512>>>(w, out, layers); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);
