@@ -1,0 +1,117 @@
+"""Command-line entry with the reference's surface (runner.py:9-65): hydra-style `key=value` overrides of config/ours.yaml's
+keys — `testlist= vol= outdir= exps_folder= opt_stepNs= grad_clip= is_continue=` and dotted `vol.train.num_pixels=...` — then,
+per scene, `VolOpt(args, batch_size=1, is_continue, timestamp='latest', checkpoint='latest', scan)`, `gen_dataset(0)`,
+`run(opt_stepNs[0])`.
+
+hydra / omegaconf are not needed (a literal `key=value` parser covers what the reference's own command lines use,
+readme.md:65,85,88).  The reference's datasets are a separate download; `data=synthetic` (default) optimises the built-in
+DTU-shaped synthetic scene instead, `points=` / `seed=` pick its size.  The optimisation itself is `spurfies_amd.train.VolOpt`
+on the HIP path; `sync_free=true` (default) is the mode `bench.py` measures.
+
+    python runner.py testlist=scan24 vol=dtu_pn opt_stepNs=[200,0,0] exps_folder=exps_vsdf
+"""
+from __future__ import annotations
+
+import ast
+import sys
+import time
+
+DEFAULTS = {   # config/base.yaml + config/ours.yaml (the keys the optimisation path reads)
+    "testlist": "scan24", "vol": "dtu_pn", "outdir": "exps_mvs", "exps_folder": "exps_vsdf", "opt_stepNs": [100000, 0, 0], "grad_clip": True,
+    "is_continue": False, "data": "synthetic", "points": 10000, "seed": 0, "sync_free": True, "root": "./",
+    "vol.train.expname": "ours", "vol.train.render_freq": 500, "vol.train.checkpoint_freq": 15000, "vol.train.num_pixels": 1024,
+    "vol.train.split_n_pixels": 500, "vol.loss.local_weight": 0.5, "vol.loss.pseudo_weight": 0.5, "vol.loss.eikonal_weight": 0.001,
+    "vol.loss.rgb_weight": 1.0, "vol.loss.tv_weight": 0.01, "vol.dataset.data_dir": "dtu",
+}
+
+
+def _literal(text: str):
+    low = text.strip().lower()
+    if low in ("true", "false"):
+        return low == "true"
+    try:
+        return ast.literal_eval(text)
+    except (ValueError, SyntaxError):
+        return text
+
+
+def parse_overrides(argv) -> dict:
+    """['testlist=scan24,scan37', 'opt_stepNs=[10,0,0]', 'vol.train.num_pixels=512'] -> flat dict over DEFAULTS."""
+    flat = dict(DEFAULTS)
+    for tok in argv:
+        if "=" not in tok:
+            raise SystemExit(f"runner.py: expected key=value, got {tok!r}")
+        key, val = tok.split("=", 1)
+        key = key.lstrip("+")
+        flat[key] = _literal(val)
+    return flat
+
+
+def nest(flat: dict):
+    """dotted keys -> nested spurfies_amd.conf.Conf (what VolOpt reads as `args` / `args['vol']`)."""
+    from spurfies_amd.conf import Conf
+
+    root: dict = {}
+    for key, val in flat.items():
+        node = root
+        parts = key.split(".")
+        if parts[0] == "vol" and len(parts) == 1:      # `vol=dtu_pn` names the config group; its content lives under vol.*
+            root.setdefault("vol_name", val)
+            continue
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = val
+
+    def conv(d):
+        return Conf({k: conv(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+    return conv(root)
+
+
+def scenes_of(flat: dict):
+    t = str(flat["testlist"])
+    if t.endswith(".txt"):
+        return [line.strip() for line in open(t) if line.strip()]
+    return [x for x in t.replace(" ", "").split(",") if x]
+
+
+def optimise_scene(scene_name: str, flat: dict, args):
+    import numpy as np
+    import torch
+
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.train import VolOpt
+
+    if flat["data"] != "synthetic":
+        raise SystemExit("runner.py: the reference's DTU / MipNeRF-360 loaders need its data download (out of scope, DESIGN.md §8); "
+                         "use data=synthetic, or construct spurfies_amd.train.VolOpt(dataset=..., neural_points=...) from Python")
+    scene = syn.make_scene(int(flat["points"]), seed=int(flat["seed"]))
+    prior = {k: torch.from_numpy(np.asarray(v)) for k, v in scene["state"].items() if k.startswith(("F_geometry", "T."))}
+    vol_opt = VolOpt(args=args, batch_size=1, is_continue=bool(flat["is_continue"]), timestamp="latest", checkpoint="latest", scan=scene_name,
+                     root=str(flat["root"]), scene=scene, neural_points={"pts": scene["state"]["neural_pts"], "colors": scene["colors"]},
+                     prior_state_dict=prior, device="cuda", sync_free=bool(flat["sync_free"]))
+    vol_opt.gen_dataset(0)
+    vol_opt.stg = 0
+    steps = flat["opt_stepNs"]
+    steps = steps[0] if isinstance(steps, (list, tuple)) else int(steps)
+    t0 = time.perf_counter()
+    epoch = vol_opt.run(int(steps))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    last = {k: float(v.detach()) for k, v in (vol_opt.last_losses or {}).items()}
+    print(f"finished training {scene_name}: {vol_opt.iter_step} steps, epoch {epoch}, {1e3 * dt / max(vol_opt.iter_step, 1):.2f} ms/step, "
+          f"loss {last.get('loss', float('nan')):.5f}, checkpoints in {vol_opt.checkpoints_path}")
+    return vol_opt
+
+
+def main(argv=None):
+    flat = parse_overrides(sys.argv[1:] if argv is None else argv)
+    args = nest(flat)
+    out = []
+    for scene in scenes_of(flat):
+        out.append(optimise_scene(scene, flat, args))
+    return out
+
+
+if __name__ == "__main__":
+    main()
