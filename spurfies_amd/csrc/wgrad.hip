@@ -124,11 +124,13 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_row) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
-__global__ void __launch_bounds__(256, 1)
-wgrad_dma_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, const int32_t* __restrict__ n_rows_dev,
+template <int NT>   // 8: A has 256 columns (one 1-KB row per DMA);  4: A has <= 128 columns, staged 128 wide (two rows per DMA)
+__global__ void __launch_bounds__(256, NT == 8 ? 1 : 2)
+wgrad_dma_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
                  int max_rows, float* __restrict__ slab) {
-    constexpr int NT = 8, U = 8, ROWS = 2 * U, NB = 3;
-    __shared__ __attribute__((aligned(16))) float sm[NB][2][ROWS][256];     // [buffer][G | A][row][col]   96 KB, one object
+    constexpr int U = 8, ROWS = 2 * U, NB = 3, CA = 32 * NT;
+    constexpr int NDMA = 4 + (NT == 8 ? 4 : 2);                             // DMA instructions per wave per stage
+    __shared__ __attribute__((aligned(16))) float sm[NB][ROWS * (256 + CA)];  // [buffer][G 16x256 | A 16xCA]   96 / 72 KB, one object
     const int tid = threadIdx.x, lane = tid & 63, ci = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
@@ -144,33 +146,49 @@ wgrad_dma_kernel(const float* __restrict__ G, const float* __restrict__ A, int l
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
-    // wave w fills rows 4w..4w+3 of both halves: 8 DMA instructions per wave per stage.  Rows past r1 re-read row r1-1
-    // (finite data) and are cancelled on the G operand below.
+    // wave w fills rows 4w..4w+3 of G and of A.  Rows past r1 re-read row r1-1 (finite data) and are cancelled on the G operand
+    // below; at NT = 4 the lanes past the last real column re-read it (those output columns are dropped by the reduce kernel).
+    const int c4max = (C - 1) / 4;
     auto issue = [&](int st) {
         const int buf = st % NB, base = r0 + st * ROWS;
+        float* sg = &sm[buf][0];
+        float* sa = sg + ROWS * 256;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int lr = 4 * wave + j, row = min(base + lr, r1 - 1);
-            glds16(G + (size_t)row * 256 + 4 * lane, &sm[buf][0][lr][0]);
-            glds16(A + (size_t)row * lda + 4 * lane, &sm[buf][1][lr][0]);
+            glds16(G + (size_t)row * 256 + 4 * lane, sg + lr * 256);
+            if (NT == 8) glds16(A + (size_t)row * lda + 4 * lane, sa + lr * CA);
+        }
+        if (NT == 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lr = 4 * wave + 2 * j + h, row = min(base + lr, r1 - 1);         // lanes 0-31: row lr, lanes 32-63: row lr + 1
+                glds16(A + (size_t)row * lda + 4 * min(ci, c4max), sa + (4 * wave + 2 * j) * CA);
+            }
         }
     };
     issue(0);
     if (nst > 1) issue(1);
     for (int st = 0; st < nst; ++st) {
-        if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // stage st landed, st+1 may still fly
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (st + 1 < nst) {                                                      // stage st landed, st+1 may still fly
+            if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                                          // ... for every wave's share of it
         if (st + 2 < nst) issue(st + 2);                                       // into the buffer read in iteration st-1
         const int buf = st % NB, left = r1 - (r0 + st * ROWS);
-        // operands of step u+1 are read from LDS before the 16 MFMAs of step u are issued (explicit register double buffer)
+        const float* sg = &sm[buf][0];
+        const float* sa = sg + ROWS * 256;
+        // operands of step u+1 are read from LDS before the MFMAs of step u are issued (explicit register double buffer)
         float2 a[2];
-        f32x4 b4[2][2];
+        f32x4 b4[2][NT / 4];
         auto rd = [&](int u, int k) {
-            a[k] = *reinterpret_cast<const float2*>(&sm[buf][0][2 * u + h][64 * wave + 2 * ci]);
+            a[k] = *reinterpret_cast<const float2*>(sg + (2 * u + h) * 256 + 64 * wave + 2 * ci);
             if (2 * u + h >= left) a[k] = float2{0.f, 0.f};
-            b4[k][0] = *reinterpret_cast<const f32x4*>(&sm[buf][1][2 * u + h][4 * ci]);
-            b4[k][1] = *reinterpret_cast<const f32x4*>(&sm[buf][1][2 * u + h][128 + 4 * ci]);
+#pragma unroll
+            for (int v = 0; v < NT / 4; ++v) b4[k][v] = *reinterpret_cast<const f32x4*>(sa + (2 * u + h) * CA + 128 * v + 4 * ci);
         };
         rd(0, 0);
 #pragma unroll
@@ -274,7 +292,8 @@ extern "C" {
 
 static constexpr int RSPLIT = 16;
 
-int64_t spf_wgrad_workspace_floats(int32_t C) { return (int64_t)256 * 256 * (C > 128 ? 256 : (C > 32 ? 128 : 32)); }
+// slabs: 256 workgroups x [256 x 256] (C > 128), 512 x [256 x 128] (two workgroups per CU), 256 x [256 x 32]
+int64_t spf_wgrad_workspace_floats(int32_t C) { return (int64_t)256 * 256 * (C > 128 ? 256 : (C > 32 ? 256 : 32)); }
 
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows, float* dW, int32_t ldw,
               float* workspace, void* stream) {
@@ -285,14 +304,15 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     if (NT >= 4 && ((C % 4) || (lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad: C and lda must be multiples of 4 for C > 32 (C=%d lda=%d)", C, lda);
     hipStream_t s = (hipStream_t)stream;
     int blocks = spf::div_up(max_rows, 512);
-    if (blocks > 256) blocks = 256;   // one workgroup per CU, one wave per SIMD
+    const int cap = NT == 4 ? 512 : 256;   // NT = 4: half the accumulators, two workgroups per CU; else one per CU, one wave per SIMD
+    if (blocks > cap) blocks = cap;
     const int per = 4 * 2 * NT * 16 * 64;
     if (NT == 8) {
-        if (C == 256) wgrad_dma_kernel<<<blocks, 256, 0, s>>>(G, A, lda, n_rows, max_rows, workspace);
+        if (C == 256) wgrad_dma_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         else wgrad_lds_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         wgrad_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     } else if (NT == 4) {
-        wgrad_lds_kernel<4><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_dma_kernel<4><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         wgrad_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     } else {
         wgrad_narrow_kernel<<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
