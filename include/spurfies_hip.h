@@ -279,6 +279,12 @@ int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float
  * rows = min(*n_rows, max_rows) read on the device (NULL: max_rows).  C in {256 | multiple of 4 <= 128 | <= 32};
  * workspace: spf_wgrad_workspace_floats(C) floats (per-workgroup partial slabs, summed in a fixed order). */
 int64_t spf_wgrad_workspace_floats(int32_t C);
+/* Arithmetic of spf_wgrad for C > 32 (process-wide).  0 (default): every fp32 operand is split into three bf16 pieces
+ * (x = p1 + p2 + p3 exactly to 24 bits) and the six products with i + j <= 4 run on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation — each piece product is exact, the dropped terms are below 2^-24 of the product, so the result differs from the
+ * fp32-MFMA GEMM only by summation order, at 2.7x the matrix rate.  1: v_mfma_f32_32x32x2_f32 everywhere (verification). */
+int spf_wgrad_set_mode(int32_t mode);
+
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows,
               float* dW, int32_t ldw, float* workspace, void* stream);
 

@@ -212,6 +212,202 @@ wgrad_dma_kernel(const float* __restrict__ G, const float* __restrict__ A, int l
             for (int r = 0; r < 16; ++r) out[((m * NT + t) * 16 + r) * 64] = acc[m][t][r];
 }
 
+// ---- fp32 products from three bf16 pieces per operand ------------------------------------------------------------------------
+// x = p1 + p2 + p3 with p1 = bf16(x), p2 = bf16(x - p1), p3 = bf16(x - p1 - p2) (both differences are exact in fp32; 3 x 8
+// mantissa bits cover fp32's 24).  A product of two fp32 numbers is then sum_{i,j} a_i b_j; every a_i b_j is EXACT in the MFMA's
+// fp32 accumulation (8 x 8 bits), and the three terms with i + j >= 5 are below 2^-24 of the product, so the six terms with
+// i + j <= 4 reproduce the fp32 product to fp32 rounding.  Six v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace eight
+// v_mfma_f32_32x32x2_f32 (64 cycles, K = 2): 2.7x the matrix rate for a GEMM whose result differs from the fp32-MFMA one only
+// by summation order.  Used where both operands stream through LDS once anyway (this weight-gradient GEMM: the splitting is
+// ~6 VALU operations per staged element, hidden beside the MFMAs); the tile engine of the MLP kernels keeps fp32 MFMA.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct Split8 {
+    bf16x8 p1, p2, p3;
+};
+__device__ __forceinline__ Split8 split8(const float (&x)[8]) {
+    Split8 s;
+#ifdef SPLIT_NO_SPLIT
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s.p1[e] = (__bf16)x[e]; s.p2[e] = s.p1[e]; s.p3[e] = s.p1[e]; }
+    return s;
+#endif
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 a = (__bf16)x[e];                 // round to nearest even (v_cvt_pk_bf16_f32)
+        const float r1 = x[e] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        const float r2 = r1 - (float)b;
+        s.p1[e] = a;
+        s.p2[e] = b;
+        s.p3[e] = (__bf16)r2;
+    }
+    return s;
+}
+
+template <int NT>   // 8: C = 256;  4: C <= 128 (staged 128 wide)
+__global__ void __launch_bounds__(256, 1)
+wgrad_split_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
+                   int max_rows, float* __restrict__ slab) {
+    // Stage = 16 rows (one K = 16 MFMA step) of G [16,256] and A [16,CA], written into a 4-slot fp32 ring by LDS-DMA (three stages
+    // requested ahead: a stage computes in < 2 us, less than a loaded HBM round trip).  The A tile feeds all four waves, so it is
+    // split into its three bf16 planes ONCE per workgroup (each wave a quarter of the columns) into `planes`, laid out [piece][column]
+    // [k-half] x 8 bf16 so that an MFMA B fragment is one 16-byte LDS read; each wave splits its own 64 columns of G in registers.
+    constexpr int ROWS = 16, NB = 4, CA = 32 * NT;
+    constexpr int NDMA = 4 + (NT == 8 ? 4 : 2);
+    __shared__ __attribute__((aligned(16))) float sm[NB * ROWS * (256 + CA) + 3 * CA * 2 * 4];
+    float* planes_f = sm + NB * ROWS * (256 + CA);
+    bf16x8* planes = reinterpret_cast<bf16x8*>(planes_f);                 // [3][CA][2]
+    const int tid = threadIdx.x, lane = tid & 63, ci = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
+    int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    chunk += chunk & 1;
+    const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, n);
+    if (r0 >= r1) return;
+    const int nst = (r1 - r0 + ROWS - 1) / ROWS;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+    const int c4max = (C - 1) / 4;
+    auto issue = [&](int st) {
+        const int buf = st % NB, base = r0 + st * ROWS;
+        float* sg = sm + buf * ROWS * (256 + CA);
+        float* sa = sg + ROWS * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = 4 * wave + j, row = min(base + lr, r1 - 1);
+            glds16(G + (size_t)row * 256 + 4 * lane, sg + lr * 256);
+            if (NT == 8) glds16(A + (size_t)row * lda + 4 * lane, sa + lr * CA);
+        }
+        if (NT == 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lr = 4 * wave + 2 * j + h, row = min(base + lr, r1 - 1);
+                glds16(A + (size_t)row * lda + 4 * min(ci, c4max), sa + (4 * wave + 2 * j) * CA);
+            }
+        }
+    };
+    issue(0);
+    if (nst > 1) issue(1);
+    if (nst > 2) issue(2);
+    T_DECL
+    for (int st = 0; st < nst; ++st) {
+        T_MARK(3)
+        // stage st landed; up to two younger stages may still be in flight
+        if (st + 2 < nst) {
+            if (NDMA == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else if (st + 1 < nst) {
+            if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        T_MARK(0)
+        __builtin_amdgcn_s_barrier();                   // every wave's share of stage st is in LDS; nobody reads stage st-1 or `planes` any more
+        T_MARK(1)
+        if (st + 3 < nst) issue(st + 3);                // into the slot stage st-1 used
+        T_MARK(2)
+        const int buf = st % NB, left = r1 - (r0 + st * ROWS);
+        const float* sg = sm + buf * ROWS * (256 + CA);
+        const float* sa = sg + ROWS * 256;
+        // ---- the workgroup's shared operand: this wave splits CA/4 columns (lane = column, k-half h) ----------------------------
+#pragma unroll
+        for (int u = 0; u < NT / 4; ++u) {
+            const int col = (CA / 4) * wave + 32 * u + ci;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = sa[(8 * h + e) * CA + col];
+            const Split8 b = split8(x);
+            planes[(0 * CA + col) * 2 + h] = b.p1;
+            planes[(1 * CA + col) * 2 + h] = b.p2;
+            planes[(2 * CA + col) * 2 + h] = b.p3;
+        }
+        // ---- this wave's own operand: 64 columns of G, rows past the end cancelled ------------------------------------------------
+        Split8 ga[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (8 * h + e < left) ? sg[(8 * h + e) * 256 + 64 * wave + 32 * m + ci] : 0.f;
+            ga[m] = split8(x);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        T_MARK(4)
+        __builtin_amdgcn_s_barrier();                   // planes complete
+        T_MARK(5)
+        // ---- 16 output tiles x 6 products; smallest terms first, the two row tiles alternate -------------------------------------
+        bf16x8 bq[2][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bq[0][q] = planes[(q * CA + ci) * 2 + h];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int k = t & 1;
+            if (t + 1 < NT) {                           // next tile's fragments are read while this tile's 12 MFMAs issue
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bq[k ^ 1][q] = planes[(q * CA + 32 * (t + 1) + ci) * 2 + h];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define SPF_MMA(PA, Q)                                                                                        \
+    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0].PA, bq[k][Q], acc[0][t], 0, 0, 0);                \
+    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1].PA, bq[k][Q], acc[1][t], 0, 0, 0);
+            SPF_MMA(p3, 0)
+            SPF_MMA(p1, 2)
+            SPF_MMA(p2, 1)
+            SPF_MMA(p2, 0)
+            SPF_MMA(p1, 1)
+            SPF_MMA(p1, 0)
+#undef SPF_MMA
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    T_MARK(3)
+    T_FLUSH
+    float* out = slab + ((size_t)blockIdx.x * 4 + wave) * (2 * NT * 16 * 64) + lane;   // slab[block][wave][m][t][reg][lane]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[((m * NT + t) * 16 + r) * 64] = acc[m][t][r];
+}
+
+// slab of wgrad_split_kernel: output row o = 64 wave + 32 m + C-row(reg, lane), column = 32 t + (lane & 31)
+template <int NT>
+__global__ void wgrad_split_reduce_kernel(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev, int max_rows,
+                                          int C, float* __restrict__ dW, int ldw) {
+    const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
+    if (n <= 0) return;
+    int chunk = (n + nblk_launched - 1) / nblk_launched;
+    chunk += chunk & 1;
+    const int active = (n + chunk - 1) / chunk;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int PER = 4 * 2 * NT * 16 * 64;
+    if (e >= PER) return;
+    const int lane = e & 63, r = (e >> 6) & 15, mt = (e >> 10) % (2 * NT), wave = (e >> 10) / (2 * NT);
+    const int m = mt / NT, t = mt % NT;
+    const int o = 64 * wave + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int i = 32 * t + (lane & 31);
+    if (i >= C) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int step = gridDim.y;
+    int b = blockIdx.y;
+    for (; b + 3 * step < active; b += 4 * step) {
+        s0 += slab[(size_t)b * PER + e];
+        s1 += slab[(size_t)(b + step) * PER + e];
+        s2 += slab[(size_t)(b + 2 * step) * PER + e];
+        s3 += slab[(size_t)(b + 3 * step) * PER + e];
+    }
+    for (; b < active; b += step) s0 += slab[(size_t)b * PER + e];
+    atomicAdd(&dW[(size_t)o * ldw + i], (s0 + s1) + (s2 + s3));
+}
+
 // NT = 1 (C <= 32: the 21 view-encoding columns, a ones column for a bias gradient): direct loads, nothing to share
 __global__ void __launch_bounds__(256, 1)
 wgrad_narrow_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
@@ -288,9 +484,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk_lau
 
 }  // namespace
 
+SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_wgrad)
+
 extern "C" {
 
 static constexpr int RSPLIT = 16;
+static int g_wgrad_mode = 0;      // 0: bf16-piece products where available (fp32-exact), 1: fp32 MFMA everywhere
+
+int spf_wgrad_set_mode(int32_t mode) {
+    if (mode != 0 && mode != 1) return spf::fail(SPF_EINVAL, "spf_wgrad_set_mode: 0 (split-bf16 products) or 1 (fp32 MFMA), got %d", mode);
+    g_wgrad_mode = mode;
+    return SPF_OK;
+}
 
 // slabs: 256 workgroups x [256 x 256] (C > 128), 512 x [256 x 128] (two workgroups per CU), 256 x [256 x 32]
 int64_t spf_wgrad_workspace_floats(int32_t C) { return (int64_t)256 * 256 * (C > 128 ? 256 : (C > 32 ? 256 : 32)); }
@@ -307,7 +512,13 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     const int cap = NT == 4 ? 512 : 256;   // NT = 4: half the accumulators, two workgroups per CU; else one per CU, one wave per SIMD
     if (blocks > cap) blocks = cap;
     const int per = 4 * 2 * NT * 16 * 64;
-    if (NT == 8) {
+    if (g_wgrad_mode == 0 && NT == 8 && C == 256) {
+        wgrad_split_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_split_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
+    } else if (g_wgrad_mode == 0 && NT == 4) {
+        wgrad_split_kernel<4><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_split_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
+    } else if (NT == 8) {
         if (C == 256) wgrad_dma_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         else wgrad_lds_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         wgrad_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);

@@ -533,6 +533,12 @@ class RHead(torch.autograd.Function):
 _wgrad_ws = {}
 
 
+def set_wgrad_mode(mode: str):
+    """'split' (default): fp32-exact products from three bf16 pieces per operand on the bf16 matrix pipe; 'f32': fp32 MFMA."""
+    _lib.check(_lib.lib().spf_wgrad_set_mode({"split": 0, "f32": 1}[mode]), "spf_wgrad_set_mode")
+
+
+
 def wgrad(G, A, n_rows, C=None, out=None, ldw=None):
     """out[256, :C] += G[:rows]^T A[:rows, :C] with the row count `n_rows` (int32 device tensor or None) read on the device."""
     dev = G.device

@@ -1,0 +1,63 @@
+"""GPU: spf_wgrad (dW = G^T A with a device-side row count).  The default arithmetic forms every fp32 product from three bf16
+pieces per operand on the bf16 matrix pipe; this file holds it to the accuracy of the fp32-MFMA kernel against a float64
+reference — on well-scaled data, on data spanning many orders of magnitude, and on sums that cancel."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(got, ref):
+    return float((got.double() - ref).abs().max() / ref.abs().max())
+
+
+def _both(G, A, n, C):
+    from spurfies_amd import ops
+
+    res = {}
+    for mode in ("f32", "split"):
+        ops.set_wgrad_mode(mode)
+        try:
+            res[mode] = ops.wgrad(G, A, n, C=C).clone()
+        finally:
+            ops.set_wgrad_mode("split")
+    return res
+
+
+@pytest.mark.parametrize("C", [256, 104])
+@pytest.mark.parametrize("rows", [70001, 1000])
+def test_split_products_match_fp32_accuracy(C, rows):
+    g = torch.Generator().manual_seed(C + rows)
+    G = torch.randn((rows + 40, 256), generator=g).cuda()
+    A = torch.randn((rows + 40, C), generator=g).cuda()
+    n = torch.tensor([rows], dtype=torch.int32, device="cuda")
+    ref = G[:rows].double().t() @ A[:rows].double()
+    res = _both(G, A, n, C)
+    e32, esp = _err(res["f32"], ref), _err(res["split"], ref)
+    assert esp < 2e-6 + 2.0 * e32, (esp, e32)          # same accuracy class as the fp32 kernel (both are summation-order noise)
+    assert esp < 1e-5
+
+
+def test_split_products_wide_dynamic_range_and_cancellation():
+    g = torch.Generator().manual_seed(7)
+    rows = 20000
+    scale = 10.0 ** (torch.rand((rows, 1), generator=g) * 8.0 - 4.0)                   # rows scaled over 8 orders of magnitude
+    G = (torch.randn((rows, 256), generator=g) * scale).cuda()
+    A = (torch.randn((rows, 256), generator=g) / scale).cuda()
+    n = torch.tensor([rows], dtype=torch.int32, device="cuda")
+    ref = G.double().t() @ A.double()
+    res = _both(G, A, n, 256)
+    assert _err(res["split"], ref) < 2e-6 + 2.0 * _err(res["f32"], ref)
+    # exact cancellation: every row appears twice with opposite sign -> the sum is exactly representable (0), whatever the order
+    G2 = torch.cat([G[:5000], -G[:5000]]).contiguous()
+    A2 = torch.cat([A[:5000], A[:5000]]).contiguous()
+    n2 = torch.tensor([10000], dtype=torch.int32, device="cuda")
+    res2 = _both(G2, A2, n2, 256)
+    big = float((G[:5000].double().abs().t() @ A[:5000].double().abs()).max())
+    assert float(res2["split"].abs().max()) <= 2e-6 * big and float(res2["f32"].abs().max()) <= 2e-6 * big
+    # single rows reproduce the fp32 product of two floats to fp32 rounding: a (x) b over one row is one product per entry
+    n1 = torch.tensor([1], dtype=torch.int32, device="cuda")
+    r1 = _both(G[:64].contiguous(), A[:64].contiguous(), n1, 256)
+    exact = torch.outer(G[0].double(), A[0].double())
+    np.testing.assert_allclose(r1["split"].double().cpu().numpy(), exact.cpu().numpy(), rtol=2.5e-7, atol=0)
