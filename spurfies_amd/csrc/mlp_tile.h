@@ -26,6 +26,17 @@ __device__ __forceinline__ gfp launder(const float* p) {
 
 __device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// [64][256] tile: LDS -> HBM as 1-KiB wave stores (the accumulator layout would give 4-byte stores two rows at a time,
+// and 64 separately addressed stores per lane cost registers)
+template <int LD = LDA>
+__device__ __forceinline__ void store_tile_256(const float* X, float* __restrict__ dst, int tid) {
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const int e4 = tid + 256 * u, row = e4 >> 6, c4 = e4 & 63;
+        *reinterpret_cast<f32x4*>(dst + row * 256 + 4 * c4) = *reinterpret_cast<const f32x4*>(X + row * LD + 4 * c4);
+    }
+}
+
 // First B fragment of a layer (k-step 0): fetched by the PREVIOUS layer's GEMM, four k-steps before its end, so that the
 // ~1 us L2 latency is not exposed at the start of every layer (the two workgroups of a CU run in phase and would both wait).
 struct BFrag {
@@ -40,8 +51,12 @@ __device__ __forceinline__ BFrag load_bfrag(gf4p wp, int lane) {
 
 // acc[mt][nt] += X[mt*32.., :] * B  for this wave's 64 output columns.  wp: [T][2][64] float4.  LD = LDS row stride.
 // `first` = this layer's k-step-0 fragment (load_bfrag(wp)); returns the k-step-0 fragment of `next_wp` (or `first`).
+// `tile_dst` != nullptr: the [64][256] tile in X (this GEMM's input) is also copied to HBM — from inside k-step 0, AFTER the weight
+// requests of k-steps 1 and 2: vmcnt retires in issue order, so stores placed in front of the loop would make the first weight
+// waits sit through the stores' write acknowledgements.
 template <int T, int LD = LDA>
-__device__ __forceinline__ BFrag gemm_rows64(const float* X, gf4p wp, int lane, f32x16 (&acc)[2][2], BFrag first, gf4p next_wp) {
+__device__ __forceinline__ BFrag gemm_rows64(const float* X, gf4p wp, int lane, f32x16 (&acc)[2][2], BFrag first, gf4p next_wp,
+                                             float* __restrict__ tile_dst = nullptr, int tid = 0) {
     const int i = lane & 31, h = lane >> 5;
     const float* a0p = X + i * LD + 4 * h;
     const float* a1p = a0p + 32 * LD;
@@ -66,6 +81,7 @@ __device__ __forceinline__ BFrag gemm_rows64(const float* X, gf4p wp, int lane, 
             d1 = bp[(t + 2) * 128 + 64];
         }
         if (t == T_PRE && next_wp) nxt = load_bfrag(next_wp, lane);
+        if (t == 0 && tile_dst) store_tile_256<LD>(X, tile_dst, tid);
         f32x4 na0 = a0, na1 = a1;
         if (t + 1 < T) {
             na0 = *reinterpret_cast<const f32x4*>(a0p + 8 * (t + 1));
@@ -93,17 +109,6 @@ __device__ __forceinline__ BFrag gemm_rows64(const float* X, gf4p wp, int lane, 
 template <int T, int LD = LDA>
 __device__ __forceinline__ void gemm_rows64(const float* X, gf4p wp, int lane, f32x16 (&acc)[2][2]) {
     gemm_rows64<T, LD>(X, wp, lane, acc, load_bfrag(wp, lane), nullptr);
-}
-
-// [64][256] tile: LDS -> HBM as 1-KiB wave stores (the accumulator layout would give 4-byte stores two rows at a time,
-// and 64 separately addressed stores per lane cost registers)
-template <int LD = LDA>
-__device__ __forceinline__ void store_tile_256(const float* X, float* __restrict__ dst, int tid) {
-#pragma unroll 4
-    for (int u = 0; u < 16; ++u) {
-        const int e4 = tid + 256 * u, row = e4 >> 6, c4 = e4 & 63;
-        *reinterpret_cast<f32x4*>(dst + row * 256 + 4 * c4) = *reinterpret_cast<const f32x4*>(X + row * LD + 4 * c4);
-    }
 }
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {

@@ -186,16 +186,14 @@ rhead_forward_kernel(const float* __restrict__ agg3, const float* __restrict__ r
         }
         __syncthreads();
         bv[0] = packed[RO_B1 + cb]; bv[1] = packed[RO_B1 + cb + 32];
-        if (STORE) store_tile_256<LDR>(X, agg + tb, tid);
         zero_acc(acc);
-        nf = gemm_rows64<T_RIN, LDR>(X, wfw1, lane, acc, nf, wfw2);
+        nf = gemm_rows64<T_RIN, LDR>(X, wfw1, lane, acc, nf, wfw2, STORE ? agg + tb : nullptr, tid);
         __syncthreads();
         r_fwd_epilogue<STORE>(X, acc, bv, wave, lane, mk);
         __syncthreads();
         bv[0] = packed[RO_B2 + cb]; bv[1] = packed[RO_B2 + cb + 32];
-        if (STORE) store_tile_256<LDR>(X, act1 + tb, tid);
         zero_acc(acc);
-        gemm_rows64<T_HID, LDR>(X, wfw2, lane, acc, nf, nullptr);
+        gemm_rows64<T_HID, LDR>(X, wfw2, lane, acc, nf, nullptr, STORE ? act1 + tb : nullptr, tid);
         __syncthreads();
         r_fwd_epilogue<STORE>(X, acc, bv, wave, lane, STORE ? mk + 512 : nullptr);
         __syncthreads();
@@ -335,19 +333,17 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
             }
         }
         __syncthreads();
-        store_tile_256<LDR>(X, G2 + tb, tid);
         f32x16 acc[2][2];
         gf4p wbwa = pk4 + (RO_BWA / 4) + wave * (T_HID * 128);
         gf4p wbw6 = pk4 + (RO_BW6 / 4) + wave * (T_HID * 128);
         const uint32_t mb1[2] = {mk[(wave * 2) * 64 + lane], mk[(wave * 2 + 1) * 64 + lane]};
         zero_acc(acc);
-        BFrag nf = gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane, acc, fr2, wbwa);
+        BFrag nf = gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane, acc, fr2, wbwa, G2 + tb, tid);
         __syncthreads();
         r_bwd_epilogue(X, acc, wave, lane, mb1, g_b0);
         __syncthreads();
-        store_tile_256<LDR>(X, G1 + tb, tid);
         zero_acc(acc);
-        nf = gemm_rows64<T_HID, LDR>(X, wbwa, lane, acc, nf, wbw6);
+        nf = gemm_rows64<T_HID, LDR>(X, wbwa, lane, acc, nf, wbw6, G1 + tb, tid);
         __syncthreads();
         {   // g_agg[p][col] -> HBM (operand of F_color.6's weight gradient; padded to whole tiles: no bounds test) and X;
             // its column sums are F_color.6's bias gradient
@@ -371,9 +367,8 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
             }
         }
         __syncthreads();
-        store_tile_256<LDR>(X, g_agg + tb, tid);
         zero_acc(acc);
-        gemm_rows64<T_HID, LDR>(X, wbw6, lane, acc, nf, nullptr);     // g_agg3 = g_agg W6
+        gemm_rows64<T_HID, LDR>(X, wbw6, lane, acc, nf, nullptr, g_agg + tb, tid);     // g_agg3 = g_agg W6
         __syncthreads();
         {
             const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
