@@ -282,7 +282,7 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
             n_off = pair_off[n_p];
         }
         zero_acc(acc);
-        nf = gemm_rows64<T_HID>(X, wfw2, lane, acc, nf, wfw3, STORE ? act1 + (size_t)tile * 64 * 256 : nullptr, tid);
+        nf = gemm_rows64<T_HID>(X, wfw2, lane, acc, nf, wfw3, side_tile(STORE ? act1 + (size_t)tile * 64 * 256 : nullptr, tid));
         T_MARK(6)
         __syncthreads();
         T_MARK(7)
@@ -293,7 +293,7 @@ color_forward_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         bv[0] = packed[CO_B3 + cb]; bv[1] = packed[CO_B3 + cb + 32];
         n_idx = n_p >= 0 ? nbr[(size_t)n_srow * k + (qn - n_off)] : -1;
         zero_acc(acc);
-        gemm_rows64<T_HID>(X, wfw3, lane, acc, nf, nullptr, STORE ? act2 + (size_t)tile * 64 * 256 : nullptr, tid);
+        gemm_rows64<T_HID>(X, wfw3, lane, acc, nf, nullptr, side_tile(STORE ? act2 + (size_t)tile * 64 * 256 : nullptr, tid));
         T_MARK(10)
         // agg3[p] = sum_j wn_j a3_j straight from the accumulators; the linear F_color.6 follows per point (rhead_mlp.hip)
         c_fwd_epilogue_reduce<STORE>(acc, bv, wave, lane, STORE ? mk + 1024 : nullptr, smem + CL_W, agg3);
@@ -429,14 +429,14 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
         }
         uint32_t mb[2] = {mk[512 + (wave * 2) * 64 + lane], mk[512 + (wave * 2 + 1) * 64 + lane]};   // sign bits: requested before the GEMM
         zero_acc(acc);
-        BFrag nf = gemm_rows64<T_HID>(X, wbw3, lane, acc, fr3, wbw2, G3 + tbase, tid);
+        BFrag nf = gemm_rows64<T_HID>(X, wbw3, lane, acc, fr3, wbw2, side_tile(G3 + tbase, tid));
         __syncthreads();
         c_bwd_epilogue(X, acc, wave, lane, mb, g_b2);
         __syncthreads();
         if ((tid & 3) == 0) s_idx[tid >> 2] = p_cur >= 0 ? nbr[(size_t)c_srow * k + (qrow - c_off)] : -1;   // read after two more barriers
         mb[0] = mk[(wave * 2) * 64 + lane]; mb[1] = mk[(wave * 2 + 1) * 64 + lane];
         zero_acc(acc);
-        gemm_rows64<T_HID>(X, wbw2, lane, acc, nf, nullptr, G2 + tbase, tid);
+        gemm_rows64<T_HID>(X, wbw2, lane, acc, nf, nullptr, side_tile(G2 + tbase, tid));
         __syncthreads();
         c_bwd_epilogue(X, acc, wave, lane, mb, g_b0);
         __syncthreads();

@@ -51,12 +51,26 @@ __device__ __forceinline__ BFrag load_bfrag(gf4p wp, int lane) {
 
 // acc[mt][nt] += X[mt*32.., :] * B  for this wave's 64 output columns.  wp: [T][2][64] float4.  LD = LDS row stride.
 // `first` = this layer's k-step-0 fragment (load_bfrag(wp)); returns the k-step-0 fragment of `next_wp` (or `first`).
-// `tile_dst` != nullptr: the [64][256] tile in X (this GEMM's input) is also copied to HBM — from inside k-step 0, AFTER the weight
-// requests of k-steps 1 and 2: vmcnt retires in issue order, so stores placed in front of the loop would make the first weight
-// waits sit through the stores' write acknowledgements.
+// HBM stores that ride inside k-step 0 of a GEMM, AFTER the weight requests of k-steps 1 and 2: vmcnt retires in issue order, so
+// stores placed in front of the loop make the first weight waits sit through the stores' write acknowledgements.
+//   tile: the [64][256] tile in X (this GEMM's input) is copied to HBM;  m0 / m1: two sign-bit words of the preceding epilogue.
+struct Side {
+    float* tile = nullptr;
+    int tid = 0;
+    uint32_t* m0 = nullptr;
+    uint32_t* m1 = nullptr;
+    uint32_t b0 = 0u, b1 = 0u;
+};
+__device__ __forceinline__ Side side_tile(float* tile, int tid) {
+    Side s;
+    s.tile = tile;
+    s.tid = tid;
+    return s;
+}
+
 template <int T, int LD = LDA>
 __device__ __forceinline__ BFrag gemm_rows64(const float* X, gf4p wp, int lane, f32x16 (&acc)[2][2], BFrag first, gf4p next_wp,
-                                             float* __restrict__ tile_dst = nullptr, int tid = 0) {
+                                             const Side& side = Side()) {
     const int i = lane & 31, h = lane >> 5;
     const float* a0p = X + i * LD + 4 * h;
     const float* a1p = a0p + 32 * LD;
@@ -81,7 +95,13 @@ __device__ __forceinline__ BFrag gemm_rows64(const float* X, gf4p wp, int lane, 
             d1 = bp[(t + 2) * 128 + 64];
         }
         if (t == T_PRE && next_wp) nxt = load_bfrag(next_wp, lane);
-        if (t == 0 && tile_dst) store_tile_256<LD>(X, tile_dst, tid);
+        if (t == 0) {
+            if (side.tile) store_tile_256<LD>(X, side.tile, side.tid);
+            if (side.m0) {
+                *side.m0 = side.b0;
+                *side.m1 = side.b1;
+            }
+        }
         f32x4 na0 = a0, na1 = a1;
         if (t + 1 < T) {
             na0 = *reinterpret_cast<const f32x4*>(a0p + 8 * (t + 1));

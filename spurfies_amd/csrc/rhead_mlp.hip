@@ -187,13 +187,13 @@ rhead_forward_kernel(const float* __restrict__ agg3, const float* __restrict__ r
         __syncthreads();
         bv[0] = packed[RO_B1 + cb]; bv[1] = packed[RO_B1 + cb + 32];
         zero_acc(acc);
-        nf = gemm_rows64<T_RIN, LDR>(X, wfw1, lane, acc, nf, wfw2, STORE ? agg + tb : nullptr, tid);
+        nf = gemm_rows64<T_RIN, LDR>(X, wfw1, lane, acc, nf, wfw2, side_tile(STORE ? agg + tb : nullptr, tid));
         __syncthreads();
         r_fwd_epilogue<STORE>(X, acc, bv, wave, lane, mk);
         __syncthreads();
         bv[0] = packed[RO_B2 + cb]; bv[1] = packed[RO_B2 + cb + 32];
         zero_acc(acc);
-        gemm_rows64<T_HID, LDR>(X, wfw2, lane, acc, nf, nullptr, STORE ? act1 + tb : nullptr, tid);
+        gemm_rows64<T_HID, LDR>(X, wfw2, lane, acc, nf, nullptr, side_tile(STORE ? act1 + tb : nullptr, tid));
         __syncthreads();
         r_fwd_epilogue<STORE>(X, acc, bv, wave, lane, STORE ? mk + 512 : nullptr);
         __syncthreads();
@@ -338,12 +338,12 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
         gf4p wbw6 = pk4 + (RO_BW6 / 4) + wave * (T_HID * 128);
         const uint32_t mb1[2] = {mk[(wave * 2) * 64 + lane], mk[(wave * 2 + 1) * 64 + lane]};
         zero_acc(acc);
-        BFrag nf = gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane, acc, fr2, wbwa, G2 + tb, tid);
+        BFrag nf = gemm_rows64<T_HID, LDR>(X, pk4 + (RO_BW2 / 4) + wave * (T_HID * 128), lane, acc, fr2, wbwa, side_tile(G2 + tb, tid));
         __syncthreads();
         r_bwd_epilogue(X, acc, wave, lane, mb1, g_b0);
         __syncthreads();
         zero_acc(acc);
-        nf = gemm_rows64<T_HID, LDR>(X, wbwa, lane, acc, nf, wbw6, G1 + tb, tid);
+        nf = gemm_rows64<T_HID, LDR>(X, wbwa, lane, acc, nf, wbw6, side_tile(G1 + tb, tid));
         __syncthreads();
         {   // g_agg[p][col] -> HBM (operand of F_color.6's weight gradient; padded to whole tiles: no bounds test) and X;
             // its column sums are F_color.6's bias gradient
@@ -368,7 +368,7 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
         }
         __syncthreads();
         zero_acc(acc);
-        gemm_rows64<T_HID, LDR>(X, wbw6, lane, acc, nf, nullptr, g_agg + tb, tid);     // g_agg3 = g_agg W6
+        gemm_rows64<T_HID, LDR>(X, wbw6, lane, acc, nf, nullptr, side_tile(g_agg + tb, tid));     // g_agg3 = g_agg W6
         __syncthreads();
         {
             const int c0 = wave * 64 + (lane & 31), h = lane >> 5;
