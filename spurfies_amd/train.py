@@ -143,6 +143,26 @@ from .utils import general as utils
 from .utils import rend_util
 
 
+def rename_prior_state_dict(prior: dict) -> dict:
+    """ckpt/local_prior.pt's `model_state_dict` -> this model's frozen-prior keys, exactly as the reference renames it
+    (spurfies/train.py:125-140): drop `sdf_features`; the i-th entry whose key contains `local_sdf_field` becomes
+    `F_geometry.{2 * (i // 2)}.<tail after the 4th dot>` (i counts ALL remaining entries, the MLP's ten tensors come first);
+    `density_branch.weight / .bias` become `T.0.weight / .bias`."""
+    prior = {k: v for k, v in prior.items() if k != "sdf_features"}
+    cnt = [0, 0, 2, 2, 4, 4, 6, 6, 8, 8]
+    out = {}
+    for i, (k, v) in enumerate(prior.items()):
+        if "local_sdf_field" in k:
+            if i >= len(cnt):
+                raise ValueError(f"prior checkpoint: unexpected position {i} of {k!r} (the reference expects the ten MLP tensors first)")
+            out[f"F_geometry.{cnt[i]}." + ".".join(k.split(".")[4:])] = v
+        if "density_branch.weight" in k:
+            out["T.0.weight"] = v
+        if "density_branch.bias" in k:
+            out["T.0.bias"] = v
+    return out
+
+
 class SyntheticDataset(torch.utils.data.Dataset):
     """Stand-in for spurfies/datasets/dtu.py:DTUDataset (images / cameras come from an unavailable download): same item layout
     `(idx, sample, ground_truth)`, `collate_fn`, `change_sampling_idx`, `total_pixels`, `img_res`."""
@@ -227,7 +247,10 @@ class VolOpt:
         model_cls = utils.get_class(self.conf.get_string("train.model_class", "spurfies_amd.model.pointneus_disent.PointVolSDF"))
         self.model = model_cls(conf=model_conf if isinstance(model_conf, Conf) else Conf(model_conf), scan_id=self.scan_id,
                                dataset=self.data_dir, neural_points=kwargs.get("neural_points"), device=device)
-        prior = kwargs.get("prior_state_dict")            # train.py:125-140 renames ckpt/local_prior.pt into F_geometry.* / T.0.*
+        prior = kwargs.get("prior_state_dict")            # already in F_geometry.* / T.0.* form, or:
+        prior_path = kwargs.get("prior_path", "ckpt/local_prior.pt")     # the reference's file (train.py:125-140), if present
+        if prior is None and prior_path and os.path.exists(prior_path):
+            prior = rename_prior_state_dict(torch.load(prior_path, map_location="cpu")["model_state_dict"])
         if prior is not None:
             self.model.load_state_dict(prior, strict=False)
         self.num_pixels = self.conf.get_int("train.num_pixels", 1024)

@@ -15,6 +15,8 @@ def _volopt(tmp_path, device, **kw):
     args = Conf(exps_folder="exps", grad_clip=True, vol=Conf(train=Conf(expname="ours", num_pixels=64, checkpoint_freq=2, split_n_pixels=500),
                                                                dataset=Conf(data_dir="dtu")))
     prior = {k: torch.from_numpy(np.asarray(v)) for k, v in scene["state"].items() if k.startswith(("F_geometry", "T."))}
+    if "prior_state_dict_override" in kw:
+        prior = kw.pop("prior_state_dict_override")
     return VolOpt(args=args, batch_size=1, is_continue=kw.pop("is_continue", False), timestamp="latest", checkpoint="latest", scan="scan24",
                   root=str(tmp_path), scene=scene, neural_points={"pts": scene["state"]["neural_pts"], "colors": scene["colors"]},
                   prior_state_dict=prior, device=device, **kw), scene
@@ -58,3 +60,29 @@ def test_short_run_reduces_the_loss(tmp_path):
     sample["uv"], gt["rgb"] = sample["uv"][:, :1500], gt["rgb"][:, :1500]
     img = t.render_step((idx, sample, gt))
     assert img["rgb_values"].shape == (1500, 3) and torch.isfinite(img["rgb_values"]).all() and torch.isfinite(img["psnr"])
+
+
+def test_prior_checkpoint_renaming_follows_the_reference(tmp_path):
+    """spurfies/train.py:125-140: positional renaming of ckpt/local_prior.pt into F_geometry.{0,2,4,6,8}.* and T.0.*."""
+    from spurfies_amd.train import rename_prior_state_dict
+
+    g = torch.Generator().manual_seed(0)
+    prior = {}
+    dims = [(256, 35), (256, 256), (256, 256), (256, 256), (256, 256)]
+    for li, (o, i) in enumerate(dims):                                   # the reference's own key style: 5 dot-separated parts
+        prior[f"model.implicit.local_sdf_field.{2 * li}.weight"] = torch.randn((o, i), generator=g)
+        prior[f"model.implicit.local_sdf_field.{2 * li}.bias"] = torch.randn((o,), generator=g)
+    prior["model.implicit.density_branch.weight"] = torch.randn((1, 256), generator=g)
+    prior["model.implicit.density_branch.bias"] = torch.randn((1,), generator=g)
+    with_feats = {"sdf_features": torch.zeros(3)}
+    with_feats.update(prior)
+    out = rename_prior_state_dict(with_feats)
+    assert set(out) == {f"F_geometry.{l}.{n}" for l in (0, 2, 4, 6, 8) for n in ("weight", "bias")} | {"T.0.weight", "T.0.bias"}
+    assert torch.equal(out["F_geometry.4.weight"], prior["model.implicit.local_sdf_field.4.weight"])
+    assert torch.equal(out["T.0.bias"], prior["model.implicit.density_branch.bias"])
+    # VolOpt picks the file up from prior_path and the model ends with those (frozen) weights
+    path = tmp_path / "local_prior.pt"
+    torch.save({"model_state_dict": with_feats}, path)
+    t, _ = _volopt(tmp_path, "cpu", prior_path=str(path), prior_state_dict_override=None)
+    assert torch.equal(t.model.F_geometry[6].weight.detach().cpu(), prior["model.implicit.local_sdf_field.6.weight"])
+    assert not t.model.T[0].weight.requires_grad
