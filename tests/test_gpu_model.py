@@ -304,3 +304,41 @@ def test_zero_level_set_chamfer_vs_oracle():
     db, _ = cKDTree(za).query(zb)
     chamfer = 0.5 * (da.mean() + db.mean())
     assert chamfer < 1e-5, chamfer
+
+
+def test_surface_route_grid_sweep_and_chamfer():
+    """SURVEY §8(f) N3 front half: the reference-shaped evaluation grid (plots.py:302-333), the chunked get_sdf_eval sweep over
+    ~3e5 points and the zero-level surface; the HIP surface coincides with the oracle's (Chamfer ~ round-off) and lies on the
+    analytic shape the synthetic prior was built around only up to the prior's own error (sanity bound)."""
+    from oracle import path as P
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.utils import surface
+
+    scene = syn.make_scene(6000, seed=0)
+    model = build_model(scene, train=False)
+    b = scene["base_radius"] * 1.25
+    grid = surface.get_grid(None, 64, input_min=np.array([-b, -b, -b]), input_max=np.array([b, b, b]), eps=0.0)
+    assert grid["grid_points"].shape[0] >= 64 ** 3
+    vol0 = surface.sdf_volume(model.get_sdf_eval, grid, splitn=100000)
+    med = float(np.median(vol0[vol0 != 1000.0]))
+    st_np = dict(scene["state"])
+    st_np["T.0.bias"] = st_np["T.0.bias"] - np.float32(med)          # a prior whose level set crosses the cloud
+    model.load_state_dict({"T.0.bias": torch.from_numpy(st_np["T.0.bias"])}, strict=False)
+    vol = surface.sdf_volume(model.get_sdf_eval, grid, splitn=100000)
+    pts = surface.surface_points(vol, grid)
+    assert len(pts) > 2000
+    st = P.load_state(st_np, requires_grad=False)
+    cfg = P.PathConfig(ranges=tuple(scene["ranges"]))
+    sub = grid["grid_points"][::7]
+    with torch.no_grad():
+        s_orc = P.sdf_at_points(sub, P.make_grid(cfg, st["neural_pts"]), st, cfg)[0].numpy()
+    s_hip = vol.reshape(-1)[::7]
+    ok = (s_orc != 1000.0)
+    assert np.array_equal(ok, s_hip != 1000.0)
+    np.testing.assert_allclose(s_hip[ok], s_orc[ok], rtol=1e-4, atol=5e-6)
+    d, acc, comp = surface.chamfer(pts, pts[::-1].copy())
+    assert d == 0.0
+    # every surface point has neural points nearby (the SDF is only defined within the kNN radius of the cloud)
+    from scipy.spatial import cKDTree
+    dist, _ = cKDTree(scene["state"]["neural_pts"]).query(pts)
+    assert float(dist.max()) <= 0.05 + 2 * (2 * b / 63)
