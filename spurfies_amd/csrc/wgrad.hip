@@ -124,6 +124,15 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_row) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// same with a wave-uniform base in SGPRs (built from kernel arguments and wave-uniform integers only, so written by the scalar
+// unit: no VALU-written-SGPR hazard in front of the request) and a 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16_s(const float* sbase, unsigned voff, float* lds_row) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)lds_row);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
+
 template <int NT>   // 8: A has 256 columns (one 1-KB row per DMA);  4: A has <= 128 columns, staged 128 wide (two rows per DMA)
 __global__ void __launch_bounds__(256, NT == 8 ? 1 : 2)
 wgrad_dma_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
@@ -245,154 +254,125 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
     return s;
 }
 
-template <int NT>   // 8: C = 256;  4: C <= 128 (staged 128 wide)
-__global__ void __launch_bounds__(256, 1)
-wgrad_split_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
-                   int max_rows, float* __restrict__ slab) {
-    // Stage = 16 rows (one K = 16 MFMA step) of G [16,256] and A [16,CA], written into a 4-slot fp32 ring by LDS-DMA (three stages
-    // requested ahead: a stage computes in < 2 us, less than a loaded HBM round trip).  The A tile feeds all four waves, so it is
-    // split into its three bf16 planes ONCE per workgroup (each wave a quarter of the columns) into `planes`, laid out [piece][column]
-    // [k-half] x 8 bf16 so that an MFMA B fragment is one 16-byte LDS read; each wave splits its own 64 columns of G in registers.
+// Stage = 16 rows (one K = 16 MFMA step) of G [16,256] and A [16,CA], written into a 4-slot fp32 ring by LDS-DMA (three stages
+// requested ahead).  EIGHT waves per workgroup (two per SIMD): wave w owns output rows [32w, 32w+32) x all columns (NT x 16
+// accumulator registers).  The A tile feeds every wave, so it is split into its three bf16 planes ONCE per workgroup (one
+// (column, k-half) item per thread) into `planes`, laid out [piece][column][k-half] x 8 bf16 so that an MFMA B fragment is one
+// 16-byte LDS read; each wave splits its own 32 columns of G in registers and issues 1/8 of the DMA requests.
+template <int NT>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
+__global__ void __launch_bounds__(512, 1)
+wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
+                    int max_rows, float* __restrict__ slab) {
     constexpr int ROWS = 16, NB = 4, CA = 32 * NT;
-    constexpr int NDMA = 4 + (NT == 8 ? 4 : 2);
+    constexpr int NDMA = 2 + (NT == 8 ? 2 : 1);                           // requests per wave per stage
     __shared__ __attribute__((aligned(16))) float sm[NB * ROWS * (256 + CA) + 3 * CA * 2 * 4];
-    float* planes_f = sm + NB * ROWS * (256 + CA);
-    bf16x8* planes = reinterpret_cast<bf16x8*>(planes_f);                 // [3][CA][2]
+    bf16x8* planes = reinterpret_cast<bf16x8*>(sm + NB * ROWS * (256 + CA));     // [3][CA][2]
     const int tid = threadIdx.x, lane = tid & 63, ci = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // 0..7
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
     int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
     chunk += chunk & 1;
     const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, n);
     if (r0 >= r1) return;
     const int nst = (r1 - r0 + ROWS - 1) / ROWS;
-    f32x16 acc[2][NT];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int c4max = (C - 1) / 4;
+    const unsigned off_row = 16u * lane, off_half = 16u * min(ci, c4max);
     auto issue = [&](int st) {
         const int buf = st % NB, base = r0 + st * ROWS;
         float* sg = sm + buf * ROWS * (256 + CA);
         float* sa = sg + ROWS * 256;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lr = 4 * wave + j, row = min(base + lr, r1 - 1);
-            glds16(G + (size_t)row * 256 + 4 * lane, sg + lr * 256);
-            if (NT == 8) glds16(A + (size_t)row * lda + 4 * lane, sa + lr * CA);
+        for (int j = 0; j < 2; ++j) {
+            const int lr = 2 * wave + j, row = min(base + lr, r1 - 1);       // wave-uniform
+            glds16_s(G + (size_t)row * 256, off_row, sg + lr * 256);
+            if (NT == 8) glds16_s(A + (size_t)row * lda, off_row, sa + lr * CA);
         }
-        if (NT == 4) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int lr = 4 * wave + 2 * j + h, row = min(base + lr, r1 - 1);
-                glds16(A + (size_t)row * lda + 4 * min(ci, c4max), sa + (4 * wave + 2 * j) * CA);
-            }
+        if (NT == 4) {                                                     // two 512-B rows per request
+            const int lr = 2 * wave, row_lo = min(base + lr, r1 - 1), row_hi = min(base + lr + 1, r1 - 1);
+            const unsigned dhi = (unsigned)(row_hi - row_lo) * (unsigned)lda * 4u;
+            glds16_s(A + (size_t)row_lo * lda, off_half + (h ? dhi : 0u), sa + lr * CA);
         }
     };
     issue(0);
     if (nst > 1) issue(1);
     if (nst > 2) issue(2);
-    T_DECL
     for (int st = 0; st < nst; ++st) {
-        T_MARK(3)
-        // stage st landed; up to two younger stages may still be in flight
-        if (st + 2 < nst) {
-            if (NDMA == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        } else if (st + 1 < nst) {
-            if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        T_MARK(0)
-        __builtin_amdgcn_s_barrier();                   // every wave's share of stage st is in LDS; nobody reads stage st-1 or `planes` any more
-        T_MARK(1)
-        if (st + 3 < nst) issue(st + 3);                // into the slot stage st-1 used
-        T_MARK(2)
+        if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");        // up to two younger stages in flight
+        else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (st + 3 < nst) issue(st + 3);
         const int buf = st % NB, left = r1 - (r0 + st * ROWS);
         const float* sg = sm + buf * ROWS * (256 + CA);
         const float* sa = sg + ROWS * 256;
-        // ---- the workgroup's shared operand: this wave splits CA/4 columns (lane = column, k-half h) ----------------------------
+        {   // the workgroup's shared operand: one (column, k-half) item per thread
+            const int col = 32 * wave + ci;
+            if (col < CA) {
+                float x[8];
 #pragma unroll
-        for (int u = 0; u < NT / 4; ++u) {
-            const int col = (CA / 4) * wave + 32 * u + ci;
-            float x[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = sa[(8 * h + e) * CA + col];
-            const Split8 b = split8(x);
-            planes[(0 * CA + col) * 2 + h] = b.p1;
-            planes[(1 * CA + col) * 2 + h] = b.p2;
-            planes[(2 * CA + col) * 2 + h] = b.p3;
+                for (int e = 0; e < 8; ++e) x[e] = sa[(8 * h + e) * CA + col];
+                const Split8 b = split8(x);
+                planes[(0 * CA + col) * 2 + h] = b.p1;
+                planes[(1 * CA + col) * 2 + h] = b.p2;
+                planes[(2 * CA + col) * 2 + h] = b.p3;
+            }
         }
-        // ---- this wave's own operand: 64 columns of G, rows past the end cancelled ------------------------------------------------
-        Split8 ga[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        Split8 ga;
+        {
             float x[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = (8 * h + e < left) ? sg[(8 * h + e) * 256 + 64 * wave + 32 * m + ci] : 0.f;
-            ga[m] = split8(x);
+            for (int e = 0; e < 8; ++e) x[e] = (8 * h + e < left) ? sg[(8 * h + e) * 256 + 32 * wave + ci] : 0.f;
+            ga = split8(x);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        T_MARK(4)
         __builtin_amdgcn_s_barrier();                   // planes complete
-        T_MARK(5)
-        // ---- 16 output tiles x 6 products; smallest terms first, the two row tiles alternate -------------------------------------
         bf16x8 bq[2][3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) bq[0][q] = planes[(q * CA + ci) * 2 + h];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int k = t & 1;
-            if (t + 1 < NT) {                           // next tile's fragments are read while this tile's 12 MFMAs issue
+            if (t + 1 < NT) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) bq[k ^ 1][q] = planes[(q * CA + 32 * (t + 1) + ci) * 2 + h];
             }
             __builtin_amdgcn_sched_barrier(0);
-#define SPF_MMA(PA, Q)                                                                                        \
-    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0].PA, bq[k][Q], acc[0][t], 0, 0, 0);                \
-    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1].PA, bq[k][Q], acc[1][t], 0, 0, 0);
-            SPF_MMA(p3, 0)
-            SPF_MMA(p1, 2)
-            SPF_MMA(p2, 1)
-            SPF_MMA(p2, 0)
-            SPF_MMA(p1, 1)
-            SPF_MMA(p1, 0)
-#undef SPF_MMA
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.p3, bq[k][0], acc[t], 0, 0, 0);      // smallest terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.p1, bq[k][2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.p2, bq[k][1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.p2, bq[k][0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.p1, bq[k][1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.p1, bq[k][0], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    T_MARK(3)
-    T_FLUSH
-    float* out = slab + ((size_t)blockIdx.x * 4 + wave) * (2 * NT * 16 * 64) + lane;   // slab[block][wave][m][t][reg][lane]
+    float* out = slab + ((size_t)blockIdx.x * 8 + wave) * (NT * 16 * 64) + lane;     // slab[block][wave 8][t][reg][lane]
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[((m * NT + t) * 16 + r) * 64] = acc[m][t][r];
+        for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64] = acc[t][r];
 }
 
-// slab of wgrad_split_kernel: output row o = 64 wave + 32 m + C-row(reg, lane), column = 32 t + (lane & 31)
+// slab of wgrad_split8_kernel: output row o = 32 wave + C-row(reg, lane), column = 32 t + (lane & 31)
 template <int NT>
-__global__ void wgrad_split_reduce_kernel(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev, int max_rows,
-                                          int C, float* __restrict__ dW, int ldw) {
+__global__ void wgrad_split8_reduce_kernel(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev, int max_rows,
+                                           int C, float* __restrict__ dW, int ldw) {
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
     if (n <= 0) return;
     int chunk = (n + nblk_launched - 1) / nblk_launched;
     chunk += chunk & 1;
     const int active = (n + chunk - 1) / chunk;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int PER = 4 * 2 * NT * 16 * 64;
+    constexpr int PER = 8 * NT * 16 * 64;
     if (e >= PER) return;
-    const int lane = e & 63, r = (e >> 6) & 15, mt = (e >> 10) % (2 * NT), wave = (e >> 10) / (2 * NT);
-    const int m = mt / NT, t = mt % NT;
-    const int o = 64 * wave + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int lane = e & 63, r = (e >> 6) & 15, t = (e >> 10) % NT, wave = (e >> 10) / NT;
+    const int o = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const int i = 32 * t + (lane & 31);
     if (i >= C) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -484,8 +464,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk_lau
 
 }  // namespace
 
-SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_wgrad)
-
 extern "C" {
 
 static constexpr int RSPLIT = 16;
@@ -513,11 +491,13 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     if (blocks > cap) blocks = cap;
     const int per = 4 * 2 * NT * 16 * 64;
     if (g_wgrad_mode == 0 && NT == 8 && C == 256) {
-        wgrad_split_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
-        wgrad_split_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
+        const int b8 = blocks > 256 ? 256 : blocks;      // one 8-wave workgroup per CU
+        wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw);
     } else if (g_wgrad_mode == 0 && NT == 4) {
-        wgrad_split_kernel<4><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
-        wgrad_split_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
+        const int b8 = blocks > 256 ? 256 : blocks;
+        wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw);
     } else if (NT == 8) {
         if (C == 256) wgrad_dma_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         else wgrad_lds_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
