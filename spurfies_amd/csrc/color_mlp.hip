@@ -16,7 +16,7 @@
 //
 // Training mode stores each layer's input activation ([rows,104] and 3 x [rows,256]) so that
 //   * the backward kernel recovers LeakyReLU' from the sign of the stored activation, and
-//   * the weight gradients dW_l = G_l^T A_{l-1} are plain library GEMMs over [rows,256] buffers
+//   * the weight gradients dW_l = G_l^T A_{l-1} are plain GEMMs over [rows,256] buffers (spf_wgrad, wgrad.hip)
 //     (G_l = gradient w.r.t. layer l's pre-activation, stored by the backward kernel).
 #include "mlp_tile.h"
 

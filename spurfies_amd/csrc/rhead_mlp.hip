@@ -8,7 +8,7 @@
 //
 // Tile = 64 consecutive valid points (rows).  Internal column order is [agg (256) | dir-enc (21) | pad] so that the
 // agg rows load 16-B aligned; spf_rhead_pack folds the permutation into the packed first-layer weights.
-// Weight gradients of the two wide layers are library GEMMs over stored [P,256] buffers (G_l^T act_{l-1}); the
+// Weight gradients of the 256-wide layers are GEMMs over stored [P,256] buffers (G_l^T act_{l-1}: spf_wgrad); the
 // 3 x 256 last layer's and all bias gradients are accumulated in-kernel.
 #include "mlp_tile.h"
 

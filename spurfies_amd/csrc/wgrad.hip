@@ -5,10 +5,13 @@
 // the device, so a library GEMM would force a host round trip per step; this kernel reads the count itself, which
 // keeps the whole optimisation step free of host synchronisation (and capturable in a hipGraph).
 //
-// K-huge / MN-tiny shape: every workgroup owns a slice of the rows and the FULL 256 x C output in accumulators
-// (one wave per SIMD, 2 x NT tiles of v_mfma_f32_32x32x2_f32 = up to 256 accumulator registers), streams G and A from HBM
-// exactly once through a double-buffered LDS stage and leaves its partial in a slab; a second tiny kernel sums the slabs
-// in a fixed order (bitwise reproducible) into dW.
+// K-huge / MN-tiny shape: every workgroup owns a slice of the rows and the FULL 256 x C output in accumulators, streams G and A
+// from HBM exactly once through an LDS ring filled by LDS-DMA and leaves its partial in a slab; a second small kernel sums the
+// slabs (16 slices, float atomics) into dW.  Kernels in this file, newest first:
+//   wgrad_split8_kernel   default for C > 32: fp32-exact products from three bf16 pieces per operand on the bf16 matrix pipe
+//   wgrad_dma_kernel      fp32 MFMA, LDS-DMA staged (spf_wgrad_set_mode(1); the verification twin of the above)
+//   wgrad_lds_kernel      fp32 MFMA, register-staged (C in (128, 256) that is not 256)
+//   wgrad_narrow_kernel   fp32 MFMA, direct loads (C <= 32)
 #include "mlp_tile.h"
 
 namespace {
