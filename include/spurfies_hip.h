@@ -116,6 +116,11 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
  * ---------------------------------------------------------------------------------------- */
 
 /* Number of floats of the packed F_geometry/T weight image. */
+/* Arithmetic of spf_geo_forward (process-wide).  0 (default): every fp32 operand is split into three bf16 pieces and the six
+ * piece products with i + j <= 4 run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (each piece product exact, dropped
+ * terms below 2^-24 of the product: the result differs from mode 1 only by summation order).  1: v_mfma_f32_32x32x2_f32. */
+int spf_geo_set_mode(int32_t mode);
+
 int64_t spf_geo_packed_floats(void);
 
 /* Pack nn.Linear weights ([out,in] row-major, as state_dict holds them) of

@@ -418,13 +418,382 @@ __global__ void geo_pack_kernel(PackArgs a, float* __restrict__ out) {
     out[e] = val;
 }
 
+
+// ==============================================================================================================================
+// Same path with fp32-EXACT products from three bf16 pieces per operand (the default; spf_geo_set_mode(1) selects the kernel above).
+//   x = p1 + p2 + p3, p1 = bf16(x), p2 = bf16(x - p1), p3 = bf16(x - p1 - p2): both differences are exact in fp32 and 3 x 8
+//   mantissa bits cover fp32's 24; a product of two fp32 numbers is sum_{i,j} a_i b_j, every piece product is exact in the
+//   MFMA's fp32 accumulation and the three with i + j >= 5 are below 2^-24 of the product, so the six with i + j <= 4 give the
+//   fp32 product to fp32 rounding.  Six v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace eight v_mfma_f32_32x32x2_f32
+//   (64 cycles, K = 2): 2.7x the matrix rate; results differ from the fp32-MFMA kernel above only by summation order.
+// Layout: transposed product D[feature][row] += W[feature][k] X[k][row] — the weights are the MFMA A operand (fragments
+// [wave][k16][m][piece][lane] x 8 bf16, streamed from L2), the activations the B operand, held in LDS as three bf16 planes
+// [piece][row][k] (one 16-byte read per fragment); a lane then owns 4 CONSECUTIVE features of one row per register quad, so an
+// epilogue (+ bias, LeakyReLU, sign bits, split into pieces) rewrites the planes with 8-byte stores.  One 4-wave workgroup per
+// CU (the planes take 101 KB), wave w owns features [64w, 64w+64) x 64 rows as 2x2 tiles.
+// ==============================================================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef const __attribute__((address_space(1))) bf16x8* gx3;
+
+constexpr int X3_LDP = 264;                       // plane row stride in bf16 (528 B: 16-B aligned, off the 256-B bank period)
+constexpr int X3_PLANE = 64 * X3_LDP;
+constexpr int X3_T1 = 3;                          // first layer: K = 35 -> 48
+constexpr int X3_TH = 16;                         // 256 / 16
+constexpr int X3_SZ1 = 4 * X3_T1 * 2 * 3 * 64;    // bf16x8 entries
+constexpr int X3_SZH = 4 * X3_TH * 2 * 3 * 64;
+constexpr int X3_SZJ = 2 * X3_TH * 3 * 64;
+constexpr int X3_FW1 = 0;
+constexpr int X3_FW2 = X3_FW1 + X3_SZ1;
+constexpr int X3_FW3 = X3_FW2 + X3_SZH;
+constexpr int X3_FW4 = X3_FW3 + X3_SZH;
+constexpr int X3_BW4 = X3_FW4 + X3_SZH;
+constexpr int X3_BW3 = X3_BW4 + X3_SZH;
+constexpr int X3_BW2 = X3_BW3 + X3_SZH;
+constexpr int X3_JW1 = X3_BW2 + X3_SZH;
+constexpr int X3_FRAGS = X3_JW1 + X3_SZJ;
+constexpr int PACKED_TOTAL = PACKED_FLOATS + 4 * X3_FRAGS;     // the fp32 image, then the piece fragments (16 B each)
+
+__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
+    a = (__bf16)x;                                // round to nearest even (v_cvt_pk_bf16_f32)
+    const float r1 = x - (float)a;
+    b = (__bf16)r1;
+    c = (__bf16)(r1 - (float)b);
+}
+
+// one thread per fragment slot (region, wave, k16, m, lane): 8 weights -> 3 x bf16x8
+__global__ void geo_pack_x3_kernel(PackArgs a, bf16x8* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int N1 = X3_SZ1 / 3, NH = X3_SZH / 3, NJ = X3_SZJ / 3;
+    if (s >= N1 + 6 * NH + NJ) return;
+    int region, local;
+    if (s < N1) { region = 0; local = s; }
+    else if (s < N1 + 6 * NH) { region = 1 + (s - N1) / NH; local = (s - N1) % NH; }
+    else { region = 7; local = s - N1 - 6 * NH; }
+    const int ln = local & 63, i = ln & 31, kg = ln >> 5;
+    float w[8];
+    size_t base;
+    if (region < 7) {
+        const int T = region == 0 ? X3_T1 : X3_TH;
+        const int m = (local >> 6) & 1, t = (local >> 7) % T, wv = (local >> 7) / T;
+        const int f = 64 * wv + 32 * m + i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * t + 8 * kg + e;
+            float v;
+            switch (region) {
+                case 0: v = k < K_IN ? a.w0[f * K_IN + k] : 0.f; break;
+                case 1: v = a.w2[f * 256 + k]; break;
+                case 2: v = a.w4[f * 256 + k]; break;
+                case 3: v = a.w6[f * 256 + k]; break;
+                case 4: v = a.w6[k * 256 + f]; break;      // g_a3[f] = sum_o g_h4[o] W6[o][f]
+                case 5: v = a.w4[k * 256 + f]; break;
+                default: v = a.w2[k * 256 + f]; break;
+            }
+            w[e] = v;
+        }
+        const int rb = region == 0 ? X3_FW1 : X3_FW2 + (region - 1) * X3_SZH;
+        base = (size_t)rb + (size_t)((wv * T + t) * 2 + m) * 3 * 64 + ln;
+    } else {
+        const int t = (local >> 6) % X3_TH, m = (local >> 6) / X3_TH;
+        const int f = 32 * m + i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * t + 8 * kg + e;
+            w[e] = f < K_IN ? a.w0[k * K_IN + f] : 0.f;  // J[f] = sum_o g_h1[o] W0[o][f]
+        }
+        base = (size_t)X3_JW1 + (size_t)(m * X3_TH + t) * 3 * 64 + ln;
+    }
+    bf16x8 p1, p2, p3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        __bf16 x, y, z;
+        split3(w[e], x, y, z);
+        p1[e] = x; p2[e] = y; p3[e] = z;
+    }
+    out[base] = p1;
+    out[base + 64] = p2;
+    out[base + 128] = p3;
+}
+
+// acc[m][n] (features 64w + 32m.., rows 32n..) += W X over T k16-steps.  wp: this wave's fragments of the layer, + lane.
+template <int T>
+__device__ __forceinline__ void gemm_x3(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][2]) {
+    const int j = lane & 31, kg = lane >> 5;
+    bf16x8 wa[2][3], wn[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wa[m][p] = wp[(m * 3 + p) * 64];
+#pragma unroll 2
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wn[m][p] = wp[((t + 1) * 6 + m * 3 + p) * 64];
+        }
+        bf16x8 xb[2][3];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) xb[n][p] = *reinterpret_cast<const bf16x8*>(X + p * X3_PLANE + (32 * n + j) * X3_LDP + 16 * t + 8 * kg);
+        // smallest terms first; four accumulators alternate
+#define SPF_X3(PW, PX)                                                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][PW], xb[0][PX], acc[0][0], 0, 0, 0);                   \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][PW], xb[1][PX], acc[0][1], 0, 0, 0);                   \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][PW], xb[0][PX], acc[1][0], 0, 0, 0);                   \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][PW], xb[1][PX], acc[1][1], 0, 0, 0);
+        SPF_X3(2, 0) SPF_X3(0, 2) SPF_X3(1, 1) SPF_X3(1, 0) SPF_X3(0, 1) SPF_X3(0, 0)
+#undef SPF_X3
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wa[m][p] = wn[m][p];
+    }
+}
+
+// write 4 consecutive features of one row as three bf16 quads
+__device__ __forceinline__ void store_quad_x3(__bf16* X, int row, int f0, const float (&v)[4]) {
+    bf16x4 pa, pb, pc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        __bf16 a, b, c;
+        split3(v[e], a, b, c);
+        pa[e] = a; pb[e] = b; pc[e] = c;
+    }
+    __bf16* dst = X + row * X3_LDP + f0;
+    *reinterpret_cast<bf16x4*>(dst) = pa;
+    *reinterpret_cast<bf16x4*>(dst + X3_PLANE) = pb;
+    *reinterpret_cast<bf16x4*>(dst + 2 * X3_PLANE) = pc;
+}
+
+// acc[m][n][4g + e] = feature 64w + 32m + 8g + 4kg + e of row 32n + j.  mask[m]: bit n * 16 + 4g + e.
+// MODE 0: a = lrelu(acc + b) -> planes.   MODE 1 (last forward layer): also sdf partial sums s[n] += v5 . a, and the planes get
+// the Jacobian seed v5 * lrelu'(h) instead of a (a itself is not needed any more).
+template <int MODE, bool WITH_JAC>
+__device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], gfp bias, gfp v5, int wave, int lane, uint32_t (&mask)[2],
+                                                float (&s)[2]) {
+    const int j = lane & 31, kg = lane >> 5;
+    mask[0] = mask[1] = 0u;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+            const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(bias + f0);
+            f32x4 vv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1) vv = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(v5 + f0);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float out[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[m][n][4 * g + e] + bv[e];
+                    const bool pos = v > 0.f;
+                    mask[m] |= (pos ? 1u : 0u) << (n * 16 + 4 * g + e);
+                    v = pos ? v : v * 0.01f;
+                    if (MODE == 1) {
+                        s[n] += vv[e] * v;
+                        out[e] = pos ? vv[e] : vv[e] * 0.01f;
+                    } else {
+                        out[e] = v;
+                    }
+                }
+                if (MODE == 0 || WITH_JAC) store_quad_x3(X, 32 * n + j, f0, out);
+            }
+        }
+}
+
+// backward epilogue: g_h = g_a * lrelu'(h) -> planes
+__device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mask)[2]) {
+    const int j = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float out[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool pos = (mask[m] >> (n * 16 + 4 * g + e)) & 1u;
+                    const float v = acc[m][n][4 * g + e];
+                    out[e] = pos ? v : v * 0.01f;
+                }
+                store_quad_x3(X, 32 * n + j, f0, out);
+            }
+        }
+}
+
+constexpr int X3_LDS_BF16 = 3 * X3_PLANE;
+
+template <bool WITH_JAC>
+__global__ void __launch_bounds__(256, 1)
+geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
+                    const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
+                    int max_pairs, int k, const float* __restrict__ pts, const float* __restrict__ feat_geo, const float* packed,
+                    float rbf, float* __restrict__ pair_tmp, float* __restrict__ jac) {
+    __shared__ __attribute__((aligned(16))) __bf16 X[X3_LDS_BF16];
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
+    const int ntiles = (NP + 63) / 64;
+    const float* packed0 = packed;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gfp pf = launder(packed0);
+        gx3 frag = reinterpret_cast<gx3>(pf + PACKED_FLOATS);
+        // ---- gather: thread = (row, quarter of the 32-d latent); pieces straight into the planes ------------------------------
+        {
+            const int row = tid >> 2, q4 = tid & 3;
+            const int q = tile * 64 + row;
+            int idx = -1, srow = 0;
+            if (q < NP) {
+                const int p = pair_point[q];
+                srow = point_slot ? point_slot[p] : p;
+                idx = nbr[(size_t)srow * k + (q - pair_off[p])];
+            }
+            f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0;
+            if (idx >= 0) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(feat_geo + (size_t)idx * SPF_GEO_DIM + q4 * 8);
+                f0 = src[0];
+                f1 = src[1];
+            }
+            const float lo[4] = {f0[0], f0[1], f0[2], f0[3]}, hi[4] = {f1[0], f1[1], f1[2], f1[3]};
+            store_quad_x3(X, row, q4 * 8, lo);
+            store_quad_x3(X, row, q4 * 8 + 4, hi);
+            if (q4 == 0) {
+                float d[4] = {0.f, 0.f, 0.f, 0.f};
+                if (idx >= 0) {
+                    d[0] = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
+                    d[1] = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
+                    d[2] = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
+                    const float dist = fmaxf(sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]), 1e-12f);
+                    const float sc = dist * rbf;
+                    pair_tmp[(size_t)q * PT_STRIDE] = expf(-(sc * sc));
+                }
+                store_quad_x3(X, row, 32, d);
+                const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                store_quad_x3(X, row, 36, z);
+                store_quad_x3(X, row, 40, z);
+                store_quad_x3(X, row, 44, z);
+            }
+        }
+        __syncthreads();
+
+        f32x16 acc[2][2];
+        uint32_t m1[2], m2[2], m3[2], m4[2];
+        float ssum[2] = {0.f, 0.f};
+        // ---- forward: 35 -> 256 -> 256 -> 256 -> 256 ---------------------------------------------------------------------------
+        zero_acc(acc);
+        gemm_x3<X3_T1>(X, frag + X3_FW1 + wave * (X3_T1 * 2 * 3 * 64) + lane, lane, acc);
+        __syncthreads();
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B1, pf + OFF_V5, wave, lane, m1, ssum);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_x3<X3_TH>(X, frag + X3_FW2 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+        __syncthreads();
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B2, pf + OFF_V5, wave, lane, m2, ssum);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_x3<X3_TH>(X, frag + X3_FW3 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+        __syncthreads();
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B3, pf + OFF_V5, wave, lane, m3, ssum);
+        __syncthreads();
+        zero_acc(acc);
+        gemm_x3<X3_TH>(X, frag + X3_FW4 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+        __syncthreads();
+        // last forward layer: sdf_j = v . a4 + c from the accumulators; the planes receive the Jacobian seed v * lrelu'(h4)
+        fwd_epilogue_x3<1, WITH_JAC>(X, acc, pf + OFF_B4, pf + OFF_V5, wave, lane, m4, ssum);
+        {
+            const int j = lane & 31, kg = lane >> 5;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float t = ssum[n] + __shfl_xor(ssum[n], 32);
+                if (kg == 0) red[wave][32 * n + j] = t;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int q = tile * 64 + tid;
+            if (q < NP) pair_tmp[(size_t)q * PT_STRIDE + 1] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + pf[OFF_C];
+        }
+
+        if (WITH_JAC) {
+            // ---- Jacobian sweep: g_a3 = g_h4 W6 ; g_h3 = g_a3 * D3 ; ... ; J = g_h1 W0 ------------------------------------------
+            zero_acc(acc);
+            gemm_x3<X3_TH>(X, frag + X3_BW4 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+            __syncthreads();
+            bwd_epilogue_x3(X, acc, wave, lane, m3);
+            __syncthreads();
+            zero_acc(acc);
+            gemm_x3<X3_TH>(X, frag + X3_BW3 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+            __syncthreads();
+            bwd_epilogue_x3(X, acc, wave, lane, m2);
+            __syncthreads();
+            zero_acc(acc);
+            gemm_x3<X3_TH>(X, frag + X3_BW2 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+            __syncthreads();
+            bwd_epilogue_x3(X, acc, wave, lane, m1);
+            __syncthreads();
+            // last step 256 -> 35 (padded 64): wave = (feature half m, row half n), one 32x32 tile each
+            {
+                const int m = wave >> 1, n = wave & 1, j = lane & 31, kg = lane >> 5;
+                f32x16 aj;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) aj[r] = 0.f;
+                gx3 wp = frag + X3_JW1 + m * (X3_TH * 3 * 64) + lane;
+#pragma unroll 2
+                for (int t = 0; t < X3_TH; ++t) {
+                    bf16x8 wa[3], xb[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        wa[p] = wp[(t * 3 + p) * 64];
+                        xb[p] = *reinterpret_cast<const bf16x8*>(X + p * X3_PLANE + (32 * n + j) * X3_LDP + 16 * t + 8 * kg);
+                    }
+                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[2], xb[0], aj, 0, 0, 0);
+                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[2], aj, 0, 0, 0);
+                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], xb[1], aj, 0, 0, 0);
+                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], xb[0], aj, 0, 0, 0);
+                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[1], aj, 0, 0, 0);
+                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[0], aj, 0, 0, 0);
+                }
+                const int q = tile * 64 + 32 * n + j;
+                if (q < NP) {
+                    if (m == 0) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<f32x4*>(jac + (size_t)q * SPF_GEO_DIM + 8 * g + 4 * kg) = f32x4{aj[4 * g], aj[4 * g + 1], aj[4 * g + 2], aj[4 * g + 3]};
+                    } else if (kg == 0) {
+                        pair_tmp[(size_t)q * PT_STRIDE + 2] = aj[0];
+                        pair_tmp[(size_t)q * PT_STRIDE + 3] = aj[1];
+                        pair_tmp[(size_t)q * PT_STRIDE + 4] = aj[2];
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the planes are rewritten by the next tile's gather
+    }
+}
+
 }  // namespace
 
 SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_geo)
 
 extern "C" {
 
-int64_t spf_geo_packed_floats(void) { return PACKED_FLOATS; }
+static int g_geo_mode = 0;      // 0: bf16-piece products (fp32-exact), 1: fp32 MFMA
+
+int spf_geo_set_mode(int32_t mode) {
+    if (mode != 0 && mode != 1) return spf::fail(SPF_EINVAL, "spf_geo_set_mode: 0 (split-bf16 products) or 1 (fp32 MFMA), got %d", mode);
+    g_geo_mode = mode;
+    return SPF_OK;
+}
+
+int64_t spf_geo_packed_floats(void) { return PACKED_TOTAL; }
 
 int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
                  const float* w6, const float* b6, const float* w8, const float* b8, const float* wT, const float* bT,
@@ -433,6 +802,7 @@ int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float*
         return spf::fail(SPF_EINVAL, "spf_geo_pack: null pointer");
     PackArgs a{w0, b0, w2, b2, w4, b4, w6, b6, w8, b8, wT, bT};
     geo_pack_kernel<<<spf::div_up(PACKED_FLOATS, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
+    geo_pack_x3_kernel<<<spf::div_up(X3_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + PACKED_FLOATS));
     SPF_LAUNCH_CHECK("geo_pack_kernel");
     return SPF_OK;
 }
@@ -451,7 +821,15 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
     const int tiles = spf::div_up(max_pairs, 64);
     hipStream_t s = (hipStream_t)stream;
     const int blocks = tiles < 512 ? tiles : 512;  // 2 workgroups per CU x 256 CUs, tiles are strided over them
-    if (grad)
+    if (g_geo_mode == 0) {
+        const int b1 = tiles < 256 ? tiles : 256;   // one workgroup per CU (the bf16 planes take 101 KB of LDS)
+        if (grad)
+            geo_pairs_x3_kernel<true><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
+                                                         pair_tmp, jac);
+        else
+            geo_pairs_x3_kernel<false><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
+                                                          rbf, pair_tmp, nullptr);
+    } else if (grad)
         geo_pairs_kernel<true><<<blocks, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
                                                       pair_tmp, jac);
     else

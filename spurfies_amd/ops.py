@@ -85,6 +85,11 @@ class PairList:
         return int(c[0]), int(c[1])
 
 
+def set_geo_mode(mode: str):
+    """'split' (default): fp32-exact products from three bf16 pieces per operand on the bf16 matrix pipe; 'f32': fp32 MFMA."""
+    _lib.check(_lib.lib().spf_geo_set_mode({"split": 0, "f32": 1}[mode]), "spf_geo_set_mode")
+
+
 def pack_geometry_weights(state: dict) -> torch.Tensor:
     """state: {'F_geometry.0.weight', ..., 'T.0.bias'} CUDA float32 tensors -> packed image."""
     names = ["F_geometry.0", "F_geometry.2", "F_geometry.4", "F_geometry.6", "F_geometry.8", "T.0"]

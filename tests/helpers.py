@@ -40,3 +40,17 @@ def check_probes(fx, name, t, rtol, atol):
     np.testing.assert_allclose(flat[idx].numpy(), fx[f"{name}.val"], rtol=rtol, atol=atol, err_msg=name)
     stats = fx[f"{name}.stats"]
     np.testing.assert_allclose(flat.norm().item(), stats[2], rtol=max(rtol, 1e-4), atol=atol, err_msg=name + " l2")
+
+
+def assert_close_except_kinks(actual, desired, rtol, atol, max_frac=1e-3, err_msg=""):
+    """Derivatives of a LeakyReLU network are discontinuous where a pre-activation is zero: when a pre-activation lies within
+    rounding of zero, two correct fp32 evaluations that sum in a different order pick different slopes (1 vs 0.01) for that unit.
+    Such kink flips are rare and isolated: at most `max_frac` of the entries may miss the tolerance, all others must meet it."""
+    import numpy as np
+
+    actual, desired = np.asarray(actual), np.asarray(desired)
+    bad = ~np.isclose(actual, desired, rtol=rtol, atol=atol)
+    frac = float(bad.mean()) if bad.size else 0.0
+    assert frac <= max_frac, f"{err_msg}: {int(bad.sum())} of {bad.size} entries ({frac:.2e}) outside rtol={rtol} atol={atol}"
+    if bad.any():   # and the outliers stay on the scale of the data (a slope flip, not garbage)
+        assert float(np.abs(actual[bad] - desired[bad]).max()) <= float(np.abs(desired).max()), err_msg

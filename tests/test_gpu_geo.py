@@ -1,13 +1,24 @@
-"""GPU parity: fused geometry kernel (gather + RBF + F_geometry/T on fp32 MFMA + Jacobian sweep)
-vs the oracle's torch-CPU restatement (pointneus_disent.py:241-247, 300-323)."""
+"""GPU parity: fused geometry kernel (gather + RBF + F_geometry/T on the matrix cores + Jacobian sweep)
+vs the oracle's torch-CPU restatement (pointneus_disent.py:241-247, 300-323) — in both arithmetic modes: fp32-exact products
+from three bf16 pieces per operand (the default) and plain fp32 MFMA."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import path as P
 from spurfies_amd import synthetic as syn
+from tests.helpers import assert_close_except_kinks
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["split", "f32"])
+def geo_mode(request):
+    from spurfies_amd import ops
+
+    ops.set_geo_mode(request.param)
+    yield request.param
+    ops.set_geo_mode("split")
 
 # fp32 tolerance: the MFMA k-ordered fma chain and the folded last layer (v = T.W8) re-associate
 # sums of ~256 terms; values are O(0.1).  Stated in DESIGN.md §tolerances.
@@ -33,7 +44,7 @@ def _setup(n_points=6000, n_query=5000, seed=0, geo_std=0.3):
     return scene, st, cfg, x, dev, grid, packed
 
 
-def test_sdf_forward_and_gradient_match_oracle():
+def test_sdf_forward_and_gradient_match_oracle(geo_mode):
     from spurfies_amd import ops
 
     scene, st, cfg, x, dev, grid, packed = _setup()
@@ -51,7 +62,8 @@ def test_sdf_forward_and_gradient_match_oracle():
     assert int(n_pts.item()) == int(valid_o.sum())
     np.testing.assert_allclose(res["sdf"].cpu().numpy(), sdf_o.detach().numpy(), rtol=SDF_RTOL, atol=SDF_ATOL)
     v = valid_o.numpy()
-    np.testing.assert_allclose(res["grad"].cpu().numpy()[v], g_o.numpy()[v], rtol=2e-4, atol=2e-5)
+    # d sdf/dx is discontinuous where a pre-activation crosses zero: isolated slope flips are tolerated (tests/helpers.py)
+    assert_close_except_kinks(res["grad"].cpu().numpy()[v], g_o.numpy()[v], rtol=2e-4, atol=2e-5, err_msg="d sdf / dx")
     assert float(res["grad"].cpu()[~valid_o].abs().max()) == 0.0
     # forward-only launch (sampler / eval mode) gives the same sdf bit for bit
     res2 = ops.geo_forward(xt, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=False)
@@ -64,7 +76,7 @@ def test_sdf_forward_and_gradient_match_oracle():
     assert torch.equal(pl.pair_point[:NP_].long().cpu(), torch.repeat_interleave(torch.arange(P_), cnt.cpu()))
 
 
-def test_latent_gradient_matches_oracle():
+def test_latent_gradient_matches_oracle(geo_mode):
     from spurfies_amd import ops
 
     scene, st, cfg, x, dev, grid, packed = _setup(n_query=3000, seed=2)
@@ -83,11 +95,11 @@ def test_latent_gradient_matches_oracle():
     (sdf_o * coef.cpu())[valid_o].sum().backward()
     go = st["neural_feats_geometry"].grad
     # float atomics: summation order differs run to run -> absolute tolerance relative to the largest entry
-    np.testing.assert_allclose(feat.grad.cpu().numpy(), go.numpy(), rtol=5e-4, atol=5e-5 * float(go.abs().max()))
-    np.testing.assert_allclose(xt.grad.cpu().numpy(), xo.grad.numpy(), rtol=5e-4, atol=2e-5)
+    assert_close_except_kinks(feat.grad.cpu().numpy(), go.numpy(), rtol=5e-4, atol=5e-5 * float(go.abs().max()), err_msg="latent gradient")
+    assert_close_except_kinks(xt.grad.cpu().numpy(), xo.grad.numpy(), rtol=5e-4, atol=2e-5, err_msg="x gradient")
 
 
-def test_full_size_linearity_property():
+def test_full_size_linearity_property(geo_mode):
     """At BASELINE size (131072 sampler points) sdf must be unchanged by permuting the query order
     (tiles are independent) and every valid value finite."""
     from spurfies_amd import ops
@@ -220,3 +232,28 @@ def test_rhead_forward_backward_match_torch():
     for n, p_ in zip(names, params):
         gr = st[n].grad
         np.testing.assert_allclose(p_.grad.cpu().numpy(), gr.numpy(), rtol=2e-3, atol=2e-4 * float(gr.abs().max()), err_msg=n)
+
+
+def test_split_products_agree_with_fp32_mfma_kernel():
+    """The default kernel forms every fp32 product exactly from three bf16 pieces per operand; against the fp32-MFMA kernel on the
+    same main-pass-shaped input the SDF agrees to summation-order noise and the Jacobian everywhere except isolated LeakyReLU
+    kinks (tests/helpers.py)."""
+    from spurfies_amd import ops
+
+    scene, st, cfg, x, dev, grid, packed = _setup(n_points=10000, n_query=40000, seed=6)
+    xt = torch.from_numpy(x).cuda()
+    q = grid.query_dense(xt.unsqueeze(1), cfg.k, cfg.r, 1)
+    ps, _, n = ops.compact_points(q["slot_valid"])
+    pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), ps, n)
+    res = {}
+    try:
+        for mode in ("f32", "split"):
+            ops.set_geo_mode(mode)
+            out = ops.geo_forward(xt, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
+            res[mode] = {k: out[k].clone().cpu().numpy() for k in ("sdf", "grad", "wn", "jac")}
+    finally:
+        ops.set_geo_mode("split")
+    np.testing.assert_allclose(res["split"]["sdf"], res["f32"]["sdf"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_array_equal(res["split"]["wn"], res["f32"]["wn"])
+    assert_close_except_kinks(res["split"]["grad"], res["f32"]["grad"], rtol=2e-5, atol=2e-8, err_msg="d sdf / dx")
+    assert_close_except_kinks(res["split"]["jac"], res["f32"]["jac"], rtol=2e-5, atol=2e-8, err_msg="latent Jacobian")
