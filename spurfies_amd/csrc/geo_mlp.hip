@@ -23,6 +23,7 @@
 //   sdf(p) = sum_j w_j sdf_j / sum_j w_j,  w_j = exp(-(rbf * max(|x_pi|, 1e-12))^2)  (detached)
 //   d sdf / d x(p) = sum_j (w_j / norm) d sdf_j / d x_pi
 #include "mlp_tile.h"
+#include "mlp_tile_x3.h"
 
 namespace {
 
@@ -432,12 +433,6 @@ __global__ void geo_pack_kernel(PackArgs a, float* __restrict__ out) {
 // epilogue (+ bias, LeakyReLU, sign bits, split into pieces) rewrites the planes with 8-byte stores.  One 4-wave workgroup per
 // CU (the planes take 101 KB), wave w owns features [64w, 64w+64) x 64 rows as 2x2 tiles.
 // ==============================================================================================================================
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef const __attribute__((address_space(1))) bf16x8* gx3;
-
-constexpr int X3_LDP = 264;                       // plane row stride in bf16 (528 B: 16-B aligned, off the 256-B bank period)
-constexpr int X3_PLANE = 64 * X3_LDP;
 constexpr int X3_T1 = 3;                          // first layer: K = 35 -> 48
 constexpr int X3_TH = 16;                         // 256 / 16
 constexpr int X3_SZ1 = 4 * X3_T1 * 2 * 3 * 64;    // bf16x8 entries
@@ -453,13 +448,6 @@ constexpr int X3_BW2 = X3_BW3 + X3_SZH;
 constexpr int X3_JW1 = X3_BW2 + X3_SZH;
 constexpr int X3_FRAGS = X3_JW1 + X3_SZJ;
 constexpr int PACKED_TOTAL = PACKED_FLOATS + 4 * X3_FRAGS;     // the fp32 image, then the piece fragments (16 B each)
-
-__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
-    a = (__bf16)x;                                // round to nearest even (v_cvt_pk_bf16_f32)
-    const float r1 = x - (float)a;
-    b = (__bf16)r1;
-    c = (__bf16)(r1 - (float)b);
-}
 
 // one thread per fragment slot (region, wave, k16, m, lane): 8 weights -> 3 x bf16x8
 __global__ void geo_pack_x3_kernel(PackArgs a, bf16x8* __restrict__ out) {
@@ -514,58 +502,6 @@ __global__ void geo_pack_x3_kernel(PackArgs a, bf16x8* __restrict__ out) {
     out[base] = p1;
     out[base + 64] = p2;
     out[base + 128] = p3;
-}
-
-// acc[m][n] (features 64w + 32m.., rows 32n..) += W X over T k16-steps.  wp: this wave's fragments of the layer, + lane.
-template <int T>
-__device__ __forceinline__ void gemm_x3(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][2]) {
-    const int j = lane & 31, kg = lane >> 5;
-    bf16x8 wa[2][3], wn[2][3];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) wa[m][p] = wp[(m * 3 + p) * 64];
-#pragma unroll 2
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) wn[m][p] = wp[((t + 1) * 6 + m * 3 + p) * 64];
-        }
-        bf16x8 xb[2][3];
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) xb[n][p] = *reinterpret_cast<const bf16x8*>(X + p * X3_PLANE + (32 * n + j) * X3_LDP + 16 * t + 8 * kg);
-        // smallest terms first; four accumulators alternate
-#define SPF_X3(PW, PX)                                                                                             \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][PW], xb[0][PX], acc[0][0], 0, 0, 0);                   \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][PW], xb[1][PX], acc[0][1], 0, 0, 0);                   \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][PW], xb[0][PX], acc[1][0], 0, 0, 0);                   \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][PW], xb[1][PX], acc[1][1], 0, 0, 0);
-        SPF_X3(2, 0) SPF_X3(0, 2) SPF_X3(1, 1) SPF_X3(1, 0) SPF_X3(0, 1) SPF_X3(0, 0)
-#undef SPF_X3
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wa[m][p] = wn[m][p];
-    }
-}
-
-// write 4 consecutive features of one row as three bf16 quads
-__device__ __forceinline__ void store_quad_x3(__bf16* X, int row, int f0, const float (&v)[4]) {
-    bf16x4 pa, pb, pc;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        __bf16 a, b, c;
-        split3(v[e], a, b, c);
-        pa[e] = a; pb[e] = b; pc[e] = c;
-    }
-    __bf16* dst = X + row * X3_LDP + f0;
-    *reinterpret_cast<bf16x4*>(dst) = pa;
-    *reinterpret_cast<bf16x4*>(dst + X3_PLANE) = pb;
-    *reinterpret_cast<bf16x4*>(dst + 2 * X3_PLANE) = pc;
 }
 
 // acc[m][n][4g + e] = feature 64w + 32m + 8g + 4kg + e of row 32n + j.  mask[m]: bit n * 16 + 4g + e.
@@ -646,6 +582,8 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gfp pf = launder(packed0);
         gx3 frag = reinterpret_cast<gx3>(pf + PACKED_FLOATS);
+        gx3 w_fw1 = frag + X3_FW1 + wave * (X3_T1 * 2 * 3 * 64) + lane;
+        const WFrag3 fr1 = load_wfrag3(w_fw1);                  // in flight during the gather
         // ---- gather: thread = (row, quarter of the 32-d latent); pieces straight into the planes ------------------------------
         {
             const int row = tid >> 2, q4 = tid & 3;
@@ -688,23 +626,26 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
         uint32_t m1[2], m2[2], m3[2], m4[2];
         float ssum[2] = {0.f, 0.f};
         // ---- forward: 35 -> 256 -> 256 -> 256 -> 256 ---------------------------------------------------------------------------
+        gx3 w_fw2 = frag + X3_FW2 + wave * (X3_TH * 2 * 3 * 64) + lane, w_fw3 = frag + X3_FW3 + wave * (X3_TH * 2 * 3 * 64) + lane;
+        gx3 w_fw4 = frag + X3_FW4 + wave * (X3_TH * 2 * 3 * 64) + lane, w_bw4 = frag + X3_BW4 + wave * (X3_TH * 2 * 3 * 64) + lane;
+        gx3 w_bw3 = frag + X3_BW3 + wave * (X3_TH * 2 * 3 * 64) + lane, w_bw2 = frag + X3_BW2 + wave * (X3_TH * 2 * 3 * 64) + lane;
         zero_acc(acc);
-        gemm_x3<X3_T1>(X, frag + X3_FW1 + wave * (X3_T1 * 2 * 3 * 64) + lane, lane, acc);
+        WFrag3 nf = gemm_x3<X3_T1>(X, w_fw1, lane, acc, fr1, w_fw2);
         __syncthreads();
         fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B1, pf + OFF_V5, wave, lane, m1, ssum);
         __syncthreads();
         zero_acc(acc);
-        gemm_x3<X3_TH>(X, frag + X3_FW2 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+        nf = gemm_x3<X3_TH>(X, w_fw2, lane, acc, nf, w_fw3);
         __syncthreads();
         fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B2, pf + OFF_V5, wave, lane, m2, ssum);
         __syncthreads();
         zero_acc(acc);
-        gemm_x3<X3_TH>(X, frag + X3_FW3 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+        nf = gemm_x3<X3_TH>(X, w_fw3, lane, acc, nf, w_fw4);
         __syncthreads();
         fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B3, pf + OFF_V5, wave, lane, m3, ssum);
         __syncthreads();
         zero_acc(acc);
-        gemm_x3<X3_TH>(X, frag + X3_FW4 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+        nf = gemm_x3<X3_TH>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
         __syncthreads();
         // last forward layer: sdf_j = v . a4 + c from the accumulators; the planes receive the Jacobian seed v * lrelu'(h4)
         fwd_epilogue_x3<1, WITH_JAC>(X, acc, pf + OFF_B4, pf + OFF_V5, wave, lane, m4, ssum);
@@ -725,17 +666,17 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
         if (WITH_JAC) {
             // ---- Jacobian sweep: g_a3 = g_h4 W6 ; g_h3 = g_a3 * D3 ; ... ; J = g_h1 W0 ------------------------------------------
             zero_acc(acc);
-            gemm_x3<X3_TH>(X, frag + X3_BW4 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+            nf = gemm_x3<X3_TH>(X, w_bw4, lane, acc, nf, w_bw3);
             __syncthreads();
             bwd_epilogue_x3(X, acc, wave, lane, m3);
             __syncthreads();
             zero_acc(acc);
-            gemm_x3<X3_TH>(X, frag + X3_BW3 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+            nf = gemm_x3<X3_TH>(X, w_bw3, lane, acc, nf, w_bw2);
             __syncthreads();
             bwd_epilogue_x3(X, acc, wave, lane, m2);
             __syncthreads();
             zero_acc(acc);
-            gemm_x3<X3_TH>(X, frag + X3_BW2 + wave * (X3_TH * 2 * 3 * 64) + lane, lane, acc);
+            gemm_x3<X3_TH>(X, w_bw2, lane, acc, nf, nullptr);
             __syncthreads();
             bwd_epilogue_x3(X, acc, wave, lane, m1);
             __syncthreads();
