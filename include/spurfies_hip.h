@@ -165,6 +165,14 @@ int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* j
  * (sum_j wn_j (W6 a_j + b6) = W6 sum_j wn_j a_j + b6, the weights sum to 1), so this stage ends at the mean of the
  * third activation, agg3, and the head stage below applies F_color.6 once per POINT instead of once per pair.
  * ---------------------------------------------------------------------------------------- */
+/* Arithmetic of spf_color_forward / spf_color_backward (process-wide; must be the same for a forward and its backward: the two
+ * modes keep the LeakyReLU sign bits in different layouts).  0 (default): fp32-exact products from three bf16 pieces per operand
+ * on v_mfma_f32_32x32x16_bf16 (see spf_geo_set_mode); spf_color_backward then leaves g_b0 / g_b2 / g_b4 untouched — the bias
+ * gradients are the column sums of G1..G3 and come from spf_wgrad's dbias output.  1: v_mfma_f32_32x32x2_f32, bias gradients
+ * accumulated by spf_color_backward. */
+int spf_color_set_mode(int32_t mode);
+int spf_color_get_mode(void);
+
 int64_t spf_color_packed_floats(void);
 
 /* Pack F_color.{0,2,4} ([out,in] row-major) into forward and transposed fragment order. */
@@ -290,8 +298,10 @@ int64_t spf_wgrad_workspace_floats(int32_t C);
  * fp32-MFMA GEMM only by summation order, at 2.7x the matrix rate.  1: v_mfma_f32_32x32x2_f32 everywhere (verification). */
 int spf_wgrad_set_mode(int32_t mode);
 
+/* dbias (may be NULL): float[256], dbias[o] += sum_rows G[row][o] — the bias gradient of the same layer, taken on the way
+ * (free in the default arithmetic; a separate pass over G otherwise). */
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows,
-              float* dW, int32_t ldw, float* workspace, void* stream);
+              float* dW, int32_t ldw, float* dbias, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Latent tables

@@ -48,6 +48,8 @@ SIGNATURES = {
     "spf_build_pairs": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "spf_geo_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
     "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "spf_color_set_mode": (C.c_int, [_I]),
+    "spf_color_get_mode": (C.c_int, []),
     "spf_color_packed_floats": (C.c_int64, []),
     "spf_color_pack": (C.c_int, [_P] * 8),
     "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -64,7 +66,7 @@ SIGNATURES = {
     "spf_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "spf_wgrad_workspace_floats": (C.c_int64, [_I]),
     "spf_wgrad_set_mode": (C.c_int, [_I]),
-    "spf_wgrad": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _I, _P, _P]),
+    "spf_wgrad": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
     "spf_scatter_add_rows": (C.c_int, [_P, _P, C.c_int64, _I, _P, _P]),
     "spf_tv_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),

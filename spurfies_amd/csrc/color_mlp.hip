@@ -19,6 +19,7 @@
 //   * the weight gradients dW_l = G_l^T A_{l-1} are plain GEMMs over [rows,256] buffers (spf_wgrad, wgrad.hip)
 //     (G_l = gradient w.r.t. layer l's pre-activation, stored by the backward kernel).
 #include "mlp_tile.h"
+#include "mlp_tile_x3.h"
 
 namespace {
 
@@ -467,19 +468,500 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
     }
 }
 
+
+// ==============================================================================================================================
+// The same two kernels on the bf16 matrix pipe with fp32-EXACT products from three bf16 pieces per operand (the default;
+// spf_color_set_mode(1) selects the fp32-MFMA kernels above).  Engine and arithmetic argument: mlp_tile_x3.h / geo_mlp.hip.
+//   * layers 0 and 2 run as transposed products (a lane owns 4 consecutive features of one row, the epilogue rewrites the bf16
+//     planes with 8-byte stores); layer 4 — whose output only feeds the RBF-weighted mean — runs non-transposed, so that a lane
+//     owns a column strip and takes the segmented weighted sum straight from its accumulators, as the fp32 kernel does;
+//   * LeakyReLU sign bits are kept ROW-MAJOR in HBM (masks[tile][layer][row][8 words], bit = feature & 31), a layout any
+//     accumulator arrangement can read: transposed epilogues combine the two k-halves of a row word with one shuffle, the
+//     non-transposed layer gets a row word per accumulator register from the wave ballot;
+//   * the layer inputs / pre-activation gradients the weight-gradient GEMM reads are written as fp32 rows rebuilt exactly from
+//     the planes (p1 + p2 + p3), coalesced; bias gradients come from the weight-gradient GEMM (column sums of G, spf_wgrad).
+// ==============================================================================================================================
+constexpr int CX_T1 = 7;                          // layer 0: K = 104 -> 112
+constexpr int CX_TH = 16;
+constexpr int CX_SZ1 = 4 * CX_T1 * 2 * 3 * 64;    // bf16x8 entries
+constexpr int CX_SZH = 4 * CX_TH * 2 * 3 * 64;
+constexpr int CX_SZL = 2 * CX_TH * 3 * 64;
+constexpr int CX_FW1 = 0;
+constexpr int CX_FW2 = CX_FW1 + CX_SZ1;
+constexpr int CX_FW3 = CX_FW2 + CX_SZH;
+constexpr int CX_BW3 = CX_FW3 + CX_SZH;
+constexpr int CX_BW2 = CX_BW3 + CX_SZH;
+constexpr int CX_BWL = CX_BW2 + CX_SZH;
+constexpr int CX_FRAGS = CX_BWL + CX_SZL;
+constexpr int C_PACKED_TOTAL = C_PACKED + 4 * CX_FRAGS;
+
+__global__ void color_pack_x3_kernel(CPackArgs a, bf16x8* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int N1 = CX_SZ1 / 3, NH = CX_SZH / 3, NL = CX_SZL / 3;
+    if (s >= N1 + 4 * NH + NL) return;
+    int region, local;
+    if (s < N1) { region = 0; local = s; }
+    else if (s < N1 + 4 * NH) { region = 1 + (s - N1) / NH; local = (s - N1) % NH; }
+    else { region = 5; local = s - N1 - 4 * NH; }
+    const int ln = local & 63, i = ln & 31, kg = ln >> 5;
+    float w[8];
+    size_t base;
+    if (region < 5) {
+        const int T = region == 0 ? CX_T1 : CX_TH;
+        const int m = (local >> 6) & 1, t = (local >> 7) % T, wv = (local >> 7) / T;
+        const int f = 64 * wv + 32 * m + i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * t + 8 * kg + e;
+            float v;
+            switch (region) {
+                case 0: v = k < C_IN ? a.w0[f * C_IN + c_orig(k)] : 0.f; break;
+                case 1: v = a.w2[f * 256 + k]; break;
+                case 2: v = a.w4[f * 256 + k]; break;
+                case 3: v = a.w4[k * 256 + f]; break;      // g_a2[f] = sum_o G3[o] W4[o][f]
+                default: v = a.w2[k * 256 + f]; break;
+            }
+            w[e] = v;
+        }
+        const int rb = region == 0 ? CX_FW1 : CX_FW2 + (region - 1) * CX_SZH;
+        base = (size_t)rb + (size_t)((wv * T + t) * 2 + m) * 3 * 64 + ln;
+    } else {
+        const int t = (local >> 6) % CX_TH, m = (local >> 6) / CX_TH;
+        const int f = 32 * m + i;                         // latent column 0..63 = reference column 39 + f
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = a.w0[(16 * t + 8 * kg + e) * C_IN + 39 + f];
+        base = (size_t)CX_BWL + (size_t)(m * CX_TH + t) * 3 * 64 + ln;
+    }
+    bf16x8 p1, p2, p3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        __bf16 x, y, z;
+        split3(w[e], x, y, z);
+        p1[e] = x; p2[e] = y; p3[e] = z;
+    }
+    out[base] = p1;
+    out[base + 64] = p2;
+    out[base + 128] = p3;
+}
+
+// transposed forward epilogue: a = lrelu(acc + b) -> planes; sign bits as row words (STORE): masks_l[row][8], word 2 wave + m
+template <bool STORE>
+__device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], gfp bias, int wave, int lane, uint32_t* masks_l) {
+    const int j = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        uint32_t bits[2] = {0u, 0u};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+            const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(bias + f0);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float out[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[m][n][4 * g + e] + bv[e];
+                    const bool pos = v > 0.f;
+                    bits[n] |= (pos ? 1u : 0u) << (8 * g + 4 * kg + e);
+                    out[e] = pos ? v : v * 0.01f;
+                }
+                store_quad_x3(X, 32 * n + j, f0, out);
+            }
+        }
+        if (STORE) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const uint32_t word = bits[n] | __shfl_xor(bits[n], 32);
+                if (kg == 0) masks_l[(32 * n + j) * 8 + 2 * wave + m] = word;
+            }
+        }
+    }
+}
+
+// transposed backward epilogue: g_h = g_a * lrelu'(h) with the row words `mw[m][n]` (word 2 wave + m of row 32 n + j) -> planes
+__device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mw)[2][2]) {
+    const int j = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float out[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool pos = (mw[m][n] >> (8 * g + 4 * kg + e)) & 1u;
+                    const float v = acc[m][n][4 * g + e];
+                    out[e] = pos ? v : v * 0.01f;
+                }
+                store_quad_x3(X, 32 * n + j, f0, out);
+            }
+        }
+}
+
+// one pair row's gather operands: a quarter of the colour latent, the offset x - p_i, the RBF weight and the point index
+struct CxRow {
+    f32x4 f[4];
+    float d[3];
+    float w;
+    int p, idx;
+};
+__device__ __forceinline__ CxRow cx_fetch_row(int idx, int srow, int p, int q, int q4, const float* __restrict__ x, const float* __restrict__ pts,
+                                              const float* __restrict__ feat_col, const float* __restrict__ wn) {
+    CxRow r;
+    r.idx = idx;
+    r.p = p;
+    r.w = 0.f;
+    r.d[0] = r.d[1] = r.d[2] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r.f[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (idx >= 0) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(feat_col + (size_t)idx * SPF_COL_DIM + q4 * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r.f[u] = src[u];
+        r.d[0] = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
+        r.d[1] = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
+        r.d[2] = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
+        r.w = wn[q];
+    }
+    return r;
+}
+
+constexpr int CX_LDS_BF16 = 3 * X3_PLANE;
+
+template <bool STORE>
+__global__ void __launch_bounds__(256, 1)
+color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
+                        const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
+                        const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k, const float* __restrict__ pts,
+                        const float* __restrict__ feat_col, const float* packed, float* __restrict__ agg3, float* __restrict__ act0,
+                        float* __restrict__ act1, float* __restrict__ act2, uint32_t* __restrict__ masks) {
+    __shared__ __attribute__((aligned(16))) __bf16 X[CX_LDS_BF16];
+    __shared__ __attribute__((aligned(8))) float s_wp[128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
+    const int ntiles = (NP + 63) / 64;
+    const float* packed0 = packed;
+    T_DECL
+    CxRow cur;
+    {
+        const int q = blockIdx.x * 64 + (tid >> 2);
+        int p = -1, srow = 0, idx = -1;
+        if (q < NP) {
+            p = pair_point[q];
+            srow = point_slot ? point_slot[p] : p;
+            idx = nbr[(size_t)srow * k + (q - pair_off[p])];
+        }
+        cur = cx_fetch_row(idx, srow, p, q, tid & 3, x, pts, feat_col, wn);
+    }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gfp pf = launder(packed0);
+        gx3 frag = reinterpret_cast<gx3>(pf + C_PACKED);
+        gx3 w_fw1 = frag + CX_FW1 + wave * (CX_T1 * 2 * 3 * 64) + lane;
+        gx3 w_fw2 = frag + CX_FW2 + wave * (CX_TH * 2 * 3 * 64) + lane;
+        gx3 w_fw3 = frag + CX_FW3 + wave * (CX_TH * 2 * 3 * 64) + lane;
+        const WFrag3 fr1 = load_wfrag3(w_fw1);
+        T_MARK(15)
+        // ---- gather: thread = (row, quarter): 16 latent floats + a share of the positional encoding, pieces into the planes; the
+        //      operands were requested during the previous tile (lookup chain pair -> point -> slot -> neighbour -> latent row)
+        {
+            const int row = tid >> 2, q4 = tid & 3;
+            const int idx = cur.idx;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v[4] = {cur.f[u][0], cur.f[u][1], cur.f[u][2], cur.f[u][3]};
+                store_quad_x3(X, row, q4 * 16 + 4 * u, v);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) {
+                const int jx = q4 + 4 * jj;          // 0..17 -> (l, c)
+                if (jx < 3 * N_FREQ) {
+                    const int l = jx / 3, c = jx % 3;
+                    float sv = 0.f, cv = 0.f;
+                    if (idx >= 0) {
+                        const float a = cur.d[c] * (float)(1 << l);
+                        sv = sinf(a);
+                        cv = cosf(a);
+                    }
+                    store_one_x3(X, row, 64 + 3 + 6 * l + c, sv);
+                    store_one_x3(X, row, 64 + 6 + 6 * l + c, cv);
+                }
+            }
+            if (q4 == 0) {
+                store_one_x3(X, row, 64, cur.d[0]);
+                store_one_x3(X, row, 65, cur.d[1]);
+                store_one_x3(X, row, 66, cur.d[2]);
+                store_one_x3(X, row, 103, 0.f);          // pad column of the 104-wide internal layout
+                const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                store_quad_x3(X, row, 104, z);           // K padded to 112
+                store_quad_x3(X, row, 108, z);
+                s_wp[2 * row] = cur.w;
+                s_wp[2 * row + 1] = __int_as_float(idx >= 0 ? cur.p : -1);
+            }
+        }
+        const int qn = (tile + (int)gridDim.x) * 64 + (tid >> 2);      // this thread's row in the workgroup's next tile
+        int n_p = qn < NP ? pair_point[qn] : -1, n_srow = 0, n_off = 0, n_idx = -1;
+        T_MARK(0)
+        lds_barrier();
+        T_MARK(1)
+        if (STORE) store_tile_from_planes<13>(X, act0 + (size_t)tile * 64 * C_INP, C_INP, tid);      // [64][104] fp32, layer-0 input
+        uint32_t* mk = STORE ? masks + (size_t)tile * 3 * 512 : nullptr;                             // [layer 3][row 64][8 words]
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        WFrag3 nf = gemm_x3<CX_T1>(X, w_fw1, lane, acc, fr1, w_fw2);
+        T_MARK(2)
+        lds_barrier();
+        T_MARK(3)
+        cx_fwd_epilogue<STORE>(X, acc, pf + CO_B1, wave, lane, mk);
+        T_MARK(4)
+        lds_barrier();
+        T_MARK(5)
+        if (n_p >= 0) {
+            n_srow = point_slot ? point_slot[n_p] : n_p;
+            n_off = pair_off[n_p];
+        }
+        if (STORE) store_tile_from_planes<32>(X, act1 + (size_t)tile * 64 * 256, 256, tid);
+        zero_acc(acc);
+        nf = gemm_x3<CX_TH>(X, w_fw2, lane, acc, nf, w_fw3);
+        T_MARK(6)
+        lds_barrier();
+        T_MARK(7)
+        cx_fwd_epilogue<STORE>(X, acc, pf + CO_B2, wave, lane, STORE ? mk + 512 : nullptr);
+        T_MARK(8)
+        lds_barrier();
+        T_MARK(9)
+        if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
+        if (STORE) store_tile_from_planes<32>(X, act2 + (size_t)tile * 64 * 256, 256, tid);
+        // ---- layer 4, NON-transposed: acc[m][n] = rows 32m.., features 64w + 32n..; lane (feature j, k-half kg) ------------------
+        zero_acc(acc);
+        gemm_x3<CX_TH, true>(X, w_fw3, lane, acc, nf, nullptr);
+        T_MARK(10)
+        cur = cx_fetch_row(n_idx, n_srow, n_p, qn, tid & 3, x, pts, feat_col, wn);      // lands during the epilogue
+        // ---- + bias, LeakyReLU, sign words by ballot, RBF-weighted segmented sum from the accumulators -> atomics ---------------
+        {
+            const int j = lane & 31, kg = lane >> 5;
+            const int c0 = 64 * wave + j;
+            const float bv[2] = {pf[CO_B3 + c0], pf[CO_B3 + c0 + 32]};
+            int cur = -1;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * m + 8 * (r >> 2) + 4 * kg + (r & 3);
+                    const float2 wp = *reinterpret_cast<const float2*>(s_wp + 2 * row);
+                    const int p = __float_as_int(wp.y);
+                    float v0 = acc[m][0][r] + bv[0], v1 = acc[m][1][r] + bv[1];
+                    const bool p0 = v0 > 0.f, p1 = v1 > 0.f;
+                    if (STORE) {     // ballot: low 32 lanes = row (kg = 0), high 32 = row + 4 (kg = 1); bit = feature & 31
+                        const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
+                        if (lane == 0) {
+                            const int rlo = 32 * m + 8 * (r >> 2) + (r & 3);
+                            mk[1024 + rlo * 8 + 2 * wave] = (uint32_t)b0;
+                            mk[1024 + rlo * 8 + 2 * wave + 1] = (uint32_t)b1;
+                            mk[1024 + (rlo + 4) * 8 + 2 * wave] = (uint32_t)(b0 >> 32);
+                            mk[1024 + (rlo + 4) * 8 + 2 * wave + 1] = (uint32_t)(b1 >> 32);
+                        }
+                    }
+                    v0 = p0 ? v0 : v0 * 0.01f;
+                    v1 = p1 ? v1 : v1 * 0.01f;
+                    if (p != cur) {
+                        if (cur >= 0) {
+                            atomicAdd(&agg3[(size_t)cur * 256 + c0], a0);
+                            atomicAdd(&agg3[(size_t)cur * 256 + c0 + 32], a1);
+                        }
+                        cur = p;
+                        a0 = 0.f;
+                        a1 = 0.f;
+                    }
+                    a0 += wp.x * v0;
+                    a1 += wp.x * v1;
+                }
+            if (cur >= 0) {
+                atomicAdd(&agg3[(size_t)cur * 256 + c0], a0);
+                atomicAdd(&agg3[(size_t)cur * 256 + c0 + 32], a1);
+            }
+        }
+        T_MARK(13)
+        lds_barrier();       // planes and s_wp are rewritten by the next tile's gather
+        T_MARK(14)
+    }
+    T_FLUSH
+}
+
+// one pair row's operands of the backward's first stage: a quarter of g_agg3[p], the RBF weight, the neighbour index and the
+// two layer-3 sign words of the quarter
+struct CxGrow {
+    f32x4 ga[16];
+    float w;
+    int idx;
+    uint32_t m0, m1;
+};
+__device__ __forceinline__ CxGrow cx_fetch_grow(const float* __restrict__ g_agg3, const uint32_t* __restrict__ mk, int p, int idx, float w, int row,
+                                                int q4) {
+    CxGrow r;
+    r.w = w;
+    r.idx = idx;
+    r.m0 = mk[1024 + row * 8 + 2 * q4];
+    r.m1 = mk[1024 + row * 8 + 2 * q4 + 1];
+    const f32x4* ga = reinterpret_cast<const f32x4*>(g_agg3 + (size_t)(p < 0 ? 0 : p) * 256 + 64 * q4);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) r.ga[u] = ga[u];
+    return r;
+}
+
+__global__ void __launch_bounds__(256, 1)
+color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
+                         const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
+                         const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k, const float* packed,
+                         const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3,
+                         float* __restrict__ g_feat_col) {
+    __shared__ __attribute__((aligned(16))) __bf16 X[CX_LDS_BF16];
+    __shared__ int s_idx[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
+    const int ntiles = (NP + 63) / 64;
+    const float* packed0 = packed;
+    T_DECL
+    CxGrow cur;
+    {
+        const int q = blockIdx.x * 64 + (tid >> 2);
+        int p = -1, idx = -1;
+        float w = 0.f;
+        if (q < NP) {
+            p = pair_point[q];
+            const int srow = point_slot ? point_slot[p] : p;
+            idx = nbr[(size_t)srow * k + (q - pair_off[p])];
+            w = wn[q];
+        }
+        cur = cx_fetch_grow(g_agg3, masks + (size_t)blockIdx.x * 3 * 512, p, idx, w, tid >> 2, tid & 3);
+    }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gfp pf = launder(packed0);
+        gx3 frag = reinterpret_cast<gx3>(pf + C_PACKED);
+        gx3 w_bw3 = frag + CX_BW3 + wave * (CX_TH * 2 * 3 * 64) + lane;
+        gx3 w_bw2 = frag + CX_BW2 + wave * (CX_TH * 2 * 3 * 64) + lane;
+        const WFrag3 fr3 = load_wfrag3(w_bw3);
+        const size_t tbase = (size_t)tile * 64 * 256;
+        const uint32_t* mk = masks + (size_t)tile * 3 * 512;
+        // ---- G3[row] = wn[row] g_agg3[p] * lrelu'(h3): thread = (row, quarter of the 256 features) -> planes; the operands were
+        //      requested during the previous tile
+        const int row0 = tid >> 2, q40 = tid & 3;
+        {
+            if (q40 == 0) s_idx[row0] = cur.idx;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t word = u < 8 ? cur.m0 : cur.m1;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool pos = (word >> ((4 * u + e) & 31)) & 1u;
+                    const float t = cur.w != 0.f ? cur.ga[u][e] * cur.w : 0.f;
+                    o[e] = pos ? t : t * 0.01f;
+                }
+                store_quad_x3(X, row0, 64 * q40 + 4 * u, o);
+            }
+        }
+        const int next_tile = tile + (int)gridDim.x;
+        const int qn = next_tile * 64 + row0;
+        int n_p = -1, n_srow = 0, n_off = 0, n_idx = -1;
+        float n_w = 0.f;
+        if (qn < NP) {
+            n_p = pair_point[qn];
+            n_w = wn[qn];
+        }
+        T_MARK(16)
+        lds_barrier();
+        T_MARK(17)
+        store_tile_from_planes<32>(X, G3 + tbase, 256, tid);          // exactly the values the planes hold (p1 + p2 + p3)
+        f32x16 acc[2][2];
+        const int j = lane & 31;
+        uint32_t mw[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) mw[m][n] = mk[512 + (32 * n + j) * 8 + 2 * wave + m];       // layer-2 sign words, before the GEMM
+        zero_acc(acc);
+        WFrag3 nf = gemm_x3<CX_TH>(X, w_bw3, lane, acc, fr3, w_bw2);
+        T_MARK(18)
+        lds_barrier();
+        T_MARK(19)
+        cx_bwd_epilogue(X, acc, wave, lane, mw);
+        T_MARK(20)
+        lds_barrier();
+        T_MARK(21)
+        store_tile_from_planes<32>(X, G2 + tbase, 256, tid);
+        if (n_p >= 0) {
+            n_srow = point_slot ? point_slot[n_p] : n_p;
+            n_off = pair_off[n_p];
+        }
+        T_MARK(22)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) mw[m][n] = mk[(32 * n + j) * 8 + 2 * wave + m];
+        zero_acc(acc);
+        gemm_x3<CX_TH>(X, w_bw2, lane, acc, nf, nullptr);
+        T_MARK(18)
+        gx3 w_bwl = frag + CX_BWL + (wave >> 1) * (CX_TH * 3 * 64) + lane;
+        const WFrag1 frl = load_wfrag1(w_bwl);
+        lds_barrier();
+        T_MARK(19)
+        cx_bwd_epilogue(X, acc, wave, lane, mw);
+        T_MARK(20)
+        lds_barrier();
+        T_MARK(21)
+        store_tile_from_planes<32>(X, G1 + tbase, 256, tid);
+        if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
+        if (next_tile < ntiles) cur = cx_fetch_grow(g_agg3, masks + (size_t)next_tile * 3 * 512, n_p, n_idx, n_w, row0, q40);
+        T_MARK(22)
+        // ---- d/d latent = G1 W0[:, 39:103]: wave = (latent half m, row half n), one 32x32 tile each; scatter-add -------------------
+        {
+            const int m = wave >> 1, n = wave & 1, kg = lane >> 5;
+            const f32x16 aj = gemm_x3_tile<CX_TH>(X, n, w_bwl, lane, frl);
+            const int idx = s_idx[32 * n + j];
+            if (idx >= 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    atomicAdd(&g_feat_col[(size_t)idx * SPF_COL_DIM + 32 * m + 8 * (r >> 2) + 4 * kg + (r & 3)], aj[r]);
+            }
+        }
+        T_MARK(23)
+        lds_barrier();
+        T_MARK(24)
+    }
+    T_FLUSH
+}
+
 }  // namespace
 
 SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_color)
 
 extern "C" {
 
-int64_t spf_color_packed_floats(void) { return C_PACKED; }
+static int g_color_mode = 0;      // 0: bf16-piece products (fp32-exact), 1: fp32 MFMA
+
+int spf_color_set_mode(int32_t mode) {
+    if (mode != 0 && mode != 1) return spf::fail(SPF_EINVAL, "spf_color_set_mode: 0 (split-bf16 products) or 1 (fp32 MFMA), got %d", mode);
+    g_color_mode = mode;
+    return SPF_OK;
+}
+
+int spf_color_get_mode(void) { return g_color_mode; }
+
+int64_t spf_color_packed_floats(void) { return C_PACKED_TOTAL; }
 
 int spf_color_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
                    float* packed, void* stream) {
     if (!w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !packed) return spf::fail(SPF_EINVAL, "spf_color_pack: null pointer");
     CPackArgs a{w0, b0, w2, b2, w4, b4};
     color_pack_kernel<<<spf::div_up(C_PACKED, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
+    color_pack_x3_kernel<<<spf::div_up(CX_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + C_PACKED));
     SPF_LAUNCH_CHECK("color_pack_kernel");
     return SPF_OK;
 }
@@ -496,6 +978,17 @@ int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const
     if (store && (!act1 || !act2 || !masks)) return spf::fail(SPF_EINVAL, "spf_color_forward: training buffers must be given together");
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
+    if (g_color_mode == 0) {
+        const int b1 = tiles < 256 ? tiles : 256;   // one workgroup per CU (bf16 planes: 101 KB of LDS)
+        if (store)
+            color_forward_x3_kernel<true><<<b1, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts,
+                                                                               feat_color, packed, agg3, act0, act1, act2, masks);
+        else
+            color_forward_x3_kernel<false><<<b1, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k,
+                                                                                pts, feat_color, packed, agg3, nullptr, nullptr, nullptr, nullptr);
+        SPF_LAUNCH_CHECK("color_forward_x3_kernel");
+        return SPF_OK;
+    }
     if (store)
         color_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts,
                                                                             feat_color, packed, agg3, act0, act1, act2, masks);
@@ -516,6 +1009,13 @@ int spf_color_backward(const float* g_agg3, const int32_t* nbr, const float* wn,
         return spf::fail(SPF_EINVAL, "spf_color_backward: null pointer");
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
+    if (g_color_mode == 0) {    // bias gradients come from spf_wgrad (dbias) in this mode: g_b0 / g_b2 / g_b4 are not touched
+        const int b1 = tiles < 256 ? tiles : 256;
+        color_backward_x3_kernel<<<b1, 256, 0, (hipStream_t)stream>>>(g_agg3, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
+                                                                      masks, G1, G2, G3, g_feat_color);
+        SPF_LAUNCH_CHECK("color_backward_x3_kernel");
+        return SPF_OK;
+    }
     color_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_agg3, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
                                                                    masks, G1, G2, G3, g_b0, g_b2, g_b4, g_feat_color);
     SPF_LAUNCH_CHECK("color_backward_kernel");

@@ -565,6 +565,29 @@ __device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
 
 constexpr int X3_LDS_BF16 = 3 * X3_PLANE;
 
+// one pair row's gather operands: a quarter of the geometry latent, the offset x - p_i, the neighbour index
+struct GxRow {
+    f32x4 f0, f1;
+    float d[3];
+    int idx;
+};
+__device__ __forceinline__ GxRow gx_fetch_row(int idx, int srow, int q4, const float* __restrict__ x, const float* __restrict__ pts,
+                                              const float* __restrict__ feat_geo) {
+    GxRow r;
+    r.idx = idx;
+    r.f0 = r.f1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.d[0] = r.d[1] = r.d[2] = 0.f;
+    if (idx >= 0) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(feat_geo + (size_t)idx * SPF_GEO_DIM + q4 * 8);
+        r.f0 = src[0];
+        r.f1 = src[1];
+        r.d[0] = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
+        r.d[1] = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
+        r.d[2] = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
+    }
+    return r;
+}
+
 template <bool WITH_JAC>
 __global__ void __launch_bounds__(256, 1)
 geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
@@ -578,49 +601,52 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
     const int ntiles = (NP + 63) / 64;
     const float* packed0 = packed;
+    T_DECL
+    GxRow cur;
+    {
+        const int q = blockIdx.x * 64 + (tid >> 2);
+        int srow = 0, idx = -1;
+        if (q < NP) {
+            const int p = pair_point[q];
+            srow = point_slot ? point_slot[p] : p;
+            idx = nbr[(size_t)srow * k + (q - pair_off[p])];
+        }
+        cur = gx_fetch_row(idx, srow, tid & 3, x, pts, feat_geo);
+    }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gfp pf = launder(packed0);
         gx3 frag = reinterpret_cast<gx3>(pf + PACKED_FLOATS);
         gx3 w_fw1 = frag + X3_FW1 + wave * (X3_T1 * 2 * 3 * 64) + lane;
         const WFrag3 fr1 = load_wfrag3(w_fw1);                  // in flight during the gather
-        // ---- gather: thread = (row, quarter of the 32-d latent); pieces straight into the planes ------------------------------
+        T_MARK(31)
+        // ---- gather: thread = (row, quarter of the 32-d latent); pieces straight into the planes.  The operands were requested
+        //      during the previous tile (lookup chain pair -> point -> slot -> neighbour -> latent row).
+        const int row0 = tid >> 2, q40 = tid & 3;
         {
-            const int row = tid >> 2, q4 = tid & 3;
-            const int q = tile * 64 + row;
-            int idx = -1, srow = 0;
-            if (q < NP) {
-                const int p = pair_point[q];
-                srow = point_slot ? point_slot[p] : p;
-                idx = nbr[(size_t)srow * k + (q - pair_off[p])];
-            }
-            f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0;
-            if (idx >= 0) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(feat_geo + (size_t)idx * SPF_GEO_DIM + q4 * 8);
-                f0 = src[0];
-                f1 = src[1];
-            }
-            const float lo[4] = {f0[0], f0[1], f0[2], f0[3]}, hi[4] = {f1[0], f1[1], f1[2], f1[3]};
-            store_quad_x3(X, row, q4 * 8, lo);
-            store_quad_x3(X, row, q4 * 8 + 4, hi);
-            if (q4 == 0) {
-                float d[4] = {0.f, 0.f, 0.f, 0.f};
-                if (idx >= 0) {
-                    d[0] = x[(size_t)srow * 3] - pts[(size_t)idx * 3];
-                    d[1] = x[(size_t)srow * 3 + 1] - pts[(size_t)idx * 3 + 1];
-                    d[2] = x[(size_t)srow * 3 + 2] - pts[(size_t)idx * 3 + 2];
+            const int q = tile * 64 + row0;
+            const float lo[4] = {cur.f0[0], cur.f0[1], cur.f0[2], cur.f0[3]}, hi[4] = {cur.f1[0], cur.f1[1], cur.f1[2], cur.f1[3]};
+            store_quad_x3(X, row0, q40 * 8, lo);
+            store_quad_x3(X, row0, q40 * 8 + 4, hi);
+            if (q40 == 0) {
+                float d[4] = {cur.d[0], cur.d[1], cur.d[2], 0.f};
+                if (cur.idx >= 0) {
                     const float dist = fmaxf(sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]), 1e-12f);
                     const float sc = dist * rbf;
                     pair_tmp[(size_t)q * PT_STRIDE] = expf(-(sc * sc));
                 }
-                store_quad_x3(X, row, 32, d);
+                store_quad_x3(X, row0, 32, d);
                 const float z[4] = {0.f, 0.f, 0.f, 0.f};
-                store_quad_x3(X, row, 36, z);
-                store_quad_x3(X, row, 40, z);
-                store_quad_x3(X, row, 44, z);
+                store_quad_x3(X, row0, 36, z);
+                store_quad_x3(X, row0, 40, z);
+                store_quad_x3(X, row0, 44, z);
             }
         }
-        __syncthreads();
+        const int qn = (tile + (int)gridDim.x) * 64 + row0;       // this thread's row in the workgroup's next tile
+        int n_p = qn < NP ? pair_point[qn] : -1, n_srow = 0, n_off = 0, n_idx = -1;
+        T_MARK(0)
+        lds_barrier();
+        T_MARK(1)
 
         f32x16 acc[2][2];
         uint32_t m1[2], m2[2], m3[2], m4[2];
@@ -631,22 +657,42 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
         gx3 w_bw3 = frag + X3_BW3 + wave * (X3_TH * 2 * 3 * 64) + lane, w_bw2 = frag + X3_BW2 + wave * (X3_TH * 2 * 3 * 64) + lane;
         zero_acc(acc);
         WFrag3 nf = gemm_x3<X3_T1>(X, w_fw1, lane, acc, fr1, w_fw2);
-        __syncthreads();
+        T_MARK(2)
+        lds_barrier();
+        T_MARK(3)
         fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B1, pf + OFF_V5, wave, lane, m1, ssum);
-        __syncthreads();
+        T_MARK(4)
+        lds_barrier();
+        T_MARK(5)
+        if (n_p >= 0) {
+            n_srow = point_slot ? point_slot[n_p] : n_p;
+            n_off = pair_off[n_p];
+        }
         zero_acc(acc);
         nf = gemm_x3<X3_TH>(X, w_fw2, lane, acc, nf, w_fw3);
-        __syncthreads();
+        T_MARK(2)
+        lds_barrier();
+        T_MARK(3)
         fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B2, pf + OFF_V5, wave, lane, m2, ssum);
-        __syncthreads();
+        T_MARK(4)
+        lds_barrier();
+        T_MARK(5)
+        if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
         zero_acc(acc);
         nf = gemm_x3<X3_TH>(X, w_fw3, lane, acc, nf, w_fw4);
-        __syncthreads();
+        T_MARK(2)
+        lds_barrier();
+        T_MARK(3)
         fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B3, pf + OFF_V5, wave, lane, m3, ssum);
-        __syncthreads();
+        T_MARK(4)
+        lds_barrier();
+        T_MARK(5)
+        cur = gx_fetch_row(n_idx, n_srow, q40, x, pts, feat_geo);
         zero_acc(acc);
         nf = gemm_x3<X3_TH>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
-        __syncthreads();
+        T_MARK(2)
+        lds_barrier();
+        T_MARK(3)
         // last forward layer: sdf_j = v . a4 + c from the accumulators; the planes receive the Jacobian seed v * lrelu'(h4)
         fwd_epilogue_x3<1, WITH_JAC>(X, acc, pf + OFF_B4, pf + OFF_V5, wave, lane, m4, ssum);
         {
@@ -657,7 +703,9 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
                 if (kg == 0) red[wave][32 * n + j] = t;
             }
         }
-        __syncthreads();
+        T_MARK(6)
+        lds_barrier();
+        T_MARK(7)
         if (tid < 64) {
             const int q = tile * 64 + tid;
             if (q < NP) pair_tmp[(size_t)q * PT_STRIDE + 1] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + pf[OFF_C];
@@ -667,41 +715,37 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
             // ---- Jacobian sweep: g_a3 = g_h4 W6 ; g_h3 = g_a3 * D3 ; ... ; J = g_h1 W0 ------------------------------------------
             zero_acc(acc);
             nf = gemm_x3<X3_TH>(X, w_bw4, lane, acc, nf, w_bw3);
-            __syncthreads();
+            T_MARK(10)
+            lds_barrier();
+            T_MARK(11)
             bwd_epilogue_x3(X, acc, wave, lane, m3);
-            __syncthreads();
+            T_MARK(12)
+            lds_barrier();
+            T_MARK(13)
             zero_acc(acc);
             nf = gemm_x3<X3_TH>(X, w_bw3, lane, acc, nf, w_bw2);
-            __syncthreads();
+            T_MARK(10)
+            lds_barrier();
+            T_MARK(11)
             bwd_epilogue_x3(X, acc, wave, lane, m2);
-            __syncthreads();
+            T_MARK(12)
+            lds_barrier();
+            T_MARK(13)
             zero_acc(acc);
             gemm_x3<X3_TH>(X, w_bw2, lane, acc, nf, nullptr);
-            __syncthreads();
+            T_MARK(10)
+            gx3 w_jw1 = frag + X3_JW1 + (wave >> 1) * (X3_TH * 3 * 64) + lane;
+            const WFrag1 frj = load_wfrag1(w_jw1);
+            lds_barrier();
+            T_MARK(11)
             bwd_epilogue_x3(X, acc, wave, lane, m1);
-            __syncthreads();
+            T_MARK(12)
+            lds_barrier();
+            T_MARK(13)
             // last step 256 -> 35 (padded 64): wave = (feature half m, row half n), one 32x32 tile each
             {
                 const int m = wave >> 1, n = wave & 1, j = lane & 31, kg = lane >> 5;
-                f32x16 aj;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) aj[r] = 0.f;
-                gx3 wp = frag + X3_JW1 + m * (X3_TH * 3 * 64) + lane;
-#pragma unroll 2
-                for (int t = 0; t < X3_TH; ++t) {
-                    bf16x8 wa[3], xb[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        wa[p] = wp[(t * 3 + p) * 64];
-                        xb[p] = *reinterpret_cast<const bf16x8*>(X + p * X3_PLANE + (32 * n + j) * X3_LDP + 16 * t + 8 * kg);
-                    }
-                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[2], xb[0], aj, 0, 0, 0);
-                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[2], aj, 0, 0, 0);
-                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], xb[1], aj, 0, 0, 0);
-                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], xb[0], aj, 0, 0, 0);
-                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[1], aj, 0, 0, 0);
-                    aj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[0], aj, 0, 0, 0);
-                }
+                const f32x16 aj = gemm_x3_tile<X3_TH>(X, n, w_jw1, lane, frj);
                 const int q = tile * 64 + 32 * n + j;
                 if (q < NP) {
                     if (m == 0) {
@@ -716,8 +760,11 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
                 }
             }
         }
-        __syncthreads();  // the planes are rewritten by the next tile's gather
+        T_MARK(14)
+        lds_barrier();  // the planes are rewritten by the next tile's gather
+        T_MARK(15)
     }
+    T_FLUSH
 }
 
 }  // namespace

@@ -131,6 +131,10 @@ __device__ __forceinline__ void gemm_rows64(const float* X, gf4p wp, int lane, f
     gemm_rows64<T, LD>(X, wp, lane, acc, load_bfrag(wp, lane), nullptr);
 }
 
+// Workgroup barrier for kernels whose waves exchange data through LDS only: __syncthreads() also drains every outstanding global
+// request of the wave (s_waitcnt vmcnt(0): weight prefetches for the next layer, tile stores, atomics) before it reaches the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)

@@ -37,44 +37,153 @@ __device__ __forceinline__ WFrag3 load_wfrag3(gx3 wp) {
     return f;
 }
 
-template <int T>
+// One k-step: [requests: weights of k-step t + 2 (LW) / the next layer's first fragments (LN), LDS operands of k-step t + 1 (LX)],
+// then this k-step's 24 MFMAs.  Weight fragments are requested TWO k-steps ahead (a k-step is 768 cycles, less than a loaded L2
+// round trip, and the wave has its SIMD to itself: nothing else covers a wait), LDS operands one k-step ahead.  Operands rotate
+// through three register buffers each, addressed by the compile-time phase R = t mod 3: a rotation by register moves would have to
+// wait for the youngest request.  The order is pinned: left alone, the scheduler sinks the requests to the end of the k-step.
+struct X3Regs {
+    bf16x8 w[3][2][3], x[3][2][3];
+};
+// SWAP = false: transposed product, acc[m][n] = (features 32 m.., rows 32 n..) = W X; SWAP = true: acc[m][n] = (rows 32 m.., features
+// 32 n..) = X^T W^T, the same fragments with the operand roles exchanged (a lane then owns a feature column strip).
+template <int R, bool LW, bool LX, bool LN, bool SWAP = false>
+__device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 (&acc)[2][2], X3Regs& r, WFrag3& nxt, gx3 next_wp) {
+    constexpr int R1 = (R + 1) % 3, R2 = (R + 2) % 3;
+    if (LW) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) r.w[R2][m][p] = wp[((t + 2) * 6 + m * 3 + p) * 64];
+    }
+    if (LN) nxt = load_wfrag3(next_wp);
+    if (LX) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) r.x[R1][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * X3_PLANE + 32 * n * X3_LDP + 16 * (t + 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // smallest terms first; four accumulators alternate
+#define SPF_X3(PW, PX)                                                                                                 \
+    if (!SWAP) {                                                                                                       \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0][PW], r.x[R][0][PX], acc[0][0], 0, 0, 0);           \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0][PW], r.x[R][1][PX], acc[0][1], 0, 0, 0);           \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1][PW], r.x[R][0][PX], acc[1][0], 0, 0, 0);           \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1][PW], r.x[R][1][PX], acc[1][1], 0, 0, 0);           \
+    } else {                                                                                                           \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][0][PX], r.w[R][0][PW], acc[0][0], 0, 0, 0);           \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][0][PX], r.w[R][1][PW], acc[0][1], 0, 0, 0);           \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][1][PX], r.w[R][0][PW], acc[1][0], 0, 0, 0);           \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][1][PX], r.w[R][1][PW], acc[1][1], 0, 0, 0);           \
+    }
+    SPF_X3(2, 0) SPF_X3(0, 2) SPF_X3(1, 1) SPF_X3(1, 0) SPF_X3(0, 1) SPF_X3(0, 0)
+#undef SPF_X3
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int T, bool SWAP = false>
 __device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][2], const WFrag3& first, gx3 next_wp) {
+    static_assert(T >= 3, "gemm_x3: at least three k-steps");
     const int j = lane & 31, kg = lane >> 5;
-    bf16x8 wa[2][3], wn[2][3];
+    const __bf16* xp = X + j * X3_LDP + 8 * kg;
+    X3Regs r;
     WFrag3 nxt = first;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wa[m][p] = first.w[m][p];
-#pragma unroll 2
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) wn[m][p] = wp[((t + 1) * 6 + m * 3 + p) * 64];
-        } else if (next_wp) {
-            nxt = load_wfrag3(next_wp);
+        for (int p = 0; p < 3; ++p) {
+            r.w[0][m][p] = first.w[m][p];
+            r.w[1][m][p] = wp[(6 + m * 3 + p) * 64];
         }
-        bf16x8 xb[2][3];
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) xb[n][p] = *reinterpret_cast<const bf16x8*>(X + p * X3_PLANE + (32 * n + j) * X3_LDP + 16 * t + 8 * kg);
-        // smallest terms first; four accumulators alternate
-#define SPF_X3(PW, PX)                                                                                             \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][PW], xb[0][PX], acc[0][0], 0, 0, 0);                   \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][PW], xb[1][PX], acc[0][1], 0, 0, 0);                   \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][PW], xb[0][PX], acc[1][0], 0, 0, 0);                   \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][PW], xb[1][PX], acc[1][1], 0, 0, 0);
-        SPF_X3(2, 0) SPF_X3(0, 2) SPF_X3(1, 1) SPF_X3(1, 0) SPF_X3(0, 1) SPF_X3(0, 0)
-#undef SPF_X3
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wa[m][p] = wn[m][p];
+        for (int p = 0; p < 3; ++p) r.x[0][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * X3_PLANE + 32 * n * X3_LDP);
+    constexpr int MAIN = T - 2, REM = MAIN % 3;        // k-steps that request weights; the last two only consume
+    int t = 0;
+#pragma unroll 1
+    for (; t + 3 <= MAIN; t += 3) {
+        x3_step<0, true, true, false, SWAP>(xp, wp, t, acc, r, nxt, next_wp);
+        x3_step<1, true, true, false, SWAP>(xp, wp, t + 1, acc, r, nxt, next_wp);
+        x3_step<2, true, true, false, SWAP>(xp, wp, t + 2, acc, r, nxt, next_wp);
     }
+    if (REM >= 1) x3_step<0, true, true, false, SWAP>(xp, wp, MAIN - REM, acc, r, nxt, next_wp);
+    if (REM == 2) x3_step<1, true, true, false, SWAP>(xp, wp, MAIN - 1, acc, r, nxt, next_wp);
+    if (next_wp) x3_step<REM, false, true, true, SWAP>(xp, wp, T - 2, acc, r, nxt, next_wp);
+    else x3_step<REM, false, true, false, SWAP>(xp, wp, T - 2, acc, r, nxt, next_wp);
+    x3_step<(REM + 1) % 3, false, false, false, SWAP>(xp, wp, T - 1, acc, r, nxt, next_wp);
     return nxt;
+}
+
+// One 32x32 output tile per wave, D[m-th 32 weight rows][n-th 32 rows of X] over T k16-steps (the narrow last products: 256 ->
+// latent / input width).  wp: [T][3][64] fragments of the wave's weight rows, + lane.  `pre`: k-steps 0 and 1, requested by the
+// caller ahead of the preceding epilogue.  Small terms and large terms go to separate accumulators (two independent MFMA chains).
+struct WFrag1 {
+    bf16x8 w[2][3];
+};
+__device__ __forceinline__ WFrag1 load_wfrag1(gx3 wp) {
+    WFrag1 f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f.w[s][p] = wp[(s * 3 + p) * 64];
+    return f;
+}
+struct X1Regs {
+    bf16x8 w[3][3], x[3][3];
+};
+template <int R, bool LW, bool LX>
+__device__ __forceinline__ void x1_step(const __bf16* xp, gx3 wp, int t, f32x16& lo, f32x16& hi, X1Regs& r) {
+    constexpr int R1 = (R + 1) % 3, R2 = (R + 2) % 3;
+    if (LW) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) r.w[R2][p] = wp[((t + 2) * 3 + p) * 64];
+    }
+    if (LX) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) r.x[R1][p] = *reinterpret_cast<const bf16x8*>(xp + p * X3_PLANE + 16 * (t + 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][2], r.x[R][0], lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1], r.x[R][0], hi, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0], r.x[R][2], lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0], r.x[R][1], hi, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1], r.x[R][1], lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0], r.x[R][0], hi, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// returns the tile in the accumulator layout (row_of / column = lane & 31)
+template <int T>
+__device__ __forceinline__ f32x16 gemm_x3_tile(const __bf16* X, int n, gx3 wp, int lane, const WFrag1& pre) {
+    static_assert(T >= 3 && (T - 2) % 3 != 0, "gemm_x3_tile: tail phases are written for (T - 2) mod 3 in {1, 2}");
+    const int j = lane & 31, kg = lane >> 5;
+    const __bf16* xp = X + (32 * n + j) * X3_LDP + 8 * kg;
+    X1Regs r;
+    f32x16 lo, hi;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) lo[q] = hi[q] = 0.f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        r.w[0][p] = pre.w[0][p];
+        r.w[1][p] = pre.w[1][p];
+        r.x[0][p] = *reinterpret_cast<const bf16x8*>(xp + p * X3_PLANE);
+    }
+    constexpr int MAIN = T - 2, REM = MAIN % 3;
+    int t = 0;
+#pragma unroll 1
+    for (; t + 3 <= MAIN; t += 3) {
+        x1_step<0, true, true>(xp, wp, t, lo, hi, r);
+        x1_step<1, true, true>(xp, wp, t + 1, lo, hi, r);
+        x1_step<2, true, true>(xp, wp, t + 2, lo, hi, r);
+    }
+    if (REM >= 1) x1_step<0, true, true>(xp, wp, MAIN - REM, lo, hi, r);
+    if (REM == 2) x1_step<1, true, true>(xp, wp, MAIN - 1, lo, hi, r);
+    x1_step<REM, false, true>(xp, wp, T - 2, lo, hi, r);
+    x1_step<(REM + 1) % 3, false, false>(xp, wp, T - 1, lo, hi, r);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) hi[q] += lo[q];
+    return hi;
 }
 
 // write 4 consecutive features of one row as three bf16 quads

@@ -265,7 +265,7 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
 template <int NT>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
 __global__ void __launch_bounds__(512, 1)
 wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
-                    int max_rows, float* __restrict__ slab) {
+                    int max_rows, float* __restrict__ slab, float* __restrict__ dbias) {
     constexpr int ROWS = 16, NB = 4, CA = 32 * NT;
     constexpr int NDMA = 2 + (NT == 8 ? 2 : 1);                           // requests per wave per stage
     __shared__ __attribute__((aligned(16))) float sm[NB * ROWS * (256 + CA) + 3 * CA * 2 * 4];
@@ -283,6 +283,7 @@ wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, in
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float gsum = 0.f;
     const int c4max = (C - 1) / 4;
     const unsigned off_row = 16u * lane, off_half = 16u * min(ci, c4max);
     auto issue = [&](int st) {
@@ -331,6 +332,7 @@ wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, in
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = (8 * h + e < left) ? sg[(8 * h + e) * 256 + 32 * wave + ci] : 0.f;
             ga = split8(x);
+            gsum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));      // column sums of G = the bias gradient
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                   // planes complete
@@ -354,6 +356,10 @@ wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, in
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (dbias) {
+        gsum += __shfl_xor(gsum, 32);
+        if (h == 0) atomicAdd(&dbias[32 * wave + ci], gsum);
     }
     float* out = slab + ((size_t)blockIdx.x * 8 + wave) * (NT * 16 * 64) + lane;     // slab[block][wave 8][t][reg][lane]
 #pragma unroll
@@ -465,6 +471,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk_lau
     atomicAdd(&dW[(size_t)o * ldw + i], (s0 + s1) + (s2 + s3));
 }
 
+// dbias[c] += sum_rows G[row][c] for the kernels that do not produce it on the way (verification / narrow paths)
+__global__ void colsum256_kernel(const float* __restrict__ G, const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ dbias) {
+    const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
+    float s = 0.f;
+    for (int r = blockIdx.x; r < n; r += gridDim.x) s += G[(size_t)r * 256 + threadIdx.x];
+    atomicAdd(&dbias[threadIdx.x], s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -482,7 +496,7 @@ int spf_wgrad_set_mode(int32_t mode) {
 int64_t spf_wgrad_workspace_floats(int32_t C) { return (int64_t)256 * 256 * (C > 128 ? 256 : (C > 32 ? 256 : 32)); }
 
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows, float* dW, int32_t ldw,
-              float* workspace, void* stream) {
+              float* dbias, float* workspace, void* stream) {
     if (max_rows < 0 || C < 1 || C > 256 || lda < C || ldw < C) return spf::fail(SPF_EINVAL, "spf_wgrad: need 1 <= C <= 256, lda >= C, ldw >= C");
     if (max_rows == 0) return SPF_OK;
     if (!G || !A || !dW || !workspace) return spf::fail(SPF_EINVAL, "spf_wgrad: null pointer");
@@ -495,11 +509,13 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     const int per = 4 * 2 * NT * 16 * 64;
     if (g_wgrad_mode == 0 && NT == 8 && C == 256) {
         const int b8 = blocks > 256 ? 256 : blocks;      // one 8-wave workgroup per CU
-        wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        dbias = nullptr;
         wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw);
     } else if (g_wgrad_mode == 0 && NT == 4) {
         const int b8 = blocks > 256 ? 256 : blocks;
-        wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
+        wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        dbias = nullptr;
         wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw);
     } else if (NT == 8) {
         if (C == 256) wgrad_dma_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
@@ -512,6 +528,7 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
         wgrad_narrow_kernel<<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         wgrad_reduce_kernel<1><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     }
+    if (dbias) colsum256_kernel<<<512, 256, 0, s>>>(G, n_rows, max_rows, dbias);
     SPF_LAUNCH_CHECK("wgrad_kernel");
     return SPF_OK;
 }

@@ -301,19 +301,23 @@ class ColorAgg(torch.autograd.Function):
                                                      _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), ctx.NP, pl.k, _lib.ptr(packed), _lib.ptr(masks),
                                                      _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_b4),
                                                      _lib.ptr(g_feat), _lib.stream_ptr()), "spf_color_backward")
+        # split-product kernels (the default) leave the bias gradients to the weight-gradient GEMM (column sums of G)
+        kb = (lambda b: b) if color_mode() == "split" else (lambda b: None)
         if sk is not None:
             # layer 0's [256,104] comes in the kernels' internal column order: one index_add_ into the reference order
-            sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs)[:, :103])
-            wgrad(G2, act1, pl.n_pairs, out=sk[3])
-            wgrad(G3, act2, pl.n_pairs, out=sk[5])
+            sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0))[:, :103])
+            wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2))
+            wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4))
             return (None,) * 13
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
         if ctx.static:   # row counts stay on the device
-            dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs)[:, :103]
-            dw2, dw4 = wgrad(G2, act1, pl.n_pairs), wgrad(G3, act2, pl.n_pairs)
+            dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0))[:, :103]
+            dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2)), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4))
         else:
             dw0[:, _color_col_perm(dev)] = _wgrad(G1, act0)[:, :103]   # [256,104] comes in the kernels' internal column order
             dw2, dw4 = _wgrad(G2, act1), _wgrad(G3, act2)
+            if color_mode() == "split":      # rows past the pair count are zero in G
+                g_b0, g_b2, g_b4 = G1.sum(0), G2.sum(0), G3.sum(0)
         grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4)
         return grads + (None,) * 6
 
@@ -538,14 +542,25 @@ class RHead(torch.autograd.Function):
 _wgrad_ws = {}
 
 
+def set_color_mode(mode: str):
+    """'split' (default) or 'f32': arithmetic of the colour trunk kernels (spf_color_set_mode).  Switch only between steps: a
+    backward must run in the mode of its forward."""
+    _lib.check(_lib.lib().spf_color_set_mode({"split": 0, "f32": 1}[mode]), "spf_color_set_mode")
+
+
+def color_mode() -> str:
+    return "split" if _lib.lib().spf_color_get_mode() == 0 else "f32"
+
+
 def set_wgrad_mode(mode: str):
     """'split' (default): fp32-exact products from three bf16 pieces per operand on the bf16 matrix pipe; 'f32': fp32 MFMA."""
     _lib.check(_lib.lib().spf_wgrad_set_mode({"split": 0, "f32": 1}[mode]), "spf_wgrad_set_mode")
 
 
 
-def wgrad(G, A, n_rows, C=None, out=None, ldw=None):
-    """out[256, :C] += G[:rows]^T A[:rows, :C] with the row count `n_rows` (int32 device tensor or None) read on the device."""
+def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None):
+    """out[256, :C] += G[:rows]^T A[:rows, :C] with the row count `n_rows` (int32 device tensor or None) read on the device;
+    dbias [256] (optional) += column sums of G[:rows] (the same layer's bias gradient)."""
     dev = G.device
     C = A.shape[1] if C is None else C
     if out is None:
@@ -556,7 +571,7 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None):
     if key not in _wgrad_ws:
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().spf_wgrad(_lib.ptr(G), _lib.ptr(A), A.stride(0), C, _lib.ptr(n_rows), min(G.shape[0], A.shape[0]), _lib.ptr(out), ldw,
+        _lib.check(_lib.lib().spf_wgrad(_lib.ptr(G), _lib.ptr(A), A.stride(0), C, _lib.ptr(n_rows), min(G.shape[0], A.shape[0]), _lib.ptr(out), ldw, _lib.ptr(dbias),
                                         _lib.ptr(_wgrad_ws[key]), _lib.stream_ptr()), "spf_wgrad")
     return out
 

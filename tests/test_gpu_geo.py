@@ -144,7 +144,17 @@ def test_tv_and_row_scatter_match_torch():
     np.testing.assert_allclose(table.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
-def test_color_path_forward_backward_match_oracle():
+@pytest.fixture(params=["split", "f32"])
+def color_mode(request):
+    from spurfies_amd import ops
+
+    ops.set_color_mode(request.param)
+    yield request.param
+    ops.set_color_mode("split")
+
+
+@pytest.mark.parametrize("static", [False, True])
+def test_color_path_forward_backward_match_oracle(color_mode, static):
     """Colour path = per-pair trunk of F_color + RBF-weighted mean (ColorAgg), then F_color's linear last layer + R head per
     point (RHead) — against torch-CPU autograd of the reference formulation, which applies ALL of F_color per pair and
     averages afterwards (pointneus_disent.py:325-346): agg3, colours, colour-latent gradient, every weight / bias gradient."""
@@ -164,8 +174,10 @@ def test_color_path_forward_backward_match_oracle():
     table = dev["neural_feats_color"].clone().requires_grad_(True)
     M = x.shape[0]
     dirs = torch.nn.functional.normalize(torch.randn((M, 3), generator=torch.Generator().manual_seed(1)), dim=-1)
-    agg3 = ops.ColorAgg.apply(table, *fcp, xt, geo["wn"], pl, dev["neural_pts"], P_, NP_)
-    colors = ops.RHead.apply(agg3, *hdp, dirs.cuda(), point_slot, n_pts, 1, M)            # SR = 1: one ray direction per row
+    # static = the sync-free training form: worst-case buffers, every kernel reads the counts on the device
+    agg3 = ops.ColorAgg.apply(table, *fcp, xt, geo["wn"], pl, dev["neural_pts"], *((None, None) if static else (P_, NP_)))
+    colors = ops.RHead.apply(agg3, *hdp, dirs.cuda(), point_slot, n_pts, 1, M, static)    # SR = 1: one ray direction per row
+    agg3 = agg3[:P_]
     rows_valid = point_slot[:P_].long()
     coef = torch.randn((P_, 3), generator=torch.Generator().manual_seed(0))
     (colors[rows_valid] * coef.cuda()).sum().backward()

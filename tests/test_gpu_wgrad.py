@@ -61,3 +61,25 @@ def test_split_products_wide_dynamic_range_and_cancellation():
     r1 = _both(G[:64].contiguous(), A[:64].contiguous(), n1, 256)
     exact = torch.outer(G[0].double(), A[0].double())
     np.testing.assert_allclose(r1["split"].double().cpu().numpy(), exact.cpu().numpy(), rtol=2.5e-7, atol=0)
+
+
+@pytest.mark.parametrize("C", [256, 104, 16])
+def test_bias_gradient_rides_along(C):
+    """dbias += column sums of G[:rows] (the bias gradient of the layer whose weight gradient is being formed), both modes."""
+    from spurfies_amd import ops
+
+    g = torch.Generator().manual_seed(C)
+    rows = 33333
+    G = torch.randn((rows + 100, 256), generator=g).cuda()
+    A = torch.randn((rows + 100, C), generator=g).cuda()
+    n = torch.tensor([rows], dtype=torch.int32, device="cuda")
+    ref = G[:rows].double().sum(0)
+    for mode in ("f32", "split"):
+        ops.set_wgrad_mode(mode)
+        try:
+            db = torch.full((256,), 2.0, device="cuda")
+            dw = ops.wgrad(G, A, n, C=C, dbias=db)
+        finally:
+            ops.set_wgrad_mode("split")
+        np.testing.assert_allclose((db.double() - 2.0).cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5 * float(G[:rows].abs().sum(0).max()))
+        assert _err(dw, G[:rows].double().t() @ A[:rows].double()) < 1e-5

@@ -7,6 +7,8 @@ from tools.microbench import timeit  # noqa: E402
 from spurfies_amd import ops, synthetic as syn  # noqa: E402
 from spurfies_amd.torch_knnquery import VoxelGrid  # noqa: E402
 
+if len(sys.argv) > 1:
+    ops.set_color_mode(sys.argv[1])          # split | f32
 scene = syn.make_scene(10000, seed=0)
 dev = {k: torch.as_tensor(np.asarray(v)).float().cuda() for k, v in scene["state"].items()}
 grid = VoxelGrid((0.025,) * 3, (3,) * 3, (3,) * 3, 26, 20000, scene["ranges"])
@@ -57,5 +59,5 @@ def bwd_only():
 
 
 t_b = timeit(bwd_only)
-print(f"P={P} pairs={NP}  fwd eval {t_e:.3f} ms ({NP*f_fwd/t_e/1e9:.1f} TF)  fwd train {t_t:.3f} ms ({NP*f_fwd/t_t/1e9:.1f} TF)  "
+print(f"[{ops.color_mode()}] P={P} pairs={NP}  fwd eval {t_e:.3f} ms ({NP*f_fwd/t_e/1e9:.1f} TF)  fwd train {t_t:.3f} ms ({NP*f_fwd/t_t/1e9:.1f} TF)  "
       f"bwd kernel {t_b:.3f} ms ({NP*f_bwd/t_b/1e9:.1f} TF)")

@@ -33,3 +33,6 @@ report("spf_debug_timing_geo",
        {31: "tile prologue", 0: "gather", 1: "sync", 2: "4 forward GEMMs", 3: "syncs after GEMM", 4: "4 forward epilogues", 5: "syncs after epilogue",
         6: "sdf dot", 7: "sync", 8: "Jacobian seed", 9: "sync", 10: "3 backward GEMMs", 11: "syncs after GEMM", 12: "3 backward epilogues",
         13: "syncs after epilogue", 14: "input-Jacobian GEMM + stores", 15: "sync"})
+report("spf_debug_timing_color", cb.bwd_only,
+       {16: "G3 = wn g_agg3 * mask -> HBM + planes", 17: "sync", 18: "2 backward GEMMs", 19: "syncs", 20: "2 backward epilogues", 21: "syncs",
+        22: "G2 / G1 tile stores", 23: "latent-gradient GEMM + scatter", 24: "sync"})
