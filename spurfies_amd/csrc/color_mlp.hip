@@ -629,6 +629,7 @@ __device__ __forceinline__ CxRow cx_fetch_row(int idx, int srow, int p, int q, i
 }
 
 constexpr int CX_LDS_BF16 = 3 * X3_PLANE;
+constexpr int CX_LDL = 68;
 
 template <bool STORE>
 __global__ void __launch_bounds__(256, 1)
@@ -820,7 +821,9 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
                          const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3,
                          float* __restrict__ g_feat_col) {
     __shared__ __attribute__((aligned(16))) __bf16 X[CX_LDS_BF16];
-    __shared__ int s_idx[64];
+    __shared__ __attribute__((aligned(16))) int s_idx[64];
+    __shared__ __attribute__((aligned(16))) float L[64 * CX_LDL];      // the tile's latent gradients, [row][64 (+4)]
+    __shared__ unsigned long long s_mask[64];                          // rows with the same neighbour (set on the first of them)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
@@ -924,12 +927,47 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         {
             const int m = wave >> 1, n = wave & 1, kg = lane >> 5;
             const f32x16 aj = gemm_x3_tile<CX_TH>(X, n, w_bwl, lane, frl);
-            const int idx = s_idx[32 * n + j];
-            if (idx >= 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    atomicAdd(&g_feat_col[(size_t)idx * SPF_COL_DIM + 32 * m + 8 * (r >> 2) + 4 * kg + (r & 3)], aj[r]);
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(&L[(32 * n + j) * CX_LDL + 32 * m + 8 * g + 4 * kg]) = f32x4{aj[4 * g], aj[4 * g + 1], aj[4 * g + 2], aj[4 * g + 3]};
+        }
+        lds_barrier();
+        // Rows of a tile that hit the same neural point (samples along a ray share most of their neighbours) are summed in LDS
+        // first: same-address atomics serialise in L2, and with one workgroup per CU nothing else runs meanwhile.
+        // thread = (row, quarter of the 64 latent columns); the first row of each group of equal indices adds the group.
+        {
+            const int my = s_idx[row0];
+            uint32_t part = 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int4 v = *reinterpret_cast<const int4*>(&s_idx[16 * q40 + 4 * u]);
+                part |= (v.x == my ? 1u : 0u) << (4 * u) | (v.y == my ? 2u : 0u) << (4 * u) | (v.z == my ? 4u : 0u) << (4 * u) |
+                        (v.w == my ? 8u : 0u) << (4 * u);
             }
+            unsigned long long mask = (unsigned long long)part << (16 * q40);
+            mask |= __shfl_xor(mask, 1);
+            mask |= __shfl_xor(mask, 2);
+            const bool leader = my >= 0 && (mask & ((1ull << row0) - 1ull)) == 0ull;
+            if (q40 == 0) s_mask[row0] = leader ? mask : 0ull;
+        }
+        lds_barrier();
+        // wave w adds rows 16 w .. 16 w + 15: one row per instruction, lane = latent column (256 contiguous bytes per atomic
+        // instruction; a lane-per-row arrangement touches 32 to 64 cache lines per instruction and runs at a fraction of the rate)
+#pragma unroll 1
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = 16 * wave + rr;
+            const unsigned long long m0 = s_mask[row];
+            unsigned long long mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m0 >> 32)) << 32) |
+                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)m0);     // (the builtin returns int)
+            if (mask == 0ull) continue;
+            const int idx = __builtin_amdgcn_readfirstlane(s_idx[row]);
+            float sum = 0.f;
+            while (mask) {
+                const int r2 = __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                sum += L[r2 * CX_LDL + lane];
+            }
+            atomicAdd(g_feat_col + (size_t)idx * SPF_COL_DIM + lane, sum);
         }
         T_MARK(23)
         lds_barrier();

@@ -9,6 +9,7 @@ from spurfies_amd.torch_knnquery import VoxelGrid  # noqa: E402
 
 if len(sys.argv) > 1:
     ops.set_color_mode(sys.argv[1])          # split | f32
+RAYS = len(sys.argv) > 2 and sys.argv[2] == "rays"      # queries along rays (neighbour sets overlap from sample to sample, as in a step)
 scene = syn.make_scene(10000, seed=0)
 dev = {k: torch.as_tensor(np.asarray(v)).float().cuda() for k, v in scene["state"].items()}
 grid = VoxelGrid((0.025,) * 3, (3,) * 3, (3,) * 3, 26, 20000, scene["ranges"])
@@ -17,7 +18,15 @@ packed = ops.pack_geometry_weights(dev)
 rng = np.random.default_rng(0)
 pts = scene["state"]["neural_pts"]
 n_q = 56000
-x = torch.from_numpy((pts[rng.integers(0, len(pts), n_q)] + rng.normal(0, 0.015, size=(n_q, 3))).astype(np.float32)).cuda()
+if RAYS:
+    n_r, n_s = 1000, 56
+    o = pts[rng.integers(0, len(pts), n_r)] + rng.normal(0, 0.01, size=(n_r, 3))
+    d = rng.normal(size=(n_r, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t = (np.arange(n_s) - n_s / 2) * 0.0015
+    x = torch.from_numpy((o[:, None, :] + t[None, :, None] * d[:, None, :]).reshape(-1, 3).astype(np.float32)).cuda()
+else:
+    x = torch.from_numpy((pts[rng.integers(0, len(pts), n_q)] + rng.normal(0, 0.015, size=(n_q, 3))).astype(np.float32)).cuda()
 q = grid.query_dense(x.unsqueeze(1), 8, 2, 1)
 ps, _, n = ops.compact_points(q["slot_valid"])
 pl = ops.PairList(q["pidx"].reshape(-1, 8), ps, n)
