@@ -475,9 +475,10 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
 //   * layers 0 and 2 run as transposed products (a lane owns 4 consecutive features of one row, the epilogue rewrites the bf16
 //     planes with 8-byte stores); layer 4 — whose output only feeds the RBF-weighted mean — runs non-transposed, so that a lane
 //     owns a column strip and takes the segmented weighted sum straight from its accumulators, as the fp32 kernel does;
-//   * LeakyReLU sign bits are kept ROW-MAJOR in HBM (masks[tile][layer][row][8 words], bit = feature & 31), a layout any
-//     accumulator arrangement can read: transposed epilogues combine the two k-halves of a row word with one shuffle, the
-//     non-transposed layer gets a row word per accumulator register from the wave ballot;
+//   * LeakyReLU sign bits, masks[tile][layer][512 words]: layers 0 and 2 lane-major ([wave][n][lane], the forward and backward
+//     transposed epilogues share the lane <-> element map and push / pop the words in the same order); layer 4 ROW-major
+//     ([row][8 words], bit = feature & 31: a row word per accumulator register from the wave ballot, read back by the
+//     backward's first stage one row quarter per thread);
 //   * the layer inputs / pre-activation gradients the weight-gradient GEMM reads are written as fp32 rows rebuilt exactly from
 //     the planes (p1 + p2 + p3), coalesced; bias gradients come from the weight-gradient GEMM (column sums of G, spf_wgrad).
 // ==============================================================================================================================
@@ -544,43 +545,27 @@ __global__ void color_pack_x3_kernel(CPackArgs a, bf16x8* __restrict__ out) {
     out[base + 128] = p3;
 }
 
-// transposed forward epilogue: a = lrelu(acc + b) -> planes; sign bits as row words (STORE): masks_l[row][8], word 2 wave + m
-template <bool STORE>
-__device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], gfp bias, int wave, int lane, uint32_t* masks_l) {
-    const int j = lane & 31, kg = lane >> 5;
+// this lane's bias values of a layer (features 64 wave + 32 m + 8 g + 4 kg ..+3), requested ahead of the layer's GEMM
+struct CxBias {
+    f32x4 b[2][4];
+};
+__device__ __forceinline__ CxBias cx_load_bias(gfp bias, int wave, int lane) {
+    CxBias r;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        uint32_t bits[2] = {0u, 0u};
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
-            const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(bias + f0);
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                float out[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[m][n][4 * g + e] + bv[e];
-                    const bool pos = v > 0.f;
-                    bits[n] |= (pos ? 1u : 0u) << (8 * g + 4 * kg + e);
-                    out[e] = pos ? v : v * 0.01f;
-                }
-                store_quad_x3(X, 32 * n + j, f0, out);
-            }
-        }
-        if (STORE) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const uint32_t word = bits[n] | __shfl_xor(bits[n], 32);
-                if (kg == 0) masks_l[(32 * n + j) * 8 + 2 * wave + m] = word;
-            }
-        }
-    }
+        for (int g = 0; g < 4; ++g)
+            r.b[m][g] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(bias + 64 * wave + 32 * m + 8 * g + 4 * (lane >> 5));
+    return r;
 }
 
-// transposed backward epilogue: g_h = g_a * lrelu'(h) with the row words `mw[m][n]` (word 2 wave + m of row 32 n + j) -> planes
-__device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mw)[2][2]) {
+// transposed forward epilogue: a = lrelu(acc + b) -> planes; the lane's sign bits are pushed into two words (n = 0, 1; order
+// (m, g, e)) and stored lane-major (STORE): masks_l[(2 wave + n) * 64 + lane] — the backward's transposed epilogue has the same
+// lane <-> element map and pops them in the same order
+template <bool STORE>
+__device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], const CxBias& bias, int wave, int lane, uint32_t* masks_l) {
     const int j = lane & 31, kg = lane >> 5;
+    uint32_t bits[2] = {0u, 0u};
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -588,13 +573,36 @@ __device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2
             const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                float out[4];
+                f32x4 h, hs;
+                bias_scale4(acc[m][n], g, bias.b[m][g], h, hs);
+                f32x4 out;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool pos = (mw[m][n] >> (8 * g + 4 * kg + e)) & 1u;
-                    const float v = acc[m][n][4 * g + e];
-                    out[e] = pos ? v : v * 0.01f;
-                }
+                for (int e = 0; e < 4; ++e) out[e] = lrelu_push(h[e], hs[e], bits[n]);
+                store_quad_x3(X, 32 * n + j, f0, out);
+            }
+        }
+    if (STORE) {
+        masks_l[(2 * wave) * 64 + lane] = bits[0];
+        masks_l[(2 * wave + 1) * 64 + lane] = bits[1];
+    }
+}
+
+// transposed backward epilogue: g_h = g_a * lrelu'(h), popping the lane's two sign words -> planes
+__device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mw)[2]) {
+    const int j = lane & 31, kg = lane >> 5;
+    uint32_t bits[2] = {mw[0], mw[1]};
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x4 v, vs;
+                scale4(acc[m][n], g, v, vs);
+                f32x4 out;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], bits[n]);
                 store_quad_x3(X, 32 * n + j, f0, out);
             }
         }
@@ -711,12 +719,13 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
         if (STORE) store_tile_from_planes<13>(X, act0 + (size_t)tile * 64 * C_INP, C_INP, tid);      // [64][104] fp32, layer-0 input
         uint32_t* mk = STORE ? masks + (size_t)tile * 3 * 512 : nullptr;                             // [layer 3][row 64][8 words]
         f32x16 acc[2][2];
+        CxBias bias = cx_load_bias(pf + CO_B1, wave, lane);
         zero_acc(acc);
         WFrag3 nf = gemm_x3<CX_T1>(X, w_fw1, lane, acc, fr1, w_fw2);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        cx_fwd_epilogue<STORE>(X, acc, pf + CO_B1, wave, lane, mk);
+        cx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, mk);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
@@ -725,12 +734,13 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
             n_off = pair_off[n_p];
         }
         if (STORE) store_tile_from_planes<32>(X, act1 + (size_t)tile * 64 * 256, 256, tid);
+        bias = cx_load_bias(pf + CO_B2, wave, lane);
         zero_acc(acc);
         nf = gemm_x3<CX_TH>(X, w_fw2, lane, acc, nf, w_fw3);
         T_MARK(6)
         lds_barrier();
         T_MARK(7)
-        cx_fwd_epilogue<STORE>(X, acc, pf + CO_B2, wave, lane, STORE ? mk + 512 : nullptr);
+        cx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, STORE ? mk + 512 : nullptr);
         T_MARK(8)
         lds_barrier();
         T_MARK(9)
@@ -884,11 +894,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         store_tile_from_planes<32>(X, G3 + tbase, 256, tid);          // exactly the values the planes hold (p1 + p2 + p3)
         f32x16 acc[2][2];
         const int j = lane & 31;
-        uint32_t mw[2][2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) mw[m][n] = mk[512 + (32 * n + j) * 8 + 2 * wave + m];       // layer-2 sign words, before the GEMM
+        uint32_t mw[2] = {mk[512 + (2 * wave) * 64 + lane], mk[512 + (2 * wave + 1) * 64 + lane]};      // layer-2 sign words, before the GEMM
         zero_acc(acc);
         WFrag3 nf = gemm_x3<CX_TH>(X, w_bw3, lane, acc, fr3, w_bw2);
         T_MARK(18)
@@ -904,10 +910,8 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
             n_off = pair_off[n_p];
         }
         T_MARK(22)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) mw[m][n] = mk[(32 * n + j) * 8 + 2 * wave + m];
+        mw[0] = mk[(2 * wave) * 64 + lane];
+        mw[1] = mk[(2 * wave + 1) * 64 + lane];
         zero_acc(acc);
         gemm_x3<CX_TH>(X, w_bw2, lane, acc, nf, nullptr);
         T_MARK(18)

@@ -507,9 +507,25 @@ __global__ void geo_pack_x3_kernel(PackArgs a, bf16x8* __restrict__ out) {
 // acc[m][n][4g + e] = feature 64w + 32m + 8g + 4kg + e of row 32n + j.  mask[m]: bit n * 16 + 4g + e.
 // MODE 0: a = lrelu(acc + b) -> planes.   MODE 1 (last forward layer): also sdf partial sums s[n] += v5 . a, and the planes get
 // the Jacobian seed v5 * lrelu'(h) instead of a (a itself is not needed any more).
+// this lane's bias values of a layer (features 64 wave + 32 m + 8 g + 4 kg ..+3), requested ahead of the layer's GEMM
+struct Bias3 {
+    f32x4 b[2][4];
+};
+__device__ __forceinline__ Bias3 load_bias3(gfp bias, int wave, int lane) {
+    Bias3 r;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            r.b[m][g] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(bias + 64 * wave + 32 * m + 8 * g + 4 * (lane >> 5));
+    return r;
+}
+
+// forward epilogue: a = lrelu(acc + b) -> planes; sign bits pushed into mask[n] in the order (m, g, e) (32 per word).
+// MODE 1 (last layer): sdf partial sums s[n] += v . a, and the planes receive the Jacobian seed v * lrelu'(h) instead.
 template <int MODE, bool WITH_JAC>
-__device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], gfp bias, gfp v5, int wave, int lane, uint32_t (&mask)[2],
-                                                float (&s)[2]) {
+__device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], const Bias3& bias, gfp v5, int wave, int lane,
+                                                uint32_t (&mask)[2], float (&s)[2]) {
     const int j = lane & 31, kg = lane >> 5;
     mask[0] = mask[1] = 0u;
 #pragma unroll
@@ -517,23 +533,26 @@ __device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
-            const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(bias + f0);
-            f32x4 vv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (MODE == 1) vv = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(v5 + f0);
+            const f32x4 bv = bias.b[m][g];
+            f32x4 vv = f32x4{0.f, 0.f, 0.f, 0.f}, vs = vv;
+            if (MODE == 1) {
+                vv = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(v5 + f0);
+                vs = vv * 0.01f;
+            }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                float out[4];
+                f32x4 h, hs;
+                bias_scale4(acc[m][n], g, bv, h, hs);
+                f32x4 out;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = acc[m][n][4 * g + e] + bv[e];
-                    const bool pos = v > 0.f;
-                    mask[m] |= (pos ? 1u : 0u) << (n * 16 + 4 * g + e);
-                    v = pos ? v : v * 0.01f;
                     if (MODE == 1) {
-                        s[n] += vv[e] * v;
-                        out[e] = pos ? vv[e] : vv[e] * 0.01f;
+                        float seed;
+                        const float a = lrelu_push_sel(h[e], hs[e], vv[e], vs[e], seed, mask[n]);
+                        s[n] += vv[e] * a;
+                        out[e] = seed;
                     } else {
-                        out[e] = v;
+                        out[e] = lrelu_push(h[e], hs[e], mask[n]);
                     }
                 }
                 if (MODE == 0 || WITH_JAC) store_quad_x3(X, 32 * n + j, f0, out);
@@ -541,9 +560,10 @@ __device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
         }
 }
 
-// backward epilogue: g_h = g_a * lrelu'(h) -> planes
-__device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mask)[2]) {
+// backward epilogue: g_h = g_a * lrelu'(h) -> planes (pops the words the forward epilogue filled, in the same order)
+__device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mask_in)[2]) {
     const int j = lane & 31, kg = lane >> 5;
+    uint32_t mask[2] = {mask_in[0], mask_in[1]};
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -551,13 +571,11 @@ __device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
             const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                float out[4];
+                f32x4 v, vs;
+                scale4(acc[m][n], g, v, vs);
+                f32x4 out;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool pos = (mask[m] >> (n * 16 + 4 * g + e)) & 1u;
-                    const float v = acc[m][n][4 * g + e];
-                    out[e] = pos ? v : v * 0.01f;
-                }
+                for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], mask[n]);
                 store_quad_x3(X, 32 * n + j, f0, out);
             }
         }
@@ -655,12 +673,13 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
         gx3 w_fw2 = frag + X3_FW2 + wave * (X3_TH * 2 * 3 * 64) + lane, w_fw3 = frag + X3_FW3 + wave * (X3_TH * 2 * 3 * 64) + lane;
         gx3 w_fw4 = frag + X3_FW4 + wave * (X3_TH * 2 * 3 * 64) + lane, w_bw4 = frag + X3_BW4 + wave * (X3_TH * 2 * 3 * 64) + lane;
         gx3 w_bw3 = frag + X3_BW3 + wave * (X3_TH * 2 * 3 * 64) + lane, w_bw2 = frag + X3_BW2 + wave * (X3_TH * 2 * 3 * 64) + lane;
+        Bias3 bias = load_bias3(pf + OFF_B1, wave, lane);
         zero_acc(acc);
         WFrag3 nf = gemm_x3<X3_T1>(X, w_fw1, lane, acc, fr1, w_fw2);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B1, pf + OFF_V5, wave, lane, m1, ssum);
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, pf + OFF_V5, wave, lane, m1, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
@@ -668,33 +687,36 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
             n_srow = point_slot ? point_slot[n_p] : n_p;
             n_off = pair_off[n_p];
         }
+        bias = load_bias3(pf + OFF_B2, wave, lane);
         zero_acc(acc);
         nf = gemm_x3<X3_TH>(X, w_fw2, lane, acc, nf, w_fw3);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B2, pf + OFF_V5, wave, lane, m2, ssum);
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, pf + OFF_V5, wave, lane, m2, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
+        bias = load_bias3(pf + OFF_B3, wave, lane);
         zero_acc(acc);
         nf = gemm_x3<X3_TH>(X, w_fw3, lane, acc, nf, w_fw4);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, pf + OFF_B3, pf + OFF_V5, wave, lane, m3, ssum);
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, pf + OFF_V5, wave, lane, m3, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
         cur = gx_fetch_row(n_idx, n_srow, q40, x, pts, feat_geo);
+        bias = load_bias3(pf + OFF_B4, wave, lane);
         zero_acc(acc);
         nf = gemm_x3<X3_TH>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
         // last forward layer: sdf_j = v . a4 + c from the accumulators; the planes receive the Jacobian seed v * lrelu'(h4)
-        fwd_epilogue_x3<1, WITH_JAC>(X, acc, pf + OFF_B4, pf + OFF_V5, wave, lane, m4, ssum);
+        fwd_epilogue_x3<1, WITH_JAC>(X, acc, bias, pf + OFF_V5, wave, lane, m4, ssum);
         {
             const int j = lane & 31, kg = lane >> 5;
 #pragma unroll

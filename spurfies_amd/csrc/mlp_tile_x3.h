@@ -186,21 +186,89 @@ __device__ __forceinline__ f32x16 gemm_x3_tile(const __bf16* X, int n, gx3 wp, i
     return hi;
 }
 
-// write 4 consecutive features of one row as three bf16 quads
-__device__ __forceinline__ void store_quad_x3(__bf16* X, int row, int f0, const float (&v)[4]) {
-    bf16x4 pa, pb, pc;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        __bf16 a, b, c;
-        split3(v[e], a, b, c);
-        pa[e] = a; pb[e] = b; pc[e] = c;
-    }
-    __bf16* dst = X + row * X3_LDP + f0;
-    *reinterpret_cast<bf16x4*>(dst) = pa;
-    *reinterpret_cast<bf16x4*>(dst + X3_PLANE) = pb;
-    *reinterpret_cast<bf16x4*>(dst + 2 * X3_PLANE) = pc;
+// ---- epilogue arithmetic, two elements per instruction where the ISA allows (v_cvt_pk_bf16_f32, v_pk_add_f32, v_pk_mul_f32) ----
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// (the compiler pairs the subtractions of the split on its own, but scalarises sums / products whose results feed inline asm)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// h = a + b and 0.01 h for four accumulator values
+__device__ __forceinline__ void bias_scale4(const f32x16& acc, int g, f32x4 b, f32x4& h, f32x4& hs) {
+    const f32x2 c = f32x2{0.01f, 0.01f};
+    const f32x2 h0 = pk_add(f32x2{acc[4 * g], acc[4 * g + 1]}, f32x2{b[0], b[1]}), h1 = pk_add(f32x2{acc[4 * g + 2], acc[4 * g + 3]}, f32x2{b[2], b[3]});
+    const f32x2 s0 = pk_mul(h0, c), s1 = pk_mul(h1, c);
+    h = f32x4{h0[0], h0[1], h1[0], h1[1]};
+    hs = f32x4{s0[0], s0[1], s1[0], s1[1]};
+}
+__device__ __forceinline__ void scale4(const f32x16& acc, int g, f32x4& v, f32x4& vs) {
+    const f32x2 c = f32x2{0.01f, 0.01f};
+    const f32x2 v0 = f32x2{acc[4 * g], acc[4 * g + 1]}, v1 = f32x2{acc[4 * g + 2], acc[4 * g + 3]};
+    const f32x2 s0 = pk_mul(v0, c), s1 = pk_mul(v1, c);
+    v = f32x4{v0[0], v0[1], v1[0], v1[1]};
+    vs = f32x4{s0[0], s0[1], s1[0], s1[1]};
 }
 
+__device__ __forceinline__ uint32_t cvt_pk_bf16(f32x2 a) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2)); }
+__device__ __forceinline__ f32x2 pk_bf16_to_f32(uint32_t c) { return f32x2{__uint_as_float(c << 16), __uint_as_float(c & 0xffff0000u)}; }
+// two floats -> three packed bf16 pairs, a = p1 + p2 + p3 exactly (same pieces as split3)
+__device__ __forceinline__ void split3_pair(f32x2 a, uint32_t& c1, uint32_t& c2, uint32_t& c3) {
+    c1 = cvt_pk_bf16(a);
+    const f32x2 r1 = a - pk_bf16_to_f32(c1);
+    c2 = cvt_pk_bf16(r1);
+    const f32x2 r2 = r1 - pk_bf16_to_f32(c2);
+    c3 = cvt_pk_bf16(r2);
+}
+
+// write 4 consecutive features of one row as three bf16 quads
+__device__ __forceinline__ void store_quad_x3(__bf16* X, int row, int f0, f32x4 v) {
+    uint32_t a1, a2, a3, b1, b2, b3;
+    split3_pair(f32x2{v[0], v[1]}, a1, a2, a3);
+    split3_pair(f32x2{v[2], v[3]}, b1, b2, b3);
+    __bf16* dst = X + row * X3_LDP + f0;
+    *reinterpret_cast<u32x2*>(dst) = u32x2{a1, b1};
+    *reinterpret_cast<u32x2*>(dst + X3_PLANE) = u32x2{a2, b2};
+    *reinterpret_cast<u32x2*>(dst + 2 * X3_PLANE) = u32x2{a3, b3};
+}
+__device__ __forceinline__ void store_quad_x3(__bf16* X, int row, int f0, const float (&v)[4]) {
+    store_quad_x3(X, row, f0, f32x4{v[0], v[1], v[2], v[3]});
+}
+
+// LeakyReLU sign bits travel in 32-bit words filled from the top: push appends (h > 0) below the bits already there
+// (bits = 2 bits + (h > 0), the carry-in form of the add), pop takes the top bit (bits = 2 bits, carry-out).  A word that received 32
+// pushes pops them in the same order.  h001 = 0.01 h is formed outside (two per instruction).
+__device__ __forceinline__ float lrelu_push(float h, float h001, uint32_t& bits) {
+    float out;
+    asm("v_cmp_lt_f32_e32 vcc, 0, %2\n\tv_cndmask_b32_e32 %0, %3, %2, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+        : "=&v"(out), "+v"(bits)
+        : "v"(h), "v"(h001)
+        : "vcc");
+    return out;
+}
+// same, and also selects `a` (h > 0) or `a001` into `sel` (the Jacobian seed of the last forward layer)
+__device__ __forceinline__ float lrelu_push_sel(float h, float h001, float a, float a001, float& sel, uint32_t& bits) {
+    float out;
+    asm("v_cmp_lt_f32_e32 vcc, 0, %3\n\tv_cndmask_b32_e32 %0, %4, %3, vcc\n\tv_cndmask_b32_e32 %1, %6, %5, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc"
+        : "=&v"(out), "=&v"(sel), "+v"(bits)
+        : "v"(h), "v"(h001), "v"(a), "v"(a001)
+        : "vcc");
+    return out;
+}
+__device__ __forceinline__ float lrelu_pop(float g, float g001, uint32_t& bits) {
+    float out;
+    asm("v_add_co_u32_e32 %1, vcc, %1, %1\n\tv_cndmask_b32_e32 %0, %3, %2, vcc" : "=&v"(out), "+v"(bits) : "v"(g), "v"(g001) : "vcc");
+    return out;
+}
 
 // [64][8 * NG] tile of the planes (exactly p1 + p2 + p3 per element) -> fp32 rows in HBM, coalesced (32 B per thread, a row's
 // threads are consecutive): what the weight-gradient GEMM reads.
