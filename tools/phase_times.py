@@ -20,7 +20,16 @@ def report(entry, fn, names):
     torch.cuda.synchronize()
     f(buf, 1)
     tot = sum(buf)
-    print(entry)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    f(buf, 1)
+    # thread 0 of each workgroup counts cycles from its first mark to its last: cycles per launch per workgroup / launch time
+    print(entry, " ~%.2f GHz shader clock (cycle counter / wall time, %d workgroups assumed)" % (tot / 5 / 256 / (e0.elapsed_time(e1) / 5 * 1e6), 256))
     for i, n in names.items():
         print(f"  {n:34s} {100.0 * buf[i] / tot:6.2f} %")
 
