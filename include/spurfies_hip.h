@@ -205,6 +205,13 @@ int spf_color_backward(const float* g_agg3, const int32_t* nbr, const float* wn,
  * layer and the second half of get_color, spurfies/model/pointneus_disent.py:333-346 (view encoding with multires 3,
  * concat, R: 277 -> 256 -> 256 -> 3, sigmoid) and its backward.
  * ---------------------------------------------------------------------------------------- */
+/* Arithmetic of spf_rhead_forward / spf_rhead_backward (process-wide; a backward must run in the mode of its forward).
+ * 0 (default): fp32-exact products from three bf16 pieces per operand (see spf_geo_set_mode); spf_rhead_backward then leaves
+ * g_b6 / g_b0 / g_b2 untouched — they are the column sums of g_agg / G1 / G2 and come from spf_wgrad's dbias output.
+ * 1: v_mfma_f32_32x32x2_f32, bias gradients accumulated by spf_rhead_backward. */
+int spf_rhead_set_mode(int32_t mode);
+int spf_rhead_get_mode(void);
+
 int64_t spf_rhead_packed_floats(void);
 int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const float* b0, const float* w2, const float* b2,
                    const float* w4, const float* b4, float* packed, void* stream);

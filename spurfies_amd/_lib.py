@@ -54,6 +54,8 @@ SIGNATURES = {
     "spf_color_pack": (C.c_int, [_P] * 8),
     "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_color_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_rhead_set_mode": (C.c_int, [_I]),
+    "spf_rhead_get_mode": (C.c_int, []),
     "spf_rhead_packed_floats": (C.c_int64, []),
     "spf_rhead_pack": (C.c_int, [_P] * 10),
     "spf_rhead_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

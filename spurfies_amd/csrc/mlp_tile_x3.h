@@ -47,7 +47,7 @@ struct X3Regs {
 };
 // SWAP = false: transposed product, acc[m][n] = (features 32 m.., rows 32 n..) = W X; SWAP = true: acc[m][n] = (rows 32 m.., features
 // 32 n..) = X^T W^T, the same fragments with the operand roles exchanged (a lane then owns a feature column strip).
-template <int R, bool LW, bool LX, bool LN, bool SWAP = false>
+template <int R, bool LW, bool LX, bool LN, bool SWAP = false, int LDP = X3_LDP>
 __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 (&acc)[2][2], X3Regs& r, WFrag3& nxt, gx3 next_wp) {
     constexpr int R1 = (R + 1) % 3, R2 = (R + 2) % 3;
     if (LW) {
@@ -61,7 +61,7 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) r.x[R1][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * X3_PLANE + 32 * n * X3_LDP + 16 * (t + 1));
+            for (int p = 0; p < 3; ++p) r.x[R1][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 32 * n * LDP + 16 * (t + 1));
     }
     __builtin_amdgcn_sched_barrier(0);
     // smallest terms first; four accumulators alternate
@@ -82,11 +82,11 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int T, bool SWAP = false>
+template <int T, bool SWAP = false, int LDP = X3_LDP>
 __device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][2], const WFrag3& first, gx3 next_wp) {
     static_assert(T >= 3, "gemm_x3: at least three k-steps");
     const int j = lane & 31, kg = lane >> 5;
-    const __bf16* xp = X + j * X3_LDP + 8 * kg;
+    const __bf16* xp = X + j * LDP + 8 * kg;
     X3Regs r;
     WFrag3 nxt = first;
 #pragma unroll
@@ -99,20 +99,20 @@ __device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) r.x[0][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * X3_PLANE + 32 * n * X3_LDP);
+        for (int p = 0; p < 3; ++p) r.x[0][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 32 * n * LDP);
     constexpr int MAIN = T - 2, REM = MAIN % 3;        // k-steps that request weights; the last two only consume
     int t = 0;
 #pragma unroll 1
     for (; t + 3 <= MAIN; t += 3) {
-        x3_step<0, true, true, false, SWAP>(xp, wp, t, acc, r, nxt, next_wp);
-        x3_step<1, true, true, false, SWAP>(xp, wp, t + 1, acc, r, nxt, next_wp);
-        x3_step<2, true, true, false, SWAP>(xp, wp, t + 2, acc, r, nxt, next_wp);
+        x3_step<0, true, true, false, SWAP, LDP>(xp, wp, t, acc, r, nxt, next_wp);
+        x3_step<1, true, true, false, SWAP, LDP>(xp, wp, t + 1, acc, r, nxt, next_wp);
+        x3_step<2, true, true, false, SWAP, LDP>(xp, wp, t + 2, acc, r, nxt, next_wp);
     }
-    if (REM >= 1) x3_step<0, true, true, false, SWAP>(xp, wp, MAIN - REM, acc, r, nxt, next_wp);
-    if (REM == 2) x3_step<1, true, true, false, SWAP>(xp, wp, MAIN - 1, acc, r, nxt, next_wp);
-    if (next_wp) x3_step<REM, false, true, true, SWAP>(xp, wp, T - 2, acc, r, nxt, next_wp);
-    else x3_step<REM, false, true, false, SWAP>(xp, wp, T - 2, acc, r, nxt, next_wp);
-    x3_step<(REM + 1) % 3, false, false, false, SWAP>(xp, wp, T - 1, acc, r, nxt, next_wp);
+    if (REM >= 1) x3_step<0, true, true, false, SWAP, LDP>(xp, wp, MAIN - REM, acc, r, nxt, next_wp);
+    if (REM == 2) x3_step<1, true, true, false, SWAP, LDP>(xp, wp, MAIN - 1, acc, r, nxt, next_wp);
+    if (next_wp) x3_step<REM, false, true, true, SWAP, LDP>(xp, wp, T - 2, acc, r, nxt, next_wp);
+    else x3_step<REM, false, true, false, SWAP, LDP>(xp, wp, T - 2, acc, r, nxt, next_wp);
+    x3_step<(REM + 1) % 3, false, false, false, SWAP, LDP>(xp, wp, T - 1, acc, r, nxt, next_wp);
     return nxt;
 }
 
@@ -133,7 +133,7 @@ __device__ __forceinline__ WFrag1 load_wfrag1(gx3 wp) {
 struct X1Regs {
     bf16x8 w[3][3], x[3][3];
 };
-template <int R, bool LW, bool LX>
+template <int R, bool LW, bool LX, int LDP = X3_LDP>
 __device__ __forceinline__ void x1_step(const __bf16* xp, gx3 wp, int t, f32x16& lo, f32x16& hi, X1Regs& r) {
     constexpr int R1 = (R + 1) % 3, R2 = (R + 2) % 3;
     if (LW) {
@@ -142,7 +142,7 @@ __device__ __forceinline__ void x1_step(const __bf16* xp, gx3 wp, int t, f32x16&
     }
     if (LX) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) r.x[R1][p] = *reinterpret_cast<const bf16x8*>(xp + p * X3_PLANE + 16 * (t + 1));
+        for (int p = 0; p < 3; ++p) r.x[R1][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 16 * (t + 1));
     }
     __builtin_amdgcn_sched_barrier(0);
     lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][2], r.x[R][0], lo, 0, 0, 0);
@@ -154,11 +154,11 @@ __device__ __forceinline__ void x1_step(const __bf16* xp, gx3 wp, int t, f32x16&
     __builtin_amdgcn_sched_barrier(0);
 }
 // returns the tile in the accumulator layout (row_of / column = lane & 31)
-template <int T>
+template <int T, int LDP = X3_LDP>
 __device__ __forceinline__ f32x16 gemm_x3_tile(const __bf16* X, int n, gx3 wp, int lane, const WFrag1& pre) {
     static_assert(T >= 3 && (T - 2) % 3 != 0, "gemm_x3_tile: tail phases are written for (T - 2) mod 3 in {1, 2}");
     const int j = lane & 31, kg = lane >> 5;
-    const __bf16* xp = X + (32 * n + j) * X3_LDP + 8 * kg;
+    const __bf16* xp = X + (32 * n + j) * LDP + 8 * kg;
     X1Regs r;
     f32x16 lo, hi;
 #pragma unroll
@@ -167,20 +167,20 @@ __device__ __forceinline__ f32x16 gemm_x3_tile(const __bf16* X, int n, gx3 wp, i
     for (int p = 0; p < 3; ++p) {
         r.w[0][p] = pre.w[0][p];
         r.w[1][p] = pre.w[1][p];
-        r.x[0][p] = *reinterpret_cast<const bf16x8*>(xp + p * X3_PLANE);
+        r.x[0][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP));
     }
     constexpr int MAIN = T - 2, REM = MAIN % 3;
     int t = 0;
 #pragma unroll 1
     for (; t + 3 <= MAIN; t += 3) {
-        x1_step<0, true, true>(xp, wp, t, lo, hi, r);
-        x1_step<1, true, true>(xp, wp, t + 1, lo, hi, r);
-        x1_step<2, true, true>(xp, wp, t + 2, lo, hi, r);
+        x1_step<0, true, true, LDP>(xp, wp, t, lo, hi, r);
+        x1_step<1, true, true, LDP>(xp, wp, t + 1, lo, hi, r);
+        x1_step<2, true, true, LDP>(xp, wp, t + 2, lo, hi, r);
     }
-    if (REM >= 1) x1_step<0, true, true>(xp, wp, MAIN - REM, lo, hi, r);
-    if (REM == 2) x1_step<1, true, true>(xp, wp, MAIN - 1, lo, hi, r);
-    x1_step<REM, false, true>(xp, wp, T - 2, lo, hi, r);
-    x1_step<(REM + 1) % 3, false, false>(xp, wp, T - 1, lo, hi, r);
+    if (REM >= 1) x1_step<0, true, true, LDP>(xp, wp, MAIN - REM, lo, hi, r);
+    if (REM == 2) x1_step<1, true, true, LDP>(xp, wp, MAIN - 1, lo, hi, r);
+    x1_step<REM, false, true, LDP>(xp, wp, T - 2, lo, hi, r);
+    x1_step<(REM + 1) % 3, false, false, LDP>(xp, wp, T - 1, lo, hi, r);
 #pragma unroll
     for (int q = 0; q < 16; ++q) hi[q] += lo[q];
     return hi;
@@ -230,17 +230,19 @@ __device__ __forceinline__ void split3_pair(f32x2 a, uint32_t& c1, uint32_t& c2,
 }
 
 // write 4 consecutive features of one row as three bf16 quads
+template <int LDP = X3_LDP>
 __device__ __forceinline__ void store_quad_x3(__bf16* X, int row, int f0, f32x4 v) {
     uint32_t a1, a2, a3, b1, b2, b3;
     split3_pair(f32x2{v[0], v[1]}, a1, a2, a3);
     split3_pair(f32x2{v[2], v[3]}, b1, b2, b3);
-    __bf16* dst = X + row * X3_LDP + f0;
+    __bf16* dst = X + row * LDP + f0;
     *reinterpret_cast<u32x2*>(dst) = u32x2{a1, b1};
-    *reinterpret_cast<u32x2*>(dst + X3_PLANE) = u32x2{a2, b2};
-    *reinterpret_cast<u32x2*>(dst + 2 * X3_PLANE) = u32x2{a3, b3};
+    *reinterpret_cast<u32x2*>(dst + (64 * LDP)) = u32x2{a2, b2};
+    *reinterpret_cast<u32x2*>(dst + 2 * (64 * LDP)) = u32x2{a3, b3};
 }
+template <int LDP = X3_LDP>
 __device__ __forceinline__ void store_quad_x3(__bf16* X, int row, int f0, const float (&v)[4]) {
-    store_quad_x3(X, row, f0, f32x4{v[0], v[1], v[2], v[3]});
+    store_quad_x3<LDP>(X, row, f0, f32x4{v[0], v[1], v[2], v[3]});
 }
 
 // LeakyReLU sign bits travel in 32-bit words filled from the top: push appends (h > 0) below the bits already there
@@ -272,13 +274,13 @@ __device__ __forceinline__ float lrelu_pop(float g, float g001, uint32_t& bits) 
 
 // [64][8 * NG] tile of the planes (exactly p1 + p2 + p3 per element) -> fp32 rows in HBM, coalesced (32 B per thread, a row's
 // threads are consecutive): what the weight-gradient GEMM reads.
-template <int NG>
+template <int NG, int LDP = X3_LDP>
 __device__ __forceinline__ void store_tile_from_planes(const __bf16* X, float* __restrict__ dst, int ld_dst, int tid) {
     for (int idx = tid; idx < 64 * NG; idx += 256) {
         const int row = idx / NG, gc = idx % NG;
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(X + row * X3_LDP + 8 * gc);
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(X + X3_PLANE + row * X3_LDP + 8 * gc);
-        const bf16x8 c = *reinterpret_cast<const bf16x8*>(X + 2 * X3_PLANE + row * X3_LDP + 8 * gc);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(X + row * LDP + 8 * gc);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(X + (64 * LDP) + row * LDP + 8 * gc);
+        const bf16x8 c = *reinterpret_cast<const bf16x8*>(X + 2 * (64 * LDP) + row * LDP + 8 * gc);
         f32x4 lo, hi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -292,12 +294,13 @@ __device__ __forceinline__ void store_tile_from_planes(const __bf16* X, float* _
 }
 
 // one element (row, col) of the planes
+template <int LDP = X3_LDP>
 __device__ __forceinline__ void store_one_x3(__bf16* X, int row, int col, float v) {
     __bf16 a, b, c;
     split3(v, a, b, c);
-    X[row * X3_LDP + col] = a;
-    X[X3_PLANE + row * X3_LDP + col] = b;
-    X[2 * X3_PLANE + row * X3_LDP + col] = c;
+    X[row * LDP + col] = a;
+    X[(64 * LDP) + row * LDP + col] = b;
+    X[2 * (64 * LDP) + row * LDP + col] = c;
 }
 
 }  // namespace spf

@@ -11,6 +11,7 @@
 // Weight gradients of the 256-wide layers are GEMMs over stored [P,256] buffers (G_l^T act_{l-1}: spf_wgrad); the
 // 3 x 256 last layer's and all bias gradients are accumulated in-kernel.
 #include "mlp_tile.h"
+#include "mlp_tile_x3.h"
 
 namespace {
 using namespace spf;
@@ -385,17 +386,406 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
     }
 }
 
+
+// ==============================================================================================================================
+// The same two kernels on the bf16 matrix pipe with fp32-exact products from three bf16 pieces per operand (the default;
+// spf_rhead_set_mode(1) selects the fp32-MFMA kernels above).  Engine: mlp_tile_x3.h; plane row stride 296 bf16 so that the first
+// head layer's 288-wide input ([agg 256 | dir-enc 21 | 0]) is one GEMM.  One workgroup per CU (113.7 KB of planes).
+// Bias gradients of the three 256-wide layers are column sums of g_agg / G1 / G2 and come from spf_wgrad (dbias) in this mode.
+// ==============================================================================================================================
+constexpr int RX_LDP = 296;                       // 592 B rows: 16-B aligned, 37 x 16 B (odd) -> conflict-free 16-byte reads
+constexpr int RX_T1 = 18;                         // 288 / 16
+constexpr int RX_TH = 16;
+constexpr int RX_SZ1 = 4 * RX_T1 * 2 * 3 * 64;    // bf16x8 entries
+constexpr int RX_SZH = 4 * RX_TH * 2 * 3 * 64;
+constexpr int RX_FW6 = 0;
+constexpr int RX_FW1 = RX_FW6 + RX_SZH;
+constexpr int RX_FW2 = RX_FW1 + RX_SZ1;
+constexpr int RX_BW2 = RX_FW2 + RX_SZH;
+constexpr int RX_BWA = RX_BW2 + RX_SZH;
+constexpr int RX_BW6 = RX_BWA + RX_SZH;
+constexpr int RX_FRAGS = RX_BW6 + RX_SZH;
+constexpr int R_PACKED_TOTAL = R_PACKED + 4 * RX_FRAGS;
+
+__global__ void rhead_pack_x3_kernel(RPackArgs a, bf16x8* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int N1 = RX_SZ1 / 3, NH = RX_SZH / 3;
+    if (s >= N1 + 5 * NH) return;
+    int region, local, base_r;      // 0 FW6, 1 FW1, 2 FW2, 3 BW2, 4 BWA, 5 BW6
+    if (s < NH) { region = 0; local = s; base_r = RX_FW6; }
+    else if (s < NH + N1) { region = 1; local = s - NH; base_r = RX_FW1; }
+    else { region = 2 + (s - NH - N1) / NH; local = (s - NH - N1) % NH; base_r = RX_FW2 + (region - 2) * RX_SZH; }
+    const int T = region == 1 ? RX_T1 : RX_TH;
+    const int ln = local & 63, i = ln & 31, kg = ln >> 5, m = (local >> 6) & 1, t = (local >> 7) % T, wv = (local >> 7) / T;
+    const int f = 64 * wv + 32 * m + i;
+    bf16x8 p1, p2, p3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 16 * t + 8 * kg + e;
+        float v;
+        switch (region) {
+            case 0: v = a.w6[f * 256 + k]; break;                                                            // agg = W6 agg3
+            case 1: v = k < 256 ? a.w0[f * R_IN + 21 + k] : (k < R_IN ? a.w0[f * R_IN + (k - 256)] : 0.f); break;
+            case 2: v = a.w2[f * 256 + k]; break;
+            case 3: v = a.w2[k * 256 + f]; break;                                                            // g_a1 = G2 W2
+            case 4: v = a.w0[k * R_IN + 21 + f]; break;                                                      // g_agg = G1 W0[:, 21:]
+            default: v = a.w6[k * 256 + f]; break;                                                           // g_agg3 = g_agg W6
+        }
+        __bf16 x, y, z;
+        split3(v, x, y, z);
+        p1[e] = x; p2[e] = y; p3[e] = z;
+    }
+    const size_t base = (size_t)base_r + (size_t)((wv * T + t) * 2 + m) * 3 * 64 + ln;
+    out[base] = p1;
+    out[base + 64] = p2;
+    out[base + 128] = p3;
+}
+
+struct RxBias {
+    f32x4 b[2][4];
+};
+__device__ __forceinline__ RxBias rx_load_bias(gfp bias, int wave, int lane) {
+    RxBias r;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            r.b[m][g] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(bias + 64 * wave + 32 * m + 8 * g + 4 * (lane >> 5));
+    return r;
+}
+
+// transposed epilogues (lane = row j of half n, 4 consecutive features per quad): linear (acc + b), LeakyReLU forward (sign words
+// pushed in the order (m, g, e), stored lane-major) and LeakyReLU backward (popped in the same order)
+__device__ __forceinline__ void rx_linear_epilogue(__bf16* X, const f32x16 (&acc)[2][2], const RxBias* bias, int wave, int lane) {
+    const int j = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x4 h = f32x4{acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+                if (bias) h += bias->b[m][g];
+                store_quad_x3<RX_LDP>(X, 32 * n + j, f0, h);
+            }
+        }
+}
+template <bool STORE>
+__device__ __forceinline__ void rx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], const RxBias& bias, int wave, int lane, uint32_t* masks_l) {
+    const int j = lane & 31, kg = lane >> 5;
+    uint32_t bits[2] = {0u, 0u};
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x4 h, hs, out;
+                bias_scale4(acc[m][n], g, bias.b[m][g], h, hs);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[e] = lrelu_push(h[e], hs[e], bits[n]);
+                store_quad_x3<RX_LDP>(X, 32 * n + j, f0, out);
+            }
+        }
+    if (STORE) {
+        masks_l[(2 * wave) * 64 + lane] = bits[0];
+        masks_l[(2 * wave + 1) * 64 + lane] = bits[1];
+    }
+}
+__device__ __forceinline__ void rx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mw)[2]) {
+    const int j = lane & 31, kg = lane >> 5;
+    uint32_t bits[2] = {mw[0], mw[1]};
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x4 v, vs, out;
+                scale4(acc[m][n], g, v, vs);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], bits[n]);
+                store_quad_x3<RX_LDP>(X, 32 * n + j, f0, out);
+            }
+        }
+}
+
+template <bool STORE>
+__global__ void __launch_bounds__(256, 1)
+rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict__ ray_dirs, const int32_t* __restrict__ point_slot,
+                        const int32_t* __restrict__ n_points_dev, int max_points, int SR, const float* packed, float* __restrict__ colors,
+                        float* __restrict__ agg, float* __restrict__ direnc, float* __restrict__ act1, float* __restrict__ act2,
+                        uint32_t* __restrict__ masks) {
+    __shared__ __attribute__((aligned(16))) __bf16 X[3 * 64 * RX_LDP];
+    __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+    __shared__ int s_row[64];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    const int ntiles = (P + 63) / 64;
+    const float* packed0 = packed;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gfp pf = launder(packed0);
+        gx3 frag = reinterpret_cast<gx3>(pf + R_PACKED);
+        gx3 w_fw6 = frag + RX_FW6 + wave * (RX_TH * 2 * 3 * 64) + lane;
+        gx3 w_fw1 = frag + RX_FW1 + wave * (RX_T1 * 2 * 3 * 64) + lane;
+        gx3 w_fw2 = frag + RX_FW2 + wave * (RX_TH * 2 * 3 * 64) + lane;
+        const WFrag3 fr6 = load_wfrag3(w_fw6);               // in flight during the gather
+        {   // gather: thread = (row, quarter): 64 agg3 floats each; quarter 0 also encodes the view direction (columns 256..287)
+            const int row = tid >> 2, q4 = tid & 3;
+            const int p = tile * 64 + row;
+            const bool ok = p < P;
+            const f32x4* src = reinterpret_cast<const f32x4*>(agg3 + (size_t)(ok ? p : 0) * 256 + q4 * 64);
+            f32x4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = ok ? src[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 16; ++u) store_quad_x3<RX_LDP>(X, row, q4 * 64 + 4 * u, v[u]);
+            if (q4 == 0) {
+                float e[32];
+#pragma unroll
+                for (int c = 0; c < 32; ++c) e[c] = 0.f;
+                int srow = -1;
+                if (ok) {
+                    srow = point_slot ? point_slot[p] : p;
+                    const float* dv = ray_dirs + (size_t)(srow / SR) * 3;
+                    const float d[3] = {dv[0], dv[1], dv[2]};
+                    e[0] = d[0]; e[1] = d[1]; e[2] = d[2];
+                    float fr = 1.f;
+#pragma unroll
+                    for (int l = 0; l < DIR_FREQ; ++l) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float a = d[c] * fr;
+                            e[3 + 6 * l + c] = sinf(a);
+                            e[6 + 6 * l + c] = cosf(a);
+                        }
+                        fr *= 2.f;
+                    }
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < 8; ++c4) store_quad_x3<RX_LDP>(X, row, 256 + 4 * c4, f32x4{e[4 * c4], e[4 * c4 + 1], e[4 * c4 + 2], e[4 * c4 + 3]});
+                if (STORE) {
+#pragma unroll
+                    for (int c4 = 0; c4 < 6; ++c4)
+                        *reinterpret_cast<f32x4*>(direnc + (size_t)(tile * 64 + row) * 24 + 4 * c4) = f32x4{e[4 * c4], e[4 * c4 + 1], e[4 * c4 + 2], e[4 * c4 + 3]};
+                }
+                s_row[row] = srow;
+            }
+        }
+        lds_barrier();
+        const size_t tb = (size_t)tile * 64 * 256;
+        uint32_t* mk = STORE ? masks + (size_t)tile * 2 * 512 : nullptr;
+        f32x16 acc[2][2];
+        RxBias bias = rx_load_bias(pf + RO_B6, wave, lane);
+        zero_acc(acc);
+        WFrag3 nf = gemm_x3<RX_TH, false, RX_LDP>(X, w_fw6, lane, acc, fr6, w_fw1);          // F_color.6 on the weighted mean
+        lds_barrier();
+        rx_linear_epilogue(X, acc, &bias, wave, lane);       // agg -> columns 0..255 (the dir-enc columns stay)
+        lds_barrier();
+        if (STORE) store_tile_from_planes<32, RX_LDP>(X, agg + tb, 256, tid);              // kept for R.0's weight gradient
+        bias = rx_load_bias(pf + RO_B1, wave, lane);
+        zero_acc(acc);
+        nf = gemm_x3<RX_T1, false, RX_LDP>(X, w_fw1, lane, acc, nf, w_fw2);
+        lds_barrier();
+        rx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, mk);
+        lds_barrier();
+        if (STORE) store_tile_from_planes<32, RX_LDP>(X, act1 + tb, 256, tid);
+        bias = rx_load_bias(pf + RO_B2, wave, lane);
+        zero_acc(acc);
+        gemm_x3<RX_TH, false, RX_LDP>(X, w_fw2, lane, acc, nf, nullptr);
+        lds_barrier();
+        {   // second activation (-> planes for the act2 store) and the 256 -> 3 layer from the registers: partial dot products per lane
+            uint32_t bits[2] = {0u, 0u};
+            float s[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+                    f32x4 w3[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) w3[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(pf + RO_W3 + c * 256 + f0);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        f32x4 h, hs, out;
+                        bias_scale4(acc[m][n], g, bias.b[m][g], h, hs);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            out[e] = lrelu_push(h[e], hs[e], bits[n]);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) s[n][c] += w3[c][e] * out[e];
+                        }
+                        if (STORE) store_quad_x3<RX_LDP>(X, 32 * n + j, f0, out);
+                    }
+                }
+            if (STORE) {
+                mk[512 + (2 * wave) * 64 + lane] = bits[0];
+                mk[512 + (2 * wave + 1) * 64 + lane] = bits[1];
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float t = s[n][c] + __shfl_xor(s[n][c], 32);
+                    if (kg == 0) red[(wave * 64 + 32 * n + j) * 4 + c] = t;
+                }
+        }
+        lds_barrier();
+        if (STORE) store_tile_from_planes<32, RX_LDP>(X, act2 + tb, 256, tid);
+        if (tid < 64) {
+            const int srow = s_row[tid];
+            if (srow >= 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float t = ((red[tid * 4 + c] + red[(64 + tid) * 4 + c]) + (red[(128 + tid) * 4 + c] + red[(192 + tid) * 4 + c])) + pf[RO_B3 + c];
+                    colors[(size_t)srow * 3 + c] = 1.f / (1.f + expf(-t));
+                }
+            }
+        }
+        lds_barrier();
+    }
+}
+
+__global__ void __launch_bounds__(256, 1)
+rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __restrict__ colors, const int32_t* __restrict__ point_slot,
+                         const int32_t* __restrict__ n_points_dev, int max_points, const float* packed, const float* __restrict__ act2,
+                         const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ g_agg,
+                         float* __restrict__ g_agg3, float* __restrict__ g_w4 /* [3,256] */, float* __restrict__ g_b4 /* [3] */) {
+    __shared__ __attribute__((aligned(16))) __bf16 X[3 * 64 * RX_LDP];
+    __shared__ __attribute__((aligned(16))) float s_g3[64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    const int ntiles = (P + 63) / 64;
+    const float* packed0 = packed;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gfp pf = launder(packed0);
+        gx3 frag = reinterpret_cast<gx3>(pf + R_PACKED);
+        gx3 w_bw2 = frag + RX_BW2 + wave * (RX_TH * 2 * 3 * 64) + lane;
+        gx3 w_bwa = frag + RX_BWA + wave * (RX_TH * 2 * 3 * 64) + lane;
+        gx3 w_bw6 = frag + RX_BW6 + wave * (RX_TH * 2 * 3 * 64) + lane;
+        const size_t tb = (size_t)tile * 64 * 256;
+        const WFrag3 fr2 = load_wfrag3(w_bw2);               // in flight during the small last-layer stage
+        if (tid < 64) {   // dL/d(pre-sigmoid) = g_c * c (1 - c)
+            const int p = tile * 64 + tid;
+            float g[3] = {0.f, 0.f, 0.f};
+            if (p < P) {
+                const int srow = point_slot ? point_slot[p] : p;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float cc = colors[(size_t)srow * 3 + c];
+                    g[c] = g_colors[(size_t)srow * 3 + c] * cc * (1.f - cc);
+                }
+            }
+            *reinterpret_cast<f32x4*>(s_g3 + tid * 4) = f32x4{g[0], g[1], g[2], 0.f};
+        }
+        lds_barrier();
+        {   // dW3[c][col] += sum_rows g3[row][c] a2[row][col]; db3[c] += sum_rows g3[row][c]   (thread = column)
+            float a0 = 0.f, a1 = 0.f, a2v = 0.f;
+            const int rows_here = min(64, P - tile * 64);
+            for (int row = 0; row < rows_here; ++row) {
+                const float a = act2[tb + row * 256 + tid];
+                a0 += s_g3[row * 4] * a;
+                a1 += s_g3[row * 4 + 1] * a;
+                a2v += s_g3[row * 4 + 2] * a;
+            }
+            atomicAdd(&g_w4[tid], a0);
+            atomicAdd(&g_w4[256 + tid], a1);
+            atomicAdd(&g_w4[512 + tid], a2v);
+            if (tid < 3) {
+                float s = 0.f;
+                for (int row = 0; row < 64; ++row) s += s_g3[row * 4 + tid];
+                atomicAdd(&g_b4[tid], s);
+            }
+        }
+        const uint32_t* mk = masks + (size_t)tile * 2 * 512;
+        {   // G2 = (g3 W3) * lrelu'(h2), formed in the transposed accumulator arrangement -> planes
+            uint32_t bits[2] = {mk[512 + (2 * wave) * 64 + lane], mk[512 + (2 * wave + 1) * 64 + lane]};
+            const f32x4 g3[2] = {*reinterpret_cast<const f32x4*>(s_g3 + j * 4), *reinterpret_cast<const f32x4*>(s_g3 + (32 + j) * 4)};
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+                    f32x4 w3[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) w3[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(pf + RO_W3 + c * 256 + f0);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        f32x4 out;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = g3[n][0] * w3[0][e] + g3[n][1] * w3[1][e] + g3[n][2] * w3[2][e];
+                            out[e] = lrelu_pop(v, v * 0.01f, bits[n]);
+                        }
+                        store_quad_x3<RX_LDP>(X, 32 * n + j, f0, out);
+                    }
+                }
+        }
+        lds_barrier();
+        store_tile_from_planes<32, RX_LDP>(X, G2 + tb, 256, tid);
+        f32x16 acc[2][2];
+        const uint32_t mw1[2] = {mk[(2 * wave) * 64 + lane], mk[(2 * wave + 1) * 64 + lane]};
+        zero_acc(acc);
+        WFrag3 nf = gemm_x3<RX_TH, false, RX_LDP>(X, w_bw2, lane, acc, fr2, w_bwa);
+        lds_barrier();
+        rx_bwd_epilogue(X, acc, wave, lane, mw1);
+        lds_barrier();
+        store_tile_from_planes<32, RX_LDP>(X, G1 + tb, 256, tid);
+        zero_acc(acc);
+        nf = gemm_x3<RX_TH, false, RX_LDP>(X, w_bwa, lane, acc, nf, w_bw6);
+        lds_barrier();
+        rx_linear_epilogue(X, acc, nullptr, wave, lane);     // g_agg: operand of F_color.6's weight gradient and of the last product
+        lds_barrier();
+        store_tile_from_planes<32, RX_LDP>(X, g_agg + tb, 256, tid);
+        zero_acc(acc);
+        gemm_x3<RX_TH, false, RX_LDP>(X, w_bw6, lane, acc, nf, nullptr);                     // g_agg3 = g_agg W6
+        lds_barrier();
+        {   // -> fp32 tile in the (now dead) plane memory -> coalesced rows in HBM
+            float* XF = reinterpret_cast<float*>(X);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        *reinterpret_cast<f32x4*>(XF + (32 * n + j) * LDA + 64 * wave + 32 * m + 8 * g + 4 * kg) =
+                            f32x4{acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+            lds_barrier();
+            store_tile_256<LDA>(XF, g_agg3 + tb, tid);
+        }
+        lds_barrier();
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-int64_t spf_rhead_packed_floats(void) { return R_PACKED; }
+static int g_rhead_mode = 0;      // 0: bf16-piece products (fp32-exact), 1: fp32 MFMA
+
+int spf_rhead_set_mode(int32_t mode) {
+    if (mode != 0 && mode != 1) return spf::fail(SPF_EINVAL, "spf_rhead_set_mode: 0 (split-bf16 products) or 1 (fp32 MFMA), got %d", mode);
+    g_rhead_mode = mode;
+    return SPF_OK;
+}
+
+int spf_rhead_get_mode(void) { return g_rhead_mode; }
+
+int64_t spf_rhead_packed_floats(void) { return R_PACKED_TOTAL; }
 
 int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const float* b0, const float* w2, const float* b2, const float* w4,
                    const float* b4, float* packed, void* stream) {
     if (!w6 || !b6 || !w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !packed) return spf::fail(SPF_EINVAL, "spf_rhead_pack: null pointer");
     RPackArgs a{w6, b6, w0, b0, w2, b2, w4, b4};
     rhead_pack_kernel<<<spf::div_up(R_PACKED, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
+    rhead_pack_x3_kernel<<<spf::div_up(RX_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + R_PACKED));
     SPF_LAUNCH_CHECK("rhead_pack_kernel");
     return SPF_OK;
 }
@@ -410,6 +800,17 @@ int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* p
     if (store && (!agg || !act1 || !act2 || !masks)) return spf::fail(SPF_EINVAL, "spf_rhead_forward: training buffers must be given together");
     const int tiles = spf::div_up(max_points, 64);
     const int blocks = tiles < 512 ? tiles : 512;
+    if (g_rhead_mode == 0) {
+        const int b1 = tiles < 256 ? tiles : 256;       // one workgroup per CU
+        if (store)
+            rhead_forward_x3_kernel<true><<<b1, 256, 0, (hipStream_t)stream>>>(agg3, ray_dirs, point_slot, n_points, max_points, SR, packed, colors, agg,
+                                                                               direnc, act1, act2, masks);
+        else
+            rhead_forward_x3_kernel<false><<<b1, 256, 0, (hipStream_t)stream>>>(agg3, ray_dirs, point_slot, n_points, max_points, SR, packed, colors,
+                                                                                nullptr, nullptr, nullptr, nullptr, nullptr);
+        SPF_LAUNCH_CHECK("rhead_forward_x3_kernel");
+        return SPF_OK;
+    }
     if (store)
         rhead_forward_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(agg3, ray_dirs, point_slot, n_points, max_points, SR, packed, colors, agg,
                                                                             direnc, act1, act2, masks);
@@ -429,6 +830,13 @@ int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t
         return spf::fail(SPF_EINVAL, "spf_rhead_backward: null pointer");
     const int tiles = spf::div_up(max_points, 64);
     const int blocks = tiles < 512 ? tiles : 512;
+    if (g_rhead_mode == 0) {    // g_b6 / g_b0 / g_b2 are not touched in this mode: spf_wgrad's dbias output provides them
+        const int b1 = tiles < 256 ? tiles : 256;
+        rhead_backward_x3_kernel<<<b1, 256, 0, (hipStream_t)stream>>>(g_colors, colors, point_slot, n_points, max_points, packed, act2, masks, G1, G2,
+                                                                      g_agg, g_agg3, g_w4, g_b4);
+        SPF_LAUNCH_CHECK("rhead_backward_x3_kernel");
+        return SPF_OK;
+    }
     rhead_backward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_colors, colors, point_slot, n_points, max_points, packed, act2, masks, G1, G2,
                                                                    g_agg, g_agg3, g_b6, g_b0, g_b2, g_w4, g_b4);
     SPF_LAUNCH_CHECK("rhead_backward_kernel");

@@ -519,23 +519,28 @@ class RHead(torch.autograd.Function):
                                                      _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_agg3),
                                                      _lib.ptr(g_b6), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_w4), _lib.ptr(g_b4),
                                                      _lib.stream_ptr()), "spf_rhead_backward")
+        # split-product kernels (the default) leave the 256-wide layers' bias gradients to the weight-gradient GEMMs (column sums)
+        split = rhead_mode() == "split"
+        kb = (lambda b: b) if split else (lambda b: None)
         if sk is not None:
-            wgrad(g_agg, agg3, n_points, out=sk[0])                     # F_color.6: K = points, not pairs
+            wgrad(g_agg, agg3, n_points, out=sk[0], dbias=kb(g_b6))     # F_color.6: K = points, not pairs
             wgrad(G1, direnc, n_points, C=21, out=sk[2])                # R.0, reference column order [dir-enc | agg]
-            wgrad(G1, agg, n_points, out=sk[2][:, 21:], ldw=277)
-            wgrad(G2, act1, n_points, out=sk[4])
+            wgrad(G1, agg, n_points, out=sk[2][:, 21:], ldw=277, dbias=kb(g_b0))
+            wgrad(G2, act1, n_points, out=sk[4], dbias=kb(g_b2))
             return (g_agg3[:P],) + (None,) * 14
         if ctx.static:
-            dw6 = wgrad(g_agg, agg3, n_points)
+            dw6 = wgrad(g_agg, agg3, n_points, dbias=kb(g_b6))
             dw0 = torch.zeros((256, 277), dtype=torch.float32, device=dev)        # reference column order [dir-enc | agg]
             wgrad(G1, direnc, n_points, C=21, out=dw0)
-            wgrad(G1, agg, n_points, out=dw0[:, 21:])
-            dw2 = wgrad(G2, act1, n_points)
+            wgrad(G1, agg, n_points, out=dw0[:, 21:], dbias=kb(g_b0))
+            dw2 = wgrad(G2, act1, n_points, dbias=kb(g_b2))
         else:
             G1p, G2p = G1[:P], G2[:P]
             dw6 = g_agg[:P].t() @ agg3
             dw0 = torch.cat([G1p.t() @ direnc[:P, :21], G1p.t() @ agg[:P]], dim=1)
             dw2 = G2p.t() @ act1[:P]
+            if split:
+                g_b6, g_b0, g_b2 = g_agg[:P].sum(0), G1p.sum(0), G2p.sum(0)
         return (g_agg3[:P], dw6, g_b6, dw0, g_b0, dw2, g_b2, g_w4, g_b4, None, None, None, None, None, None)
 
 
@@ -550,6 +555,15 @@ def set_color_mode(mode: str):
 
 def color_mode() -> str:
     return "split" if _lib.lib().spf_color_get_mode() == 0 else "f32"
+
+
+def set_rhead_mode(mode: str):
+    """'split' (default) or 'f32': arithmetic of the per-point head kernels (spf_rhead_set_mode); switch only between steps."""
+    _lib.check(_lib.lib().spf_rhead_set_mode({"split": 0, "f32": 1}[mode]), "spf_rhead_set_mode")
+
+
+def rhead_mode() -> str:
+    return "split" if _lib.lib().spf_rhead_get_mode() == 0 else "f32"
 
 
 def set_wgrad_mode(mode: str):

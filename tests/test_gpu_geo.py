@@ -149,8 +149,10 @@ def color_mode(request):
     from spurfies_amd import ops
 
     ops.set_color_mode(request.param)
+    ops.set_rhead_mode(request.param)
     yield request.param
     ops.set_color_mode("split")
+    ops.set_rhead_mode("split")
 
 
 @pytest.mark.parametrize("static", [False, True])
@@ -212,7 +214,7 @@ def test_color_path_forward_backward_match_oracle(color_mode, static):
         np.testing.assert_allclose(params[n].grad.cpu().numpy(), g.numpy(), rtol=2e-3, atol=2e-4 * float(g.abs().max()), err_msg=n)
 
 
-def test_rhead_forward_backward_match_torch():
+def test_rhead_forward_backward_match_torch(color_mode):
     """Head stage alone (F_color.6 per point + R, pointneus_disent.py:333-346) vs the oracle's torch ops: colours, d/d agg3,
     weight and bias gradients; sparse slot rows and SR > 1."""
     from spurfies_amd import ops
