@@ -192,7 +192,7 @@ def main():
                    "rays_per_gpu": args.rays, "neural_points": args.points, "k": 8, "max_shading_pts": 80,
                    "parallelism": f"ray-sharded dp{world}", "valid_points_last_step": model.stats.get("valid_points", int(model.stats["counts"][0].item()) if "counts" in model.stats else None),
                    "host_syncs_per_step": 1 if args.sync else 0,
-                   "arithmetic": "fp32 throughout; the geometry and colour-trunk MLP kernels and the weight-gradient GEMMs form each fp32 product exactly from three bf16 pieces per operand (6 bf16 MFMAs, fp32 accumulate); the per-point head MLP kernels run on fp32 MFMA",
+                   "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product exactly from three bf16 pieces per operand (6 bf16 MFMAs, fp32 accumulate)",
                    "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~110 per step)")},
         "roofline": roof,
         "loss_last": loss_last,
