@@ -26,14 +26,18 @@ __device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c)
 // `first`: the layer's k-step-0 fragments, requested by the previous layer's GEMM (its last k-step) so that their L2 round trip
 // is not exposed behind the barriers; returns the k-step-0 fragments of `next_wp` (or `first`).
 struct WFrag3 {
-    bf16x8 w[2][3];
+    bf16x8 w[2][3];       // k-step 0
+    bf16x8 w1[2][3];      // k-step 1
 };
 __device__ __forceinline__ WFrag3 load_wfrag3(gx3 wp) {
     WFrag3 f;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) f.w[m][p] = wp[(m * 3 + p) * 64];
+        for (int p = 0; p < 3; ++p) {
+            f.w[m][p] = wp[(m * 3 + p) * 64];
+            f.w1[m][p] = wp[(6 + m * 3 + p) * 64];
+        }
     return f;
 }
 
@@ -47,7 +51,7 @@ struct X3Regs {
 };
 // SWAP = false: transposed product, acc[m][n] = (features 32 m.., rows 32 n..) = W X; SWAP = true: acc[m][n] = (rows 32 m.., features
 // 32 n..) = X^T W^T, the same fragments with the operand roles exchanged (a lane then owns a feature column strip).
-template <int R, bool LW, bool LX, bool LN, bool SWAP = false, int LDP = X3_LDP>
+template <int R, bool LW, bool LX, int LN, bool SWAP = false, int LDP = X3_LDP, bool FIRST = false>
 __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 (&acc)[2][2], X3Regs& r, WFrag3& nxt, gx3 next_wp) {
     constexpr int R1 = (R + 1) % 3, R2 = (R + 2) % 3;
     if (LW) {
@@ -56,29 +60,66 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
 #pragma unroll
             for (int p = 0; p < 3; ++p) r.w[R2][m][p] = wp[((t + 2) * 6 + m * 3 + p) * 64];
     }
-    if (LN) nxt = load_wfrag3(next_wp);
+    if (LN == 1) {          // the next layer's k-step 0 (second-to-last k-step) and k-step 1 (last k-step): no request of this layer left
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) nxt.w[m][p] = next_wp[(m * 3 + p) * 64];
+    }
+    if (LN == 2) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) nxt.w1[m][p] = next_wp[(6 + m * 3 + p) * 64];
+    }
     if (LX) {
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int p = 0; p < 3; ++p) r.x[R1][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 32 * n * LDP + 16 * (t + 1));
     }
+#ifdef SPF_X3_PINNED
     __builtin_amdgcn_sched_barrier(0);
+#endif
     // smallest terms first; four accumulators alternate
-#define SPF_X3(PW, PX)                                                                                                 \
-    if (!SWAP) {                                                                                                       \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0][PW], r.x[R][0][PX], acc[0][0], 0, 0, 0);           \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0][PW], r.x[R][1][PX], acc[0][1], 0, 0, 0);           \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1][PW], r.x[R][0][PX], acc[1][0], 0, 0, 0);           \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1][PW], r.x[R][1][PX], acc[1][1], 0, 0, 0);           \
-    } else {                                                                                                           \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][0][PX], r.w[R][0][PW], acc[0][0], 0, 0, 0);           \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][0][PX], r.w[R][1][PW], acc[0][1], 0, 0, 0);           \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][1][PX], r.w[R][0][PW], acc[1][0], 0, 0, 0);           \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][1][PX], r.w[R][1][PW], acc[1][1], 0, 0, 0);           \
+    // (the first product of a GEMM takes C = 0 as an inline constant: no accumulator zeroing)
+#define SPF_X3(PW, PX, Z)                                                                                              \
+    {                                                                                                                  \
+        const f32x16 c00 = (Z) ? zero16 : acc[0][0], c01 = (Z) ? zero16 : acc[0][1], c10 = (Z) ? zero16 : acc[1][0],       \
+                     c11 = (Z) ? zero16 : acc[1][1];                                                                   \
+        if (!SWAP) {                                                                                                   \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0][PW], r.x[R][0][PX], c00, 0, 0, 0);             \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0][PW], r.x[R][1][PX], c01, 0, 0, 0);             \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1][PW], r.x[R][0][PX], c10, 0, 0, 0);             \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1][PW], r.x[R][1][PX], c11, 0, 0, 0);             \
+        } else {                                                                                                       \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][0][PX], r.w[R][0][PW], c00, 0, 0, 0);             \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][0][PX], r.w[R][1][PW], c01, 0, 0, 0);             \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][1][PX], r.w[R][0][PW], c10, 0, 0, 0);             \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][1][PX], r.w[R][1][PW], c11, 0, 0, 0);             \
+        }                                                                                                              \
     }
-    SPF_X3(2, 0) SPF_X3(0, 2) SPF_X3(1, 1) SPF_X3(1, 0) SPF_X3(0, 1) SPF_X3(0, 0)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    SPF_X3(2, 0, FIRST) SPF_X3(0, 2, false) SPF_X3(1, 1, false) SPF_X3(1, 0, false) SPF_X3(0, 1, false) SPF_X3(0, 0, false)
 #undef SPF_X3
+#ifndef SPF_X3_PINNED
+    // the requests ride between the MFMAs (issued in one block in front of them, their ~25 issue slots leave the matrix pipe idle
+    // once per k-step): LDS reads first (needed at the start of the next k-step), then the L2 requests (needed one k-step later)
+    if (LX) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+    if (LW || LN != 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -94,25 +135,42 @@ __device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             r.w[0][m][p] = first.w[m][p];
+#ifdef SPF_X3_OLDPRO
             r.w[1][m][p] = wp[(6 + m * 3 + p) * 64];
+#else
+            r.w[1][m][p] = first.w1[m][p];
+#endif
         }
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int p = 0; p < 3; ++p) r.x[0][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 32 * n * LDP);
     constexpr int MAIN = T - 2, REM = MAIN % 3;        // k-steps that request weights; the last two only consume
-    int t = 0;
+#ifdef SPF_X3_OLDPRO
+    constexpr bool ZC = false;
+#else
+    constexpr bool ZC = true;
+#endif
+    if (MAIN >= 3) {
+        x3_step<0, true, true, 0, SWAP, LDP, ZC>(xp, wp, 0, acc, r, nxt, next_wp);
+        x3_step<1, true, true, 0, SWAP, LDP>(xp, wp, 1, acc, r, nxt, next_wp);
+        x3_step<2, true, true, 0, SWAP, LDP>(xp, wp, 2, acc, r, nxt, next_wp);
 #pragma unroll 1
-    for (; t + 3 <= MAIN; t += 3) {
-        x3_step<0, true, true, false, SWAP, LDP>(xp, wp, t, acc, r, nxt, next_wp);
-        x3_step<1, true, true, false, SWAP, LDP>(xp, wp, t + 1, acc, r, nxt, next_wp);
-        x3_step<2, true, true, false, SWAP, LDP>(xp, wp, t + 2, acc, r, nxt, next_wp);
+        for (int t = 3; t + 3 <= MAIN; t += 3) {
+            x3_step<0, true, true, 0, SWAP, LDP>(xp, wp, t, acc, r, nxt, next_wp);
+            x3_step<1, true, true, 0, SWAP, LDP>(xp, wp, t + 1, acc, r, nxt, next_wp);
+            x3_step<2, true, true, 0, SWAP, LDP>(xp, wp, t + 2, acc, r, nxt, next_wp);
+        }
     }
-    if (REM >= 1) x3_step<0, true, true, false, SWAP, LDP>(xp, wp, MAIN - REM, acc, r, nxt, next_wp);
-    if (REM == 2) x3_step<1, true, true, false, SWAP, LDP>(xp, wp, MAIN - 1, acc, r, nxt, next_wp);
-    if (next_wp) x3_step<REM, false, true, true, SWAP, LDP>(xp, wp, T - 2, acc, r, nxt, next_wp);
-    else x3_step<REM, false, true, false, SWAP, LDP>(xp, wp, T - 2, acc, r, nxt, next_wp);
-    x3_step<(REM + 1) % 3, false, false, false, SWAP, LDP>(xp, wp, T - 1, acc, r, nxt, next_wp);
+    if (REM >= 1) x3_step<0, true, true, 0, SWAP, LDP, (ZC && MAIN < 3)>(xp, wp, MAIN - REM, acc, r, nxt, next_wp);
+    if (REM == 2) x3_step<1, true, true, 0, SWAP, LDP>(xp, wp, MAIN - 1, acc, r, nxt, next_wp);
+    if (next_wp) {
+        x3_step<REM, false, true, 1, SWAP, LDP>(xp, wp, T - 2, acc, r, nxt, next_wp);
+        x3_step<(REM + 1) % 3, false, false, 2, SWAP, LDP>(xp, wp, T - 1, acc, r, nxt, next_wp);
+    } else {
+        x3_step<REM, false, true, 0, SWAP, LDP>(xp, wp, T - 2, acc, r, nxt, next_wp);
+        x3_step<(REM + 1) % 3, false, false, 0, SWAP, LDP>(xp, wp, T - 1, acc, r, nxt, next_wp);
+    }
     return nxt;
 }
 
