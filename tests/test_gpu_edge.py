@@ -1,0 +1,131 @@
+"""GPU: edge cases of the fused MLP kernels on the pair lists the training step produces — no valid point at all, pair counts on
+and next to tile boundaries (a tile is 64 pairs), every row of a tile hitting the same few neural points (the colour backward
+sums such rows in LDS before its atomics), in both arithmetic modes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import path as P
+from spurfies_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["split", "f32"])
+def mode(request):
+    from spurfies_amd import ops
+
+    for f in (ops.set_geo_mode, ops.set_color_mode, ops.set_rhead_mode):
+        f(request.param)
+    yield request.param
+    for f in (ops.set_geo_mode, ops.set_color_mode, ops.set_rhead_mode):
+        f("split")
+
+
+def _scene(n_points=3000, seed=3):
+    from spurfies_amd import ops
+    from spurfies_amd.torch_knnquery import VoxelGrid
+
+    scene = syn.make_scene(n_points, seed=seed)
+    st = P.load_state(scene["state"])
+    cfg = P.PathConfig(ranges=tuple(scene["ranges"]))
+    dev = {k: v.detach().cuda() for k, v in st.items()}
+    grid = VoxelGrid(cfg.voxel_size, cfg.voxel_scale, cfg.kernel_size, 26, 20000, cfg.ranges)
+    grid.set_pointset(dev["neural_pts"].unsqueeze(0))
+    return scene, cfg, dev, grid, ops.pack_geometry_weights(dev)
+
+
+def _colour_step(x, cfg, dev, grid, packed, static=True):
+    """geometry + colour trunk + head on the rows `x`, sync-free form; returns (colors, sdf, grads dict, counts)."""
+    from spurfies_amd import ops
+
+    M = x.shape[0]
+    q = grid.query_dense(x.unsqueeze(1), cfg.k, cfg.r, 1)
+    point_slot, _, n_pts = ops.compact_points(q["slot_valid"])
+    pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), point_slot, n_pts)
+    geo = ops.geo_forward(x, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
+    names = [f"{m}.{i}.{n}" for m, idx in (("F_color", (0, 2, 4, 6)), ("R", (0, 2, 4))) for i in idx for n in ("weight", "bias")]
+    params = {n: dev[n].clone().requires_grad_(True) for n in names}
+    fcp = [params[f"F_color.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")]
+    hdp = [params[f"F_color.6.{n}"] for n in ("weight", "bias")] + [params[f"R.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")]
+    table = dev["neural_feats_color"].clone().requires_grad_(True)
+    dirs = torch.nn.functional.normalize(torch.randn((M, 3), generator=torch.Generator().manual_seed(1)), dim=-1).cuda()
+    agg3 = ops.ColorAgg.apply(table, *fcp, x, geo["wn"], pl, dev["neural_pts"], None, None)
+    colors = ops.RHead.apply(agg3, *hdp, dirs, point_slot, n_pts, 1, M, static)
+    coef = torch.randn((M, 3), generator=torch.Generator().manual_seed(2)).cuda()
+    (colors * coef).sum().backward()
+    grads = {n: p.grad for n, p in params.items()}
+    grads["neural_feats_color"] = table.grad
+    return colors.detach(), geo["sdf"], grads, pl.host_counts()
+
+
+def test_no_valid_point_at_all(mode):
+    """Every query far outside the cloud: zero points, zero pairs — the kernels run on empty lists and leave zeros behind."""
+    scene, cfg, dev, grid, packed = _scene()
+    x = torch.full((300, 3), 50.0, device="cuda") + torch.rand((300, 3), device="cuda")
+    colors, sdf, grads, (n_p, n_q) = _colour_step(x, cfg, dev, grid, packed)
+    assert (n_p, n_q) == (0, 0)
+    assert float(colors.abs().max()) == 0.0 and bool((sdf == 1000.0).all())
+    for n, g in grads.items():
+        assert g is not None and float(g.abs().max()) == 0.0, n
+
+
+@pytest.mark.parametrize("n_query", [8, 9, 16, 64, 72])
+def test_pair_counts_on_tile_boundaries(mode, n_query):
+    """n_query points with all k = 8 neighbours -> 8 n_query pairs: 64 = exactly one tile, 72 = one tile + 8 rows, 128, 512 = whole
+    tiles, 576 = nine; SDF against the same rows computed inside a larger batch, colours / gradients finite and non-trivial."""
+    scene, cfg, dev, grid, packed = _scene()
+    pts = dev["neural_pts"]
+    q0 = grid.query_dense(pts[:1500].unsqueeze(1), cfg.k, cfg.r, 1)
+    full = torch.nonzero((q0["pidx"].reshape(-1, cfg.k) >= 0).sum(1) == cfg.k).reshape(-1)      # points with all k neighbours in reach
+    assert full.numel() >= n_query
+    x_small = pts[full[:n_query]].clone()
+    x_big = torch.cat([x_small, pts[1500:1800] + 0.003])
+    c_s, sdf_s, g_s, (n_p, n_q) = _colour_step(x_small, cfg, dev, grid, packed)
+    assert n_p == n_query and n_q == 8 * n_query
+    from spurfies_amd import ops
+
+    # reference: the same rows as the head of a bigger batch, forward only (row-wise independent)
+    q = grid.query_dense(x_big.unsqueeze(1), cfg.k, cfg.r, 1)
+    ps, _, npts = ops.compact_points(q["slot_valid"])
+    pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), ps, npts)
+    geo = ops.geo_forward(x_big, pl, pts, dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=False)
+    np.testing.assert_allclose(sdf_s.cpu().numpy(), geo["sdf"][:n_query].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert bool(torch.isfinite(c_s).all()) and float(c_s.min()) > 0.0 and float(c_s.max()) < 1.0
+    for n, g in g_s.items():
+        assert bool(torch.isfinite(g).all()), n
+    assert float(g_s["neural_feats_color"].abs().sum()) > 0.0
+
+
+def test_every_row_of_a_tile_hits_the_same_neural_points(mode):
+    """All queries at (nearly) the same place: each 64-pair tile holds the same 8 neural points 8 times.  The latent gradient must
+    equal the torch scatter of the per-pair gradients — compared between the two arithmetic modes' common oracle: float64 torch."""
+    scene, cfg, dev, grid, packed = _scene()
+    pts = dev["neural_pts"]
+    x = pts[7].unsqueeze(0).repeat(256, 1) + torch.rand((256, 3), device="cuda") * 1e-4
+    c, sdf, g, (n_p, n_q) = _colour_step(x, cfg, dev, grid, packed)
+    assert n_p == 256 and n_q == 2048
+    gt = g["neural_feats_color"]
+    rows = torch.nonzero(gt.abs().sum(1) > 0).reshape(-1)
+    assert 8 <= rows.numel() <= 16                      # the handful of neighbours around point 7 receive everything
+    # oracle: the reference formulation on the CPU (autograd through gather + MLP + weighted mean + head)
+    st = P.load_state(scene["state"])
+    for n in ("neural_feats_color",):
+        st[n].requires_grad_(True)
+    ogrid = P.make_grid(cfg, st["neural_pts"])
+    xc = x.cpu()
+    nb, _, mask, _ = P.knn_query(ogrid, xc.unsqueeze(1), cfg.k, cfg.r, 1)
+    valid = nb >= 0
+    prow = P.pair_index(valid)
+    pos, fc, fg = P.gather_pairs(nb, valid, st)
+    x_pi = xc[mask.reshape(-1)][prow] - pos
+    w, norm = P.rbf_weights(x_pi, prow, nb.shape[0], cfg.rbf)
+    feat = P.mlp(torch.cat([P.posenc(x_pi, 6), fc], -1), st, "F_color")
+    agg = torch.zeros(nb.shape[0], 256).index_add_(0, prow, w.unsqueeze(-1) * feat) / norm.unsqueeze(-1)
+    dirs = torch.nn.functional.normalize(torch.randn((256, 3), generator=torch.Generator().manual_seed(1)), dim=-1)
+    col = torch.sigmoid(P.mlp(torch.cat([P.posenc(dirs, 3), agg], -1), st, "R"))
+    coef = torch.randn((256, 3), generator=torch.Generator().manual_seed(2))
+    (col * coef).sum().backward()
+    go = st["neural_feats_color"].grad
+    np.testing.assert_allclose(c.cpu().numpy(), col.detach().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(gt.cpu().numpy(), go.numpy(), rtol=2e-3, atol=1e-4 * float(go.abs().max()))
