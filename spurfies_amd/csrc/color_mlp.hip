@@ -745,6 +745,7 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
         lds_barrier();
         T_MARK(9)
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
+        const float bv[2] = {pf[CO_B3 + 64 * wave + (lane & 31)], pf[CO_B3 + 64 * wave + (lane & 31) + 32]};     // layer-4 biases, ahead of the GEMM
         if (STORE) store_tile_from_planes<32>(X, act2 + (size_t)tile * 64 * 256, 256, tid);
         // ---- layer 4, NON-transposed: acc[m][n] = rows 32m.., features 64w + 32n..; lane (feature j, k-half kg) ------------------
         zero_acc(acc);
@@ -755,7 +756,6 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
         {
             const int j = lane & 31, kg = lane >> 5;
             const int c0 = 64 * wave + j;
-            const float bv[2] = {pf[CO_B3 + c0], pf[CO_B3 + c0 + 32]};
             int cur = -1;
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll

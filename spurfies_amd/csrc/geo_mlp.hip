@@ -524,7 +524,7 @@ __device__ __forceinline__ Bias3 load_bias3(gfp bias, int wave, int lane) {
 // forward epilogue: a = lrelu(acc + b) -> planes; sign bits pushed into mask[n] in the order (m, g, e) (32 per word).
 // MODE 1 (last layer): sdf partial sums s[n] += v . a, and the planes receive the Jacobian seed v * lrelu'(h) instead.
 template <int MODE, bool WITH_JAC>
-__device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], const Bias3& bias, gfp v5, int wave, int lane,
+__device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], const Bias3& bias, const Bias3& v5, int wave, int lane,
                                                 uint32_t (&mask)[2], float (&s)[2]) {
     const int j = lane & 31, kg = lane >> 5;
     mask[0] = mask[1] = 0u;
@@ -536,7 +536,7 @@ __device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
             const f32x4 bv = bias.b[m][g];
             f32x4 vv = f32x4{0.f, 0.f, 0.f, 0.f}, vs = vv;
             if (MODE == 1) {
-                vv = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(v5 + f0);
+                vv = v5.b[m][g];
                 vs = vv * 0.01f;
             }
 #pragma unroll
@@ -679,7 +679,7 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, pf + OFF_V5, wave, lane, m1, ssum);
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m1, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
@@ -693,7 +693,7 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, pf + OFF_V5, wave, lane, m2, ssum);
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m2, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
@@ -704,19 +704,20 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, pf + OFF_V5, wave, lane, m3, ssum);
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m3, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
         cur = gx_fetch_row(n_idx, n_srow, q40, x, pts, feat_geo);
         bias = load_bias3(pf + OFF_B4, wave, lane);
+        const Bias3 v5q = load_bias3(pf + OFF_V5, wave, lane);       // folded last layer v = T W8, same quads: requested ahead of the GEMM too
         zero_acc(acc);
         nf = gemm_x3<X3_TH>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
         // last forward layer: sdf_j = v . a4 + c from the accumulators; the planes receive the Jacobian seed v * lrelu'(h4)
-        fwd_epilogue_x3<1, WITH_JAC>(X, acc, bias, pf + OFF_V5, wave, lane, m4, ssum);
+        fwd_epilogue_x3<1, WITH_JAC>(X, acc, bias, v5q, wave, lane, m4, ssum);
         {
             const int j = lane & 31, kg = lane >> 5;
 #pragma unroll

@@ -596,6 +596,8 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
         lds_barrier();
         if (STORE) store_tile_from_planes<32, RX_LDP>(X, act1 + tb, 256, tid);
         bias = rx_load_bias(pf + RO_B2, wave, lane);
+        const RxBias w3q0 = rx_load_bias(pf + RO_W3, wave, lane), w3q1 = rx_load_bias(pf + RO_W3 + 256, wave, lane),
+                     w3q2 = rx_load_bias(pf + RO_W3 + 512, wave, lane);      // the 3 x 256 last layer, this lane's quads: ahead of the GEMM
         zero_acc(acc);
         gemm_x3<RX_TH, false, RX_LDP>(X, w_fw2, lane, acc, nf, nullptr);
         lds_barrier();
@@ -607,9 +609,7 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
-                    f32x4 w3[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) w3[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(pf + RO_W3 + c * 256 + f0);
+                    const f32x4 w3[3] = {w3q0.b[m][g], w3q1.b[m][g], w3q2.b[m][g]};
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         f32x4 h, hs, out;
@@ -686,6 +686,11 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
             *reinterpret_cast<f32x4*>(s_g3 + tid * 4) = f32x4{g[0], g[1], g[2], 0.f};
         }
         lds_barrier();
+        const uint32_t* mk = masks + (size_t)tile * 2 * 512;
+        // operands of the G2 stage, requested ahead of the dW3 stage
+        const RxBias w3q0 = rx_load_bias(pf + RO_W3, wave, lane), w3q1 = rx_load_bias(pf + RO_W3 + 256, wave, lane),
+                     w3q2 = rx_load_bias(pf + RO_W3 + 512, wave, lane);
+        uint32_t bits[2] = {mk[512 + (2 * wave) * 64 + lane], mk[512 + (2 * wave + 1) * 64 + lane]};
         {   // dW3[c][col] += sum_rows g3[row][c] a2[row][col]; db3[c] += sum_rows g3[row][c]   (thread = column)
             float a0 = 0.f, a1 = 0.f, a2v = 0.f;
             const int rows_here = min(64, P - tile * 64);
@@ -704,18 +709,14 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
                 atomicAdd(&g_b4[tid], s);
             }
         }
-        const uint32_t* mk = masks + (size_t)tile * 2 * 512;
         {   // G2 = (g3 W3) * lrelu'(h2), formed in the transposed accumulator arrangement -> planes
-            uint32_t bits[2] = {mk[512 + (2 * wave) * 64 + lane], mk[512 + (2 * wave + 1) * 64 + lane]};
             const f32x4 g3[2] = {*reinterpret_cast<const f32x4*>(s_g3 + j * 4), *reinterpret_cast<const f32x4*>(s_g3 + (32 + j) * 4)};
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
-                    f32x4 w3[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) w3[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(pf + RO_W3 + c * 256 + f0);
+                    const f32x4 w3[3] = {w3q0.b[m][g], w3q1.b[m][g], w3q2.b[m][g]};
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         f32x4 out;
