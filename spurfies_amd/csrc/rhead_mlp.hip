@@ -687,10 +687,7 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
         }
         lds_barrier();
         const uint32_t* mk = masks + (size_t)tile * 2 * 512;
-        // operands of the G2 stage, requested ahead of the dW3 stage
-        const RxBias w3q0 = rx_load_bias(pf + RO_W3, wave, lane), w3q1 = rx_load_bias(pf + RO_W3 + 256, wave, lane),
-                     w3q2 = rx_load_bias(pf + RO_W3 + 512, wave, lane);
-        uint32_t bits[2] = {mk[512 + (2 * wave) * 64 + lane], mk[512 + (2 * wave + 1) * 64 + lane]};
+        uint32_t bits[2] = {mk[512 + (2 * wave) * 64 + lane], mk[512 + (2 * wave + 1) * 64 + lane]};    // G2 stage's sign words, ahead of the dW3 stage
         {   // dW3[c][col] += sum_rows g3[row][c] a2[row][col]; db3[c] += sum_rows g3[row][c]   (thread = column)
             float a0 = 0.f, a1 = 0.f, a2v = 0.f;
             const int rows_here = min(64, P - tile * 64);
@@ -716,7 +713,9 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
-                    const f32x4 w3[3] = {w3q0.b[m][g], w3q1.b[m][g], w3q2.b[m][g]};
+                    f32x4 w3[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) w3[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(pf + RO_W3 + c * 256 + f0);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         f32x4 out;

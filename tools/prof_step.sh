@@ -7,3 +7,18 @@ f=$(find gpurun_out/prof_$NAME -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/${NAME}_kernel_stats.csv
 head -32 gpurun_out/${NAME}_kernel_stats.csv | cut -c1-150
 tail -1 gpurun_out/prof_$NAME.log | cut -c1-200
+# per-launch durations of the dominant kernel's MAIN-PASS launches (the stats file above averages them with the small pseudo-point launches)
+python3 - "$NAME" <<'PY'
+import csv, glob, sys
+name = sys.argv[1]
+f = glob.glob(f"gpurun_out/prof_{name}/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if "geo_pairs_x3_kernel<true>" in r["Kernel_Name"]]
+d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+big = [x for x in d if x > 0.3 * max(d)]
+with open(f"gpurun_out/{name}_geo_main_pass_launches.csv", "w") as o:
+    o.write(f'"# geo_pairs_x3_kernel<true>: {len(d)} launches in the trace, {len(big)} of them main-pass launches (the others are the pseudo-point pass); main-pass mean {sum(big) / len(big) / 1e3:.1f} us, min {min(big) / 1e3:.1f}, max {max(big) / 1e3:.1f}"\n')
+    o.write("launch,DurationNs\n")
+    for i, x in enumerate(big):
+        o.write(f"{i},{x}\n")
+print(open(f"gpurun_out/{name}_geo_main_pass_launches.csv").readline())
+PY
