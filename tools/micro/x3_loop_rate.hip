@@ -9,7 +9,41 @@
 #include "mlp_tile_x3.h"
 using namespace spf;
 
-template <int MODE>
+// ablations of the loop's operand traffic (wrong results, timing only): VAR 1 = every k-step re-reads the k-step-0 weight fragments
+// (same request count, one 6 KB line set per wave: L1-resident instead of streamed from L2), VAR 2 = LDS operand of k-step 0 every step
+template <int VAR>
+__device__ __forceinline__ WFrag3 gemm_var(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][2], const WFrag3& first) {
+    const int j = lane & 31, kg = lane >> 5;
+    const __bf16* xp = X + j * X3_LDP + 8 * kg;
+    X3Regs r;
+    WFrag3 nxt = first;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { r.w[0][m][p] = first.w[m][p]; r.w[1][m][p] = first.w1[m][p]; }
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) r.x[0][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * X3_PLANE + 32 * n * X3_LDP);
+    gx3 wq = VAR == 1 ? wp - 12 * 64 : wp;           // (t + 2) * 6 * 64 with t = 0 lands on k-step 0 ... keep the address arithmetic, pin t
+    x3_step<0, true, true, 0, false, X3_LDP, true>(VAR == 2 ? xp - 16 : xp, wq, 0, acc, r, nxt, wp);
+    x3_step<1, true, true, 0>(VAR == 2 ? xp - 32 : xp, VAR == 1 ? wq - 6 * 64 : wq, 1, acc, r, nxt, wp);
+    x3_step<2, true, true, 0>(VAR == 2 ? xp - 48 : xp, VAR == 1 ? wq - 12 * 64 : wq, 2, acc, r, nxt, wp);
+#pragma unroll 1
+    for (int t = 3; t + 3 <= 14; t += 3) {
+        const int tw = VAR == 1 ? 0 : t, tx = VAR == 2 ? 0 : t;
+        x3_step<0, true, true, 0>(xp + 16 * (tx - t), wp + (tw - t) * 6 * 64 - (VAR == 1 ? 12 * 64 : 0), t, acc, r, nxt, wp);
+        x3_step<1, true, true, 0>(xp + 16 * (tx - t) - (VAR == 2 ? 16 : 0), wp + (tw - t) * 6 * 64 - (VAR == 1 ? 18 * 64 : 0), t + 1, acc, r, nxt, wp);
+        x3_step<2, true, true, 0>(xp + 16 * (tx - t) - (VAR == 2 ? 32 : 0), wp + (tw - t) * 6 * 64 - (VAR == 1 ? 24 * 64 : 0), t + 2, acc, r, nxt, wp);
+    }
+    x3_step<0, true, true, 0>(VAR == 2 ? xp - 16 * 13 : xp, VAR == 1 ? wp - 14 * 6 * 64 : wp, 12, acc, r, nxt, wp);
+    x3_step<1, true, true, 0>(VAR == 2 ? xp - 16 * 14 : xp, VAR == 1 ? wp - 15 * 6 * 64 : wp, 13, acc, r, nxt, wp);
+    x3_step<2, false, true, 1>(VAR == 2 ? xp - 16 * 15 : xp, wp, 14, acc, r, nxt, wp);
+    x3_step<0, false, false, 2>(xp, wp, 15, acc, r, nxt, wp);
+    return nxt;
+}
+
+template <int MODE, int VAR = 0>
 __global__ void __launch_bounds__(256, 1) k(const bf16x8* __restrict__ wfrag, const float* __restrict__ bias, int layers, unsigned long long* cyc) {
     __shared__ __attribute__((aligned(16))) __bf16 X[3 * X3_PLANE];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kg = lane >> 5;
@@ -23,7 +57,8 @@ __global__ void __launch_bounds__(256, 1) k(const bf16x8* __restrict__ wfrag, co
     float keep = 0.f;
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int l = 0; l < layers; ++l) {
-        nf = gemm_x3<16>(X, wp, lane, acc, nf, wp);
+        if (VAR == 0) nf = gemm_x3<16>(X, wp, lane, acc, nf, wp);
+        else nf = gemm_var<VAR>(X, wp, lane, acc, nf);
         keep += (acc[0][0][0] + acc[0][1][0]) + (acc[1][0][0] + acc[1][1][0]);      // every accumulator chain stays live
         lds_barrier();
         if (MODE >= 1) {
@@ -74,5 +109,14 @@ int main() {
     RUN(0, "GEMM + barrier                      ")
     RUN(1, "GEMM + minimal epilogue (split only)")
     RUN(2, "GEMM + bias / LeakyReLU / sign words")
+#undef RUN
+#define RUN(M, V, label)                                                                                                           \
+    k<M, V><<<256, 256>>>(dW, dB, layers, dC);                                                                                     \
+    (void)hipEventRecord(e0); k<M, V><<<256, 256>>>(dW, dB, layers, dC); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);  \
+    (void)hipEventElapsedTime(&ms, e0, e1); (void)hipMemcpy(&c0, dC, 8, hipMemcpyDeviceToHost);                                    \
+    printf(label ": %.3f ms, %.1f fp32-equivalent TFLOP/s, %.0f cycles per k-step, %.2f GHz\n", ms,                                \
+           256.0 * layers * 2.0 * 64 * 256 * 256 / (ms * 1e-3) / 1e12, (double)c0 / layers / 16.0, (double)c0 / (ms * 1e6));
+    RUN(2, 1, "  same, weights not streamed (k-step-0 fragments every step)")
+    RUN(2, 2, "  same, LDS operand of k-step 0 every step                  ")
     return 0;
 }
