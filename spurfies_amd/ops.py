@@ -246,7 +246,22 @@ def pack_color_weights(ws):
     return packed
 
 
-class ColorAgg(torch.autograd.Function):
+class _GradModeFunction(torch.autograd.Function):
+    """autograd.Function whose forward needs to know whether a backward can follow: `ctx.needs_input_grad` only mirrors the
+    inputs' requires_grad (also under torch.no_grad()), and grad mode is always off inside forward()."""
+
+    _outer_grad_mode = True
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        prev, _GradModeFunction._outer_grad_mode = _GradModeFunction._outer_grad_mode, torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _GradModeFunction._outer_grad_mode = prev
+
+
+class ColorAgg(_GradModeFunction):
     """agg3[p,256] = sum_j wn_j a3_j for the P valid points, a3 = the third activation of F_color on
     [posenc6(x_pi) | colour latent] (pointneus_disent.py:325-336).  F_color's last layer is linear and commutes with the
     weighted mean, so it runs once per point inside `RHead`.  Forward and the data-gradient chain are HIP kernels; the
@@ -263,7 +278,7 @@ class ColorAgg(torch.autograd.Function):
         rows = 64 * tiles
         packed = pack_color_weights([w0, b0, w2, b2, w4, b4])
         agg3 = torch.zeros((P, 256), dtype=torch.float32, device=dev)
-        train = any(ctx.needs_input_grad[:7])
+        train = _GradModeFunction._outer_grad_mode and any(ctx.needs_input_grad[:7])     # no training stores under torch.no_grad()
         if train:
             bufs = [torch.empty((rows, 104), dtype=torch.float32, device=dev), torch.empty((rows, 256), dtype=torch.float32, device=dev),
                     torch.empty((rows, 256), dtype=torch.float32, device=dev), torch.empty((tiles, 3, 512), dtype=torch.int32, device=dev)]
@@ -466,7 +481,7 @@ def pack_rhead_weights(ws):
     return packed
 
 
-class RHead(torch.autograd.Function):
+class RHead(_GradModeFunction):
     """colors [rows,3] = sigmoid(R([direnc3(ray dir) | F_color.6(agg3)])) on the P valid points (pointneus_disent.py:333-346),
     written at the points' slot rows (0 elsewhere).  F_color's linear last layer is applied here, per point, to the
     RBF-weighted mean `agg3` that `ColorAgg` produced.  Forward and the data-gradient chain are HIP kernels; the wide
@@ -482,7 +497,7 @@ class RHead(torch.autograd.Function):
         T = 64 * tiles
         packed = pack_rhead_weights([w6, b6, w0, b0, w2, b2, w4, b4])
         colors = torch.zeros((n_rows, 3), dtype=torch.float32, device=dev)
-        train = any(ctx.needs_input_grad[:9])
+        train = _GradModeFunction._outer_grad_mode and any(ctx.needs_input_grad[:9])
         if train:
             bufs = [torch.empty((T, 256), dtype=torch.float32, device=dev), torch.empty((T, 24), dtype=torch.float32, device=dev),
                     torch.empty((T, 256), dtype=torch.float32, device=dev), torch.empty((T, 256), dtype=torch.float32, device=dev),
