@@ -178,6 +178,9 @@ def main():
                 "peak_basis": "algorithmic fp32 FLOP/s; each fp32 product = 6 exact bf16 piece products on v_mfma_f32_32x32x16_bf16, so the "
                               "ceiling is the dense bf16 MFMA peak (2516.6 TFLOP/s) / 6; for scale, the fp32-MFMA peak is 157.3 TFLOP/s",
                 "achieved_over_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+                "power_envelope_note": "peak is the 2.4 GHz data-sheet figure; the library's GEMM loop alone (tools/micro/x3_loop_rate.hip) holds 1.53 GHz "
+                                       "at 90 % matrix-pipe duty and 2.2 GHz at 66-76 %, i.e. 240-290 algorithmic TFLOP/s is what this instruction mix "
+                                       "can draw (DESIGN.md section 6)",
                 "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                 if traffic else None, "kernel": "geo_pairs_x3_kernel<true> (+ geo_point_reduce_kernel, < 1 % of the launch)",
                 "timing": ("HIP events over eager passes of the timed batches, right after the timed region (events cannot sit inside a "
