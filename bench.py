@@ -201,7 +201,7 @@ def main():
         "loss_last": loss_last,
     }
     if rank == 0:
-        res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(scene, args.cpu_rays)
+        res["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(scene, args.cpu_rays)     # N = 1 only
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()
