@@ -78,9 +78,6 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
 #pragma unroll
             for (int p = 0; p < 3; ++p) r.x[R1][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 32 * n * LDP + 16 * (t + 1));
     }
-#ifdef SPF_X3_PINNED
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     // smallest terms first; four accumulators alternate
     // (the first product of a GEMM takes C = 0 as an inline constant: no accumulator zeroing)
 #define SPF_X3(PW, PX, Z)                                                                                              \
@@ -102,7 +99,6 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     SPF_X3(2, 0, FIRST) SPF_X3(0, 2, false) SPF_X3(1, 1, false) SPF_X3(1, 0, false) SPF_X3(0, 1, false) SPF_X3(0, 0, false)
 #undef SPF_X3
-#ifndef SPF_X3_PINNED
     // the requests ride between the MFMAs (issued in one block in front of them, their ~25 issue slots leave the matrix pipe idle
     // once per k-step): LDS reads first (needed at the start of the next k-step), then the L2 requests (needed one k-step later)
     if (LX) {
@@ -119,7 +115,6 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -135,22 +130,14 @@ __device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             r.w[0][m][p] = first.w[m][p];
-#ifdef SPF_X3_OLDPRO
-            r.w[1][m][p] = wp[(6 + m * 3 + p) * 64];
-#else
             r.w[1][m][p] = first.w1[m][p];
-#endif
         }
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int p = 0; p < 3; ++p) r.x[0][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 32 * n * LDP);
     constexpr int MAIN = T - 2, REM = MAIN % 3;        // k-steps that request weights; the last two only consume
-#ifdef SPF_X3_OLDPRO
-    constexpr bool ZC = false;
-#else
-    constexpr bool ZC = true;
-#endif
+    constexpr bool ZC = true;                          // C = 0 on the first product of the GEMM
     if (MAIN >= 3) {
         x3_step<0, true, true, 0, SWAP, LDP, ZC>(xp, wp, 0, acc, r, nxt, next_wp);
         x3_step<1, true, true, 0, SWAP, LDP>(xp, wp, 1, acc, r, nxt, next_wp);

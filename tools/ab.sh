@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/ab.sh "<flags A>" "<flags B>"  -- same-box A/B of two library builds on the kernel micro-benchmarks
+# usage (GPU box): bash tools/ab.sh "<flags A>" "<flags B>"  (e.g. "" vs "-DSPF_SOLO")  -- same-box A/B of two library builds on the kernel micro-benchmarks
 cd $GRAFT_REPO_ROOT
 for F in "$1" "$2" "$1" "$2"; do
   SPF_EXTRA_HIPCC_FLAGS="$F" python -m spurfies_amd.build --force 2>&1 | grep -E "error"
