@@ -833,7 +833,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
     __shared__ __attribute__((aligned(16))) __bf16 X[CX_LDS_BF16];
     __shared__ __attribute__((aligned(16))) int s_idx[64];
     __shared__ __attribute__((aligned(16))) float L[64 * CX_LDL];      // the tile's latent gradients, [row][64 (+4)]
-    __shared__ unsigned long long s_mask[64];                          // rows with the same neighbour (set on the first of them)
+    __shared__ __attribute__((aligned(16))) int s_lead[64];            // neighbour index of the rows that lead a group of equal indices, else -1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
@@ -938,7 +938,8 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         lds_barrier();
         // Rows of a tile that hit the same neural point (samples along a ray share most of their neighbours) are summed in LDS
         // first: same-address atomics serialise in L2, and with one workgroup per CU nothing else runs meanwhile.
-        // thread = (row, quarter of the 64 latent columns); the first row of each group of equal indices adds the group.
+        // thread = (row, quarter of the 64 latent columns): the first row of each group of equal indices takes the group's sum (in
+        // place: a row is read by its group's first row only), all groups in parallel.
         {
             const int my = s_idx[row0];
             uint32_t part = 0u;
@@ -952,26 +953,42 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
             mask |= __shfl_xor(mask, 1);
             mask |= __shfl_xor(mask, 2);
             const bool leader = my >= 0 && (mask & ((1ull << row0) - 1ull)) == 0ull;
-            if (q40 == 0) s_mask[row0] = leader ? mask : 0ull;
+            if (q40 == 0) s_lead[row0] = leader ? my : -1;
+            mask &= ~(1ull << row0);
+            if (leader && mask) {
+                float* own = &L[row0 * CX_LDL + 16 * q40];
+                f32x4 sum[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sum[u] = *reinterpret_cast<const f32x4*>(own + 4 * u);
+                while (mask) {
+                    const int r2 = __builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sum[u] += *reinterpret_cast<const f32x4*>(&L[r2 * CX_LDL + 16 * q40 + 4 * u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(own + 4 * u) = sum[u];
+            }
         }
         lds_barrier();
-        // wave w adds rows 16 w .. 16 w + 15: one row per instruction, lane = latent column (256 contiguous bytes per atomic
-        // instruction; a lane-per-row arrangement touches 32 to 64 cache lines per instruction and runs at a fraction of the rate)
-#pragma unroll 1
-        for (int rr = 0; rr < 16; ++rr) {
-            const int row = 16 * wave + rr;
-            const unsigned long long m0 = s_mask[row];
-            unsigned long long mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m0 >> 32)) << 32) |
-                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)m0);     // (the builtin returns int)
-            if (mask == 0ull) continue;
-            const int idx = __builtin_amdgcn_readfirstlane(s_idx[row]);
-            float sum = 0.f;
-            while (mask) {
-                const int r2 = __builtin_ctzll(mask);
-                mask &= mask - 1ull;
-                sum += L[r2 * CX_LDL + lane];
+        // wave w adds rows 16 w .. 16 w + 15 that lead a group: one row per instruction, lane = latent column (256 contiguous bytes per
+        // atomic instruction; a lane-per-row arrangement touches 32 to 64 cache lines per instruction and runs at a fraction of the
+        // rate).  The 16 row reads are independent of each other and of the atomics.
+        {
+            int lead[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int4 v = *reinterpret_cast<const int4*>(&s_lead[16 * wave + 4 * u]);
+                lead[4 * u] = v.x; lead[4 * u + 1] = v.y; lead[4 * u + 2] = v.z; lead[4 * u + 3] = v.w;
             }
-            atomicAdd(g_feat_col + (size_t)idx * SPF_COL_DIM + lane, sum);
+            float val[16];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) val[rr] = L[(16 * wave + rr) * CX_LDL + lane];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int idx = __builtin_amdgcn_readfirstlane(lead[rr]);
+                if (idx >= 0) atomicAdd(g_feat_col + (size_t)idx * SPF_COL_DIM + lane, val[rr]);
+            }
         }
         T_MARK(23)
         lds_barrier();
