@@ -58,8 +58,7 @@ struct CPackArgs {
     const float *w0, *b0, *w2, *b2, *w4, *b4;
 };
 
-__global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void color_pack_kernel_body(const CPackArgs& a, float* __restrict__ out, int e) {
     if (e >= C_PACKED) return;
     float val = 0.f;
     if (e < CO_BWL) {
@@ -496,8 +495,7 @@ constexpr int CX_BWL = CX_BW2 + CX_SZH;
 constexpr int CX_FRAGS = CX_BWL + CX_SZL;
 constexpr int C_PACKED_TOTAL = C_PACKED + 4 * CX_FRAGS;
 
-__global__ void color_pack_x3_kernel(CPackArgs a, bf16x8* __restrict__ out) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void color_pack_x3_kernel_body(const CPackArgs& a, bf16x8* __restrict__ out, int s) {
     constexpr int N1 = CX_SZ1 / 3, NH = CX_SZH / 3, NL = CX_SZL / 3;
     if (s >= N1 + 4 * NH + NL) return;
     int region, local;
@@ -997,6 +995,14 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
     T_FLUSH
 }
 
+
+// both images in one launch (the weights change every optimisation step: the packing is on the step's critical path)
+__global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    color_pack_kernel_body(a, out, e);
+    color_pack_x3_kernel_body(a, reinterpret_cast<bf16x8*>(out + C_PACKED), e);
+}
+
 }  // namespace
 
 SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_color)
@@ -1019,8 +1025,8 @@ int spf_color_pack(const float* w0, const float* b0, const float* w2, const floa
                    float* packed, void* stream) {
     if (!w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !packed) return spf::fail(SPF_EINVAL, "spf_color_pack: null pointer");
     CPackArgs a{w0, b0, w2, b2, w4, b4};
-    color_pack_kernel<<<spf::div_up(C_PACKED, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
-    color_pack_x3_kernel<<<spf::div_up(CX_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + C_PACKED));
+    constexpr int NTH = C_PACKED > CX_FRAGS / 3 ? C_PACKED : CX_FRAGS / 3;
+    color_pack_kernel<<<spf::div_up(NTH, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
     SPF_LAUNCH_CHECK("color_pack_kernel");
     return SPF_OK;
 }

@@ -47,8 +47,7 @@ struct RPackArgs {
     const float *w6, *b6, *w0, *b0, *w2, *b2, *w4, *b4;
 };
 
-__global__ void rhead_pack_kernel(RPackArgs a, float* __restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void rhead_pack_kernel_body(const RPackArgs& a, float* __restrict__ out, int e) {
     if (e >= R_PACKED) return;
     float val = 0.f;
     if (e < RO_B1) {
@@ -407,8 +406,7 @@ constexpr int RX_BW6 = RX_BWA + RX_SZH;
 constexpr int RX_FRAGS = RX_BW6 + RX_SZH;
 constexpr int R_PACKED_TOTAL = R_PACKED + 4 * RX_FRAGS;
 
-__global__ void rhead_pack_x3_kernel(RPackArgs a, bf16x8* __restrict__ out) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void rhead_pack_x3_kernel_body(const RPackArgs& a, bf16x8* __restrict__ out, int s) {
     constexpr int N1 = RX_SZ1 / 3, NH = RX_SZH / 3;
     if (s >= N1 + 5 * NH) return;
     int region, local, base_r;      // 0 FW6, 1 FW1, 2 FW2, 3 BW2, 4 BWA, 5 BW6
@@ -764,6 +762,14 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
     }
 }
 
+
+// both images in one launch (the weights change every optimisation step: the packing is on the step's critical path)
+__global__ void rhead_pack_kernel(RPackArgs a, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    rhead_pack_kernel_body(a, out, e);
+    rhead_pack_x3_kernel_body(a, reinterpret_cast<bf16x8*>(out + R_PACKED), e);
+}
+
 }  // namespace
 
 extern "C" {
@@ -784,8 +790,8 @@ int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const floa
                    const float* b4, float* packed, void* stream) {
     if (!w6 || !b6 || !w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !packed) return spf::fail(SPF_EINVAL, "spf_rhead_pack: null pointer");
     RPackArgs a{w6, b6, w0, b0, w2, b2, w4, b4};
-    rhead_pack_kernel<<<spf::div_up(R_PACKED, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
-    rhead_pack_x3_kernel<<<spf::div_up(RX_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + R_PACKED));
+    constexpr int NTH = R_PACKED > RX_FRAGS / 3 ? R_PACKED : RX_FRAGS / 3;
+    rhead_pack_kernel<<<spf::div_up(NTH, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
     SPF_LAUNCH_CHECK("rhead_pack_kernel");
     return SPF_OK;
 }

@@ -27,3 +27,14 @@ class LaplaceDensity(Density):
 
     def get_beta(self):
         return self.beta.abs() + self.beta_min
+
+    def get_beta_value(self):
+        """get_beta().detach(), computed once per parameter version (the sampler and the compositing kernel of one step read the
+        same value: two launches instead of four)."""
+        key = (self.beta._version, self.beta.data_ptr())
+        capturing = self.beta.is_cuda and torch.cuda.is_current_stream_capturing()     # a graph replay must recompute it itself
+        if capturing or getattr(self, "_beta_value_key", None) != key:
+            with torch.no_grad():
+                self._beta_value = self.beta.abs() + self.beta_min
+            self._beta_value_key = None if capturing else key
+        return self._beta_value

@@ -259,7 +259,7 @@ class PointVolSDF(nn.Module):
 
         # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------
         if static and ops._sink(self.density.beta) is not None:    # beta's gradient goes straight into its .grad buffer
-            weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta().detach(), q["slot_valid"], z_slots,
+            weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta_value(), q["slot_valid"], z_slots,
                                                                   deltas, self.density.beta)
         else:
             weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta(), q["slot_valid"], z_slots, deltas)

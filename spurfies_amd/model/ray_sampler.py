@@ -88,7 +88,7 @@ class ErrorBoundSampler_pn(RaySampler):
         R = ray_dirs.shape[0]
         ray_dirs, cam_loc = ray_dirs.detach().contiguous(), cam_loc.detach().contiguous()
         max_total_iters = fast if fast >= 0 else self.max_total_iters
-        beta0 = model.density.get_beta().detach().reshape(1).contiguous()
+        beta0 = (model.density.get_beta_value() if hasattr(model.density, "get_beta_value") else model.density.get_beta().detach()).reshape(1).contiguous()
         n0 = self.N_samples_eval
         ext = self.draws if (self.draws is not None and model.training) else None
         if ext is not None:

@@ -47,7 +47,7 @@ def compact_points(slot_valid):
     dev = slot_valid.device
     point_slot = torch.empty((R * SR,), dtype=torch.int32, device=dev)
     slot_point = torch.empty((R * SR,), dtype=torch.int32, device=dev)
-    n_points = torch.empty((1,), dtype=torch.int32, device=dev)
+    n_points = torch.empty((2,), dtype=torch.int32, device=dev)[:1]     # first half of a [n_points, n_pairs] pair: PairList adopts it
     scratch = torch.empty((R + 1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_compact_points(_lib.ptr(slot_valid), R, SR, _lib.ptr(point_slot), _lib.ptr(slot_point),
@@ -65,11 +65,15 @@ class PairList:
         self.nbr, self.point_slot, self.k = nbr, point_slot, k
         self.max_points = rows if point_slot is None else min(rows, point_slot.shape[0])
         self.max_pairs = self.max_points * k
-        self.counts = torch.empty((2,), dtype=torch.int32, device=dev)
-        if n_points is None:
-            self.counts[0] = self.max_points
+        base = getattr(n_points, "_base", None) if n_points is not None else None
+        if base is not None and base.dtype == torch.int32 and base.numel() == 2 and n_points.data_ptr() == base.data_ptr():
+            self.counts = base                  # compact_points() left room for n_pairs next to its count: no copy launch
         else:
-            self.counts[:1].copy_(n_points)
+            self.counts = torch.empty((2,), dtype=torch.int32, device=dev)
+            if n_points is None:
+                self.counts[0] = self.max_points
+            else:
+                self.counts[:1].copy_(n_points)
         self.n_points, self.n_pairs = self.counts[:1], self.counts[1:]
         self.pair_off = torch.empty((self.max_points + 1,), dtype=torch.int32, device=dev)
         self.pair_point = torch.empty((self.max_pairs,), dtype=torch.int32, device=dev)
