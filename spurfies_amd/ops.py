@@ -154,11 +154,14 @@ class GeoSDF(torch.autograd.Function):
         ctx.n_table = feat_geo.shape[0]
         ctx.sink = _sink(feat_geo)
         ctx.mark_non_differentiable(res["grad"], res["wn"])
+        ctx.set_materialize_grads(False)      # no zero tensors (two fill launches per pass) for the two non-differentiable outputs
         return res["sdf"], res["grad"], res["wn"]
 
     @staticmethod
     def backward(ctx, g_sdf, _g_grad, _g_wn):
         wn, jac, grad = ctx.saved_tensors
+        if g_sdf is None:
+            return None, None, None, None, None, None
         g_sdf = g_sdf.contiguous()
         g_x = g_feat = None
         if ctx.needs_input_grad[0]:
@@ -388,6 +391,7 @@ class Render(torch.autograd.Function):
         its gradient should be accumulated straight into its .grad buffer (set_grad_sinks)."""
         R, SR = sdf.shape
         dev = sdf.device
+        ctx.set_materialize_grads(False)        # backward handles None: no zero tensors (fill launches) for the outputs the loss ignores
         sdf_c, col_c = sdf.detach().contiguous(), colors.detach().contiguous()
         beta_c = beta.detach().reshape(1).contiguous()
         weights = torch.empty((R, SR), dtype=torch.float32, device=dev)
@@ -661,6 +665,7 @@ class FusedLoss(torch.autograd.Function):
         ctx.save_for_backward(rgb_c, acc_c, psdf_c, rgb_gt, mask_gt, pvalid, ray_valid, den)
         ctx.misc = (mask_stride, weights, acc.shape, None if psdf is None else psdf.shape, tv is not None)
         ctx.mark_non_differentiable(terms)
+        ctx.set_materialize_grads(False)
         return total, terms
 
     @staticmethod
@@ -668,6 +673,8 @@ class FusedLoss(torch.autograd.Function):
         rgb, acc, psdf, rgb_gt, mask_gt, pvalid, ray_valid, den = ctx.saved_tensors
         mask_stride, weights, acc_shape, psdf_shape, has_tv = ctx.misc
         R, dev = rgb.shape[0], rgb.device
+        if g_total is None:
+            return (None,) * 14
         g = g_total.detach().reshape(1).contiguous()
         g_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
         g_acc = torch.empty((R,), dtype=torch.float32, device=dev)
