@@ -232,8 +232,10 @@ class PointVolSDF(nn.Module):
 
         # ---- kNN of the main pass, dense [R,SR] ------------------------------------------------
         q = grid.query_dense(points.detach(), k, conf.r, SR)
-        valid = q["slot_valid"].bool()                            # [R,SR]  == reference `mask`
-        ray_mask = q["ray_valid"].bool()                          # [R]
+        static = self.sync_free and self.training
+        # the bool forms of the two masks are read by the reference-shaped outputs only (two conversion launches)
+        valid = None if static else q["slot_valid"].bool()        # [R,SR]  == reference `mask`
+        ray_mask = None if static else q["ray_valid"].bool()      # [R]
         point_slot, _, n_points = ops.compact_points(q["slot_valid"])
         pl = ops.PairList(q["pidx"].view(R * SR, k), point_slot, n_points)
 
@@ -245,7 +247,6 @@ class PointVolSDF(nn.Module):
         sdf = sdf_flat.view(R, SR)                                # gradients: [R*SR,3], zero rows where not a point
 
         # ---- colours (PyTorch ops on the P valid points; one host sync for P) -------------------
-        static = self.sync_free and self.training
         if static:       # no host round trip: worst-case buffers, counts stay on the device
             P, n_pairs, rows = 1, None, None
             self.stats = {"rays": R, "counts": pl.counts}

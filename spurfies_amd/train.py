@@ -119,16 +119,20 @@ class TrainStep:
         s = self.model.ray_sampler
         n0, N, Ne, M = s.N_samples_eval, s.N_samples, s.N_samples_extra, s.N_samples + 2 + s.N_samples_extra
         if self._draws is None or self._draws["t_rand"].shape[0] != R:
-            self._draws = {"t_rand": torch.empty((R, n0), device=dev), "u": torch.empty((R, N), device=dev),
-                           "sel": torch.empty((Ne,), dtype=torch.int32, device=dev)}
-            self._pinned = {"t_rand": torch.empty((R, n0)).pin_memory(), "u": torch.empty((R, N)).pin_memory(),
-                            "sel": torch.empty((Ne,), dtype=torch.int32).pin_memory()}
+            # one flat staging buffer on each side (the int32 selection rides as raw bits): one host-to-device copy per step
+            a, b = R * n0, R * n0 + R * N
+
+            def views(flat):
+                return {"t_rand": flat[:a].view(R, n0), "u": flat[a:b].view(R, N), "sel": flat[b:].view(torch.int32)}
+
+            self._draws_flat = torch.empty((b + Ne,), dtype=torch.float32, device=dev)
+            self._pinned_flat = torch.empty((b + Ne,), dtype=torch.float32).pin_memory()
+            self._draws, self._pinned = views(self._draws_flat), views(self._pinned_flat)
         torch.rand((R, n0), out=self._pinned["t_rand"])
         torch.rand((R, N), out=self._pinned["u"])
         self._pinned["sel"].copy_(torch.randperm(n0)[:Ne])
         torch.randint(M, (R,))                       # the unused eikonal index (:562) — keeps the generator in step
-        for k, v in self._draws.items():
-            v.copy_(self._pinned[k], non_blocking=True)
+        self._draws_flat.copy_(self._pinned_flat, non_blocking=True)
         s.draws = self._draws
 
 

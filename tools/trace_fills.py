@@ -21,7 +21,9 @@ cnt = collections.Counter()
 class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
-        if any(k in name for k in ("fill", "zero", "copy_", "full", "ones")):
+        skip = ("view", "reshape", "empty", "detach", "alias", "slice", "select", "unsqueeze", "squeeze", "expand", "transpose", "t.default",
+                "as_strided", "size", "stride", "is_", "_local_scalar", "split", "unbind", "permute", "lift_fresh", "_unsafe_view", "numel")
+        if not any(k in name for k in skip):
             st_ = [f"{f.filename.split('/')[-1]}:{f.lineno}" for f in traceback.extract_stack() if "spurfies_amd" in f.filename or "bench.py" in f.filename][-3:]
             shape = tuple(args[0].shape) if args and hasattr(args[0], "shape") else (args[0] if args else None)
             cnt[(name, " < ".join(st_), str(shape))] += 1
