@@ -310,6 +310,21 @@ int spf_wgrad_set_mode(int32_t mode);
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows,
               float* dW, int32_t ldw, float* dbias, float* workspace, void* stream);
 
+/* Up to three C = 256 weight-gradient GEMMs over the SAME rows (n_rows / max_rows) in one pair of launches: dW_q += G_q^T A_q,
+ * dbias_q += column sums of G_q (may be NULL).  The head stage's three GEMMs have K = valid points: launched one after the other
+ * each pays the pipeline ramp and a tail on a mostly idle chip; side by side they share the CUs.  `problems` is a HOST array;
+ * workspace: n_problems * spf_wgrad_workspace_floats(256) floats. */
+struct spf_wgrad_problem {
+    const float* G;
+    const float* A;
+    int32_t lda;
+    float* dW;
+    int32_t ldw;
+    float* dbias;
+};
+int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_problems, const int32_t* n_rows, int32_t max_rows,
+                      float* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Latent tables
  * ---------------------------------------------------------------------------------------- */

@@ -33,6 +33,11 @@ class LossWeights(C.Structure):
                 ("world", C.c_int32)]
 
 
+class WgradProblem(C.Structure):
+    """spf_wgrad_problem"""
+    _fields_ = [("G", C.c_void_p), ("A", C.c_void_p), ("lda", C.c_int32), ("dW", C.c_void_p), ("ldw", C.c_int32), ("dbias", C.c_void_p)]
+
+
 SIGNATURES = {
     "spf_abi_version": (C.c_int, []),
     "spf_last_error": (C.c_char_p, []),
@@ -69,6 +74,7 @@ SIGNATURES = {
     "spf_wgrad_workspace_floats": (C.c_int64, [_I]),
     "spf_wgrad_set_mode": (C.c_int, [_I]),
     "spf_wgrad": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
+    "spf_wgrad_batched": (C.c_int, [C.POINTER(WgradProblem), _I, _P, _I, _P, _P]),
     "spf_scatter_add_rows": (C.c_int, [_P, _P, C.c_int64, _I, _P, _P]),
     "spf_tv_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),

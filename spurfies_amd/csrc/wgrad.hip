@@ -263,9 +263,9 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
 // (column, k-half) item per thread) into `planes`, laid out [piece][column][k-half] x 8 bf16 so that an MFMA B fragment is one
 // 16-byte LDS read; each wave splits its own 32 columns of G in registers and issues 1/8 of the DMA requests.
 template <int NT>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
-__global__ void __launch_bounds__(512, 1)
-wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
-                    int max_rows, float* __restrict__ slab, float* __restrict__ dbias) {
+__device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, const float* __restrict__ A, int lda, int C,
+                                                  const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slab,
+                                                  float* __restrict__ dbias, const int bid, const int nblk) {
     constexpr int ROWS = 16, NB = 4, CA = 32 * NT;
     constexpr int NDMA = 2 + (NT == 8 ? 2 : 1);                           // requests per wave per stage
     __shared__ __attribute__((aligned(16))) float sm[NB * ROWS * (256 + CA) + 3 * CA * 2 * 4];
@@ -273,9 +273,9 @@ wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, in
     const int tid = threadIdx.x, lane = tid & 63, ci = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // 0..7
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
-    int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    int chunk = (n + nblk - 1) / nblk;
     chunk += chunk & 1;
-    const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, n);
+    const int r0 = bid * chunk, r1 = min(r0 + chunk, n);
     if (r0 >= r1) return;
     const int nst = (r1 - r0 + ROWS - 1) / ROWS;
     f32x16 acc[NT];
@@ -361,17 +361,41 @@ wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, in
         gsum += __shfl_xor(gsum, 32);
         if (h == 0) atomicAdd(&dbias[32 * wave + ci], gsum);
     }
-    float* out = slab + ((size_t)blockIdx.x * 8 + wave) * (NT * 16 * 64) + lane;     // slab[block][wave 8][t][reg][lane]
+    float* out = slab + ((size_t)bid * 8 + wave) * (NT * 16 * 64) + lane;     // slab[block][wave 8][t][reg][lane]
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64] = acc[t][r];
 }
 
+
+template <int NT>
+__global__ void __launch_bounds__(512, 1)
+wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
+                    int max_rows, float* __restrict__ slab, float* __restrict__ dbias) {
+    wgrad_split8_body<NT>(G, A, lda, C, n_rows_dev, max_rows, slab, dbias, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// up to three C = 256 problems over the same rows in one launch: blockIdx.y = problem, each with gridDim.x workgroups and its own slab
+struct WgradBatch {
+    const float* G[3];
+    const float* A[3];
+    int lda[3];
+    float* dW[3];
+    int ldw[3];
+    float* dbias[3];
+};
+__global__ void __launch_bounds__(512, 1)
+wgrad_split8_batched_kernel(WgradBatch pb, const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slabs, size_t slab_floats) {
+    const int q = blockIdx.y;
+    wgrad_split8_body<8>(pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slabs + (size_t)q * slab_floats, pb.dbias[q], (int)blockIdx.x,
+                         (int)gridDim.x);
+}
+
 // slab of wgrad_split8_kernel: output row o = 32 wave + C-row(reg, lane), column = 32 t + (lane & 31)
 template <int NT>
-__global__ void wgrad_split8_reduce_kernel(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev, int max_rows,
-                                           int C, float* __restrict__ dW, int ldw) {
+__device__ __forceinline__ void wgrad_split8_reduce_body(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev,
+                                                         int max_rows, int C, float* __restrict__ dW, int ldw) {
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
     if (n <= 0) return;
     int chunk = (n + nblk_launched - 1) / nblk_launched;
@@ -395,6 +419,17 @@ __global__ void wgrad_split8_reduce_kernel(const float* __restrict__ slab, int n
     }
     for (; b < active; b += step) s0 += slab[(size_t)b * PER + e];
     atomicAdd(&dW[(size_t)o * ldw + i], (s0 + s1) + (s2 + s3));
+}
+
+template <int NT>
+__global__ void wgrad_split8_reduce_kernel(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev, int max_rows,
+                                           int C, float* __restrict__ dW, int ldw) {
+    wgrad_split8_reduce_body<NT>(slab, nblk_launched, n_rows_dev, max_rows, C, dW, ldw);
+}
+__global__ void wgrad_split8_reduce_batched_kernel(const float* __restrict__ slabs, size_t slab_floats, int nblk_launched,
+                                                   const int32_t* __restrict__ n_rows_dev, int max_rows, WgradBatch pb) {
+    const int q = blockIdx.z;
+    wgrad_split8_reduce_body<8>(slabs + (size_t)q * slab_floats, nblk_launched, n_rows_dev, max_rows, 256, pb.dW[q], pb.ldw[q]);
 }
 
 // NT = 1 (C <= 32: the 21 view-encoding columns, a ones column for a bias gradient): direct loads, nothing to share
@@ -530,6 +565,45 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     }
     if (dbias) colsum256_kernel<<<512, 256, 0, s>>>(G, n_rows, max_rows, dbias);
     SPF_LAUNCH_CHECK("wgrad_kernel");
+    return SPF_OK;
+}
+
+
+int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_problems, const int32_t* n_rows, int32_t max_rows, float* workspace,
+                      void* stream) {
+    if (!problems || n_problems < 1 || n_problems > 3 || max_rows < 0) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: 1 to 3 problems");
+    if (max_rows == 0) return SPF_OK;
+    if (!workspace) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: null workspace");
+    const int64_t slab_floats = spf_wgrad_workspace_floats(256);
+    for (int q = 0; q < n_problems; ++q) {
+        const spf_wgrad_problem& p = problems[q];
+        if (!p.G || !p.A || !p.dW || p.lda < 256 || (p.lda % 4) || p.ldw < 256)
+            return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: need G, A, dW, lda >= 256 (multiple of 4), ldw >= 256", q);
+    }
+    if (g_wgrad_mode != 0 || n_problems == 1) {      // fp32-MFMA verification mode / nothing to batch: the single-problem path
+        for (int q = 0; q < n_problems; ++q) {
+            const spf_wgrad_problem& p = problems[q];
+            const int rc = spf_wgrad(p.G, p.A, p.lda, 256, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, stream);
+            if (rc != SPF_OK) return rc;
+        }
+        return SPF_OK;
+    }
+    WgradBatch pb{};
+    for (int q = 0; q < n_problems; ++q) {
+        pb.G[q] = problems[q].G; pb.A[q] = problems[q].A; pb.lda[q] = problems[q].lda;
+        pb.dW[q] = problems[q].dW; pb.ldw[q] = problems[q].ldw; pb.dbias[q] = problems[q].dbias;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // one 8-wave workgroup per CU over ALL problems: each problem gets 256 / n_problems of them, so that the problems run side by side
+    // with n_problems times longer (better amortised) pipelines instead of one after the other
+    int blocks = spf::div_up(max_rows, 512);
+    const int cap = 256 / n_problems;
+    if (blocks > cap) blocks = cap;
+    const int per = 4 * 2 * 8 * 16 * 64;
+    wgrad_split8_batched_kernel<<<dim3(blocks, n_problems), 512, 0, s>>>(pb, n_rows, max_rows, workspace, (size_t)slab_floats);
+    wgrad_split8_reduce_batched_kernel<<<dim3(spf::div_up(per, 256), RSPLIT, n_problems), 256, 0, s>>>(workspace, (size_t)slab_floats, blocks, n_rows,
+                                                                                                     max_rows, pb);
+    SPF_LAUNCH_CHECK("wgrad_split8_batched_kernel");
     return SPF_OK;
 }
 

@@ -546,10 +546,9 @@ class RHead(_GradModeFunction):
         split = rhead_mode() == "split"
         kb = (lambda b: b) if split else (lambda b: None)
         if sk is not None:
-            wgrad(g_agg, agg3, n_points, out=sk[0], dbias=kb(g_b6))     # F_color.6: K = points, not pairs
-            wgrad(G1, direnc, n_points, C=21, out=sk[2])                # R.0, reference column order [dir-enc | agg]
-            wgrad(G1, agg, n_points, out=sk[2][:, 21:], ldw=277, dbias=kb(g_b0))
-            wgrad(G2, act1, n_points, out=sk[4], dbias=kb(g_b2))
+            # F_color.6 (K = points, not pairs), R.0's agg block (reference column order [dir-enc | agg]) and R.2: side by side
+            wgrad_batched([(g_agg, agg3, sk[0], kb(g_b6)), (G1, agg, sk[2][:, 21:], kb(g_b0)), (G2, act1, sk[4], kb(g_b2))], n_points)
+            wgrad(G1, direnc, n_points, C=21, out=sk[2])
             return (g_agg3[:P],) + (None,) * 14
         if ctx.static:
             dw6 = wgrad(g_agg, agg3, n_points, dbias=kb(g_b6))
@@ -611,6 +610,28 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None):
         _lib.check(_lib.lib().spf_wgrad(_lib.ptr(G), _lib.ptr(A), A.stride(0), C, _lib.ptr(n_rows), min(G.shape[0], A.shape[0]), _lib.ptr(out), ldw, _lib.ptr(dbias),
                                         _lib.ptr(_wgrad_ws[key]), _lib.stream_ptr()), "spf_wgrad")
     return out
+
+
+def wgrad_batched(problems, n_rows):
+    """problems: up to three (G, A, out [256, >= 256 row stride], dbias | None) with A [rows, 256]: out += G[:rows]^T A[:rows],
+    dbias += column sums of G[:rows], all in one pair of launches (spf_wgrad_batched)."""
+    dev = problems[0][0].device
+    arr = (_lib.WgradProblem * len(problems))()
+    max_rows = None
+    for q, (G, A, out, dbias) in enumerate(problems):
+        if A.shape[1] != 256 or G.shape[1] != 256 or out.shape != (256, 256):
+            raise ValueError("wgrad_batched: every problem is [rows,256]^T x [rows,256] -> [256,256]")
+        arr[q].G, arr[q].A, arr[q].lda = _lib.ptr(G), _lib.ptr(A), A.stride(0)
+        arr[q].dW, arr[q].ldw, arr[q].dbias = _lib.ptr(out), out.stride(0), _lib.ptr(dbias)
+        rows = min(G.shape[0], A.shape[0])
+        max_rows = rows if max_rows is None else min(max_rows, rows)
+    nws = int(_lib.lib().spf_wgrad_workspace_floats(256)) * len(problems)
+    key = (dev.index, nws)
+    if key not in _wgrad_ws:
+        _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_wgrad_batched(arr, len(problems), _lib.ptr(n_rows), max_rows, _lib.ptr(_wgrad_ws[key]), _lib.stream_ptr()),
+                   "spf_wgrad_batched")
 
 
 # ---- ray set-up and loss terms (one launch each instead of dozens of elementwise PyTorch kernels) ----------------

@@ -83,3 +83,33 @@ def test_bias_gradient_rides_along(C):
             ops.set_wgrad_mode("split")
         np.testing.assert_allclose((db.double() - 2.0).cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5 * float(G[:rows].abs().sum(0).max()))
         assert _err(dw, G[:rows].double().t() @ A[:rows].double()) < 1e-5
+
+
+@pytest.mark.parametrize("rows", [55000, 700])
+def test_three_problems_side_by_side_equal_three_calls(rows):
+    """spf_wgrad_batched: three [rows,256]^T x [rows,256] GEMMs in one pair of launches (strided output, bias sums) against the
+    single-problem entry point, both arithmetic modes."""
+    from spurfies_amd import ops
+
+    g = torch.Generator().manual_seed(rows)
+    Gs = [torch.randn((rows + 64, 256), generator=g).cuda() for _ in range(3)]
+    As = [torch.randn((rows + 64, 256), generator=g).cuda() for _ in range(3)]
+    n = torch.tensor([rows], dtype=torch.int32, device="cuda")
+    for mode in ("split", "f32"):
+        ops.set_wgrad_mode(mode)
+        try:
+            wide = torch.zeros((256, 277), device="cuda")                        # problem 1 writes a column block of a wider matrix
+            outs = [torch.ones((256, 256), device="cuda"), wide[:, 21:], torch.zeros((256, 256), device="cuda")]
+            dbs = [torch.zeros(256, device="cuda"), None, torch.full((256,), 3.0, device="cuda")]
+            ops.wgrad_batched([(Gs[q], As[q], outs[q], dbs[q]) for q in range(3)], n)
+            for q in range(3):
+                ref = Gs[q][:rows].double().t() @ As[q][:rows].double()
+                base = 1.0 if q == 0 else 0.0
+                assert _err(outs[q] - base, ref) < 1e-5, (mode, q)
+            assert float(wide[:, :21].abs().max()) == 0.0
+            np.testing.assert_allclose(dbs[0].double().cpu().numpy(), Gs[0][:rows].double().sum(0).cpu().numpy(), rtol=0,
+                                       atol=2e-5 * float(Gs[0][:rows].abs().sum(0).max()))
+            np.testing.assert_allclose((dbs[2].double() - 3.0).cpu().numpy(), Gs[2][:rows].double().sum(0).cpu().numpy(), rtol=0,
+                                       atol=2e-5 * float(Gs[2][:rows].abs().sum(0).max()))
+        finally:
+            ops.set_wgrad_mode("split")
