@@ -196,7 +196,7 @@ def main():
                    "parallelism": f"ray-sharded dp{world}", "valid_points_last_step": model.stats.get("valid_points", int(model.stats["counts"][0].item()) if "counts" in model.stats else None),
                    "host_syncs_per_step": 1 if args.sync else 0,
                    "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product exactly from three bf16 pieces per operand (6 bf16 MFMAs, fp32 accumulate)",
-                   "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~95 per step)")},
+                   "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~91 per step)")},
         "roofline": roof,
         "loss_last": loss_last,
     }
