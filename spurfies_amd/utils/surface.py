@@ -2,8 +2,12 @@
 evaluation grid, the `get_sdf_eval` sweep over it (the biggest pure-inference consumer of the kNN + geometry kernels), the
 zero-level surface points, and the symmetric Chamfer distance the acceptance criterion is stated in (evals/eval_dtu.py:120-254).
 
-Marching-cubes triangulation itself (skimage, absent here) is not reproduced: `surface_points` returns the points marching
-cubes places its vertices at — the linear-interpolation zero crossings along grid edges — which is what Chamfer is measured on."""
+`surface_points` returns the points marching cubes places its vertices at — the linear-interpolation zero crossings along grid
+edges — which is what Chamfer is measured on.  `triangulate` is this build's own iso-surface mesher (skimage's marching cubes is
+absent here): marching TETRAHEDRA on the Kuhn split of every cell (six tetrahedra around the main diagonal; the split is
+translation-invariant, so neighbouring cells agree on every shared face and the mesh is watertight wherever the volume is defined),
+the same vertices on the cube edges plus vertices on face / body diagonals; `write_ply` stores it the way the reference exports
+its meshes (plots.py:266-300 via trimesh)."""
 from __future__ import annotations
 
 import numpy as np
@@ -70,3 +74,113 @@ def chamfer(a, b):
     da, _ = cKDTree(b).query(a)
     db, _ = cKDTree(a).query(b)
     return 0.5 * (float(da.mean()) + float(db.mean())), float(da.mean()), float(db.mean())
+
+
+# ---- own triangulation (marching tetrahedra) --------------------------------------------------------------------------------
+# cube corner c = x + 2 y + 4 z (bits); Kuhn split: six tetrahedra that all contain the main diagonal 0-7
+_TETS = np.array([[0, 1, 3, 7], [0, 1, 5, 7], [0, 2, 3, 7], [0, 2, 6, 7], [0, 4, 5, 7], [0, 4, 6, 7]], dtype=np.int64)
+
+
+def _tet_table():
+    """sign case (bit i = vertex i inside) -> list of triangles, each three edges (i, j) with i inside, j outside."""
+    table = []
+    for case in range(16):
+        ins = [i for i in range(4) if case >> i & 1]
+        outs = [i for i in range(4) if not case >> i & 1]
+        if len(ins) in (0, 4):
+            table.append([])
+        elif len(ins) == 1:
+            a = ins[0]
+            table.append([[(a, outs[0]), (a, outs[1]), (a, outs[2])]])
+        elif len(ins) == 3:
+            d = outs[0]
+            table.append([[(ins[0], d), (ins[1], d), (ins[2], d)]])
+        else:
+            a, b = ins
+            c, d = outs
+            table.append([[(a, c), (a, d), (b, d)], [(a, c), (b, d), (b, c)]])
+    return table
+
+
+_TET_TABLE = _tet_table()
+
+
+def triangulate(volume, grid, level=0.0):
+    """Iso-surface of `volume` ([y, x, z] as sdf_volume returns it) at `level` -> (vertices [V,3] float64, faces [F,3] int64),
+    vertices welded (one per crossed grid edge / diagonal), faces wound so that normals point towards larger values (outside of a
+    signed-distance volume).  Cells touching a no-neighbour sample (1000) are skipped."""
+    x, y, z = (np.asarray(a, dtype=np.float64) for a in grid["xyz"])
+    ny, nx, nz = volume.shape
+    vol = volume.astype(np.float64) - level
+    valid = volume != SDF_FILL
+    # cells and their 8 corners (global vertex id = index into the raveled [y, x, z] volume)
+    iy, ix, iz = np.meshgrid(np.arange(ny - 1), np.arange(nx - 1), np.arange(nz - 1), indexing="ij")
+    corner_ids, corner_val, corner_ok = [], [], []
+    for c in range(8):
+        dx, dy, dz = c & 1, c >> 1 & 1, c >> 2 & 1
+        gid = ((iy + dy) * nx + (ix + dx)) * nz + (iz + dz)
+        corner_ids.append(gid.ravel())
+    corner_ids = np.stack(corner_ids, 1)                                    # [cells, 8]
+    flat_val, flat_ok = vol.ravel(), valid.ravel()
+    cv = flat_val[corner_ids]
+    active = flat_ok[corner_ids].all(1) & (cv.min(1) < 0) & (cv.max(1) >= 0)
+    corner_ids, cv = corner_ids[active], cv[active]
+    if corner_ids.shape[0] == 0:
+        return np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int64)
+    gy, gx, gz = np.unravel_index(np.arange(ny * nx * nz), (ny, nx, nz))
+
+    def pos(ids):
+        return np.stack([x[gx[ids]], y[gy[ids]], z[gz[ids]]], -1)
+
+    keys, pts, tri_inside, tri_outside = [], [], [], []
+    for tet in _TETS:
+        tid, tv = corner_ids[:, tet], cv[:, tet]                            # [cells, 4]
+        case = ((tv < 0) * (1 << np.arange(4))).sum(1)
+        for cs in range(1, 15):
+            sel = case == cs
+            if not sel.any():
+                continue
+            ids, vals = tid[sel], tv[sel]
+            ins = [i for i in range(4) if cs >> i & 1]
+            outs = [i for i in range(4) if not cs >> i & 1]
+            c_in, c_out = pos(ids[:, ins]).mean(1), pos(ids[:, outs]).mean(1)
+            for tri in _TET_TABLE[cs]:
+                for (i, j) in tri:
+                    a, b = ids[:, i], ids[:, j]
+                    t = vals[:, i] / (vals[:, i] - vals[:, j])
+                    pa, pb = pos(a), pos(b)
+                    pts.append(pa + t[:, None] * (pb - pa))
+                    keys.append(np.stack([np.minimum(a, b), np.maximum(a, b)], 1))
+                tri_inside.append(c_in)
+                tri_outside.append(c_out)
+    pts, keys = np.concatenate(pts, 0), np.concatenate(keys, 0)              # three consecutive blocks per triangle batch
+    # rebuild per-triangle corner order: blocks were appended as [edge0 of batch, edge1 of batch, edge2 of batch] per batch
+    sizes = [c.shape[0] for c in tri_inside]
+    corners, off = [], 0
+    for n in sizes:
+        corners.append(np.stack([np.arange(off, off + n), np.arange(off + n, off + 2 * n), np.arange(off + 2 * n, off + 3 * n)], 1))
+        off += 3 * n
+    corners = np.concatenate(corners, 0)                                    # [F, 3] indices into pts / keys
+    c_in, c_out = np.concatenate(tri_inside, 0), np.concatenate(tri_outside, 0)
+    uniq, inverse = np.unique(keys, axis=0, return_inverse=True)
+    inverse = inverse.reshape(-1)
+    verts = np.zeros((uniq.shape[0], 3))
+    verts[inverse] = pts                                                    # all copies of a welded vertex coincide
+    faces = inverse[corners]
+    p0, p1, p2 = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    flip = (np.cross(p1 - p0, p2 - p0) * (c_out - c_in)).sum(1) < 0         # normal must point from the inside corners to the outside ones
+    faces[flip] = faces[flip][:, [0, 2, 1]]
+    good = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])   # a value exactly on a corner
+    return verts, faces[good]
+
+
+def write_ply(path, verts, faces):
+    """Binary little-endian PLY (vertex x y z float32, face vertex_indices int32 lists)."""
+    verts, faces = np.asarray(verts, dtype="<f4"), np.asarray(faces, dtype="<i4")
+    with open(path, "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\nelement vertex {len(verts)}\nproperty float x\nproperty float y\n"
+                 f"property float z\nelement face {len(faces)}\nproperty list uchar int vertex_indices\nend_header\n").encode())
+        f.write(verts.tobytes())
+        rec = np.empty(len(faces), dtype=[("n", "u1"), ("v", "<i4", (3,))])
+        rec["n"], rec["v"] = 3, faces
+        f.write(rec.tobytes())
