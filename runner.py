@@ -1,7 +1,7 @@
 """Command-line entry with the reference's surface (runner.py:9-65): hydra-style `key=value` overrides of config/ours.yaml's
 keys — `testlist= vol= outdir= exps_folder= opt_stepNs= grad_clip= is_continue=` and dotted `vol.train.num_pixels=...` — then,
 per scene, `VolOpt(args, batch_size=1, is_continue, timestamp='latest', checkpoint='latest', scan)`, `gen_dataset(0)`,
-`run(opt_stepNs[0])`.
+`run(opt_stepNs[0])`; `mesh_resolution=N` (own addition) then sweeps `get_sdf_eval` over an N-cell grid and writes the iso-surface as `.ply`.
 
 hydra / omegaconf are not needed (a literal `key=value` parser covers what the reference's own command lines use,
 readme.md:65,85,88).  The reference's datasets are a separate download; `data=synthetic` (default) optimises the built-in
@@ -18,7 +18,7 @@ import time
 
 DEFAULTS = {   # config/base.yaml + config/ours.yaml (the keys the optimisation path reads)
     "testlist": "scan24", "vol": "dtu_pn", "outdir": "exps_mvs", "exps_folder": "exps_vsdf", "opt_stepNs": [100000, 0, 0], "grad_clip": True,
-    "is_continue": False, "data": "synthetic", "points": 10000, "seed": 0, "sync_free": True, "root": "./",
+    "is_continue": False, "data": "synthetic", "points": 10000, "seed": 0, "sync_free": True, "root": "./", "mesh_resolution": 0, "mesh_level": 0.0,
     "vol.train.expname": "ours", "vol.train.render_freq": 500, "vol.train.checkpoint_freq": 15000, "vol.train.num_pixels": 1024,
     "vol.train.split_n_pixels": 500, "vol.loss.local_weight": 0.5, "vol.loss.pseudo_weight": 0.5, "vol.loss.eikonal_weight": 0.001,
     "vol.loss.rgb_weight": 1.0, "vol.loss.tv_weight": 0.01, "vol.dataset.data_dir": "dtu",
@@ -101,6 +101,22 @@ def optimise_scene(scene_name: str, flat: dict, args):
     last = {k: float(v.detach()) for k, v in (vol_opt.last_losses or {}).items()}
     print(f"finished training {scene_name}: {vol_opt.iter_step} steps, epoch {epoch}, {1e3 * dt / max(vol_opt.iter_step, 1):.2f} ms/step, "
           f"loss {last.get('loss', float('nan')):.5f}, checkpoints in {vol_opt.checkpoints_path}")
+    if int(flat["mesh_resolution"]) > 0:       # the reference's mesh route (utils/plots.py:188-333): grid, get_sdf_eval sweep, iso-surface
+        import os
+
+        from spurfies_amd.utils import surface
+
+        model = vol_opt.model
+        model.eval()
+        pts = scene["state"]["neural_pts"]
+        grid = surface.get_grid(pts, int(flat["mesh_resolution"]))
+        vol = surface.sdf_volume(model.get_sdf_eval, grid)
+        level = flat["mesh_level"]      # a number (the reference: 0), or "median": the synthetic scene's random prior has no zero level set
+        level = float(np.median(vol[vol != surface.SDF_FILL])) if str(level) == "median" else float(level)
+        verts, faces = surface.triangulate(vol, grid, level=level)
+        path = os.path.join(os.path.dirname(vol_opt.checkpoints_path), f"surface_{vol_opt.iter_step}.ply")
+        surface.write_ply(path, verts, faces)
+        print(f"mesh: {grid['grid_points'].shape[0]} grid points, level {level:.4f}, {len(verts)} vertices, {len(faces)} faces -> {path}")
     return vol_opt
 
 
