@@ -198,10 +198,11 @@ class SyntheticDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, idx):
         sample = {"uv": self.uv, "intrinsics": self.intrinsics, "pose": self.poses[idx], "local_data": None}
-        gt = {"rgb": self.rgb[idx], "mask": self.mask[idx][:, None].repeat(1, 3)}
-        if self.sampling_idx is not None:
+        if self.sampling_idx is not None:            # select first, widen the mask to three channels afterwards
             sample["uv"] = self.uv[self.sampling_idx]
-            gt = {"rgb": self.rgb[idx][self.sampling_idx], "mask": gt["mask"][self.sampling_idx]}
+            gt = {"rgb": self.rgb[idx][self.sampling_idx], "mask": self.mask[idx][self.sampling_idx][:, None].repeat(1, 3)}
+        else:
+            gt = {"rgb": self.rgb[idx], "mask": self.mask[idx][:, None].repeat(1, 3)}
         return idx, sample, gt
 
     @staticmethod
