@@ -190,7 +190,7 @@ def main():
         "metric": "ray-samples/sec (kNN+SDF+render, train step)", "value": SAMPLES_PER_RAY * rays_total * args.steps / dt,
         "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"DTU scan24-shaped synthetic scene: {args.points} neural points, {args.rays} rays/GPU/step x "
+        "config": {"workload": f"BASELINE.json configs[1] shape (DTU scan24 3-view optimisation, 1024-ray batches) on a synthetic scene: {args.points} neural points, {args.rays} rays/GPU/step x "
                                f"(128 sampler + 98 main) samples, fast=1 optimisation step (fwd+bwd+clip+Adam)",
                    "rays_per_gpu": args.rays, "neural_points": args.points, "k": 8, "max_shading_pts": 80,
                    "parallelism": f"ray-sharded dp{world}", "valid_points_last_step": model.stats.get("valid_points", int(model.stats["counts"][0].item()) if "counts" in model.stats else None),
