@@ -45,8 +45,8 @@ def parse():
     ap.add_argument("--spacing", type=float, default=0.025, help="nearest-neighbour spacing of the synthetic cloud (0.0125 = dense stress cloud)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync", action="store_true", help="default (reference-shaped) step with one host read-back per step")
-    ap.add_argument("--graph", action="store_true", help="replay forward + loss + backward as one hipGraph (measured 4 %% SLOWER than the "
-                    "eager sync-free step on MI355X: ~3 us of dependency handling per graph node x ~105 nodes; the eager launches run ahead of the GPU)")
+    ap.add_argument("--graph", action="store_true", help="replay forward + loss + backward as one hipGraph (measured no faster than the eager sync-free "
+                    "step on MI355X: ~3 us of dependency handling per graph node; the eager launches run ahead of the GPU)")
     ap.add_argument("--no-graph", action="store_true", help="(default since the sync-free step became GPU-bound; kept for old command lines)")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     return ap.parse_args()
