@@ -33,6 +33,27 @@ def all_reduce_sum(t: torch.Tensor, group=None):
     return t
 
 
+def broadcast_model(model, optimizer=None, group=None, src=0):
+    """Make every rank's replica identical to rank `src`'s: the trainable parameters (one broadcast of FlatAdam's flat buffer
+    when there is one), the frozen prior weights and the buffers (the cloud)."""
+    if world_size(group) == 1:
+        return
+    flat = getattr(optimizer, "_flat", None) if optimizer is not None else None
+    done = set()
+    if flat is not None:
+        dist.broadcast(flat["param"], src=src, group=group)
+        done = {id(p) for g in optimizer.param_groups for p in g["params"]}
+    for p in model.parameters():
+        if id(p) not in done:
+            dist.broadcast(p.data, src=src, group=group)
+            torch.autograd.graph.increment_version(p)
+    for p in model.parameters():
+        if id(p) in done:
+            torch.autograd.graph.increment_version(p)
+    for b in model.buffers():
+        dist.broadcast(b, src=src, group=group)
+
+
 class FlatGrads:
     """One contiguous fp32 buffer holding every trainable tensor's gradient ([N*64 + N*32 + F_color +
     R + beta] floats); each parameter's .grad is a view into it, so the all-reduce needs no packing."""

@@ -33,6 +33,9 @@ class VolSDFLoss(nn.Module):
         {R_total, P_total, pseudo_count_total} for ray-sharded batches (spurfies_amd/dist.py)."""
         from .. import _lib, ops
 
+        if not (isinstance(self.rgb_loss, nn.L1Loss) and self.rgb_loss.reduction == "mean"):
+            raise NotImplementedError(f"the fused loss kernels implement the reference recipe's rgb term, torch.nn.L1Loss(reduction='mean') "
+                                      f"(config/ours.yaml); got {self.rgb_loss!r} — run the step with sync_free=False")
         f = model_outputs["_fused"]
         dev = model_outputs["rgb_values"].device
         rgb_gt = ground_truth["rgb"].to(dev).reshape(-1, 3).float().contiguous()

@@ -82,6 +82,7 @@ class PointVolSDF(nn.Module):
         self._packed_geo = None
         self._packed_key = None
         self._tv_graph = None
+        self._tv_key = None
         self.stats = {}
         self.sync_free = False   # training only: static shapes, no host synchronisation (spurfies_amd/train.py sets it)
 
@@ -138,6 +139,20 @@ class PointVolSDF(nn.Module):
             self._packed_geo = ops.pack_geometry_weights(sd)
             self._packed_key = key
         return self._packed_geo
+
+    def cache_key(self):
+        """Identity of everything the cached device state (cell table, TV graph, packed prior image) was derived from; a
+        captured hipGraph holds pointers into that state and must be dropped when the key changes (train.py:TrainStep)."""
+        self._packed()
+        return (self.neural_pts.data_ptr(), self.neural_pts._version, self.neural_pts.shape[0], self._packed_key)
+
+    def tv_graph(self):
+        """Static neighbour graph of tv_regul (utils.py:221-282), rebuilt only when the cloud (or k / r) changes."""
+        key = (self.neural_pts.data_ptr(), self.neural_pts._version, self.neural_pts.shape[0], self.conf.k, self.conf.r)
+        if self._tv_graph is None or self._tv_key != key:
+            self._tv_graph = TVGraph(self._grid(), self.neural_pts, self.conf.k, self.conf.r)
+            self._tv_key = key
+        return self._tv_graph
 
     def freeze_prior(self):
         """train.py:151-154: the local geometry prior (F_geometry, T) is not optimised."""
@@ -290,9 +305,7 @@ class PointVolSDF(nn.Module):
                 # no rendered point has a neighbour -> the reference's constant 1000 (no gradient)
                 pseudo_pts_loss = torch.where(cnt > 0, l1, torch.full_like(l1, SDF_FILL))
             output.update({"pseudo_pts_loss": pseudo_pts_loss, "pseudo_sum": pseudo_sum, "pseudo_count": pseudo_cnt})
-        if self._tv_graph is None:
-            self._tv_graph = TVGraph(grid, self.neural_pts, k, conf.r)
-        output["tv_loss"] = self._tv_graph.loss(self.neural_feats_geometry)
+        output["tv_loss"] = self.tv_graph().loss(self.neural_feats_geometry)
         if not self.training:
             g = gradients.view(R, SR, 3)
             nrm = torch.where(valid.unsqueeze(-1), g / g.norm(2, -1, keepdim=True), torch.zeros(1, device=dev))

@@ -272,7 +272,7 @@ class ColorAgg(_GradModeFunction):
     """agg3[p,256] = sum_j wn_j a3_j for the P valid points, a3 = the third activation of F_color on
     [posenc6(x_pi) | colour latent] (pointneus_disent.py:325-336).  F_color's last layer is linear and commutes with the
     weighted mean, so it runs once per point inside `RHead`.  Forward and the data-gradient chain are HIP kernels; the
-    weight gradients are GEMMs over the activation / pre-activation-gradient buffers the kernels store."""
+    weight gradients are spf_wgrad launches over the activation / pre-activation-gradient buffers the kernels store."""
 
     @staticmethod
     def forward(ctx, feat_col, w0, b0, w2, b2, w4, b4, x, wn, pl, pts, n_valid, n_pairs):
@@ -331,39 +331,12 @@ class ColorAgg(_GradModeFunction):
             wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2))
             wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4))
             return (None,) * 13
+        # exact-size (default) and worst-case (sync-free) buffers alike: the weight-gradient kernel reads the row count on the device
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
-        if ctx.static:   # row counts stay on the device
-            dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0))[:, :103]
-            dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2)), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4))
-        else:
-            dw0[:, _color_col_perm(dev)] = _wgrad(G1, act0)[:, :103]   # [256,104] comes in the kernels' internal column order
-            dw2, dw4 = _wgrad(G2, act1), _wgrad(G3, act2)
-            if color_mode() == "split":      # rows past the pair count are zero in G
-                g_b0, g_b2, g_b4 = G1.sum(0), G2.sum(0), G3.sum(0)
+        dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0))[:, :103]   # [256,104] comes in the kernels' internal column order
+        dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2)), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4))
         grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4)
         return grads + (None,) * 6
-
-
-_ones = {}
-
-
-def _ones_col(n, dev):
-    key = (dev.index, n)
-    if key not in _ones:
-        _ones[key] = torch.ones((n, 4), dtype=torch.float32, device=dev)
-    return _ones[key]
-
-
-def _wgrad(G, A, split=32):
-    """dW = G^T A for [rows,256] x [rows,C] with rows ~ 4e5: a K-huge, tiny-MN GEMM.  A single library GEMM fills
-    only a few workgroups; batching over `split` row blocks (rows is a multiple of 64) fills the chip
-    (measured 0.43 ms vs 1.06 ms on MI355X, tools/wgrad_bench.py)."""
-    rows = G.shape[0]
-    while split > 1 and rows % split:
-        split //= 2
-    if rows < 64 * split or split == 1:
-        return G.t() @ A
-    return torch.bmm(G.view(split, rows // split, G.shape[1]).transpose(1, 2), A.view(split, rows // split, A.shape[1])).sum(0)
 
 
 # ---- per-ray compositing --------------------------------------------------------------------------
@@ -493,7 +466,7 @@ class RHead(_GradModeFunction):
     """colors [rows,3] = sigmoid(R([direnc3(ray dir) | F_color.6(agg3)])) on the P valid points (pointneus_disent.py:333-346),
     written at the points' slot rows (0 elsewhere).  F_color's linear last layer is applied here, per point, to the
     RBF-weighted mean `agg3` that `ColorAgg` produced.  Forward and the data-gradient chain are HIP kernels; the wide
-    layers' weight gradients are GEMMs over [P,256] buffers."""
+    layers' weight gradients are spf_wgrad launches over [P,256] buffers."""
 
     @staticmethod
     def forward(ctx, agg3, w6, b6, w0, b0, w2, b2, w4, b4, ray_dirs, point_slot, n_points, SR, n_rows, static=False):
@@ -550,19 +523,11 @@ class RHead(_GradModeFunction):
             wgrad_batched([(g_agg, agg3, sk[0], kb(g_b6)), (G1, agg, sk[2][:, 21:], kb(g_b0)), (G2, act1, sk[4], kb(g_b2))], n_points)
             wgrad(G1, direnc, n_points, C=21, out=sk[2])
             return (g_agg3[:P],) + (None,) * 14
-        if ctx.static:
-            dw6 = wgrad(g_agg, agg3, n_points, dbias=kb(g_b6))
-            dw0 = torch.zeros((256, 277), dtype=torch.float32, device=dev)        # reference column order [dir-enc | agg]
-            wgrad(G1, direnc, n_points, C=21, out=dw0)
-            wgrad(G1, agg, n_points, out=dw0[:, 21:], dbias=kb(g_b0))
-            dw2 = wgrad(G2, act1, n_points, dbias=kb(g_b2))
-        else:
-            G1p, G2p = G1[:P], G2[:P]
-            dw6 = g_agg[:P].t() @ agg3
-            dw0 = torch.cat([G1p.t() @ direnc[:P, :21], G1p.t() @ agg[:P]], dim=1)
-            dw2 = G2p.t() @ act1[:P]
-            if split:
-                g_b6, g_b0, g_b2 = g_agg[:P].sum(0), G1p.sum(0), G2p.sum(0)
+        dw6 = wgrad(g_agg, agg3, n_points, dbias=kb(g_b6))
+        dw0 = torch.zeros((256, 277), dtype=torch.float32, device=dev)        # reference column order [dir-enc | agg]
+        wgrad(G1, direnc, n_points, C=21, out=dw0)
+        wgrad(G1, agg, n_points, out=dw0[:, 21:], dbias=kb(g_b0))
+        dw2 = wgrad(G2, act1, n_points, dbias=kb(g_b2))
         return (g_agg3[:P], dw6, g_b6, dw0, g_b0, dw2, g_b2, g_w4, g_b4, None, None, None, None, None, None)
 
 

@@ -22,6 +22,8 @@ def default_loss() -> VolSDFLoss:
 
 
 class TrainStep:
+    N_STAGING = 4            # pinned staging buffers for the CPU-generator draws (sync-free steps run ahead of the GPU)
+
     def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False, use_graph=False):
         """sync_free: static shapes and device-side counts everywhere — no host synchronisation inside the step (the
         default path reads [P, n_pairs] back once per step to size the colour buffers exactly).
@@ -32,6 +34,7 @@ class TrainStep:
         self.sync_free = sync_free
         self.use_graph = use_graph
         self._graph = None
+        self._graph_key = None
         model.sync_free = sync_free
         self._draws = None
         self.loss = loss or default_loss()
@@ -44,6 +47,10 @@ class TrainStep:
         self.grad_clip = grad_clip
         self.group = process_group
         self.world = sdist.world_size(process_group)
+        if self.world > 1:
+            # the all-reduce sums gradients only: replicas must START identical (latents and MLPs are drawn from the local
+            # generators in the constructors).  Rank 0's parameters, frozen prior and cloud win.
+            sdist.broadcast_model(model, self.optimizer, process_group)
         self.iter_step = 0
         self.skipped = 0
 
@@ -81,7 +88,9 @@ class TrainStep:
     def _graphed_forward_backward(self, model_input, ground_truth):
         dev = model_input["uv"].device
         keys_in = ("intrinsics", "uv", "pose")
-        if self._graph is None or self._static_in["uv"].shape != model_input["uv"].shape:
+        key = self.model.cache_key()
+        if self._graph is None or self._static_in["uv"].shape != model_input["uv"].shape or key != self._graph_key:
+            self._graph_key = key
             if self.world > 1:
                 raise NotImplementedError("use_graph with ray sharding: the count all-reduce inside the loss is not captured yet")
             self._static_in = {k: model_input[k].clone() for k in keys_in}
@@ -126,13 +135,27 @@ class TrainStep:
                 return {"t_rand": flat[:a].view(R, n0), "u": flat[a:b].view(R, N), "sel": flat[b:].view(torch.int32)}
 
             self._draws_flat = torch.empty((b + Ne,), dtype=torch.float32, device=dev)
-            self._pinned_flat = torch.empty((b + Ne,), dtype=torch.float32).pin_memory()
-            self._draws, self._pinned = views(self._draws_flat), views(self._pinned_flat)
-        torch.rand((R, n0), out=self._pinned["t_rand"])
-        torch.rand((R, N), out=self._pinned["u"])
-        self._pinned["sel"].copy_(torch.randperm(n0)[:Ne])
+            self._draws = views(self._draws_flat)
+            # The host runs several steps ahead of the GPU in this mode, so ONE pinned buffer would be rewritten while an earlier
+            # step's copy is still queued: a ring of pinned buffers, each guarded by an event recorded behind its copy.
+            self._pinned_ring = []
+            for _ in range(self.N_STAGING):
+                flat = torch.empty((b + Ne,), dtype=torch.float32).pin_memory()
+                self._pinned_ring.append((flat, views(flat), torch.cuda.Event()))
+            self._pinned_next = 0
+            self._pinned_used = [False] * self.N_STAGING
+        slot = self._pinned_next
+        self._pinned_next = (slot + 1) % self.N_STAGING
+        pinned_flat, pinned, ev = self._pinned_ring[slot]
+        if self._pinned_used[slot]:
+            ev.synchronize()                         # the copy that last read this buffer has completed (normally long ago)
+        torch.rand((R, n0), out=pinned["t_rand"])
+        torch.rand((R, N), out=pinned["u"])
+        pinned["sel"].copy_(torch.randperm(n0)[:Ne])
         torch.randint(M, (R,))                       # the unused eikonal index (:562) — keeps the generator in step
-        self._draws_flat.copy_(self._pinned_flat, non_blocking=True)
+        self._draws_flat.copy_(pinned_flat, non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        self._pinned_used[slot] = True
         s.draws = self._draws
 
 
