@@ -102,13 +102,21 @@ def reference_loss():
                       rgb_weight=1.0, tv_weight=0.01)  # config/ours.yaml:15-20
 
 
-def golden_train_step(name, n_points, n_rays, view, seed, cam_radius=2.2):
-    scene = syn.make_scene(n_points, seed=seed)
+def torch_local_data(local):
+    return {k: (torch.from_numpy(np.asarray(v)) if isinstance(v, np.ndarray) or isinstance(v, np.floating) else v) for k, v in local.items()}
+
+
+def golden_train_step(name, n_points, n_rays, view, seed, cam_radius=2.2, prior="kaiming", local=False):
+    """One reference optimisation step (train.py:330-363) on a synthetic scene: forward (fast=1), VolSDFLoss, backward,
+    clip_grad_norm_(1.0), Adam(lr 5e-4) — every stage tensor the HIP path can be compared with in isolation."""
+    scene = syn.make_scene(n_points, seed=seed, prior=prior)
     if cam_radius != 2.2:
         scene["intrinsics"], scene["poses"] = syn.make_cameras(ring_radius=cam_radius)
     model, ref_mod = ref_shim.build_reference_model(scene)
     model.train()
     inp, uv, rgb_gt, mask_gt = make_inputs(scene, n_rays, view, seed + 100)
+    if local:
+        inp["local_data"] = torch_local_data(syn.make_local_data(scene, view, seed=seed))
     loss_fn = reference_loss()
     captured = {}
     orig_query = ref_mod.query
@@ -120,20 +128,33 @@ def golden_train_step(name, n_points, n_rays, view, seed, cam_radius=2.2):
             captured["neighbor_idx"] = res[0].clone()
             captured["mask"] = res[2].clone()
             captured["ray_mask"] = res[3].clone()
+        elif "points" in captured and "pseudo_idx" not in captured and inputs.shape[0] != n_rays * 128:
+            captured["pseudo_pts"] = inputs.detach().clone().reshape(-1, 3)
+            captured["pseudo_idx"] = res[0].clone()
+            captured["pseudo_ray_mask"] = res[3].clone()
         return res
 
     ref_mod.query = query_spy
-    orig_get_sdf, orig_get_color = model.get_sdf, model.get_color
 
-    def sdf_spy(*a, **k):
-        captured["agg_sdf"] = orig_get_sdf(*a, **k)
-        return captured["agg_sdf"]
+    def spy(obj, attr, keys):
+        orig = getattr(obj, attr)
 
-    def color_spy(*a, **k):
-        captured["colors"] = orig_get_color(*a, **k)
-        return captured["colors"]
+        def wrapped(*a, **k):
+            res = orig(*a, **k)
+            outs = res if isinstance(res, tuple) else (res,)
+            for key, v in zip(keys, outs):
+                if key is not None and key not in captured:
+                    captured[key] = v.detach().clone()
+            return res
 
-    model.get_sdf, model.get_color = sdf_spy, color_spy
+        setattr(obj, attr, wrapped)
+
+    spy(model, "get_sdf", ["agg_sdf"])
+    spy(model, "get_color", ["colors"])
+    spy(model, "get_importance_rays", [None, "z_vals", "cam_loc", "ray_dirs"])
+    spy(model, "filter_points", ["shading_pts", "z_slots", "deltas"])
+    spy(model, "get_gradients", ["gradients"])
+    spy(model, "find_surface_points", ["d_surface", "network_mask"])
     torch.manual_seed(seed + 7)
     with DrawRecorder() as rec:
         out = model(inp, fast=1)
@@ -143,24 +164,35 @@ def golden_train_step(name, n_points, n_rays, view, seed, cam_radius=2.2):
     model.zero_grad()
     losses["loss"].backward()
     fx = {"meta.n_points": n_points, "meta.n_rays": n_rays, "meta.view": view, "meta.seed": seed,
-          "meta.cam_radius": cam_radius, "meta.checksum": scene_checksum(scene),
-          "in.uv": uv, "in.rgb_gt": rgb_gt, "in.mask_gt": mask_gt}
+          "meta.cam_radius": cam_radius, "meta.checksum": scene_checksum(scene), "meta.prior": np.asarray(prior),
+          "meta.local": np.asarray(bool(local)), "in.uv": uv, "in.rgb_gt": rgb_gt, "in.mask_gt": mask_gt}
     fx.update({f"draw.{k}": v for k, v in rec.draws.items()})
-    for k in ("rgb_values", "depth_values", "depth_vals", "weights", "xyz", "pseudo_pts_loss", "tv_loss", "grad_theta"):
+    for k in ("rgb_values", "depth_values", "depth_vals", "weights", "xyz", "pseudo_pts_loss", "tv_loss", "grad_theta", "local_loss"):
         fx[f"out.{k}"] = out[k].detach().numpy()
-    for k in ("points", "neighbor_idx", "mask", "ray_mask", "agg_sdf", "colors"):
-        fx[f"stage.{k}"] = captured[k].detach().numpy()
-    fx["stage.neighbor_idx"] = fx["stage.neighbor_idx"].astype(np.int32)
+    for k, v in captured.items():
+        fx[f"stage.{k}"] = v.detach().numpy()
+    for k in ("neighbor_idx", "pseudo_idx"):
+        if f"stage.{k}" in fx:
+            fx[f"stage.{k}"] = fx[f"stage.{k}"].astype(np.int32)
     for k, v in losses.items():
         fx[f"loss.{k}"] = np.float64(v.item())
-    for pname, p in model.named_parameters():
-        if p.requires_grad:
-            g = p.grad if p.grad is not None else torch.zeros_like(p)
-            fx.update(probes(f"grad.{pname}", g))
+    trainable = [(pname, p) for pname, p in model.named_parameters() if p.requires_grad]
+    for pname, p in trainable:
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        fx.update(probes(f"grad.{pname}", g))
+    # ---- the step tail (train.py:359-363): clip, Adam with the reference's two param groups (the first one empty)
+    before = {pname: p.detach().clone() for pname, p in trainable}
+    opt = torch.optim.Adam([{"params": [], "lr": 1e-2}, {"params": [p for _, p in trainable], "lr": 5.0e-4}])
+    fx["adam.grad_norm"] = np.float64(torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0).item())
+    opt.step()
+    for pname, p in trainable:
+        fx.update(probes(f"adam.{pname}", p.detach() - before[pname]))
     fx["meta.knn_calls"] = np.asarray([c[1] for c in model._voxel_grid_neural.calls], np.int64)
     np.savez_compressed(os.path.join(OUT, name), **fx)
     print(name, "rays valid", int(captured["ray_mask"].sum()), "P", captured["neighbor_idx"].shape[0],
-          "loss", losses["loss"].item(), "pseudo", out["pseudo_pts_loss"].item())
+          "loss", losses["loss"].item(), "pseudo", out["pseudo_pts_loss"].item(), "local", float(out["local_loss"]),
+          "surface rays", int(captured["network_mask"].sum()) if "network_mask" in captured else None,
+          "ranges", scene["ranges"], "size", os.path.getsize(os.path.join(OUT, name)))
 
 
 def golden_eval_step(name, n_points, n_rays, view, seed):
@@ -248,14 +280,136 @@ def golden_knn(name, seed):
     np.savez_compressed(os.path.join(OUT, name), **fx)
 
 
+SHELL_R, SHELL_W = 0.6, 0.08
+
+
+def shell_sdf(x):
+    """Analytic SDF callback of the standalone sampler fixture: sphere of radius SHELL_R, the reference's 1000 filler
+    outside a shell of half-width SHELL_W (what sdf_importance returns where a sample has no neighbour)."""
+    d = x.norm(dim=-1) - SHELL_R
+    return torch.where(d.abs() < SHELL_W, d, torch.full_like(d, 1000.0))
+
+
+def sampler_rays(n_rays, seed):
+    g = torch.Generator().manual_seed(seed)
+    cam = torch.tensor([2.0, 0.2, 0.1]).repeat(n_rays, 1)
+    tgt = torch.randn((n_rays, 3), generator=g) * 0.35
+    tgt[:6] = torch.tensor([0.0, 0.0, 9.0])          # rays that miss everything
+    return torch.nn.functional.normalize(tgt - cam, dim=-1), cam
+
+
+def golden_sampler(name, n_rays=192, seed=3):
+    """the reference's ErrorBoundSampler_pn.get_z_vals (ray_sampler.py:377-574) alone, driven by an
+    analytic SDF callback — train fast=1 (the optimisation step), eval fast=-1 (up to 5 iterations) and eval fast=1."""
+    ref_shim.enter_reference()
+    from spurfies.model.density import LaplaceDensity
+    from spurfies.model.ray_sampler import ErrorBoundSampler_pn
+
+    dirs, cam = sampler_rays(n_rays, seed)
+    fx = {"meta.n_rays": n_rays, "meta.seed": seed, "meta.shell": np.asarray([SHELL_R, SHELL_W]), "in.ray_dirs": dirs.numpy(), "in.cam_loc": cam.numpy()}
+    for tag, training, fast in (("train_fast1", True, 1), ("eval_full", False, -1), ("eval_fast1", False, 1)):
+        calls = []
+
+        class Fake:
+            pass
+
+        fake = Fake()
+        fake.training = training
+        fake.density = LaplaceDensity(params_init={"beta": 0.1}, beta_min=0.0001)
+
+        def sdf_importance(x, calls=calls):
+            calls.append(int(x.shape[0]))
+            return shell_sdf(x)
+
+        fake.sdf_importance = sdf_importance
+        sampler = ErrorBoundSampler_pn(3.0, near=0.5, far=4.5, N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1,
+                                       beta_iters=10, max_total_iters=5)
+        torch.manual_seed(seed + 8)
+        with DrawRecorder() as rec:
+            z, z_eik = sampler.get_z_vals(dirs, cam, fake, fast=fast, iter_step=0)
+        fx[f"{tag}.z_vals"] = z.detach().numpy()
+        fx[f"{tag}.z_eik"] = z_eik.detach().numpy()
+        fx[f"{tag}.calls"] = np.asarray(calls, np.int64)
+        fx.update({f"{tag}.draw.{k}": v for k, v in rec.draws.items()})
+        print(name, tag, "sdf calls", calls, "finite rays", int(torch.isfinite(z).all(-1).sum()))
+    np.savez_compressed(os.path.join(OUT, name), **fx)
+
+
+def golden_voxelize(name, seed=5, vox_res=60):
+    """the reference's load_neural_points / voxelize / construct_vox_points_closest
+    (spurfies/model/utils.py:6-88) on a synthetic .ply, with `plyfile` replaced by the build's own reader and `torch_scatter`
+    by its documented semantics (scatter_mean = per-segment sum / count; scatter_min = per-segment minimum and the index of
+    its FIRST occurrence, as torch_scatter's CPU kernel: strict `<` update) — both absent from this image."""
+    import tempfile
+
+    from spurfies_amd.model import utils as own_utils
+    from spurfies_amd.utils import surface
+
+    ref_shim.enter_reference()
+    import spurfies.model.utils as ref_utils
+
+    def scatter_mean(src, index, dim=0):
+        n = int(index.max()) + 1
+        out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype).index_add_(0, index, src)
+        cnt = torch.zeros((n,), dtype=src.dtype).index_add_(0, index, torch.ones_like(index, dtype=src.dtype)).clamp(min=1)
+        return out / cnt.view(-1, *([1] * (src.dim() - 1)))
+
+    def scatter_min(src, index, dim=0):
+        n = int(index.max()) + 1
+        s, ix = src.numpy(), index.numpy()
+        best = np.full((n,), np.inf, s.dtype)
+        arg = np.full((n,), len(s), np.int64)
+        for i in range(len(s)):
+            if s[i] < best[ix[i]]:
+                best[ix[i]], arg[ix[i]] = s[i], i
+        return torch.from_numpy(best), torch.from_numpy(arg)
+
+    class _Ply:
+        @staticmethod
+        def read(path):
+            return {"vertex": own_utils.read_ply_vertices(path)}
+
+    ref_utils.scatter_mean, ref_utils.scatter_min = scatter_mean, scatter_min
+    ref_utils.plyfile = types.SimpleNamespace(PlyData=_Ply)
+    pts, col = syn.make_raw_cloud(seed)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "cloud.ply")
+        surface.write_ply_points(path, pts, col)
+        res = ref_utils.load_neural_points(path, vox_res=vox_res)
+    centroid, grid_idx, min_idx = ref_utils.construct_vox_points_closest(torch.from_numpy(pts), vox_res)
+    fx = {"meta.seed": seed, "meta.vox_res": vox_res, "meta.checksum": np.float64(pts.astype(np.float64).sum()),
+          "out.pts": res["pts"].numpy(), "out.colors": res["colors"].numpy(), "out.min_idx": min_idx.numpy(),
+          "out.grid_idx": grid_idx.numpy(), "out.centroid": centroid.numpy()}
+    np.savez_compressed(os.path.join(OUT, name), **fx)
+    print(name, "in", len(pts), "-> out", len(res["pts"]), "size", os.path.getsize(os.path.join(OUT, name)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    golden_knn("knn_spec.npz", seed=3)
-    golden_train_step("step_train_r128.npz", n_points=6000, n_rays=128, view=0, seed=0)
-    golden_train_step("step_train_far.npz", n_points=3000, n_rays=96, view=1, seed=1, cam_radius=1.6)
-    golden_eval_step("step_eval_r24.npz", n_points=6000, n_rays=24, view=2, seed=2)
-    golden_sdf_eval("sdf_eval_grid.npz", n_points=6000, seed=0)
+    only = set(sys.argv[1:])
+
+    def want(n):
+        return not only or n in only
+
+    if want("knn_spec.npz"):
+        golden_knn("knn_spec.npz", seed=3)
+    if want("step_train_r128.npz"):
+        golden_train_step("step_train_r128.npz", n_points=6000, n_rays=128, view=0, seed=0)
+    if want("step_train_far.npz"):
+        golden_train_step("step_train_far.npz", n_points=3000, n_rays=96, view=1, seed=1, cam_radius=1.6)
+    if want("step_train_garden.npz"):       # +-2 grid, selected by scan name as pointneus_disent.py:45-53 does
+        golden_train_step("step_train_garden.npz", n_points=20000, n_rays=64, view=0, seed=4, cam_radius=4.0)
+    if want("step_train_local.npz"):        # fitted prior (the SDF crosses zero) + local_data: find_surface_points + get_local_loss
+        golden_train_step("step_train_local.npz", n_points=6000, n_rays=96, view=0, seed=6, prior="fitted", local=True)
+    if want("step_eval_r24.npz"):
+        golden_eval_step("step_eval_r24.npz", n_points=6000, n_rays=24, view=2, seed=2)
+    if want("sdf_eval_grid.npz"):
+        golden_sdf_eval("sdf_eval_grid.npz", n_points=6000, seed=0, res=32)
+    if want("sampler_g4.npz"):
+        golden_sampler("sampler_g4.npz")
+    if want("voxelize.npz"):
+        golden_voxelize("voxelize.npz")
 
 
 if __name__ == "__main__":

@@ -383,6 +383,52 @@ def tv_loss(grid, st, cfg):
     return (tv / norm).mean()
 
 
+# --------------------------------------------------------------------------- local (feature-consistency) loss
+def find_surface_points(sdf, z):
+    """pointneus_disent.py:586-612: per ray, the FIRST interval whose SDF changes sign from + to - (back-facing crossings are
+    ignored; slots without a point carry 1000 -> NaN and never form a crossing), linearly interpolated depth.
+    sdf, z [Rv,SR] -> (d_surface [Rv] (0 where no crossing), hit bool [Rv])."""
+    s = torch.where(sdf == SDF_FILL, torch.full_like(sdf, float("nan")), sdf)
+    cross = (s[:, 1:] * s[:, :-1] < 0) & (s[:, 1:] < s[:, :-1])
+    hit = cross.any(-1)
+    first = ((torch.cumsum(cross.int(), -1) == 0).sum(-1)).clamp(max=cross.shape[1] - 1)      # index of the first True
+    s0, s1 = torch.gather(s, 1, first[:, None]).squeeze(1), torch.gather(s, 1, first[:, None] + 1).squeeze(1)
+    d0, d1 = torch.gather(z, 1, first[:, None]).squeeze(1), torch.gather(z, 1, first[:, None] + 1).squeeze(1)
+    d = torch.zeros(sdf.shape[0])
+    d[hit] = ((s0 * d1 - s1 * d0) / (s0 - s1))[hit]
+    return d, hit
+
+
+def local_feature_loss(surf_pts, local):
+    """feat_utils.py:377-451 for one reference view, uncerts=None: project the surface points into the reference and the
+    source views (idx_world2cam :43-47, idx_cam2img :50-55), bilinear-sample the half-resolution feature maps
+    (normalize_for_grid_sample :58-68, grid / 2), 1 - cosine similarity between the reference and each source feature,
+    masked to points visible in both views and to |1 - corr| < 0.5, mean over sources x points.
+    surf_pts [n,3] (n > 0); local: size [], center [3], feat [C,H,W], feat_src [m,C,H,W], cam [2,4,4], src_cams [m,2,4,4]."""
+    n = surf_pts.shape[0]
+    if n == 0:
+        return torch.tensor(0.0)
+    pw = (surf_pts / 2 * local["size"].view(1, 1) + local["center"].view(1, 3)).view(1, -1, 1, 3, 1)
+    pw = torch.cat([pw, torch.ones_like(pw[..., -1:, :])], dim=-2)                          # [1,n,1,4,1]
+    cams = torch.cat([local["cam"][None], local["src_cams"]], dim=0)                        # [1+m,2,4,4]
+    pc = cams[:, 0:1].unsqueeze(1) @ pw
+    pc = pc / (pc[..., -1:, :] + 1e-9)
+    pc3 = pc[..., :3, :] / (pc[..., 3:4, :] + 1e-9)
+    pi = cams[:, 1:2, :3, :3].unsqueeze(1) @ pc3
+    pi = pi / (pi[..., -1:, :] + 1e-9)
+    grid = pi[..., :2, 0]                                                                   # [1+m,n,1,2] pixel (x, y)
+    feats = torch.cat([local["feat"][None], local["feat_src"]], dim=0)                      # [1+m,C,H,W]
+    wh = torch.tensor(feats.shape[2:]).flip(0).to(grid.dtype).view(1, 1, 1, -1)
+    gn = ((grid / 2) / wh * 2 - 1).clamp(-1.1, 1.1)
+    in_range = ((gn[..., 0] <= 1) & (gn[..., 0] >= -1) & (gn[..., 1] <= 1) & (gn[..., 1] >= -1)).to(gn.dtype)
+    valid = (in_range[:1] * in_range[1:]).unsqueeze(1) > 0.5                                # [m,1,n,1]
+    g = F.grid_sample(feats, gn, mode="bilinear", padding_mode="zeros", align_corners=False)  # [1+m,C,n,1]
+    gnorm = g.norm(dim=1, keepdim=True)
+    corr = (g[:1] * g[1:]).sum(dim=1, keepdim=True) / gnorm[:1].clamp(min=1e-9) / gnorm[1:].clamp(min=1e-9)
+    corr_loss = (1 - corr).abs()
+    return (corr_loss * valid * (corr_loss < 0.5)).mean()
+
+
 # --------------------------------------------------------------------------- full forward
 def forward(inp, st, cfg: PathConfig, grid=None, training=True, fast=-1, draws=None, stages=None):
     """pointneus_disent.py:614-892.  inp: {'intrinsics' [1,4,4], 'uv' [1,R,2], 'pose' [1,4,4]}.
@@ -391,6 +437,8 @@ def forward(inp, st, cfg: PathConfig, grid=None, training=True, fast=-1, draws=N
         grid = make_grid(cfg, st["neural_pts"])
     K, uv, pose = inp["intrinsics"], inp["uv"], inp["pose"]
     pseudo_loss = torch.tensor(0.0)
+    local_loss = torch.tensor(0.0)
+    local = inp.get("local_data")
     dirs_b, cam_b = camera_rays(uv, pose, K)
     dirs_tmp, _ = camera_rays(uv, torch.eye(4)[None], K)
     depth_scale = dirs_tmp[0, :, 2:]
@@ -439,6 +487,11 @@ def forward(inp, st, cfg: PathConfig, grid=None, training=True, fast=-1, draws=N
         dens[vmask] = laplace_density(agg_sdf, get_beta(st, cfg))
         weights_v = volume_weights(deltas[..., 0], dens[..., 0])
         zv = zf.squeeze(-1)
+        if local is not None and training:              # pointneus_disent.py:727-763
+            d_surf, hit = find_surface_points(sdf_f.squeeze(-1), zv)
+            local_loss = local_feature_loss((o + dvec * d_surf[:, None])[hit], local)
+            if stages is not None:
+                stages.update(d_surface=d_surf, network_mask=hit)
         dist_map = torch.sum(weights_v / (weights_v.sum(-1, keepdim=True) + 1e-10) * zv, -1)
         pts_rendered = o + dvec * dist_map[:, None]
         sdf_r, rend_valid = sdf_at_points(pts_rendered, grid, st, cfg)
@@ -473,7 +526,7 @@ def forward(inp, st, cfg: PathConfig, grid=None, training=True, fast=-1, draws=N
         weights[ray_mask] = weights_v
         depth_vals[ray_mask] = zv * depth_scale[ray_mask]
     out = {"rgb_values": rgb, "depth_values": depth, "depth_vals": depth_vals, "weights": weights, "xyz": xyz,
-           "local_loss": torch.tensor(0.0), "pseudo_pts_loss": pseudo_loss, "tv_loss": tv_loss(grid, st, cfg)}
+           "local_loss": local_loss, "pseudo_pts_loss": pseudo_loss, "tv_loss": tv_loss(grid, st, cfg)}
     if not training:
         if have:
             normal[ray_mask] = normal_v
@@ -507,6 +560,26 @@ def volsdf_loss(out, rgb_gt, mask_gt, cfg: PathConfig):
                    + cfg.tv_weight * res["tv_loss"] + cfg.local_weight * res["local_loss"]
                    + cfg.pseudo_weight * res["pseudo_loss"] + res["mask_loss"])
     return res
+
+
+def make_optimizer(st, lr=5.0e-4):
+    """spurfies/train.py:168-189: Adam, two param groups (the first one empty), CosineAnnealingLR(T_max=1e5, eta_min=3e-4)."""
+    params = [v for v in st.values() if v.requires_grad]
+    opt = torch.optim.Adam([{"params": [], "lr": 1e-2}, {"params": params, "lr": lr}])
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=100_000, eta_min=3e-4, last_epoch=-1)
+    return opt, sched
+
+
+def optimizer_step(st, opt, sched=None, max_norm=1.0):
+    """spurfies/train.py:359-363, 548-564: clip_grad_norm_(1.0), drop the update when a gradient is not finite, Adam, scheduler.
+    Returns the total gradient norm before clipping."""
+    params = [v for v in st.values() if v.requires_grad]
+    norm = torch.nn.utils.clip_grad_norm_(params, max_norm)
+    if all(bool(torch.isfinite(p.grad).all()) for p in params if p.grad is not None):
+        opt.step()
+    if sched is not None:
+        sched.step()
+    return norm
 
 
 def train_step_grads(inp, rgb_gt, mask_gt, st, cfg, grid=None, draws=None, stages=None):

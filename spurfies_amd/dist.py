@@ -90,7 +90,8 @@ def sharded_loss(loss_mod, out, ground_truth, group=None):
     if "_fused" in out:                          # sync-free mode: fused loss kernels with the all-reduced counts as normalisers
         f = out["_fused"]
         cnt = (f["pvalid"].bool() & f["ray_valid"].bool()).sum().float()
-        counts = torch.stack([torch.full((), float(out["rgb_values"].shape[0]), device=dev), f["n_points"][0].float(), cnt])
+        lcnt = out["local_count"] if "local_count" in out else torch.zeros((), device=dev)
+        counts = torch.stack([torch.full((), float(out["rgb_values"].shape[0]), device=dev), f["n_points"][0].float(), cnt, lcnt])
         all_reduce_sum(counts, group)
         return loss_mod.fused_forward(out, ground_truth, denom=counts, world=G)
     rgb_gt = ground_truth["rgb"].to(dev).reshape(-1, 3)
@@ -100,7 +101,8 @@ def sharded_loss(loss_mod, out, ground_truth, group=None):
     eik_sum = ((g.norm(2, dim=1) - 1) ** 2).sum() if g is not None else torch.zeros((), device=dev)
     P_loc = torch.full((), float(0 if g is None else g.shape[0]), device=dev)
     pseudo_cnt = out.get("pseudo_count", torch.ones((), device=dev))
-    counts = torch.stack([torch.full((), float(R_loc), device=dev), P_loc, pseudo_cnt.float()])
+    lcnt = out["local_count"] if "local_count" in out else torch.zeros((), device=dev)
+    counts = torch.stack([torch.full((), float(R_loc), device=dev), P_loc, pseudo_cnt.float(), lcnt])
     all_reduce_sum(counts, group)
     R_tot, P_tot, ps_tot = counts[0], counts[1].clamp(min=1), counts[2]
     zero = torch.zeros((), device=dev)
@@ -109,7 +111,8 @@ def sharded_loss(loss_mod, out, ground_truth, group=None):
     res["tv_loss"] = out["tv_loss"] / G if loss_mod.tv_weight > 0 else zero
     wsum = out["weights"].sum(-1, keepdim=True).clip(1e-3, 1.0 - 1e-3)
     res["mask_loss"] = F.binary_cross_entropy(wsum, mask_gt, reduction="sum") / R_tot
-    res["local_loss"] = out.get("local_loss", zero) / G
+    # feature-consistency term: mean over the batch's surface hits (x sources) -> local sum / global count
+    res["local_loss"] = (out["local_sum"] / counts[3].clamp(min=1.0)) if "local_sum" in out else out.get("local_loss", zero) / G
     if loss_mod.pseudo_weight > 0 and "pseudo_sum" in out:
         # no rank has a valid rendered point -> the reference's constant 1000 (split over ranks)
         res["pseudo_loss"] = torch.where(ps_tot > 0, out["pseudo_sum"] / ps_tot.clamp(min=1), torch.full_like(ps_tot, 1000.0 / G))

@@ -48,7 +48,14 @@ class VolSDFLoss(nn.Module):
         total, t = ops.FusedLoss.apply(model_outputs["rgb_values"], f["acc"], psdf, tv, f["grad"], f["slot_valid"], f["n_points"],
                                        f["pvalid"], f["ray_valid"], rgb_gt, mask, mask.stride(0), w, denom)
         self.iter_step += 1
-        return {"loss": total, "rgb_loss": t[1], "eikonal_loss": t[2], "tv_loss": t[3], "mask_loss": t[4], "local_loss": t[5],
+        local = t[5]
+        if "local_sum" in model_outputs and self.local_weight > 0:
+            # the feature-consistency term is PyTorch ops (grid_sample) upstream of the loss kernels: added here, normalised by the
+            # global hit count when rays are sharded (denom[3])
+            cnt = model_outputs["local_count"] if (denom is None or denom.numel() < 4) else denom[3]
+            local = model_outputs["local_sum"] / cnt.clamp(min=1.0)
+            total = total + self.local_weight * local
+        return {"loss": total, "rgb_loss": t[1], "eikonal_loss": t[2], "tv_loss": t[3], "mask_loss": t[4], "local_loss": local,
                 "pseudo_loss": t[6]}
 
     def forward(self, model_outputs, ground_truth):

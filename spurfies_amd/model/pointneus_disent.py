@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import feat_utils, ops
 from ..torch_knnquery import VoxelGrid
 from ..utils import rend_util
 from .density import LaplaceDensity
@@ -84,6 +84,8 @@ class PointVolSDF(nn.Module):
         self._tv_graph = None
         self._tv_key = None
         self.stats = {}
+        self.keep_stages = False
+        self.stages = None
         self.sync_free = False   # training only: static shapes, no host synchronisation (spurfies_amd/train.py sets it)
 
     # ------------------------------------------------------------------ initialisation (:116-205)
@@ -194,6 +196,25 @@ class PointVolSDF(nn.Module):
             return torch.ones((inputs.shape[0]), device=inputs.device) * SDF_FILL
         return r["sdf"][valid].unsqueeze(-1)
 
+    # ------------------------------------------------------------------ SDF zero crossings (:586-612)
+    @staticmethod
+    def find_surface_points(sdf, d_all, device=None):
+        """Per ray, the first interval where the SDF goes from + to - between ADJACENT slots (slots without a point hold 1000
+        and never form a crossing), and the linearly interpolated depth of the zero.  sdf, d_all [..., SR] ->
+        (d_surface [...] (0 where there is none), network_mask bool [...]).  Differentiable w.r.t. sdf.  Unlike the
+        reference (which overwrites the 1000s of its input with NaN in place, :587) the input is left untouched."""
+        ok = sdf != SDF_FILL
+        s0, s1 = sdf[..., :-1], sdf[..., 1:]
+        cross = ok[..., :-1] & ok[..., 1:] & (s1 * s0 < 0) & (s1 < s0)
+        hit = cross.any(-1)
+        first = (torch.cumsum(cross.to(torch.int32), -1) == 0).sum(-1, keepdim=True).clamp(max=cross.shape[-1] - 1)
+        # rays without a crossing get a harmless (1, -1) pair: no NaN / Inf enters the backward of the division
+        a = torch.where(hit, torch.gather(sdf, -1, first).squeeze(-1), torch.ones_like(sdf[..., 0]))
+        b = torch.where(hit, torch.gather(sdf, -1, first + 1).squeeze(-1), -torch.ones_like(sdf[..., 0]))
+        d0, d1 = torch.gather(d_all, -1, first).squeeze(-1), torch.gather(d_all, -1, first + 1).squeeze(-1)
+        d_surface = torch.where(hit, (a * d1 - b * d0) / (a - b), torch.zeros_like(a))
+        return d_surface, hit
+
     # ------------------------------------------------------------------ rays
     def get_importance_rays(self, cam_loc, ray_dirs, model, fast=-1, iter_step=None):
         ray_dirs = ray_dirs.reshape(-1, 3)
@@ -243,6 +264,16 @@ class PointVolSDF(nn.Module):
             dirs_cam, _ = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], intrinsics)
             depth_scale = dirs_cam[0, :, 2:]
             points, _, cam_loc, ray_dirs = self.get_importance_rays(cam_loc, ray_dirs, self, fast, iter_step)
+        return self.render_points(points, ray_dirs, cam_loc, depth_scale, input.get("local_data"))
+
+    def render_points(self, points, ray_dirs, cam_loc, depth_scale, local_data=None):
+        """Everything of forward() behind the sampler (:654-892): main-pass kNN of the sample positions `points` [R,D,3] (the
+        sampler's o + z d), filter_points, SDF + normals + colours at the hits, compositing, the pseudo-point / local / TV terms
+        and the output dict.  Split out so that a stage test can feed recorded sample positions."""
+        dev = self.neural_pts.device
+        conf = self.conf
+        SR, k = conf.max_shading_pts, conf.k
+        grid = self._grid()
         R = ray_dirs.shape[0]
 
         # ---- kNN of the main pass, dense [R,SR] ------------------------------------------------
@@ -280,6 +311,16 @@ class PointVolSDF(nn.Module):
         else:
             weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta(), q["slot_valid"], z_slots, deltas)
         output = {"rgb_values": rgb, "weights": weights, "local_loss": torch.zeros((), device=dev)}
+        if self.keep_stages:        # stage tests: dense-row intermediates next to the reference's per-stage tensors
+            self.stages = {"pidx": q["pidx"], "loc": q["loc"], "slot_valid": q["slot_valid"], "ray_valid": q["ray_valid"], "x": x, "z_slots": z_slots,
+                           "deltas": deltas, "sdf": sdf, "gradients": gradients, "colors": colors, "dist_map": dist_map}
+
+        # ---- multi-view feature consistency at the SDF zero crossings (:727-763), DTU training only ---------
+        if local_data is not None and self.training:
+            d_surface, hit = self.find_surface_points(sdf, z_slots)
+            lsum, lcnt = feat_utils.local_loss_terms(DistPoints.apply(cam_loc, ray_dirs, d_surface), hit, local_data)
+            output["local_loss"] = lsum / lcnt.clamp(min=1.0)          # 0 when no ray crosses the surface, as feat_utils.py:390-391
+            output["local_sum"], output["local_count"] = lsum, lcnt    # ray-sharded steps normalise by the global count
         if not static:          # per-slot maps the trainer never reads in an optimisation step (plots only)
             far_fill = float(conf.ray_sampler.far)
             output["depth_values"] = torch.where(ray_mask[:, None], depth, torch.ones_like(depth))

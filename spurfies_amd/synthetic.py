@@ -123,15 +123,120 @@ def make_latents(n: int, colors: np.ndarray, seed: int = 0, geo_std: float = 0.0
     return fc, fg
 
 
-def make_scene(n_points: int = 10000, seed: int = 0, spacing: float = 0.025, geo_std: float = 0.3) -> dict:
-    """Everything a step needs, as numpy arrays (state_dict-style keys)."""
+def surface_normals(pts: np.ndarray, base: float) -> np.ndarray:
+    """Outward unit normals of the lobed sphere at (points near) its surface: gradient of f(p) = |p| - R(p / |p|) by
+    central differences in float64."""
+    p = pts.astype(np.float64)
+
+    def f(q):
+        r = np.linalg.norm(q, axis=-1)
+        return r - lobed_radius(q / r[:, None], base)
+
+    h = 1e-5
+    g = np.stack([(f(p + h * e) - f(p - h * e)) / (2 * h) for e in np.eye(3)], -1)
+    return (g / np.linalg.norm(g, axis=-1, keepdims=True)).astype(np.float32)
+
+
+def surface_sdf(x: np.ndarray, base: float) -> np.ndarray:
+    """First-order signed distance to the lobed sphere: f / |grad f| with f(p) = |p| - R(p / |p|)."""
+    p = x.astype(np.float64)
+
+    def f(q):
+        r = np.linalg.norm(q, axis=-1)
+        return r - lobed_radius(q / r[:, None], base)
+
+    h = 1e-5
+    g = np.stack([(f(p + h * e) - f(p - h * e)) / (2 * h) for e in np.eye(3)], -1)
+    return f(p) / np.linalg.norm(g, axis=-1)
+
+
+PRIOR_FITTED = None
+
+
+def fitted_prior() -> dict:
+    """F_geometry / T weights fitted by tools/fit_prior.py (the reference's ckpt/local_prior.pt is a separate download):
+    with geometry latents g[:3] = 0.5 n they turn an oriented cloud into its signed-distance field."""
+    global PRIOR_FITTED
+    if PRIOR_FITTED is None:
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "prior_fitted.npz")
+        PRIOR_FITTED = {k: v for k, v in np.load(path).items()}
+    return PRIOR_FITTED
+
+
+def make_scene(n_points: int = 10000, seed: int = 0, spacing: float = 0.025, geo_std: float = 0.3, prior: str = "kaiming") -> dict:
+    """Everything a step needs, as numpy arrays (state_dict-style keys).
+    prior='kaiming': random F_geometry / T and random geometry latents (the SDF is a generic smooth function);
+    prior='fitted': the fitted local prior + latents carrying the analytic normals, i.e. the SDF is the signed distance
+    to the analytic surface (realistic sampler convergence, zero crossings, pair counts)."""
     pts, colors, base = make_cloud(n_points, spacing, seed)
-    fc, fg = make_latents(len(pts), colors, seed, geo_std)
     K, poses = make_cameras()
     sd = make_mlp_weights(seed)
+    if prior == "fitted":
+        fc, _ = make_latents(len(pts), colors, seed, geo_std)
+        rng = np.random.default_rng(seed + 77)
+        fg = (0.05 * rng.standard_normal((len(pts), 32))).astype(np.float32)
+        fg[:, :3] = np.float32(0.5) * surface_normals(pts, base)
+        sd.update(fitted_prior())
+    elif prior == "kaiming":
+        fc, fg = make_latents(len(pts), colors, seed, geo_std)
+    else:
+        raise ValueError(prior)
     sd["neural_pts"] = pts
     sd["neural_feats_color"] = fc
     sd["neural_feats_geometry"] = fg
     sd["density.beta"] = np.float32(0.1)
-    return {"state": sd, "colors": colors, "intrinsics": K, "poses": poses, "base_radius": base,
+    return {"state": sd, "colors": colors, "intrinsics": K, "poses": poses, "base_radius": base, "prior": prior,
             "ranges": (-1.0, -1.0, -1.0, 1.0, 1.0, 1.0) if base * 1.3 < 1.0 else (-2.0, -2.0, -2.0, 2.0, 2.0, 2.0)}
+
+
+def _smooth_field(rng, channels: int, h: int, w: int, coarse=(9, 12)) -> np.ndarray:
+    """[channels, h, w] float32: coarse Gaussian noise, separably linearly interpolated (numpy only, deterministic)."""
+    ch, cw = coarse
+    base = rng.standard_normal((channels, ch, cw))
+    ys, xs = np.linspace(0.0, ch - 1.0, h), np.linspace(0.0, cw - 1.0, w)
+    y0, x0 = np.minimum(ys.astype(np.int64), ch - 2), np.minimum(xs.astype(np.int64), cw - 2)
+    fy, fx = (ys - y0)[None, :, None], (xs - x0)[None, None, :]
+    rows = base[:, y0, :] * (1.0 - fy) + base[:, y0 + 1, :] * fy               # [C, h, cw]
+    return (rows[:, :, x0] * (1.0 - fx) + rows[:, :, x0 + 1] * fx).astype(np.float32)
+
+
+def make_local_data(scene: dict, view: int, channels: int = 8, seed: int = 0, size: float = 2.5,
+                    center=(0.1, -0.05, 0.02)) -> dict:
+    """Stand-in for the `local_data` dict datasets/dtu.py:268-291 hands to the model (VisMVSNet feature maps and MVS
+    cameras come from an unavailable download): feature maps at half the image resolution for the reference view and
+    the other views, `cam` / `src_cams` = [2,4,4] packs (world->camera extrinsic; K in [1,:3,:3]) expressed in the
+    de-normalised world frame p_world = p / 2 * size + center that feat_utils.get_local_loss:405-408 maps back to."""
+    rng = np.random.default_rng(seed + 4242)
+    poses = scene["poses"]
+    n_views = len(poses)
+    src = [v for v in range(n_views) if v != view]
+    h2, w2 = IMG_H // 2, IMG_W // 2
+    common = _smooth_field(rng, channels, h2, w2)                            # shared structure, so views correlate
+    feats = [(common + 0.5 * _smooth_field(rng, channels, h2, w2)).astype(np.float32) for _ in range(n_views)]
+    A = np.eye(4)
+    A[:3, :3] *= size / 2.0
+    A[:3, 3] = np.asarray(center, np.float64)
+    A_inv = np.linalg.inv(A)
+
+    def cam_pack(v):
+        pack = np.zeros((2, 4, 4), np.float32)
+        pack[0] = (np.linalg.inv(poses[v].astype(np.float64)) @ A_inv).astype(np.float32)
+        pack[1] = np.eye(4, dtype=np.float32)
+        pack[1, :3, :3] = scene["intrinsics"][:3, :3]
+        return pack
+
+    return {"size": np.float32(size), "center": np.asarray(center, np.float32), "feat": feats[view],
+            "feat_src": np.stack([feats[v] for v in src]), "cam": cam_pack(view), "src_cams": np.stack([cam_pack(v) for v in src]),
+            "H": IMG_H, "W": IMG_W, "src_idxs": np.asarray(src, np.int64)}
+
+
+def make_raw_cloud(seed: int, n: int = 30000):
+    """Unthinned, noisy cloud (what a DUSt3R .ply looks like before load_neural_points thins it, spurfies/model/utils.py:59-88):
+    many points per voxel and a few exact duplicates.  -> (pts float32 [n,3], colors uint8 [n,3])."""
+    pts, colors, _ = make_cloud(n, spacing=0.008, seed=seed, jitter=0.6)
+    rng = np.random.default_rng(seed + 5)
+    pts = (pts + 0.004 * rng.standard_normal(pts.shape)).astype(np.float32)
+    pts[-50:] = pts[:50]
+    return pts, colors.astype(np.uint8)

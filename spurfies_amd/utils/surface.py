@@ -184,3 +184,22 @@ def write_ply(path, verts, faces):
         rec = np.empty(len(faces), dtype=[("n", "u1"), ("v", "<i4", (3,))])
         rec["n"], rec["v"] = 3, faces
         f.write(rec.tobytes())
+
+
+def write_ply_points(path, pts, colors=None):
+    """Binary little-endian point-cloud PLY in the layout the reference's clouds use (vertex x y z float32 [+ red green
+    blue uchar], dust3r_inference.py -> spurfies/model/utils.py:59-88)."""
+    pts = np.asarray(pts, dtype="<f4")
+    fields = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")]
+    header = f"ply\nformat binary_little_endian 1.0\nelement vertex {len(pts)}\nproperty float x\nproperty float y\nproperty float z\n"
+    if colors is not None:
+        fields += [("red", "u1"), ("green", "u1"), ("blue", "u1")]
+        header += "property uchar red\nproperty uchar green\nproperty uchar blue\n"
+    rec = np.empty(len(pts), dtype=fields)
+    rec["x"], rec["y"], rec["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    if colors is not None:
+        col = np.asarray(colors, dtype="u1")
+        rec["red"], rec["green"], rec["blue"] = col[:, 0], col[:, 1], col[:, 2]
+    with open(path, "wb") as f:
+        f.write((header + "end_header\n").encode())
+        f.write(rec.tobytes())

@@ -14,7 +14,7 @@ def load_golden(name):
 
 
 def scene_of(fx):
-    scene = syn.make_scene(int(fx["meta.n_points"]), seed=int(fx["meta.seed"]))
+    scene = syn.make_scene(int(fx["meta.n_points"]), seed=int(fx["meta.seed"]), prior=str(fx["meta.prior"]) if "meta.prior" in fx else "kaiming")
     if "meta.cam_radius" in fx and float(fx["meta.cam_radius"]) != 2.2:
         scene["intrinsics"], scene["poses"] = syn.make_cameras(ring_radius=float(fx["meta.cam_radius"]))
     st = scene["state"]
@@ -23,11 +23,19 @@ def scene_of(fx):
     return scene
 
 
+def local_data_of(fx, scene, device="cpu"):
+    """The synthetic `local_data` dict of a fixture generated with local=True (regenerated from the seed), else None."""
+    if "meta.local" not in fx or not bool(fx["meta.local"]):
+        return None
+    local = syn.make_local_data(scene, int(fx["meta.view"]), seed=int(fx["meta.seed"]))
+    return {k: (torch.from_numpy(np.asarray(v)).to(device) if isinstance(v, (np.ndarray, np.floating)) else v) for k, v in local.items()}
+
+
 def inputs_of(fx, scene, device="cpu"):
     return {"intrinsics": torch.from_numpy(scene["intrinsics"])[None].to(device),
             "uv": torch.from_numpy(fx["in.uv"])[None].to(device),
             "pose": torch.from_numpy(scene["poses"][int(fx["meta.view"])])[None].to(device),
-            "local_data": None, "iter_step": 0}
+            "local_data": local_data_of(fx, scene, device), "iter_step": 0}
 
 
 def draws_of(fx):

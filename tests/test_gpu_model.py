@@ -191,6 +191,34 @@ def test_sync_free_step_equals_default_step():
     np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=2e-3, atol=2e-5 * float(g0.abs().max()))
 
 
+def test_sync_free_steps_run_ahead_without_tearing_draws():
+    """Sync-free steps never synchronise, so the host runs several steps ahead of the GPU while the CPU-generator draws travel
+    through pinned staging buffers: with a ring of only two buffers and eight steps queued back to back, every step must still
+    consume exactly its own draws — the loss trajectory equals the default (synchronising) mode's."""
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.train import TrainStep
+
+    scene = syn.make_scene(3000, seed=14)
+    g = torch.Generator().manual_seed(8)
+    K = torch.from_numpy(scene["intrinsics"])[None].cuda()
+    batches = []
+    for it in range(8):
+        uv = torch.from_numpy(syn.make_pixels(256, g))[None].cuda()
+        pose = torch.from_numpy(scene["poses"][it % 3])[None].cuda()
+        gt = {"rgb": torch.rand((256, 3), generator=g)[None].cuda(), "mask": (torch.rand((256,), generator=g) > 0.2).float()[None, :, None].repeat(1, 1, 3).cuda()}
+        batches.append(({"intrinsics": K, "uv": uv, "pose": pose, "local_data": None}, gt))
+    traj = []
+    for sync_free in (False, True):
+        model = build_model(scene)
+        step = TrainStep(model, sync_free=sync_free)
+        step.N_STAGING = 2
+        torch.manual_seed(21)
+        torch.cuda.synchronize()
+        ls = [step(*b)[0]["loss"] for b in batches]           # device scalars: nothing is read back between the steps
+        traj.append([float(v.item()) for v in ls])
+    np.testing.assert_allclose(traj[1], traj[0], rtol=5e-4)
+
+
 def test_graphed_step_tracks_eager_step():
     """hipGraph replay of forward + loss + backward gives the same three-step trajectory as eager launches."""
     from spurfies_amd import synthetic as syn
