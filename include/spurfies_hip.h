@@ -32,7 +32,7 @@ extern "C" {
 #define SPF_ENOMEM (-12)
 #define SPF_EHIP (-5)
 
-#define SPF_ABI_VERSION 1
+#define SPF_ABI_VERSION 2
 #define SPF_KMAX 8          /* neighbours per point (config/vol/dtu_pn.yaml:27, k: 8) */
 #define SPF_GEO_DIM 32      /* geometry latent width = feature_vector_size/2 (pointneus_disent.py:172) */
 #define SPF_COL_DIM 64      /* colour latent width  = feature_vector_size   (pointneus_disent.py:161) */
@@ -99,6 +99,11 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
 int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t* point_slot,
                        int32_t* slot_point, int32_t* n_points, int32_t* scratch, void* stream);
 
+/* Load-time voxel thinning of the .ply cloud (spurfies/model/utils.py:21-27, construct_vox_points_closest): integer cell of
+ * every point, cells[i] = floor((xyz[i] - space_min) / voxel) in float32 with IEEE division (what torch computes on the CPU;
+ * a device-side elementwise division need not be correctly rounded).  space_min: HOST float[3]; xyz [n,3], cells [n,3] device. */
+int spf_voxel_cells(const float* xyz, int64_t n, const float* space_min, float voxel, int32_t* cells, void* stream);
+
 /* Pair list over the valid points (replaces mask_to_batch_ray_idx, spurfies/model/utils.py:172-183): the rows
  * of the MLP kernels are the valid (point, neighbour) pairs, grouped by point, WITHOUT padding.
  *   pair_off   [max_points+1] int32  exclusive scan of the per-point neighbour counts (pair_off[P] = n_pairs)
@@ -115,11 +120,17 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
  * get_sdf_eval :284-296.
  * ---------------------------------------------------------------------------------------- */
 
+/* Arithmetic of the MLP / weight-gradient kernels, chosen PER CALL (`arith` argument; the library keeps no process-wide mode):
+ *   SPF_ARITH_SPLIT  every fp32 operand is split into three bf16 pieces (x = p1 + p2 + p3 exactly to 24 bits) and the six piece
+ *                    products with i + j <= 4 run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: each piece product is
+ *                    exact and the dropped terms are below 2^-24 of the product, so the result differs from SPF_ARITH_F32 only
+ *                    by summation order, at 2.7x the matrix rate.  What the product path uses.
+ *   SPF_ARITH_F32    v_mfma_f32_32x32x2_f32 (verification twin).
+ * A backward must be called with the arith of its forward (the two keep LeakyReLU sign bits in different layouts). */
+#define SPF_ARITH_SPLIT 0
+#define SPF_ARITH_F32 1
+
 /* Number of floats of the packed F_geometry/T weight image. */
-/* Arithmetic of spf_geo_forward (process-wide).  0 (default): every fp32 operand is split into three bf16 pieces and the six
- * piece products with i + j <= 4 run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (each piece product exact, dropped
- * terms below 2^-24 of the product: the result differs from mode 1 only by summation order).  1: v_mfma_f32_32x32x2_f32. */
-int spf_geo_set_mode(int32_t mode);
 
 int64_t spf_geo_packed_floats(void);
 
@@ -147,7 +158,7 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
                     const int32_t* pair_point, const int32_t* n_points, const int32_t* n_pairs,
                     int32_t max_points, int32_t max_pairs, int32_t k, const float* pts, const float* feat_geo,
                     const float* packed, float rbf, float* sdf, float* grad, float* wn, float* jac,
-                    float* pair_tmp, void* stream);
+                    float* pair_tmp, int32_t arith, void* stream);
 
 /* Backward of the weighted mean w.r.t. the geometry latents:
  *   g_feat_geo[nbr(q), :] += g_sdf[row(q)] * wn[q] * jac[q,:]   (float atomics)
@@ -165,13 +176,8 @@ int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* j
  * (sum_j wn_j (W6 a_j + b6) = W6 sum_j wn_j a_j + b6, the weights sum to 1), so this stage ends at the mean of the
  * third activation, agg3, and the head stage below applies F_color.6 once per POINT instead of once per pair.
  * ---------------------------------------------------------------------------------------- */
-/* Arithmetic of spf_color_forward / spf_color_backward (process-wide; must be the same for a forward and its backward: the two
- * modes keep the LeakyReLU sign bits in different layouts).  0 (default): fp32-exact products from three bf16 pieces per operand
- * on v_mfma_f32_32x32x16_bf16 (see spf_geo_set_mode); spf_color_backward then leaves g_b0 / g_b2 / g_b4 untouched — the bias
- * gradients are the column sums of G1..G3 and come from spf_wgrad's dbias output.  1: v_mfma_f32_32x32x2_f32, bias gradients
- * accumulated by spf_color_backward. */
-int spf_color_set_mode(int32_t mode);
-int spf_color_get_mode(void);
+/* arith (see SPF_ARITH_*): with SPF_ARITH_SPLIT spf_color_backward leaves g_b0 / g_b2 / g_b4 untouched — the bias gradients are
+ * the column sums of G1..G3 and come from spf_wgrad's dbias output; with SPF_ARITH_F32 spf_color_backward accumulates them. */
 
 int64_t spf_color_packed_floats(void);
 
@@ -189,7 +195,7 @@ int spf_color_pack(const float* w0, const float* b0, const float* w2, const floa
 int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot,
                       const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs,
                       int32_t k, const float* pts, const float* feat_color, const float* packed, float* agg3,
-                      float* act0, float* act1, float* act2, uint32_t* masks, void* stream);
+                      float* act0, float* act1, float* act2, uint32_t* masks, int32_t arith, void* stream);
 
 /* Data-gradient chain for g_agg3[p,256] = dL/d agg3: writes the pre-activation gradients G1..G3 [T,256]
  * (weight gradients of F_color.0/2/4 are then dW_l = G_l^T act_{l-1}: spf_wgrad), ADDS their column sums to
@@ -198,19 +204,15 @@ int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const
 int spf_color_backward(const float* g_agg3, const int32_t* nbr, const float* wn, const int32_t* point_slot,
                        const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs,
                        int32_t k, const float* packed, const uint32_t* masks, float* G1, float* G2, float* G3,
-                       float* g_b0, float* g_b2, float* g_b4, float* g_feat_color, void* stream);
+                       float* g_b0, float* g_b2, float* g_b4, float* g_feat_color, int32_t arith, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Head stage, per valid POINT (tiles of 64): agg = F_color.6(agg3), then the radiance head R — replaces F_color's last
  * layer and the second half of get_color, spurfies/model/pointneus_disent.py:333-346 (view encoding with multires 3,
  * concat, R: 277 -> 256 -> 256 -> 3, sigmoid) and its backward.
  * ---------------------------------------------------------------------------------------- */
-/* Arithmetic of spf_rhead_forward / spf_rhead_backward (process-wide; a backward must run in the mode of its forward).
- * 0 (default): fp32-exact products from three bf16 pieces per operand (see spf_geo_set_mode); spf_rhead_backward then leaves
- * g_b6 / g_b0 / g_b2 untouched — they are the column sums of g_agg / G1 / G2 and come from spf_wgrad's dbias output.
- * 1: v_mfma_f32_32x32x2_f32, bias gradients accumulated by spf_rhead_backward. */
-int spf_rhead_set_mode(int32_t mode);
-int spf_rhead_get_mode(void);
+/* arith (see SPF_ARITH_*): with SPF_ARITH_SPLIT spf_rhead_backward leaves g_b6 / g_b0 / g_b2 untouched — they are the column
+ * sums of g_agg / G1 / G2 and come from spf_wgrad's dbias output; with SPF_ARITH_F32 spf_rhead_backward accumulates them. */
 
 int64_t spf_rhead_packed_floats(void);
 int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const float* b0, const float* w2, const float* b2,
@@ -222,7 +224,7 @@ int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const floa
  * act1, act2 [T,256], masks [T/64,2,512]. */
 int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* point_slot, const int32_t* n_points,
                       int32_t max_points, int32_t SR, const float* packed, float* colors, float* agg, float* direnc,
-                      float* act1, float* act2, uint32_t* masks, void* stream);
+                      float* act1, float* act2, uint32_t* masks, int32_t arith, void* stream);
 
 /* Given g_colors[row,3]: writes G1, G2 [T,256] (pre-activation gradients of R.0 / R.2; dW_l = G_l^T act_{l-1}: spf_wgrad),
  * g_agg [T,256] = dL/d agg (F_color.6's weight gradient is g_agg^T agg3) and g_agg3 [T,256] = g_agg W6 (input of
@@ -232,7 +234,7 @@ int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* p
 int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t* point_slot, const int32_t* n_points,
                        int32_t max_points, const float* packed, const float* act2, const uint32_t* masks,
                        float* G1, float* G2, float* g_agg, float* g_agg3, float* g_b6, float* g_b0, float* g_b2,
-                       float* g_w4, float* g_b4, void* stream);
+                       float* g_w4, float* g_b4, int32_t arith, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * VolSDF error-bounded sampler — replaces UniformSampler.get_z_vals (spurfies/model/ray_sampler.py:33-59),
@@ -299,16 +301,12 @@ int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float
  * rows = min(*n_rows, max_rows) read on the device (NULL: max_rows).  C in {256 | multiple of 4 <= 128 | <= 32};
  * workspace: spf_wgrad_workspace_floats(C) floats (per-workgroup partial slabs, summed in a fixed order). */
 int64_t spf_wgrad_workspace_floats(int32_t C);
-/* Arithmetic of spf_wgrad for C > 32 (process-wide).  0 (default): every fp32 operand is split into three bf16 pieces
- * (x = p1 + p2 + p3 exactly to 24 bits) and the six products with i + j <= 4 run on v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation — each piece product is exact, the dropped terms are below 2^-24 of the product, so the result differs from the
- * fp32-MFMA GEMM only by summation order, at 2.7x the matrix rate.  1: v_mfma_f32_32x32x2_f32 everywhere (verification). */
-int spf_wgrad_set_mode(int32_t mode);
+/* arith (see SPF_ARITH_*) applies for C > 32; narrower operands always take the fp32-MFMA kernel. */
 
 /* dbias (may be NULL): float[256], dbias[o] += sum_rows G[row][o] — the bias gradient of the same layer, taken on the way
  * (free in the default arithmetic; a separate pass over G otherwise). */
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows,
-              float* dW, int32_t ldw, float* dbias, float* workspace, void* stream);
+              float* dW, int32_t ldw, float* dbias, float* workspace, int32_t arith, void* stream);
 
 /* Up to three C = 256 weight-gradient GEMMs over the SAME rows (n_rows / max_rows) in one pair of launches: dW_q += G_q^T A_q,
  * dbias_q += column sums of G_q (may be NULL).  The head stage's three GEMMs have K = valid points: launched one after the other
@@ -323,7 +321,7 @@ struct spf_wgrad_problem {
     float* dbias;
 };
 int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_problems, const int32_t* n_rows, int32_t max_rows,
-                      float* workspace, void* stream);
+                      float* workspace, int32_t arith, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Latent tables

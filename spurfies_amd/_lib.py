@@ -47,24 +47,20 @@ SIGNATURES = {
     "spf_grid_get_info": (C.c_int, [_P, C.POINTER(GridInfo)]),
     "spf_grid_query": (C.c_int, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
     "spf_compact_points": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P]),
-    "spf_geo_set_mode": (C.c_int, [_I]),
+    "spf_voxel_cells": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_float * 3), _F, _P, _P]),
     "spf_geo_packed_floats": (C.c_int64, []),
     "spf_geo_pack": (C.c_int, [_P] * 14),
     "spf_build_pairs": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "spf_geo_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
+    "spf_geo_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P]),
     "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
-    "spf_color_set_mode": (C.c_int, [_I]),
-    "spf_color_get_mode": (C.c_int, []),
     "spf_color_packed_floats": (C.c_int64, []),
     "spf_color_pack": (C.c_int, [_P] * 8),
-    "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "spf_color_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "spf_rhead_set_mode": (C.c_int, [_I]),
-    "spf_rhead_get_mode": (C.c_int, []),
+    "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "spf_color_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_rhead_packed_floats": (C.c_int64, []),
     "spf_rhead_pack": (C.c_int, [_P] * 10),
-    "spf_rhead_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "spf_rhead_backward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_rhead_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "spf_rhead_backward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_sampler_uniform": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
     "spf_sampler_iter": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _I, _P, _P, _P, _P, _P]),
     "spf_sampler_finish": (C.c_int, [_P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _I, _P, _P, _P]),
@@ -72,9 +68,8 @@ SIGNATURES = {
     "spf_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "spf_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "spf_wgrad_workspace_floats": (C.c_int64, [_I]),
-    "spf_wgrad_set_mode": (C.c_int, [_I]),
-    "spf_wgrad": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
-    "spf_wgrad_batched": (C.c_int, [C.POINTER(WgradProblem), _I, _P, _I, _P, _P]),
+    "spf_wgrad": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P]),
+    "spf_wgrad_batched": (C.c_int, [C.POINTER(WgradProblem), _I, _P, _I, _P, _I, _P]),
     "spf_scatter_add_rows": (C.c_int, [_P, _P, C.c_int64, _I, _P, _P]),
     "spf_tv_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),

@@ -470,7 +470,7 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
 
 // ==============================================================================================================================
 // The same two kernels on the bf16 matrix pipe with fp32-EXACT products from three bf16 pieces per operand (the default;
-// spf_color_set_mode(1) selects the fp32-MFMA kernels above).  Engine and arithmetic argument: mlp_tile_x3.h / geo_mlp.hip.
+// arith = SPF_ARITH_F32 selects the fp32-MFMA kernels above).  Engine and arithmetic argument: mlp_tile_x3.h / geo_mlp.hip.
 //   * layers 0 and 2 run as transposed products (a lane owns 4 consecutive features of one row, the epilogue rewrites the bf16
 //     planes with 8-byte stores); layer 4 — whose output only feeds the RBF-weighted mean — runs non-transposed, so that a lane
 //     owns a column strip and takes the segmented weighted sum straight from its accumulators, as the fp32 kernel does;
@@ -1009,16 +1009,6 @@ SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_color)
 
 extern "C" {
 
-static int g_color_mode = 0;      // 0: bf16-piece products (fp32-exact), 1: fp32 MFMA
-
-int spf_color_set_mode(int32_t mode) {
-    if (mode != 0 && mode != 1) return spf::fail(SPF_EINVAL, "spf_color_set_mode: 0 (split-bf16 products) or 1 (fp32 MFMA), got %d", mode);
-    g_color_mode = mode;
-    return SPF_OK;
-}
-
-int spf_color_get_mode(void) { return g_color_mode; }
-
 int64_t spf_color_packed_floats(void) { return C_PACKED_TOTAL; }
 
 int spf_color_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
@@ -1034,7 +1024,8 @@ int spf_color_pack(const float* w0, const float* b0, const float* w2, const floa
 int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* pair_off,
                       const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* pts,
                       const float* feat_color, const float* packed, float* agg3, float* act0, float* act1, float* act2, uint32_t* masks,
-                      void* stream) {
+                      int32_t arith, void* stream) {
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_color_forward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_forward: bad sizes");
     if (max_pairs == 0) return SPF_OK;
     if (!x || !nbr || !wn || !pair_off || !pair_point || !pts || !feat_color || !packed || !agg3)
@@ -1043,7 +1034,7 @@ int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const
     if (store && (!act1 || !act2 || !masks)) return spf::fail(SPF_EINVAL, "spf_color_forward: training buffers must be given together");
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
-    if (g_color_mode == 0) {
+    if (arith == SPF_ARITH_SPLIT) {
         const int b1 = tiles < 256 ? tiles : 256;   // one workgroup per CU (bf16 planes: 101 KB of LDS)
         if (store)
             color_forward_x3_kernel<true><<<b1, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts,
@@ -1067,14 +1058,15 @@ int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const
 int spf_color_backward(const float* g_agg3, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* pair_off,
                        const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* packed,
                        const uint32_t* masks, float* G1, float* G2, float* G3, float* g_b0, float* g_b2, float* g_b4, float* g_feat_color,
-                       void* stream) {
+                       int32_t arith, void* stream) {
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_color_backward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_backward: bad sizes");
     if (max_pairs == 0) return SPF_OK;
     if (!g_agg3 || !nbr || !wn || !pair_off || !pair_point || !packed || !masks || !G1 || !G2 || !G3 || !g_b0 || !g_b2 || !g_b4 || !g_feat_color)
         return spf::fail(SPF_EINVAL, "spf_color_backward: null pointer");
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
-    if (g_color_mode == 0) {    // bias gradients come from spf_wgrad (dbias) in this mode: g_b0 / g_b2 / g_b4 are not touched
+    if (arith == SPF_ARITH_SPLIT) {    // bias gradients come from spf_wgrad (dbias) in this mode: g_b0 / g_b2 / g_b4 are not touched
         const int b1 = tiles < 256 ? tiles : 256;
         color_backward_x3_kernel<<<b1, 256, 0, (hipStream_t)stream>>>(g_agg3, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
                                                                       masks, G1, G2, G3, g_feat_color);

@@ -421,7 +421,7 @@ __global__ void geo_pack_kernel(PackArgs a, float* __restrict__ out) {
 
 
 // ==============================================================================================================================
-// Same path with fp32-EXACT products from three bf16 pieces per operand (the default; spf_geo_set_mode(1) selects the kernel above).
+// Same path with fp32-EXACT products from three bf16 pieces per operand (the default; arith = SPF_ARITH_F32 selects the kernel above).
 //   x = p1 + p2 + p3, p1 = bf16(x), p2 = bf16(x - p1), p3 = bf16(x - p1 - p2): both differences are exact in fp32 and 3 x 8
 //   mantissa bits cover fp32's 24; a product of two fp32 numbers is sum_{i,j} a_i b_j, every piece product is exact in the
 //   MFMA's fp32 accumulation and the three with i + j >= 5 are below 2^-24 of the product, so the six with i + j <= 4 give the
@@ -796,14 +796,6 @@ SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_geo)
 
 extern "C" {
 
-static int g_geo_mode = 0;      // 0: bf16-piece products (fp32-exact), 1: fp32 MFMA
-
-int spf_geo_set_mode(int32_t mode) {
-    if (mode != 0 && mode != 1) return spf::fail(SPF_EINVAL, "spf_geo_set_mode: 0 (split-bf16 products) or 1 (fp32 MFMA), got %d", mode);
-    g_geo_mode = mode;
-    return SPF_OK;
-}
-
 int64_t spf_geo_packed_floats(void) { return PACKED_TOTAL; }
 
 int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
@@ -821,7 +813,8 @@ int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float*
 int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slot, const int32_t* pair_off, const int32_t* pair_point,
                     const int32_t* n_points, const int32_t* n_pairs, int32_t max_points, int32_t max_pairs, int32_t k, const float* pts,
                     const float* feat_geo, const float* packed, float rbf, float* sdf, float* grad, float* wn, float* jac,
-                    float* pair_tmp, void* stream) {
+                    float* pair_tmp, int32_t arith, void* stream) {
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_geo_forward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (max_points < 0 || max_pairs < 0 || k < 1 || k > SPF_KMAX)
         return spf::fail(SPF_EINVAL, "spf_geo_forward: bad sizes (max_points=%d max_pairs=%d k=%d)", max_points, max_pairs, k);
     if (max_points == 0 || max_pairs == 0) return SPF_OK;
@@ -832,7 +825,7 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
     const int tiles = spf::div_up(max_pairs, 64);
     hipStream_t s = (hipStream_t)stream;
     const int blocks = tiles < 512 ? tiles : 512;  // 2 workgroups per CU x 256 CUs, tiles are strided over them
-    if (g_geo_mode == 0) {
+    if (arith == SPF_ARITH_SPLIT) {
         const int b1 = tiles < 256 ? tiles : 256;   // one workgroup per CU (the bf16 planes take 101 KB of LDS)
         if (grad)
             geo_pairs_x3_kernel<true><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,

@@ -650,6 +650,25 @@ int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t
     return SPF_OK;
 }
 
+// load-time voxel thinning (spurfies/model/utils.py:21-27): cell = floor((p - space_min) / voxel) in float32 with IEEE division
+__global__ void voxel_cells_kernel(const float* __restrict__ xyz, long long n, float mx, float my, float mz, float v, int32_t* __restrict__ cells) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cells[3 * i + 0] = (int32_t)floorf((xyz[3 * i + 0] - mx) / v);
+    cells[3 * i + 1] = (int32_t)floorf((xyz[3 * i + 1] - my) / v);
+    cells[3 * i + 2] = (int32_t)floorf((xyz[3 * i + 2] - mz) / v);
+}
+
+int spf_voxel_cells(const float* xyz, int64_t n, const float* space_min, float voxel, int32_t* cells, void* stream_) {
+    if (n < 0 || !(voxel > 0.f) || !space_min) return spf::fail(SPF_EINVAL, "spf_voxel_cells: need n >= 0, voxel > 0, space_min");
+    if (n == 0) return SPF_OK;
+    if (!xyz || !cells) return spf::fail(SPF_EINVAL, "spf_voxel_cells: null buffer");
+    voxel_cells_kernel<<<spf::div_up((long long)n, 256), 256, 0, (hipStream_t)stream_>>>(xyz, (long long)n, space_min[0], space_min[1], space_min[2], voxel,
+                                                                                       cells);
+    SPF_LAUNCH_CHECK("voxel_cells_kernel");
+    return SPF_OK;
+}
+
 int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t* n_points, int32_t max_points, int32_t k,
                     int32_t* pair_off, int32_t* pair_point, int32_t* n_pairs, int32_t* scratch, void* stream_) {
     if (max_points < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_build_pairs: bad sizes");

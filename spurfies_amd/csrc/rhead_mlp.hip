@@ -388,7 +388,7 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
 
 // ==============================================================================================================================
 // The same two kernels on the bf16 matrix pipe with fp32-exact products from three bf16 pieces per operand (the default;
-// spf_rhead_set_mode(1) selects the fp32-MFMA kernels above).  Engine: mlp_tile_x3.h; plane row stride 296 bf16 so that the first
+// arith = SPF_ARITH_F32 selects the fp32-MFMA kernels above).  Engine: mlp_tile_x3.h; plane row stride 296 bf16 so that the first
 // head layer's 288-wide input ([agg 256 | dir-enc 21 | 0]) is one GEMM.  One workgroup per CU (113.7 KB of planes).
 // Bias gradients of the three 256-wide layers are column sums of g_agg / G1 / G2 and come from spf_wgrad (dbias) in this mode.
 // ==============================================================================================================================
@@ -774,16 +774,6 @@ __global__ void rhead_pack_kernel(RPackArgs a, float* __restrict__ out) {
 
 extern "C" {
 
-static int g_rhead_mode = 0;      // 0: bf16-piece products (fp32-exact), 1: fp32 MFMA
-
-int spf_rhead_set_mode(int32_t mode) {
-    if (mode != 0 && mode != 1) return spf::fail(SPF_EINVAL, "spf_rhead_set_mode: 0 (split-bf16 products) or 1 (fp32 MFMA), got %d", mode);
-    g_rhead_mode = mode;
-    return SPF_OK;
-}
-
-int spf_rhead_get_mode(void) { return g_rhead_mode; }
-
 int64_t spf_rhead_packed_floats(void) { return R_PACKED_TOTAL; }
 
 int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const float* b0, const float* w2, const float* b2, const float* w4,
@@ -798,7 +788,8 @@ int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const floa
 
 int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
                       int32_t SR, const float* packed, float* colors, float* agg, float* direnc, float* act1, float* act2, uint32_t* masks,
-                      void* stream) {
+                      int32_t arith, void* stream) {
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_rhead_forward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (max_points < 0 || SR < 1) return spf::fail(SPF_EINVAL, "spf_rhead_forward: bad sizes");
     if (max_points == 0) return SPF_OK;
     if (!agg3 || !ray_dirs || !packed || !colors) return spf::fail(SPF_EINVAL, "spf_rhead_forward: null pointer");
@@ -806,7 +797,7 @@ int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* p
     if (store && (!agg || !act1 || !act2 || !masks)) return spf::fail(SPF_EINVAL, "spf_rhead_forward: training buffers must be given together");
     const int tiles = spf::div_up(max_points, 64);
     const int blocks = tiles < 512 ? tiles : 512;
-    if (g_rhead_mode == 0) {
+    if (arith == SPF_ARITH_SPLIT) {
         const int b1 = tiles < 256 ? tiles : 256;       // one workgroup per CU
         if (store)
             rhead_forward_x3_kernel<true><<<b1, 256, 0, (hipStream_t)stream>>>(agg3, ray_dirs, point_slot, n_points, max_points, SR, packed, colors, agg,
@@ -829,14 +820,15 @@ int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* p
 
 int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
                        const float* packed, const float* act2, const uint32_t* masks, float* G1, float* G2, float* g_agg, float* g_agg3,
-                       float* g_b6, float* g_b0, float* g_b2, float* g_w4, float* g_b4, void* stream) {
+                       float* g_b6, float* g_b0, float* g_b2, float* g_w4, float* g_b4, int32_t arith, void* stream) {
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_rhead_backward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (max_points < 0) return spf::fail(SPF_EINVAL, "spf_rhead_backward: bad sizes");
     if (max_points == 0) return SPF_OK;
     if (!g_colors || !colors || !packed || !act2 || !masks || !G1 || !G2 || !g_agg || !g_agg3 || !g_b6 || !g_b0 || !g_b2 || !g_w4 || !g_b4)
         return spf::fail(SPF_EINVAL, "spf_rhead_backward: null pointer");
     const int tiles = spf::div_up(max_points, 64);
     const int blocks = tiles < 512 ? tiles : 512;
-    if (g_rhead_mode == 0) {    // g_b6 / g_b0 / g_b2 are not touched in this mode: spf_wgrad's dbias output provides them
+    if (arith == SPF_ARITH_SPLIT) {    // g_b6 / g_b0 / g_b2 are not touched in this mode: spf_wgrad's dbias output provides them
         const int b1 = tiles < 256 ? tiles : 256;
         rhead_backward_x3_kernel<<<b1, 256, 0, (hipStream_t)stream>>>(g_colors, colors, point_slot, n_points, max_points, packed, act2, masks, G1, G2,
                                                                       g_agg, g_agg3, g_w4, g_b4);

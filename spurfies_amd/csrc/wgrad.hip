@@ -9,7 +9,7 @@
 // from HBM exactly once through an LDS ring filled by LDS-DMA and leaves its partial in a slab; a second small kernel sums the
 // slabs (16 slices, float atomics) into dW.  Kernels in this file, newest first:
 //   wgrad_split8_kernel   default for C > 32: fp32-exact products from three bf16 pieces per operand on the bf16 matrix pipe
-//   wgrad_dma_kernel      fp32 MFMA, LDS-DMA staged (spf_wgrad_set_mode(1); the verification twin of the above)
+//   wgrad_dma_kernel      fp32 MFMA, LDS-DMA staged (arith = SPF_ARITH_F32; the verification twin of the above)
 //   wgrad_lds_kernel      fp32 MFMA, register-staged (C in (128, 256) that is not 256)
 //   wgrad_narrow_kernel   fp32 MFMA, direct loads (C <= 32)
 #include "mlp_tile.h"
@@ -519,19 +519,12 @@ __global__ void colsum256_kernel(const float* __restrict__ G, const int32_t* __r
 extern "C" {
 
 static constexpr int RSPLIT = 16;
-static int g_wgrad_mode = 0;      // 0: bf16-piece products where available (fp32-exact), 1: fp32 MFMA everywhere
-
-int spf_wgrad_set_mode(int32_t mode) {
-    if (mode != 0 && mode != 1) return spf::fail(SPF_EINVAL, "spf_wgrad_set_mode: 0 (split-bf16 products) or 1 (fp32 MFMA), got %d", mode);
-    g_wgrad_mode = mode;
-    return SPF_OK;
-}
-
 // slabs: 256 workgroups x [256 x 256] (C > 128), 512 x [256 x 128] (two workgroups per CU), 256 x [256 x 32]
 int64_t spf_wgrad_workspace_floats(int32_t C) { return (int64_t)256 * 256 * (C > 128 ? 256 : (C > 32 ? 256 : 32)); }
 
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows, float* dW, int32_t ldw,
-              float* dbias, float* workspace, void* stream) {
+              float* dbias, float* workspace, int32_t arith, void* stream) {
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_wgrad: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (max_rows < 0 || C < 1 || C > 256 || lda < C || ldw < C) return spf::fail(SPF_EINVAL, "spf_wgrad: need 1 <= C <= 256, lda >= C, ldw >= C");
     if (max_rows == 0) return SPF_OK;
     if (!G || !A || !dW || !workspace) return spf::fail(SPF_EINVAL, "spf_wgrad: null pointer");
@@ -542,12 +535,12 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     const int cap = NT == 4 ? 512 : 256;   // NT = 4: half the accumulators, two workgroups per CU; else one per CU, one wave per SIMD
     if (blocks > cap) blocks = cap;
     const int per = 4 * 2 * NT * 16 * 64;
-    if (g_wgrad_mode == 0 && NT == 8 && C == 256) {
+    if (arith == SPF_ARITH_SPLIT && NT == 8 && C == 256) {
         const int b8 = blocks > 256 ? 256 : blocks;      // one 8-wave workgroup per CU
         wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         dbias = nullptr;
         wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw);
-    } else if (g_wgrad_mode == 0 && NT == 4) {
+    } else if (arith == SPF_ARITH_SPLIT && NT == 4) {
         const int b8 = blocks > 256 ? 256 : blocks;
         wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         dbias = nullptr;
@@ -570,7 +563,8 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
 
 
 int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_problems, const int32_t* n_rows, int32_t max_rows, float* workspace,
-                      void* stream) {
+                      int32_t arith, void* stream) {
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (!problems || n_problems < 1 || n_problems > 3 || max_rows < 0) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: 1 to 3 problems");
     if (max_rows == 0) return SPF_OK;
     if (!workspace) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: null workspace");
@@ -580,10 +574,10 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
         if (!p.G || !p.A || !p.dW || p.lda < 256 || (p.lda % 4) || p.ldw < 256)
             return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: need G, A, dW, lda >= 256 (multiple of 4), ldw >= 256", q);
     }
-    if (g_wgrad_mode != 0 || n_problems == 1) {      // fp32-MFMA verification mode / nothing to batch: the single-problem path
+    if (arith != SPF_ARITH_SPLIT || n_problems == 1) {      // fp32-MFMA verification mode / nothing to batch: the single-problem path
         for (int q = 0; q < n_problems; ++q) {
             const spf_wgrad_problem& p = problems[q];
-            const int rc = spf_wgrad(p.G, p.A, p.lda, 256, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, stream);
+            const int rc = spf_wgrad(p.G, p.A, p.lda, 256, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, arith, stream);
             if (rc != SPF_OK) return rc;
         }
         return SPF_OK;

@@ -131,11 +131,25 @@ def read_ply_vertices(path):
 def construct_vox_points_closest(xyz, vox_res):
     """utils.py:6-36: per occupied voxel of a vox_res^3 grid over the 1.05x bounding cube, the index
     of the point closest to the voxel's centroid."""
-    xyz_min, xyz_max = xyz.min(dim=-2)[0], xyz.max(dim=-2)[0]
+    # the three scalars of the grid are formed on the host in float32, op for op as torch-CPU runs the reference's lines 10-21
+    # (on a device `edge / vox_res` with a Python-scalar divisor becomes a multiplication by the reciprocal: one ulp off)
+    xyz_min, xyz_max = xyz.min(dim=-2)[0].cpu(), xyz.max(dim=-2)[0].cpu()
     edge = torch.max(xyz_max - xyz_min) * 1.05
     space_min = (xyz_max + xyz_min) / 2 - edge / 2
     vsz = edge / vox_res
-    cell = torch.floor((xyz - space_min[None]) / vsz).to(torch.int32)
+    if xyz.is_cuda:         # spf_voxel_cells: the same float32 subtraction / IEEE division / floor the CPU performs
+        import ctypes as C
+
+        from .. import _lib
+
+        xyz_c = xyz.detach().float().contiguous()
+        cell = torch.empty((xyz_c.shape[0], 3), dtype=torch.int32, device=xyz.device)
+        mn = (C.c_float * 3)(*[float(v) for v in space_min.float().tolist()])
+        with torch.cuda.device(xyz.device):
+            _lib.check(_lib.lib().spf_voxel_cells(_lib.ptr(xyz_c), xyz_c.shape[0], C.byref(mn), float(vsz.float().item()), _lib.ptr(cell),
+                                                  _lib.stream_ptr()), "spf_voxel_cells")
+    else:
+        cell = torch.floor((xyz - space_min[None]) / vsz).to(torch.int32)
     grid_idx, inv = torch.unique(cell, dim=0, return_inverse=True)
     m = grid_idx.shape[0]
     cnt = torch.zeros(m, device=xyz.device).index_add_(0, inv, torch.ones(len(xyz), device=xyz.device))

@@ -89,9 +89,15 @@ class PairList:
         return int(c[0]), int(c[1])
 
 
+# Arithmetic of the MLP / weight-gradient kernels (include/spurfies_hip.h: SPF_ARITH_*), chosen per call; this table is host-side
+# state of the Python layer only — the C ABI itself keeps none.  'split' (default): fp32-exact products from three bf16 pieces per
+# operand on the bf16 matrix pipe; 'f32': fp32 MFMA (the verification twin).
+_ARITH = {"geo": 0, "color": 0, "rhead": 0, "wgrad": 0}
+_ARITH_NAMES = {"split": 0, "f32": 1}
+
+
 def set_geo_mode(mode: str):
-    """'split' (default): fp32-exact products from three bf16 pieces per operand on the bf16 matrix pipe; 'f32': fp32 MFMA."""
-    _lib.check(_lib.lib().spf_geo_set_mode({"split": 0, "f32": 1}[mode]), "spf_geo_set_mode")
+    _ARITH["geo"] = _ARITH_NAMES[mode]
 
 
 def pack_geometry_weights(state: dict) -> torch.Tensor:
@@ -125,7 +131,7 @@ def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_ou
         _lib.check(_lib.lib().spf_geo_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off), _lib.ptr(pl.pair_point),
                                               _lib.ptr(pl.n_points), _lib.ptr(pl.n_pairs), pl.max_points, pl.max_pairs, pl.k, _lib.ptr(pts),
                                               _lib.ptr(feat_geo), _lib.ptr(packed), float(rbf), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(wn),
-                                              _lib.ptr(jac), _lib.ptr(tmp), _lib.stream_ptr()), "spf_geo_forward")
+                                              _lib.ptr(jac), _lib.ptr(tmp), _ARITH["geo"], _lib.stream_ptr()), "spf_geo_forward")
     if _prof is not None:
         e1.record()
         _prof.append((e0, e1, pl.n_pairs, rows, bool(with_grad)))
@@ -295,7 +301,8 @@ class ColorAgg(_GradModeFunction):
             _lib.check(_lib.lib().spf_color_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                     _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), NP, pl.k, _lib.ptr(pts),
                                                     _lib.ptr(feat_col.detach()), _lib.ptr(packed), _lib.ptr(agg3),
-                                                    *[_lib.ptr(a) for a in bufs], _lib.stream_ptr()), "spf_color_forward")
+                                                    *[_lib.ptr(a) for a in bufs], _ARITH["color"], _lib.stream_ptr()), "spf_color_forward")
+        ctx.arith = _ARITH["color"]
         if train:
             ctx.save_for_backward(wn, packed, *bufs)
             ctx.pl, ctx.NP, ctx.n_table = pl, NP, feat_col.shape[0]
@@ -322,9 +329,9 @@ class ColorAgg(_GradModeFunction):
             _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg3), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                      _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), ctx.NP, pl.k, _lib.ptr(packed), _lib.ptr(masks),
                                                      _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_b4),
-                                                     _lib.ptr(g_feat), _lib.stream_ptr()), "spf_color_backward")
+                                                     _lib.ptr(g_feat), ctx.arith, _lib.stream_ptr()), "spf_color_backward")
         # split-product kernels (the default) leave the bias gradients to the weight-gradient GEMM (column sums of G)
-        kb = (lambda b: b) if color_mode() == "split" else (lambda b: None)
+        kb = (lambda b: b) if ctx.arith == 0 else (lambda b: None)
         if sk is not None:
             # layer 0's [256,104] comes in the kernels' internal column order: one index_add_ into the reference order
             sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0))[:, :103])
@@ -488,8 +495,9 @@ class RHead(_GradModeFunction):
         agg3_c = agg3.detach().contiguous()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_rhead_forward(_lib.ptr(agg3_c), _lib.ptr(ray_dirs), _lib.ptr(point_slot), _lib.ptr(n_points), P, int(SR),
-                                                    _lib.ptr(packed), _lib.ptr(colors), *[_lib.ptr(b) for b in bufs], _lib.stream_ptr()),
-                       "spf_rhead_forward")
+                                                    _lib.ptr(packed), _lib.ptr(colors), *[_lib.ptr(b) for b in bufs], _ARITH["rhead"],
+                                                    _lib.stream_ptr()), "spf_rhead_forward")
+        ctx.arith = _ARITH["rhead"]
         if train:
             ctx.save_for_backward(agg3_c, colors, point_slot, n_points, packed, *bufs)
             sinks = [_sink(t) for t in (w6, b6, w0, b0, w2, b2, w4, b4)]
@@ -514,9 +522,9 @@ class RHead(_GradModeFunction):
             _lib.check(_lib.lib().spf_rhead_backward(_lib.ptr(g_colors), _lib.ptr(colors), _lib.ptr(point_slot), _lib.ptr(n_points), P, _lib.ptr(packed),
                                                      _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_agg3),
                                                      _lib.ptr(g_b6), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_w4), _lib.ptr(g_b4),
-                                                     _lib.stream_ptr()), "spf_rhead_backward")
+                                                     ctx.arith, _lib.stream_ptr()), "spf_rhead_backward")
         # split-product kernels (the default) leave the 256-wide layers' bias gradients to the weight-gradient GEMMs (column sums)
-        split = rhead_mode() == "split"
+        split = ctx.arith == 0
         kb = (lambda b: b) if split else (lambda b: None)
         if sk is not None:
             # F_color.6 (K = points, not pairs), R.0's agg block (reference column order [dir-enc | agg]) and R.2: side by side
@@ -535,27 +543,26 @@ _wgrad_ws = {}
 
 
 def set_color_mode(mode: str):
-    """'split' (default) or 'f32': arithmetic of the colour trunk kernels (spf_color_set_mode).  Switch only between steps: a
-    backward must run in the mode of its forward."""
-    _lib.check(_lib.lib().spf_color_set_mode({"split": 0, "f32": 1}[mode]), "spf_color_set_mode")
+    """'split' (default) or 'f32' for the colour trunk kernels; a backward runs in the arithmetic its forward recorded."""
+    _ARITH["color"] = _ARITH_NAMES[mode]
 
 
 def color_mode() -> str:
-    return "split" if _lib.lib().spf_color_get_mode() == 0 else "f32"
+    return "split" if _ARITH["color"] == 0 else "f32"
 
 
 def set_rhead_mode(mode: str):
-    """'split' (default) or 'f32': arithmetic of the per-point head kernels (spf_rhead_set_mode); switch only between steps."""
-    _lib.check(_lib.lib().spf_rhead_set_mode({"split": 0, "f32": 1}[mode]), "spf_rhead_set_mode")
+    """'split' (default) or 'f32' for the per-point head kernels."""
+    _ARITH["rhead"] = _ARITH_NAMES[mode]
 
 
 def rhead_mode() -> str:
-    return "split" if _lib.lib().spf_rhead_get_mode() == 0 else "f32"
+    return "split" if _ARITH["rhead"] == 0 else "f32"
 
 
 def set_wgrad_mode(mode: str):
-    """'split' (default): fp32-exact products from three bf16 pieces per operand on the bf16 matrix pipe; 'f32': fp32 MFMA."""
-    _lib.check(_lib.lib().spf_wgrad_set_mode({"split": 0, "f32": 1}[mode]), "spf_wgrad_set_mode")
+    """'split' (default) or 'f32' for the weight-gradient GEMMs."""
+    _ARITH["wgrad"] = _ARITH_NAMES[mode]
 
 
 
@@ -573,7 +580,7 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None):
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_wgrad(_lib.ptr(G), _lib.ptr(A), A.stride(0), C, _lib.ptr(n_rows), min(G.shape[0], A.shape[0]), _lib.ptr(out), ldw, _lib.ptr(dbias),
-                                        _lib.ptr(_wgrad_ws[key]), _lib.stream_ptr()), "spf_wgrad")
+                                        _lib.ptr(_wgrad_ws[key]), _ARITH["wgrad"], _lib.stream_ptr()), "spf_wgrad")
     return out
 
 
@@ -595,7 +602,8 @@ def wgrad_batched(problems, n_rows):
     if key not in _wgrad_ws:
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().spf_wgrad_batched(arr, len(problems), _lib.ptr(n_rows), max_rows, _lib.ptr(_wgrad_ws[key]), _lib.stream_ptr()),
+        _lib.check(_lib.lib().spf_wgrad_batched(arr, len(problems), _lib.ptr(n_rows), max_rows, _lib.ptr(_wgrad_ws[key]), _ARITH["wgrad"],
+                                                    _lib.stream_ptr()),
                    "spf_wgrad_batched")
 
 

@@ -31,7 +31,8 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     missing = [n for n in decl if not hasattr(lib, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert set(_lib.SIGNATURES) == decl, (set(_lib.SIGNATURES) ^ decl)
-    assert lib.spf_abi_version() == 1
+    assert lib.spf_abi_version() == 2
+    assert not [n for n in decl if n.endswith("_set_mode") or n.endswith("_get_mode")], "no process-global modes in the ABI"
     assert lib.spf_geo_packed_floats() > 0 and lib.spf_color_packed_floats() > 0
 
 
@@ -49,7 +50,11 @@ def test_argument_validation_without_gpu(lib):
     cfg.kernel_size[:] = (3, 3, 3)
     assert lib.spf_grid_create(ctypes.byref(cfg), ctypes.byref(h)) == 0 and h.value
     assert lib.spf_grid_query(h, None, 4, 3, 9, 2.0, 2, None, None, None, None, None, None) == -22   # k > SPF_KMAX
-    assert lib.spf_geo_forward(None, None, None, None, None, None, None, 8, 64, 9, None, None, None, 45.0, None, None, None, None, None, None) == -22
+    assert lib.spf_geo_forward(None, None, None, None, None, None, None, 8, 64, 9, None, None, None, 45.0, None, None, None, None, None, 0, None) == -22
+    # the arithmetic is a per-call argument (no process-wide mode in the library): unknown values are refused
+    assert lib.spf_geo_forward(None, None, None, None, None, None, None, 8, 64, 8, None, None, None, 45.0, None, None, None, None, None, 7, None) == -22
+    assert b"arith" in lib.spf_last_error()
+    assert lib.spf_wgrad(None, None, 256, 256, None, 16, None, 256, None, None, 2, None) == -22 and b"arith" in lib.spf_last_error()
     assert lib.spf_render_forward(None, None, None, None, None, None, 4, 1000, None, None, None, None, None, None) == -22
     lib.spf_grid_destroy(h)
 

@@ -1,4 +1,4 @@
-"""bf16-piece geometry kernel (spf_geo_set_mode(1)) against the fp32-MFMA kernel: outputs and speed on main-pass-shaped input."""
+"""bf16-piece geometry kernel (ops.set_geo_mode('split')) against the fp32-MFMA kernel: outputs and speed on main-pass-shaped input."""
 import sys
 import numpy as np
 import torch
