@@ -301,12 +301,18 @@ int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float
  * rows = min(*n_rows, max_rows) read on the device (NULL: max_rows).  C in {256 | multiple of 4 <= 128 | <= 32};
  * workspace: spf_wgrad_workspace_floats(C) floats (per-workgroup partial slabs, summed in a fixed order). */
 int64_t spf_wgrad_workspace_floats(int32_t C);
-/* arith (see SPF_ARITH_*) applies for C > 32; narrower operands always take the fp32-MFMA kernel. */
+/* arith (see SPF_ARITH_*) applies for C > 32; narrower operands always take the fp32-MFMA kernel.
+ * layout: 0 = both operands are row-major [rows, .]; SPF_WGRAD_G_TILES / SPF_WGRAD_A_TILES (or-ed): that operand is stored as
+ * K-MAJOR TILES of 64 rows x 256 features, element (tile t, feature f, row r) at ((256 t + f) 64 + r) — what spf_color_forward
+ * (act1, act2) and spf_color_backward (G2, G1) write with SPF_ARITH_SPLIT.  Tiled operands need SPF_ARITH_SPLIT, C > 32,
+ * max_rows % 64 == 0 (whole tiles allocated) and, for A, C = 256; lda is ignored for a tiled A. */
+#define SPF_WGRAD_G_TILES 1
+#define SPF_WGRAD_A_TILES 2
 
 /* dbias (may be NULL): float[256], dbias[o] += sum_rows G[row][o] — the bias gradient of the same layer, taken on the way
  * (free in the default arithmetic; a separate pass over G otherwise). */
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows,
-              float* dW, int32_t ldw, float* dbias, float* workspace, int32_t arith, void* stream);
+              float* dW, int32_t ldw, float* dbias, float* workspace, int32_t layout, int32_t arith, void* stream);
 
 /* Up to three C = 256 weight-gradient GEMMs over the SAME rows (n_rows / max_rows) in one pair of launches: dW_q += G_q^T A_q,
  * dbias_q += column sums of G_q (may be NULL).  The head stage's three GEMMs have K = valid points: launched one after the other

@@ -478,8 +478,10 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
 //     transposed epilogues share the lane <-> element map and push / pop the words in the same order); layer 4 ROW-major
 //     ([row][8 words], bit = feature & 31: a row word per accumulator register from the wave ballot, read back by the
 //     backward's first stage one row quarter per thread);
-//   * the layer inputs / pre-activation gradients the weight-gradient GEMM reads are written as fp32 rows rebuilt exactly from
-//     the planes (p1 + p2 + p3), coalesced; bias gradients come from the weight-gradient GEMM (column sums of G, spf_wgrad).
+//   * what the weight-gradient GEMM reads: act1 / act2 (forward) and G2 / G1 (backward) leave the transposed epilogues straight
+//     from the registers as K-major tiles [256 features][64 rows] (SPF_WGRAD_*_TILES; exactly the values the planes hold, since
+//     p1 + p2 + p3 reproduces the fp32 value); act0 and G3 — produced by the row-per-thread gather stages — are written as fp32 rows
+//     rebuilt from the planes; bias gradients come from the weight-gradient GEMM (column sums of G, spf_wgrad).
 // ==============================================================================================================================
 constexpr int CX_T1 = 7;                          // layer 0: K = 104 -> 112
 constexpr int CX_TH = 16;
@@ -560,8 +562,12 @@ __device__ __forceinline__ CxBias cx_load_bias(gfp bias, int wave, int lane) {
 // transposed forward epilogue: a = lrelu(acc + b) -> planes; the lane's sign bits are pushed into two words (n = 0, 1; order
 // (m, g, e)) and stored lane-major (STORE): masks_l[(2 wave + n) * 64 + lane] — the backward's transposed epilogue has the same
 // lane <-> element map and pops them in the same order
+// STORE also writes the activations to `tile_out`, the tile's K-MAJOR image [256 features][64 rows] fp32 the weight-gradient GEMM
+// reads (SPF_WGRAD_*_TILES): straight from the registers — for each of a lane's four features the 32 lanes of a k-group cover 128
+// contiguous bytes — instead of a second pass that rebuilds fp32 rows from the planes.
 template <bool STORE>
-__device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], const CxBias& bias, int wave, int lane, uint32_t* masks_l) {
+__device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], const CxBias& bias, int wave, int lane, uint32_t* masks_l,
+                                                float* __restrict__ tile_out) {
     const int j = lane & 31, kg = lane >> 5;
     uint32_t bits[2] = {0u, 0u};
 #pragma unroll
@@ -577,6 +583,10 @@ __device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[e] = lrelu_push(h[e], hs[e], bits[n]);
                 store_quad_x3(X, 32 * n + j, f0, out);
+                if (STORE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tile_out[(f0 + e) * 64 + 32 * n + j] = out[e];
+                }
             }
         }
     if (STORE) {
@@ -586,7 +596,8 @@ __device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2
 }
 
 // transposed backward epilogue: g_h = g_a * lrelu'(h), popping the lane's two sign words -> planes
-__device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mw)[2]) {
+__device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mw)[2],
+                                                float* __restrict__ tile_out) {
     const int j = lane & 31, kg = lane >> 5;
     uint32_t bits[2] = {mw[0], mw[1]};
 #pragma unroll
@@ -602,6 +613,8 @@ __device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], bits[n]);
                 store_quad_x3(X, 32 * n + j, f0, out);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tile_out[(f0 + e) * 64 + 32 * n + j] = out[e];      // K-major tile for spf_wgrad
             }
         }
 }
@@ -723,7 +736,7 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        cx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, mk);
+        cx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, mk, STORE ? act1 + (size_t)tile * 64 * 256 : nullptr);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
@@ -731,20 +744,18 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
             n_srow = point_slot ? point_slot[n_p] : n_p;
             n_off = pair_off[n_p];
         }
-        if (STORE) store_tile_from_planes<32>(X, act1 + (size_t)tile * 64 * 256, 256, tid);
         bias = cx_load_bias(pf + CO_B2, wave, lane);
         zero_acc(acc);
         nf = gemm_x3<CX_TH>(X, w_fw2, lane, acc, nf, w_fw3);
         T_MARK(6)
         lds_barrier();
         T_MARK(7)
-        cx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, STORE ? mk + 512 : nullptr);
+        cx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, STORE ? mk + 512 : nullptr, STORE ? act2 + (size_t)tile * 64 * 256 : nullptr);
         T_MARK(8)
         lds_barrier();
         T_MARK(9)
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
         const float bv[2] = {pf[CO_B3 + 64 * wave + (lane & 31)], pf[CO_B3 + 64 * wave + (lane & 31) + 32]};     // layer-4 biases, ahead of the GEMM
-        if (STORE) store_tile_from_planes<32>(X, act2 + (size_t)tile * 64 * 256, 256, tid);
         // ---- layer 4, NON-transposed: acc[m][n] = rows 32m.., features 64w + 32n..; lane (feature j, k-half kg) ------------------
         zero_acc(acc);
         gemm_x3<CX_TH, true>(X, w_fw3, lane, acc, nf, nullptr);
@@ -898,11 +909,10 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         T_MARK(18)
         lds_barrier();
         T_MARK(19)
-        cx_bwd_epilogue(X, acc, wave, lane, mw);
+        cx_bwd_epilogue(X, acc, wave, lane, mw, G2 + tbase);
         T_MARK(20)
         lds_barrier();
         T_MARK(21)
-        store_tile_from_planes<32>(X, G2 + tbase, 256, tid);
         if (n_p >= 0) {
             n_srow = point_slot ? point_slot[n_p] : n_p;
             n_off = pair_off[n_p];
@@ -917,11 +927,10 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         const WFrag1 frl = load_wfrag1(w_bwl);
         lds_barrier();
         T_MARK(19)
-        cx_bwd_epilogue(X, acc, wave, lane, mw);
+        cx_bwd_epilogue(X, acc, wave, lane, mw, G1 + tbase);
         T_MARK(20)
         lds_barrier();
         T_MARK(21)
-        store_tile_from_planes<32>(X, G1 + tbase, 256, tid);
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
         if (next_tile < ntiles) cur = cx_fetch_grow(g_agg3, masks + (size_t)next_tile * 3 * 512, n_p, n_idx, n_w, row0, q40);
         T_MARK(22)

@@ -262,7 +262,12 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
 // accumulator registers).  The A tile feeds every wave, so it is split into its three bf16 planes ONCE per workgroup (one
 // (column, k-half) item per thread) into `planes`, laid out [piece][column][k-half] x 8 bf16 so that an MFMA B fragment is one
 // 16-byte LDS read; each wave splits its own 32 columns of G in registers and issues 1/8 of the DMA requests.
-template <int NT>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
+// GK / AK: the operand arrives as K-MAJOR TILES instead of rows: tile t = rows [64 t, 64 t + 64), element (t, feature f, row r) at
+// ((256 t + f) 64 + r) — what the colour kernels' transposed epilogues write straight from their accumulators (a lane owns 4
+// features of one row there: 32 lanes = 128 contiguous bytes per feature).  A stage's 16 rows of a feature are then 64 contiguous
+// bytes; one DMA request moves 16 features x 4 row quads, laid out [row quad][feature][4 rows] in LDS so that a thread's eight
+// k-values are two conflict-free 16-byte reads (row-major operands need eight 4-byte reads).
+template <int NT, bool GK = false, bool AK = false>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
 __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, const float* __restrict__ A, int lda, int C,
                                                   const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slab,
                                                   float* __restrict__ dbias, const int bid, const int nblk) {
@@ -273,8 +278,10 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
     const int tid = threadIdx.x, lane = tid & 63, ci = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // 0..7
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
+    static_assert(!AK || NT == 8, "tiled A: 256 columns");
+    constexpr int ALIGN = (GK || AK) ? 64 : 2;                             // tiled operands: a workgroup's rows start on a tile
     int chunk = (n + nblk - 1) / nblk;
-    chunk += chunk & 1;
+    chunk = (chunk + ALIGN - 1) / ALIGN * ALIGN;
     const int r0 = bid * chunk, r1 = min(r0 + chunk, n);
     if (r0 >= r1) return;
     const int nst = (r1 - r0 + ROWS - 1) / ROWS;
@@ -286,6 +293,7 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
     float gsum = 0.f;
     const int c4max = (C - 1) / 4;
     const unsigned off_row = 16u * lane, off_half = 16u * min(ci, c4max);
+    const unsigned off_k = (unsigned)(((lane & 15) * 64 + 4 * (lane >> 4)) * 4);      // tiled: lane = (feature in block, row quad)
     auto issue = [&](int st) {
         const int buf = st % NB, base = r0 + st * ROWS;
         float* sg = sm + buf * ROWS * (256 + CA);
@@ -293,8 +301,13 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int lr = 2 * wave + j, row = min(base + lr, r1 - 1);       // wave-uniform
-            glds16_s(G + (size_t)row * 256, off_row, sg + lr * 256);
-            if (NT == 8) glds16_s(A + (size_t)row * lda, off_row, sa + lr * CA);
+            // tiled: request lr = 16-feature block lr, rows base .. base + 15 of its tile (whole tiles exist: no clamp)
+            if (GK) glds16_s(G + (size_t)(base >> 6) * 16384 + lr * 1024 + (base & 63), off_k, sg + lr * 256);
+            else glds16_s(G + (size_t)row * 256, off_row, sg + lr * 256);
+            if (NT == 8) {
+                if (AK) glds16_s(A + (size_t)(base >> 6) * 16384 + lr * 1024 + (base & 63), off_k, sa + lr * CA);
+                else glds16_s(A + (size_t)row * lda, off_row, sa + lr * CA);
+            }
         }
         if (NT == 4) {                                                     // two 512-B rows per request
             const int lr = 2 * wave, row_lo = min(base + lr, r1 - 1), row_hi = min(base + lr + 1, r1 - 1);
@@ -318,8 +331,15 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
             const int col = 32 * wave + ci;
             if (col < CA) {
                 float x[8];
+                if (AK) {
+                    const float* p = sa + (col >> 4) * 256 + (2 * h) * 64 + (col & 15) * 4;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 64);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = sa[(8 * h + e) * CA + col];
+                    for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = sa[(8 * h + e) * CA + col];
+                }
                 const Split8 b = split8(x);
                 planes[(0 * CA + col) * 2 + h] = b.p1;
                 planes[(1 * CA + col) * 2 + h] = b.p2;
@@ -329,8 +349,19 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
         Split8 ga;
         {
             float x[8];
+            if (GK) {
+                const int col = 32 * wave + ci;
+                const float* p = sg + (col >> 4) * 256 + (2 * h) * 64 + (col & 15) * 4;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 64);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = (8 * h + e < left) ? sg[(8 * h + e) * 256 + 32 * wave + ci] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = (8 * h + e < left) ? lo[e] : 0.f;
+                    x[4 + e] = (8 * h + 4 + e < left) ? hi[e] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = (8 * h + e < left) ? sg[(8 * h + e) * 256 + 32 * wave + ci] : 0.f;
+            }
             ga = split8(x);
             gsum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));      // column sums of G = the bias gradient
         }
@@ -369,11 +400,11 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
 }
 
 
-template <int NT>
+template <int NT, bool GK = false, bool AK = false>
 __global__ void __launch_bounds__(512, 1)
 wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
                     int max_rows, float* __restrict__ slab, float* __restrict__ dbias) {
-    wgrad_split8_body<NT>(G, A, lda, C, n_rows_dev, max_rows, slab, dbias, (int)blockIdx.x, (int)gridDim.x);
+    wgrad_split8_body<NT, GK, AK>(G, A, lda, C, n_rows_dev, max_rows, slab, dbias, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // up to three C = 256 problems over the same rows in one launch: blockIdx.y = problem, each with gridDim.x workgroups and its own slab
@@ -395,11 +426,11 @@ wgrad_split8_batched_kernel(WgradBatch pb, const int32_t* __restrict__ n_rows_de
 // slab of wgrad_split8_kernel: output row o = 32 wave + C-row(reg, lane), column = 32 t + (lane & 31)
 template <int NT>
 __device__ __forceinline__ void wgrad_split8_reduce_body(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev,
-                                                         int max_rows, int C, float* __restrict__ dW, int ldw) {
+                                                         int max_rows, int C, float* __restrict__ dW, int ldw, int align = 2) {
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
     if (n <= 0) return;
     int chunk = (n + nblk_launched - 1) / nblk_launched;
-    chunk += chunk & 1;
+    chunk = (chunk + align - 1) / align * align;        // the row split of wgrad_split8_body
     const int active = (n + chunk - 1) / chunk;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr int PER = 8 * NT * 16 * 64;
@@ -423,8 +454,8 @@ __device__ __forceinline__ void wgrad_split8_reduce_body(const float* __restrict
 
 template <int NT>
 __global__ void wgrad_split8_reduce_kernel(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev, int max_rows,
-                                           int C, float* __restrict__ dW, int ldw) {
-    wgrad_split8_reduce_body<NT>(slab, nblk_launched, n_rows_dev, max_rows, C, dW, ldw);
+                                           int C, float* __restrict__ dW, int ldw, int align) {
+    wgrad_split8_reduce_body<NT>(slab, nblk_launched, n_rows_dev, max_rows, C, dW, ldw, align);
 }
 __global__ void wgrad_split8_reduce_batched_kernel(const float* __restrict__ slabs, size_t slab_floats, int nblk_launched,
                                                    const int32_t* __restrict__ n_rows_dev, int max_rows, WgradBatch pb) {
@@ -523,28 +554,37 @@ static constexpr int RSPLIT = 16;
 int64_t spf_wgrad_workspace_floats(int32_t C) { return (int64_t)256 * 256 * (C > 128 ? 256 : (C > 32 ? 256 : 32)); }
 
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows, float* dW, int32_t ldw,
-              float* dbias, float* workspace, int32_t arith, void* stream) {
+              float* dbias, float* workspace, int32_t layout, int32_t arith, void* stream) {
     if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_wgrad: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (max_rows < 0 || C < 1 || C > 256 || lda < C || ldw < C) return spf::fail(SPF_EINVAL, "spf_wgrad: need 1 <= C <= 256, lda >= C, ldw >= C");
     if (max_rows == 0) return SPF_OK;
     if (!G || !A || !dW || !workspace) return spf::fail(SPF_EINVAL, "spf_wgrad: null pointer");
     const int NT = C > 128 ? 8 : (C > 32 ? 4 : 1);
+    const bool gk = layout & SPF_WGRAD_G_TILES, ak = layout & SPF_WGRAD_A_TILES;
+    if (layout & ~(SPF_WGRAD_G_TILES | SPF_WGRAD_A_TILES)) return spf::fail(SPF_EINVAL, "spf_wgrad: unknown layout bits %d", layout);
+    if ((gk || ak) && (arith != SPF_ARITH_SPLIT || NT < 4 || (max_rows % 64) || (ak && C != 256)))
+        return spf::fail(SPF_EINVAL, "spf_wgrad: tiled operands need SPF_ARITH_SPLIT, C > 32, max_rows a multiple of 64 (whole tiles) and, for A, C = 256");
     if (NT >= 4 && ((C % 4) || (lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad: C and lda must be multiples of 4 for C > 32 (C=%d lda=%d)", C, lda);
     hipStream_t s = (hipStream_t)stream;
     int blocks = spf::div_up(max_rows, 512);
     const int cap = NT == 4 ? 512 : 256;   // NT = 4: half the accumulators, two workgroups per CU; else one per CU, one wave per SIMD
     if (blocks > cap) blocks = cap;
     const int per = 4 * 2 * NT * 16 * 64;
+    const int align = (gk || ak) ? 64 : 2;
     if (arith == SPF_ARITH_SPLIT && NT == 8 && C == 256) {
         const int b8 = blocks > 256 ? 256 : blocks;      // one 8-wave workgroup per CU
-        wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        if (gk && ak) wgrad_split8_kernel<8, true, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        else if (gk) wgrad_split8_kernel<8, true, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        else if (ak) wgrad_split8_kernel<8, false, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        else wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         dbias = nullptr;
-        wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw);
+        wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align);
     } else if (arith == SPF_ARITH_SPLIT && NT == 4) {
         const int b8 = blocks > 256 ? 256 : blocks;
-        wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        if (gk) wgrad_split8_kernel<4, true, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        else wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         dbias = nullptr;
-        wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw);
+        wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align);
     } else if (NT == 8) {
         if (C == 256) wgrad_dma_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         else wgrad_lds_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
@@ -577,7 +617,7 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
     if (arith != SPF_ARITH_SPLIT || n_problems == 1) {      // fp32-MFMA verification mode / nothing to batch: the single-problem path
         for (int q = 0; q < n_problems; ++q) {
             const spf_wgrad_problem& p = problems[q];
-            const int rc = spf_wgrad(p.G, p.A, p.lda, 256, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, arith, stream);
+            const int rc = spf_wgrad(p.G, p.A, p.lda, 256, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, 0, arith, stream);
             if (rc != SPF_OK) return rc;
         }
         return SPF_OK;

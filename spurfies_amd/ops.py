@@ -332,16 +332,18 @@ class ColorAgg(_GradModeFunction):
                                                      _lib.ptr(g_feat), ctx.arith, _lib.stream_ptr()), "spf_color_backward")
         # split-product kernels (the default) leave the bias gradients to the weight-gradient GEMM (column sums of G)
         kb = (lambda b: b) if ctx.arith == 0 else (lambda b: None)
+        # the bf16-piece kernels write act1 / act2 / G2 / G1 as K-major tiles (include/spurfies_hip.h: SPF_WGRAD_*_TILES)
+        GT, AT = (WGRAD_G_TILES, WGRAD_A_TILES) if ctx.arith == 0 else (0, 0)
         if sk is not None:
             # layer 0's [256,104] comes in the kernels' internal column order: one index_add_ into the reference order
-            sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0))[:, :103])
-            wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2))
-            wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4))
+            sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=GT)[:, :103])
+            wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2), layout=GT | AT)
+            wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=AT)
             return (None,) * 13
         # exact-size (default) and worst-case (sync-free) buffers alike: the weight-gradient kernel reads the row count on the device
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
-        dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0))[:, :103]   # [256,104] comes in the kernels' internal column order
-        dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2)), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4))
+        dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=GT)[:, :103]   # [256,104] comes in the kernels' internal column order
+        dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2), layout=GT | AT), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4), layout=AT)
         grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4)
         return grads + (None,) * 6
 
@@ -566,7 +568,10 @@ def set_wgrad_mode(mode: str):
 
 
 
-def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None):
+WGRAD_G_TILES, WGRAD_A_TILES = 1, 2      # spf_wgrad layout bits: that operand is stored as K-major tiles [tile][256 features][64 rows]
+
+
+def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0):
     """out[256, :C] += G[:rows]^T A[:rows, :C] with the row count `n_rows` (int32 device tensor or None) read on the device;
     dbias [256] (optional) += column sums of G[:rows] (the same layer's bias gradient)."""
     dev = G.device
@@ -580,7 +585,7 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None):
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_wgrad(_lib.ptr(G), _lib.ptr(A), A.stride(0), C, _lib.ptr(n_rows), min(G.shape[0], A.shape[0]), _lib.ptr(out), ldw, _lib.ptr(dbias),
-                                        _lib.ptr(_wgrad_ws[key]), _ARITH["wgrad"], _lib.stream_ptr()), "spf_wgrad")
+                                        _lib.ptr(_wgrad_ws[key]), int(layout), _ARITH["wgrad"], _lib.stream_ptr()), "spf_wgrad")
     return out
 
 

@@ -113,3 +113,36 @@ def test_three_problems_side_by_side_equal_three_calls(rows):
                                        atol=2e-5 * float(Gs[2][:rows].abs().sum(0).max()))
         finally:
             ops.set_wgrad_mode("split")
+
+
+def _to_tiles(M):
+    """[rows, 256] (rows a multiple of 64) -> the K-major tile image [tile][256 features][64 rows] the colour kernels write."""
+    t = M.shape[0] // 64
+    return M.view(t, 64, 256).transpose(1, 2).contiguous().view(-1, 256)
+
+
+@pytest.mark.parametrize("rows", [70001, 1000, 64, 5])
+@pytest.mark.parametrize("layout", [1, 2, 3])
+def test_tiled_operands_match_row_major(rows, layout):
+    """SPF_WGRAD_G_TILES / SPF_WGRAD_A_TILES: the same GEMM with one or both operands stored as K-major tiles (what the colour
+    trunk's epilogues write) — same accuracy against float64 as the row-major call, incl. a row count inside the last tile."""
+    from spurfies_amd import ops
+
+    g = torch.Generator().manual_seed(rows + layout)
+    alloc = (rows + 63) // 64 * 64
+    G = torch.randn((alloc, 256), generator=g).cuda()
+    A = torch.randn((alloc, 256), generator=g).cuda()
+    n = torch.tensor([rows], dtype=torch.int32, device="cuda")
+    ref = G[:rows].double().t() @ A[:rows].double()
+    db_ref = G[:rows].double().sum(0)
+    Gx = _to_tiles(G) if layout & 1 else G
+    Ax = _to_tiles(A) if layout & 2 else A
+    db = torch.zeros(256, device="cuda")
+    got = ops.wgrad(Gx, Ax, n, dbias=db, layout=layout)
+    base = ops.wgrad(G, A, n)
+    assert _err(got, ref) < 2e-6 + 2.0 * _err(base, ref)
+    np.testing.assert_allclose(db.double().cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    if layout == 1:          # the 104-column operand of F_color's first layer stays row-major next to a tiled G
+        A104 = A[:, :104].contiguous()
+        got4 = ops.wgrad(Gx, A104, n, layout=1)
+        assert _err(got4, G[:rows].double().t() @ A104[:rows].double()) < 1e-5
