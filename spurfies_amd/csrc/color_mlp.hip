@@ -480,8 +480,8 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
 //     backward's first stage one row quarter per thread);
 //   * what the weight-gradient GEMM reads: act1 / act2 (forward) and G2 / G1 (backward) leave the transposed epilogues straight
 //     from the registers as K-major tiles [256 features][64 rows] (SPF_WGRAD_*_TILES; exactly the values the planes hold, since
-//     p1 + p2 + p3 reproduces the fp32 value); act0 and G3 — produced by the row-per-thread gather stages — are written as fp32 rows
-//     rebuilt from the planes; bias gradients come from the weight-gradient GEMM (column sums of G, spf_wgrad).
+//     p1 + p2 + p3 reproduces the fp32 value); G3 likewise from the backward's first stage (thread = (row = lane, feature quarter = wave));
+//     act0 — produced by the (row, quarter) gather stage — is written as fp32 rows rebuilt from the planes; bias gradients come from the weight-gradient GEMM (column sums of G, spf_wgrad).
 // ==============================================================================================================================
 constexpr int CX_T1 = 7;                          // layer 0: K = 104 -> 112
 constexpr int CX_TH = 16;
@@ -767,6 +767,7 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
             const int c0 = 64 * wave + j;
             int cur = -1;
             float a0 = 0.f, a1 = 0.f;
+            uint32_t mw0 = 0u, mw1 = 0u;      // lane l collects the two sign words of row l (features 64 wave + 0..31 and + 32..63)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -778,13 +779,13 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                     const bool p0 = v0 > 0.f, p1 = v1 > 0.f;
                     if (STORE) {     // ballot: low 32 lanes = row (kg = 0), high 32 = row + 4 (kg = 1); bit = feature & 31
                         const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
-                        if (lane == 0) {
-                            const int rlo = 32 * m + 8 * (r >> 2) + (r & 3);
-                            mk[1024 + rlo * 8 + 2 * wave] = (uint32_t)b0;
-                            mk[1024 + rlo * 8 + 2 * wave + 1] = (uint32_t)b1;
-                            mk[1024 + (rlo + 4) * 8 + 2 * wave] = (uint32_t)(b0 >> 32);
-                            mk[1024 + (rlo + 4) * 8 + 2 * wave + 1] = (uint32_t)(b1 >> 32);
-                        }
+                        const int rlo = 32 * m + 8 * (r >> 2) + (r & 3);          // compile-time lane selects
+                        // (a VALU-written SGPR needs 4 wait states before v_writelane reads it; the hazard recogniser does not see
+                        // into inline asm)
+                        asm("s_nop 3\n\tv_writelane_b32 %0, %2, %6\n\tv_writelane_b32 %1, %3, %6\n\tv_writelane_b32 %0, %4, %7\n\t"
+                            "v_writelane_b32 %1, %5, %7"
+                            : "+v"(mw0), "+v"(mw1)
+                            : "s"((uint32_t)b0), "s"((uint32_t)b1), "s"((uint32_t)(b0 >> 32)), "s"((uint32_t)(b1 >> 32)), "n"(rlo), "n"(rlo + 4));
                     }
                     v0 = p0 ? v0 : v0 * 0.01f;
                     v1 = p1 ? v1 : v1 * 0.01f;
@@ -804,6 +805,7 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                 atomicAdd(&agg3[(size_t)cur * 256 + c0], a0);
                 atomicAdd(&agg3[(size_t)cur * 256 + c0 + 32], a1);
             }
+            if (STORE) *reinterpret_cast<u32x2*>(mk + 1024 + lane * 8 + 2 * wave) = u32x2{mw0, mw1};      // [row][8 words]
         }
         T_MARK(13)
         lds_barrier();       // planes and s_wp are rewritten by the next tile's gather
@@ -849,9 +851,11 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
     const int ntiles = (NP + 63) / 64;
     const float* packed0 = packed;
     T_DECL
+    // first stage: thread = (pair row = lane, quarter of the 256 features = wave): a feature's 64 rows are then 64 consecutive
+    // lanes, i.e. the K-major G3 tile leaves the registers in fully used 128-byte lines
     CxGrow cur;
     {
-        const int q = blockIdx.x * 64 + (tid >> 2);
+        const int q = blockIdx.x * 64 + lane;
         int p = -1, idx = -1;
         float w = 0.f;
         if (q < NP) {
@@ -860,7 +864,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
             idx = nbr[(size_t)srow * k + (q - pair_off[p])];
             w = wn[q];
         }
-        cur = cx_fetch_grow(g_agg3, masks + (size_t)blockIdx.x * 3 * 512, p, idx, w, tid >> 2, tid & 3);
+        cur = cx_fetch_grow(g_agg3, masks + (size_t)blockIdx.x * 3 * 512, p, idx, w, lane, wave);
     }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -873,9 +877,10 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         const uint32_t* mk = masks + (size_t)tile * 3 * 512;
         // ---- G3[row] = wn[row] g_agg3[p] * lrelu'(h3): thread = (row, quarter of the 256 features) -> planes; the operands were
         //      requested during the previous tile
-        const int row0 = tid >> 2, q40 = tid & 3;
+        const int row0 = tid >> 2, q40 = tid & 3;              // (row, quarter) of the latent-gradient stages below
         {
-            if (q40 == 0) s_idx[row0] = cur.idx;
+            if (wave == 0) s_idx[lane] = cur.idx;
+            float* g3t = G3 + tbase + (size_t)(64 * wave) * 64 + lane;       // K-major tile: feature f, row r at f * 64 + r
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const uint32_t word = u < 8 ? cur.m0 : cur.m1;
@@ -885,12 +890,13 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
                     const bool pos = (word >> ((4 * u + e) & 31)) & 1u;
                     const float t = cur.w != 0.f ? cur.ga[u][e] * cur.w : 0.f;
                     o[e] = pos ? t : t * 0.01f;
+                    g3t[(4 * u + e) * 64] = o[e];
                 }
-                store_quad_x3(X, row0, 64 * q40 + 4 * u, o);
+                store_quad_x3(X, lane, 64 * wave + 4 * u, o);
             }
         }
         const int next_tile = tile + (int)gridDim.x;
-        const int qn = next_tile * 64 + row0;
+        const int qn = next_tile * 64 + lane;
         int n_p = -1, n_srow = 0, n_off = 0, n_idx = -1;
         float n_w = 0.f;
         if (qn < NP) {
@@ -900,7 +906,6 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         T_MARK(16)
         lds_barrier();
         T_MARK(17)
-        store_tile_from_planes<32>(X, G3 + tbase, 256, tid);          // exactly the values the planes hold (p1 + p2 + p3)
         f32x16 acc[2][2];
         const int j = lane & 31;
         uint32_t mw[2] = {mk[512 + (2 * wave) * 64 + lane], mk[512 + (2 * wave + 1) * 64 + lane]};      // layer-2 sign words, before the GEMM
@@ -932,7 +937,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         lds_barrier();
         T_MARK(21)
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
-        if (next_tile < ntiles) cur = cx_fetch_grow(g_agg3, masks + (size_t)next_tile * 3 * 512, n_p, n_idx, n_w, row0, q40);
+        if (next_tile < ntiles) cur = cx_fetch_grow(g_agg3, masks + (size_t)next_tile * 3 * 512, n_p, n_idx, n_w, lane, wave);
         T_MARK(22)
         // ---- d/d latent = G1 W0[:, 39:103]: wave = (latent half m, row half n), one 32x32 tile each; scatter-add -------------------
         {
@@ -942,6 +947,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<f32x4*>(&L[(32 * n + j) * CX_LDL + 32 * m + 8 * g + 4 * kg]) = f32x4{aj[4 * g], aj[4 * g + 1], aj[4 * g + 2], aj[4 * g + 3]};
         }
+        T_MARK(25)
         lds_barrier();
         // Rows of a tile that hit the same neural point (samples along a ray share most of their neighbours) are summed in LDS
         // first: same-address atomics serialise in L2, and with one workgroup per CU nothing else runs meanwhile.
@@ -977,6 +983,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
                 for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(own + 4 * u) = sum[u];
             }
         }
+        T_MARK(26)
         lds_barrier();
         // wave w adds rows 16 w .. 16 w + 15 that lead a group: one row per instruction, lane = latent column (256 contiguous bytes per
         // atomic instruction; a lane-per-row arrangement touches 32 to 64 cache lines per instruction and runs at a fraction of the

@@ -338,12 +338,12 @@ class ColorAgg(_GradModeFunction):
             # layer 0's [256,104] comes in the kernels' internal column order: one index_add_ into the reference order
             sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=GT)[:, :103])
             wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2), layout=GT | AT)
-            wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=AT)
+            wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=GT | AT)
             return (None,) * 13
         # exact-size (default) and worst-case (sync-free) buffers alike: the weight-gradient kernel reads the row count on the device
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
         dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=GT)[:, :103]   # [256,104] comes in the kernels' internal column order
-        dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2), layout=GT | AT), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4), layout=AT)
+        dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2), layout=GT | AT), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4), layout=GT | AT)
         grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4)
         return grads + (None,) * 6
 

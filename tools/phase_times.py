@@ -44,4 +44,4 @@ report("spf_debug_timing_geo",
         13: "syncs after epilogue", 14: "input-Jacobian GEMM + stores", 15: "sync"})
 report("spf_debug_timing_color", cb.bwd_only,
        {16: "G3 = wn g_agg3 * mask -> HBM + planes", 17: "sync", 18: "2 backward GEMMs", 19: "syncs", 20: "2 backward epilogues", 21: "syncs",
-        22: "G2 / G1 tile stores", 23: "latent-gradient GEMM + scatter", 24: "sync"})
+        22: "next-tile lookups", 25: "latent-gradient GEMM + L store", 26: "sync + duplicate sums", 23: "sync + atomics", 24: "sync"})
