@@ -303,11 +303,15 @@ int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float
 int64_t spf_wgrad_workspace_floats(int32_t C);
 /* arith (see SPF_ARITH_*) applies for C > 32; narrower operands always take the fp32-MFMA kernel.
  * layout: 0 = both operands are row-major [rows, .]; SPF_WGRAD_G_TILES / SPF_WGRAD_A_TILES (or-ed): that operand is stored as
- * K-MAJOR TILES of 64 rows x 256 features, element (tile t, feature f, row r) at ((256 t + f) 64 + r) — what spf_color_forward
- * (act1, act2) and spf_color_backward (G2, G1) write with SPF_ARITH_SPLIT.  Tiled operands need SPF_ARITH_SPLIT, C > 32,
- * max_rows % 64 == 0 (whole tiles allocated) and, for A, C = 256; lda is ignored for a tiled A. */
+ * K-MAJOR BLOCKS of 16 rows x 256 features, element (row, feature f) at ((256 (row / 16) + f) 16 + row % 16) — what
+ * spf_color_forward (act1, act2) and spf_color_backward (G2, G1) write with SPF_ARITH_SPLIT: one 16-row MFMA K-step of an
+ * operand is a contiguous 16-KB run with each feature's rows adjacent.  Blocked operands need SPF_ARITH_SPLIT, C > 32,
+ * max_rows % 16 == 0 (whole blocks allocated) and, for A, C = 256; lda is ignored for a blocked A.
+ * SPF_WGRAD_G_TILES64 (C = 256 only): G in K-major TILES of 64 rows, element (row, f) at ((256 (row / 64) + f) 64 + row % 64), the
+ * form a row-per-lane producer writes in full cache lines (spf_color_backward's G3); max_rows % 64 == 0. */
 #define SPF_WGRAD_G_TILES 1
 #define SPF_WGRAD_A_TILES 2
+#define SPF_WGRAD_G_TILES64 4
 
 /* dbias (may be NULL): float[256], dbias[o] += sum_rows G[row][o] — the bias gradient of the same layer, taken on the way
  * (free in the default arithmetic; a separate pass over G otherwise). */

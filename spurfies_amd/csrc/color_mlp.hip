@@ -479,7 +479,7 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
 //     ([row][8 words], bit = feature & 31: a row word per accumulator register from the wave ballot, read back by the
 //     backward's first stage one row quarter per thread);
 //   * what the weight-gradient GEMM reads: act1 / act2 (forward) and G2 / G1 (backward) leave the transposed epilogues straight
-//     from the registers as K-major tiles [256 features][64 rows] (SPF_WGRAD_*_TILES; exactly the values the planes hold, since
+//     from the registers as K-major blocks [256 features][16 rows] (SPF_WGRAD_*_TILES; exactly the values the planes hold, since
 //     p1 + p2 + p3 reproduces the fp32 value); G3 likewise from the backward's first stage (thread = (row = lane, feature quarter = wave));
 //     act0 — produced by the (row, quarter) gather stage — is written as fp32 rows rebuilt from the planes; bias gradients come from the weight-gradient GEMM (column sums of G, spf_wgrad).
 // ==============================================================================================================================
@@ -562,9 +562,9 @@ __device__ __forceinline__ CxBias cx_load_bias(gfp bias, int wave, int lane) {
 // transposed forward epilogue: a = lrelu(acc + b) -> planes; the lane's sign bits are pushed into two words (n = 0, 1; order
 // (m, g, e)) and stored lane-major (STORE): masks_l[(2 wave + n) * 64 + lane] — the backward's transposed epilogue has the same
 // lane <-> element map and pops them in the same order
-// STORE also writes the activations to `tile_out`, the tile's K-MAJOR image [256 features][64 rows] fp32 the weight-gradient GEMM
-// reads (SPF_WGRAD_*_TILES): straight from the registers — for each of a lane's four features the 32 lanes of a k-group cover 128
-// contiguous bytes — instead of a second pass that rebuilds fp32 rows from the planes.
+// STORE also writes the activations to `tile_out`, the tile's K-MAJOR image (four blocks of [256 features][16 rows] fp32) the
+// weight-gradient GEMM reads (SPF_WGRAD_*_TILES): straight from the registers — for each of a lane's four features 16 lanes cover
+// 64 contiguous bytes — instead of a second pass that rebuilds fp32 rows from the planes.
 template <bool STORE>
 __device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], const CxBias& bias, int wave, int lane, uint32_t* masks_l,
                                                 float* __restrict__ tile_out) {
@@ -585,7 +585,7 @@ __device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2
                 store_quad_x3(X, 32 * n + j, f0, out);
                 if (STORE) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) tile_out[(f0 + e) * 64 + 32 * n + j] = out[e];
+                    for (int e = 0; e < 4; ++e) tile_out[(2 * n + (j >> 4)) * 4096 + (f0 + e) * 16 + (j & 15)] = out[e];
                 }
             }
         }
@@ -614,7 +614,7 @@ __device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2
                 for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], bits[n]);
                 store_quad_x3(X, 32 * n + j, f0, out);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) tile_out[(f0 + e) * 64 + 32 * n + j] = out[e];      // K-major tile for spf_wgrad
+                for (int e = 0; e < 4; ++e) tile_out[(2 * n + (j >> 4)) * 4096 + (f0 + e) * 16 + (j & 15)] = out[e];      // K-major blocks for spf_wgrad
             }
         }
 }
@@ -880,7 +880,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         const int row0 = tid >> 2, q40 = tid & 3;              // (row, quarter) of the latent-gradient stages below
         {
             if (wave == 0) s_idx[lane] = cur.idx;
-            float* g3t = G3 + tbase + (size_t)(64 * wave) * 64 + lane;       // K-major tile: feature f, row r at f * 64 + r
+            float* g3t = G3 + tbase + (size_t)(64 * wave) * 64 + lane;       // K-major 64-row tile (SPF_WGRAD_G_TILES64): feature f, row r at f * 64 + r
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const uint32_t word = u < 8 ? cur.m0 : cur.m1;

@@ -262,12 +262,14 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
 // accumulator registers).  The A tile feeds every wave, so it is split into its three bf16 planes ONCE per workgroup (one
 // (column, k-half) item per thread) into `planes`, laid out [piece][column][k-half] x 8 bf16 so that an MFMA B fragment is one
 // 16-byte LDS read; each wave splits its own 32 columns of G in registers and issues 1/8 of the DMA requests.
-// GK / AK: the operand arrives as K-MAJOR TILES instead of rows: tile t = rows [64 t, 64 t + 64), element (t, feature f, row r) at
-// ((256 t + f) 64 + r) — what the colour kernels' transposed epilogues write straight from their accumulators (a lane owns 4
-// features of one row there: 32 lanes = 128 contiguous bytes per feature).  A stage's 16 rows of a feature are then 64 contiguous
-// bytes; one DMA request moves 16 features x 4 row quads, laid out [row quad][feature][4 rows] in LDS so that a thread's eight
-// k-values are two conflict-free 16-byte reads (row-major operands need eight 4-byte reads).
-template <int NT, bool GK = false, bool AK = false>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
+// GK / AK: the operand arrives as K-MAJOR BLOCKS instead of rows: block b = rows [16 b, 16 b + 16), element (b, feature f, row r) at
+// ((256 b + f) 16 + r) — what the colour kernels' transposed epilogues write straight from their accumulators (a lane owns 4
+// features of one row there: 16 lanes = 64 contiguous bytes per feature).  A stage (16 rows x 256 features) is then ONE contiguous
+// 16-KB run: a DMA request moves 1 KB = 16 features, its 16-byte pieces permuted so that LDS holds [row quad][feature][4 rows] and
+// a thread's eight k-values are two conflict-free 16-byte reads (row-major operands need eight 4-byte reads).
+// GK = 2: G as K-major TILES of 64 rows, element (row, f) at ((256 (row / 64) + f) 64 + row % 64): what a row-per-lane producer
+// writes in full 128-byte lines (spf_color_backward's G3); a stage's 16 rows of a feature are then half a line (64 B) per request.
+template <int NT, int GK = 0, bool AK = false>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
 __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, const float* __restrict__ A, int lda, int C,
                                                   const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slab,
                                                   float* __restrict__ dbias, const int bid, const int nblk) {
@@ -279,7 +281,7 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // 0..7
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
     static_assert(!AK || NT == 8, "tiled A: 256 columns");
-    constexpr int ALIGN = (GK || AK) ? 64 : 2;                             // tiled operands: a workgroup's rows start on a tile
+    constexpr int ALIGN = GK == 2 ? 64 : ((GK || AK) ? 16 : 2);            // blocked operands: a workgroup's rows start on a block / tile
     int chunk = (n + nblk - 1) / nblk;
     chunk = (chunk + ALIGN - 1) / ALIGN * ALIGN;
     const int r0 = bid * chunk, r1 = min(r0 + chunk, n);
@@ -293,7 +295,8 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
     float gsum = 0.f;
     const int c4max = (C - 1) / 4;
     const unsigned off_row = 16u * lane, off_half = 16u * min(ci, c4max);
-    const unsigned off_k = (unsigned)(((lane & 15) * 64 + 4 * (lane >> 4)) * 4);      // tiled: lane = (feature in block, row quad)
+    const unsigned off_k = (unsigned)(((lane & 15) * 16 + 4 * (lane >> 4)) * 4);      // blocked: lane = (feature in request, row quad)
+    const unsigned off_k64 = (unsigned)(((lane & 15) * 64 + 4 * (lane >> 4)) * 4);    // 64-row tiles: a feature's rows are 256 B apart
     auto issue = [&](int st) {
         const int buf = st % NB, base = r0 + st * ROWS;
         float* sg = sm + buf * ROWS * (256 + CA);
@@ -301,11 +304,12 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int lr = 2 * wave + j, row = min(base + lr, r1 - 1);       // wave-uniform
-            // tiled: request lr = 16-feature block lr, rows base .. base + 15 of its tile (whole tiles exist: no clamp)
-            if (GK) glds16_s(G + (size_t)(base >> 6) * 16384 + lr * 1024 + (base & 63), off_k, sg + lr * 256);
+            // blocked: request lr = features 16 lr .. 16 lr + 15 of the 16-row block base / 16 (whole blocks exist: no clamp)
+            if (GK == 2) glds16_s(G + (size_t)(base >> 6) * 16384 + lr * 1024 + (base & 63), off_k64, sg + lr * 256);
+            else if (GK) glds16_s(G + (size_t)(base >> 4) * 4096 + lr * 256, off_k, sg + lr * 256);
             else glds16_s(G + (size_t)row * 256, off_row, sg + lr * 256);
             if (NT == 8) {
-                if (AK) glds16_s(A + (size_t)(base >> 6) * 16384 + lr * 1024 + (base & 63), off_k, sa + lr * CA);
+                if (AK) glds16_s(A + (size_t)(base >> 4) * 4096 + lr * 256, off_k, sa + lr * CA);
                 else glds16_s(A + (size_t)row * lda, off_row, sa + lr * CA);
             }
         }
@@ -400,7 +404,7 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
 }
 
 
-template <int NT, bool GK = false, bool AK = false>
+template <int NT, int GK = 0, bool AK = false>
 __global__ void __launch_bounds__(512, 1)
 wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
                     int max_rows, float* __restrict__ slab, float* __restrict__ dbias) {
@@ -560,28 +564,32 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     if (max_rows == 0) return SPF_OK;
     if (!G || !A || !dW || !workspace) return spf::fail(SPF_EINVAL, "spf_wgrad: null pointer");
     const int NT = C > 128 ? 8 : (C > 32 ? 4 : 1);
-    const bool gk = layout & SPF_WGRAD_G_TILES, ak = layout & SPF_WGRAD_A_TILES;
-    if (layout & ~(SPF_WGRAD_G_TILES | SPF_WGRAD_A_TILES)) return spf::fail(SPF_EINVAL, "spf_wgrad: unknown layout bits %d", layout);
-    if ((gk || ak) && (arith != SPF_ARITH_SPLIT || NT < 4 || (max_rows % 64) || (ak && C != 256)))
-        return spf::fail(SPF_EINVAL, "spf_wgrad: tiled operands need SPF_ARITH_SPLIT, C > 32, max_rows a multiple of 64 (whole tiles) and, for A, C = 256");
+    const bool g64 = layout & SPF_WGRAD_G_TILES64, gk = (layout & SPF_WGRAD_G_TILES) || g64, ak = layout & SPF_WGRAD_A_TILES;
+    if (layout & ~(SPF_WGRAD_G_TILES | SPF_WGRAD_A_TILES | SPF_WGRAD_G_TILES64)) return spf::fail(SPF_EINVAL, "spf_wgrad: unknown layout bits %d", layout);
+    if ((layout & SPF_WGRAD_G_TILES) && g64) return spf::fail(SPF_EINVAL, "spf_wgrad: G is either in 16-row blocks or in 64-row tiles");
+    if ((gk || ak) && (arith != SPF_ARITH_SPLIT || NT < 4 || (max_rows % (g64 ? 64 : 16)) || (ak && C != 256) || (g64 && C != 256)))
+        return spf::fail(SPF_EINVAL, "spf_wgrad: blocked operands need SPF_ARITH_SPLIT, C > 32, max_rows a multiple of 16 (64 for SPF_WGRAD_G_TILES64: whole "
+                                     "blocks) and C = 256 for a blocked A or 64-row G tiles");
     if (NT >= 4 && ((C % 4) || (lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad: C and lda must be multiples of 4 for C > 32 (C=%d lda=%d)", C, lda);
     hipStream_t s = (hipStream_t)stream;
     int blocks = spf::div_up(max_rows, 512);
     const int cap = NT == 4 ? 512 : 256;   // NT = 4: half the accumulators, two workgroups per CU; else one per CU, one wave per SIMD
     if (blocks > cap) blocks = cap;
     const int per = 4 * 2 * NT * 16 * 64;
-    const int align = (gk || ak) ? 64 : 2;
+    const int align = g64 ? 64 : ((gk || ak) ? 16 : 2);
     if (arith == SPF_ARITH_SPLIT && NT == 8 && C == 256) {
         const int b8 = blocks > 256 ? 256 : blocks;      // one 8-wave workgroup per CU
-        if (gk && ak) wgrad_split8_kernel<8, true, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
-        else if (gk) wgrad_split8_kernel<8, true, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
-        else if (ak) wgrad_split8_kernel<8, false, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        if (g64 && ak) wgrad_split8_kernel<8, 2, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        else if (g64) wgrad_split8_kernel<8, 2, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        else if (gk && ak) wgrad_split8_kernel<8, 1, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        else if (gk) wgrad_split8_kernel<8, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        else if (ak) wgrad_split8_kernel<8, 0, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         else wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         dbias = nullptr;
         wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align);
     } else if (arith == SPF_ARITH_SPLIT && NT == 4) {
         const int b8 = blocks > 256 ? 256 : blocks;
-        if (gk) wgrad_split8_kernel<4, true, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        if (gk) wgrad_split8_kernel<4, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         else wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         dbias = nullptr;
         wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align);

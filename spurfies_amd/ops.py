@@ -333,17 +333,17 @@ class ColorAgg(_GradModeFunction):
         # split-product kernels (the default) leave the bias gradients to the weight-gradient GEMM (column sums of G)
         kb = (lambda b: b) if ctx.arith == 0 else (lambda b: None)
         # the bf16-piece kernels write act1 / act2 / G2 / G1 as K-major tiles (include/spurfies_hip.h: SPF_WGRAD_*_TILES)
-        GT, AT = (WGRAD_G_TILES, WGRAD_A_TILES) if ctx.arith == 0 else (0, 0)
+        GT, AT, G64 = (WGRAD_G_TILES, WGRAD_A_TILES, WGRAD_G_TILES64) if ctx.arith == 0 else (0, 0, 0)
         if sk is not None:
             # layer 0's [256,104] comes in the kernels' internal column order: one index_add_ into the reference order
             sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=GT)[:, :103])
             wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2), layout=GT | AT)
-            wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=GT | AT)
+            wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=G64 | AT)
             return (None,) * 13
         # exact-size (default) and worst-case (sync-free) buffers alike: the weight-gradient kernel reads the row count on the device
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
         dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=GT)[:, :103]   # [256,104] comes in the kernels' internal column order
-        dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2), layout=GT | AT), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4), layout=GT | AT)
+        dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2), layout=GT | AT), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4), layout=G64 | AT)
         grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4)
         return grads + (None,) * 6
 
@@ -568,7 +568,7 @@ def set_wgrad_mode(mode: str):
 
 
 
-WGRAD_G_TILES, WGRAD_A_TILES = 1, 2      # spf_wgrad layout bits: that operand is stored as K-major tiles [tile][256 features][64 rows]
+WGRAD_G_TILES, WGRAD_A_TILES, WGRAD_G_TILES64 = 1, 2, 4      # spf_wgrad layout bits: operand stored as K-major blocks [block][256 features][16 | 64 rows]
 
 
 def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0):

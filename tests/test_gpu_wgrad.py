@@ -115,14 +115,14 @@ def test_three_problems_side_by_side_equal_three_calls(rows):
             ops.set_wgrad_mode("split")
 
 
-def _to_tiles(M):
-    """[rows, 256] (rows a multiple of 64) -> the K-major tile image [tile][256 features][64 rows] the colour kernels write."""
-    t = M.shape[0] // 64
-    return M.view(t, 64, 256).transpose(1, 2).contiguous().view(-1, 256)
+def _to_tiles(M, rows_per_block=16):
+    """[rows, 256] (rows a multiple of the block) -> the K-major image [block][256 features][16 | 64 rows] the colour kernels write."""
+    t = M.shape[0] // rows_per_block
+    return M.view(t, rows_per_block, 256).transpose(1, 2).contiguous().view(-1, 256)
 
 
 @pytest.mark.parametrize("rows", [70001, 1000, 64, 5])
-@pytest.mark.parametrize("layout", [1, 2, 3])
+@pytest.mark.parametrize("layout", [1, 2, 3, 4, 6])
 def test_tiled_operands_match_row_major(rows, layout):
     """SPF_WGRAD_G_TILES / SPF_WGRAD_A_TILES: the same GEMM with one or both operands stored as K-major tiles (what the colour
     trunk's epilogues write) — same accuracy against float64 as the row-major call, incl. a row count inside the last tile."""
@@ -135,13 +135,13 @@ def test_tiled_operands_match_row_major(rows, layout):
     n = torch.tensor([rows], dtype=torch.int32, device="cuda")
     ref = G[:rows].double().t() @ A[:rows].double()
     db_ref = G[:rows].double().sum(0)
-    Gx = _to_tiles(G) if layout & 1 else G
+    Gx = _to_tiles(G) if layout & 1 else (_to_tiles(G, 64) if layout & 4 else G)
     Ax = _to_tiles(A) if layout & 2 else A
     db = torch.zeros(256, device="cuda")
     got = ops.wgrad(Gx, Ax, n, dbias=db, layout=layout)
     base = ops.wgrad(G, A, n)
     assert _err(got, ref) < 2e-6 + 2.0 * _err(base, ref)
-    np.testing.assert_allclose(db.double().cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(db.double().cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-5, atol=2e-5 * rows ** 0.5 + 1e-5)     # fp32 sums of `rows` N(0,1) terms, atomics in any order
     if layout == 1:          # the 104-column operand of F_color's first layer stays row-major next to a tiled G
         A104 = A[:, :104].contiguous()
         got4 = ops.wgrad(Gx, A104, n, layout=1)

@@ -9,7 +9,7 @@ out = cb.fwd_train()
 wn, pk, act0, act1, act2, masks = out.grad_fn.saved_tensors
 tiles = masks.shape[0]
 w4, b4 = cb.fcp[4].detach(), cb.fcp[5].detach()
-a2 = act2.view(tiles, 256, 64).transpose(1, 2).reshape(-1, 256)          # K-major tiles -> rows
+a2 = act2.view(tiles * 4, 256, 16).transpose(1, 2).reshape(-1, 256)          # K-major 16-row blocks -> rows
 h3 = a2 @ w4.t() + b4
 NP = cb.NP
 m = masks.view(tiles, 3, 512)[:, 2, :].reshape(tiles * 64, 8)          # [row][8 words]
