@@ -33,6 +33,9 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6                      # dense bf16 MFMA: 256 CUs x
 # The dominant kernel forms every fp32 product exactly from 6 bf16 piece products: its matrix-pipe ceiling in
 # ALGORITHMIC (fp32) FLOP/s is the bf16 peak / 6.
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_HBM_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+F_COLOR_FWD = 2.0 * (103 * 256 + 2 * 256 * 256)     # F_color's three activated layers, per pair (the linear fourth runs per point)
+F_COLOR_BWD = 2.0 * (2 * 256 * 256 + 256 * 64)      # data-gradient chain of the same, per pair (weight gradients: spf_wgrad)
 
 
 def parse():
@@ -40,9 +43,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (config/ours.yaml:14 num_pixels)")
+    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (config/ours.yaml:14 num_pixels); weak scaling")
+    ap.add_argument("--global-rays", type=int, default=0, help="strong scaling: ONE batch of this many rays per step, rank r renders rays r::N of it "
+                    "(SURVEY.md section 8(e)); 0 = weak scaling with --rays per GPU")
     ap.add_argument("--points", type=int, default=10000, help="neural points (DTU-like cloud)")
     ap.add_argument("--spacing", type=float, default=0.025, help="nearest-neighbour spacing of the synthetic cloud (0.0125 = dense stress cloud)")
+    ap.add_argument("--prior", choices=["fitted", "kaiming"], default="fitted", help="fitted: F_geometry/T + latents reproduce the signed distance to the "
+                    "analytic surface (realistic sampler convergence / pair counts, SURVEY.md section 8(d)); kaiming: random prior (round-1 scene)")
+    ap.add_argument("--scenes", type=int, default=1, help="BASELINE.json configs[3]: this many scenes optimised concurrently on the same ray-sharded "
+                    "group (round-robin, no cross-scene collective); a step = one round over all scenes")
+    ap.add_argument("--sustained", type=int, default=200, help="extra steps timed after the contract region (sustained clocks); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync", action="store_true", help="default (reference-shaped) step with one host read-back per step")
     ap.add_argument("--graph", action="store_true", help="replay forward + loss + backward as one hipGraph (measured no faster than the eager sync-free "
@@ -52,11 +62,11 @@ def parse():
     return ap.parse_args()
 
 
-def make_batches(scene, n_steps, rays_total, rank, world, device):
-    """Seeded synthetic batches, resident on the device before the timed region."""
+def make_batches(scene, n_steps, rays_total, rank, world, device, seed=12345):
+    """Seeded synthetic batches of `rays_total` rays, resident on the device before the timed region; rank r keeps rays r::world."""
     from spurfies_amd import synthetic as syn
 
-    g = torch.Generator().manual_seed(12345)
+    g = torch.Generator().manual_seed(seed)
     K = torch.from_numpy(scene["intrinsics"])[None].to(device)
     out = []
     for s in range(n_steps):
@@ -71,27 +81,53 @@ def make_batches(scene, n_steps, rays_total, rank, world, device):
 
 
 def cpu_baseline(scene, n_rays):
-    """The oracle (CPU restatement of the reference's PyTorch path, validated against the reference
-    through tests/golden) timed on this box's host cores on a bounded sample of the same workload."""
+    """The oracle (CPU restatement of the reference's PyTorch path, pinned to the reference through tests/golden) timed on this box's
+    host cores on a bounded sample of the same workload: full optimisation steps (forward, loss, backward, clip, Adam — train.py:330-363)
+    with (i) one thread, as the reference itself pins (train.py:24), and (ii) the host's cores."""
     from oracle import path as P
     from spurfies_amd import synthetic as syn
 
-    cores = min(os.cpu_count() or 1, 8)   # more intra-op threads only slow these small CPU ops down
-    torch.set_num_threads(cores)
-    st = P.load_state(scene["state"])
     cfg = P.PathConfig(ranges=tuple(scene["ranges"]))
-    grid = P.make_grid(cfg, st["neural_pts"])
     g = torch.Generator().manual_seed(999)
-    uv = torch.from_numpy(syn.make_pixels(n_rays, g))[None]
-    inp = {"intrinsics": torch.from_numpy(scene["intrinsics"])[None], "uv": uv, "pose": torch.from_numpy(scene["poses"][0])[None]}
-    rgb, mask = torch.rand((n_rays, 3), generator=g), torch.ones(n_rays)
-    n_steps = 2
-    t0 = time.time()
-    for _ in range(n_steps):
-        P.train_step_grads(inp, rgb, mask, st, cfg, grid=grid)
-    dt = time.time() - t0
-    return {"value": SAMPLES_PER_RAY * n_rays * n_steps / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n_steps} train steps (fwd+bwd, no optimiser) of {n_rays} rays on the same cloud, {dt:.1f} s"}
+
+    def run(threads, rays, n_steps):
+        torch.set_num_threads(threads)
+        st = P.load_state(scene["state"])
+        grid = P.make_grid(cfg, st["neural_pts"])
+        opt, sched = P.make_optimizer(st)
+        uv = torch.from_numpy(syn.make_pixels(rays, g))[None]
+        inp = {"intrinsics": torch.from_numpy(scene["intrinsics"])[None], "uv": uv, "pose": torch.from_numpy(scene["poses"][0])[None]}
+        rgb, mask = torch.rand((rays, 3), generator=g), torch.ones(rays)
+        t0 = time.time()
+        for _ in range(n_steps):
+            P.train_step_grads(inp, rgb, mask, st, cfg, grid=grid)
+            P.optimizer_step(st, opt, sched)
+        dt = time.time() - t0
+        return SAMPLES_PER_RAY * rays * n_steps / dt, dt
+
+    cores = min(os.cpu_count() or 1, 8)   # more intra-op threads only slow these small CPU ops down
+    v_all, t_all = run(cores, n_rays, 2)
+    r1 = max(64, n_rays // 4)
+    v_one, t_one = run(1, r1, 1)
+    torch.set_num_threads(cores)
+    return {"value": v_all, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+            "sample": f"2 optimisation steps (fwd+loss+bwd+clip+Adam) of {n_rays} rays on the same scene, {t_all:.1f} s on {cores} threads",
+            "single_thread": {"value": v_one, "unit": "ray-samples/s", "cores": 1,
+                              "sample": f"1 optimisation step of {r1} rays, {t_one:.1f} s (the reference pins torch.set_num_threads(1), train.py:24)"}}
+
+
+def build_scene_step(args, seed, device, world, use_graph):
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.conf import default_model_conf
+    from spurfies_amd.model.pointneus_disent import PointVolSDF
+    from spurfies_amd.train import TrainStep
+
+    scene = syn.make_scene(args.points, seed=seed, spacing=args.spacing, prior=args.prior)
+    st = scene["state"]
+    conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
+    model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
+    model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
+    return scene, model, TrainStep(model, sync_free=not args.sync, use_graph=use_graph)
 
 
 def main():
@@ -113,36 +149,41 @@ def main():
         else:
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
-    from spurfies_amd import ops, synthetic as syn
-    from spurfies_amd.conf import default_model_conf
-    from spurfies_amd.model.pointneus_disent import PointVolSDF
-    from spurfies_amd.train import TrainStep
+    from spurfies_amd import ops
+    from spurfies_amd.train import MultiSceneTrainer
 
+    strong = args.global_rays > 0
+    if strong and args.global_rays % world:
+        raise SystemExit(f"--global-rays {args.global_rays} must be a multiple of the {world} ranks")
+    rays_total = args.global_rays if strong else args.rays * world
+    rays_local = rays_total // world
     torch.manual_seed(0)
-    scene = syn.make_scene(args.points, seed=0, spacing=args.spacing)
-    st = scene["state"]
-    conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
-    model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
-    model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
-    use_graph = args.graph and not args.sync and world == 1
-    step = TrainStep(model, sync_free=not args.sync, use_graph=use_graph)
-    rays_total = args.rays * world
-    batches = make_batches(scene, args.warmup + args.steps, rays_total, rank, world, device)
+    use_graph = args.graph and not args.sync and world == 1 and args.scenes == 1
+    scenes = [build_scene_step(args, seed, device, world, use_graph) for seed in range(args.scenes)]
+    scene, model, step = scenes[0]
+    n_batches = args.warmup + args.steps + max(args.sustained, 0)
+    batches = [make_batches(sc, min(n_batches, 64), rays_total, rank, world, device, seed=12345 + i) for i, (sc, _, _) in enumerate(scenes)]
+    multi = MultiSceneTrainer([st for _, _, st in scenes], n_streams=2, device=device) if args.scenes > 1 else None
+
+    def run_step(i):
+        if multi is not None:
+            return multi.step([b[i % len(b)] for b in batches])[0], None
+        return step(*batches[0][i % len(batches[0])])
 
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    torch.manual_seed(1 + rank * 0)   # identical CPU draws on every rank (stratified jitter is per ray anyway)
+    torch.manual_seed(1)          # the same CPU-generator stream on every rank: each draws batch-wide and keeps its rays' rows
     for i in range(args.warmup):
-        step(*batches[i])
+        run_step(i)
     if not use_graph:
-        ops.profile_start()          # HIP events around every spf_geo_forward launch of the timed region
+        ops.profile_start()          # HIP events around the profiled launches of the timed region
     sync()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
-        losses, out = step(*batches[i])
+        losses, out = run_step(i)
     sync()
     dt = time.perf_counter() - t0
     loss_last = float(losses["loss"].item())
@@ -151,25 +192,38 @@ def main():
         # the SAME batches right after the timed region (same kernels, same inputs; no optimiser step)
         ops.profile_start()
         for i in range(args.warmup, args.warmup + args.steps):
-            step._forward_backward(dict(batches[i][0]), batches[i][1])
+            step._forward_backward(dict(batches[0][i][0]), batches[0][i][1])
         sync()
     prof = ops.profile_stop()
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
+    sustained = None
+    if args.sustained > 0:        # clocks settle under a continuous load: the same step over a >= 1 s region, reported beside the contract region
+        sync()
+        t1 = time.perf_counter()
+        for i in range(args.warmup + args.steps, args.warmup + args.steps + args.sustained):
+            run_step(i)
+        sync()
+        ts = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
+        sustained = float(ts.item()) / args.sustained * 1e3
 
-    # dominant kernel: geo_pairs_kernel<true> of the main pass (the largest with-Jacobian launch per step)
-    main = [p for p in prof if p["with_grad"] and p["rows"] >= args.rays * 2]
+    # ---- roofline: dominant kernel = geo_pairs_x3_kernel<true> of the main pass (the largest with-Jacobian launch per step) ----
+    geo = [p for p in prof if p["tag"] == "geo"]
+    main = [p for p in geo if p["with_grad"] and p["rows"] >= rays_local * 2]
     roof = None
-    traffic = None   # HBM bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process)
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc))
-        if rec["config"] == {"points": args.points, "rays": args.rays}:
-            hit = [v for k, v in rec["kernels"].items() if "geo_pairs_x3_kernel<true>" in k] or \
-                  [v for k, v in rec["kernels"].items() if "geo_pairs_kernel<true>" in k]
-            traffic = hit[0]["hbm_bytes_max_corrected"] if hit else None
+    traffic, traffic_src = None, None   # HBM bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process)
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if traffic is None and os.path.exists(pmc):
+            rec = json.load(open(pmc))
+            if rec["config"].get("points") == args.points and rec["config"].get("rays") == rays_local and rec["config"].get("prior", "kaiming") == args.prior:
+                hit = [v for k, v in rec["kernels"].items() if "geo_pairs_x3_kernel<true>" in k]
+                if hit:
+                    traffic, traffic_src = hit[0]["hbm_bytes_max_corrected"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     if main:
         ms = sum(p["ms"] for p in main)
         pairs = sum(p["pairs"] for p in main)
@@ -181,23 +235,30 @@ def main():
                 "power_envelope_note": "peak is the 2.4 GHz data-sheet figure; the library's GEMM loop alone (tools/micro/x3_loop_rate.hip) holds 1.53 GHz "
                                        "at 90 % matrix-pipe duty and 2.2 GHz at 66-76 %, i.e. 240-290 algorithmic TFLOP/s is what this instruction mix "
                                        "can draw (DESIGN.md section 6)",
-                "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-                if traffic else None, "kernel": "geo_pairs_x3_kernel<true> (+ geo_point_reduce_kernel, < 1 % of the launch)",
+                "traffic": traffic, "traffic_source": traffic_src, "kernel": "geo_pairs_x3_kernel<true> (+ geo_point_reduce_kernel, < 1 % of the launch)",
                 "timing": ("HIP events over eager passes of the timed batches, right after the timed region (events cannot sit inside a "
                            "hipGraph replay)") if use_graph else "HIP events over the timed region", "launches": len(main), "avg_ms": ms / len(main),
-                "pairs_per_launch": pairs / len(main)}
+                "pairs_per_launch": pairs / len(main), "flop_per_pair": F_FWD + F_JAC}
+        roof["secondary"] = secondary_rooflines(prof, rays_local)
+    spr = SAMPLES_PER_RAY * rays_total * args.scenes
+    counts = model.stats.get("counts")
     res = {
-        "metric": "ray-samples/sec (kNN+SDF+render, train step)", "value": SAMPLES_PER_RAY * rays_total * args.steps / dt,
+        "metric": "ray-samples/sec (kNN+SDF+render, train step)", "value": spr * args.steps / dt,
         "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[1] shape (DTU scan24 3-view optimisation, 1024-ray batches) on a synthetic scene: {args.points} neural points, {args.rays} rays/GPU/step x "
-                               f"(128 sampler + 98 main) samples, fast=1 optimisation step (fwd+bwd+clip+Adam)",
-                   "rays_per_gpu": args.rays, "neural_points": args.points, "k": 8, "max_shading_pts": 80,
-                   "parallelism": f"ray-sharded dp{world}", "valid_points_last_step": model.stats.get("valid_points", int(model.stats["counts"][0].item()) if "counts" in model.stats else None),
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"BASELINE.json configs[3] shape: {args.scenes} scenes optimised concurrently (round-robin, one ray-sharded group), each " if args.scenes > 1 else
+                                "BASELINE.json configs[1] shape (DTU scan24 3-view optimisation, 1024-ray batches) on a synthetic scene: ") +
+                               f"{args.points} neural points, {rays_total} rays/step over {world} GPU(s) x (128 sampler + 98 main) samples, fast=1 optimisation step "
+                               f"(fwd+bwd+clip+Adam); prior = {args.prior}",
+                   "rays_per_gpu": rays_local, "rays_per_step": rays_total, "scenes": args.scenes, "neural_points": args.points, "k": 8, "max_shading_pts": 80,
+                   "prior": args.prior, "parallelism": f"ray-sharded dp{world}",
+                   "valid_points_last_step": model.stats.get("valid_points", int(counts[0].item()) if counts is not None else None),
+                   "pairs_last_step": model.stats.get("pairs", int(counts[1].item()) if counts is not None else None),
                    "host_syncs_per_step": 1 if args.sync else 0,
                    "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product exactly from three bf16 pieces per operand (6 bf16 MFMAs, fp32 accumulate)",
                    "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~91 per step)")},
         "roofline": roof,
+        "sustained_ms_per_step": sustained, "sustained_steps": args.sustained if sustained is not None else 0,
         "loss_last": loss_last,
     }
     if rank == 0:
@@ -206,6 +267,37 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def secondary_rooflines(prof, rays_local):
+    """The other regimes of the step, same HIP events: the colour-trunk kernels against the same MFMA ceiling, the kNN and
+    compositing kernels against HBM (algorithmic bytes / time / 8 TB/s)."""
+    out = []
+
+    def mean(rows, key):
+        return sum(r[key] for r in rows) / len(rows)
+
+    for tag, flop, name in (("color_fwd", F_COLOR_FWD, "color_forward_x3_kernel<true>"), ("color_bwd", F_COLOR_BWD, "color_backward_x3_kernel")):
+        rows = [p for p in prof if p["tag"] == tag and p["pairs"] > 0]
+        if rows:
+            ach = sum(p["pairs"] for p in rows) * flop / (sum(p["ms"] for p in rows) * 1e-3) / 1e12
+            out.append({"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
+                        "avg_ms": mean(rows, "ms"), "pairs_per_launch": mean(rows, "pairs"), "flop_per_pair": flop})
+    knn = [p for p in prof if p["tag"] == "knn" and p["slots"] > 1 and p["rays"] == rays_local]        # the main pass (98 samples/ray, SR = 80)
+    if knn:
+        # 12 B position in + 1 B mask out per sample; per hit slot 4 k B of indices + 16 B (location, sample id) out (SURVEY.md section 8(d))
+        byts = [p["rays"] * p["samples_per_ray"] * 13.0 + p["hit_slots"] * (4.0 * p["k"] + 16.0) for p in knn]
+        ach = sum(byts) / (sum(p["ms"] for p in knn) * 1e-3) / 1e9
+        out.append({"kernel": "spf_grid_query, main pass (point_slots + hit_slots + knn + ray_valid kernels)", "bound": "hbm", "achieved": ach,
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "avg_ms": mean(knn, "ms"), "hit_slots_per_launch": mean(knn, "hit_slots"),
+                    "note": "latency-bound at this size (1e5 samples): ~100 candidate reads per hit slot are L2 hits, not HBM traffic"})
+    for tag, bps, name in (("render_fwd", 29.0, "render_forward_kernel"), ("render_bwd", 45.0, "render_backward_kernel")):
+        rows = [p for p in prof if p["tag"] == tag]
+        if rows:
+            ach = sum(p["rays"] * p["slots"] * bps for p in rows) / (sum(p["ms"] for p in rows) * 1e-3) / 1e9
+            out.append({"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                        "avg_ms": mean(rows, "ms"), "bytes_per_slot": bps, "note": "launch-latency-bound: 1024 rays x 80 slots is ~3 MB"})
+    return out
 
 
 if __name__ == "__main__":

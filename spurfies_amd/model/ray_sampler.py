@@ -66,6 +66,7 @@ class ErrorBoundSampler_pn(RaySampler):
         self.add_tiny = add_tiny
         self.last_iters = 0
         self.last_points = None
+        self.shard = None   # (rank, world) for ray-sharded batches: CPU-generator draws are made for the whole batch, this rank's rows kept
         self.draws = None   # sync-free / graph mode: {'t_rand' [R,128], 'u' [R,N_samples], 'sel' int32 [N_extra]} device tensors the
         #                     caller fills from the CPU generator (same calls, same order) before every step
         # Lemma-2 constant exactly as the reference forms it in float32 (ray_sampler.py:389)
@@ -77,6 +78,14 @@ class ErrorBoundSampler_pn(RaySampler):
         if key not in self._lin:
             self._lin[key] = torch.linspace(0.0, 1.0, steps=n).to(dev)
         return self._lin[key]
+
+    def _rand_rows(self, R, n):
+        """torch.rand([R, n]) from the CPU generator; for a ray-sharded batch the draw covers all ranks' rays and this rank keeps
+        rows rank::world (the order dist.shard_rays deals rays out), so the generator advances as in a single-GPU run."""
+        if self.shard is None:
+            return torch.rand((R, n))
+        rank, world = self.shard
+        return torch.rand((R * world, n))[rank::world].contiguous()
 
     def get_z_vals(self, ray_dirs, cam_loc, model, fast=-1, iter_step=None):
         """Same contract as the reference (:377-574): returns (z_vals [R, N_samples + 2 + N_samples_extra], z_samples_eik).
@@ -94,7 +103,7 @@ class ErrorBoundSampler_pn(RaySampler):
         if ext is not None:
             t_rand = ext["t_rand"]
         else:
-            t_rand = torch.rand((R, n0)).to(dev) if model.training else None  # CPU generator, as the reference (:55)
+            t_rand = self._rand_rows(R, n0).to(dev) if model.training else None  # CPU generator, as the reference (:55)
         z_vals, points = ops.sampler_uniform(self._linspace(n0, dev), t_rand, cam_loc, ray_dirs, self.near, self.far)
         samples, samples_idx, sdf, beta = z_vals, None, None, None
         total_iters, not_converge = 0, True
@@ -122,7 +131,7 @@ class ErrorBoundSampler_pn(RaySampler):
                 if not model.training:
                     u = self._linspace(N, dev)
                 else:
-                    u = ext["u"] if ext is not None else torch.rand([R, N]).to(dev).contiguous()
+                    u = ext["u"] if ext is not None else self._rand_rows(R, N).to(dev).contiguous()
             samples, beta, zm, mi = ops.sampler_iter(z_vals, sdf, beta, beta0, self.eps, self._bound_coef, iters_left, more, self.add_tiny, u, N)
             if more:
                 z_vals, samples_idx = zm, mi.long()
@@ -142,6 +151,7 @@ class ErrorBoundSampler_pn(RaySampler):
         z_out, self.last_points = ops.sampler_finish(samples.contiguous(), z_vals, sel, self.near, self.far, cam_loc, ray_dirs)
         if ext is not None:
             return z_out, None                                            # the caller drew (and dropped) the eikonal index
-        idx = torch.randint(z_out.shape[-1], (z_out.shape[0],)).to(dev)   # consumes the generator like :562
+        rank, world = self.shard if (self.shard is not None and model.training) else (0, 1)
+        idx = torch.randint(z_out.shape[-1], (z_out.shape[0] * world,))[rank::world].to(dev)   # consumes the generator like :562
         z_samples_eik = torch.gather(z_out, 1, idx.unsqueeze(-1))
         return z_out, z_samples_eik

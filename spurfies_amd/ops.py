@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib
+from . import _lib, _prof
 
 SDF_FILL = 1000.0  # pointneus_disent.py:271,371,445,703
 
@@ -22,22 +22,15 @@ def _sink(p):
     g = getattr(p, "_spf_grad_sink", None)
     return g if (g is not None and g.shape == p.shape and g.is_contiguous() and g.device == p.device) else None
 
-# ---- optional per-launch timing of the fused geometry kernel (bench.py roofline) -----------------
-_prof = None
-
-
+# ---- optional per-launch timing (bench.py roofline): spurfies_amd/_prof.py -----------------------
 def profile_start():
-    global _prof
-    _prof = []
+    _prof.start()
 
 
 def profile_stop():
-    """-> [{'ms', 'pairs', 'rows', 'with_grad'}] per spf_geo_forward launch since profile_start()."""
-    global _prof
-    rec, _prof = _prof or [], None
-    torch.cuda.synchronize()
-    return [{"ms": e0.elapsed_time(e1), "pairs": int(npairs.item()), "rows": rows, "with_grad": wg}
-            for e0, e1, npairs, rows, wg in rec]
+    """-> [{'tag', 'ms', ...}] per profiled launch since profile_start(): 'geo' (pairs, rows, with_grad), 'knn' (rays, samples_per_ray,
+    slots, hits), 'render_fwd' / 'render_bwd' (rays, slots), 'color_fwd' / 'color_bwd' (pairs)."""
+    return _prof.stop()
 
 
 
@@ -124,17 +117,11 @@ def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_ou
     grad = torch.zeros((rows, 3), dtype=torch.float32, device=dev) if with_grad else None
     jac = torch.empty((pl.max_pairs, 32), dtype=torch.float32, device=dev) if with_grad else None
     tmp = torch.empty((pl.max_pairs, 5), dtype=torch.float32, device=dev)
-    if _prof is not None:  # HIP events on the launch stream (torch's current stream is the one passed to the kernel)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _prof.span("geo", pairs=pl.n_pairs, rows=rows, with_grad=bool(with_grad)):
         _lib.check(_lib.lib().spf_geo_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off), _lib.ptr(pl.pair_point),
                                               _lib.ptr(pl.n_points), _lib.ptr(pl.n_pairs), pl.max_points, pl.max_pairs, pl.k, _lib.ptr(pts),
                                               _lib.ptr(feat_geo), _lib.ptr(packed), float(rbf), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(wn),
                                               _lib.ptr(jac), _lib.ptr(tmp), _ARITH["geo"], _lib.stream_ptr()), "spf_geo_forward")
-    if _prof is not None:
-        e1.record()
-        _prof.append((e0, e1, pl.n_pairs, rows, bool(with_grad)))
     return {"sdf": sdf, "wn": wn, "grad": grad, "jac": jac}
 
 
@@ -297,7 +284,7 @@ class ColorAgg(_GradModeFunction):
                     torch.empty((rows, 256), dtype=torch.float32, device=dev), torch.empty((tiles, 3, 512), dtype=torch.int32, device=dev)]
         else:
             bufs = [None] * 4
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _prof.span("color_fwd", pairs=pl.n_pairs, train=bool(train)):
             _lib.check(_lib.lib().spf_color_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                     _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), NP, pl.k, _lib.ptr(pts),
                                                     _lib.ptr(feat_col.detach()), _lib.ptr(packed), _lib.ptr(agg3),
@@ -325,7 +312,7 @@ class ColorAgg(_GradModeFunction):
             g_b0, g_b2, g_b4 = g_bias[0], g_bias[1], g_bias[2]
             g_feat = torch.zeros((ctx.n_table, 64), dtype=torch.float32, device=dev)
         g_agg3 = g_agg3.contiguous()
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _prof.span("color_bwd", pairs=pl.n_pairs):
             _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg3), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                      _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), ctx.NP, pl.k, _lib.ptr(packed), _lib.ptr(masks),
                                                      _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_b4),
@@ -381,7 +368,7 @@ class Render(torch.autograd.Function):
         depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
         dist = torch.empty((R,), dtype=torch.float32, device=dev)
         acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _prof.span("render_fwd", rays=R, slots=SR):
             _lib.check(_lib.lib().spf_render_forward(_lib.ptr(sdf_c), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(col_c),
                                                      _lib.ptr(beta_c), R, SR, _lib.ptr(weights), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(dist),
                                                      _lib.ptr(acc), _lib.stream_ptr()), "spf_render_forward")
@@ -410,7 +397,7 @@ class Render(torch.autograd.Function):
         g_col = torch.empty((R, SR, 3), dtype=torch.float32, device=dev)
         sink = ctx.beta_sink
         g_beta = sink.reshape(1) if sink is not None else torch.zeros((1,), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _prof.span("render_bwd", rays=R, slots=SR):
             _lib.check(_lib.lib().spf_render_backward(_lib.ptr(sdf), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(colors),
                                                       _lib.ptr(beta), _lib.ptr(weights), _lib.ptr(gw), _lib.ptr(g_rgb), _lib.ptr(g_depth),
                                                       _lib.ptr(g_dist), R, SR, _lib.ptr(g_sdf), _lib.ptr(g_col), _lib.ptr(g_beta),
@@ -580,7 +567,7 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0):
         out = torch.zeros((256, C), dtype=torch.float32, device=dev)
     ldw = out.stride(0) if ldw is None else ldw
     nws = int(_lib.lib().spf_wgrad_workspace_floats(C))
-    key = (dev.index, nws)
+    key = (dev.index, nws, torch.cuda.current_stream(dev).cuda_stream)      # scenes stepped on different streams must not share scratch
     if key not in _wgrad_ws:
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -603,7 +590,7 @@ def wgrad_batched(problems, n_rows):
         rows = min(G.shape[0], A.shape[0])
         max_rows = rows if max_rows is None else min(max_rows, rows)
     nws = int(_lib.lib().spf_wgrad_workspace_floats(256)) * len(problems)
-    key = (dev.index, nws)
+    key = (dev.index, nws, torch.cuda.current_stream(dev).cuda_stream)
     if key not in _wgrad_ws:
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -648,7 +635,7 @@ class FusedLoss(torch.autograd.Function):
         rgb_c, acc_c = rgb.detach().contiguous(), acc.detach().reshape(R).contiguous()
         psdf_c = None if psdf is None else psdf.detach().reshape(R).contiguous()
         tv_c = None if tv is None else tv.detach().reshape(1)
-        key = str(dev)
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
         if key not in _loss_ws:
             _loss_ws[key] = torch.empty((int(_lib.lib().spf_loss_workspace_floats()),), dtype=torch.float32, device=dev)
         total = torch.empty((), dtype=torch.float32, device=dev)

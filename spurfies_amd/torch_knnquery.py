@@ -14,7 +14,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, _prof
 
 
 class VoxelGrid:
@@ -96,7 +96,7 @@ class VoxelGrid:
             "slot_valid": torch.empty((R, SR), dtype=torch.uint8, device=dev),
             "ray_valid": torch.empty((R,), dtype=torch.uint8, device=dev),
         }
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _prof.span("knn", rays=R, samples_per_ray=D, slots=SR, k=k, hit_slots=out["slot_valid"]):
             _lib.check(_lib.lib().spf_grid_query(self._h, _lib.ptr(x), R, D, k, float(radius_limit_scale), SR,
                                                  _lib.ptr(out["pidx"]), _lib.ptr(out["loc"]), _lib.ptr(out["slot_sample"]),
                                                  _lib.ptr(out["slot_valid"]), _lib.ptr(out["ray_valid"]), _lib.stream_ptr()),

@@ -47,6 +47,10 @@ class TrainStep:
         self.grad_clip = grad_clip
         self.group = process_group
         self.world = sdist.world_size(process_group)
+        self.rank = sdist.rank(process_group)
+        # ray-sharded batches: every rank issues the reference's CPU-generator calls for the WHOLE batch (same seed, same order) and
+        # keeps the rows of its own rays (rank::world, dist.shard_rays), so N ranks over a batch consume exactly the draws one GPU would
+        model.ray_sampler.shard = (self.rank, self.world) if self.world > 1 else None
         if self.world > 1:
             # the all-reduce sums gradients only: replicas must START identical (latents and MLPs are drawn from the local
             # generators in the constructors).  Rank 0's parameters, frozen prior and cloud win.
@@ -149,14 +153,55 @@ class TrainStep:
         pinned_flat, pinned, ev = self._pinned_ring[slot]
         if self._pinned_used[slot]:
             ev.synchronize()                         # the copy that last read this buffer has completed (normally long ago)
-        torch.rand((R, n0), out=pinned["t_rand"])
-        torch.rand((R, N), out=pinned["u"])
+        if self.world > 1:                           # batch-wide draws, this rank's rows
+            pinned["t_rand"].copy_(torch.rand((R * self.world, n0))[self.rank::self.world])
+            pinned["u"].copy_(torch.rand((R * self.world, N))[self.rank::self.world])
+        else:
+            torch.rand((R, n0), out=pinned["t_rand"])
+            torch.rand((R, N), out=pinned["u"])
         pinned["sel"].copy_(torch.randperm(n0)[:Ne])
-        torch.randint(M, (R,))                       # the unused eikonal index (:562) — keeps the generator in step
+        torch.randint(M, (R * self.world,))          # the unused eikonal index (:562) — keeps the generator in step
         self._draws_flat.copy_(pinned_flat, non_blocking=True)
         ev.record(torch.cuda.current_stream(dev))
         self._pinned_used[slot] = True
         s.draws = self._draws
+
+
+class MultiSceneTrainer:
+    """BASELINE.json configs[3]: several scenes optimised concurrently on ONE ray-sharded process group — S independent
+    (model, TrainStep) pairs, stepped round-robin; no collective ever mixes scenes (each step's flat-gradient all-reduce belongs to
+    its own scene).  Scenes alternate between `n_streams` HIP streams, so one scene's gradient all-reduce overlaps the next
+    scene's kernels; a scene always runs on the same stream, which keeps its own steps ordered."""
+
+    def __init__(self, steps, n_streams=2, device=None):
+        self.steps = list(steps)
+        self.device = device
+        cuda = device is not None and torch.device(device).type == "cuda"
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))] if cuda else [None]
+        self.order = []                                  # (round, scene) log of the last call, for tests
+
+    def __len__(self):
+        return len(self.steps)
+
+    def step(self, batches):
+        """batches[s] = (model_input, ground_truth) of scene s for this round -> [loss dict per scene]."""
+        if len(batches) != len(self.steps):
+            raise ValueError(f"{len(batches)} batches for {len(self.steps)} scenes")
+        out, self.order = [], []
+        cur = torch.cuda.current_stream(self.device) if self.streams[0] is not None else None
+        for s, (step, batch) in enumerate(zip(self.steps, batches)):
+            st = self.streams[s % len(self.streams)]
+            self.order.append(s)
+            if st is None:
+                out.append(step(*batch)[0])
+                continue
+            st.wait_stream(cur)                          # inputs prepared on the caller's stream
+            with torch.cuda.stream(st):
+                out.append(step(*batch)[0])
+        if cur is not None:
+            for st in self.streams:
+                cur.wait_stream(st)
+        return out
 
 
 # ---------------------------------------------------------------------------------------------------------------

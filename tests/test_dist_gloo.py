@@ -104,3 +104,28 @@ def test_single_process_helpers():
     assert sdist.shard_rays(5).tolist() == [0, 1, 2, 3, 4]
     t = torch.ones(3)
     assert sdist.all_reduce_sum(t) is t
+
+
+def test_multi_scene_trainer_round_robin_cpu():
+    """BASELINE.json configs[3] driver logic without a GPU: every scene's step callable sees exactly its own batch, once per round,
+    in scene order; a batch-count mismatch is refused."""
+    import pytest
+
+    from spurfies_amd.train import MultiSceneTrainer
+
+    seen = []
+
+    def make(s):
+        def step(inp, gt):
+            seen.append((s, inp, gt))
+            return {"loss": torch.tensor(float(s))}, None
+        return step
+
+    multi = MultiSceneTrainer([make(s) for s in range(11)], n_streams=2, device=None)
+    assert len(multi) == 11
+    for rnd in range(2):
+        out = multi.step([(f"in{s}.{rnd}", f"gt{s}.{rnd}") for s in range(11)])
+        assert [float(o["loss"]) for o in out] == [float(s) for s in range(11)]
+    assert seen == [(s, f"in{s}.{r}", f"gt{s}.{r}") for r in range(2) for s in range(11)]
+    with pytest.raises(ValueError):
+        multi.step([("a", "b")])

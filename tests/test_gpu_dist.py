@@ -41,22 +41,6 @@ def _setup_model():
     return model, uv, rgb, mask, K, pose
 
 
-def _patch_draws(rank, world):
-    """Every rank draws the batch-wide CPU random numbers and keeps its rays' rows, so that ranks and the
-    single-process run see identical per-ray draws."""
-    orig = torch.rand
-
-    def rand(*shape, **kw):
-        shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
-        if len(shp) == 2 and shp[0] == R_TOTAL // world and world > 1:
-            out = kw.pop("out", None)                 # the sync-free step draws into pinned buffers
-            mine = orig((R_TOTAL, shp[1]), **kw)[rank::world].contiguous()
-            return mine if out is None else out.copy_(mine)
-        return orig(*shape, **kw)
-
-    torch.rand = rand
-
-
 def _run_step(rank, world, sync_free=False):
     from spurfies_amd import dist as sdist
     from spurfies_amd.train import TrainStep
@@ -64,8 +48,7 @@ def _run_step(rank, world, sync_free=False):
     model, uv, rgb, mask, K, pose = _setup_model()
     step = TrainStep(model, sync_free=sync_free)
     sel = sdist.shard_rays(R_TOTAL)
-    torch.manual_seed(21)
-    _patch_draws(rank, world)
+    torch.manual_seed(21)        # the same CPU-generator stream everywhere: each rank draws batch-wide and keeps its rays' rows (TrainStep)
     losses, _ = step({"intrinsics": K, "uv": uv[sel][None].cuda(), "pose": pose, "local_data": None},
                      {"rgb": rgb[sel][None].cuda(), "mask": mask[sel][None, :, None].repeat(1, 1, 3).cuda()})
     # TrainStep clipped + zero-guarded the flat buffer in place; recover the raw summed gradient direction
@@ -74,10 +57,14 @@ def _run_step(rank, world, sync_free=False):
     return total.item(), step.flat.buffer.detach().cpu().numpy()
 
 
-def _worker(rank, world, port, q, sync_free=False):
+def _worker(rank, world, port, q, sync_free=False, backend="gloo"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.cuda.set_device(0)
-    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":            # RCCL: one rank per GPU
+        torch.cuda.set_device(rank)
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     try:
         q.put((rank,) + _run_step(rank, world, sync_free))
     finally:
@@ -105,14 +92,107 @@ def test_two_ranks_on_one_gpu_match_single_process(sync_free):
     np.testing.assert_array_equal(res[0][2], res[1][2])   # replicas stay bit-identical after the all-reduce
 
 
-def test_bench_under_torchrun_two_ranks_gloo():
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the test box has one; the driver's 8-GPU node runs this)")
+def test_two_ranks_rccl_match_single_process():
+    """The same check over the real backend: backend "nccl" = RCCL over xGMI, one rank per GPU."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, True, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    loss1, g1 = _run_step(0, 1, True)
+    for _, loss2, g2 in res:
+        np.testing.assert_allclose(loss2, loss1, rtol=2e-5)
+        np.testing.assert_allclose(g2, g1, rtol=5e-3, atol=2e-5 * float(np.abs(g1).max()))
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+def _bench(extra, nproc=2):
     env = dict(os.environ, SPF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--rays", "128", "--points", "3000", "--no-cpu-baseline"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
+           "--points", "3000", "--no-cpu-baseline", "--sustained", "0"] + extra
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    rec = json.loads(line)
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_under_torchrun_two_ranks_gloo():
+    rec = _bench(["--rays", "128"])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
-    assert rec["config"]["rays_per_gpu"] == 128
+    assert rec["config"]["rays_per_gpu"] == 128 and rec["config"]["rays_per_step"] == 256
+
+
+def test_bench_strong_scaling_mode_two_ranks():
+    """--global-rays: one batch per step shared by the ranks; value counts the batch once."""
+    rec = _bench(["--global-rays", "256"])
+    assert rec["scaling"] == "strong" and rec["config"]["rays_per_gpu"] == 128 and rec["config"]["rays_per_step"] == 256
+    np.testing.assert_allclose(rec["value"], 226 * 256 * 2 / (rec["ms_per_step"] * 2e-3), rtol=1e-6)
+
+
+def test_bench_multi_scene_round_robin_two_ranks():
+    """BASELINE.json configs[3] shape: several scenes on one ray-sharded group; a step is one round over all of them."""
+    rec = _bench(["--rays", "64", "--scenes", "3"])
+    assert rec["config"]["scenes"] == 3 and rec["value"] > 0
+    np.testing.assert_allclose(rec["value"], 226 * 128 * 3 * 2 / (rec["ms_per_step"] * 2e-3), rtol=1e-6)
+
+
+def test_multi_scene_trainer_equals_separate_training():
+    """Scenes stepped round-robin on alternating streams reproduce, scene by scene, the trajectory of training each scene alone:
+    nothing (workspaces, draws, gradients) leaks between scenes."""
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.conf import default_model_conf
+    from spurfies_amd.model.pointneus_disent import PointVolSDF
+    from spurfies_amd.train import MultiSceneTrainer, TrainStep
+
+    def make(seed):
+        scene = syn.make_scene(2500, seed=seed, prior="fitted")
+        st = scene["state"]
+        model = PointVolSDF(default_model_conf(near=0.5, grid_ranges=list(scene["ranges"])), 24, "dtu",
+                            neural_points={"pts": st["neural_pts"], "colors": scene["colors"]})
+        model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
+        g = torch.Generator().manual_seed(seed + 50)
+        K = torch.from_numpy(scene["intrinsics"])[None].cuda()
+        bs = []
+        for it in range(3):
+            uv = torch.from_numpy(syn.make_pixels(64, g))[None].cuda()
+            gt = {"rgb": torch.rand((64, 3), generator=g)[None].cuda(), "mask": torch.ones((1, 64, 3)).cuda()}
+            bs.append(({"intrinsics": K, "uv": uv, "pose": torch.from_numpy(scene["poses"][it])[None].cuda(), "local_data": None}, gt))
+        return model, bs
+
+    seeds = (31, 32, 33)
+    alone = []
+    for sd in seeds:                                   # each scene alone; the CPU generator is re-seeded per (scene, step)
+        model, bs = make(sd)
+        step = TrainStep(model, sync_free=True)
+        ls = []
+        for it, b in enumerate(bs):
+            torch.manual_seed(1000 * sd + it)
+            ls.append(step(*b)[0]["loss"].item())
+        alone.append(ls)
+    built = [make(sd) for sd in seeds]
+
+    class Seeded:                                      # same seeding discipline inside the round-robin
+        def __init__(self, step, sd):
+            self.step, self.sd, self.it = step, sd, 0
+
+        def __call__(self, *b):
+            torch.manual_seed(1000 * self.sd + self.it)
+            self.it += 1
+            return self.step(*b)
+
+    multi = MultiSceneTrainer([Seeded(TrainStep(m, sync_free=True), sd) for (m, _), sd in zip(built, seeds)], n_streams=2, device="cuda")
+    together = [[] for _ in seeds]
+    for it in range(3):
+        out = multi.step([bs[it] for _, bs in built])
+        assert multi.order == [0, 1, 2]
+        for s, l in enumerate(out):
+            together[s].append(l["loss"])
+    torch.cuda.synchronize()
+    for s in range(len(seeds)):
+        np.testing.assert_allclose([float(v.item()) for v in together[s]], alone[s], rtol=2e-5)

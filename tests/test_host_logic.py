@@ -1,0 +1,72 @@
+"""CPU: host-side logic of the path that needs no kernel — CPU-generator draw sharding, SDF zero crossings, the local
+(feature-consistency) loss against the oracle, the Chamfer / component utilities."""
+import numpy as np
+import torch
+
+from oracle import path as P
+from tests.helpers import load_golden, local_data_of, scene_of
+
+
+def test_sharded_ranks_consume_the_single_gpu_draws():
+    """every rank issues the reference's torch.rand calls for the whole batch and keeps rows rank::world, so
+    the ranks' draws interleave to exactly what one GPU would have drawn, and the generator ends in the same state."""
+    from spurfies_amd.model.ray_sampler import ErrorBoundSampler_pn
+
+    def sampler(shard):
+        s = ErrorBoundSampler_pn(3.0, near=0.5, far=4.5, N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1, beta_iters=10,
+                                 max_total_iters=5)
+        s.shard = shard
+        return s
+
+    torch.manual_seed(7)
+    full = [sampler(None)._rand_rows(96, 128), sampler(None)._rand_rows(96, 64)]
+    end_state = torch.rand(1)
+    for world in (2, 4, 8):
+        parts = []
+        for rank in range(world):
+            torch.manual_seed(7)
+            s = sampler((rank, world))
+            parts.append([s._rand_rows(96 // world, 128), s._rand_rows(96 // world, 64)])
+            assert torch.equal(torch.rand(1), end_state)
+        for q in range(2):
+            merged = torch.empty_like(full[q])
+            for rank in range(world):
+                merged[rank::world] = parts[rank][q]
+            assert torch.equal(merged, full[q])
+
+
+def test_find_surface_points_and_local_loss_match_oracle_on_reference_stage_tensors():
+    """PointVolSDF.find_surface_points (dense rows, branch-free) and feat_utils (sync-free masked form + the reference-signature
+    get_local_loss) on the REFERENCE's recorded SDF / depth rows: crossings, depths and the loss value."""
+    from spurfies_amd import feat_utils
+    from spurfies_amd.model.pointneus_disent import PointVolSDF
+
+    fx = load_golden("step_train_local.npz")
+    scene = scene_of(fx)
+    mask, ray_mask = fx["stage.mask"], fx["stage.ray_mask"]
+    R, SR = mask.shape
+    sdf = np.full((R, SR), 1000.0, np.float32)
+    sdf[mask] = fx["stage.agg_sdf"][:, 0]
+    z = np.zeros((R, SR), np.float32)
+    z[ray_mask] = fx["stage.z_slots"][..., 0]
+    d, hit = PointVolSDF.find_surface_points(torch.from_numpy(sdf), torch.from_numpy(z))
+    assert np.array_equal(hit.numpy()[ray_mask], fx["stage.network_mask"][0]) and not hit.numpy()[~ray_mask].any()
+    np.testing.assert_allclose(d.numpy()[ray_mask], fx["stage.d_surface"][0], rtol=1e-6, atol=1e-7)
+    od, ohit = P.find_surface_points(torch.from_numpy(sdf), torch.from_numpy(z))
+    assert torch.equal(ohit, hit)
+    np.testing.assert_allclose(d.numpy(), od.numpy(), rtol=1e-6, atol=1e-7)
+    # the loss on those surface points: masked dense form == reference-signature compacted form == recorded value
+    local = local_data_of(fx, scene)
+    o, dirs = torch.from_numpy(fx["stage.cam_loc"]), torch.from_numpy(fx["stage.ray_dirs"])
+    pts = o + dirs * d[:, None]
+    s, c = feat_utils.local_loss_terms(pts, hit, local)
+    np.testing.assert_allclose(float(s / c), float(fx["out.local_loss"]), rtol=2e-5)
+    ref_form = feat_utils.get_local_loss(pts[hit], None, local["feat"][None], local["cam"][None], local["feat_src"][None], local["src_cams"][None],
+                                         local["size"].reshape(1), local["center"].reshape(1, 3), hit, hit)
+    np.testing.assert_allclose(float(ref_form), float(fx["out.local_loss"]), rtol=2e-5)
+    # no crossing anywhere -> exactly 0, and no NaN reaches the gradient of rays without a crossing
+    sdf_t = torch.from_numpy(np.abs(sdf)).requires_grad_(True)
+    d0, hit0 = PointVolSDF.find_surface_points(sdf_t, torch.from_numpy(z))
+    assert not hit0.any() and float(d0.abs().sum()) == 0.0
+    d0.sum().backward()
+    assert torch.isfinite(sdf_t.grad).all()
