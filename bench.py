@@ -179,7 +179,7 @@ def main():
     for i in range(args.warmup):
         run_step(i)
     if not use_graph:
-        ops.profile_start()          # HIP events around the profiled launches of the timed region
+        ops.profile_start(tags=("geo",))          # HIP events around the dominant kernel's launches of the timed region
     sync()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
@@ -190,7 +190,7 @@ def main():
     if use_graph:
         # events cannot be placed inside a hipGraph replay: time the dominant kernel over eager forward+backward passes of
         # the SAME batches right after the timed region (same kernels, same inputs; no optimiser step)
-        ops.profile_start()
+        ops.profile_start(tags=("geo",))
         for i in range(args.warmup, args.warmup + args.steps):
             step._forward_backward(dict(batches[0][i][0]), batches[0][i][1])
         sync()
@@ -210,6 +210,12 @@ def main():
         if world > 1:
             torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
         sustained = float(ts.item()) / args.sustained * 1e3
+
+    if not use_graph and args.scenes == 1:          # the other regimes' kernels, timed over separate steps (outside both timed regions)
+        ops.profile_start(tags=("color_fwd", "color_bwd", "knn", "render_fwd", "render_bwd"))
+        for i in range(args.warmup, args.warmup + min(args.steps, 10)):
+            run_step(i)
+        prof += ops.profile_stop()
 
     # ---- roofline: dominant kernel = geo_pairs_x3_kernel<true> of the main pass (the largest with-Jacobian launch per step) ----
     geo = [p for p in prof if p["tag"] == "geo"]

@@ -55,10 +55,21 @@ typedef struct spf_grid_config {
     float voxel_size[3];           /* (0.025, 0.025, 0.025) */
     int32_t voxel_scale[3];        /* (3, 3, 3)  -> cell = voxel_size * voxel_scale */
     int32_t kernel_size[3];        /* (3, 3, 3)  -> occupancy dilation box */
-    int32_t max_points_per_voxel;  /* accepted for signature parity; all points are kept */
-    int32_t max_occ_voxels;        /* accepted for signature parity; all cells are kept */
+    int32_t max_points_per_voxel;  /* 26 in the reference; applied only with SPF_KNN_TRUNCATE */
+    int32_t max_occ_voxels;        /* 20000 in the reference; applied only with SPF_KNN_TRUNCATE */
     float ranges[6];               /* (xmin, ymin, zmin, xmax, ymax, zmax) */
+    int32_t compat;                /* 0 = the frozen specification (exact radius-limited kNN, nothing dropped); or-ed SPF_KNN_* switches */
 } spf_grid_config;
+
+/* Upstream-compatibility switches (what the absent torch_knnquery source is BELIEVED to do — unverified):
+ *   SPF_KNN_TRUNCATE  capacity limits, made deterministic: a cell keeps its max_points_per_voxel LOWEST-INDEX points, the grid keeps
+ *                     the max_occ_voxels cells whose lowest point index is smallest (the order one-thread-per-point kernels claim them
+ *                     when points arrive in index order; upstream's atomics / wall-clock-seeded reservoir make its own result random);
+ *                     dropped points are never returned and do not occupy cells.
+ *   SPF_KNN_LAYERED   layer-by-layer search with early exit: if the sample's own cell already holds k points within the radius, those
+ *                     k (nearest of that cell) are returned and the 26 surrounding cells are not searched. */
+#define SPF_KNN_TRUNCATE 1
+#define SPF_KNN_LAYERED 2
 
 typedef struct spf_grid_info {
     float origin[3];
@@ -67,6 +78,7 @@ typedef struct spf_grid_info {
     int32_t n_points;     /* points handed to spf_grid_build */
     int32_t n_in_range;   /* points inside `ranges` (the others are never returned) */
     int32_t n_occupied;   /* occupied cells */
+    int32_t max_cell_points; /* points in the fullest cell (> max_points_per_voxel: upstream would drop some at random) */
 } spf_grid_info;
 
 int spf_grid_create(const spf_grid_config* cfg, spf_grid** out);
@@ -166,7 +178,7 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
 int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* jac, const int32_t* nbr,
                              const int32_t* point_slot, const int32_t* pair_off, const int32_t* pair_point,
                              const int32_t* n_pairs, int32_t max_pairs, int32_t k, float* g_feat_geo,
-                             void* stream);
+                             int64_t* g_feat_geo_fixed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused colour-feature path — replaces the F_color half of get_color,
@@ -204,7 +216,8 @@ int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const
 int spf_color_backward(const float* g_agg3, const int32_t* nbr, const float* wn, const int32_t* point_slot,
                        const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs,
                        int32_t k, const float* packed, const uint32_t* masks, float* G1, float* G2, float* G3,
-                       float* g_b0, float* g_b2, float* g_b4, float* g_feat_color, int32_t arith, void* stream);
+                       float* g_b0, float* g_b2, float* g_b4, float* g_feat_color, int64_t* g_feat_color_fixed,
+                       int32_t arith, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Head stage, per valid POINT (tiles of 64): agg = F_color.6(agg3), then the radiance head R — replaces F_color's last
@@ -349,7 +362,16 @@ int spf_scatter_add_rows(const float* src, const int32_t* idx, int64_t m, int32_
 int spf_tv_forward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm, int32_t n,
                    int32_t k, float* tv, void* stream);
 int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm,
-                    const float* g_tv, int32_t n, int32_t k, float* g_feat_geo, void* stream);
+                    const float* g_tv, int32_t n, int32_t k, float* g_feat_geo, int64_t* g_feat_geo_fixed, void* stream);
+
+/* Reproducible latent gradients.  The three latent-gradient scatters (spf_color_backward -> g_feat_color, spf_geo_backward_latents and
+ * spf_tv_backward -> g_feat_geo) add with float atomics by default: the sum depends on the order the atomics land in (run-to-run
+ * noise in the last bits).  With a non-NULL `*_fixed` argument (int64 [N, 64 | 32], zero before the first use) they instead add
+ * every fp32 term as a 2^-48 fixed-point integer (64-bit integer atomics: associative, so order-independent; a term is exact when
+ * its last mantissa bit is >= 2^-48, smaller ones round at 3.6e-15 absolute; |sum| < 2^14), and spf_fixed_accumulate rounds the sums
+ * to fp32 once: dst[i] += acc[i] * 2^-48, acc[i] = 0.  This is the
+ * deterministic alternative to sorting the pairs by neighbour (the reference's index_add_ is itself atomic and unordered). */
+int spf_fixed_accumulate(int64_t* acc, float* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ray set-up of one view

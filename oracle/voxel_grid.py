@@ -45,7 +45,12 @@ F32 = np.float32
 
 
 class VoxelGridOracle:
-    def __init__(self, voxel_size, voxel_scale, kernel_size, max_points_per_voxel, max_occ_voxels_per_example, ranges):
+    def __init__(self, voxel_size, voxel_scale, kernel_size, max_points_per_voxel, max_occ_voxels_per_example, ranges, compat=()):
+        """compat: 'truncate' / 'layered' — deterministic restatements of what upstream is BELIEVED to do (SURVEY.md Appendix B;
+        unverifiable, the source is absent): a cell keeps its max_points_per_voxel lowest-index points and the grid the
+        max_occ_voxels cells with the lowest first index; the search stops at the sample's own cell when that already holds k points
+        within the radius."""
+        self.compat = tuple(compat)
         self.voxel_size = tuple(float(v) for v in voxel_size)
         self.voxel_scale = tuple(int(v) for v in voxel_scale)
         self.kernel_size = tuple(int(v) for v in kernel_size)
@@ -67,17 +72,16 @@ class VoxelGridOracle:
         self.in_range = np.all((pts >= lo) & (pts <= hi), axis=1)
         self.idx_in = np.nonzero(self.in_range)[0].astype(np.int64)
         pin = pts[self.in_range]
+        self._grid_geometry(pin)
+        if "truncate" in self.compat and len(pin):
+            self._truncate()
+            pin = pts[self.in_range]
         if len(pin) == 0:
             self.dims = np.zeros(3, np.int64)
             self.origin = np.zeros(3, F32)
             self.occ = np.zeros((0, 0, 0), bool)
             self.dil = self.occ
             return
-        half = np.asarray([k / 2.0 for k in self.kernel_size], F32)
-        pad = (self.cell * half).astype(F32)
-        self.origin = (pin.min(0) - pad).astype(F32)
-        top = (pin.max(0) + pad).astype(F32)
-        self.dims = np.maximum(np.ceil(((top - self.origin).astype(F32) / self.cell).astype(F32)).astype(np.int64), 1)
         c = self.cell_of(pin)
         c = np.minimum(c, self.dims - 1)  # cannot trigger (padding), kept for safety
         occ = np.zeros(tuple(self.dims), bool)
@@ -85,6 +89,34 @@ class VoxelGridOracle:
         self.occ = occ
         self.dil = self._dilate(occ)
         self.tree = cKDTree(pin.astype(np.float64)) if cKDTree is not None else None
+
+    def _grid_geometry(self, pin):
+        """origin / dims from ALL in-range points (truncation drops points afterwards, the grid stays)."""
+        if len(pin) == 0:
+            return
+        half = np.asarray([k / 2.0 for k in self.kernel_size], F32)
+        pad = (self.cell * half).astype(F32)
+        self.origin = (pin.min(0) - pad).astype(F32)
+        top = (pin.max(0) + pad).astype(F32)
+        self.dims = np.maximum(np.ceil(((top - self.origin).astype(F32) / self.cell).astype(F32)).astype(np.int64), 1)
+
+    def _truncate(self):
+        ids = self.idx_in
+        c = np.minimum(self.cell_of(self.pts[ids]), self.dims - 1)
+        lin = (c[:, 0] * self.dims[1] + c[:, 1]) * self.dims[2] + c[:, 2]
+        order = np.lexsort((ids, lin))                       # by cell, then by point index
+        lin_s, ids_s = lin[order], ids[order]
+        first = np.r_[True, lin_s[1:] != lin_s[:-1]]
+        start = np.maximum.accumulate(np.where(first, np.arange(len(lin_s)), 0))
+        keep = (np.arange(len(lin_s)) - start) < (self.max_points_per_voxel if self.max_points_per_voxel > 0 else 1 << 60)
+        if self.max_occ_voxels > 0 and first.sum() > self.max_occ_voxels:
+            cell_min = ids_s[first]                          # lowest index of every occupied cell
+            thr = np.sort(cell_min)[self.max_occ_voxels - 1]
+            keep &= (ids_s[start] <= thr)
+        kept = np.zeros(len(self.pts), bool)
+        kept[ids_s[keep]] = True
+        self.in_range = self.in_range & kept
+        self.idx_in = np.nonzero(self.in_range)[0].astype(np.int64)
 
     def cell_of(self, x):
         x = np.asarray(x, F32)
@@ -144,7 +176,11 @@ class VoxelGridOracle:
             d2 = ((d[:, 0] * d[:, 0]).astype(F32) + (d[:, 1] * d[:, 1]).astype(F32)).astype(F32)
             d2 = (d2 + (d[:, 2] * d[:, 2]).astype(F32)).astype(F32)
             keep = d2 <= rad2
-            ci, d2 = self.idx_in[ci[keep]], d2[keep]
+            cj, ci, d2 = ci[keep], self.idx_in[ci[keep]], d2[keep]
+            if "layered" in self.compat and len(ci):
+                own = np.all(self.cell_of(pin[cj]) == self.cell_of(x[m]), axis=1)
+                if own.sum() >= k:                           # the sample's own cell already holds k points within the radius
+                    ci, d2 = ci[own], d2[own]
             order = np.lexsort((ci, d2))[:k]
             out[m, : len(order)] = ci[order]
         return out

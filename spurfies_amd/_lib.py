@@ -14,12 +14,12 @@ LIB_PATH = os.path.join(HERE, "lib", "libspurfies_hip.so")
 
 class GridConfig(C.Structure):
     _fields_ = [("voxel_size", C.c_float * 3), ("voxel_scale", C.c_int32 * 3), ("kernel_size", C.c_int32 * 3),
-                ("max_points_per_voxel", C.c_int32), ("max_occ_voxels", C.c_int32), ("ranges", C.c_float * 6)]
+                ("max_points_per_voxel", C.c_int32), ("max_occ_voxels", C.c_int32), ("ranges", C.c_float * 6), ("compat", C.c_int32)]
 
 
 class GridInfo(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("cell", C.c_float * 3), ("dims", C.c_int32 * 3),
-                ("n_points", C.c_int32), ("n_in_range", C.c_int32), ("n_occupied", C.c_int32)]
+                ("n_points", C.c_int32), ("n_in_range", C.c_int32), ("n_occupied", C.c_int32), ("max_cell_points", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -52,11 +52,11 @@ SIGNATURES = {
     "spf_geo_pack": (C.c_int, [_P] * 14),
     "spf_build_pairs": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "spf_geo_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P]),
-    "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "spf_color_packed_floats": (C.c_int64, []),
     "spf_color_pack": (C.c_int, [_P] * 8),
     "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "spf_color_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "spf_color_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_rhead_packed_floats": (C.c_int64, []),
     "spf_rhead_pack": (C.c_int, [_P] * 10),
     "spf_rhead_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
@@ -72,7 +72,8 @@ SIGNATURES = {
     "spf_wgrad_batched": (C.c_int, [C.POINTER(WgradProblem), _I, _P, _I, _P, _I, _P]),
     "spf_scatter_add_rows": (C.c_int, [_P, _P, C.c_int64, _I, _P, _P]),
     "spf_tv_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
-    "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "spf_fixed_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
     "spf_camera_rays": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "spf_adam_workspace_floats": (C.c_int64, []),
     "spf_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P]),

@@ -5,11 +5,13 @@ from __future__ import annotations
 import torch
 
 _records = None
+_tags = None
 
 
-def start():
-    global _records
-    _records = []
+def start(tags=None):
+    """tags: only spans with these tags are timed (None = all)."""
+    global _records, _tags
+    _records, _tags = [], (None if tags is None else set(tags))
 
 
 def active() -> bool:
@@ -23,13 +25,14 @@ class span:
         self.tag, self.meta = tag, meta
 
     def __enter__(self):
-        if _records is not None:
+        self.on = _records is not None and (_tags is None or self.tag in _tags)
+        if self.on:
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *exc):
-        if _records is not None:
+        if self.on and _records is not None:
             self.e1.record()
             _records.append((self.tag, self.e0, self.e1, self.meta))
         return False

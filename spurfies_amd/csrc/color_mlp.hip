@@ -840,7 +840,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
                          const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
                          const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k, const float* packed,
                          const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ G3,
-                         float* __restrict__ g_feat_col) {
+                         float* __restrict__ g_feat_col, long long* __restrict__ g_fixed) {
     __shared__ __attribute__((aligned(16))) __bf16 X[CX_LDS_BF16];
     __shared__ __attribute__((aligned(16))) int s_idx[64];
     __shared__ __attribute__((aligned(16))) float L[64 * CX_LDL];      // the tile's latent gradients, [row][64 (+4)]
@@ -1001,7 +1001,10 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int idx = __builtin_amdgcn_readfirstlane(lead[rr]);
-                if (idx >= 0) atomicAdd(g_feat_col + (size_t)idx * SPF_COL_DIM + lane, val[rr]);
+                if (idx >= 0) {
+                    if (g_fixed) fixed_add(g_fixed + (size_t)idx * SPF_COL_DIM + lane, val[rr]);      // order-independent (common.h)
+                    else atomicAdd(g_feat_col + (size_t)idx * SPF_COL_DIM + lane, val[rr]);
+                }
             }
         }
         T_MARK(23)
@@ -1074,18 +1077,20 @@ int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const
 int spf_color_backward(const float* g_agg3, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* pair_off,
                        const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* packed,
                        const uint32_t* masks, float* G1, float* G2, float* G3, float* g_b0, float* g_b2, float* g_b4, float* g_feat_color,
-                       int32_t arith, void* stream) {
+                       int64_t* g_feat_color_fixed, int32_t arith, void* stream) {
     if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_color_backward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_backward: bad sizes");
     if (max_pairs == 0) return SPF_OK;
-    if (!g_agg3 || !nbr || !wn || !pair_off || !pair_point || !packed || !masks || !G1 || !G2 || !G3 || !g_b0 || !g_b2 || !g_b4 || !g_feat_color)
+    if (!g_agg3 || !nbr || !wn || !pair_off || !pair_point || !packed || !masks || !G1 || !G2 || !G3 || !g_b0 || !g_b2 || !g_b4 ||
+        (!g_feat_color && !g_feat_color_fixed))
         return spf::fail(SPF_EINVAL, "spf_color_backward: null pointer");
+    if (g_feat_color_fixed && arith != SPF_ARITH_SPLIT) return spf::fail(SPF_EINVAL, "spf_color_backward: the fixed-point latent accumulator needs SPF_ARITH_SPLIT");
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
     if (arith == SPF_ARITH_SPLIT) {    // bias gradients come from spf_wgrad (dbias) in this mode: g_b0 / g_b2 / g_b4 are not touched
         const int b1 = tiles < 256 ? tiles : 256;
         color_backward_x3_kernel<<<b1, 256, 0, (hipStream_t)stream>>>(g_agg3, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
-                                                                      masks, G1, G2, G3, g_feat_color);
+                                                                      masks, G1, G2, G3, g_feat_color, reinterpret_cast<long long*>(g_feat_color_fixed));
         SPF_LAUNCH_CHECK("color_backward_x3_kernel");
         return SPF_OK;
     }

@@ -29,4 +29,19 @@ int fail(int code, const char* fmt, ...);
 
 inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Order-independent accumulation for the latent-gradient scatters (the `*_fixed` arguments of the C ABI): every fp32 term is added
+// as a 2^-48 fixed-point integer (float -> double -> x 2^48 -> nearest int64: exact for terms whose last mantissa bit is >= 2^-48,
+// i.e. |v| >= 2^-25; smaller terms round at 3.6e-15 absolute; range |sum| < 2^14) with 64-bit integer atomics.  Integer addition is
+// associative, so the result does not depend on the order the atomics land in — run-to-run reproducible, unlike float atomics —
+// and spf_fixed_accumulate rounds the sum to fp32 once (more accurate than any fp32 summation order).
+constexpr double FIXED_SCALE = 281474976710656.0;              // 2^48
+constexpr double FIXED_LIMIT = 4611686018427387904.0;          // 2^62: clamp (a non-finite or absurd term poisons the entry instead of wrapping)
+#ifdef __HIPCC__
+__device__ __forceinline__ void fixed_add(long long* acc, float v) {
+    double d = (double)v * FIXED_SCALE;
+    d = (d == d) ? fmin(fmax(d, -FIXED_LIMIT), FIXED_LIMIT) : FIXED_LIMIT;
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)__double2ll_rn(d));
+}
+#endif
+
 }  // namespace spf

@@ -360,7 +360,7 @@ __global__ void geo_backward_latents_kernel(const float* __restrict__ g_sdf, con
                                             const float* __restrict__ jac, const int32_t* __restrict__ nbr,
                                             const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off,
                                             const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
-                                            int max_pairs, int k, float* __restrict__ g_feat) {
+                                            int max_pairs, int k, float* __restrict__ g_feat, long long* __restrict__ g_fixed) {
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
     const int c = threadIdx.x & 31;
     for (long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; q < NP; q += ((long long)gridDim.x * blockDim.x) >> 5) {
@@ -368,7 +368,11 @@ __global__ void geo_backward_latents_kernel(const float* __restrict__ g_sdf, con
         const int srow = point_slot ? point_slot[p] : p;
         const int idx = nbr[(size_t)srow * k + ((int)q - pair_off[p])];
         const float coef = g_sdf[srow] * wn[q];
-        if (coef != 0.f) atomicAdd(&g_feat[(size_t)idx * SPF_GEO_DIM + c], coef * jac[(size_t)q * SPF_GEO_DIM + c]);
+        if (coef != 0.f) {
+            const float v = coef * jac[(size_t)q * SPF_GEO_DIM + c];
+            if (g_fixed) fixed_add(&g_fixed[(size_t)idx * SPF_GEO_DIM + c], v);       // order-independent (common.h)
+            else atomicAdd(&g_feat[(size_t)idx * SPF_GEO_DIM + c], v);
+        }
     }
 }
 
@@ -847,16 +851,16 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
 
 int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* jac, const int32_t* nbr, const int32_t* point_slot,
                              const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k,
-                             float* g_feat_geo, void* stream) {
+                             float* g_feat_geo, int64_t* g_feat_geo_fixed, void* stream) {
     if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: bad sizes");
     if (max_pairs == 0) return SPF_OK;
-    if (!g_sdf || !wn || !jac || !nbr || !pair_off || !pair_point || !g_feat_geo)
+    if (!g_sdf || !wn || !jac || !nbr || !pair_off || !pair_point || (!g_feat_geo && !g_feat_geo_fixed))
         return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: null pointer");
     long long threads = (long long)max_pairs * 32;
     int blocks = spf::div_up(threads, 256);
     if (blocks > 8192) blocks = 8192;
     geo_backward_latents_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_sdf, wn, jac, nbr, point_slot, pair_off, pair_point, n_pairs,
-                                                                         max_pairs, k, g_feat_geo);
+                                                                         max_pairs, k, g_feat_geo, reinterpret_cast<long long*>(g_feat_geo_fixed));
     SPF_LAUNCH_CHECK("geo_backward_latents_kernel");
     return SPF_OK;
 }

@@ -14,6 +14,7 @@
 #include <cfloat>
 #include <cmath>
 #include <new>
+#include <vector>
 
 #include "common.h"
 
@@ -39,7 +40,7 @@ struct spf_grid {
     float origin[3];
     int32_t dims[3];
     int32_t ncell;
-    int32_t n_points, n_in, n_occ;
+    int32_t n_points, n_in, n_occ, max_cell;
     int32_t* cell_start;  // [ncell+1]
     float4* sorted;       // [n_in] xyz + original index (bit pattern in .w), grouped by cell
     uint32_t* dil;        // [(ncell+63)/64*2] dilated-occupancy bitmask
@@ -126,11 +127,12 @@ __device__ __forceinline__ int point_cell(const GridDev& g, float x, float y, fl
 }
 
 __global__ void count_kernel(const float* __restrict__ pts, int n, GridDev g, float lx, float ly, float lz,
-                             float hx, float hy, float hz, int32_t* counts /* = cell_start + 1 */) {
+                             float hx, float hy, float hz, int32_t* counts /* = cell_start + 1 */, const uint8_t* __restrict__ drop) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
     if (!(x >= lx && x <= hx && y >= ly && y <= hy && z >= lz && z <= hz)) return;
+    if (drop && drop[i]) return;
     atomicAdd(&counts[point_cell(g, x, y, z)], 1);
 }
 
@@ -168,13 +170,41 @@ __global__ void __launch_bounds__(1024) scan_kernel(int32_t* a, int n, int32_t* 
 }
 
 __global__ void fill_kernel(const float* __restrict__ pts, int n, GridDev g, float lx, float ly, float lz,
-                            float hx, float hy, float hz, int32_t* cursor, float4* sorted) {
+                            float hx, float hy, float hz, int32_t* cursor, float4* sorted, const uint8_t* __restrict__ drop) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
     if (!(x >= lx && x <= hx && y >= ly && y <= hy && z >= lz && z <= hz)) return;
+    if (drop && drop[i]) return;
     int pos = atomicAdd(&cursor[point_cell(g, x, y, z)], 1);
     sorted[pos] = make_float4(x, y, z, __int_as_float(i));
+}
+
+// SPF_KNN_TRUNCATE, pass 1 (one thread per cell of the full table): a cell keeps its P lowest-index points (drop[] = 1 for the
+// others) and reports its lowest index (INT_MAX when empty) — the order in which upstream's one-thread-per-point kernels would
+// claim cells and fill them if points arrived in index order.
+__global__ void truncate_cells_kernel(GridDev g, int ncell, int P, uint8_t* __restrict__ drop, int32_t* __restrict__ cell_min) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const int s = g.cell_start[c], e = g.cell_start[c + 1];
+    int mn = 0x7fffffff;
+    for (int j = s; j < e; ++j) {
+        const int ij = __float_as_int(g.sorted[j].w);
+        mn = min(mn, ij);
+        if (e - s > P) {
+            int rank = 0;
+            for (int t = s; t < e; ++t) rank += __float_as_int(g.sorted[t].w) < ij;
+            if (rank >= P) drop[ij] = 1;
+        }
+    }
+    cell_min[c] = mn;
+}
+
+// pass 2: every point of a cell whose lowest index lies above `threshold` (the max_occ-th smallest over the occupied cells) is dropped
+__global__ void drop_cells_kernel(GridDev g, int ncell, const int32_t* __restrict__ cell_min, int threshold, uint8_t* __restrict__ drop) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell || cell_min[c] <= threshold) return;
+    for (int j = g.cell_start[c]; j < g.cell_start[c + 1]; ++j) drop[__float_as_int(g.sorted[j].w)] = 1;
 }
 
 // one thread per cell: dilated occupancy = any occupied cell in the kernel box; 64 cells -> one ballot
@@ -198,6 +228,7 @@ __global__ void dilate_kernel(GridDev g, int ncell, int hkx, int hky, int hkz, u
         dil[w + 1] = (uint32_t)(b >> 32);
         if (bs) atomicAdd(&stats[7], (uint32_t)__popcll(bs));
     }
+    if (c < ncell && self) atomicMax(&stats[6], (uint32_t)(g.cell_start[c + 1] - g.cell_start[c]));      // fullest cell
 }
 
 __device__ __forceinline__ bool dil_hit(const GridDev& g, float x, float y, float z) {
@@ -254,6 +285,9 @@ __device__ __forceinline__ void cmpx(unsigned long long& a, unsigned long long& 
     b = hi;
 }
 
+// LAYERED (SPF_KNN_LAYERED, what upstream is believed to do — SURVEY.md Appendix B): the sample's own cell is searched first and, if it
+// already holds k points within the radius, the search stops there (closer points in the neighbouring cells are then missed).
+template <bool LAYERED>
 __global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ raypos, int R, int D, int SR, int k,
                                                   float rad2, GridDev g, int hkx, int hky, int hkz,
                                                   const int32_t* __restrict__ slot_sample, int32_t* __restrict__ pidx,
@@ -276,40 +310,60 @@ __global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ rayp
         z = p[2];
         int cx, cy, cz;
         cell_of(g, x, y, z, cx, cy, cz);  // a slot's sample is always inside the grid
-        for (int ax = max(cx - hkx, 0); ax <= min(cx + hkx, g.dx - 1); ++ax)
-            for (int ay = max(cy - hky, 0); ay <= min(cy + hky, g.dy - 1); ++ay) {
-                const int col = (ax * g.dy + ay) * g.dz;
-                const int s = g.cell_start[col + max(cz - hkz, 0)];
-                const int e = g.cell_start[col + min(cz + hkz, g.dz - 1) + 1];
-                for (int j = s + sub; j < e; j += 8) {
-                    const float4 q = g.sorted[j];
-                    const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
-                    const float d2 = (dx * dx + dy * dy) + dz * dz;
-                    const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(q.w);
-                    if (d2 <= rad2 && kk < key[SPF_KMAX - 1]) {
-                        key[SPF_KMAX - 1] = kk;
+        auto scan = [&](int s, int e) {
+            for (int j = s + sub; j < e; j += 8) {
+                const float4 q = g.sorted[j];
+                const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(q.w);
+                if (d2 <= rad2 && kk < key[SPF_KMAX - 1]) {
+                    key[SPF_KMAX - 1] = kk;
 #pragma unroll
-                        for (int t = SPF_KMAX - 1; t > 0; --t) cmpx(key[t - 1], key[t]);
-                    }
+                    for (int t = SPF_KMAX - 1; t > 0; --t) cmpx(key[t - 1], key[t]);
                 }
             }
+        };
         // merge the octet's eight sorted lists: min(mine[t], partner[7 - t]) is a bitonic sequence holding the 8 smallest of both
+        auto merge = [&]() {
 #pragma unroll
-        for (int m = 1; m < 8; m <<= 1) {
-            unsigned long long o[SPF_KMAX];
+            for (int m = 1; m < 8; m <<= 1) {
+                unsigned long long o[SPF_KMAX];
 #pragma unroll
-            for (int t = 0; t < SPF_KMAX; ++t) {
-                const unsigned lo = __shfl_xor((unsigned)key[SPF_KMAX - 1 - t], m);
-                const unsigned hi = __shfl_xor((unsigned)(key[SPF_KMAX - 1 - t] >> 32), m);
-                o[t] = ((unsigned long long)hi << 32) | lo;
+                for (int t = 0; t < SPF_KMAX; ++t) {
+                    const unsigned lo = __shfl_xor((unsigned)key[SPF_KMAX - 1 - t], m);
+                    const unsigned hi = __shfl_xor((unsigned)(key[SPF_KMAX - 1 - t] >> 32), m);
+                    o[t] = ((unsigned long long)hi << 32) | lo;
+                }
+#pragma unroll
+                for (int t = 0; t < SPF_KMAX; ++t) key[t] = key[t] < o[t] ? key[t] : o[t];
+#pragma unroll
+                for (int j = 4; j > 0; j >>= 1)
+#pragma unroll
+                    for (int t = 0; t < SPF_KMAX; ++t)
+                        if ((t & j) == 0) cmpx(key[t], key[t + j]);
             }
+        };
+        bool done = false;
+        if (LAYERED) {
+            const int lin = (cx * g.dy + cy) * g.dz + cz;
+            scan(g.cell_start[lin], g.cell_start[lin + 1]);
+            merge();
+            unsigned long long kth = key[0];
 #pragma unroll
-            for (int t = 0; t < SPF_KMAX; ++t) key[t] = key[t] < o[t] ? key[t] : o[t];
+            for (int t = 1; t < SPF_KMAX; ++t) kth = (t == k - 1) ? key[t] : kth;
+            done = kth != NONE;                              // the same in all eight lanes of the octet
+            if (!done) {
 #pragma unroll
-            for (int j = 4; j > 0; j >>= 1)
-#pragma unroll
-                for (int t = 0; t < SPF_KMAX; ++t)
-                    if ((t & j) == 0) cmpx(key[t], key[t + j]);
+                for (int t = 0; t < SPF_KMAX; ++t) key[t] = NONE;
+            }
+        }
+        if (!done) {
+            for (int ax = max(cx - hkx, 0); ax <= min(cx + hkx, g.dx - 1); ++ax)
+                for (int ay = max(cy - hky, 0); ay <= min(cy + hky, g.dy - 1); ++ay) {
+                    const int col = (ax * g.dy + ay) * g.dz;
+                    scan(g.cell_start[col + max(cz - hkz, 0)], g.cell_start[col + min(cz + hkz, g.dz - 1) + 1]);
+                }
+            merge();
         }
     }
     // lane s writes neighbour s; lane 0 the slot's position and validity
@@ -561,20 +615,55 @@ int spf_grid_build(spf_grid* g, const float* points, int32_t n, void* stream_) {
     SPF_HIP_CHECK(hipMalloc(&g->cursor, (size_t)ncell * sizeof(int32_t)));
     SPF_HIP_CHECK(hipMalloc(&g->sorted, (size_t)g->n_in * sizeof(float4)));
     SPF_HIP_CHECK(hipMalloc(&g->dil, dil_words * sizeof(uint32_t)));
-    SPF_HIP_CHECK(hipMemsetAsync(g->cell_start, 0, (size_t)(ncell + 1) * sizeof(int32_t), stream));
     GridDev d = dev_view(g);
-    count_kernel<<<spf::div_up(n, 256), 256, 0, stream>>>(points, n, d, rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], g->cell_start + 1);
-    SPF_LAUNCH_CHECK("count_kernel");
-    scan_kernel<<<1, 1024, 0, stream>>>(g->cell_start, (int)(ncell + 1), g->cursor);
-    SPF_LAUNCH_CHECK("scan_kernel");
-    fill_kernel<<<spf::div_up(n, 256), 256, 0, stream>>>(points, n, d, rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], g->cursor, g->sorted);
-    SPF_LAUNCH_CHECK("fill_kernel");
+    auto build_tables = [&](const uint8_t* drop) -> int {
+        SPF_HIP_CHECK(hipMemsetAsync(g->cell_start, 0, (size_t)(ncell + 1) * sizeof(int32_t), stream));
+        count_kernel<<<spf::div_up(n, 256), 256, 0, stream>>>(points, n, d, rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], g->cell_start + 1, drop);
+        SPF_LAUNCH_CHECK("count_kernel");
+        scan_kernel<<<1, 1024, 0, stream>>>(g->cell_start, (int)(ncell + 1), g->cursor);
+        SPF_LAUNCH_CHECK("scan_kernel");
+        fill_kernel<<<spf::div_up(n, 256), 256, 0, stream>>>(points, n, d, rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], g->cursor, g->sorted, drop);
+        SPF_LAUNCH_CHECK("fill_kernel");
+        return SPF_OK;
+    };
+    if (int rc = build_tables(nullptr)) return rc;
+    if (g->cfg.compat & SPF_KNN_TRUNCATE) {
+        // deterministic stand-in for upstream's per-cell / per-grid capacity limits: keep the P lowest-index points of a cell and the
+        // max_occ cells with the lowest first index, then rebuild the tables without the dropped points
+        const int P = g->cfg.max_points_per_voxel > 0 ? g->cfg.max_points_per_voxel : 0x7fffffff;
+        uint8_t* drop = nullptr;
+        int32_t* cell_min = nullptr;
+        SPF_HIP_CHECK(hipMalloc(&drop, (size_t)n));
+        SPF_HIP_CHECK(hipMalloc(&cell_min, (size_t)ncell * sizeof(int32_t)));
+        SPF_HIP_CHECK(hipMemsetAsync(drop, 0, (size_t)n, stream));
+        truncate_cells_kernel<<<spf::div_up(ncell, 256), 256, 0, stream>>>(d, (int)ncell, P, drop, cell_min);
+        if (g->cfg.max_occ_voxels > 0) {
+            std::vector<int32_t> mins((size_t)ncell);
+            SPF_HIP_CHECK(hipMemcpyAsync(mins.data(), cell_min, (size_t)ncell * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            SPF_HIP_CHECK(hipStreamSynchronize(stream));
+            std::vector<int32_t> occ;
+            for (int32_t v : mins)
+                if (v != 0x7fffffff) occ.push_back(v);
+            if ((long long)occ.size() > (long long)g->cfg.max_occ_voxels) {
+                std::nth_element(occ.begin(), occ.begin() + (g->cfg.max_occ_voxels - 1), occ.end());
+                drop_cells_kernel<<<spf::div_up(ncell, 256), 256, 0, stream>>>(d, (int)ncell, cell_min, occ[g->cfg.max_occ_voxels - 1], drop);
+            }
+        }
+        const int rc = build_tables(drop);
+        SPF_HIP_CHECK(hipStreamSynchronize(stream));
+        (void)hipFree(drop);
+        (void)hipFree(cell_min);
+        if (rc) return rc;
+    }
+    uint32_t zero2[2] = {0u, 0u};
+    SPF_HIP_CHECK(hipMemcpyAsync(g->stats + 6, zero2, sizeof(zero2), hipMemcpyHostToDevice, stream));      // [6] fullest cell, [7] occupied cells
     dilate_kernel<<<spf::div_up(ncell, 256), 256, 0, stream>>>(d, (int)ncell, g->cfg.kernel_size[0] / 2, g->cfg.kernel_size[1] / 2,
                                                              g->cfg.kernel_size[2] / 2, g->dil, g->stats);
     SPF_LAUNCH_CHECK("dilate_kernel");
     SPF_HIP_CHECK(hipMemcpyAsync(host, g->stats, sizeof(host), hipMemcpyDeviceToHost, stream));
     SPF_HIP_CHECK(hipStreamSynchronize(stream));
     g->n_occ = (int32_t)host[7];
+    g->max_cell = (int32_t)host[6];
     return SPF_OK;
 }
 
@@ -588,6 +677,7 @@ int spf_grid_get_info(const spf_grid* g, spf_grid_info* out) {
     out->n_points = g->n_points;
     out->n_in_range = g->n_in;
     out->n_occupied = g->n_occ;
+    out->max_cell_points = g->max_cell;
     return SPF_OK;
 }
 
@@ -621,9 +711,14 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
         hit_slots_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, stream>>>(raypos, R, D, SR, d, slot_sample);
         SPF_LAUNCH_CHECK("hit_slots_kernel");
     }
-    knn_kernel<<<spf::div_up((long long)nslot * 8, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
-                                                                       g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
-                                                                       slot_sample, pidx, loc, slot_valid);
+    if (g->cfg.compat & SPF_KNN_LAYERED)
+        knn_kernel<true><<<spf::div_up((long long)nslot * 8, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
+                                                                                 g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
+                                                                                 slot_sample, pidx, loc, slot_valid);
+    else
+        knn_kernel<false><<<spf::div_up((long long)nslot * 8, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
+                                                                                  g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
+                                                                                  slot_sample, pidx, loc, slot_valid);
     SPF_LAUNCH_CHECK("knn_kernel");
     ray_valid_kernel<<<spf::div_up(R, 256), 256, 0, stream>>>(slot_valid, R, SR, ray_valid);
     SPF_LAUNCH_CHECK("ray_valid_kernel");

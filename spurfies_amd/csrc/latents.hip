@@ -50,7 +50,7 @@ __global__ void tv_forward_kernel(const float* __restrict__ feat, const int32_t*
 // g_feat[i] += s_i * sign(f_i - f_j) * w_ij ; g_feat[j] -= same,  s_i = g_tv[i] / norm_i
 __global__ void tv_backward_kernel(const float* __restrict__ feat, const int32_t* __restrict__ nbr, const float* __restrict__ w,
                                    const float* __restrict__ norm, const float* __restrict__ g_tv, int n, int k,
-                                   float* __restrict__ g_feat) {
+                                   float* __restrict__ g_feat, long long* __restrict__ g_fixed) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = gid >> 5, c = gid & 31;
     if (i >= n) return;
@@ -64,10 +64,24 @@ __global__ void tv_backward_kernel(const float* __restrict__ feat, const int32_t
         const float d = feat[(size_t)q * 32 + c] - fi;
         const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);   // d|d|/dd, 0 at 0 like torch.abs
         const float g = s * wj * sg;
-        atomicAdd(&g_feat[(size_t)q * 32 + c], g);
+        if (g_fixed) fixed_add(&g_fixed[(size_t)q * 32 + c], g);
+        else atomicAdd(&g_feat[(size_t)q * 32 + c], g);
         own -= g;
     }
-    atomicAdd(&g_feat[(size_t)i * 32 + c], own);
+    if (g_fixed) fixed_add(&g_fixed[(size_t)i * 32 + c], own);
+    else atomicAdd(&g_feat[(size_t)i * 32 + c], own);
+}
+
+// dst[i] += acc[i] * 2^-48 (the exact sum, rounded to fp32 once); acc[i] = 0 for the next use
+__global__ void fixed_accumulate_kernel(long long* __restrict__ acc, float* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long a = acc[i];
+        if (a != 0) {
+            const double d = (double)a;
+            dst[i] += (fabs(d) >= 0.5 * FIXED_LIMIT) ? __builtin_nanf("") : (float)(d / FIXED_SCALE);
+            acc[i] = 0;
+        }
+    }
 }
 
 }  // namespace
@@ -99,12 +113,24 @@ int spf_tv_forward(const float* feat_geo, const int32_t* nbr, const float* w, co
 }
 
 int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm, const float* g_tv,
-                    int32_t n, int32_t k, float* g_feat_geo, void* stream) {
+                    int32_t n, int32_t k, float* g_feat_geo, int64_t* g_feat_geo_fixed, void* stream) {
     if (n < 0 || k < 1) return spf::fail(SPF_EINVAL, "spf_tv_backward: bad sizes");
     if (n == 0) return SPF_OK;
-    if (!feat_geo || !nbr || !w || !norm || !g_tv || !g_feat_geo) return spf::fail(SPF_EINVAL, "spf_tv_backward: null pointer");
-    tv_backward_kernel<<<spf::div_up((long long)n * 32, 256), 256, 0, (hipStream_t)stream>>>(feat_geo, nbr, w, norm, g_tv, n, k, g_feat_geo);
+    if (!feat_geo || !nbr || !w || !norm || !g_tv || (!g_feat_geo && !g_feat_geo_fixed)) return spf::fail(SPF_EINVAL, "spf_tv_backward: null pointer");
+    tv_backward_kernel<<<spf::div_up((long long)n * 32, 256), 256, 0, (hipStream_t)stream>>>(feat_geo, nbr, w, norm, g_tv, n, k, g_feat_geo,
+                                                                                           reinterpret_cast<long long*>(g_feat_geo_fixed));
     SPF_LAUNCH_CHECK("tv_backward_kernel");
+    return SPF_OK;
+}
+
+int spf_fixed_accumulate(int64_t* acc, float* dst, int64_t n, void* stream) {
+    if (n < 0) return spf::fail(SPF_EINVAL, "spf_fixed_accumulate: bad size");
+    if (n == 0) return SPF_OK;
+    if (!acc || !dst) return spf::fail(SPF_EINVAL, "spf_fixed_accumulate: null pointer");
+    int blocks = spf::div_up(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    fixed_accumulate_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<long long*>(acc), dst, (long long)n);
+    SPF_LAUNCH_CHECK("fixed_accumulate_kernel");
     return SPF_OK;
 }
 

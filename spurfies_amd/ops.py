@@ -23,8 +23,8 @@ def _sink(p):
     return g if (g is not None and g.shape == p.shape and g.is_contiguous() and g.device == p.device) else None
 
 # ---- optional per-launch timing (bench.py roofline): spurfies_amd/_prof.py -----------------------
-def profile_start():
-    _prof.start()
+def profile_start(tags=None):
+    _prof.start(tags)
 
 
 def profile_stop():
@@ -125,11 +125,46 @@ def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_ou
     return {"sdf": sdf, "wn": wn, "grad": grad, "jac": jac}
 
 
+# ---- latent-gradient scatter: float atomics (default) or order-independent fixed-point accumulation --------------------------
+_SCATTER = {"mode": "atomic"}
+_fixed_bufs = {}
+
+
+def set_scatter_mode(mode: str):
+    """'atomic' (default): float atomics, sums depend on the order the atomics land in (last-bit run-to-run noise, like the
+    reference's index_add_).  'fixed': every term is added as a 2^-48 fixed-point integer with 64-bit integer atomics and the sum is
+    rounded to fp32 once (include/spurfies_hip.h: spf_fixed_accumulate) — latent gradients are then bit-reproducible run to run."""
+    if mode not in ("atomic", "fixed"):
+        raise ValueError(mode)
+    _SCATTER["mode"] = mode
+
+
+def scatter_mode() -> str:
+    return _SCATTER["mode"]
+
+
+def _fixed_acc(like):
+    """Zero int64 accumulator shaped like the latent-gradient buffer `like` (one per device / shape / stream; spf_fixed_accumulate
+    leaves it zero again)."""
+    key = (like.device.index, tuple(like.shape), torch.cuda.current_stream(like.device).cuda_stream)
+    if key not in _fixed_bufs:
+        _fixed_bufs[key] = torch.zeros(like.shape, dtype=torch.int64, device=like.device)
+    return _fixed_bufs[key]
+
+
+def _fixed_flush(acc, dst):
+    with torch.cuda.device(dst.device):
+        _lib.check(_lib.lib().spf_fixed_accumulate(_lib.ptr(acc), _lib.ptr(dst), dst.numel(), _lib.stream_ptr()), "spf_fixed_accumulate")
+
+
 def geo_backward_latents(g_sdf, wn, jac, pl: "PairList", g_feat_geo):
+    acc = _fixed_acc(g_feat_geo) if _SCATTER["mode"] == "fixed" else None
     with torch.cuda.device(g_sdf.device):
         _lib.check(_lib.lib().spf_geo_backward_latents(_lib.ptr(g_sdf), _lib.ptr(wn), _lib.ptr(jac), _lib.ptr(pl.nbr), _lib.ptr(pl.point_slot),
                                                        _lib.ptr(pl.pair_off), _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), pl.max_pairs, pl.k,
-                                                       _lib.ptr(g_feat_geo), _lib.stream_ptr()), "spf_geo_backward_latents")
+                                                       _lib.ptr(g_feat_geo), _lib.ptr(acc), _lib.stream_ptr()), "spf_geo_backward_latents")
+    if acc is not None:
+        _fixed_flush(acc, g_feat_geo)
     return g_feat_geo
 
 
@@ -217,9 +252,12 @@ class TVLoss(torch.autograd.Function):
         n, k = nbr.shape
         g_tv = (g / n).expand(n).contiguous()
         out = ctx.sink if ctx.sink is not None else torch.zeros_like(feat)
+        acc = _fixed_acc(out) if _SCATTER["mode"] == "fixed" else None
         with torch.cuda.device(feat.device):
             _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), _lib.ptr(g_tv), n, k,
-                                                  _lib.ptr(out), _lib.stream_ptr()), "spf_tv_backward")
+                                                  _lib.ptr(out), _lib.ptr(acc), _lib.stream_ptr()), "spf_tv_backward")
+        if acc is not None:
+            _fixed_flush(acc, out)
         return (None if ctx.sink is not None else out), None, None, None
 
 
@@ -312,11 +350,16 @@ class ColorAgg(_GradModeFunction):
             g_b0, g_b2, g_b4 = g_bias[0], g_bias[1], g_bias[2]
             g_feat = torch.zeros((ctx.n_table, 64), dtype=torch.float32, device=dev)
         g_agg3 = g_agg3.contiguous()
+        acc = _fixed_acc(g_feat) if (_SCATTER["mode"] == "fixed" and ctx.arith == 0) else None
+        if _SCATTER["mode"] == "fixed" and ctx.arith != 0:
+            raise RuntimeError("scatter mode 'fixed' needs the default ('split') colour kernels")
         with torch.cuda.device(dev), _prof.span("color_bwd", pairs=pl.n_pairs):
             _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg3), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                      _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), ctx.NP, pl.k, _lib.ptr(packed), _lib.ptr(masks),
                                                      _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_b4),
-                                                     _lib.ptr(g_feat), ctx.arith, _lib.stream_ptr()), "spf_color_backward")
+                                                     _lib.ptr(g_feat), _lib.ptr(acc), ctx.arith, _lib.stream_ptr()), "spf_color_backward")
+        if acc is not None:
+            _fixed_flush(acc, g_feat)
         # split-product kernels (the default) leave the bias gradients to the weight-gradient GEMM (column sums of G)
         kb = (lambda b: b) if ctx.arith == 0 else (lambda b: None)
         # the bf16-piece kernels write act1 / act2 / G2 / G1 as K-major tiles (include/spurfies_hip.h: SPF_WGRAD_*_TILES)

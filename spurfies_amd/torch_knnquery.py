@@ -17,8 +17,14 @@ import torch
 from . import _lib, _prof
 
 
+KNN_TRUNCATE, KNN_LAYERED = 1, 2       # include/spurfies_hip.h: SPF_KNN_*
+
+
 class VoxelGrid:
-    def __init__(self, voxel_size, voxel_scale, kernel_size, max_points_per_voxel, max_occ_voxels_per_example, ranges):
+    def __init__(self, voxel_size, voxel_scale, kernel_size, max_points_per_voxel, max_occ_voxels_per_example, ranges, compat=()):
+        """The reference's six positional arguments (pointneus_disent.py:45-62).  `compat`: names of the upstream-compatibility
+        switches to apply, 'truncate' (deterministic max_points_per_voxel / max_occ_voxels limits) and / or 'layered' (own-cell early
+        exit) — what the absent CUDA source is believed to do; default: the frozen exact specification."""
         self.voxel_size = tuple(float(v) for v in voxel_size)
         self.voxel_scale = tuple(int(v) for v in voxel_scale)
         self.kernel_size = tuple(int(v) for v in kernel_size)
@@ -30,6 +36,12 @@ class VoxelGrid:
         cfg.max_points_per_voxel = int(max_points_per_voxel)
         cfg.max_occ_voxels = int(max_occ_voxels_per_example)
         cfg.ranges[:] = self.ranges
+        self.compat = tuple(compat)
+        bad = set(self.compat) - {"truncate", "layered"}
+        if bad:
+            raise ValueError(f"VoxelGrid: unknown compat switches {sorted(bad)}")
+        cfg.compat = (KNN_TRUNCATE if "truncate" in self.compat else 0) | (KNN_LAYERED if "layered" in self.compat else 0)
+        self.max_points_per_voxel, self.max_occ_voxels = int(max_points_per_voxel), int(max_occ_voxels_per_example)
         self._h = C.c_void_p()
         _lib.check(_lib.lib().spf_grid_create(C.byref(cfg), C.byref(self._h)), "spf_grid_create")
         self._built_for = None
@@ -65,6 +77,15 @@ class VoxelGrid:
             _lib.check(_lib.lib().spf_grid_build(self._h, _lib.ptr(pts), n, _lib.stream_ptr()), "spf_grid_build")
         self._built_for = key
         self._points = pts  # keep the cloud alive: later kernels gather from it
+        if "truncate" not in self.compat:      # the exact specification keeps everything: say where upstream's capacity limits would bite
+            gi = self.info()
+            if gi["max_cell_points"] > self.max_points_per_voxel > 0 or gi["n_occupied"] > self.max_occ_voxels > 0:
+                import warnings
+
+                warnings.warn(f"VoxelGrid: fullest cell holds {gi['max_cell_points']} points (max_points_per_voxel = {self.max_points_per_voxel}), "
+                              f"{gi['n_occupied']} cells are occupied (max_occ_voxels = {self.max_occ_voxels}): upstream torch_knnquery would drop "
+                              "points / cells here, at random; this build keeps all of them (compat=('truncate',) applies the limits "
+                              "deterministically)", stacklevel=2)
 
     def query(self, raypos, k, radius_limit_scale, max_shading_points_per_ray):
         """raypos float32 [1,R,D,3] -> (sample_pidx int32 [1,Rv,SR,k] (-1 pad),
@@ -107,4 +128,4 @@ class VoxelGrid:
         gi = _lib.GridInfo()
         _lib.check(_lib.lib().spf_grid_get_info(self._h, C.byref(gi)), "spf_grid_get_info")
         return {"origin": tuple(gi.origin), "cell": tuple(gi.cell), "dims": tuple(gi.dims), "n_points": gi.n_points,
-                "n_in_range": gi.n_in_range, "n_occupied": gi.n_occupied}
+                "n_in_range": gi.n_in_range, "n_occupied": gi.n_occupied, "max_cell_points": gi.max_cell_points}

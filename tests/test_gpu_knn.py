@@ -111,3 +111,55 @@ def test_knn_edge_cases():
     assert empty["pidx"].shape == (0, 4, 8)
     with pytest.raises(Exception):
         g2.query_dense(q, 9, 2, 1)  # k > SPF_KMAX is refused loudly
+
+
+@pytest.mark.parametrize("compat", [("truncate",), ("layered",), ("truncate", "layered")])
+def test_upstream_compat_switches_match_their_oracle_twins(compat):
+    """SURVEY.md Appendix B switches (what the absent torch_knnquery source is believed to do, made deterministic): capacity limits
+    per cell / per grid and the own-cell early exit — HIP against the oracle's restatement of the same rules, bit for bit, on a
+    cloud dense enough that every rule bites."""
+    from oracle.voxel_grid import VoxelGridOracle
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.torch_knnquery import VoxelGrid
+
+    pts, _, base = syn.make_cloud(20000, spacing=0.012, seed=11)      # ~40 points per 0.075 cell
+    P, max_occ = 6, 150
+    args = ((0.025,) * 3, (3,) * 3, (3,) * 3, P, max_occ, (-1, -1, -1, 1, 1, 1))
+    orc = VoxelGridOracle(*args, compat=compat)
+    orc.set_pointset(pts)
+    g = VoxelGrid(*args, compat=compat)
+    g.set_pointset(torch.from_numpy(pts).cuda().unsqueeze(0))
+    info = g.info()
+    if "truncate" in compat:
+        assert info["max_cell_points"] <= P and info["n_occupied"] <= max_occ and int(orc.occ.sum()) == info["n_occupied"]
+        assert len(orc.idx_in) < len(pts) // 3, "the limits must actually drop points"
+    rng = np.random.default_rng(2)
+    x1 = (pts[rng.integers(0, len(pts), 3000)] + rng.normal(0, 0.01, size=(3000, 3))).astype(np.float32)
+    o = np.asarray([1.6, 0.2, 0.1], np.float32)
+    dirs = pts[rng.integers(0, len(pts), 64)] - o
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    z = np.sort(rng.uniform(0.8, 2.4, size=(64, 98)).astype(np.float32), axis=1)
+    xr = (o[None, None] + z[..., None] * dirs[:, None]).astype(np.float32)
+    exact = VoxelGridOracle(*args)
+    exact.set_pointset(pts)
+    differs = False
+    for x, sr in ((x1[:, None, :], 1), (xr, 80)):
+        pidx, loc, slot_sample, ray_valid = orc.query_dense(x, 8, 2, sr)
+        d = g.query_dense(torch.from_numpy(x).cuda(), 8, 2, sr)
+        assert np.array_equal(d["slot_sample"].cpu().numpy(), slot_sample)
+        assert np.array_equal(d["pidx"].cpu().numpy(), pidx)
+        assert np.array_equal(d["loc"].cpu().numpy(), loc)
+        assert np.array_equal(d["ray_valid"].cpu().numpy().astype(bool), ray_valid)
+        differs |= not np.array_equal(pidx, exact.query_dense(x, 8, 2, sr)[0])
+    assert differs, "on this cloud the compat rules must change some neighbour lists"
+
+
+def test_capacity_warning_without_truncation():
+    """The exact specification keeps every point: the Python shim says so when upstream's limits would have dropped some."""
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.torch_knnquery import VoxelGrid
+
+    pts, _, _ = syn.make_cloud(20000, spacing=0.012, seed=11)
+    g = VoxelGrid((0.025,) * 3, (3,) * 3, (3,) * 3, 26, 20000, (-1, -1, -1, 1, 1, 1))
+    with pytest.warns(UserWarning, match="max_points_per_voxel"):
+        g.set_pointset(torch.from_numpy(pts).cuda().unsqueeze(0))

@@ -70,3 +70,44 @@ def test_find_surface_points_and_local_loss_match_oracle_on_reference_stage_tens
     assert not hit0.any() and float(d0.abs().sum()) == 0.0
     d0.sum().backward()
     assert torch.isfinite(sdf_t.grad).all()
+
+
+def test_knn_compat_rules_of_the_oracle():
+    """oracle/voxel_grid.py compat switches: the capacity limits keep the lowest-index points / cells, the layered search returns
+    own-cell neighbours only when the own cell has k of them — checked against first principles on a dense cloud."""
+    from oracle.voxel_grid import VoxelGridOracle
+    from spurfies_amd import synthetic as syn
+
+    pts, _, _ = syn.make_cloud(6000, spacing=0.012, seed=3)
+    args = ((0.025,) * 3, (3,) * 3, (3,) * 3, 5, 40, (-1, -1, -1, 1, 1, 1))
+    exact = VoxelGridOracle(*args)
+    exact.set_pointset(pts)
+    cells = exact.cell_of(pts)
+    lin = (cells[:, 0] * exact.dims[1] + cells[:, 1]) * exact.dims[2] + cells[:, 2]
+    tr = VoxelGridOracle(*args, compat=("truncate",))
+    tr.set_pointset(pts)
+    assert np.array_equal(tr.dims, exact.dims) and np.array_equal(tr.origin, exact.origin)
+    kept = tr.in_range
+    first_idx = {}
+    for i, c in enumerate(lin):
+        first_idx.setdefault(int(c), i)
+    allowed = set(sorted(first_idx, key=first_idx.get)[:40])               # the 40 cells claimed first in index order
+    for c in np.unique(lin):
+        members = np.nonzero(lin == c)[0]
+        want = members[:5] if int(c) in allowed else members[:0]           # their 5 lowest-index points
+        assert np.array_equal(np.nonzero(kept & (lin == c))[0], want)
+    x = (pts[::7] + np.float32(0.004)).astype(np.float32)
+    lay = VoxelGridOracle(*args, compat=("layered",))
+    lay.set_pointset(pts)
+    a, b = exact.knn(x, 8, exact.radius(2)), lay.knn(x, 8, lay.radius(2))
+    xc = exact.cell_of(x)
+    n_own_only = 0
+    for m in range(len(x)):
+        d2 = ((pts - x[m]) ** 2).sum(1)
+        own = np.all(cells == xc[m], axis=1) & (d2 <= float(exact.radius(2)) ** 2 * (1 + 1e-6))
+        if own.sum() >= 8 + 2:                                             # clearly >= k in the own cell (margin for the fp32 radius test)
+            assert set(b[m][b[m] >= 0]) <= set(np.nonzero(np.all(cells == xc[m], axis=1))[0])
+            n_own_only += 1
+        elif own.sum() < 8 - 2:
+            assert np.array_equal(a[m], b[m])
+    assert n_own_only > 20 and not np.array_equal(a, b)
