@@ -207,7 +207,8 @@ int spf_color_pack(const float* w0, const float* b0, const float* w2, const floa
 int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot,
                       const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs,
                       int32_t k, const float* pts, const float* feat_color, const float* packed, float* agg3,
-                      float* act0, float* act1, float* act2, uint32_t* masks, int32_t arith, void* stream);
+                      float* act0, float* act1, float* act2, uint32_t* masks, int64_t* agg3_fixed,
+                      int32_t arith, void* stream);
 
 /* Data-gradient chain for g_agg3[p,256] = dL/d agg3: writes the pre-activation gradients G1..G3 [T,256]
  * (weight gradients of F_color.0/2/4 are then dW_l = G_l^T act_{l-1}: spf_wgrad), ADDS their column sums to
@@ -365,7 +366,8 @@ int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, c
                     const float* g_tv, int32_t n, int32_t k, float* g_feat_geo, int64_t* g_feat_geo_fixed, void* stream);
 
 /* Reproducible latent gradients.  The three latent-gradient scatters (spf_color_backward -> g_feat_color, spf_geo_backward_latents and
- * spf_tv_backward -> g_feat_geo) add with float atomics by default: the sum depends on the order the atomics land in (run-to-run
+ * spf_tv_backward -> g_feat_geo) and the forward's weighted mean (spf_color_forward -> agg3, up to four partial sums per entry) add
+ * with float atomics by default: the sum depends on the order the atomics land in (run-to-run
  * noise in the last bits).  With a non-NULL `*_fixed` argument (int64 [N, 64 | 32], zero before the first use) they instead add
  * every fp32 term as a 2^-48 fixed-point integer (64-bit integer atomics: associative, so order-independent; a term is exact when
  * its last mantissa bit is >= 2^-48, smaller ones round at 3.6e-15 absolute; |sum| < 2^14), and spf_fixed_accumulate rounds the sums

@@ -55,7 +55,7 @@ SIGNATURES = {
     "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "spf_color_packed_floats": (C.c_int64, []),
     "spf_color_pack": (C.c_int, [_P] * 8),
-    "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_color_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_rhead_packed_floats": (C.c_int64, []),
     "spf_rhead_pack": (C.c_int, [_P] * 10),

@@ -656,7 +656,7 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                         const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
                         const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k, const float* __restrict__ pts,
                         const float* __restrict__ feat_col, const float* packed, float* __restrict__ agg3, float* __restrict__ act0,
-                        float* __restrict__ act1, float* __restrict__ act2, uint32_t* __restrict__ masks) {
+                        float* __restrict__ act1, float* __restrict__ act2, uint32_t* __restrict__ masks, long long* __restrict__ agg3_fixed) {
     __shared__ __attribute__((aligned(16))) __bf16 X[CX_LDS_BF16];
     __shared__ __attribute__((aligned(8))) float s_wp[128];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -791,8 +791,13 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                     v1 = p1 ? v1 : v1 * 0.01f;
                     if (p != cur) {
                         if (cur >= 0) {
-                            atomicAdd(&agg3[(size_t)cur * 256 + c0], a0);
-                            atomicAdd(&agg3[(size_t)cur * 256 + c0 + 32], a1);
+                            if (agg3_fixed) {          // order-independent accumulation (common.h): up to four partial sums meet per entry
+                                fixed_add(&agg3_fixed[(size_t)cur * 256 + c0], a0);
+                                fixed_add(&agg3_fixed[(size_t)cur * 256 + c0 + 32], a1);
+                            } else {
+                                atomicAdd(&agg3[(size_t)cur * 256 + c0], a0);
+                                atomicAdd(&agg3[(size_t)cur * 256 + c0 + 32], a1);
+                            }
                         }
                         cur = p;
                         a0 = 0.f;
@@ -802,8 +807,13 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                     a1 += wp.x * v1;
                 }
             if (cur >= 0) {
-                atomicAdd(&agg3[(size_t)cur * 256 + c0], a0);
-                atomicAdd(&agg3[(size_t)cur * 256 + c0 + 32], a1);
+                if (agg3_fixed) {
+                    fixed_add(&agg3_fixed[(size_t)cur * 256 + c0], a0);
+                    fixed_add(&agg3_fixed[(size_t)cur * 256 + c0 + 32], a1);
+                } else {
+                    atomicAdd(&agg3[(size_t)cur * 256 + c0], a0);
+                    atomicAdd(&agg3[(size_t)cur * 256 + c0 + 32], a1);
+                }
             }
             if (STORE) *reinterpret_cast<u32x2*>(mk + 1024 + lane * 8 + 2 * wave) = u32x2{mw0, mw1};      // [row][8 words]
         }
@@ -1043,7 +1053,7 @@ int spf_color_pack(const float* w0, const float* b0, const float* w2, const floa
 int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const int32_t* point_slot, const int32_t* pair_off,
                       const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* pts,
                       const float* feat_color, const float* packed, float* agg3, float* act0, float* act1, float* act2, uint32_t* masks,
-                      int32_t arith, void* stream) {
+                      int64_t* agg3_fixed, int32_t arith, void* stream) {
     if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_color_forward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_forward: bad sizes");
     if (max_pairs == 0) return SPF_OK;
@@ -1051,16 +1061,18 @@ int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const
         return spf::fail(SPF_EINVAL, "spf_color_forward: null pointer");
     const bool store = act0 != nullptr;
     if (store && (!act1 || !act2 || !masks)) return spf::fail(SPF_EINVAL, "spf_color_forward: training buffers must be given together");
+    if (agg3_fixed && arith != SPF_ARITH_SPLIT) return spf::fail(SPF_EINVAL, "spf_color_forward: the fixed-point accumulator needs SPF_ARITH_SPLIT");
+    long long* afx = reinterpret_cast<long long*>(agg3_fixed);
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
     if (arith == SPF_ARITH_SPLIT) {
         const int b1 = tiles < 256 ? tiles : 256;   // one workgroup per CU (bf16 planes: 101 KB of LDS)
         if (store)
             color_forward_x3_kernel<true><<<b1, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts,
-                                                                               feat_color, packed, agg3, act0, act1, act2, masks);
+                                                                               feat_color, packed, agg3, act0, act1, act2, masks, afx);
         else
             color_forward_x3_kernel<false><<<b1, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k,
-                                                                                pts, feat_color, packed, agg3, nullptr, nullptr, nullptr, nullptr);
+                                                                                pts, feat_color, packed, agg3, nullptr, nullptr, nullptr, nullptr, afx);
         SPF_LAUNCH_CHECK("color_forward_x3_kernel");
         return SPF_OK;
     }

@@ -322,11 +322,14 @@ class ColorAgg(_GradModeFunction):
                     torch.empty((rows, 256), dtype=torch.float32, device=dev), torch.empty((tiles, 3, 512), dtype=torch.int32, device=dev)]
         else:
             bufs = [None] * 4
+        acc = _fixed_acc(agg3) if (_SCATTER["mode"] == "fixed" and _ARITH["color"] == 0) else None
         with torch.cuda.device(dev), _prof.span("color_fwd", pairs=pl.n_pairs, train=bool(train)):
             _lib.check(_lib.lib().spf_color_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                     _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), NP, pl.k, _lib.ptr(pts),
                                                     _lib.ptr(feat_col.detach()), _lib.ptr(packed), _lib.ptr(agg3),
-                                                    *[_lib.ptr(a) for a in bufs], _ARITH["color"], _lib.stream_ptr()), "spf_color_forward")
+                                                    *[_lib.ptr(a) for a in bufs], _lib.ptr(acc), _ARITH["color"], _lib.stream_ptr()), "spf_color_forward")
+        if acc is not None:      # the RBF-weighted mean meets up to four partial sums per entry: order-independent in this mode
+            _fixed_flush(acc, agg3)
         ctx.arith = _ARITH["color"]
         if train:
             ctx.save_for_backward(wn, packed, *bufs)
