@@ -203,3 +203,110 @@ def write_ply_points(path, pts, colors=None):
     with open(path, "wb") as f:
         f.write((header + "end_header\n").encode())
         f.write(rec.tobytes())
+
+
+# -------------------------------------------------------------------------------------------------------------------------------
+# Back half of the route: what the reference does with the mesh before it quotes a Chamfer number.
+def largest_component(verts, faces):
+    """plots.py:213-215: keep the connected component (faces linked through shared EDGES, as trimesh.split(only_watertight=False))
+    with the largest surface area; vertices are re-indexed.  -> (verts, faces)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    verts, faces = np.asarray(verts, np.float64), np.asarray(faces, np.int64)
+    if len(faces) == 0:
+        return verts[:0], faces
+    e = np.sort(np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]], 0), 1)
+    fid = np.tile(np.arange(len(faces)), 3)
+    order = np.lexsort((e[:, 1], e[:, 0]))
+    e, fid = e[order], fid[order]
+    same = np.all(e[1:] == e[:-1], axis=1)                      # consecutive entries share an edge
+    a, b = fid[:-1][same], fid[1:][same]
+    adj = coo_matrix((np.ones(len(a)), (a, b)), shape=(len(faces), len(faces)))
+    _, label = connected_components(adj, directed=False)
+    p0, p1, p2 = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(p1 - p0, p2 - p0), axis=1)
+    keep = label == np.argmax(np.bincount(label, weights=area))
+    used = np.unique(faces[keep])
+    remap = np.full(len(verts), -1, np.int64)
+    remap[used] = np.arange(len(used))
+    return verts[used], remap[faces[keep]]
+
+
+def sample_mesh_points(verts, faces, thresh):
+    """evals/eval_dtu.py:20-29,72-109 ('mesh' mode): the mesh vertices plus, per triangle, the lattice points
+    (i + 0.5) / n1 v1 + (j + 0.5) / n2 v2 with i / n1 + j / n2 < 1 (n = floor(edge / (thresh sqrt(l1 l2 / 2A)))), so that the
+    samples are about `thresh` apart on every triangle."""
+    verts, faces = np.asarray(verts, np.float64), np.asarray(faces, np.int64)
+    tri = verts[faces]
+    v1, v2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    l1, l2 = np.linalg.norm(v1, axis=-1), np.linalg.norm(v2, axis=-1)
+    area2 = np.linalg.norm(np.cross(v1, v2), axis=-1)
+    ok = area2 > 0
+    tri, v1, v2, l1, l2, area2 = tri[ok], v1[ok], v2[ok], l1[ok], l2[ok], area2[ok]
+    thr = thresh * np.sqrt(l1 * l2 / area2)
+    n1, n2 = np.floor(l1 / thr), np.floor(l2 / thr)
+    out = [verts]
+    for key in np.unique(np.stack([n1, n2], 1), axis=0):     # triangles with the same lattice share the barycentric offsets
+        sel = (n1 == key[0]) & (n2 == key[1])
+        c = np.mgrid[: int(key[0]) + 1, : int(key[1]) + 1].astype(np.float64) + 0.5
+        c[0] /= max(key[0], 1e-7)
+        c[1] /= max(key[1], 1e-7)
+        kk = c.reshape(2, -1).T
+        kk = kk[kk.sum(-1) < 1]
+        if len(kk):
+            out.append((v1[sel][:, None, :] * kk[None, :, :1] + v2[sel][:, None, :] * kk[None, :, 1:] + tri[sel][:, :1, :]).reshape(-1, 3))
+    return np.concatenate(out, 0)
+
+
+def downsample_points(points, thresh, seed=None):
+    """evals/eval_dtu.py:118-138: shuffle, then greedily keep a point and strike out everything within `thresh` of it."""
+    from scipy.spatial import cKDTree
+
+    pts = np.array(points, np.float64)
+    np.random.default_rng(seed).shuffle(pts, axis=0)
+    nbrs = cKDTree(pts).query_ball_point(pts, thresh)
+    mask = np.ones(len(pts), bool)
+    for cur, idxs in enumerate(nbrs):
+        if mask[cur]:
+            mask[idxs] = False
+            mask[cur] = True
+    return pts[mask]
+
+
+def chamfer_dtu(data_pts, gt_pts, max_dist=20.0, thresh=None, seed=0, bbox=None):
+    """evals/eval_dtu.py:110-232 without the scan-specific files (ObsMask / ground plane come with the DTU download): optional greedy
+    down-sampling of the reconstruction at `thresh`, optional axis-aligned `bbox` = (lo [3], hi [3]) in place of the observation
+    mask, then accuracy = mean distance data -> ground truth and completeness = ground truth -> data, each over the distances below
+    `max_dist`, and their mean.  Units are those of the inputs (the reference works in millimetres: thresh 0.2, max_dist 20).
+    -> dict(accuracy, completeness, overall, n_data, n_gt)."""
+    from scipy.spatial import cKDTree
+
+    data = np.asarray(data_pts, np.float64)
+    gt = np.asarray(gt_pts, np.float64)
+    if thresh is not None:
+        data = downsample_points(data, thresh, seed)
+    data_in = data
+    if bbox is not None:
+        lo, hi = np.asarray(bbox[0], np.float64), np.asarray(bbox[1], np.float64)
+        data_in = data[np.all((data >= lo) & (data < hi), axis=1)]
+    d2s = cKDTree(gt).query(data_in)[0]
+    s2d = cKDTree(data).query(gt)[0]
+    acc = float(d2s[d2s < max_dist].mean()) if (d2s < max_dist).any() else float("nan")
+    comp = float(s2d[s2d < max_dist].mean()) if (s2d < max_dist).any() else float("nan")
+    return {"accuracy": acc, "completeness": comp, "overall": 0.5 * (acc + comp), "n_data": len(data_in), "n_gt": len(gt)}
+
+
+def extract_surface(sdf, resolution, input_min, input_max, splitn=100000, device="cuda", keep_largest=True):
+    """get_surface_by_grid's plain branch (plots.py:188-287 with higher_res=False): reference-shaped grid over the box, chunked SDF
+    sweep, iso-surface at 0, largest component.  -> (verts, faces, volume, grid); (None, None, volume, grid) when the SDF does not
+    cross zero inside the box."""
+    grid = get_grid(None, resolution, input_min=np.asarray(input_min), input_max=np.asarray(input_max), eps=0.0)
+    vol = sdf_volume(sdf, grid, splitn=splitn, device=device)
+    ok = vol != SDF_FILL
+    if not ok.any() or vol[ok].min() > 0 or vol[ok].max() < 0:
+        return None, None, vol, grid
+    verts, faces = triangulate(vol, grid)
+    if keep_largest and len(faces):
+        verts, faces = largest_component(verts, faces)
+    return verts, faces, vol, grid

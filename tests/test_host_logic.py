@@ -111,3 +111,40 @@ def test_knn_compat_rules_of_the_oracle():
         elif own.sum() < 8 - 2:
             assert np.array_equal(a[m], b[m])
     assert n_own_only > 20 and not np.array_equal(a, b)
+
+
+def test_mesh_route_back_half_on_an_analytic_sphere():
+    """SURVEY.md section 8(f) N3, back half (evals/eval_dtu.py:60-254, plots.py:213-215) on a case with a known answer: two spheres,
+    the small one is discarded by the largest-component rule; triangle sampling covers the surface at the requested density; greedy
+    down-sampling leaves no two points closer than the threshold; accuracy / completeness against exact sphere points are at the
+    discretisation error and zero for identical clouds."""
+    from spurfies_amd.utils import surface
+
+    n = 40
+    ax = np.linspace(-1.0, 1.0, n)
+    grid = {"xyz": [ax, ax, ax]}
+    gx, gy, gz = np.meshgrid(ax, ax, ax)
+    big = np.sqrt(gx ** 2 + gy ** 2 + gz ** 2) - 0.5
+    small = np.sqrt((gx - 0.8) ** 2 + (gy - 0.8) ** 2 + (gz - 0.8) ** 2) - 0.12
+    vol = np.minimum(big, small).astype(np.float32)
+    verts, faces = surface.triangulate(vol, grid)
+    v1, f1 = surface.largest_component(verts, faces)
+    assert len(f1) < len(faces) and np.abs(np.linalg.norm(v1, axis=1) - 0.5).max() < 0.01      # only the big sphere is left
+    e = np.sort(np.concatenate([f1[:, [0, 1]], f1[:, [1, 2]], f1[:, [2, 0]]], 0), 1)
+    assert (np.unique(e, axis=0, return_counts=True)[1] == 2).all()                             # and it is closed
+    pts = surface.sample_mesh_points(v1, f1, 0.01)
+    assert len(pts) > 3 * len(v1) and np.abs(np.linalg.norm(pts, axis=1) - 0.5).max() < 0.01
+    down = surface.downsample_points(pts, 0.03, seed=1)
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(down).query(down, k=2)
+    assert d[:, 1].min() >= 0.03 and len(down) < len(pts) / 3
+    assert cKDTree(down).query(pts)[0].max() <= 0.03 + 1e-12                                   # nothing struck out without a keeper nearby
+    rng = np.random.default_rng(0)
+    gt = rng.standard_normal((20000, 3))
+    gt = 0.5 * gt / np.linalg.norm(gt, axis=1, keepdims=True)
+    res = surface.chamfer_dtu(pts, gt, max_dist=0.2, thresh=0.02, seed=0)
+    assert res["accuracy"] < 0.01 and res["completeness"] < 0.015 and abs(res["overall"] - 0.5 * (res["accuracy"] + res["completeness"])) < 1e-15
+    same = surface.chamfer_dtu(gt, gt)
+    assert same["accuracy"] == 0.0 and same["completeness"] == 0.0
+    far = surface.chamfer_dtu(np.concatenate([gt, [[5.0, 5.0, 5.0]]]), gt, max_dist=0.2)         # outliers beyond max_dist are not averaged in
+    assert far["accuracy"] == 0.0

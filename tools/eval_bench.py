@@ -15,7 +15,7 @@ from spurfies_amd.conf import default_model_conf  # noqa: E402
 from spurfies_amd.model.pointneus_disent import PointVolSDF  # noqa: E402
 
 dev = torch.device("cuda", 0)
-scene = syn.make_scene(10000, seed=0)
+scene = syn.make_scene(10000, seed=0, prior="fitted")
 st = scene["state"]
 conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
 model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=dev)
@@ -50,3 +50,20 @@ with torch.no_grad():
     dt = time.perf_counter() - t0
     hit = float((sdf < 999.0).float().mean())
     print(f"get_sdf_eval: {pts.shape[0]} grid points ({n}^3, {100 * hit:.1f} % near the cloud) in {dt * 1e3:.1f} ms = {pts.shape[0] / dt / 1e6:.1f} M points/s")
+
+    # the reference's mesh extraction samples ~512 points along the shortest axis of the box (eval_spurfies.py:141-157, plots.py:188-287)
+    if "--sweep512" in sys.argv:
+        from spurfies_amd.utils import surface
+
+        b = scene["base_radius"] * 1.25
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        verts, faces, vol, grid = surface.extract_surface(model.get_sdf_eval, 512, [-b] * 3, [b] * 3)
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        vol = surface.sdf_volume(model.get_sdf_eval, grid)
+        torch.cuda.synchronize()
+        t_sweep = time.perf_counter() - t0
+        print(f"512-grid sweep: {vol.size} points in {t_sweep:.2f} s = {vol.size / t_sweep / 1e6:.1f} M points/s (incl. H2D of the chunks and D2H of the "
+              f"volume); with the host-side triangulation + largest component: {t_all:.1f} s, {0 if faces is None else len(faces)} faces")
