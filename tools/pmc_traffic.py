@@ -1,6 +1,6 @@
 """HBM traffic per launch of every kernel of the step, the way MI355X_MICROARCH.md prescribes: separate rocprofv3 --pmc passes
 for FETCH_SIZE and WRITE_SIZE (counter collection only, plus --kernel-trace), gfx950 correction hbm = (2*FETCH + WRITE) KiB.
-Run on the GPU box from the repo root; writes gpurun_out/r01_pmc_traffic.json (copy into profiles/)."""
+Run on the GPU box from the repo root; writes gpurun_out/r02_pmc_traffic.json (copy into profiles/)."""
 import collections
 import csv
 import glob
@@ -28,7 +28,7 @@ for k, v in out.items():
 rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on bench.py --steps 3 --warmup 1; per-launch values of the "
                "largest launch per kernel (main pass). hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reads half of a wide "
                "coalesced stream (MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are included in both counters.",
-       "config": {"points": POINTS, "rays": RAYS}, "kernels": out}
-json.dump(rec, open("gpurun_out/r01_pmc_traffic.json", "w"), indent=1)
+       "config": {"points": POINTS, "rays": RAYS, "prior": "fitted"}, "kernels": out}
+json.dump(rec, open("gpurun_out/r02_pmc_traffic.json", "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_max_corrected"])[:12]:
     print(f"{k[:60]:60s} {v['hbm_bytes_max_corrected'] / 1e6:10.1f} MB")

@@ -18,7 +18,11 @@ def short(name):
 
 def load(tag, steps):
     out = {}
-    for r in csv.DictReader(open(f"gpurun_out/{tag}_kernel_stats.csv")):
+    rows = list(csv.DictReader(open(f"gpurun_out/{tag}_kernel_stats.csv")))
+    one_per_step = [int(r["Calls"]) for r in rows if "color_forward_x3_kernel<true>" in r["Name"] or "color_forward_kernel<true>" in r["Name"]]
+    if one_per_step:
+        steps = one_per_step[0]          # the colour trunk runs once per optimisation step: the trace's own step count
+    for r in rows:
         k = short(r["Name"])
         c, t = out.get(k, (0.0, 0.0))
         out[k] = (c + int(r["Calls"]) / steps, t + int(r["TotalDurationNs"]) / steps / 1e3)
