@@ -318,11 +318,11 @@ int64_t spf_wgrad_workspace_floats(int32_t C);
 /* arith (see SPF_ARITH_*) applies for C > 32; narrower operands always take the fp32-MFMA kernel.
  * layout: 0 = both operands are row-major [rows, .]; SPF_WGRAD_G_TILES / SPF_WGRAD_A_TILES (or-ed): that operand is stored as
  * K-MAJOR BLOCKS of 16 rows x 256 features, element (row, feature f) at ((256 (row / 16) + f) 16 + row % 16) — what
- * spf_color_forward (act1, act2) and spf_color_backward (G2, G1) write with SPF_ARITH_SPLIT: one 16-row MFMA K-step of an
+ * spf_color_forward (act1, act2) writes with SPF_ARITH_SPLIT: one 16-row MFMA K-step of an
  * operand is a contiguous 16-KB run with each feature's rows adjacent.  Blocked operands need SPF_ARITH_SPLIT, C > 32,
  * max_rows % 16 == 0 (whole blocks allocated) and, for A, C = 256; lda is ignored for a blocked A.
- * SPF_WGRAD_G_TILES64 (C = 256 only): G in K-major TILES of 64 rows, element (row, f) at ((256 (row / 64) + f) 64 + row % 64), the
- * form a row-per-lane producer writes in full cache lines (spf_color_backward's G3); max_rows % 64 == 0. */
+ * SPF_WGRAD_G_TILES64: G in K-major TILES of 64 rows, element (row, f) at ((256 (row / 64) + f) 64 + row % 64): what
+ * spf_color_backward writes for G3 / G2 / G1 (full 128-byte lines from its registers); max_rows % 64 == 0. */
 #define SPF_WGRAD_G_TILES 1
 #define SPF_WGRAD_A_TILES 2
 #define SPF_WGRAD_G_TILES64 4

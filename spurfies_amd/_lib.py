@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libspurfies_hip.so")
+LIB_PATH = os.environ.get("SPF_LIB_PATH") or os.path.join(HERE, "lib", "libspurfies_hip.so")      # SPF_LIB_PATH: same-box A/B of two builds (tools/ab_prof.sh)
 
 
 class GridConfig(C.Structure):

@@ -27,6 +27,23 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, flags: str, verbose: bool = False) -> str:
+    """Side build for same-box A/B runs (tools/ab_prof.sh): lib/variants/<name>.so compiled with extra flags; select with SPF_LIB_PATH."""
+    vdir = os.path.join(LIBDIR, "variants", name)
+    os.makedirs(vdir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(vdir, src.replace(".hip", ".o"))
+        subprocess.run([hipcc, *FLAGS, *flags.split(), "-c", os.path.join(CSRC, src), "-o", obj], check=True)
+        objs.append(obj)
+    out = os.path.join(LIBDIR, "variants", name + ".so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    if verbose:
+        print(out)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
@@ -48,5 +65,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--variant" in sys.argv:          # python -m spurfies_amd.build --variant NAME "-DFLAG ..."
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2] if len(sys.argv) > i + 2 else ""))
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

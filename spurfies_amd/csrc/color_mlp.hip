@@ -614,7 +614,7 @@ __device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2
                 for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], bits[n]);
                 store_quad_x3(X, 32 * n + j, f0, out);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) tile_out[(2 * n + (j >> 4)) * 4096 + (f0 + e) * 16 + (j & 15)] = out[e];      // K-major blocks for spf_wgrad
+                for (int e = 0; e < 4; ++e) tile_out[(f0 + e) * 64 + 32 * n + j] = out[e];      // K-major 64-row tile (SPF_WGRAD_G_TILES64): full 128-byte lines
             }
         }
 }

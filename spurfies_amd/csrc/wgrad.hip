@@ -567,9 +567,9 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     const bool g64 = layout & SPF_WGRAD_G_TILES64, gk = (layout & SPF_WGRAD_G_TILES) || g64, ak = layout & SPF_WGRAD_A_TILES;
     if (layout & ~(SPF_WGRAD_G_TILES | SPF_WGRAD_A_TILES | SPF_WGRAD_G_TILES64)) return spf::fail(SPF_EINVAL, "spf_wgrad: unknown layout bits %d", layout);
     if ((layout & SPF_WGRAD_G_TILES) && g64) return spf::fail(SPF_EINVAL, "spf_wgrad: G is either in 16-row blocks or in 64-row tiles");
-    if ((gk || ak) && (arith != SPF_ARITH_SPLIT || NT < 4 || (max_rows % (g64 ? 64 : 16)) || (ak && C != 256) || (g64 && C != 256)))
+    if ((gk || ak) && (arith != SPF_ARITH_SPLIT || NT < 4 || (max_rows % (g64 ? 64 : 16)) || (ak && C != 256)))
         return spf::fail(SPF_EINVAL, "spf_wgrad: blocked operands need SPF_ARITH_SPLIT, C > 32, max_rows a multiple of 16 (64 for SPF_WGRAD_G_TILES64: whole "
-                                     "blocks) and C = 256 for a blocked A or 64-row G tiles");
+                                     "blocks) and C = 256 for a blocked A");
     if (NT >= 4 && ((C % 4) || (lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad: C and lda must be multiples of 4 for C > 32 (C=%d lda=%d)", C, lda);
     hipStream_t s = (hipStream_t)stream;
     int blocks = spf::div_up(max_rows, 512);
@@ -589,7 +589,8 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
         wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align);
     } else if (arith == SPF_ARITH_SPLIT && NT == 4) {
         const int b8 = blocks > 256 ? 256 : blocks;
-        if (gk) wgrad_split8_kernel<4, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        if (g64) wgrad_split8_kernel<4, 2, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        else if (gk) wgrad_split8_kernel<4, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         else wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         dbias = nullptr;
         wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align);

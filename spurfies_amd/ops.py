@@ -365,18 +365,18 @@ class ColorAgg(_GradModeFunction):
             _fixed_flush(acc, g_feat)
         # split-product kernels (the default) leave the bias gradients to the weight-gradient GEMM (column sums of G)
         kb = (lambda b: b) if ctx.arith == 0 else (lambda b: None)
-        # the bf16-piece kernels write act1 / act2 / G2 / G1 as K-major tiles (include/spurfies_hip.h: SPF_WGRAD_*_TILES)
+        # the bf16-piece kernels write act1 / act2 as K-major 16-row blocks, G3 / G2 / G1 as K-major 64-row tiles (include/spurfies_hip.h: SPF_WGRAD_*)
         GT, AT, G64 = (WGRAD_G_TILES, WGRAD_A_TILES, WGRAD_G_TILES64) if ctx.arith == 0 else (0, 0, 0)
         if sk is not None:
             # layer 0's [256,104] comes in the kernels' internal column order: one index_add_ into the reference order
-            sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=GT)[:, :103])
-            wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2), layout=GT | AT)
+            sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=G64)[:, :103])
+            wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2), layout=G64 | AT)
             wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=G64 | AT)
             return (None,) * 13
         # exact-size (default) and worst-case (sync-free) buffers alike: the weight-gradient kernel reads the row count on the device
         dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
-        dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=GT)[:, :103]   # [256,104] comes in the kernels' internal column order
-        dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2), layout=GT | AT), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4), layout=G64 | AT)
+        dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=G64)[:, :103]   # [256,104] comes in the kernels' internal column order
+        dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2), layout=G64 | AT), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4), layout=G64 | AT)
         grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4)
         return grads + (None,) * 6
 

@@ -142,7 +142,7 @@ def test_tiled_operands_match_row_major(rows, layout):
     base = ops.wgrad(G, A, n)
     assert _err(got, ref) < 2e-6 + 2.0 * _err(base, ref)
     np.testing.assert_allclose(db.double().cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-5, atol=2e-5 * rows ** 0.5 + 1e-5)     # fp32 sums of `rows` N(0,1) terms, atomics in any order
-    if layout == 1:          # the 104-column operand of F_color's first layer stays row-major next to a tiled G
+    if layout in (1, 4):     # the 104-column operand of F_color's first layer stays row-major next to a blocked / tiled G
         A104 = A[:, :104].contiguous()
-        got4 = ops.wgrad(Gx, A104, n, layout=1)
+        got4 = ops.wgrad(Gx, A104, n, layout=layout)
         assert _err(got4, G[:rows].double().t() @ A104[:rows].double()) < 1e-5
