@@ -8,6 +8,7 @@ across ranks and gradients are summed with one all-reduce of a flat buffer (spur
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import dist as sdist
@@ -239,7 +240,9 @@ class SyntheticDataset(torch.utils.data.Dataset):
     """Stand-in for spurfies/datasets/dtu.py:DTUDataset (images / cameras come from an unavailable download): same item layout
     `(idx, sample, ground_truth)`, `collate_fn`, `change_sampling_idx`, `total_pixels`, `img_res`."""
 
-    def __init__(self, scene, img_res=(576, 768), n_views=3, seed=0):
+    def __init__(self, scene, img_res=(576, 768), n_views=3, seed=0, local=False):
+        """local=True: every item carries a synthetic `local_data` dict (synthetic.make_local_data: feature maps + MVS camera packs of the
+        shapes datasets/dtu.py:268-291 provides), so the feature-consistency loss (local_weight 0.5) takes part in the optimisation."""
         from . import synthetic as syn
 
         self.img_res = list(img_res)
@@ -256,6 +259,10 @@ class SyntheticDataset(torch.utils.data.Dataset):
         cx, cy = syn.CX, syn.CY
         self.mask = [(((self.uv[:, 0] - cx) ** 2 + (self.uv[:, 1] - cy) ** 2) < (0.45 * img_res[0]) ** 2).float() for _ in range(n_views)]
         self.sampling_idx = None
+        self.local = None
+        if local:
+            self.local = [{k: (torch.from_numpy(np.asarray(v)) if isinstance(v, (np.ndarray, np.floating)) else v)
+                           for k, v in syn.make_local_data(scene, v_, seed=seed).items()} for v_ in range(n_views)]
 
     def __len__(self):
         return self.n_images
@@ -265,7 +272,7 @@ class SyntheticDataset(torch.utils.data.Dataset):
         self.sampling_idx = None if sampling_size == -1 else torch.randperm(self.total_pixels)[:sampling_size]
 
     def __getitem__(self, idx):
-        sample = {"uv": self.uv, "intrinsics": self.intrinsics, "pose": self.poses[idx], "local_data": None}
+        sample = {"uv": self.uv, "intrinsics": self.intrinsics, "pose": self.poses[idx], "local_data": None if self.local is None else self.local[idx]}
         if self.sampling_idx is not None:            # select first, widen the mask to three channels afterwards
             sample["uv"] = self.uv[self.sampling_idx]
             gt = {"rgb": self.rgb[idx][self.sampling_idx], "mask": self.mask[idx][self.sampling_idx][:, None].repeat(1, 3)}
@@ -276,7 +283,8 @@ class SyntheticDataset(torch.utils.data.Dataset):
     @staticmethod
     def collate_fn(batch):
         idx, samples, gts = zip(*batch)
-        stack = lambda ds: {k: (None if ds[0][k] is None else torch.stack([d[k] for d in ds])) for k in ds[0]}
+        # datasets/dtu.py:339-356: `local_data` is passed through from the first item, everything else is stacked
+        stack = lambda ds: {k: (ds[0][k] if (k == "local_data" or ds[0][k] is None) else torch.stack([d[k] for d in ds])) for k in ds[0]}
         return torch.as_tensor(idx), stack(samples), stack(gts)
 
 
@@ -383,6 +391,8 @@ class VolOpt:
         indices, model_input, ground_truth = batch
         dev = self.model.neural_pts.device
         model_input = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in model_input.items()}
+        if model_input.get("local_data") is not None:          # train.py:339-343
+            model_input["local_data"] = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in model_input["local_data"].items()}
         ground_truth = {k: v.to(dev) for k, v in ground_truth.items()}
         self.step.iter_step = self.iter_step
         losses, out = self.step(model_input, ground_truth)
