@@ -17,6 +17,7 @@ _MAP = {
     "spurfies.utils.rend_util": "spurfies_amd.utils.rend_util",
     "spurfies.utils.general": "spurfies_amd.utils.general",
     "spurfies.train": "spurfies_amd.train",
+    "spurfies.feat_utils": "spurfies_amd.feat_utils",
 }
 
 

@@ -20,8 +20,10 @@ def test_reference_names_resolve_after_install():
     from spurfies.utils.rend_util import get_camera_params, lift
 
     # signatures the reference's call sites rely on
-    assert list(inspect.signature(VoxelGrid.__init__).parameters)[1:] == [
+    assert list(inspect.signature(VoxelGrid.__init__).parameters)[1:7] == [
         "voxel_size", "voxel_scale", "kernel_size", "max_points_per_voxel", "max_occ_voxels_per_example", "ranges"]
+    # one optional extra after the reference's six: the upstream-compatibility switches, default = the frozen specification
+    assert inspect.signature(VoxelGrid.__init__).parameters["compat"].default == ()
     assert list(inspect.signature(VoxelGrid.query).parameters)[1:] == ["raypos", "k", "radius_limit_scale", "max_shading_points_per_ray"]
     assert list(inspect.signature(PointVolSDF.__init__).parameters)[1:4] == ["conf", "scan_id", "dataset"]
     assert list(inspect.signature(PointVolSDF.forward).parameters)[1:] == ["input", "fast"]
