@@ -107,9 +107,12 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
  *   point_slot [R*SR] int32  flat slot id (r*SR+s) of the p-th valid point, ray-major order
  *   slot_point [R*SR] int32  inverse map, -1 for slots that are not valid points
  *   n_points   [1]    int32  number of valid points P (stays on the device)
- * scratch: >= R+1 int32. */
+ * scratch: >= R+1 int32.
+ * fill_sdf [R*SR] / fill_grad [R*SR,3] (optional): every slot of them is set to fill_value / 0 on the way — the rows spf_geo_forward
+ * leaves untouched because they are not valid points (the reference's 1000 filler, pointneus_disent.py:271,371,445,703). */
 int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t* point_slot,
-                       int32_t* slot_point, int32_t* n_points, int32_t* scratch, void* stream);
+                       int32_t* slot_point, int32_t* n_points, int32_t* scratch, float* fill_sdf, float fill_value,
+                       float* fill_grad, void* stream);
 
 /* Load-time voxel thinning of the .ply cloud (spurfies/model/utils.py:21-27, construct_vox_points_closest): integer cell of
  * every point, cells[i] = floor((xyz[i] - space_min) / voxel) in float32 with IEEE division (what torch computes on the CPU;
@@ -359,11 +362,13 @@ int spf_scatter_add_rows(const float* src, const int32_t* idx, int64_t m, int32_
 /* Total-variation regulariser of the geometry latents over the static neighbour graph
  * (spurfies/model/utils.py:221-282): nbr[n,k] int32 (any valid index where w == 0), w[n,k] inverse-
  * distance weights (0 = absent), norm[n] = sum_j w.  tv[i] = sum_j w_ij |f_j - f_i|_1 / norm_i
- * (the caller takes the mean).  Backward accumulates into g_feat_geo[n,32] (float atomics). */
+ * (the caller takes the mean).  Backward accumulates into g_feat_geo[n,32] (float atomics); the upstream gradient of tv_i is
+ * g_tv[i * g_tv_stride] * scale (stride 0 + scale 1/n: the gradient of the mean, one device scalar for all points). */
 int spf_tv_forward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm, int32_t n,
                    int32_t k, float* tv, void* stream);
 int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm,
-                    const float* g_tv, int32_t n, int32_t k, float* g_feat_geo, int64_t* g_feat_geo_fixed, void* stream);
+                    const float* g_tv, int32_t g_tv_stride, float scale, int32_t n, int32_t k, float* g_feat_geo,
+                    int64_t* g_feat_geo_fixed, void* stream);
 
 /* Reproducible latent gradients.  The three latent-gradient scatters (spf_color_backward -> g_feat_color, spf_geo_backward_latents and
  * spf_tv_backward -> g_feat_geo) and the forward's weighted mean (spf_color_forward -> agg3, up to four partial sums per entry) add

@@ -46,7 +46,7 @@ SIGNATURES = {
     "spf_grid_build": (C.c_int, [_P, _P, _I, _P]),
     "spf_grid_get_info": (C.c_int, [_P, C.POINTER(GridInfo)]),
     "spf_grid_query": (C.c_int, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
-    "spf_compact_points": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P]),
+    "spf_compact_points": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P]),
     "spf_voxel_cells": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_float * 3), _F, _P, _P]),
     "spf_geo_packed_floats": (C.c_int64, []),
     "spf_geo_pack": (C.c_int, [_P] * 14),
@@ -72,7 +72,7 @@ SIGNATURES = {
     "spf_wgrad_batched": (C.c_int, [C.POINTER(WgradProblem), _I, _P, _I, _P, _I, _P]),
     "spf_scatter_add_rows": (C.c_int, [_P, _P, C.c_int64, _I, _P, _P]),
     "spf_tv_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
-    "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P]),
     "spf_fixed_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
     "spf_camera_rays": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "spf_adam_workspace_floats": (C.c_int64, []),

@@ -291,7 +291,7 @@ template <bool LAYERED>
 __global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ raypos, int R, int D, int SR, int k,
                                                   float rad2, GridDev g, int hkx, int hky, int hkz,
                                                   const int32_t* __restrict__ slot_sample, int32_t* __restrict__ pidx,
-                                                  float* __restrict__ loc, uint8_t* __restrict__ slot_valid) {
+                                                  float* __restrict__ loc, uint8_t* __restrict__ slot_valid, uint8_t* __restrict__ ray_valid1) {
     constexpr unsigned long long NONE = ~0ull;
     const size_t t8 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t gid = t8 >> 3;
@@ -376,6 +376,7 @@ __global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ rayp
         loc[gid * 3 + 1] = y;
         loc[gid * 3 + 2] = z;
         slot_valid[gid] = key[0] != NONE;
+        if (ray_valid1) ray_valid1[gid] = key[0] != NONE;      // SR == 1: the ray's validity is its only slot's (no ray_valid_kernel launch)
     }
 }
 
@@ -428,7 +429,8 @@ __global__ void __launch_bounds__(256) compact_count_kernel(const uint8_t* __res
 
 __global__ void __launch_bounds__(256) compact_write_kernel(const uint8_t* __restrict__ slot_valid, long long nslot,
                                                             const int32_t* __restrict__ chunk_counts, int32_t* __restrict__ point_slot,
-                                                            int32_t* __restrict__ slot_point, int32_t* __restrict__ n_points) {
+                                                            int32_t* __restrict__ slot_point, int32_t* __restrict__ n_points,
+                                                            float* __restrict__ fill_sdf, float fill_value, float* __restrict__ fill_grad) {
     __shared__ int32_t wsum[4];
     __shared__ int32_t wsum2[4];
     int before = 0;
@@ -453,6 +455,13 @@ __global__ void __launch_bounds__(256) compact_write_kernel(const uint8_t* __res
                 slot_point[base + u] = p++;
             } else {
                 slot_point[base + u] = -1;
+            }
+            // rows the geometry kernels never write (they only touch valid points): the reference's 1000 filler / zero gradient
+            if (fill_sdf) fill_sdf[base + u] = fill_value;
+            if (fill_grad) {
+                fill_grad[3 * (base + u)] = 0.f;
+                fill_grad[3 * (base + u) + 1] = 0.f;
+                fill_grad[3 * (base + u) + 2] = 0.f;
             }
         }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_points = chunk_base + total;
@@ -714,19 +723,21 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
     if (g->cfg.compat & SPF_KNN_LAYERED)
         knn_kernel<true><<<spf::div_up((long long)nslot * 8, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
                                                                                  g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
-                                                                                 slot_sample, pidx, loc, slot_valid);
+                                                                                 slot_sample, pidx, loc, slot_valid, SR == 1 ? ray_valid : nullptr);
     else
         knn_kernel<false><<<spf::div_up((long long)nslot * 8, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
                                                                                   g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
-                                                                                  slot_sample, pidx, loc, slot_valid);
+                                                                                  slot_sample, pidx, loc, slot_valid, SR == 1 ? ray_valid : nullptr);
     SPF_LAUNCH_CHECK("knn_kernel");
-    ray_valid_kernel<<<spf::div_up(R, 256), 256, 0, stream>>>(slot_valid, R, SR, ray_valid);
-    SPF_LAUNCH_CHECK("ray_valid_kernel");
+    if (SR > 1) {
+        ray_valid_kernel<<<spf::div_up(R, 256), 256, 0, stream>>>(slot_valid, R, SR, ray_valid);
+        SPF_LAUNCH_CHECK("ray_valid_kernel");
+    }
     return SPF_OK;
 }
 
 int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t* point_slot, int32_t* slot_point,
-                       int32_t* n_points, int32_t* scratch, void* stream_) {
+                       int32_t* n_points, int32_t* scratch, float* fill_sdf, float fill_value, float* fill_grad, void* stream_) {
     if (R < 0 || SR < 1) return spf::fail(SPF_EINVAL, "spf_compact_points: bad sizes");
     if (!n_points) return spf::fail(SPF_EINVAL, "spf_compact_points: null n_points");
     hipStream_t stream = (hipStream_t)stream_;
@@ -740,7 +751,7 @@ int spf_compact_points(const uint8_t* slot_valid, int32_t R, int32_t SR, int32_t
     if (chunks > R + 1) return spf::fail(SPF_EINVAL, "spf_compact_points: scratch (R+1 ints) too small for %d chunks", chunks);
     compact_count_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nslot, scratch);
     SPF_LAUNCH_CHECK("compact_count_kernel");
-    compact_write_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nslot, scratch, point_slot, slot_point, n_points);
+    compact_write_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nslot, scratch, point_slot, slot_point, n_points, fill_sdf, fill_value, fill_grad);
     SPF_LAUNCH_CHECK("compact_write_kernel");
     return SPF_OK;
 }

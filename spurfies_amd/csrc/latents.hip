@@ -49,13 +49,13 @@ __global__ void tv_forward_kernel(const float* __restrict__ feat, const int32_t*
 
 // g_feat[i] += s_i * sign(f_i - f_j) * w_ij ; g_feat[j] -= same,  s_i = g_tv[i] / norm_i
 __global__ void tv_backward_kernel(const float* __restrict__ feat, const int32_t* __restrict__ nbr, const float* __restrict__ w,
-                                   const float* __restrict__ norm, const float* __restrict__ g_tv, int n, int k,
+                                   const float* __restrict__ norm, const float* __restrict__ g_tv, int g_tv_stride, float scale, int n, int k,
                                    float* __restrict__ g_feat, long long* __restrict__ g_fixed) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = gid >> 5, c = gid & 31;
     if (i >= n) return;
     const float fi = feat[(size_t)i * 32 + c];
-    const float s = g_tv[i] / norm[i];
+    const float s = g_tv[(size_t)i * g_tv_stride] * scale / norm[i];
     float own = 0.f;
     for (int j = 0; j < k; ++j) {
         const float wj = w[(size_t)i * k + j];
@@ -113,11 +113,12 @@ int spf_tv_forward(const float* feat_geo, const int32_t* nbr, const float* w, co
 }
 
 int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm, const float* g_tv,
-                    int32_t n, int32_t k, float* g_feat_geo, int64_t* g_feat_geo_fixed, void* stream) {
+                    int32_t g_tv_stride, float scale, int32_t n, int32_t k, float* g_feat_geo, int64_t* g_feat_geo_fixed, void* stream) {
     if (n < 0 || k < 1) return spf::fail(SPF_EINVAL, "spf_tv_backward: bad sizes");
     if (n == 0) return SPF_OK;
     if (!feat_geo || !nbr || !w || !norm || !g_tv || (!g_feat_geo && !g_feat_geo_fixed)) return spf::fail(SPF_EINVAL, "spf_tv_backward: null pointer");
-    tv_backward_kernel<<<spf::div_up((long long)n * 32, 256), 256, 0, (hipStream_t)stream>>>(feat_geo, nbr, w, norm, g_tv, n, k, g_feat_geo,
+    if (g_tv_stride != 0 && g_tv_stride != 1) return spf::fail(SPF_EINVAL, "spf_tv_backward: g_tv_stride is 1 (per point) or 0 (one value for all points)");
+    tv_backward_kernel<<<spf::div_up((long long)n * 32, 256), 256, 0, (hipStream_t)stream>>>(feat_geo, nbr, w, norm, g_tv, g_tv_stride, scale, n, k, g_feat_geo,
                                                                                            reinterpret_cast<long long*>(g_feat_geo_fixed));
     SPF_LAUNCH_CHECK("tv_backward_kernel");
     return SPF_OK;

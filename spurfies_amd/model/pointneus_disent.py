@@ -169,13 +169,16 @@ class PointVolSDF(nn.Module):
         grid = self._grid()
         x = x.contiguous()
         q = grid.query_dense(x.detach().unsqueeze(1), self.conf.k, self.conf.r, 1)
-        point_slot, _, n_points = ops.compact_points(q["slot_valid"])
+        M = x.shape[0]          # the compaction pass also lays down the 1000 filler / zero gradient of the rows without a neighbour
+        sdf_buf = torch.empty((M,), dtype=torch.float32, device=x.device)
+        grad_buf = torch.empty((M, 3), dtype=torch.float32, device=x.device) if with_grad else None
+        point_slot, _, n_points = ops.compact_points(q["slot_valid"], fill_sdf=sdf_buf, fill_grad=grad_buf)
         pl = ops.PairList(q["pidx"].view(-1, self.conf.k), point_slot, n_points)
         if with_grad:
-            sdf, grad, _ = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(self.conf.rbf))
+            sdf, grad, _ = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(self.conf.rbf), sdf_buf, grad_buf)
         else:
             res = ops.geo_forward(x.detach(), pl, self.neural_pts, self.neural_feats_geometry.detach(), self._packed(),
-                                  float(self.conf.rbf), with_grad=False)
+                                  float(self.conf.rbf), with_grad=False, sdf_out=sdf_buf)
             sdf, grad = res["sdf"], None
         return {"sdf": sdf, "grad": grad, "valid": q["slot_valid"].view(-1), "pairs": pl}
 
@@ -282,14 +285,16 @@ class PointVolSDF(nn.Module):
         # the bool forms of the two masks are read by the reference-shaped outputs only (two conversion launches)
         valid = None if static else q["slot_valid"].bool()        # [R,SR]  == reference `mask`
         ray_mask = None if static else q["ray_valid"].bool()      # [R]
-        point_slot, _, n_points = ops.compact_points(q["slot_valid"])
+        sdf_buf = torch.empty((R * SR,), dtype=torch.float32, device=dev)
+        grad_buf = torch.empty((R * SR, 3), dtype=torch.float32, device=dev)
+        point_slot, _, n_points = ops.compact_points(q["slot_valid"], fill_sdf=sdf_buf, fill_grad=grad_buf)
         pl = ops.PairList(q["pidx"].view(R * SR, k), point_slot, n_points)
 
         # ---- filter_points (:207-239) on dense rows (HIP) ---------------------------------------
         z_slots, deltas, x = ops.filter_points(q["loc"], q["slot_valid"], cam_loc.detach(), ray_dirs.detach())
 
         # ---- geometry: sdf, d sdf/d x, normalised RBF weights (HIP) -----------------------------
-        sdf_flat, gradients, wn = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(conf.rbf))
+        sdf_flat, gradients, wn = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(conf.rbf), sdf_buf, grad_buf)
         sdf = sdf_flat.view(R, SR)                                # gradients: [R*SR,3], zero rows where not a point
 
         # ---- colours (PyTorch ops on the P valid points; one host sync for P) -------------------

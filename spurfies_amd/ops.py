@@ -34,8 +34,10 @@ def profile_stop():
 
 
 
-def compact_points(slot_valid):
-    """slot_valid uint8 [R,SR] -> (point_slot i32 [R*SR], slot_point i32 [R*SR], n_points i32 [1]); no host sync."""
+def compact_points(slot_valid, fill_sdf=None, fill_grad=None):
+    """slot_valid uint8 [R,SR] -> (point_slot i32 [R*SR], slot_point i32 [R*SR], n_points i32 [1]); no host sync.
+    fill_sdf [R*SR] / fill_grad [R*SR,3] (optional, uninitialised): set to the 1000 filler / 0 on the way, so that geo_forward's
+    output buffers need no separate fill launches."""
     R, SR = slot_valid.shape
     dev = slot_valid.device
     point_slot = torch.empty((R * SR,), dtype=torch.int32, device=dev)
@@ -44,7 +46,8 @@ def compact_points(slot_valid):
     scratch = torch.empty((R + 1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_compact_points(_lib.ptr(slot_valid), R, SR, _lib.ptr(point_slot), _lib.ptr(slot_point),
-                                                 _lib.ptr(n_points), _lib.ptr(scratch), _lib.stream_ptr()), "spf_compact_points")
+                                                 _lib.ptr(n_points), _lib.ptr(scratch), _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad),
+                                                 _lib.stream_ptr()), "spf_compact_points")
     return point_slot, slot_point, n_points
 
 
@@ -107,14 +110,14 @@ def pack_geometry_weights(state: dict) -> torch.Tensor:
     return packed
 
 
-def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_out=None):
+def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_out=None, grad_out=None):
     """Rows = first dim of x / nbr.  Returns dict(sdf [rows] (1000 where not a valid point), grad [rows,3] | None,
-    wn [max_pairs], jac [max_pairs,32] | None)."""
+    wn [max_pairs], jac [max_pairs,32] | None).  sdf_out / grad_out: buffers already holding the filler (compact_points(fill_*))."""
     rows = pl.nbr.shape[0]
     dev = x.device
     sdf = sdf_out if sdf_out is not None else torch.full((rows,), SDF_FILL, dtype=torch.float32, device=dev)
     wn = torch.empty((pl.max_pairs,), dtype=torch.float32, device=dev)
-    grad = torch.zeros((rows, 3), dtype=torch.float32, device=dev) if with_grad else None
+    grad = (grad_out if grad_out is not None else torch.zeros((rows, 3), dtype=torch.float32, device=dev)) if with_grad else None
     jac = torch.empty((pl.max_pairs, 32), dtype=torch.float32, device=dev) if with_grad else None
     tmp = torch.empty((pl.max_pairs, 5), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _prof.span("geo", pairs=pl.n_pairs, rows=rows, with_grad=bool(with_grad)):
@@ -175,8 +178,10 @@ class GeoSDF(torch.autograd.Function):
     d sdf_j/d latent_j is the Jacobian row the forward sweep stored)."""
 
     @staticmethod
-    def forward(ctx, x, feat_geo, pl, pts, packed, rbf):
-        res = geo_forward(x.detach(), pl, pts, feat_geo.detach(), packed, rbf, with_grad=True)
+    def forward(ctx, x, feat_geo, pl, pts, packed, rbf, sdf_out=None, grad_out=None):
+        if sdf_out is not None:          # caller-provided output buffers (already holding the filler) are written in place and returned
+            ctx.mark_dirty(sdf_out, grad_out)
+        res = geo_forward(x.detach(), pl, pts, feat_geo.detach(), packed, rbf, with_grad=True, sdf_out=sdf_out, grad_out=grad_out)
         ctx.save_for_backward(res["wn"], res["jac"], res["grad"])
         ctx.pl = pl
         ctx.n_table = feat_geo.shape[0]
@@ -189,7 +194,7 @@ class GeoSDF(torch.autograd.Function):
     def backward(ctx, g_sdf, _g_grad, _g_wn):
         wn, jac, grad = ctx.saved_tensors
         if g_sdf is None:
-            return None, None, None, None, None, None
+            return (None,) * 8
         g_sdf = g_sdf.contiguous()
         g_x = g_feat = None
         if ctx.needs_input_grad[0]:
@@ -200,7 +205,7 @@ class GeoSDF(torch.autograd.Function):
             else:
                 g_feat = torch.zeros((ctx.n_table, 32), dtype=torch.float32, device=g_sdf.device)
                 geo_backward_latents(g_sdf, wn, jac, ctx.pl, g_feat)
-        return g_x, g_feat, None, None, None, None
+        return g_x, g_feat, None, None, None, None, None, None
 
 
 class GatherRows(torch.autograd.Function):
@@ -250,11 +255,11 @@ class TVLoss(torch.autograd.Function):
     def backward(ctx, g):
         feat, nbr, w, norm = ctx.saved_tensors
         n, k = nbr.shape
-        g_tv = (g / n).expand(n).contiguous()
+        g_tv = g.detach().reshape(1).contiguous()          # one device scalar: d mean / d tv_i = g / n for every point (stride 0, scale 1/n)
         out = ctx.sink if ctx.sink is not None else torch.zeros_like(feat)
         acc = _fixed_acc(out) if _SCATTER["mode"] == "fixed" else None
         with torch.cuda.device(feat.device):
-            _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), _lib.ptr(g_tv), n, k,
+            _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), _lib.ptr(g_tv), 0, 1.0 / n, n, k,
                                                   _lib.ptr(out), _lib.ptr(acc), _lib.stream_ptr()), "spf_tv_backward")
         if acc is not None:
             _fixed_flush(acc, out)

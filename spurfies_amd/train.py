@@ -35,6 +35,7 @@ class TrainStep:
         self.sync_free = sync_free
         self.use_graph = use_graph
         self._graph = None
+        self._one = None
         self._graph_key = None
         model.sync_free = sync_free
         self._draws = None
@@ -86,7 +87,7 @@ class TrainStep:
         else:
             losses = self.loss(out, ground_truth)
         self.flat.zero_()
-        losses["loss"].backward()
+        losses["loss"].backward(gradient=self._root_grad(losses["loss"]))       # a cached 1 (autograd would launch a fill for its own)
         return losses, out
 
     # ------------------------------------------------------------------ hipGraph path
@@ -117,7 +118,7 @@ class TrainStep:
                 out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
                 losses = self.loss(out, self._static_gt)
                 self.flat.zero_()
-                losses["loss"].backward()
+                losses["loss"].backward(gradient=self._root_grad(losses["loss"]))
             self._static_out = (losses, out)
         for k in keys_in:
             self._static_in[k].copy_(model_input[k], non_blocking=True)
@@ -126,6 +127,11 @@ class TrainStep:
         self._refresh_draws(model_input["uv"].shape[1], dev)
         self._graph.replay()
         return self._static_out
+
+    def _root_grad(self, loss):
+        if self._one is None or self._one.device != loss.device:
+            self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return self._one
 
     def _refresh_draws(self, R, dev):
         """The reference draws its random numbers from the CPU generator and moves them (ray_sampler.py:55,514,550,562); in
