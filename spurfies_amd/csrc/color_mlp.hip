@@ -940,13 +940,14 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         T_MARK(18)
         gx3 w_bwl = frag + CX_BWL + (wave >> 1) * (CX_TH * 3 * 64) + lane;
         const WFrag1 frl = load_wfrag1(w_bwl);
+        // third link of the next tile's lookup chain (pair -> point -> slot -> NEIGHBOUR), ahead of the epilogue that covers its round trip
+        if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
         lds_barrier();
         T_MARK(19)
         cx_bwd_epilogue(X, acc, wave, lane, mw, G1 + tbase);
         T_MARK(20)
         lds_barrier();
         T_MARK(21)
-        if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
         if (next_tile < ntiles) cur = cx_fetch_grow(g_agg3, masks + (size_t)next_tile * 3 * 512, n_p, n_idx, n_w, lane, wave);
         T_MARK(22)
         // ---- d/d latent = G1 W0[:, 39:103]: wave = (latent half m, row half n), one 32x32 tile each; scatter-add -------------------

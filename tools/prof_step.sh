@@ -10,13 +10,18 @@ tail -1 gpurun_out/prof_$NAME.log | cut -c1-200
 # per-launch durations of the dominant kernel's MAIN-PASS launches (the stats file above averages them with the small pseudo-point launches)
 python3 - "$NAME" <<'PY'
 import csv, glob, sys
+import json
 name = sys.argv[1]
+bench = json.loads([l for l in open(f"gpurun_out/prof_{name}.log") if l.startswith("{")][-1])
+roof = bench.get("roofline") or {}
 f = glob.glob(f"gpurun_out/prof_{name}/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "geo_pairs_x3_kernel<true>" in r["Kernel_Name"]]
 d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
 big = [x for x in d if x > 0.3 * max(d)]
 with open(f"gpurun_out/{name}_geo_main_pass_launches.csv", "w") as o:
-    o.write(f'"# geo_pairs_x3_kernel<true>: {len(d)} launches in the trace, {len(big)} of them main-pass launches (the others are the pseudo-point pass); main-pass mean {sum(big) / len(big) / 1e3:.1f} us, min {min(big) / 1e3:.1f}, max {max(big) / 1e3:.1f}"\n')
+    o.write(f'"# geo_pairs_x3_kernel<true>: {len(d)} launches in the trace, {len(big)} of them main-pass launches (the others are the pseudo-point pass); main-pass mean {sum(big) / len(big) / 1e3:.1f} us, min {min(big) / 1e3:.1f}, max {max(big) / 1e3:.1f}; the same run's bench line (HIP events over its timed region): '
+            f'pairs_per_launch {roof.get("pairs_per_launch")}, flop_per_pair {roof.get("flop_per_pair")}, avg_ms {roof.get("avg_ms")}, achieved {roof.get("achieved")} TFLOP/s, '
+            f'frac {roof.get("frac")} of {roof.get("peak")}; colour trunk: ' + "; ".join(f'{s_["kernel"]}: pairs_per_launch {s_.get("pairs_per_launch")}, avg_ms {s_["avg_ms"]}' for s_ in (roof.get("secondary") or []) if "color" in s_["kernel"]) + '"\n')
     o.write("launch,DurationNs\n")
     for i, x in enumerate(big):
         o.write(f"{i},{x}\n")
