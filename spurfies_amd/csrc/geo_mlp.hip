@@ -355,24 +355,92 @@ __global__ void geo_point_reduce_kernel(const float* __restrict__ pair_tmp, cons
     }
 }
 
-// g_feat[nbr(q)] += g_sdf[row(q)] * wn[q] * jac[q, :]   — 32 lanes per pair, two 128-B atomic segments per wave
-__global__ void geo_backward_latents_kernel(const float* __restrict__ g_sdf, const float* __restrict__ wn,
-                                            const float* __restrict__ jac, const int32_t* __restrict__ nbr,
-                                            const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off,
-                                            const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
-                                            int max_pairs, int k, float* __restrict__ g_feat, long long* __restrict__ g_fixed) {
+// g_feat[nbr(q)] += g_sdf[row(q)] * wn[q] * jac[q, :].  One workgroup per tile of 64 consecutive pairs (pairs are grouped by point,
+// points follow each other along a ray: neighbouring samples share most of their neighbours, so a tile holds each neural point 2-4
+// times).  Rows of a tile that hit the SAME neural point are summed in LDS first (fixed order: ascending row) and each group is added
+// with ONE 128-byte atomic row — same-address atomics serialise in L2, and atomics are priced per cache line touched.
+__global__ void __launch_bounds__(256)
+geo_backward_latents_kernel(const float* __restrict__ g_sdf, const float* __restrict__ wn, const float* __restrict__ jac,
+                            const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off,
+                            const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k,
+                            float* __restrict__ g_feat, long long* __restrict__ g_fixed) {
+    constexpr int LDL = SPF_GEO_DIM + 4;                                  // row stride of L in floats (16-byte aligned, off the bank period)
+    __shared__ __attribute__((aligned(16))) float L[64 * LDL];
+    __shared__ __attribute__((aligned(16))) int s_idx[64];
+    __shared__ __attribute__((aligned(16))) int s_lead[64];
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
-    const int c = threadIdx.x & 31;
-    for (long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; q < NP; q += ((long long)gridDim.x * blockDim.x) >> 5) {
-        const int p = pair_point[q];
-        const int srow = point_slot ? point_slot[p] : p;
-        const int idx = nbr[(size_t)srow * k + ((int)q - pair_off[p])];
-        const float coef = g_sdf[srow] * wn[q];
-        if (coef != 0.f) {
-            const float v = coef * jac[(size_t)q * SPF_GEO_DIM + c];
-            if (g_fixed) fixed_add(&g_fixed[(size_t)idx * SPF_GEO_DIM + c], v);       // order-independent (common.h)
-            else atomicAdd(&g_feat[(size_t)idx * SPF_GEO_DIM + c], v);
+    const int ntiles = (NP + 63) / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = tid >> 2, q40 = tid & 3;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- thread = (pair row, quarter of the 32 latent columns): coef * jac row -> LDS
+        {
+            const int q = tile * 64 + row0;
+            int idx = -1;
+            float coef = 0.f;
+            if (q < NP) {
+                const int p = pair_point[q];
+                const int srow = point_slot ? point_slot[p] : p;
+                idx = nbr[(size_t)srow * k + (q - pair_off[p])];
+                coef = g_sdf[srow] * wn[q];
+            }
+            if (coef == 0.f) idx = -1;                                    // nothing to add (also rows past the pair count)
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+            if (idx >= 0) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(jac + (size_t)q * SPF_GEO_DIM + 8 * q40);
+                a = src[0] * coef;
+                b = src[1] * coef;
+            }
+            *reinterpret_cast<f32x4*>(&L[row0 * LDL + 8 * q40]) = a;
+            *reinterpret_cast<f32x4*>(&L[row0 * LDL + 8 * q40 + 4]) = b;
+            if (q40 == 0) s_idx[row0] = idx;
         }
+        __syncthreads();
+        // ---- the first row of each group of equal indices takes the group's sum, all groups in parallel
+        {
+            const int my = s_idx[row0];
+            uint32_t part = 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int4 v = *reinterpret_cast<const int4*>(&s_idx[16 * q40 + 4 * u]);
+                part |= (v.x == my ? 1u : 0u) << (4 * u) | (v.y == my ? 2u : 0u) << (4 * u) | (v.z == my ? 4u : 0u) << (4 * u) |
+                        (v.w == my ? 8u : 0u) << (4 * u);
+            }
+            unsigned long long mask = (unsigned long long)part << (16 * q40);
+            mask |= __shfl_xor(mask, 1);
+            mask |= __shfl_xor(mask, 2);
+            const bool leader = my >= 0 && (mask & ((1ull << row0) - 1ull)) == 0ull;
+            if (q40 == 0) s_lead[row0] = leader ? my : -1;
+            mask &= ~(1ull << row0);
+            if (leader && mask) {                                         // in place: a row is read by its group's first row only
+                float* own = &L[row0 * LDL + 8 * q40];
+                f32x4 sa = *reinterpret_cast<const f32x4*>(own), sb = *reinterpret_cast<const f32x4*>(own + 4);
+                while (mask) {
+                    const int r2 = __builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                    sa += *reinterpret_cast<const f32x4*>(&L[r2 * LDL + 8 * q40]);
+                    sb += *reinterpret_cast<const f32x4*>(&L[r2 * LDL + 8 * q40 + 4]);
+                }
+                *reinterpret_cast<f32x4*>(own) = sa;
+                *reinterpret_cast<f32x4*>(own + 4) = sb;
+            }
+        }
+        __syncthreads();
+        // ---- wave w adds the leading rows among 16 w .. 16 w + 15, two rows per instruction (lane = (row parity, column))
+        {
+            const int c = lane & 31, half = lane >> 5;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int row = 16 * wave + 2 * rr + half;
+                const int idx = s_lead[row];
+                if (idx >= 0) {
+                    const float v = L[row * LDL + c];
+                    if (g_fixed) fixed_add(&g_fixed[(size_t)idx * SPF_GEO_DIM + c], v);       // order-independent (common.h)
+                    else atomicAdd(&g_feat[(size_t)idx * SPF_GEO_DIM + c], v);
+                }
+            }
+        }
+        __syncthreads();                                                  // L / s_idx are rewritten by the next tile
     }
 }
 
@@ -856,9 +924,8 @@ int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* j
     if (max_pairs == 0) return SPF_OK;
     if (!g_sdf || !wn || !jac || !nbr || !pair_off || !pair_point || (!g_feat_geo && !g_feat_geo_fixed))
         return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: null pointer");
-    long long threads = (long long)max_pairs * 32;
-    int blocks = spf::div_up(threads, 256);
-    if (blocks > 8192) blocks = 8192;
+    int blocks = spf::div_up(max_pairs, 64);                              // one workgroup per 64-pair tile, grid-strided
+    if (blocks > 2048) blocks = 2048;
     geo_backward_latents_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_sdf, wn, jac, nbr, point_slot, pair_off, pair_point, n_pairs,
                                                                          max_pairs, k, g_feat_geo, reinterpret_cast<long long*>(g_feat_geo_fixed));
     SPF_LAUNCH_CHECK("geo_backward_latents_kernel");

@@ -18,10 +18,13 @@ f = glob.glob(f"gpurun_out/prof_{name}/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "geo_pairs_x3_kernel<true>" in r["Kernel_Name"]]
 d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
 big = [x for x in d if x > 0.3 * max(d)]
+col = "; ".join("%s: pairs_per_launch %s, avg_ms %s" % (s_["kernel"], s_.get("pairs_per_launch"), s_["avg_ms"]) for s_ in (roof.get("secondary") or []) if "color" in s_["kernel"])
+head = ("# geo_pairs_x3_kernel<true>: %d launches in the trace, %d of them main-pass launches (the others are the pseudo-point pass); main-pass mean %.1f us, "
+        "min %.1f, max %.1f; the bench line of the same run (HIP events over its timed region): pairs_per_launch %s, flop_per_pair %s, avg_ms %s, achieved %s TFLOP/s, "
+        "frac %s of %s; colour trunk: %s" % (len(d), len(big), sum(big) / len(big) / 1e3, min(big) / 1e3, max(big) / 1e3, roof.get("pairs_per_launch"),
+                                               roof.get("flop_per_pair"), roof.get("avg_ms"), roof.get("achieved"), roof.get("frac"), roof.get("peak"), col))
 with open(f"gpurun_out/{name}_geo_main_pass_launches.csv", "w") as o:
-    o.write(f'"# geo_pairs_x3_kernel<true>: {len(d)} launches in the trace, {len(big)} of them main-pass launches (the others are the pseudo-point pass); main-pass mean {sum(big) / len(big) / 1e3:.1f} us, min {min(big) / 1e3:.1f}, max {max(big) / 1e3:.1f}; the same run's bench line (HIP events over its timed region): '
-            f'pairs_per_launch {roof.get("pairs_per_launch")}, flop_per_pair {roof.get("flop_per_pair")}, avg_ms {roof.get("avg_ms")}, achieved {roof.get("achieved")} TFLOP/s, '
-            f'frac {roof.get("frac")} of {roof.get("peak")}; colour trunk: ' + "; ".join(f'{s_["kernel"]}: pairs_per_launch {s_.get("pairs_per_launch")}, avg_ms {s_["avg_ms"]}' for s_ in (roof.get("secondary") or []) if "color" in s_["kernel"]) + '"\n')
+    o.write('"' + head + '"\n')
     o.write("launch,DurationNs\n")
     for i, x in enumerate(big):
         o.write(f"{i},{x}\n")
