@@ -128,6 +128,13 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
                     int32_t k, int32_t* pair_off, int32_t* pair_point, int32_t* n_pairs, int32_t* scratch,
                     void* stream);
 
+/* spf_compact_points + spf_build_pairs in ONE pair of launches (what the model's passes use: the four-launch form costs more in
+ * dispatch than in work at 10^5 slots): nbr [R*SR, k] is indexed by SLOT (the kNN output as it is); outputs as above, with
+ * counts[2] = {n_points, n_pairs} on the device and the same optional fillers.  scratch: >= 2 * (R*SR / 2048 + 1) int32. */
+int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot,
+                      int32_t* slot_point, int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch,
+                      float* fill_sdf, float fill_value, float* fill_grad, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused geometry path — replaces get_keypoint_data + compute_weights + get_sdf (+ the value of
  * get_gradients): spurfies/model/utils.py:140-170, spurfies/model/pointneus_disent.py:241-247,

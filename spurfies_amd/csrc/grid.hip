@@ -526,6 +526,88 @@ __global__ void __launch_bounds__(256) pairs_write_kernel(const int32_t* __restr
     }
 }
 
+// ---- spf_compact_pairs: point compaction AND pair list in two launches (spf_compact_points + spf_build_pairs take four) ----------
+// Chunks of 2048 slots; pass 1 counts a chunk's valid points and their neighbours, pass 2 places them behind the chunks before it.
+__global__ void __launch_bounds__(256) cp_count_kernel(const uint8_t* __restrict__ slot_valid, const int32_t* __restrict__ nbr, long long nslot,
+                                                       int k, int32_t* __restrict__ chunk_counts /* [chunks][2] */) {
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t wsum2[4];
+    const long long base = (long long)blockIdx.x * CMP_CHUNK + (long long)threadIdx.x * CMP_PER_THREAD;
+    int np = 0, nq = 0;
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u)
+        if (base + u < nslot && slot_valid[base + u]) {
+            ++np;
+            nq += nbr_count(nbr + (size_t)(base + u) * k, k);
+        }
+    int tp, tq;
+    block_excl_scan_256(np, tp, wsum);
+    block_excl_scan_256(nq, tq, wsum2);
+    if (threadIdx.x == 0) {
+        chunk_counts[2 * blockIdx.x] = tp;
+        chunk_counts[2 * blockIdx.x + 1] = tq;
+    }
+}
+
+__global__ void __launch_bounds__(256) cp_write_kernel(const uint8_t* __restrict__ slot_valid, const int32_t* __restrict__ nbr, long long nslot,
+                                                       int k, const int32_t* __restrict__ chunk_counts, int32_t* __restrict__ point_slot,
+                                                       int32_t* __restrict__ slot_point, int32_t* __restrict__ pair_off,
+                                                       int32_t* __restrict__ pair_point, int32_t* __restrict__ counts /* [n_points, n_pairs] */,
+                                                       float* __restrict__ fill_sdf, float fill_value, float* __restrict__ fill_grad) {
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t wsum2[4];
+    int bp = 0, bq = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) {
+        bp += chunk_counts[2 * b];
+        bq += chunk_counts[2 * b + 1];
+    }
+    int base_p, base_q;
+    block_excl_scan_256(bp, base_p, wsum);          // totals over the block = sums over all earlier chunks
+    __syncthreads();
+    block_excl_scan_256(bq, base_q, wsum2);
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * CMP_CHUNK + (long long)threadIdx.x * CMP_PER_THREAD;
+    int c[CMP_PER_THREAD], np = 0, nq = 0;
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u) {
+        c[u] = -1;                                   // -1: not a valid point
+        if (base + u < nslot && slot_valid[base + u]) {
+            c[u] = nbr_count(nbr + (size_t)(base + u) * k, k);
+            ++np;
+            nq += c[u];
+        }
+    }
+    int tp, tq;
+    int p = base_p + block_excl_scan_256(np, tp, wsum);
+    __syncthreads();
+    int q = base_q + block_excl_scan_256(nq, tq, wsum2);
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u)
+        if (base + u < nslot) {
+            if (c[u] >= 0) {
+                point_slot[p] = (int32_t)(base + u);
+                slot_point[base + u] = p;
+                pair_off[p] = q;
+                for (int j = 0; j < c[u]; ++j) pair_point[q + j] = p;
+                q += c[u];
+                ++p;
+            } else {
+                slot_point[base + u] = -1;
+            }
+            if (fill_sdf) fill_sdf[base + u] = fill_value;
+            if (fill_grad) {
+                fill_grad[3 * (base + u)] = 0.f;
+                fill_grad[3 * (base + u) + 1] = 0.f;
+                fill_grad[3 * (base + u) + 2] = 0.f;
+            }
+        }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        counts[0] = base_p + tp;
+        counts[1] = base_q + tq;
+        pair_off[base_p + tp] = base_q + tq;         // closes the list
+    }
+}
+
 GridDev dev_view(const spf_grid* g) {
     GridDev d;
     d.ox = g->origin[0], d.oy = g->origin[1], d.oz = g->origin[2];
@@ -785,6 +867,28 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
     SPF_LAUNCH_CHECK("pairs_count_kernel");
     pairs_write_kernel<<<chunks, 256, 0, stream>>>(nbr, point_slot, n_points, max_points, k, scratch, pair_off, pair_point, n_pairs);
     SPF_LAUNCH_CHECK("pairs_write_kernel");
+    return SPF_OK;
+}
+
+int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot, int32_t* slot_point,
+                      int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch, float* fill_sdf, float fill_value,
+                      float* fill_grad, void* stream_) {
+    if (R < 0 || SR < 1 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_compact_pairs: bad sizes");
+    if (!counts || !pair_off) return spf::fail(SPF_EINVAL, "spf_compact_pairs: null counts / pair_off");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (R == 0) {
+        SPF_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), stream));
+        SPF_HIP_CHECK(hipMemsetAsync(pair_off, 0, sizeof(int32_t), stream));
+        return SPF_OK;
+    }
+    if (!slot_valid || !nbr || !point_slot || !slot_point || !pair_point || !scratch) return spf::fail(SPF_EINVAL, "spf_compact_pairs: null buffer");
+    const long long nslot = (long long)R * SR;
+    const int chunks = spf::div_up(nslot, CMP_CHUNK);
+    cp_count_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nbr, nslot, k, scratch);
+    SPF_LAUNCH_CHECK("cp_count_kernel");
+    cp_write_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nbr, nslot, k, scratch, point_slot, slot_point, pair_off, pair_point, counts, fill_sdf,
+                                                fill_value, fill_grad);
+    SPF_LAUNCH_CHECK("cp_write_kernel");
     return SPF_OK;
 }
 

@@ -172,8 +172,7 @@ class PointVolSDF(nn.Module):
         M = x.shape[0]          # the compaction pass also lays down the 1000 filler / zero gradient of the rows without a neighbour
         sdf_buf = torch.empty((M,), dtype=torch.float32, device=x.device)
         grad_buf = torch.empty((M, 3), dtype=torch.float32, device=x.device) if with_grad else None
-        point_slot, _, n_points = ops.compact_points(q["slot_valid"], fill_sdf=sdf_buf, fill_grad=grad_buf)
-        pl = ops.PairList(q["pidx"].view(-1, self.conf.k), point_slot, n_points)
+        pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(-1, self.conf.k), fill_sdf=sdf_buf, fill_grad=grad_buf)
         if with_grad:
             sdf, grad, _ = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(self.conf.rbf), sdf_buf, grad_buf)
         else:
@@ -287,8 +286,8 @@ class PointVolSDF(nn.Module):
         ray_mask = None if static else q["ray_valid"].bool()      # [R]
         sdf_buf = torch.empty((R * SR,), dtype=torch.float32, device=dev)
         grad_buf = torch.empty((R * SR, 3), dtype=torch.float32, device=dev)
-        point_slot, _, n_points = ops.compact_points(q["slot_valid"], fill_sdf=sdf_buf, fill_grad=grad_buf)
-        pl = ops.PairList(q["pidx"].view(R * SR, k), point_slot, n_points)
+        pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(R * SR, k), fill_sdf=sdf_buf, fill_grad=grad_buf)
+        point_slot = pl.point_slot
 
         # ---- filter_points (:207-239) on dense rows (HIP) ---------------------------------------
         z_slots, deltas, x = ops.filter_points(q["loc"], q["slot_valid"], cam_loc.detach(), ray_dirs.detach())

@@ -79,6 +79,29 @@ class PairList:
                                                   _lib.ptr(self.pair_off), _lib.ptr(self.pair_point), _lib.ptr(self.n_pairs),
                                                   _lib.ptr(scratch), _lib.stream_ptr()), "spf_build_pairs")
 
+    @classmethod
+    def from_slots(cls, slot_valid, nbr, fill_sdf=None, fill_grad=None):
+        """Valid-point compaction AND the pair list of a kNN result in one pair of launches (spf_compact_pairs): slot_valid uint8 [R,SR],
+        nbr int32 [R*SR,k] indexed by slot; optional uninitialised fill_sdf [R*SR] / fill_grad [R*SR,3] receive the 1000 filler / zeros."""
+        R, SR = slot_valid.shape
+        rows, k = nbr.shape
+        dev = nbr.device
+        self = cls.__new__(cls)
+        self.nbr, self.k = nbr, k
+        self.point_slot = torch.empty((rows,), dtype=torch.int32, device=dev)
+        self.slot_point = torch.empty((rows,), dtype=torch.int32, device=dev)
+        self.max_points, self.max_pairs = rows, rows * k
+        self.counts = torch.empty((2,), dtype=torch.int32, device=dev)
+        self.n_points, self.n_pairs = self.counts[:1], self.counts[1:]
+        self.pair_off = torch.empty((rows + 1,), dtype=torch.int32, device=dev)
+        self.pair_point = torch.empty((self.max_pairs,), dtype=torch.int32, device=dev)
+        scratch = torch.empty((2 * (rows // 2048 + 2),), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_compact_pairs(_lib.ptr(slot_valid), _lib.ptr(nbr), R, SR, k, _lib.ptr(self.point_slot), _lib.ptr(self.slot_point),
+                                                    _lib.ptr(self.pair_off), _lib.ptr(self.pair_point), _lib.ptr(self.counts), _lib.ptr(scratch),
+                                                    _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad), _lib.stream_ptr()), "spf_compact_pairs")
+        return self
+
     def host_counts(self):
         """(P, n_pairs) on the host — ONE synchronising copy."""
         c = self.counts.tolist()

@@ -163,3 +163,27 @@ def test_capacity_warning_without_truncation():
     g = VoxelGrid((0.025,) * 3, (3,) * 3, (3,) * 3, 26, 20000, (-1, -1, -1, 1, 1, 1))
     with pytest.warns(UserWarning, match="max_points_per_voxel"):
         g.set_pointset(torch.from_numpy(pts).cuda().unsqueeze(0))
+
+
+def test_fused_compaction_and_pair_list_equal_the_two_step_form():
+    """spf_compact_pairs (two launches) against spf_compact_points + spf_build_pairs (four): identical lists, counts and fillers, from
+    a single slot to the sampler pass's 131 072 slots, incl. all-invalid input."""
+    from spurfies_amd import ops
+
+    rng = np.random.default_rng(1)
+    for R, SR, frac in ((1024, 80, 0.6), (131072, 1, 0.04), (7, 3, 0.5), (1, 1, 1.0), (300, 80, 0.0)):
+        sv = (rng.uniform(size=(R, SR)) < frac).astype(np.uint8)
+        cnt = rng.integers(1, 9, size=(R * SR,))
+        nb = np.where(np.arange(8)[None, :] < cnt[:, None], rng.integers(0, 5000, size=(R * SR, 8)), -1).astype(np.int32)
+        nb[sv.reshape(-1) == 0] = -1
+        svt, nbt = torch.from_numpy(sv).cuda(), torch.from_numpy(nb).cuda()
+        ps, sp, n = ops.compact_points(svt)
+        old = ops.PairList(nbt, ps, n)
+        sdf = torch.empty((R * SR,), device="cuda")
+        grad = torch.empty((R * SR, 3), device="cuda")
+        new = ops.PairList.from_slots(svt, nbt, fill_sdf=sdf, fill_grad=grad)
+        P, NP = old.host_counts()
+        assert new.host_counts() == (P, NP) and P == int(sv.sum()) and NP == int(cnt[sv.reshape(-1) == 1].sum())
+        assert torch.equal(new.point_slot[:P], ps[:P]) and torch.equal(new.slot_point, sp)
+        assert torch.equal(new.pair_off[:P + 1], old.pair_off[:P + 1]) and torch.equal(new.pair_point[:NP], old.pair_point[:NP])
+        assert bool((sdf == 1000.0).all()) and bool((grad == 0).all())
