@@ -5,7 +5,8 @@ per scene, `VolOpt(args, batch_size=1, is_continue, timestamp='latest', checkpoi
 
 hydra / omegaconf are not needed (a literal `key=value` parser covers what the reference's own command lines use,
 readme.md:65,85,88).  The reference's datasets are a separate download; `data=synthetic` (default) optimises the built-in
-DTU-shaped synthetic scene instead, `points=` / `seed=` pick its size.  The optimisation itself is `spurfies_amd.train.VolOpt`
+DTU-shaped synthetic scene instead, `points=` / `seed=` pick its size, `prior=fitted|kaiming` its local prior (fitted: the SDF is the
+signed distance to the analytic surface), `local=true` adds synthetic `local_data` so that the feature-consistency term (weight 0.5) runs.  The optimisation itself is `spurfies_amd.train.VolOpt`
 on the HIP path; `sync_free=true` (default) is the mode `bench.py` measures.
 
     python runner.py testlist=scan24 vol=dtu_pn opt_stepNs=[200,0,0] exps_folder=exps_vsdf
@@ -18,7 +19,7 @@ import time
 
 DEFAULTS = {   # config/base.yaml + config/ours.yaml (the keys the optimisation path reads)
     "testlist": "scan24", "vol": "dtu_pn", "outdir": "exps_mvs", "exps_folder": "exps_vsdf", "opt_stepNs": [100000, 0, 0], "grad_clip": True,
-    "is_continue": False, "data": "synthetic", "points": 10000, "seed": 0, "sync_free": True, "root": "./", "mesh_resolution": 0, "mesh_level": 0.0,
+    "is_continue": False, "data": "synthetic", "points": 10000, "seed": 0, "prior": "fitted", "local": False, "sync_free": True, "root": "./", "mesh_resolution": 0, "mesh_level": 0.0,
     "vol.train.expname": "ours", "vol.train.render_freq": 500, "vol.train.checkpoint_freq": 15000, "vol.train.num_pixels": 1024,
     "vol.train.split_n_pixels": 500, "vol.loss.local_weight": 0.5, "vol.loss.pseudo_weight": 0.5, "vol.loss.eikonal_weight": 0.001,
     "vol.loss.rgb_weight": 1.0, "vol.loss.tv_weight": 0.01, "vol.dataset.data_dir": "dtu",
@@ -85,11 +86,16 @@ def optimise_scene(scene_name: str, flat: dict, args):
     if flat["data"] != "synthetic":
         raise SystemExit("runner.py: the reference's DTU / MipNeRF-360 loaders need its data download (out of scope, DESIGN.md §8); "
                          "use data=synthetic, or construct spurfies_amd.train.VolOpt(dataset=..., neural_points=...) from Python")
-    scene = syn.make_scene(int(flat["points"]), seed=int(flat["seed"]))
+    from spurfies_amd.train import SyntheticDataset
+
+    scene = syn.make_scene(int(flat["points"]), seed=int(flat["seed"]), prior=str(flat["prior"]))
     prior = {k: torch.from_numpy(np.asarray(v)) for k, v in scene["state"].items() if k.startswith(("F_geometry", "T."))}
     vol_opt = VolOpt(args=args, batch_size=1, is_continue=bool(flat["is_continue"]), timestamp="latest", checkpoint="latest", scan=scene_name,
                      root=str(flat["root"]), scene=scene, neural_points={"pts": scene["state"]["neural_pts"], "colors": scene["colors"]},
-                     prior_state_dict=prior, device="cuda", sync_free=bool(flat["sync_free"]))
+                     prior_state_dict=prior, device="cuda", sync_free=bool(flat["sync_free"]),
+                     dataset=SyntheticDataset(scene, local=True) if bool(flat["local"]) else None)
+    if str(flat["prior"]) == "fitted":      # the fitted prior pairs with latents that carry the normals (synthetic.make_scene)
+        vol_opt.model.load_state_dict({"neural_feats_geometry": torch.from_numpy(scene["state"]["neural_feats_geometry"])}, strict=False)
     vol_opt.gen_dataset(0)
     vol_opt.stg = 0
     steps = flat["opt_stepNs"]
@@ -114,9 +120,19 @@ def optimise_scene(scene_name: str, flat: dict, args):
         level = flat["mesh_level"]      # a number (the reference: 0), or "median": the synthetic scene's random prior has no zero level set
         level = float(np.median(vol[vol != surface.SDF_FILL])) if str(level) == "median" else float(level)
         verts, faces = surface.triangulate(vol, grid, level=level)
+        verts, faces = surface.largest_component(verts, faces)          # plots.py:213-215
         path = os.path.join(os.path.dirname(vol_opt.checkpoints_path), f"surface_{vol_opt.iter_step}.ply")
         surface.write_ply(path, verts, faces)
         print(f"mesh: {grid['grid_points'].shape[0]} grid points, level {level:.4f}, {len(verts)} vertices, {len(faces)} faces -> {path}")
+        if len(faces):      # the synthetic scene has a ground truth: the analytic surface (evals/eval_dtu.py-style accuracy / completeness)
+            rng = np.random.default_rng(0)
+            d = rng.standard_normal((100000, 3))
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            gt = d * syn.lobed_radius(d, scene["base_radius"])[:, None]
+            h = float(grid["xyz"][0][1] - grid["xyz"][0][0])
+            res = surface.chamfer_dtu(surface.sample_mesh_points(verts, faces, 0.5 * h), gt, max_dist=20 * h, thresh=0.5 * h)
+            print(f"chamfer vs the analytic surface (grid step {h:.4f}): accuracy {res['accuracy']:.5f}, completeness {res['completeness']:.5f}, "
+                  f"overall {res['overall']:.5f}")
     return vol_opt
 
 

@@ -29,4 +29,9 @@ def get_psnr(img1, img2, normalize_rgb=False):
     if normalize_rgb:
         img1, img2 = (img1 + 1.0) / 2.0, (img2 + 1.0) / 2.0
     mse = torch.mean((img1 - img2) ** 2)
-    return -10.0 * torch.log(mse) / torch.log(torch.tensor(10.0, device=mse.device))
+    # log(10) as the float32 constant the reference forms on the device: building a device tensor from a Python scalar is a
+    # synchronous host-to-device copy, i.e. a full stop of the otherwise sync-free optimisation loop
+    return -10.0 * torch.log(mse) / _LOG10
+
+
+_LOG10 = float(torch.log(torch.tensor(10.0)))

@@ -15,3 +15,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _restore_torch_threads():
+    """VolOpt pins torch to one intra-op thread like the reference (train.py:24); keep that from leaking into later tests."""
+    import torch
+
+    n = torch.get_num_threads()
+    yield
+    if torch.get_num_threads() != n:
+        torch.set_num_threads(n)
