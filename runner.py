@@ -7,7 +7,9 @@ hydra / omegaconf are not needed (a literal `key=value` parser covers what the r
 readme.md:65,85,88).  The reference's datasets are a separate download; `data=synthetic` (default) optimises the built-in
 DTU-shaped synthetic scene instead, `points=` / `seed=` pick its size, `prior=fitted|kaiming` its local prior (fitted: the SDF is the
 signed distance to the analytic surface), `local=true` adds synthetic `local_data` so that the feature-consistency term (weight 0.5) runs.  The optimisation itself is `spurfies_amd.train.VolOpt`
-on the HIP path; `sync_free=true` (default) is the mode `bench.py` measures.
+on the HIP path; `sync_free=true` (default) is the mode `bench.py` measures; `use_graph=true` replays forward + loss + backward as one
+hipGraph, which takes the host's ~3.5 ms of launch work per step out of the loop (the loop, unlike the bench, also pays the reference's
+per-step `randperm` over the image's pixels on the host).
 
     python runner.py testlist=scan24 vol=dtu_pn opt_stepNs=[200,0,0] exps_folder=exps_vsdf
 """
@@ -19,7 +21,7 @@ import time
 
 DEFAULTS = {   # config/base.yaml + config/ours.yaml (the keys the optimisation path reads)
     "testlist": "scan24", "vol": "dtu_pn", "outdir": "exps_mvs", "exps_folder": "exps_vsdf", "opt_stepNs": [100000, 0, 0], "grad_clip": True,
-    "is_continue": False, "data": "synthetic", "points": 10000, "seed": 0, "prior": "fitted", "local": False, "sync_free": True, "root": "./", "mesh_resolution": 0, "mesh_level": 0.0,
+    "is_continue": False, "data": "synthetic", "points": 10000, "seed": 0, "prior": "fitted", "local": False, "sync_free": True, "use_graph": False, "root": "./", "mesh_resolution": 0, "mesh_level": 0.0,
     "vol.train.expname": "ours", "vol.train.render_freq": 500, "vol.train.checkpoint_freq": 15000, "vol.train.num_pixels": 1024,
     "vol.train.split_n_pixels": 500, "vol.loss.local_weight": 0.5, "vol.loss.pseudo_weight": 0.5, "vol.loss.eikonal_weight": 0.001,
     "vol.loss.rgb_weight": 1.0, "vol.loss.tv_weight": 0.01, "vol.dataset.data_dir": "dtu",
@@ -92,7 +94,7 @@ def optimise_scene(scene_name: str, flat: dict, args):
     prior = {k: torch.from_numpy(np.asarray(v)) for k, v in scene["state"].items() if k.startswith(("F_geometry", "T."))}
     vol_opt = VolOpt(args=args, batch_size=1, is_continue=bool(flat["is_continue"]), timestamp="latest", checkpoint="latest", scan=scene_name,
                      root=str(flat["root"]), scene=scene, neural_points={"pts": scene["state"]["neural_pts"], "colors": scene["colors"]},
-                     prior_state_dict=prior, device="cuda", sync_free=bool(flat["sync_free"]),
+                     prior_state_dict=prior, device="cuda", sync_free=bool(flat["sync_free"]), use_graph=bool(flat["use_graph"]),
                      dataset=SyntheticDataset(scene, local=True) if bool(flat["local"]) else None)
     if str(flat["prior"]) == "fitted":      # the fitted prior pairs with latents that carry the normals (synthetic.make_scene)
         vol_opt.model.load_state_dict({"neural_feats_geometry": torch.from_numpy(scene["state"]["neural_feats_geometry"])}, strict=False)
