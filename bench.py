@@ -52,6 +52,9 @@ def parse():
                     "analytic surface (realistic sampler convergence / pair counts, SURVEY.md section 8(d)); kaiming: random prior (round-1 scene)")
     ap.add_argument("--scenes", type=int, default=1, help="BASELINE.json configs[3]: this many scenes optimised concurrently on the same ray-sharded "
                     "group (round-robin, no cross-scene collective); a step = one round over all scenes")
+    ap.add_argument("--exact-draws", action="store_true", help="N > 1: every rank draws the sampler's CPU random numbers for the WHOLE batch and keeps its "
+                    "rays' rows (bit-equal to a single-GPU run of the batch; N times the host-side draws). Default at N > 1: per-rank generator "
+                    "streams, each rank draws for its own rays only")
     ap.add_argument("--sustained", type=int, default=200, help="extra steps timed after the contract region (sustained clocks); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync", action="store_true", help="default (reference-shaped) step with one host read-back per step")
@@ -127,7 +130,7 @@ def build_scene_step(args, seed, device, world, use_graph):
     conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
     model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
     model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
-    return scene, model, TrainStep(model, sync_free=not args.sync, use_graph=use_graph)
+    return scene, model, TrainStep(model, sync_free=not args.sync, use_graph=use_graph, draws="batch" if (args.exact_draws or world == 1) else "local")
 
 
 def main():
@@ -175,7 +178,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    torch.manual_seed(1)          # the same CPU-generator stream on every rank: each draws batch-wide and keeps its rays' rows
+    # host side of the step = a few hundred tiny torch ops: with the intra-op pool enabled a strided slice of the draws costs tens of
+    # milliseconds (thread wake-ups); the reference pins one thread as well (train.py:24).  cpu_baseline sets its own thread counts.
+    torch.set_num_threads(1)
+    # --exact-draws: the same CPU-generator stream on every rank (each draws batch-wide and keeps its rays' rows); otherwise one stream per rank
+    torch.manual_seed(1 if (args.exact_draws or world == 1) else 1 + rank)
     for i in range(args.warmup):
         run_step(i)
     if not use_graph:
@@ -261,6 +268,8 @@ def main():
                    "valid_points_last_step": model.stats.get("valid_points", int(counts[0].item()) if counts is not None else None),
                    "pairs_last_step": model.stats.get("pairs", int(counts[1].item()) if counts is not None else None),
                    "host_syncs_per_step": 1 if args.sync else 0,
+                   "sampler_draws": "CPU generator, reference call order" + ("" if world == 1 else ("; batch-wide per rank, own rows kept (--exact-draws)" if args.exact_draws
+                                                                                                   else "; per-rank streams, own rays only")),
                    "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product exactly from three bf16 pieces per operand (6 bf16 MFMAs, fp32 accumulate)",
                    "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~91 per step)")},
         "roofline": roof,

@@ -25,7 +25,7 @@ def default_loss() -> VolSDFLoss:
 class TrainStep:
     N_STAGING = 4            # pinned staging buffers for the CPU-generator draws (sync-free steps run ahead of the GPU)
 
-    def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False, use_graph=False):
+    def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False, use_graph=False, draws="batch"):
         """sync_free: static shapes and device-side counts everywhere — no host synchronisation inside the step (the
         default path reads [P, n_pairs] back once per step to size the colour buffers exactly).
         use_graph (implies sync_free): forward + loss + backward (~230 kernel launches) are captured once into a hipGraph
@@ -50,9 +50,15 @@ class TrainStep:
         self.group = process_group
         self.world = sdist.world_size(process_group)
         self.rank = sdist.rank(process_group)
-        # ray-sharded batches: every rank issues the reference's CPU-generator calls for the WHOLE batch (same seed, same order) and
-        # keeps the rows of its own rays (rank::world, dist.shard_rays), so N ranks over a batch consume exactly the draws one GPU would
-        model.ray_sampler.shard = (self.rank, self.world) if self.world > 1 else None
+        # ray-sharded batches, draws="batch" (default): every rank issues the reference's CPU-generator calls for the WHOLE batch (same seed,
+        # same order) and keeps the rows of its own rays (rank::world, dist.shard_rays), so N ranks over a batch consume exactly the draws
+        # one GPU would — at the price of N times the host-side random numbers per rank (5 ms per step at 8 x 1024 rays: more than the GPU
+        # step).  draws="local": a rank draws only for its own rays from ITS OWN generator stream (seed the ranks differently): the same
+        # distribution, not the same numbers as a single-GPU run — what a throughput run wants.
+        if draws not in ("batch", "local"):
+            raise ValueError(draws)
+        self.draw_world = self.world if draws == "batch" else 1
+        model.ray_sampler.shard = (self.rank, self.world) if self.draw_world > 1 else None
         if self.world > 1:
             # the all-reduce sums gradients only: replicas must START identical (latents and MLPs are drawn from the local
             # generators in the constructors).  Rank 0's parameters, frozen prior and cloud win.
@@ -160,14 +166,14 @@ class TrainStep:
         pinned_flat, pinned, ev = self._pinned_ring[slot]
         if self._pinned_used[slot]:
             ev.synchronize()                         # the copy that last read this buffer has completed (normally long ago)
-        if self.world > 1:                           # batch-wide draws, this rank's rows
+        if self.draw_world > 1:                      # batch-wide draws, this rank's rows
             pinned["t_rand"].copy_(torch.rand((R * self.world, n0))[self.rank::self.world])
             pinned["u"].copy_(torch.rand((R * self.world, N))[self.rank::self.world])
         else:
             torch.rand((R, n0), out=pinned["t_rand"])
             torch.rand((R, N), out=pinned["u"])
         pinned["sel"].copy_(torch.randperm(n0)[:Ne])
-        torch.randint(M, (R * self.world,))          # the unused eikonal index (:562) — keeps the generator in step
+        torch.randint(M, (R * self.draw_world,))     # the unused eikonal index (:562) — keeps the generator in step
         self._draws_flat.copy_(pinned_flat, non_blocking=True)
         ev.record(torch.cuda.current_stream(dev))
         self._pinned_used[slot] = True
