@@ -690,10 +690,14 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
         {
             const int row = tid >> 2, q4 = tid & 3;
             const int idx = cur.idx;
+            // training: the layer-0 input row [64 latent | 3 offset | 36 sin / cos | 0] also goes to act0 (fp32 rows, what the weight-gradient
+            // GEMM of F_color.0 reads) straight from these registers — the values the planes hold, without a pass that rebuilds them
+            float* a0 = STORE ? act0 + ((size_t)tile * 64 + row) * C_INP : nullptr;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float v[4] = {cur.f[u][0], cur.f[u][1], cur.f[u][2], cur.f[u][3]};
                 store_quad_x3(X, row, q4 * 16 + 4 * u, v);
+                if (STORE) *reinterpret_cast<f32x4*>(a0 + q4 * 16 + 4 * u) = cur.f[u];
             }
 #pragma unroll
             for (int jj = 0; jj < 5; ++jj) {
@@ -708,6 +712,10 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                     }
                     store_one_x3(X, row, 64 + 3 + 6 * l + c, sv);
                     store_one_x3(X, row, 64 + 6 + 6 * l + c, cv);
+                    if (STORE) {
+                        a0[64 + 3 + 6 * l + c] = sv;
+                        a0[64 + 6 + 6 * l + c] = cv;
+                    }
                 }
             }
             if (q4 == 0) {
@@ -715,6 +723,12 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                 store_one_x3(X, row, 65, cur.d[1]);
                 store_one_x3(X, row, 66, cur.d[2]);
                 store_one_x3(X, row, 103, 0.f);          // pad column of the 104-wide internal layout
+                if (STORE) {
+                    a0[64] = cur.d[0];
+                    a0[65] = cur.d[1];
+                    a0[66] = cur.d[2];
+                    a0[103] = 0.f;
+                }
                 const float z[4] = {0.f, 0.f, 0.f, 0.f};
                 store_quad_x3(X, row, 104, z);           // K padded to 112
                 store_quad_x3(X, row, 108, z);
@@ -727,7 +741,6 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
         T_MARK(0)
         lds_barrier();
         T_MARK(1)
-        if (STORE) store_tile_from_planes<13>(X, act0 + (size_t)tile * 64 * C_INP, C_INP, tid);      // [64][104] fp32, layer-0 input
         uint32_t* mk = STORE ? masks + (size_t)tile * 3 * 512 : nullptr;                             // [layer 3][row 64][8 words]
         f32x16 acc[2][2];
         CxBias bias = cx_load_bias(pf + CO_B1, wave, lane);

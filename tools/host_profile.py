@@ -12,12 +12,12 @@ from spurfies_amd.conf import default_model_conf  # noqa: E402
 from spurfies_amd.model.pointneus_disent import PointVolSDF  # noqa: E402
 from spurfies_amd.train import TrainStep  # noqa: E402
 
-scene = syn.make_scene(10000, seed=0)
+scene = syn.make_scene(10000, seed=0, prior="fitted")
 st = scene["state"]
 conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
 model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]})
 model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
-step = TrainStep(model)
+step = TrainStep(model, sync_free="--default" not in sys.argv)
 batches = bench.make_batches(scene, 10, 1024, 0, 1, torch.device("cuda"))
 for b in batches[:4]:
     step(*b)
@@ -28,7 +28,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         step(*b)
     torch.cuda.synchronize()
 ka = prof.key_averages()
-print(ka.table(sort_by="self_cpu_time_total", row_limit=22, max_name_column_width=50))
+print(ka.table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=50))
 n_launch = sum(e.count for e in ka if e.key.startswith("hipLaunchKernel") or e.key.startswith("hipExtModuleLaunch") or "LaunchKernel" in e.key)
 print("kernel launches per step ~", n_launch / 4)
 # pure-python wall for phases without GPU sync inside (enqueue cost only)
