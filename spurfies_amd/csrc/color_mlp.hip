@@ -647,6 +647,11 @@ __device__ __forceinline__ CxRow cx_fetch_row(int idx, int srow, int p, int q, i
     return r;
 }
 
+#ifdef SPF_NO_AGG_ATOMICS      // timing-only ablation (wrong results): what the weighted mean's atomics cost
+#define SPF_AGG_ATOMIC(p, v) ((void)(p), (void)(v))
+#else
+#define SPF_AGG_ATOMIC(p, v) atomicAdd(p, v)
+#endif
 constexpr int CX_LDS_BF16 = 3 * X3_PLANE;
 constexpr int CX_LDL = 68;
 
@@ -808,8 +813,8 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                                 fixed_add(&agg3_fixed[(size_t)cur * 256 + c0], a0);
                                 fixed_add(&agg3_fixed[(size_t)cur * 256 + c0 + 32], a1);
                             } else {
-                                atomicAdd(&agg3[(size_t)cur * 256 + c0], a0);
-                                atomicAdd(&agg3[(size_t)cur * 256 + c0 + 32], a1);
+                                SPF_AGG_ATOMIC(&agg3[(size_t)cur * 256 + c0], a0);
+                                SPF_AGG_ATOMIC(&agg3[(size_t)cur * 256 + c0 + 32], a1);
                             }
                         }
                         cur = p;
@@ -824,8 +829,8 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                     fixed_add(&agg3_fixed[(size_t)cur * 256 + c0], a0);
                     fixed_add(&agg3_fixed[(size_t)cur * 256 + c0 + 32], a1);
                 } else {
-                    atomicAdd(&agg3[(size_t)cur * 256 + c0], a0);
-                    atomicAdd(&agg3[(size_t)cur * 256 + c0 + 32], a1);
+                    SPF_AGG_ATOMIC(&agg3[(size_t)cur * 256 + c0], a0);
+                    SPF_AGG_ATOMIC(&agg3[(size_t)cur * 256 + c0 + 32], a1);
                 }
             }
             if (STORE) *reinterpret_cast<u32x2*>(mk + 1024 + lane * 8 + 2 * wave) = u32x2{mw0, mw1};      // [row][8 words]
