@@ -271,7 +271,7 @@ def main():
                    "sampler_draws": "CPU generator, reference call order" + ("" if world == 1 else ("; batch-wide per rank, own rows kept (--exact-draws)" if args.exact_draws
                                                                                                    else "; per-rank streams, own rays only")),
                    "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product exactly from three bf16 pieces per operand (6 bf16 MFMAs, fp32 accumulate)",
-                   "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~91 per step)")},
+                   "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~66 per step)")},
         "roofline": roof,
         "sustained_ms_per_step": sustained, "sustained_steps": args.sustained if sustained is not None else 0,
         "loss_last": loss_last,
