@@ -170,6 +170,28 @@ static __device__ unsigned long long spf_timing_buf[32];      // one per transla
 #define T_FLUSH                                                      \
     if (tid == 0)                                                    \
         for (int i = 0; i < 32; ++i) atomicAdd(&spf_timing_buf[i], tacc[i]);
+#elif defined(SPF_CLOCK)
+// In-kernel clock for tools/kernel_clocks.py (-DSPF_CLOCK build, never the product library): thread 0 of every workgroup stamps the
+// shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) at the start and the end of the kernel;
+// sum of cycles / sum of ticks x 100 MHz = the clock the chip held while the kernel ran (MI355X_MICROARCH.md, DVFS give-back (6)).
+static __device__ unsigned long long spf_timing_buf[32];
+#define SPF_DEFINE_TIMING_ENTRY(name)                                                                                       \
+    extern "C" int name(unsigned long long* out32, int reset) {                                                            \
+        if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(spf_timing_buf), 32 * sizeof(unsigned long long)) != hipSuccess) return -5; \
+        if (reset) {                                                                                                        \
+            unsigned long long z[32] = {};                                                                                  \
+            if (hipMemcpyToSymbol(HIP_SYMBOL(spf_timing_buf), z, sizeof(z)) != hipSuccess) return -5;                       \
+        }                                                                                                                   \
+        return 0;                                                                                                           \
+    }
+#define T_DECL const unsigned long long tck0 = __builtin_amdgcn_s_memtime(), trt0 = __builtin_amdgcn_s_memrealtime();
+#define T_MARK(i)
+#define T_FLUSH                                                                           \
+    if (threadIdx.x == 0) {                                                               \
+        atomicAdd(&spf_timing_buf[0], __builtin_amdgcn_s_memtime() - tck0);               \
+        atomicAdd(&spf_timing_buf[1], __builtin_amdgcn_s_memrealtime() - trt0);           \
+        atomicAdd(&spf_timing_buf[2], 1ull);                                              \
+    }
 #else
 #define T_DECL
 #define T_MARK(i)

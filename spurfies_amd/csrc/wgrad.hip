@@ -269,16 +269,39 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
 // a thread's eight k-values are two conflict-free 16-byte reads (row-major operands need eight 4-byte reads).
 // GK = 2: G as K-major TILES of 64 rows, element (row, f) at ((256 (row / 64) + f) 64 + row % 64): what a row-per-lane producer
 // writes in full 128-byte lines (spf_color_backward's G3); a stage's 16 rows of a feature are then half a line (64 B) per request.
+// Round 2: software pipeline with ONE barrier per stage.  The planes are double buffered, so inside one barrier period a wave
+// splits stage s + 1 (ring -> planes / registers) and multiplies stage s; the fp32 ring is three stages deep (one being split, two
+// in flight across the barrier): 144 KB of LDS at C = 256.  Measured on the 389 k-row colour GEMM (tools/wgrad_phases.py, cycles per
+// stage of wave 0 / wave 4): DMA issue 0.3 / 0.5 k, split 1.1 k, 48 MFMAs 1.7 - 2.3 k, barrier + waits 0.5 - 2 k; 5.4 k per stage
+// against 3.07 k of matrix-pipe time for the SIMD's two waves.
+// SPF_WGRAD_LATE_MASK (timing builds) makes the selected waves multiply FIRST and split afterwards, so that the two waves of a SIMD
+// (w, w + 4 for mask 4) are in opposite phases.  That de-phased order measured no faster (same 5.4 k): a wave's VALU stream beside
+// its partner's back-to-back MFMAs runs ~2.5x slower (split 2.3 - 2.7 k instead of 1.1 k) -- the partner's next MFMA waits at the
+// SIMD's vector issue for the pipe and only ~2 other vector instructions get through per 32-cycle MFMA; raising the splitting
+// wave's priority (s_setprio) changes nothing, and scalar idles (s_nop) after each MFMA do free the issue port (split back to
+// 1.3 k) but cost the multiplying wave more than that (48 MFMAs 2.2 - 3.8 k).  Default: every wave splits first.
+#ifndef SPF_WGRAD_LATE_MASK
+#define SPF_WGRAD_LATE_MASK 0
+#endif
 template <int NT, int GK = 0, bool AK = false>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
 __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, const float* __restrict__ A, int lda, int C,
                                                   const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slab,
                                                   float* __restrict__ dbias, const int bid, const int nblk) {
-    constexpr int ROWS = 16, NB = 4, CA = 32 * NT;
+    constexpr int ROWS = 16, NB = 3, CA = 32 * NT;
     constexpr int NDMA = 2 + (NT == 8 ? 2 : 1);                           // requests per wave per stage
-    __shared__ __attribute__((aligned(16))) float sm[NB * ROWS * (256 + CA) + 3 * CA * 2 * 4];
-    bf16x8* planes = reinterpret_cast<bf16x8*>(sm + NB * ROWS * (256 + CA));     // [3][CA][2]
+    constexpr int PLANE = 3 * CA * 2;                                     // bf16x8 items of one plane set: [3][CA][2]
+    __shared__ __attribute__((aligned(16))) float sm[NB * ROWS * (256 + CA) + 2 * PLANE * 4];
+    bf16x8* planes = reinterpret_cast<bf16x8*>(sm + NB * ROWS * (256 + CA));     // [2][3][CA][2]
     const int tid = threadIdx.x, lane = tid & 63, ci = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // 0..7
+    // plane item of (column, k-half): 2 column + (k-half ^ bit 3 of the column).  A 16-byte LDS access is served in groups of 16 lanes
+    // (lanes {0-3, 12-15, 20-27}, ...: all of one k-half); without the swizzle their 32-byte stride uses half of the 64 banks twice
+#ifdef SPF_WGRAD_NO_SWIZZLE
+    const int hs = h;
+#else
+    const int hs = h ^ ((ci >> 3) & 1);
+#endif
+    const bool late = (wave & SPF_WGRAD_LATE_MASK) != 0;                   // this wave multiplies first, its SIMD partner splits first
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
     static_assert(!AK || NT == 8, "tiled A: 256 columns");
     constexpr int ALIGN = GK == 2 ? 64 : ((GK || AK) ? 16 : 2);            // blocked operands: a workgroup's rows start on a block / tile
@@ -287,17 +310,29 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
     const int r0 = bid * chunk, r1 = min(r0 + chunk, n);
     if (r0 >= r1) return;
     const int nst = (r1 - r0 + ROWS - 1) / ROWS;
+#ifdef SPF_CLOCK
+    T_DECL
+#endif
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float gsum = 0.f;
+#ifdef SPF_TIMING      // tools/wgrad_phases.py: cycles of waves 0 (splits first) and 4 (multiplies first) per phase of the stage loop
+    unsigned long long wt[10] = {}, wl = __builtin_readcyclecounter();
+#define W_MARK(i) { const unsigned long long now = __builtin_readcyclecounter(); wt[i] += now - wl; wl = now; }
+#else
+#define W_MARK(i)
+#endif
     const int c4max = (C - 1) / 4;
     const unsigned off_row = 16u * lane, off_half = 16u * min(ci, c4max);
     const unsigned off_k = (unsigned)(((lane & 15) * 16 + 4 * (lane >> 4)) * 4);      // blocked: lane = (feature in request, row quad)
     const unsigned off_k64 = (unsigned)(((lane & 15) * 64 + 4 * (lane >> 4)) * 4);    // 64-row tiles: a feature's rows are 256 B apart
     auto issue = [&](int st) {
+#ifdef SPF_WGRAD_NO_DMA       // timing build (wrong results): only the first three stages are ever requested
+        if (st > 2) return;
+#endif
         const int buf = st % NB, base = r0 + st * ROWS;
         float* sg = sm + buf * ROWS * (256 + CA);
         float* sa = sg + ROWS * 256;
@@ -319,67 +354,62 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
             glds16_s(A + (size_t)row_lo * lda, off_half + (h ? dhi : 0u), sa + lr * CA);
         }
     };
-    issue(0);
-    if (nst > 1) issue(1);
-    if (nst > 2) issue(2);
-    for (int st = 0; st < nst; ++st) {
-        if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");        // up to two younger stages in flight
-        else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (st + 3 < nst) issue(st + 3);
+    // stage st out of the ring: the workgroup's shared operand into plane set st & 1 (one (column, k-half) item per thread), this
+    // wave's 32 columns of G into registers
+    auto split_stage = [&](int st, Split8& ga) {
         const int buf = st % NB, left = r1 - (r0 + st * ROWS);
         const float* sg = sm + buf * ROWS * (256 + CA);
         const float* sa = sg + ROWS * 256;
-        {   // the workgroup's shared operand: one (column, k-half) item per thread
-            const int col = 32 * wave + ci;
-            if (col < CA) {
-                float x[8];
-                if (AK) {
-                    const float* p = sa + (col >> 4) * 256 + (2 * h) * 64 + (col & 15) * 4;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 64);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = sa[(8 * h + e) * CA + col];
-                }
-                const Split8 b = split8(x);
-                planes[(0 * CA + col) * 2 + h] = b.p1;
-                planes[(1 * CA + col) * 2 + h] = b.p2;
-                planes[(2 * CA + col) * 2 + h] = b.p3;
-            }
-        }
-        Split8 ga;
-        {
+        bf16x8* pl = planes + (st & 1) * PLANE;
+        const int col = 32 * wave + ci;
+        if (col < CA) {
             float x[8];
-            if (GK) {
-                const int col = 32 * wave + ci;
-                const float* p = sg + (col >> 4) * 256 + (2 * h) * 64 + (col & 15) * 4;
+            if (AK) {
+                const float* p = sa + (col >> 4) * 256 + (2 * h) * 64 + (col & 15) * 4;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 64);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    x[e] = (8 * h + e < left) ? lo[e] : 0.f;
-                    x[4 + e] = (8 * h + 4 + e < left) ? hi[e] : 0.f;
-                }
+                for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = (8 * h + e < left) ? sg[(8 * h + e) * 256 + 32 * wave + ci] : 0.f;
+                for (int e = 0; e < 8; ++e) x[e] = sa[(8 * h + e) * CA + col];
             }
-            ga = split8(x);
-            gsum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));      // column sums of G = the bias gradient
+            W_MARK(5)
+            const Split8 b = split8(x);
+            W_MARK(6)
+            pl[(0 * CA + col) * 2 + hs] = b.p1;
+            pl[(1 * CA + col) * 2 + hs] = b.p2;
+            pl[(2 * CA + col) * 2 + hs] = b.p3;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                   // planes complete
+        float x[8];
+        if (GK) {
+            const float* p = sg + (col >> 4) * 256 + (2 * h) * 64 + (col & 15) * 4;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 64);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = sg[(8 * h + e) * 256 + col];
+        }
+        W_MARK(7)
+        if (left < ROWS) {                              // the workgroup's last stage only: rows past the end count as zero
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (8 * h + e < left) ? x[e] : 0.f;
+        }
+        ga = split8(x);
+        gsum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));      // column sums of G = the bias gradient
+        W_MARK(8)
+    };
+    auto mfma_stage = [&](int st, const Split8& ga) {
+        const bf16x8* pl = planes + (st & 1) * PLANE;
         bf16x8 bq[2][3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bq[0][q] = planes[(q * CA + ci) * 2 + h];
+        for (int q = 0; q < 3; ++q) bq[0][q] = pl[(q * CA + ci) * 2 + hs];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int k = t & 1;
             if (t + 1 < NT) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) bq[k ^ 1][q] = planes[(q * CA + 32 * (t + 1) + ci) * 2 + h];
+                for (int q = 0; q < 3; ++q) bq[k ^ 1][q] = pl[(q * CA + 32 * (t + 1) + ci) * 2 + hs];
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.p3, bq[k][0], acc[t], 0, 0, 0);      // smallest terms first
@@ -390,8 +420,46 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.p1, bq[k][0], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    issue(0);
+    if (nst > 1) issue(1);
+    if (nst > 2) issue(2);
+    if (nst > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");                 // stage 0 landed
+    else if (nst > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Split8 ga, gn;
+    split_stage(0, ga);
+    gn = ga;
+    if (nst > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");                     // stage 1 landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // planes of stage 0 complete, stage 1 visible
+    for (int st = 0; st < nst; ++st) {
+        // period st: slot st % 3 was read for the last time before the barrier above; stages st + 1 (landed) and st + 2 hold the others
+        const bool ahead = st + 3 < nst, more = st + 1 < nst;
+        W_MARK(4)
+        if (ahead) issue(st + 3);
+        W_MARK(0)
+        if (more && !late) split_stage(st + 1, gn);
+        W_MARK(1)
+        mfma_stage(st, ga);
+        W_MARK(2)
+        if (more && late) split_stage(st + 1, gn);
+        W_MARK(1)
+        ga = gn;
+        if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");                   // stage st + 2 landed (this wave's share)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W_MARK(3)
+        __builtin_amdgcn_s_barrier();
     }
+#ifdef SPF_TIMING
+    if (lane == 0 && (wave & 3) == 0) {
+        for (int i = 0; i < 10; ++i) atomicAdd(&spf_timing_buf[16 * (wave >> 2) + i], wt[i]);
+        atomicAdd(&spf_timing_buf[16 * (wave >> 2) + 10], (unsigned long long)nst);
+    }
+#endif
     if (dbias) {
         gsum += __shfl_xor(gsum, 32);
         if (h == 0) atomicAdd(&dbias[32 * wave + ci], gsum);
@@ -401,6 +469,9 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64] = acc[t][r];
+#ifdef SPF_CLOCK
+    T_FLUSH
+#endif
 }
 
 
@@ -550,6 +621,8 @@ __global__ void colsum256_kernel(const float* __restrict__ G, const int32_t* __r
 }
 
 }  // namespace
+
+SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_wgrad)
 
 extern "C" {
 
