@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import os
 import sys
+import time
 import types
 
 import numpy as np
@@ -384,6 +385,62 @@ def golden_voxelize(name, seed=5, vox_res=60):
     print(name, "in", len(pts), "-> out", len(res["pts"]), "size", os.path.getsize(os.path.join(OUT, name)))
 
 
+def golden_trajectory(name, n_points, n_rays, steps, seed):
+    """G10: `steps` consecutive reference optimisation steps (train.py:330-364: forward fast=1, VolSDFLoss, backward, clip_grad_norm_(1.0),
+    Adam(lr 5e-4) in the reference's two param groups, CosineAnnealingLR(T_max 100 000, eta_min 3e-4)) on a fitted-prior scene, cycling
+    the three views, with ONE CPU-generator stream across all steps (the sampler's draws of step i + 1 continue where step i stopped).
+    Recorded: per-step inputs, losses, gradient norm, PSNR, beta; probes of every trainable parameter's total change."""
+    scene = syn.make_scene(n_points, seed=seed, prior="fitted")
+    model, ref_mod = ref_shim.build_reference_model(scene)
+    model.train()
+    loss_fn = reference_loss()
+    trainable = [(pname, p) for pname, p in model.named_parameters() if p.requires_grad]
+    before = {pname: p.detach().clone() for pname, p in trainable}
+    opt = torch.optim.Adam([{"params": [], "lr": 1e-2}, {"params": [p for _, p in trainable], "lr": 5.0e-4}])
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=100_000, eta_min=3e-4, last_epoch=-1)
+    tints = np.asarray([[1.0, 0.8, 0.7], [0.7, 1.0, 0.8], [0.8, 0.7, 1.0]], np.float32)
+    rec = {"uv": [], "rgb_gt": [], "mask_gt": [], "view": [], "grad_norm": [], "psnr": [], "beta": [], "n_points": []}
+    loss_rec = {}
+    torch.manual_seed(seed + 7)
+    t0 = time.time()
+    for i in range(steps):
+        view = i % 3
+        g = torch.Generator().manual_seed(seed + 100 + i)
+        uv = syn.make_pixels(n_rays, g)
+        rgb_gt = (np.stack([uv[:, 0] / 768.0, uv[:, 1] / 576.0, 0.5 + 0.0 * uv[:, 0]], -1) * tints[view]).astype(np.float32)
+        mask_gt = (((uv[:, 0] - syn.CX) ** 2 + (uv[:, 1] - syn.CY) ** 2) < (0.45 * 576) ** 2).astype(np.float32)
+        inp = {"intrinsics": torch.from_numpy(scene["intrinsics"])[None], "uv": torch.from_numpy(uv)[None],
+               "pose": torch.from_numpy(scene["poses"][view])[None], "local_data": None, "iter_step": i}
+        out = model(inp, fast=1)
+        gt = {"rgb": torch.from_numpy(rgb_gt)[None], "mask": torch.from_numpy(mask_gt)[None, :, None].repeat(1, 1, 3)}
+        losses = loss_fn(out, gt)
+        opt.zero_grad()
+        losses["loss"].backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        sched.step()
+        for k, v in losses.items():
+            loss_rec.setdefault(k, []).append(float(v.item()))
+        rec["uv"].append(uv); rec["rgb_gt"].append(rgb_gt); rec["mask_gt"].append(mask_gt); rec["view"].append(view)
+        rec["grad_norm"].append(float(gn.item()))
+        mse = float(((out["rgb_values"].detach() - gt["rgb"].reshape(-1, 3)) ** 2).mean().item())     # rend_util.py:143-156 get_psnr
+        rec["psnr"].append(-10.0 * np.log10(mse))
+        rec["beta"].append(float(model.density.get_beta().item()))
+        rec["n_points"].append(int(out["grad_theta"].shape[0]))
+        if i % 10 == 0:
+            print(name, "step", i, "loss", loss_rec["loss"][-1], "psnr", rec["psnr"][-1], "|g|", rec["grad_norm"][-1], "%.1f s" % (time.time() - t0))
+    fx = {"meta.n_points": n_points, "meta.n_rays": n_rays, "meta.steps": steps, "meta.seed": seed, "meta.cam_radius": 2.2,
+          "meta.checksum": scene_checksum(scene), "meta.prior": np.asarray("fitted")}
+    for k, v in rec.items():
+        fx[f"step.{k}"] = np.asarray(v)
+    for k, v in loss_rec.items():
+        fx[f"loss.{k}"] = np.asarray(v, np.float64)
+    for pname, p in trainable:
+        fx.update(probes(f"delta.{pname}", p.detach() - before[pname]))
+    np.savez_compressed(os.path.join(OUT, name), **fx)
+    print(name, "loss", loss_rec["loss"][0], "->", loss_rec["loss"][-1], "psnr", rec["psnr"][0], "->", rec["psnr"][-1], "size", os.path.getsize(os.path.join(OUT, name)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -410,6 +467,8 @@ def main():
         golden_sampler("sampler_g4.npz")
     if want("voxelize.npz"):
         golden_voxelize("voxelize.npz")
+    if want("trajectory_ref.npz"):
+        golden_trajectory("trajectory_ref.npz", n_points=3000, n_rays=96, steps=200, seed=9)
 
 
 if __name__ == "__main__":

@@ -168,3 +168,25 @@ def test_eikonal_term_has_zero_gradient_for_trainables():
     gs = torch.autograd.grad(eik, [st["neural_feats_geometry"], st["neural_feats_color"]], allow_unused=True)
     assert gs[1] is None or float(gs[1].abs().max()) == 0.0
     assert gs[0] is None or float(gs[0].abs().max()) == 0.0
+
+
+def test_oracle_tracks_reference_trajectory():
+    """G10 (tests/golden/trajectory_ref.npz: consecutive REFERENCE optimisation steps with one CPU-generator stream across them, Adam +
+    clip + cosine schedule, train.py:330-364): the oracle, driven by its own optimiser restatement, stays on the reference's loss
+    trajectory — i.e. it consumes the generator, updates every trainable and schedules the learning rate exactly like the reference."""
+    fx = load_golden("trajectory_ref.npz")
+    scene = scene_of(fx)
+    st = P.load_state(scene["state"])
+    cfg = P.PathConfig(ranges=tuple(scene["ranges"]))
+    grid = P.make_grid(cfg, st["neural_pts"])
+    opt, sched = P.make_optimizer(st)
+    K = torch.from_numpy(scene["intrinsics"])[None]
+    torch.manual_seed(int(fx["meta.seed"]) + 7)
+    for i in range(8):
+        inp = {"intrinsics": K, "uv": torch.from_numpy(fx["step.uv"][i])[None], "pose": torch.from_numpy(scene["poses"][int(fx["step.view"][i])])[None]}
+        _, losses, _ = P.train_step_grads(inp, torch.from_numpy(fx["step.rgb_gt"][i]), torch.from_numpy(fx["step.mask_gt"][i]), st, cfg, grid=grid)
+        norm = P.optimizer_step(st, opt, sched)
+        for k, v in losses.items():
+            np.testing.assert_allclose(v.item(), fx[f"loss.{k}"][i], rtol=2e-5, atol=1e-7, err_msg=f"step {i} {k}")
+        np.testing.assert_allclose(float(norm), fx["step.grad_norm"][i], rtol=1e-4, err_msg=f"step {i} grad norm")
+    np.testing.assert_allclose(float(P.get_beta(st, cfg).detach()), fx["step.beta"][7], rtol=1e-5)      # step.beta[i]: after step i's update
