@@ -385,7 +385,7 @@ def golden_voxelize(name, seed=5, vox_res=60):
     print(name, "in", len(pts), "-> out", len(res["pts"]), "size", os.path.getsize(os.path.join(OUT, name)))
 
 
-def golden_trajectory(name, n_points, n_rays, steps, seed):
+def golden_trajectory(name, n_points, n_rays, steps, seed, local=False):
     """G10: `steps` consecutive reference optimisation steps (train.py:330-364: forward fast=1, VolSDFLoss, backward, clip_grad_norm_(1.0),
     Adam(lr 5e-4) in the reference's two param groups, CosineAnnealingLR(T_max 100 000, eta_min 3e-4)) on a fitted-prior scene, cycling
     the three views, with ONE CPU-generator stream across all steps (the sampler's draws of step i + 1 continue where step i stopped).
@@ -401,6 +401,8 @@ def golden_trajectory(name, n_points, n_rays, steps, seed):
     tints = np.asarray([[1.0, 0.8, 0.7], [0.7, 1.0, 0.8], [0.8, 0.7, 1.0]], np.float32)
     rec = {"uv": [], "rgb_gt": [], "mask_gt": [], "view": [], "grad_norm": [], "psnr": [], "beta": [], "n_points": []}
     loss_rec = {}
+    # local=True: the feature-consistency term (find_surface_points + get_local_loss, local_weight 0.5) takes part in every step
+    local_data = [torch_local_data(syn.make_local_data(scene, v, seed=seed)) for v in range(3)] if local else [None] * 3
     torch.manual_seed(seed + 7)
     t0 = time.time()
     for i in range(steps):
@@ -410,7 +412,7 @@ def golden_trajectory(name, n_points, n_rays, steps, seed):
         rgb_gt = (np.stack([uv[:, 0] / 768.0, uv[:, 1] / 576.0, 0.5 + 0.0 * uv[:, 0]], -1) * tints[view]).astype(np.float32)
         mask_gt = (((uv[:, 0] - syn.CX) ** 2 + (uv[:, 1] - syn.CY) ** 2) < (0.45 * 576) ** 2).astype(np.float32)
         inp = {"intrinsics": torch.from_numpy(scene["intrinsics"])[None], "uv": torch.from_numpy(uv)[None],
-               "pose": torch.from_numpy(scene["poses"][view])[None], "local_data": None, "iter_step": i}
+               "pose": torch.from_numpy(scene["poses"][view])[None], "local_data": local_data[view], "iter_step": i}
         out = model(inp, fast=1)
         gt = {"rgb": torch.from_numpy(rgb_gt)[None], "mask": torch.from_numpy(mask_gt)[None, :, None].repeat(1, 1, 3)}
         losses = loss_fn(out, gt)
@@ -430,7 +432,7 @@ def golden_trajectory(name, n_points, n_rays, steps, seed):
         if i % 10 == 0:
             print(name, "step", i, "loss", loss_rec["loss"][-1], "psnr", rec["psnr"][-1], "|g|", rec["grad_norm"][-1], "%.1f s" % (time.time() - t0))
     fx = {"meta.n_points": n_points, "meta.n_rays": n_rays, "meta.steps": steps, "meta.seed": seed, "meta.cam_radius": 2.2,
-          "meta.checksum": scene_checksum(scene), "meta.prior": np.asarray("fitted")}
+          "meta.checksum": scene_checksum(scene), "meta.prior": np.asarray("fitted"), "meta.local": np.asarray(bool(local))}
     for k, v in rec.items():
         fx[f"step.{k}"] = np.asarray(v)
     for k, v in loss_rec.items():
@@ -469,6 +471,8 @@ def main():
         golden_voxelize("voxelize.npz")
     if want("trajectory_ref.npz"):
         golden_trajectory("trajectory_ref.npz", n_points=3000, n_rays=96, steps=200, seed=9)
+    if want("trajectory_local_ref.npz"):
+        golden_trajectory("trajectory_local_ref.npz", n_points=3000, n_rays=96, steps=60, seed=11, local=True)
 
 
 if __name__ == "__main__":

@@ -164,17 +164,24 @@ def test_three_optimisation_steps_track_the_oracle():
         np.testing.assert_allclose(a, b, rtol=0, atol=0.1 * moved + 1e-7, err_msg=k)
 
 
-def test_200_step_trajectory_tracks_the_reference():
+@pytest.mark.parametrize("name", ["trajectory_ref.npz", "trajectory_local_ref.npz"])
+def test_multi_step_trajectory_tracks_the_reference(name):
     """G10: 200 consecutive optimisation steps of the REFERENCE itself (tests/golden/trajectory_ref.npz, generated by
     oracle/make_golden.py from the imported reference: forward fast=1, VolSDFLoss, backward, clip 1.0, Adam, cosine schedule, the three
     views in turn, ONE CPU-generator stream across all steps) replayed through the sync-free HIP step.  A step's random draws continue
     where the previous step stopped, so a single extra or missing draw would derail the run at step 2.  fp32 differences are amplified
     by Adam from step to step; measured on MI355X: total loss within 2.3e-7 over the first 10 steps, 1.1e-4 over the first 50, 2.3 %
-    at worst over 200; norms of the parameters' total change within 1 % (latents) to 11 % (the smallest bias vector)."""
+    at worst over 200; norms of the parameters' total change within 1 % (latents) to 11 % (the smallest bias vector).
+    trajectory_local_ref.npz: 60 steps with `local_data` on every step (find_surface_points + get_local_loss at local_weight 0.5)."""
+    from spurfies_amd import synthetic as syn
     from spurfies_amd.train import TrainStep
 
-    fx = load_golden("trajectory_ref.npz")
+    fx = load_golden(name)
     scene = scene_of(fx)
+    local = [None] * 3
+    if bool(fx["meta.local"]):
+        local = [{k: (torch.from_numpy(np.asarray(v)).cuda() if isinstance(v, (np.ndarray, np.floating)) else v)
+                  for k, v in syn.make_local_data(scene, v_, seed=int(fx["meta.seed"])).items()} for v_ in range(3)]
     model = build_model(scene)
     step = TrainStep(model, sync_free=True)
     before = {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad}
@@ -184,14 +191,16 @@ def test_200_step_trajectory_tracks_the_reference():
     got = []
     for i in range(n):
         inp = {"intrinsics": K, "uv": torch.from_numpy(fx["step.uv"][i])[None].cuda(),
-               "pose": torch.from_numpy(scene["poses"][int(fx["step.view"][i])])[None].cuda(), "local_data": None, "iter_step": i}
+               "pose": torch.from_numpy(scene["poses"][int(fx["step.view"][i])])[None].cuda(), "local_data": local[int(fx["step.view"][i])], "iter_step": i}
         gt = {"rgb": torch.from_numpy(fx["step.rgb_gt"][i])[None].cuda(), "mask": torch.from_numpy(fx["step.mask_gt"][i])[None, :, None].repeat(1, 1, 3).cuda()}
         losses, _ = step(inp, gt)
         got.append(losses)                       # device scalars: no host read-back inside the loop
-    for k in ("loss", "rgb_loss", "tv_loss", "mask_loss", "pseudo_loss", "eikonal_loss"):
+    for k in ("loss", "rgb_loss", "tv_loss", "mask_loss", "pseudo_loss", "eikonal_loss") + (("local_loss",) if bool(fx["meta.local"]) else ()):
         ref, mine = fx[f"loss.{k}"], np.asarray([g[k].item() for g in got])
-        np.testing.assert_allclose(mine[:10], ref[:10], rtol=2e-3 if k == "eikonal_loss" else 1e-4, err_msg=k)
-        np.testing.assert_allclose(mine[:50], ref[:50], rtol=5e-3, err_msg=k)
+        # the eikonal and feature-consistency terms sit on kinks (a neighbour set / a zero crossing flipping between two samples)
+        kinky = k in ("eikonal_loss", "local_loss")
+        np.testing.assert_allclose(mine[:10], ref[:10], rtol=5e-3 if kinky else 1e-4, err_msg=k)
+        np.testing.assert_allclose(mine[:50], ref[:50], rtol=3e-2 if kinky else 5e-3, err_msg=k)
         np.testing.assert_allclose(mine, ref, rtol=0.15, err_msg=k)
         np.testing.assert_allclose(mine[-20:].mean(), ref[-20:].mean(), rtol=0.03, err_msg=k)
     state = step.optimizer._flat["state"].tolist()        # {t, skipped (non-finite) updates, last gradient norm, last clip coefficient}

@@ -6,6 +6,7 @@ import torch
 
 from oracle import path as P
 from oracle.voxel_grid import VoxelGridOracle, brute_force_knn
+from spurfies_amd import synthetic as syn
 from tests.helpers import check_probes, draws_of, inputs_of, load_golden, scene_of
 
 TOL = dict(rtol=2e-5, atol=2e-6)  # float32 round-off between two CPU evaluations of the same op sequence
@@ -170,12 +171,17 @@ def test_eikonal_term_has_zero_gradient_for_trainables():
     assert gs[0] is None or float(gs[0].abs().max()) == 0.0
 
 
-def test_oracle_tracks_reference_trajectory():
+@pytest.mark.parametrize("name", ["trajectory_ref.npz", "trajectory_local_ref.npz"])
+def test_oracle_tracks_reference_trajectory(name):
     """G10 (tests/golden/trajectory_ref.npz: consecutive REFERENCE optimisation steps with one CPU-generator stream across them, Adam +
     clip + cosine schedule, train.py:330-364): the oracle, driven by its own optimiser restatement, stays on the reference's loss
     trajectory — i.e. it consumes the generator, updates every trainable and schedules the learning rate exactly like the reference."""
-    fx = load_golden("trajectory_ref.npz")
+    fx = load_golden(name)
     scene = scene_of(fx)
+    local = [None] * 3
+    if bool(fx["meta.local"]):
+        local = [{k: (torch.from_numpy(np.asarray(v)) if isinstance(v, (np.ndarray, np.floating)) else v)
+                  for k, v in syn.make_local_data(scene, v_, seed=int(fx["meta.seed"])).items()} for v_ in range(3)]
     st = P.load_state(scene["state"])
     cfg = P.PathConfig(ranges=tuple(scene["ranges"]))
     grid = P.make_grid(cfg, st["neural_pts"])
@@ -183,7 +189,8 @@ def test_oracle_tracks_reference_trajectory():
     K = torch.from_numpy(scene["intrinsics"])[None]
     torch.manual_seed(int(fx["meta.seed"]) + 7)
     for i in range(8):
-        inp = {"intrinsics": K, "uv": torch.from_numpy(fx["step.uv"][i])[None], "pose": torch.from_numpy(scene["poses"][int(fx["step.view"][i])])[None]}
+        inp = {"intrinsics": K, "uv": torch.from_numpy(fx["step.uv"][i])[None], "pose": torch.from_numpy(scene["poses"][int(fx["step.view"][i])])[None],
+               "local_data": local[int(fx["step.view"][i])]}
         _, losses, _ = P.train_step_grads(inp, torch.from_numpy(fx["step.rgb_gt"][i]), torch.from_numpy(fx["step.mask_gt"][i]), st, cfg, grid=grid)
         norm = P.optimizer_step(st, opt, sched)
         for k, v in losses.items():
