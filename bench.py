@@ -248,6 +248,7 @@ def main():
                 "power_envelope_note": "peak is the 2.4 GHz data-sheet figure; the library's GEMM loop alone (tools/micro/x3_loop_rate.hip) holds 1.53 GHz "
                                        "at 90 % matrix-pipe duty and 2.2 GHz at 66-76 %, i.e. 240-290 algorithmic TFLOP/s is what this instruction mix "
                                        "can draw (DESIGN.md section 6)",
+                "held_clock": held_clock(ach),
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": "geo_pairs_x3_kernel<true> (+ geo_point_reduce_kernel, < 1 % of the launch)",
                 "timing": ("HIP events over eager passes of the timed batches, right after the timed region (events cannot sit inside a "
                            "hipGraph replay)") if use_graph else "HIP events over the timed region", "launches": len(main), "avg_ms": ms / len(main),
@@ -271,7 +272,7 @@ def main():
                    "sampler_draws": "CPU generator, reference call order" + ("" if world == 1 else ("; batch-wide per rank, own rows kept (--exact-draws)" if args.exact_draws
                                                                                                    else "; per-rank streams, own rays only")),
                    "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product exactly from three bf16 pieces per operand (6 bf16 MFMAs, fp32 accumulate)",
-                   "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~66 per step)")},
+                   "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~80 per step: 52 library kernels + torch's small elementwise / copy / fill launches)")},
         "roofline": roof,
         "sustained_ms_per_step": sustained, "sustained_steps": args.sustained if sustained is not None else 0,
         "loss_last": loss_last,
@@ -282,6 +283,18 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def held_clock(achieved_tflops):
+    """The shader clock the dominant kernel was MEASURED to hold inside the step (tools/kernel_clocks.py on a -DSPF_CLOCK build; the product
+    library carries no stamps, so this is read from the committed measurement) and the roofline fraction at that clock."""
+    path = os.path.join(ROOT, "profiles", "r02_kernel_clocks.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    ghz = [v["ghz"] for k, v in rec["clocks_ghz"].items() if "geo_pairs" in k][0]
+    return {"ghz": ghz, "nominal_ghz": 2.4, "peak_at_held_clock": PEAK_SPLIT_TFLOPS * ghz / 2.4, "frac_at_held_clock": achieved_tflops / (PEAK_SPLIT_TFLOPS * ghz / 2.4),
+            "source": "profiles/r02_kernel_clocks.json (s_memtime / s_memrealtime stamps around the kernel, 6 s of back-to-back steps); `frac` above stays priced at 2.4 GHz"}
 
 
 def secondary_rooflines(prof, rays_local):
