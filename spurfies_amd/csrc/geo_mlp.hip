@@ -23,7 +23,7 @@
 //   sdf(p) = sum_j w_j sdf_j / sum_j w_j,  w_j = exp(-(rbf * max(|x_pi|, 1e-12))^2)  (detached)
 //   d sdf / d x(p) = sum_j (w_j / norm) d sdf_j / d x_pi
 #include "mlp_tile.h"
-#include "mlp_tile_x3.h"
+#include "mlp_tile_x3s.h"
 
 namespace {
 
@@ -497,19 +497,23 @@ __global__ void geo_pack_kernel(PackArgs a, float* __restrict__ out) {
 //   x = p1 + p2 + p3, p1 = bf16(x), p2 = bf16(x - p1), p3 = bf16(x - p1 - p2): both differences are exact in fp32 and 3 x 8
 //   mantissa bits cover fp32's 24; a product of two fp32 numbers is sum_{i,j} a_i b_j, every piece product is exact in the
 //   MFMA's fp32 accumulation and the three with i + j >= 5 are below 2^-24 of the product, so the six with i + j <= 4 give the
-//   fp32 product to fp32 rounding.  Six v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace eight v_mfma_f32_32x32x2_f32
+//   fp32 product to fp32 rounding.  Six bf16 MFMAs (K = 16 in 32 cycles on a 32 x 32 tile) replace eight v_mfma_f32_32x32x2_f32
 //   (64 cycles, K = 2): 2.7x the matrix rate; results differ from the fp32-MFMA kernel above only by summation order.
-// Layout: transposed product D[feature][row] += W[feature][k] X[k][row] — the weights are the MFMA A operand (fragments
-// [wave][k16][m][piece][lane] x 8 bf16, streamed from L2), the activations the B operand, held in LDS as three bf16 planes
-// [piece][row][k] (one 16-byte read per fragment); a lane then owns 4 CONSECUTIVE features of one row per register quad, so an
-// epilogue (+ bias, LeakyReLU, sign bits, split into pieces) rewrites the planes with 8-byte stores.  One 4-wave workgroup per
-// CU (the planes take 101 KB), wave w owns features [64w, 64w+64) x 64 rows as 2x2 tiles.
+// Layout: transposed product D[feature][row] += W[feature][k] X[k][row] — the weights are the MFMA A operand (piece fragments streamed
+// from L2), the activations the B operand, held in LDS as three bf16 planes [piece][row][k] (one 16-byte read per fragment); a lane
+// owns 4 CONSECUTIVE features of a row per accumulator, so an epilogue (+ bias, LeakyReLU, sign bits, split into pieces) rewrites the
+// planes with 8-byte stores.  One 4-wave workgroup per CU (the planes take 101 KB), wave w owns features [64w, 64w+64) x 64 rows.
+// Round 2: the products run on v_mfma_f32_16x16x32_bf16 (mlp_tile_x3s.h: 4 x 4 tiles of 16 x 16, K = 32 per instruction, 16 cycles)
+// instead of v_mfma_f32_32x32x16_bf16 (2 x 2 tiles, 32 cycles): same FLOP per cycle, same operand bytes, but the chip holds a higher
+// clock under this shape (in the optimisation step: 1.99 vs 1.88 GHz on the same box, kernel -2.3 %; run back to back on its own:
+// 2.05 vs 1.88 GHz, -5.2 %, at +3 % cycles).
 // ==============================================================================================================================
-constexpr int X3_T1 = 3;                          // first layer: K = 35 -> 48
-constexpr int X3_TH = 16;                         // 256 / 16
-constexpr int X3_SZ1 = 4 * X3_T1 * 2 * 3 * 64;    // bf16x8 entries
-constexpr int X3_SZH = 4 * X3_TH * 2 * 3 * 64;
-constexpr int X3_SZJ = 2 * X3_TH * 3 * 64;
+// k32-steps of v_mfma_f32_16x16x32_bf16 (mlp_tile_x3s.h: 4 x 4 tiles of 16 x 16 per wave; the shape holds a higher clock under load)
+constexpr int X3_T1 = 2;                          // first layer: K = 35 -> 64
+constexpr int X3_TH = 8;                          // 256 / 32
+constexpr int X3_SZ1 = 4 * X3_T1 * 4 * 3 * 64;    // bf16x8 entries: [wave][k32][a][piece][lane]
+constexpr int X3_SZH = 4 * X3_TH * 4 * 3 * 64;
+constexpr int X3_SZJ = 2 * X3_TH * 2 * 3 * 64;    // [m][k32][a][piece][lane]
 constexpr int X3_FW1 = 0;
 constexpr int X3_FW2 = X3_FW1 + X3_SZ1;
 constexpr int X3_FW3 = X3_FW2 + X3_SZH;
@@ -521,7 +525,8 @@ constexpr int X3_JW1 = X3_BW2 + X3_SZH;
 constexpr int X3_FRAGS = X3_JW1 + X3_SZJ;
 constexpr int PACKED_TOTAL = PACKED_FLOATS + 4 * X3_FRAGS;     // the fp32 image, then the piece fragments (16 B each)
 
-// one thread per fragment slot (region, wave, k16, m, lane): 8 weights -> 3 x bf16x8
+// one thread per fragment slot (region, wave, k32, a, lane): 8 weights -> 3 x bf16x8.  lane = (i = lane & 15, g = lane >> 4):
+// feature 16 a + i, k = 32 t + 8 g .. + 7
 __global__ void geo_pack_x3_kernel(PackArgs a, bf16x8* __restrict__ out) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr int N1 = X3_SZ1 / 3, NH = X3_SZH / 3, NJ = X3_SZJ / 3;
@@ -530,16 +535,16 @@ __global__ void geo_pack_x3_kernel(PackArgs a, bf16x8* __restrict__ out) {
     if (s < N1) { region = 0; local = s; }
     else if (s < N1 + 6 * NH) { region = 1 + (s - N1) / NH; local = (s - N1) % NH; }
     else { region = 7; local = s - N1 - 6 * NH; }
-    const int ln = local & 63, i = ln & 31, kg = ln >> 5;
+    const int ln = local & 63, i = ln & 15, g = ln >> 4;
     float w[8];
     size_t base;
     if (region < 7) {
         const int T = region == 0 ? X3_T1 : X3_TH;
-        const int m = (local >> 6) & 1, t = (local >> 7) % T, wv = (local >> 7) / T;
-        const int f = 64 * wv + 32 * m + i;
+        const int at = (local >> 6) & 3, t = (local >> 8) % T, wv = (local >> 8) / T;
+        const int f = 64 * wv + 16 * at + i;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int k = 16 * t + 8 * kg + e;
+            const int k = 32 * t + 8 * g + e;
             float v;
             switch (region) {
                 case 0: v = k < K_IN ? a.w0[f * K_IN + k] : 0.f; break;
@@ -553,16 +558,16 @@ __global__ void geo_pack_x3_kernel(PackArgs a, bf16x8* __restrict__ out) {
             w[e] = v;
         }
         const int rb = region == 0 ? X3_FW1 : X3_FW2 + (region - 1) * X3_SZH;
-        base = (size_t)rb + (size_t)((wv * T + t) * 2 + m) * 3 * 64 + ln;
+        base = (size_t)rb + (size_t)((wv * T + t) * 4 + at) * 3 * 64 + ln;
     } else {
-        const int t = (local >> 6) % X3_TH, m = (local >> 6) / X3_TH;
-        const int f = 32 * m + i;
+        const int at = (local >> 6) & 1, t = (local >> 7) % X3_TH, m = (local >> 7) / X3_TH;
+        const int f = 32 * m + 16 * at + i;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int k = 16 * t + 8 * kg + e;
+            const int k = 32 * t + 8 * g + e;
             w[e] = f < K_IN ? a.w0[k * K_IN + f] : 0.f;  // J[f] = sum_o g_h1[o] W0[o][f]
         }
-        base = (size_t)X3_JW1 + (size_t)(m * X3_TH + t) * 3 * 64 + ln;
+        base = (size_t)X3_JW1 + (size_t)((m * X3_TH + t) * 2 + at) * 3 * 64 + ln;
     }
     bf16x8 p1, p2, p3;
 #pragma unroll
@@ -576,81 +581,62 @@ __global__ void geo_pack_x3_kernel(PackArgs a, bf16x8* __restrict__ out) {
     out[base + 128] = p3;
 }
 
-// acc[m][n][4g + e] = feature 64w + 32m + 8g + 4kg + e of row 32n + j.  mask[m]: bit n * 16 + 4g + e.
-// MODE 0: a = lrelu(acc + b) -> planes.   MODE 1 (last forward layer): also sdf partial sums s[n] += v5 . a, and the planes get
-// the Jacobian seed v5 * lrelu'(h) instead of a (a itself is not needed any more).
-// this lane's bias values of a layer (features 64 wave + 32 m + 8 g + 4 kg ..+3), requested ahead of the layer's GEMM
-struct Bias3 {
-    f32x4 b[2][4];
-};
-__device__ __forceinline__ Bias3 load_bias3(gfp bias, int wave, int lane) {
-    Bias3 r;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            r.b[m][g] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(bias + 64 * wave + 32 * m + 8 * g + 4 * (lane >> 5));
-    return r;
-}
-
-// forward epilogue: a = lrelu(acc + b) -> planes; sign bits pushed into mask[n] in the order (m, g, e) (32 per word).
-// MODE 1 (last layer): sdf partial sums s[n] += v . a, and the planes receive the Jacobian seed v * lrelu'(h) instead.
+// acc[a][b][e] = feature 64 w + 16 a + 4 g + e of row 16 b + i (i = lane & 15, g = lane >> 4).
+// forward epilogue: a = lrelu(acc + b) -> planes; sign bits pushed into mask[b >> 1] in the order (a, b & 1, e) (32 per word).
+// MODE 1 (last forward layer): sdf partial sums s[b] += v . a, and the planes receive the Jacobian seed v * lrelu'(h) instead of a
+// (a itself is not needed any more).
 template <int MODE, bool WITH_JAC>
-__device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], const Bias3& bias, const Bias3& v5, int wave, int lane,
-                                                uint32_t (&mask)[2], float (&s)[2]) {
-    const int j = lane & 31, kg = lane >> 5;
+__device__ __forceinline__ void fwd_epilogue_xs(__bf16* X, const f32x4 (&acc)[4][4], const BiasS& bias, const BiasS& v5, int wave, int lane,
+                                                uint32_t (&mask)[2], float (&s)[4]) {
+    const int i = lane & 15, g = lane >> 4;
     mask[0] = mask[1] = 0u;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
-            const f32x4 bv = bias.b[m][g];
-            f32x4 vv = f32x4{0.f, 0.f, 0.f, 0.f}, vs = vv;
-            if (MODE == 1) {
-                vv = v5.b[m][g];
-                vs = vv * 0.01f;
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                f32x4 h, hs;
-                bias_scale4(acc[m][n], g, bv, h, hs);
-                f32x4 out;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (MODE == 1) {
-                        float seed;
-                        const float a = lrelu_push_sel(h[e], hs[e], vv[e], vs[e], seed, mask[n]);
-                        s[n] += vv[e] * a;
-                        out[e] = seed;
-                    } else {
-                        out[e] = lrelu_push(h[e], hs[e], mask[n]);
-                    }
-                }
-                if (MODE == 0 || WITH_JAC) store_quad_x3(X, 32 * n + j, f0, out);
-            }
+    for (int a = 0; a < 4; ++a) {
+        const int f0 = 64 * wave + 16 * a + 4 * g;
+        const f32x4 bv = bias.b[a];
+        f32x4 vv = f32x4{0.f, 0.f, 0.f, 0.f}, vs = vv;
+        if (MODE == 1) {
+            vv = v5.b[a];
+            vs = vv * 0.01f;
         }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            f32x4 h, hs;
+            bias_scale4s(acc[a][b], bv, h, hs);
+            f32x4 out;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (MODE == 1) {
+                    float seed;
+                    const float act = lrelu_push_sel(h[e], hs[e], vv[e], vs[e], seed, mask[b >> 1]);
+                    s[b] += vv[e] * act;
+                    out[e] = seed;
+                } else {
+                    out[e] = lrelu_push(h[e], hs[e], mask[b >> 1]);
+                }
+            }
+            if (MODE == 0 || WITH_JAC) store_quad_x3(X, 16 * b + i, f0, out);
+        }
+    }
 }
 
 // backward epilogue: g_h = g_a * lrelu'(h) -> planes (pops the words the forward epilogue filled, in the same order)
-__device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mask_in)[2]) {
-    const int j = lane & 31, kg = lane >> 5;
+__device__ __forceinline__ void bwd_epilogue_xs(__bf16* X, const f32x4 (&acc)[4][4], int wave, int lane, const uint32_t (&mask_in)[2]) {
+    const int i = lane & 15, g = lane >> 4;
     uint32_t mask[2] = {mask_in[0], mask_in[1]};
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int a = 0; a < 4; ++a) {
+        const int f0 = 64 * wave + 16 * a + 4 * g;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+        for (int b = 0; b < 4; ++b) {
+            f32x4 vs;
+            scale4s(acc[a][b], vs);
+            f32x4 out;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                f32x4 v, vs;
-                scale4(acc[m][n], g, v, vs);
-                f32x4 out;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], mask[n]);
-                store_quad_x3(X, 32 * n + j, f0, out);
-            }
+            for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(acc[a][b][e], vs[e], mask[b >> 1]);
+            store_quad_x3(X, 16 * b + i, f0, out);
         }
+    }
 }
 
 constexpr int X3_LDS_BF16 = 3 * X3_PLANE;
@@ -707,8 +693,8 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gfp pf = launder(packed0);
         gx3 frag = reinterpret_cast<gx3>(pf + PACKED_FLOATS);
-        gx3 w_fw1 = frag + X3_FW1 + wave * (X3_T1 * 2 * 3 * 64) + lane;
-        const WFrag3 fr1 = load_wfrag3(w_fw1);                  // in flight during the gather
+        gx3 w_fw1 = frag + X3_FW1 + wave * (X3_T1 * 4 * 3 * 64) + lane;
+        const WFragS fr1 = load_wfrags(w_fw1);                  // in flight during the gather
         T_MARK(31)
         // ---- gather: thread = (row, quarter of the 32-d latent); pieces straight into the planes.  The operands were requested
         //      during the previous tile (lookup chain pair -> point -> slot -> neighbour -> latent row).
@@ -718,6 +704,7 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
             const float lo[4] = {cur.f0[0], cur.f0[1], cur.f0[2], cur.f0[3]}, hi[4] = {cur.f1[0], cur.f1[1], cur.f1[2], cur.f1[3]};
             store_quad_x3(X, row0, q40 * 8, lo);
             store_quad_x3(X, row0, q40 * 8 + 4, hi);
+            const float z[4] = {0.f, 0.f, 0.f, 0.f};
             if (q40 == 0) {
                 float d[4] = {cur.d[0], cur.d[1], cur.d[2], 0.f};
                 if (cur.idx >= 0) {
@@ -726,10 +713,10 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
                     pair_tmp[(size_t)q * PT_STRIDE] = expf(-(sc * sc));
                 }
                 store_quad_x3(X, row0, 32, d);
-                const float z[4] = {0.f, 0.f, 0.f, 0.f};
                 store_quad_x3(X, row0, 36, z);
-                store_quad_x3(X, row0, 40, z);
-                store_quad_x3(X, row0, 44, z);
+            } else {                                             // K = 35 is padded to two k32-steps: columns 40 .. 63 are zero
+                store_quad_x3(X, row0, 32 + 8 * q40, z);
+                store_quad_x3(X, row0, 36 + 8 * q40, z);
             }
         }
         const int qn = (tile + (int)gridDim.x) * 64 + row0;       // this thread's row in the workgroup's next tile
@@ -738,20 +725,23 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
         lds_barrier();
         T_MARK(1)
 
-        f32x16 acc[2][2];
+        f32x4 acc[4][4];
         uint32_t m1[2], m2[2], m3[2], m4[2];
-        float ssum[2] = {0.f, 0.f};
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f};
         // ---- forward: 35 -> 256 -> 256 -> 256 -> 256 ---------------------------------------------------------------------------
-        gx3 w_fw2 = frag + X3_FW2 + wave * (X3_TH * 2 * 3 * 64) + lane, w_fw3 = frag + X3_FW3 + wave * (X3_TH * 2 * 3 * 64) + lane;
-        gx3 w_fw4 = frag + X3_FW4 + wave * (X3_TH * 2 * 3 * 64) + lane, w_bw4 = frag + X3_BW4 + wave * (X3_TH * 2 * 3 * 64) + lane;
-        gx3 w_bw3 = frag + X3_BW3 + wave * (X3_TH * 2 * 3 * 64) + lane, w_bw2 = frag + X3_BW2 + wave * (X3_TH * 2 * 3 * 64) + lane;
-        Bias3 bias = load_bias3(pf + OFF_B1, wave, lane);
+        constexpr int WH = X3_TH * 4 * 3 * 64;                    // a wave's fragments of a hidden layer
+        gx3 w_fw2 = frag + X3_FW2 + wave * WH + lane, w_fw3 = frag + X3_FW3 + wave * WH + lane;
+        gx3 w_fw4 = frag + X3_FW4 + wave * WH + lane, w_bw4 = frag + X3_BW4 + wave * WH + lane;
+        gx3 w_bw3 = frag + X3_BW3 + wave * WH + lane, w_bw2 = frag + X3_BW2 + wave * WH + lane;
+        const int coff = 64 * wave + 4 * (lane >> 4);              // this lane's first feature of feature tile 0
+        BiasS bias, v5q;
+        WFragS nf;
         zero_acc(acc);
-        WFrag3 nf = gemm_x3<X3_T1>(X, w_fw1, lane, acc, fr1, w_fw2);
+        gemm_xs<X3_T1, true, 1>(X, w_fw1, lane, acc, fr1, nf, w_fw2, pf + OFF_B1 + coff, pf, bias, v5q);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m1, ssum);
+        fwd_epilogue_xs<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m1, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
@@ -759,43 +749,40 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
             n_srow = point_slot ? point_slot[n_p] : n_p;
             n_off = pair_off[n_p];
         }
-        bias = load_bias3(pf + OFF_B2, wave, lane);
         zero_acc(acc);
-        nf = gemm_x3<X3_TH>(X, w_fw2, lane, acc, nf, w_fw3);
+        gemm_xs<X3_TH, true, 1>(X, w_fw2, lane, acc, nf, nf, w_fw3, pf + OFF_B2 + coff, pf, bias, v5q);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m2, ssum);
+        fwd_epilogue_xs<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m2, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
-        bias = load_bias3(pf + OFF_B3, wave, lane);
         zero_acc(acc);
-        nf = gemm_x3<X3_TH>(X, w_fw3, lane, acc, nf, w_fw4);
+        gemm_xs<X3_TH, true, 1>(X, w_fw3, lane, acc, nf, nf, w_fw4, pf + OFF_B3 + coff, pf, bias, v5q);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m3, ssum);
+        fwd_epilogue_xs<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m3, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
         cur = gx_fetch_row(n_idx, n_srow, q40, x, pts, feat_geo);
-        bias = load_bias3(pf + OFF_B4, wave, lane);
-        const Bias3 v5q = load_bias3(pf + OFF_V5, wave, lane);       // folded last layer v = T W8, same quads: requested ahead of the GEMM too
-        zero_acc(acc);
-        nf = gemm_x3<X3_TH>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
+        zero_acc(acc);       // bias and the folded last layer v = T W8 (same quads) arrive with the last k-step
+        gemm_xs<X3_TH, WITH_JAC, 2>(X, w_fw4, lane, acc, nf, nf, w_bw4, pf + OFF_B4 + coff, pf + OFF_V5 + coff, bias, v5q);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
         // last forward layer: sdf_j = v . a4 + c from the accumulators; the planes receive the Jacobian seed v * lrelu'(h4)
-        fwd_epilogue_x3<1, WITH_JAC>(X, acc, bias, v5q, wave, lane, m4, ssum);
+        fwd_epilogue_xs<1, WITH_JAC>(X, acc, bias, v5q, wave, lane, m4, ssum);
         {
-            const int j = lane & 31, kg = lane >> 5;
+            const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const float t = ssum[n] + __shfl_xor(ssum[n], 32);
-                if (kg == 0) red[wave][32 * n + j] = t;
+            for (int b = 0; b < 4; ++b) {
+                float t = ssum[b] + __shfl_xor(ssum[b], 16);
+                t += __shfl_xor(t, 32);
+                if (g == 0) red[wave][16 * b + i] = t;
             }
         }
         T_MARK(6)
@@ -809,48 +796,51 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
         if (WITH_JAC) {
             // ---- Jacobian sweep: g_a3 = g_h4 W6 ; g_h3 = g_a3 * D3 ; ... ; J = g_h1 W0 ------------------------------------------
             zero_acc(acc);
-            nf = gemm_x3<X3_TH>(X, w_bw4, lane, acc, nf, w_bw3);
+            gemm_xs<X3_TH, true, 0>(X, w_bw4, lane, acc, nf, nf, w_bw3, pf, pf, bias, v5q);
             T_MARK(10)
             lds_barrier();
             T_MARK(11)
-            bwd_epilogue_x3(X, acc, wave, lane, m3);
+            bwd_epilogue_xs(X, acc, wave, lane, m3);
             T_MARK(12)
             lds_barrier();
             T_MARK(13)
             zero_acc(acc);
-            nf = gemm_x3<X3_TH>(X, w_bw3, lane, acc, nf, w_bw2);
+            gemm_xs<X3_TH, true, 0>(X, w_bw3, lane, acc, nf, nf, w_bw2, pf, pf, bias, v5q);
             T_MARK(10)
             lds_barrier();
             T_MARK(11)
-            bwd_epilogue_x3(X, acc, wave, lane, m2);
+            bwd_epilogue_xs(X, acc, wave, lane, m2);
             T_MARK(12)
             lds_barrier();
             T_MARK(13)
             zero_acc(acc);
-            gemm_x3<X3_TH>(X, w_bw2, lane, acc, nf, nullptr);
+            gemm_xs<X3_TH, false, 0>(X, w_bw2, lane, acc, nf, nf, w_bw2, pf, pf, bias, v5q);
             T_MARK(10)
-            gx3 w_jw1 = frag + X3_JW1 + (wave >> 1) * (X3_TH * 3 * 64) + lane;
-            const WFrag1 frj = load_wfrag1(w_jw1);
+            gx3 w_jw1 = frag + X3_JW1 + (wave >> 1) * (X3_TH * 2 * 3 * 64) + lane;
+            const WFragS2 frj = load_wfrags2(w_jw1);
             lds_barrier();
             T_MARK(11)
-            bwd_epilogue_x3(X, acc, wave, lane, m1);
+            bwd_epilogue_xs(X, acc, wave, lane, m1);
             T_MARK(12)
             lds_barrier();
             T_MARK(13)
-            // last step 256 -> 35 (padded 64): wave = (feature half m, row half n), one 32x32 tile each
+            // last step 256 -> 35 (padded 64): wave = (feature half m, row half n), 2 x 2 tiles each
             {
-                const int m = wave >> 1, n = wave & 1, j = lane & 31, kg = lane >> 5;
-                const f32x16 aj = gemm_x3_tile<X3_TH>(X, n, w_jw1, lane, frj);
-                const int q = tile * 64 + 32 * n + j;
-                if (q < NP) {
-                    if (m == 0) {
+                const int m = wave >> 1, n = wave & 1, i = lane & 15, g = lane >> 4;
+                f32x4 aj[2][2];
+                gemm_xs_tile<X3_TH>(X, n, w_jw1, lane, frj, aj);
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<f32x4*>(jac + (size_t)q * SPF_GEO_DIM + 8 * g + 4 * kg) = f32x4{aj[4 * g], aj[4 * g + 1], aj[4 * g + 2], aj[4 * g + 3]};
-                    } else if (kg == 0) {
-                        pair_tmp[(size_t)q * PT_STRIDE + 2] = aj[0];
-                        pair_tmp[(size_t)q * PT_STRIDE + 3] = aj[1];
-                        pair_tmp[(size_t)q * PT_STRIDE + 4] = aj[2];
+                for (int b = 0; b < 2; ++b) {
+                    const int q = tile * 64 + 32 * n + 16 * b + i;
+                    if (q < NP) {
+                        if (m == 0) {
+#pragma unroll
+                            for (int a = 0; a < 2; ++a) *reinterpret_cast<f32x4*>(jac + (size_t)q * SPF_GEO_DIM + 16 * a + 4 * g) = aj[a][b];
+                        } else if (g == 0) {
+                            pair_tmp[(size_t)q * PT_STRIDE + 2] = aj[0][b][0];
+                            pair_tmp[(size_t)q * PT_STRIDE + 3] = aj[0][b][1];
+                            pair_tmp[(size_t)q * PT_STRIDE + 4] = aj[0][b][2];
+                        }
                     }
                 }
             }

@@ -29,7 +29,8 @@ def report(entry, fn, names):
     torch.cuda.synchronize()
     f(buf, 1)
     # thread 0 of each workgroup counts cycles from its first mark to its last: cycles per launch per workgroup / launch time
-    print(entry, " ~%.2f GHz shader clock (cycle counter / wall time, %d workgroups assumed)" % (tot / 5 / 256 / (e0.elapsed_time(e1) / 5 * 1e6), 256))
+    print(entry, " ~%.2f GHz shader clock (cycle counter / wall time, %d workgroups assumed); %.0f k cycles per workgroup and launch, %.3f ms per launch"
+          % (tot / 5 / 256 / (e0.elapsed_time(e1) / 5 * 1e6), 256, tot / 5 / 256 / 1e3, e0.elapsed_time(e1) / 5))
     for i, n in names.items():
         print(f"  {n:34s} {100.0 * buf[i] / tot:6.2f} %")
 
