@@ -242,7 +242,7 @@ def main():
         pairs = sum(p["pairs"] for p in main)
         ach = pairs * (F_FWD + F_JAC) / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
-                "peak_basis": "algorithmic fp32 FLOP/s; each fp32 product = 6 exact bf16 piece products on v_mfma_f32_32x32x16_bf16, so the "
+                "peak_basis": "algorithmic fp32 FLOP/s; each fp32 product = 6 exact bf16 piece products on the bf16 matrix pipe (this kernel: v_mfma_f32_16x16x32_bf16), so the "
                               "ceiling is the dense bf16 MFMA peak (2516.6 TFLOP/s) / 6; for scale, the fp32-MFMA peak is 157.3 TFLOP/s",
                 "achieved_over_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                 "power_envelope_note": "peak is the 2.4 GHz data-sheet figure; the library's GEMM loop alone (tools/micro/x3_loop_rate.hip) holds 1.53 GHz "
