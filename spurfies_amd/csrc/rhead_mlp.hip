@@ -525,6 +525,33 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
     const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
     const int ntiles = (P + 63) / 64;
     const float* packed0 = packed;
+    T_DECL
+    // this thread's gather operands (row = tid >> 2, quarter = tid & 3: 64 agg3 floats; quarter 0 also the ray direction) are requested one
+    // tile ahead: the slot lookup before the second GEMM, the rows right after the last GEMM's weight requests (vector-memory results
+    // return in order: requested earlier, the GEMMs' weight fragments would wait behind these HBM rows; and a dependent lookup issued
+    // after them would wait for all sixteen), so they land under the last epilogue and the stores
+    f32x4 v[16];
+    float dnext[3] = {0.f, 0.f, 0.f};
+    int srow_next = -1, slot_pf = -1;
+    auto fetch_slot = [&](int t) {
+        const int p = t * 64 + (tid >> 2);
+        slot_pf = ((tid & 3) == 0 && t < ntiles && p < P) ? (point_slot ? point_slot[p] : p) : -1;
+    };
+    auto fetch_rows = [&](int t) {
+        const int row = tid >> 2, q4 = tid & 3;
+        const int p = t * 64 + row;
+        const bool ok = t < ntiles && p < P;
+        srow_next = slot_pf;
+        if (srow_next >= 0) {
+            const float* dv = ray_dirs + (size_t)(srow_next / SR) * 3;
+            dnext[0] = dv[0]; dnext[1] = dv[1]; dnext[2] = dv[2];
+        }
+        const f32x4* src = reinterpret_cast<const f32x4*>(agg3 + (size_t)(ok ? p : 0) * 256 + q4 * 64);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = ok ? src[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    fetch_slot((int)blockIdx.x);
+    fetch_rows((int)blockIdx.x);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gfp pf = launder(packed0);
@@ -533,25 +560,18 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
         gx3 w_fw1 = frag + RX_FW1 + wave * (RX_T1 * 2 * 3 * 64) + lane;
         gx3 w_fw2 = frag + RX_FW2 + wave * (RX_TH * 2 * 3 * 64) + lane;
         const WFrag3 fr6 = load_wfrag3(w_fw6);               // in flight during the gather
+        T_MARK(0)
         {   // gather: thread = (row, quarter): 64 agg3 floats each; quarter 0 also encodes the view direction (columns 256..287)
             const int row = tid >> 2, q4 = tid & 3;
-            const int p = tile * 64 + row;
-            const bool ok = p < P;
-            const f32x4* src = reinterpret_cast<const f32x4*>(agg3 + (size_t)(ok ? p : 0) * 256 + q4 * 64);
-            f32x4 v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = ok ? src[u] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 16; ++u) store_quad_x3<RX_LDP>(X, row, q4 * 64 + 4 * u, v[u]);
             if (q4 == 0) {
                 float e[32];
 #pragma unroll
                 for (int c = 0; c < 32; ++c) e[c] = 0.f;
-                int srow = -1;
-                if (ok) {
-                    srow = point_slot ? point_slot[p] : p;
-                    const float* dv = ray_dirs + (size_t)(srow / SR) * 3;
-                    const float d[3] = {dv[0], dv[1], dv[2]};
+                const int srow = srow_next;
+                if (srow >= 0) {
+                    const float d[3] = {dnext[0], dnext[1], dnext[2]};
                     e[0] = d[0]; e[1] = d[1]; e[2] = d[2];
                     float fr = 1.f;
 #pragma unroll
@@ -575,30 +595,46 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
                 s_row[row] = srow;
             }
         }
+        T_MARK(1)
         lds_barrier();
+        T_MARK(2)
         const size_t tb = (size_t)tile * 64 * 256;
         uint32_t* mk = STORE ? masks + (size_t)tile * 2 * 512 : nullptr;
         f32x16 acc[2][2];
         RxBias bias = rx_load_bias(pf + RO_B6, wave, lane);
         zero_acc(acc);
         WFrag3 nf = gemm_x3<RX_TH, false, RX_LDP>(X, w_fw6, lane, acc, fr6, w_fw1);          // F_color.6 on the weighted mean
+        T_MARK(3)
         lds_barrier();
+        T_MARK(2)
         rx_linear_epilogue(X, acc, &bias, wave, lane);       // agg -> columns 0..255 (the dir-enc columns stay)
+        T_MARK(4)
         lds_barrier();
+        T_MARK(2)
         if (STORE) store_tile_from_planes<32, RX_LDP>(X, agg + tb, 256, tid);              // kept for R.0's weight gradient
+        T_MARK(5)
         bias = rx_load_bias(pf + RO_B1, wave, lane);
+        fetch_slot(tile + (int)gridDim.x);
         zero_acc(acc);
         nf = gemm_x3<RX_T1, false, RX_LDP>(X, w_fw1, lane, acc, nf, w_fw2);
+        T_MARK(3)
         lds_barrier();
+        T_MARK(2)
         rx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, mk);
+        T_MARK(4)
         lds_barrier();
+        T_MARK(2)
         if (STORE) store_tile_from_planes<32, RX_LDP>(X, act1 + tb, 256, tid);
+        T_MARK(5)
         bias = rx_load_bias(pf + RO_B2, wave, lane);
         const RxBias w3q0 = rx_load_bias(pf + RO_W3, wave, lane), w3q1 = rx_load_bias(pf + RO_W3 + 256, wave, lane),
                      w3q2 = rx_load_bias(pf + RO_W3 + 512, wave, lane);      // the 3 x 256 last layer, this lane's quads: ahead of the GEMM
         zero_acc(acc);
         gemm_x3<RX_TH, false, RX_LDP>(X, w_fw2, lane, acc, nf, nullptr);
+        fetch_rows(tile + (int)gridDim.x);
+        T_MARK(3)
         lds_barrier();
+        T_MARK(2)
         {   // second activation (-> planes for the act2 store) and the 256 -> 3 layer from the registers: partial dot products per lane
             uint32_t bits[2] = {0u, 0u};
             float s[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
@@ -633,8 +669,11 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
                     if (kg == 0) red[(wave * 64 + 32 * n + j) * 4 + c] = t;
                 }
         }
+        T_MARK(4)
         lds_barrier();
+        T_MARK(2)
         if (STORE) store_tile_from_planes<32, RX_LDP>(X, act2 + tb, 256, tid);
+        T_MARK(5)
         if (tid < 64) {
             const int srow = s_row[tid];
             if (srow >= 0) {
@@ -645,8 +684,11 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
                 }
             }
         }
+        T_MARK(6)
         lds_barrier();
+        T_MARK(2)
     }
+    T_FLUSH
 }
 
 __global__ void __launch_bounds__(256, 1)
@@ -771,6 +813,8 @@ __global__ void rhead_pack_kernel(RPackArgs a, float* __restrict__ out) {
 }
 
 }  // namespace
+
+SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_rhead)
 
 extern "C" {
 

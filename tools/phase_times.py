@@ -46,3 +46,16 @@ report("spf_debug_timing_geo",
 report("spf_debug_timing_color", cb.bwd_only,
        {16: "G3 = wn g_agg3 * mask -> HBM + planes", 17: "sync", 18: "2 backward GEMMs", 19: "syncs", 20: "2 backward epilogues", 21: "syncs",
         22: "next-tile lookups", 25: "latent-gradient GEMM + L store", 26: "sync + duplicate sums", 23: "sync + atomics", 24: "sync"})
+
+# per-point head forward (training stores on), on the bench-sized point count
+_P = 55600
+_dev = cb.dev
+_agg3 = torch.randn((_P, 256), device="cuda") * 0.1
+_ws = [_dev[f"F_color.6.{w}"].clone().requires_grad_(True) for w in ("weight", "bias")] + \
+      [_dev[f"R.{i}.{w}"].clone().requires_grad_(True) for i in (0, 2, 4) for w in ("weight", "bias")]
+_dirs = torch.nn.functional.normalize(torch.randn((1024, 3), device="cuda"), dim=-1)
+_slot = torch.arange(_P, dtype=torch.int32, device="cuda")
+_n = torch.tensor([_P], dtype=torch.int32, device="cuda")
+report("spf_debug_timing_rhead", lambda: ops.RHead.apply(_agg3, *_ws, _dirs, _slot, _n, 80, 81920),
+       {0: "tile prologue", 1: "gather (agg3 rows, view encoding) -> planes", 2: "syncs", 3: "3 GEMMs", 4: "3 epilogues (+ 256 -> 3, sigmoid inputs)",
+        5: "3 store_tile_from_planes passes", 6: "colour reduction + store"})
