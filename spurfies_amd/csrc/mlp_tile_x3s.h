@@ -157,6 +157,9 @@ __device__ __forceinline__ void gemm_xs(const __bf16* X, gx3 wp, int lane, f32x4
     xs_step<1, false, HAS_NEXT, NB, LDP>(xp, wp, T - 1, acc, r, nxt, next_wp, cptr0, cptr1, c0, c1);
 }
 
+#undef SPF_XS_GROUP
+#undef SPF_XS_PIN
+
 // 32 weight rows x 32 rows of X per wave (2 x 2 tiles) over T k32-steps: the narrow last products (256 -> latent / input width).
 // wp: [T][2][3][64] fragments of the wave's weight rows, + lane; rows 32 n .. 32 n + 31 of X.
 struct WFragS2 {
