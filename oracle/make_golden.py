@@ -385,12 +385,14 @@ def golden_voxelize(name, seed=5, vox_res=60):
     print(name, "in", len(pts), "-> out", len(res["pts"]), "size", os.path.getsize(os.path.join(OUT, name)))
 
 
-def golden_trajectory(name, n_points, n_rays, steps, seed, local=False):
+def golden_trajectory(name, n_points, n_rays, steps, seed, local=False, cam_radius=2.2):
     """G10: `steps` consecutive reference optimisation steps (train.py:330-364: forward fast=1, VolSDFLoss, backward, clip_grad_norm_(1.0),
     Adam(lr 5e-4) in the reference's two param groups, CosineAnnealingLR(T_max 100 000, eta_min 3e-4)) on a fitted-prior scene, cycling
     the three views, with ONE CPU-generator stream across all steps (the sampler's draws of step i + 1 continue where step i stopped).
     Recorded: per-step inputs, losses, gradient norm, PSNR, beta; probes of every trainable parameter's total change."""
     scene = syn.make_scene(n_points, seed=seed, prior="fitted")
+    if cam_radius != 2.2:
+        scene["intrinsics"], scene["poses"] = syn.make_cameras(ring_radius=cam_radius)
     model, ref_mod = ref_shim.build_reference_model(scene)
     model.train()
     loss_fn = reference_loss()
@@ -431,7 +433,7 @@ def golden_trajectory(name, n_points, n_rays, steps, seed, local=False):
         rec["n_points"].append(int(out["grad_theta"].shape[0]))
         if i % 10 == 0:
             print(name, "step", i, "loss", loss_rec["loss"][-1], "psnr", rec["psnr"][-1], "|g|", rec["grad_norm"][-1], "%.1f s" % (time.time() - t0))
-    fx = {"meta.n_points": n_points, "meta.n_rays": n_rays, "meta.steps": steps, "meta.seed": seed, "meta.cam_radius": 2.2,
+    fx = {"meta.n_points": n_points, "meta.n_rays": n_rays, "meta.steps": steps, "meta.seed": seed, "meta.cam_radius": cam_radius,
           "meta.checksum": scene_checksum(scene), "meta.prior": np.asarray("fitted"), "meta.local": np.asarray(bool(local))}
     for k, v in rec.items():
         fx[f"step.{k}"] = np.asarray(v)
@@ -471,6 +473,8 @@ def main():
         golden_voxelize("voxelize.npz")
     if want("trajectory_ref.npz"):
         golden_trajectory("trajectory_ref.npz", n_points=3000, n_rays=96, steps=200, seed=9)
+    if want("trajectory_garden_ref.npz"):   # the +-2 grid (MipNeRF-360 garden), selected by scan name as pointneus_disent.py:45-53 does
+        golden_trajectory("trajectory_garden_ref.npz", n_points=20000, n_rays=64, steps=30, seed=4, cam_radius=4.0)
     if want("trajectory_local_ref.npz"):
         golden_trajectory("trajectory_local_ref.npz", n_points=3000, n_rays=96, steps=60, seed=11, local=True)
 

@@ -164,7 +164,7 @@ def test_three_optimisation_steps_track_the_oracle():
         np.testing.assert_allclose(a, b, rtol=0, atol=0.1 * moved + 1e-7, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["trajectory_ref.npz", "trajectory_local_ref.npz"])
+@pytest.mark.parametrize("name", ["trajectory_ref.npz", "trajectory_local_ref.npz", "trajectory_garden_ref.npz"])
 def test_multi_step_trajectory_tracks_the_reference(name):
     """G10: 200 consecutive optimisation steps of the REFERENCE itself (tests/golden/trajectory_ref.npz, generated by
     oracle/make_golden.py from the imported reference: forward fast=1, VolSDFLoss, backward, clip 1.0, Adam, cosine schedule, the three

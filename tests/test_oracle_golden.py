@@ -171,7 +171,7 @@ def test_eikonal_term_has_zero_gradient_for_trainables():
     assert gs[0] is None or float(gs[0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("name", ["trajectory_ref.npz", "trajectory_local_ref.npz"])
+@pytest.mark.parametrize("name", ["trajectory_ref.npz", "trajectory_local_ref.npz", "trajectory_garden_ref.npz"])
 def test_oracle_tracks_reference_trajectory(name):
     """G10 (tests/golden/trajectory_ref.npz: consecutive REFERENCE optimisation steps with one CPU-generator stream across them, Adam +
     clip + cosine schedule, train.py:330-364): the oracle, driven by its own optimiser restatement, stays on the reference's loss
