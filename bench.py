@@ -30,7 +30,7 @@ F_FWD = 2.0 * (35 * 256 + 3 * 256 * 256 + 256)      # F_geometry (4 layers; the 
 F_JAC = 2.0 * (3 * 256 * 256 + 256 * 35)            # input-Jacobian sweep, per pair
 PEAK_F32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2516.6                      # dense bf16 MFMA: 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz
-# The dominant kernel forms every fp32 product exactly from 6 bf16 piece products: its matrix-pipe ceiling in
+# The dominant kernel forms every fp32 product from 6 exact bf16 piece products (fp32-class accuracy): its matrix-pipe ceiling in
 # ALGORITHMIC (fp32) FLOP/s is the bf16 peak / 6.
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -62,6 +62,9 @@ def parse():
                     "step on MI355X: ~3 us of dependency handling per graph node; the eager launches run ahead of the GPU)")
     ap.add_argument("--no-graph", action="store_true", help="(default since the sync-free step became GPU-bound; kept for old command lines)")
     ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--geo-engine", choices=["auto", "split", "split_w"], default="auto", help="MFMA shape of the dominant kernel: 16x16x32 (split), 32x32x16 "
+                    "(split_w), or auto = time both on this box before the warm-up steps (TrainStep.autotune_geo_engine) and keep the faster")
+    ap.add_argument("--ab-reps", type=int, default=10, help="forward+backward passes per leg of the A B B A engine comparison after the timed region (0 = skip)")
     return ap.parse_args()
 
 
@@ -182,9 +185,17 @@ def main():
     # milliseconds (thread wake-ups); the reference pins one thread as well (train.py:24).  cpu_baseline sets its own thread counts.
     torch.set_num_threads(1)
     # --exact-draws: the same CPU-generator stream on every rank (each draws batch-wide and keeps its rays' rows); otherwise one stream per rank
+    # MFMA shape of the dominant kernel: chosen on THIS box, before the warm-up steps (untimed)
+    tune = None
+    if args.geo_engine == "auto":
+        tune = step.autotune_geo_engine(*batches[0][0])
+    else:
+        ops.set_geo_mode(args.geo_engine)
+    engine = ops.geo_mode()
     torch.manual_seed(1 if (args.exact_draws or world == 1) else 1 + rank)
     for i in range(args.warmup):
         run_step(i)
+    ops.geo_clock(reset=True)                     # in-kernel clock counters of the dominant kernel: zeroed before the timed region
     if not use_graph:
         ops.profile_start(tags=("geo",))          # HIP events around the dominant kernel's launches of the timed region
     sync()
@@ -194,6 +205,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     loss_last = float(losses["loss"].item())
+    clk = ops.geo_clock(reset=True).get((engine, True))       # the clock the chip held under the dominant kernel DURING the timed region
     if use_graph:
         # events cannot be placed inside a hipGraph replay: time the dominant kernel over eager forward+backward passes of
         # the SAME batches right after the timed region (same kernels, same inputs; no optimiser step)
@@ -228,32 +240,42 @@ def main():
     geo = [p for p in prof if p["tag"] == "geo"]
     main = [p for p in geo if p["with_grad"] and p["rows"] >= rays_local * 2]
     roof = None
-    traffic, traffic_src = None, None   # HBM bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process)
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    # HBM bytes per launch need a rocprofv3 --pmc pass around the process: they cannot be collected from inside this run.  The figure
+    # below is the committed collection of THIS code (tools/pmc_traffic.py) on the box it was profiled on — labelled as such.
+    traffic, traffic_src = None, None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if traffic is None and os.path.exists(pmc):
             rec = json.load(open(pmc))
             if rec["config"].get("points") == args.points and rec["config"].get("rays") == rays_local and rec["config"].get("prior", "kaiming") == args.prior:
-                hit = [v for k, v in rec["kernels"].items() if "geo_pairs_x3_kernel<true>" in k]
+                hit = [v for k, v in rec["kernels"].items() if "geo_pairs_x3_kernel<true>" in k or "geo_pairs_x3w_kernel<true>" in k]
                 if hit:
-                    traffic, traffic_src = hit[0]["hbm_bytes_max_corrected"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                    traffic = hit[0]["hbm_bytes_max_corrected"]
+                    traffic_src = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 corrections) of the same workload, "
+                                   "collected on ANOTHER box and committed — not measured in this run")
     if main:
         ms = sum(p["ms"] for p in main)
         pairs = sum(p["pairs"] for p in main)
         ach = pairs * (F_FWD + F_JAC) / (ms * 1e-3) / 1e12
+        kname = "geo_pairs_x3_kernel<true>" if engine == "split" else "geo_pairs_x3w_kernel<true>"
+        shape = "v_mfma_f32_16x16x32_bf16" if engine == "split" else "v_mfma_f32_32x32x16_bf16"
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
-                "peak_basis": "algorithmic fp32 FLOP/s; each fp32 product = 6 exact bf16 piece products on the bf16 matrix pipe (this kernel: v_mfma_f32_16x16x32_bf16), so the "
+                "peak_basis": f"algorithmic fp32 FLOP/s; each fp32 product = 6 exact bf16 piece products on the bf16 matrix pipe (this run: {shape}), so the "
                               "ceiling is the dense bf16 MFMA peak (2516.6 TFLOP/s) / 6; for scale, the fp32-MFMA peak is 157.3 TFLOP/s",
                 "achieved_over_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                 "power_envelope_note": "peak is the 2.4 GHz data-sheet figure; the library's GEMM loop alone (tools/micro/x3_loop_rate.hip) holds 1.53 GHz "
                                        "at 90 % matrix-pipe duty and 2.2 GHz at 66-76 %, i.e. 240-290 algorithmic TFLOP/s is what this instruction mix "
                                        "can draw (DESIGN.md section 6)",
-                "held_clock": held_clock(ach),
-                "traffic": traffic, "traffic_source": traffic_src, "kernel": "geo_pairs_x3_kernel<true> (+ geo_point_reduce_kernel, < 1 % of the launch)",
+                "held_clock": held_clock(ach, clk),
+                "engine": {"selected": engine, "mfma": shape, "how": ("timed both shapes on this box before the warm-up steps (main-pass launch, A B B A)" if tune else "--geo-engine"),
+                           "autotune_ms": tune},
+                "traffic": traffic, "traffic_source": traffic_src, "kernel": kname + " (+ geo_point_reduce_kernel, < 1 % of the launch)",
                 "timing": ("HIP events over eager passes of the timed batches, right after the timed region (events cannot sit inside a "
                            "hipGraph replay)") if use_graph else "HIP events over the timed region", "launches": len(main), "avg_ms": ms / len(main),
                 "pairs_per_launch": pairs / len(main), "flop_per_pair": F_FWD + F_JAC}
         roof["secondary"] = secondary_rooflines(prof, rays_local)
+        if args.ab_reps > 0 and args.scenes == 1:
+            roof["ab"] = engine_ab(step, batches[0], args.warmup, args.ab_reps, rays_local, sync)
     spr = SAMPLES_PER_RAY * rays_total * args.scenes
     counts = model.stats.get("counts")
     res = {
@@ -271,7 +293,7 @@ def main():
                    "host_syncs_per_step": 1 if args.sync else 0,
                    "sampler_draws": "CPU generator, reference call order" + ("" if world == 1 else ("; batch-wide per rank, own rows kept (--exact-draws)" if args.exact_draws
                                                                                                    else "; per-rank streams, own rays only")),
-                   "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product exactly from three bf16 pieces per operand (6 bf16 MFMAs, fp32 accumulate)",
+                   "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product from three bf16 pieces per operand (6 exact bf16 piece products, fp32 accumulate: fp32-class, <= 2 ulp per product)",
                    "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~80 per step: 52 library kernels + torch's small elementwise / copy / fill launches)")},
         "roofline": roof,
         "sustained_ms_per_step": sustained, "sustained_steps": args.sustained if sustained is not None else 0,
@@ -285,16 +307,57 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def held_clock(achieved_tflops):
-    """The shader clock the dominant kernel was MEASURED to hold inside the step (tools/kernel_clocks.py on a -DSPF_CLOCK build; the product
-    library carries no stamps, so this is read from the committed measurement) and the roofline fraction at that clock."""
-    path = os.path.join(ROOT, "profiles", "r02_kernel_clocks.json")
-    if not os.path.exists(path):
+def held_clock(achieved_tflops, clk):
+    """The shader clock the dominant kernel HELD inside the timed region, measured by the kernel itself (s_memtime / s_memrealtime stamps
+    of every workgroup, spf_geo_clock_read) in this run, and the roofline fraction at that clock."""
+    if not clk:
         return None
-    rec = json.load(open(path))
-    ghz = [v["ghz"] for k, v in rec["clocks_ghz"].items() if "geo_pairs" in k][0]
+    ghz = clk["ghz"]
     return {"ghz": ghz, "nominal_ghz": 2.4, "peak_at_held_clock": PEAK_SPLIT_TFLOPS * ghz / 2.4, "frac_at_held_clock": achieved_tflops / (PEAK_SPLIT_TFLOPS * ghz / 2.4),
-            "source": "profiles/r02_kernel_clocks.json (s_memtime / s_memrealtime stamps around the kernel, 6 s of back-to-back steps); `frac` above stays priced at 2.4 GHz"}
+            "workgroups": clk["workgroups"], "mean_us_per_workgroup": clk["mean_us_per_workgroup"],
+            "source": "measured in this run: in-kernel s_memtime / s_memrealtime stamps of every workgroup of the dominant kernel's launches in the timed region "
+                      "(spf_geo_clock_read); `frac` above stays priced at 2.4 GHz"}
+
+
+def engine_ab(step, batches, first, reps, rays_local, sync):
+    """Both MFMA shapes of the dominant kernel on the SAME batches in this process, after the timed regions: legs A B B A of `reps`
+    forward + backward passes each (no optimiser step: every leg sees the same parameters and pair counts), main-pass launch timed with HIP
+    events, clock read from the kernels' own counters."""
+    from spurfies_amd import ops
+
+    prev = ops.geo_mode()
+    acc = {"split": {"ms": 0.0, "pairs": 0.0, "n": 0, "cyc": 0.0, "ticks": 0.0}, "split_w": {"ms": 0.0, "pairs": 0.0, "n": 0, "cyc": 0.0, "ticks": 0.0}}
+    try:
+        for mode in ("split", "split_w", "split_w", "split"):
+            ops.set_geo_mode(mode)
+            step._forward_backward(dict(batches[first % len(batches)][0]), batches[first % len(batches)][1])
+            ops.geo_clock(reset=True)
+            ops.profile_start(tags=("geo",))
+            for i in range(reps):
+                b = batches[(first + i) % len(batches)]
+                step._forward_backward(dict(b[0]), b[1])
+            sync()
+            rows = [p for p in ops.profile_stop() if p["with_grad"] and p["rows"] >= 2 * rays_local]
+            c = ops.geo_clock(reset=True).get((mode, True))
+            a = acc[mode]
+            a["ms"] += sum(p["ms"] for p in rows)
+            a["pairs"] += sum(p["pairs"] for p in rows)
+            a["n"] += len(rows)
+            if c:
+                a["cyc"] += c["ghz"] * c["workgroups"] * c["mean_us_per_workgroup"]
+                a["ticks"] += c["workgroups"] * c["mean_us_per_workgroup"]
+    finally:
+        ops.set_geo_mode(prev)
+    out = {"order": "A B B A, %d forward+backward passes per leg on the timed batches, after the timed regions" % reps}
+    for mode, shape in (("split", "v_mfma_f32_16x16x32_bf16"), ("split_w", "v_mfma_f32_32x32x16_bf16")):
+        a = acc[mode]
+        if a["n"]:
+            ach = a["pairs"] * (F_FWD + F_JAC) / (a["ms"] * 1e-3) / 1e12
+            out[mode] = {"mfma": shape, "avg_ms": a["ms"] / a["n"], "pairs_per_launch": a["pairs"] / a["n"], "achieved": ach, "frac": ach / PEAK_SPLIT_TFLOPS,
+                         "held_ghz": (a["cyc"] / a["ticks"]) if a["ticks"] else None, "launches": a["n"]}
+    if "split" in out and "split_w" in out:
+        out["faster"] = min(("split", "split_w"), key=lambda m: out[m]["avg_ms"])
+    return out
 
 
 def secondary_rooflines(prof, rays_local):

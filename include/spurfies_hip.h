@@ -32,7 +32,7 @@ extern "C" {
 #define SPF_ENOMEM (-12)
 #define SPF_EHIP (-5)
 
-#define SPF_ABI_VERSION 2
+#define SPF_ABI_VERSION 3
 #define SPF_KMAX 8          /* neighbours per point (config/vol/dtu_pn.yaml:27, k: 8) */
 #define SPF_GEO_DIM 32      /* geometry latent width = feature_vector_size/2 (pointneus_disent.py:172) */
 #define SPF_COL_DIM 64      /* colour latent width  = feature_vector_size   (pointneus_disent.py:161) */
@@ -144,13 +144,18 @@ int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, 
 
 /* Arithmetic of the MLP / weight-gradient kernels, chosen PER CALL (`arith` argument; the library keeps no process-wide mode):
  *   SPF_ARITH_SPLIT  every fp32 operand is split into three bf16 pieces (x = p1 + p2 + p3 exactly to 24 bits) and the six piece
- *                    products with i + j <= 4 run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: each piece product is
- *                    exact and the dropped terms are below 2^-24 of the product, so the result differs from SPF_ARITH_F32 only
- *                    by summation order, at 2.7x the matrix rate.  What the product path uses.
+ *                    products with i + j <= 4 run on the bf16 matrix pipe with fp32 accumulation: each piece product is exact,
+ *                    the three dropped ones are below 2^-24 of the product each — fp32-CLASS accuracy (<= 2 ulp per product,
+ *                    tests/test_gpu_wgrad.py; results differ from SPF_ARITH_F32 by that and by summation order), at 2.7x the
+ *                    matrix rate.  What the product path uses.  The geometry kernel runs it on v_mfma_f32_16x16x32_bf16.
  *   SPF_ARITH_F32    v_mfma_f32_32x32x2_f32 (verification twin).
+ *   SPF_ARITH_SPLIT_W  spf_geo_forward only: SPF_ARITH_SPLIT's arithmetic on v_mfma_f32_32x32x16_bf16 tiles (same products, other
+ *                    summation order) — the second MFMA shape of the dominant kernel, kept so that a benchmark can time both shapes
+ *                    in one process on the box it runs on (bench.py: roofline.ab).
  * A backward must be called with the arith of its forward (the two keep LeakyReLU sign bits in different layouts). */
 #define SPF_ARITH_SPLIT 0
 #define SPF_ARITH_F32 1
+#define SPF_ARITH_SPLIT_W 2
 
 /* Number of floats of the packed F_geometry/T weight image. */
 
@@ -181,6 +186,13 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
                     int32_t max_points, int32_t max_pairs, int32_t k, const float* pts, const float* feat_geo,
                     const float* packed, float rbf, float* sdf, float* grad, float* wn, float* jac,
                     float* pair_tmp, int32_t arith, void* stream);
+
+/* Diagnostics (no reference counterpart; bench.py's `roofline.held_clock`): the shader clock the chip held while the bf16-piece
+ * geometry kernels ran since the last reset, measured by the kernels themselves (s_memtime / s_memrealtime stamps of every workgroup).
+ * out12 (HOST, 12 x uint64) = [mfma shape: 0 = 16x16x32 (SPF_ARITH_SPLIT), 1 = 32x32x16 (SPF_ARITH_SPLIT_W)][0 = without, 1 = with the
+ * Jacobian sweep][shader cycles, 100 MHz ticks, workgroups], summed over workgroups; clock [GHz] = 0.1 * cycles / ticks.  Synchronous
+ * (a device-to-host copy of the current device's counters); reset != 0 zeroes them afterwards. */
+int spf_geo_clock_read(uint64_t* out12, int32_t reset);
 
 /* Backward of the weighted mean w.r.t. the geometry latents:
  *   g_feat_geo[nbr(q), :] += g_sdf[row(q)] * wn[q] * jac[q,:]   (float atomics)
@@ -382,9 +394,13 @@ int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, c
  * with float atomics by default: the sum depends on the order the atomics land in (run-to-run
  * noise in the last bits).  With a non-NULL `*_fixed` argument (int64 [N, 64 | 32], zero before the first use) they instead add
  * every fp32 term as a 2^-48 fixed-point integer (64-bit integer atomics: associative, so order-independent; a term is exact when
- * its last mantissa bit is >= 2^-48, smaller ones round at 3.6e-15 absolute; |sum| < 2^14), and spf_fixed_accumulate rounds the sums
+ * its last mantissa bit is >= 2^-48, smaller ones round at 3.6e-15 absolute; |sum| < 2^13), and spf_fixed_accumulate rounds the sums
  * to fp32 once: dst[i] += acc[i] * 2^-48, acc[i] = 0.  This is the
- * deterministic alternative to sorting the pairs by neighbour (the reference's index_add_ is itself atomic and unordered). */
+ * deterministic alternative to sorting the pairs by neighbour (the reference's index_add_ is itself atomic and unordered).
+ * BUFFER CONTRACT (ABI 3): every `*_fixed` pointer addresses the accumulators of an allocation that holds ONE MORE int64 directly in
+ * front of them — the status word acc[-1], zero before the first use.  A non-finite term (NaN, Inf, |v| >= 2^14) adds nothing and sets
+ * the status word instead; spf_fixed_accumulate then writes NaN to ALL n destination entries (so the optimiser's non-finite guard skips
+ * the update, train.py:548-564, whatever the number and signs of the offending terms) and clears the word. */
 int spf_fixed_accumulate(int64_t* acc, float* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------

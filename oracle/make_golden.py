@@ -445,6 +445,171 @@ def golden_trajectory(name, n_points, n_rays, steps, seed, local=False, cam_radi
     print(name, "loss", loss_rec["loss"][0], "->", loss_rec["loss"][-1], "psnr", rec["psnr"][0], "->", rec["psnr"][-1], "size", os.path.getsize(os.path.join(OUT, name)))
 
 
+def golden_mesh_grid(name):
+    """SURVEY.md §8(f) N3, front half: the reference's evaluation grids, spurfies/utils/plots.py:288-333 (`get_grid_uniform`, `get_grid`
+    imported as they are; plots.py's plotting-only imports — torchvision, trimesh — are stubbed, its `.cuda()` calls land on the CPU).
+    Cases: shortest axis 0 / 1 / 2 from a point cloud (float32 min / max as torch.min gives them, eps 0.1 and 0.01), and the
+    `input_min` / `input_max` + eps = 0 form `get_surface_by_grid` uses (plots.py:190-196, grid_params * [[1.5], [1.0]])."""
+    ref_shim.enter_reference()
+    for m in ("torchvision", "trimesh"):
+        if m not in sys.modules:
+            sys.modules[m] = types.ModuleType(m)
+    import spurfies.utils.plots as ref_plots
+
+    fx = {}
+    rng = np.random.default_rng(17)
+    cases = []
+    for s_axis, res, eps in ((0, 24, 0.1), (1, 17, 0.1), (2, 20, 0.01)):
+        ext = np.asarray([1.3, 1.1, 0.9], np.float32)
+        ext[s_axis] = 0.6
+        pts = ((rng.random((500, 3), dtype=np.float32) - 0.5) * 2.0 * ext + np.asarray([0.05, -0.1, 0.2], np.float32)).astype(np.float32)
+        cases.append((f"cloud_axis{s_axis}", {"points": pts}, res, eps))
+    gp = (np.asarray([[-0.71, -0.52, -0.63], [0.74, 0.55, 0.61]], np.float64) * [[1.5], [1.0]])         # plots.py:190
+    cases.append(("minmax_eps0", {"input_min": gp[0].astype(np.float32), "input_max": gp[1].astype(np.float32)}, 30, 0.0))
+    for tag, kw, res, eps in cases:
+        if "points" in kw:
+            g = ref_plots.get_grid(torch.from_numpy(kw["points"]), res, eps=eps)
+            fx[f"{tag}.in.points"] = kw["points"]
+        else:       # get_surface_by_grid hands float32 torch tensors (plots.py:193-194); with this image's numpy 2 np.max() of the resulting
+            # tensor-valued linspace raises, so the same float32 values go in as numpy arrays (what `.numpy()` of those tensors holds)
+            g = ref_plots.get_grid(None, res, input_min=kw["input_min"], input_max=kw["input_max"], eps=eps)
+            fx[f"{tag}.in.input_min"], fx[f"{tag}.in.input_max"] = kw["input_min"], kw["input_max"]
+        fx[f"{tag}.in.resolution"], fx[f"{tag}.in.eps"] = np.int64(res), np.float64(eps)
+        fx[f"{tag}.out.grid_points"] = g["grid_points"].numpy()
+        for a, ax in zip("xyz", g["xyz"]):
+            fx[f"{tag}.out.{a}"] = np.asarray(ax)
+        fx[f"{tag}.out.shortest_axis_length"] = np.float64(g["shortest_axis_length"])
+        fx[f"{tag}.out.shortest_axis_index"] = np.int64(g["shortest_axis_index"])
+        print(name, tag, "axes", [len(ax) for ax in g["xyz"]], "shortest", int(g["shortest_axis_index"]))
+    g = ref_plots.get_grid_uniform(21, grid_boundary=[-1.25, 1.5])
+    fx["uniform.in.resolution"], fx["uniform.in.boundary"] = np.int64(21), np.asarray([-1.25, 1.5])
+    fx["uniform.out.grid_points"] = g["grid_points"].numpy()
+    fx["uniform.out.x"] = np.asarray(g["xyz"][0])
+    np.savez_compressed(os.path.join(OUT, name), **fx)
+    print(name, "size", os.path.getsize(os.path.join(OUT, name)))
+
+
+def golden_eval_dtu(name, seed=21):
+    """SURVEY.md §8(f) N3, back half: the reference's DTU evaluation, evals/eval_dtu.py, RUN as the script it is (runpy, `--mode pcd` and
+    `--mode mesh`) on synthetic inputs.  Only its file I/O is replaced: `open3d` (absent) by a module whose read_point_cloud /
+    read_triangle_mesh return the synthetic prediction / ground-truth cloud, `scipy.io.loadmat` by the synthetic observation mask (ObsMask,
+    BB, Res) and ground plane, `np.random.default_rng()` (the script shuffles with an UNSEEDED generator) by a seeded one, and
+    multiprocessing.Pool by an in-process map (the script's per-triangle sampler is the function that runs).  Everything numeric —
+    sklearn radius down-sampling, the in-bound / observation-mask / ground-plane filters, both nearest-neighbour passes, the truncation at
+    max_dist — is the reference's code.  The script loops over 11 scans with identical inputs here; the first row of `results` is kept."""
+    import runpy
+    import tempfile
+
+    import scipy.io
+
+    rng = np.random.default_rng(seed)
+
+    def sphere(n, r, noise):
+        d = rng.standard_normal((n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        return d * r + rng.normal(0, noise, size=(n, 3))
+
+    centre = np.asarray([10.0, -20.0, 600.0])
+    stl = sphere(30000, 50.0, 0.0) + centre                              # ground truth ("stl" points), millimetre scale like DTU
+    pred = sphere(24000, 50.6, 0.35) + centre                            # prediction: slightly inflated, noisy
+    pred = pred[pred[:, 0] < centre[0] + 35.0]                           # with a missing cap (completeness > accuracy)
+    pred = np.concatenate([pred, sphere(300, 95.0, 0.5) + centre], 0)    # and far outliers (outside the mask / beyond max_dist)
+    # icosphere-ish mesh for --mode mesh: a coarse triangulated octahedron subdivision of radius 50.4
+    v = np.asarray([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float64)
+    f = np.asarray([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]])
+    for _ in range(3):
+        mid = {}
+        nf = []
+        v = list(map(tuple, v))
+        for a, b, c in f:
+            ids = []
+            for i, j in ((a, b), (b, c), (c, a)):
+                key = (min(i, j), max(i, j))
+                if key not in mid:
+                    m = np.asarray(v[i]) + np.asarray(v[j])
+                    v.append(tuple(m / np.linalg.norm(m)))
+                    mid[key] = len(v) - 1
+                ids.append(mid[key])
+            nf += [[a, ids[0], ids[2]], [b, ids[1], ids[0]], [c, ids[2], ids[1]], ids]
+        v, f = np.asarray(v), np.asarray(nf)
+    mesh_v, mesh_f = v * 50.4 + centre, f
+    res_mm = 4.0
+    bb = np.stack([centre - 80.0, centre + 80.0]).astype(np.float32)
+    dims = np.ceil((bb[1] - bb[0]) / res_mm).astype(int) + 1
+    gi = np.stack(np.meshgrid(*[np.arange(d) for d in dims], indexing="ij"), -1)
+    cell = bb[0] + gi * res_mm
+    obs = (np.linalg.norm(cell - centre, axis=-1) < 70.0) & (cell[..., 2] > centre[2] - 40.0)       # observed region: a ball cut from below
+    plane = np.asarray([0.0, 0.0, 1.0, -(centre[2] - 30.0)])                                          # stl points above z = c_z - 30 count
+
+    class _Cloud:
+        def __init__(self, p):
+            self.points = p
+
+    class _Mesh:
+        vertices, triangles = mesh_v, mesh_f
+
+    o3d = types.ModuleType("open3d")
+    o3d.io = types.SimpleNamespace(read_point_cloud=lambda path: _Cloud(stl.copy() if "stl" in os.path.basename(path) else pred.copy()),
+                                   read_triangle_mesh=lambda path: _Mesh, write_point_cloud=lambda *a, **k: None)
+    o3d.geometry, o3d.utility = _AnythingNS(), _AnythingNS()
+
+    def loadmat(path):
+        return {"ObsMask": obs, "BB": bb, "Res": np.float64(res_mm)} if "ObsMask" in os.path.basename(path) and "Plane" not in os.path.basename(path) \
+            else {"P": plane.reshape(4, 1)}
+
+    class _Pool:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def map(self, fn, it, chunksize=1):
+            return [fn(x) for x in it]
+
+    fx = {"meta.seed": seed, "in.stl": stl.astype(np.float32), "in.pred": pred.astype(np.float32), "in.mesh_v": mesh_v, "in.mesh_f": mesh_f,
+          "in.obs_mask": obs, "in.bb": bb, "in.res": np.float64(res_mm), "in.plane": plane, "in.thresh": np.float64(0.8),
+          "in.patch": np.float64(60.0), "in.max_dist": np.float64(20.0), "in.shuffle_seed": np.int64(1234)}
+    # float32 copies are what the fixture stores: feed the script exactly those values
+    stl, pred = fx["in.stl"].astype(np.float64), fx["in.pred"].astype(np.float64)
+    import multiprocessing as mp
+
+    real = (sys.modules.get("open3d"), scipy.io.loadmat, np.random.default_rng, mp.Pool, sys.argv, os.getcwd())
+    try:
+        sys.modules["open3d"] = o3d
+        scipy.io.loadmat = loadmat
+        np.random.default_rng = lambda *a, **k: real[2](1234)
+        mp.Pool = _Pool
+        for mode in ("pcd", "mesh"):
+            with tempfile.TemporaryDirectory() as tmp:
+                os.chdir(tmp)
+                sys.argv = ["eval_dtu.py", "--mode", mode, "--downsample_density", "0.8"]
+                g = runpy.run_path(os.path.join(ref_shim.REFERENCE_ROOT, "evals", "eval_dtu.py"), run_name="__main__")
+                os.chdir(real[5])
+            row = np.asarray(g["results"], np.float64)     # after the loop `results` is the mean over the (identical) scans
+            fx[f"out.{mode}"] = row
+            fx[f"out.{mode}.n_down"] = np.int64(len(g["data_down"]))
+            fx[f"out.{mode}.n_in_obs"] = np.int64(len(g["data_in_obs"]))
+            fx[f"out.{mode}.n_stl_above"] = np.int64(len(g["stl_above"]))
+            if mode == "mesh":
+                fx["out.mesh.n_sampled"] = np.int64(len(g["data_pcd"]))
+            print(name, mode, "accuracy / completeness / overall", row, "down", len(g["data_down"]), "in obs", len(g["data_in_obs"]))
+    finally:
+        if real[0] is None:
+            sys.modules.pop("open3d", None)
+        else:
+            sys.modules["open3d"] = real[0]
+        scipy.io.loadmat, np.random.default_rng, mp.Pool, sys.argv = real[1], real[2], real[3], real[4]
+        os.chdir(real[5])
+    np.savez_compressed(os.path.join(OUT, name), **fx)
+    print(name, "size", os.path.getsize(os.path.join(OUT, name)))
+
+
+class _AnythingNS:
+    def __getattr__(self, k):
+        return lambda *a, **kw: None
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -475,6 +640,10 @@ def main():
         golden_trajectory("trajectory_ref.npz", n_points=3000, n_rays=96, steps=200, seed=9)
     if want("trajectory_garden_ref.npz"):   # the +-2 grid (MipNeRF-360 garden), selected by scan name as pointneus_disent.py:45-53 does
         golden_trajectory("trajectory_garden_ref.npz", n_points=20000, n_rays=64, steps=30, seed=4, cam_radius=4.0)
+    if want("mesh_grid.npz"):
+        golden_mesh_grid("mesh_grid.npz")
+    if want("eval_dtu.npz"):
+        golden_eval_dtu("eval_dtu.npz")
     if want("trajectory_local_ref.npz"):
         golden_trajectory("trajectory_local_ref.npz", n_points=3000, n_rays=96, steps=60, seed=11, local=True)
 

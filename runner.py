@@ -95,9 +95,11 @@ def optimise_scene(scene_name: str, flat: dict, args):
     vol_opt = VolOpt(args=args, batch_size=1, is_continue=bool(flat["is_continue"]), timestamp="latest", checkpoint="latest", scan=scene_name,
                      root=str(flat["root"]), scene=scene, neural_points={"pts": scene["state"]["neural_pts"], "colors": scene["colors"]},
                      prior_state_dict=prior, device="cuda", sync_free=bool(flat["sync_free"]), use_graph=bool(flat["use_graph"]),
-                     dataset=SyntheticDataset(scene, local=True) if bool(flat["local"]) else None)
-    if str(flat["prior"]) == "fitted":      # the fitted prior pairs with latents that carry the normals (synthetic.make_scene)
-        vol_opt.model.load_state_dict({"neural_feats_geometry": torch.from_numpy(scene["state"]["neural_feats_geometry"])}, strict=False)
+                     dataset=SyntheticDataset(scene, local=True) if bool(flat["local"]) else None,
+                     # the fitted prior pairs with latents that carry the normals (synthetic.make_scene): START values — VolOpt applies them
+                     # before it restores a checkpoint, so a resumed run (is_continue=true) keeps its trained latents
+                     init_state_dict=({"neural_feats_geometry": torch.from_numpy(scene["state"]["neural_feats_geometry"])}
+                                      if str(flat["prior"]) == "fitted" else None))
     vol_opt.gen_dataset(0)
     vol_opt.stg = 0
     steps = flat["opt_stepNs"]

@@ -53,6 +53,7 @@ SIGNATURES = {
     "spf_geo_pack": (C.c_int, [_P] * 14),
     "spf_build_pairs": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "spf_geo_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P]),
+    "spf_geo_clock_read": (C.c_int, [_P, _I]),
     "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "spf_color_packed_floats": (C.c_int64, []),
     "spf_color_pack": (C.c_int, [_P] * 8),

@@ -469,7 +469,7 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
 
 
 // ==============================================================================================================================
-// The same two kernels on the bf16 matrix pipe with fp32-EXACT products from three bf16 pieces per operand (the default;
+// The same two kernels on the bf16 matrix pipe with fp32-CLASS products (six exact bf16 piece products, <= 2 ulp per fp32 product) from three bf16 pieces per operand (the default;
 // arith = SPF_ARITH_F32 selects the fp32-MFMA kernels above).  Engine and arithmetic argument: mlp_tile_x3.h / geo_mlp.hip.
 //   * layers 0 and 2 run as transposed products (a lane owns 4 consecutive features of one row, the epilogue rewrites the bf16
 //     planes with 8-byte stores); layer 4 — whose output only feeds the RBF-weighted mean — runs non-transposed, so that a lane
@@ -810,8 +810,8 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                     if (p != cur) {
                         if (cur >= 0) {
                             if (agg3_fixed) {          // order-independent accumulation (common.h): up to four partial sums meet per entry
-                                fixed_add(&agg3_fixed[(size_t)cur * 256 + c0], a0);
-                                fixed_add(&agg3_fixed[(size_t)cur * 256 + c0 + 32], a1);
+                                fixed_add(agg3_fixed, (size_t)cur * 256 + c0, a0);
+                                fixed_add(agg3_fixed, (size_t)cur * 256 + c0 + 32, a1);
                             } else {
                                 SPF_AGG_ATOMIC(&agg3[(size_t)cur * 256 + c0], a0);
                                 SPF_AGG_ATOMIC(&agg3[(size_t)cur * 256 + c0 + 32], a1);
@@ -826,8 +826,8 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                 }
             if (cur >= 0) {
                 if (agg3_fixed) {
-                    fixed_add(&agg3_fixed[(size_t)cur * 256 + c0], a0);
-                    fixed_add(&agg3_fixed[(size_t)cur * 256 + c0 + 32], a1);
+                    fixed_add(agg3_fixed, (size_t)cur * 256 + c0, a0);
+                    fixed_add(agg3_fixed, (size_t)cur * 256 + c0 + 32, a1);
                 } else {
                     SPF_AGG_ATOMIC(&agg3[(size_t)cur * 256 + c0], a0);
                     SPF_AGG_ATOMIC(&agg3[(size_t)cur * 256 + c0 + 32], a1);
@@ -1031,7 +1031,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
             for (int rr = 0; rr < 16; ++rr) {
                 const int idx = __builtin_amdgcn_readfirstlane(lead[rr]);
                 if (idx >= 0) {
-                    if (g_fixed) fixed_add(g_fixed + (size_t)idx * SPF_COL_DIM + lane, val[rr]);      // order-independent (common.h)
+                    if (g_fixed) fixed_add(g_fixed, (size_t)idx * SPF_COL_DIM + lane, val[rr]);      // order-independent (common.h)
                     else atomicAdd(g_feat_col + (size_t)idx * SPF_COL_DIM + lane, val[rr]);
                 }
             }

@@ -435,7 +435,7 @@ geo_backward_latents_kernel(const float* __restrict__ g_sdf, const float* __rest
                 const int idx = s_lead[row];
                 if (idx >= 0) {
                     const float v = L[row * LDL + c];
-                    if (g_fixed) fixed_add(&g_fixed[(size_t)idx * SPF_GEO_DIM + c], v);       // order-independent (common.h)
+                    if (g_fixed) fixed_add(g_fixed, (size_t)idx * SPF_GEO_DIM + c, v);       // order-independent (common.h)
                     else atomicAdd(&g_feat[(size_t)idx * SPF_GEO_DIM + c], v);
                 }
             }
@@ -493,7 +493,7 @@ __global__ void geo_pack_kernel(PackArgs a, float* __restrict__ out) {
 
 
 // ==============================================================================================================================
-// Same path with fp32-EXACT products from three bf16 pieces per operand (the default; arith = SPF_ARITH_F32 selects the kernel above).
+// Same path with fp32-CLASS products (six exact bf16 piece products, <= 2 ulp per fp32 product) from three bf16 pieces per operand (the default; arith = SPF_ARITH_F32 selects the kernel above).
 //   x = p1 + p2 + p3, p1 = bf16(x), p2 = bf16(x - p1), p3 = bf16(x - p1 - p2): both differences are exact in fp32 and 3 x 8
 //   mantissa bits cover fp32's 24; a product of two fp32 numbers is sum_{i,j} a_i b_j, every piece product is exact in the
 //   MFMA's fp32 accumulation and the three with i + j >= 5 are below 2^-24 of the product, so the six with i + j <= 4 give the
@@ -523,7 +523,6 @@ constexpr int X3_BW3 = X3_BW4 + X3_SZH;
 constexpr int X3_BW2 = X3_BW3 + X3_SZH;
 constexpr int X3_JW1 = X3_BW2 + X3_SZH;
 constexpr int X3_FRAGS = X3_JW1 + X3_SZJ;
-constexpr int PACKED_TOTAL = PACKED_FLOATS + 4 * X3_FRAGS;     // the fp32 image, then the piece fragments (16 B each)
 
 // one thread per fragment slot (region, wave, k32, a, lane): 8 weights -> 3 x bf16x8.  lane = (i = lane & 15, g = lane >> 4):
 // feature 16 a + i, k = 32 t + 8 g .. + 7
@@ -641,6 +640,21 @@ __device__ __forceinline__ void bwd_epilogue_xs(__bf16* X, const f32x4 (&acc)[4]
 
 constexpr int X3_LDS_BF16 = 3 * X3_PLANE;
 
+// Held-clock counters of the bf16-piece kernels, ALWAYS compiled in (spf_geo_clock_read): thread 0 of every workgroup stamps the
+// shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) at kernel entry and exit and adds the two
+// differences to a per-(MFMA shape, with / without Jacobian sweep) triple {cycles, ticks, workgroups}: sum(cycles) / sum(ticks) x 100 MHz
+// is the shader clock the chip HELD while these kernels ran (DVFS give-back under MFMA-dense load, MI355X_MICROARCH.md) — measured in
+// the run that reports it, not read from a file.  Cost: two scalar-memory reads and three atomics per workgroup per launch
+// (256 workgroups x ~1.5 ms).
+__device__ unsigned long long spf_geo_clock_buf[2][2][3];
+#define CLK_DECL const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#define CLK_FLUSH(ENGINE, JAC)                                                                            \
+    if (threadIdx.x == 0) {                                                                               \
+        atomicAdd(&spf_geo_clock_buf[ENGINE][JAC][0], __builtin_amdgcn_s_memtime() - clk_c0);             \
+        atomicAdd(&spf_geo_clock_buf[ENGINE][JAC][1], __builtin_amdgcn_s_memrealtime() - clk_r0);         \
+        atomicAdd(&spf_geo_clock_buf[ENGINE][JAC][2], 1ull);                                              \
+    }
+
 // one pair row's gather operands: a quarter of the geometry latent, the offset x - p_i, the neighbour index
 struct GxRow {
     f32x4 f0, f1;
@@ -678,6 +692,7 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
     const int ntiles = (NP + 63) / 64;
     const float* packed0 = packed;
     T_DECL
+    CLK_DECL
     GxRow cur;
     {
         const int q = blockIdx.x * 64 + (tid >> 2);
@@ -850,6 +865,351 @@ geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr
         T_MARK(15)
     }
     T_FLUSH
+    CLK_FLUSH(0, WITH_JAC ? 1 : 0)
+}
+
+
+// ==============================================================================================================================
+// The same kernel on the 32 x 32 x 16 tile engine (mlp_tile_x3.h: 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 per wave) — the round-1
+// form of the dominant kernel, kept selectable per call (arith = SPF_ARITH_SPLIT_W) so that bench.py can time BOTH MFMA shapes on the
+// same batches in the same process on whatever box it runs on (roofline.ab): which shape holds the higher clock under load differs
+// from box to box by about as much as the difference between them.  Same arithmetic (six exact bf16 piece products per fp32 product),
+// own fragment image behind the 16 x 16 x 32 engine's inside the packed buffer.
+// ==============================================================================================================================
+constexpr int XW_T1 = 3;                          // first layer: K = 35 -> 48
+constexpr int XW_TH = 16;                         // 256 / 16
+constexpr int XW_SZ1 = 4 * XW_T1 * 2 * 3 * 64;    // bf16x8 entries
+constexpr int XW_SZH = 4 * XW_TH * 2 * 3 * 64;
+constexpr int XW_SZJ = 2 * XW_TH * 3 * 64;
+constexpr int XW_FW1 = 0;
+constexpr int XW_FW2 = XW_FW1 + XW_SZ1;
+constexpr int XW_FW3 = XW_FW2 + XW_SZH;
+constexpr int XW_FW4 = XW_FW3 + XW_SZH;
+constexpr int XW_BW4 = XW_FW4 + XW_SZH;
+constexpr int XW_BW3 = XW_BW4 + XW_SZH;
+constexpr int XW_BW2 = XW_BW3 + XW_SZH;
+constexpr int XW_JW1 = XW_BW2 + XW_SZH;
+constexpr int XW_FRAGS = XW_JW1 + XW_SZJ;
+constexpr int XW_BASE = PACKED_FLOATS + 4 * X3_FRAGS;          // float offset of this engine's fragments inside the packed image
+constexpr int PACKED_TOTAL = XW_BASE + 4 * XW_FRAGS;
+
+// one thread per fragment slot (region, wave, k16, m, lane): 8 weights -> 3 x bf16x8
+__global__ void geo_pack_x3w_kernel(PackArgs a, bf16x8* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int N1 = XW_SZ1 / 3, NH = XW_SZH / 3, NJ = XW_SZJ / 3;
+    if (s >= N1 + 6 * NH + NJ) return;
+    int region, local;
+    if (s < N1) { region = 0; local = s; }
+    else if (s < N1 + 6 * NH) { region = 1 + (s - N1) / NH; local = (s - N1) % NH; }
+    else { region = 7; local = s - N1 - 6 * NH; }
+    const int ln = local & 63, i = ln & 31, kg = ln >> 5;
+    float w[8];
+    size_t base;
+    if (region < 7) {
+        const int T = region == 0 ? XW_T1 : XW_TH;
+        const int m = (local >> 6) & 1, t = (local >> 7) % T, wv = (local >> 7) / T;
+        const int f = 64 * wv + 32 * m + i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * t + 8 * kg + e;
+            float v;
+            switch (region) {
+                case 0: v = k < K_IN ? a.w0[f * K_IN + k] : 0.f; break;
+                case 1: v = a.w2[f * 256 + k]; break;
+                case 2: v = a.w4[f * 256 + k]; break;
+                case 3: v = a.w6[f * 256 + k]; break;
+                case 4: v = a.w6[k * 256 + f]; break;      // g_a3[f] = sum_o g_h4[o] W6[o][f]
+                case 5: v = a.w4[k * 256 + f]; break;
+                default: v = a.w2[k * 256 + f]; break;
+            }
+            w[e] = v;
+        }
+        const int rb = region == 0 ? XW_FW1 : XW_FW2 + (region - 1) * XW_SZH;
+        base = (size_t)rb + (size_t)((wv * T + t) * 2 + m) * 3 * 64 + ln;
+    } else {
+        const int t = (local >> 6) % XW_TH, m = (local >> 6) / XW_TH;
+        const int f = 32 * m + i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * t + 8 * kg + e;
+            w[e] = f < K_IN ? a.w0[k * K_IN + f] : 0.f;  // J[f] = sum_o g_h1[o] W0[o][f]
+        }
+        base = (size_t)XW_JW1 + (size_t)(m * XW_TH + t) * 3 * 64 + ln;
+    }
+    bf16x8 p1, p2, p3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        __bf16 x, y, z;
+        split3(w[e], x, y, z);
+        p1[e] = x; p2[e] = y; p3[e] = z;
+    }
+    out[base] = p1;
+    out[base + 64] = p2;
+    out[base + 128] = p3;
+}
+
+// acc[m][n][4g + e] = feature 64w + 32m + 8g + 4kg + e of row 32n + j.  mask[m]: bit n * 16 + 4g + e.
+// MODE 0: a = lrelu(acc + b) -> planes.   MODE 1 (last forward layer): also sdf partial sums s[n] += v5 . a, and the planes get
+// the Jacobian seed v5 * lrelu'(h) instead of a (a itself is not needed any more).
+// this lane's bias values of a layer (features 64 wave + 32 m + 8 g + 4 kg ..+3), requested ahead of the layer's GEMM
+struct Bias3 {
+    f32x4 b[2][4];
+};
+__device__ __forceinline__ Bias3 load_bias3(gfp bias, int wave, int lane) {
+    Bias3 r;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            r.b[m][g] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(bias + 64 * wave + 32 * m + 8 * g + 4 * (lane >> 5));
+    return r;
+}
+
+// forward epilogue: a = lrelu(acc + b) -> planes; sign bits pushed into mask[n] in the order (m, g, e) (32 per word).
+// MODE 1 (last layer): sdf partial sums s[n] += v . a, and the planes receive the Jacobian seed v * lrelu'(h) instead.
+template <int MODE, bool WITH_JAC>
+__device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], const Bias3& bias, const Bias3& v5, int wave, int lane,
+                                                uint32_t (&mask)[2], float (&s)[2]) {
+    const int j = lane & 31, kg = lane >> 5;
+    mask[0] = mask[1] = 0u;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+            const f32x4 bv = bias.b[m][g];
+            f32x4 vv = f32x4{0.f, 0.f, 0.f, 0.f}, vs = vv;
+            if (MODE == 1) {
+                vv = v5.b[m][g];
+                vs = vv * 0.01f;
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x4 h, hs;
+                bias_scale4(acc[m][n], g, bv, h, hs);
+                f32x4 out;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (MODE == 1) {
+                        float seed;
+                        const float a = lrelu_push_sel(h[e], hs[e], vv[e], vs[e], seed, mask[n]);
+                        s[n] += vv[e] * a;
+                        out[e] = seed;
+                    } else {
+                        out[e] = lrelu_push(h[e], hs[e], mask[n]);
+                    }
+                }
+                if (MODE == 0 || WITH_JAC) store_quad_x3(X, 32 * n + j, f0, out);
+            }
+        }
+}
+
+// backward epilogue: g_h = g_a * lrelu'(h) -> planes (pops the words the forward epilogue filled, in the same order)
+__device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mask_in)[2]) {
+    const int j = lane & 31, kg = lane >> 5;
+    uint32_t mask[2] = {mask_in[0], mask_in[1]};
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x4 v, vs;
+                scale4(acc[m][n], g, v, vs);
+                f32x4 out;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], mask[n]);
+                store_quad_x3(X, 32 * n + j, f0, out);
+            }
+        }
+}
+
+
+template <bool WITH_JAC>
+__global__ void __launch_bounds__(256, 1)
+geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
+                    const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
+                    int max_pairs, int k, const float* __restrict__ pts, const float* __restrict__ feat_geo, const float* packed,
+                    float rbf, float* __restrict__ pair_tmp, float* __restrict__ jac) {
+    __shared__ __attribute__((aligned(16))) __bf16 X[X3_LDS_BF16];
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
+    const int ntiles = (NP + 63) / 64;
+    const float* packed0 = packed;
+    T_DECL
+    CLK_DECL
+    GxRow cur;
+    {
+        const int q = blockIdx.x * 64 + (tid >> 2);
+        int srow = 0, idx = -1;
+        if (q < NP) {
+            const int p = pair_point[q];
+            srow = point_slot ? point_slot[p] : p;
+            idx = nbr[(size_t)srow * k + (q - pair_off[p])];
+        }
+        cur = gx_fetch_row(idx, srow, tid & 3, x, pts, feat_geo);
+    }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gfp pf = launder(packed0);
+        gx3 frag = reinterpret_cast<gx3>(pf + XW_BASE);
+        gx3 w_fw1 = frag + XW_FW1 + wave * (XW_T1 * 2 * 3 * 64) + lane;
+        const WFrag3 fr1 = load_wfrag3(w_fw1);                  // in flight during the gather
+        T_MARK(31)
+        // ---- gather: thread = (row, quarter of the 32-d latent); pieces straight into the planes.  The operands were requested
+        //      during the previous tile (lookup chain pair -> point -> slot -> neighbour -> latent row).
+        const int row0 = tid >> 2, q40 = tid & 3;
+        {
+            const int q = tile * 64 + row0;
+            const float lo[4] = {cur.f0[0], cur.f0[1], cur.f0[2], cur.f0[3]}, hi[4] = {cur.f1[0], cur.f1[1], cur.f1[2], cur.f1[3]};
+            store_quad_x3(X, row0, q40 * 8, lo);
+            store_quad_x3(X, row0, q40 * 8 + 4, hi);
+            if (q40 == 0) {
+                float d[4] = {cur.d[0], cur.d[1], cur.d[2], 0.f};
+                if (cur.idx >= 0) {
+                    const float dist = fmaxf(sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]), 1e-12f);
+                    const float sc = dist * rbf;
+                    pair_tmp[(size_t)q * PT_STRIDE] = expf(-(sc * sc));
+                }
+                store_quad_x3(X, row0, 32, d);
+                const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                store_quad_x3(X, row0, 36, z);
+                store_quad_x3(X, row0, 40, z);
+                store_quad_x3(X, row0, 44, z);
+            }
+        }
+        const int qn = (tile + (int)gridDim.x) * 64 + row0;       // this thread's row in the workgroup's next tile
+        int n_p = qn < NP ? pair_point[qn] : -1, n_srow = 0, n_off = 0, n_idx = -1;
+        T_MARK(0)
+        lds_barrier();
+        T_MARK(1)
+
+        f32x16 acc[2][2];
+        uint32_t m1[2], m2[2], m3[2], m4[2];
+        float ssum[2] = {0.f, 0.f};
+        // ---- forward: 35 -> 256 -> 256 -> 256 -> 256 ---------------------------------------------------------------------------
+        gx3 w_fw2 = frag + XW_FW2 + wave * (XW_TH * 2 * 3 * 64) + lane, w_fw3 = frag + XW_FW3 + wave * (XW_TH * 2 * 3 * 64) + lane;
+        gx3 w_fw4 = frag + XW_FW4 + wave * (XW_TH * 2 * 3 * 64) + lane, w_bw4 = frag + XW_BW4 + wave * (XW_TH * 2 * 3 * 64) + lane;
+        gx3 w_bw3 = frag + XW_BW3 + wave * (XW_TH * 2 * 3 * 64) + lane, w_bw2 = frag + XW_BW2 + wave * (XW_TH * 2 * 3 * 64) + lane;
+        Bias3 bias = load_bias3(pf + OFF_B1, wave, lane);
+        zero_acc(acc);
+        WFrag3 nf = gemm_x3<XW_T1>(X, w_fw1, lane, acc, fr1, w_fw2);
+        T_MARK(2)
+        lds_barrier();
+        T_MARK(3)
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m1, ssum);
+        T_MARK(4)
+        lds_barrier();
+        T_MARK(5)
+        if (n_p >= 0) {
+            n_srow = point_slot ? point_slot[n_p] : n_p;
+            n_off = pair_off[n_p];
+        }
+        bias = load_bias3(pf + OFF_B2, wave, lane);
+        zero_acc(acc);
+        nf = gemm_x3<XW_TH>(X, w_fw2, lane, acc, nf, w_fw3);
+        T_MARK(2)
+        lds_barrier();
+        T_MARK(3)
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m2, ssum);
+        T_MARK(4)
+        lds_barrier();
+        T_MARK(5)
+        if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
+        bias = load_bias3(pf + OFF_B3, wave, lane);
+        zero_acc(acc);
+        nf = gemm_x3<XW_TH>(X, w_fw3, lane, acc, nf, w_fw4);
+        T_MARK(2)
+        lds_barrier();
+        T_MARK(3)
+        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m3, ssum);
+        T_MARK(4)
+        lds_barrier();
+        T_MARK(5)
+        cur = gx_fetch_row(n_idx, n_srow, q40, x, pts, feat_geo);
+        bias = load_bias3(pf + OFF_B4, wave, lane);
+        const Bias3 v5q = load_bias3(pf + OFF_V5, wave, lane);       // folded last layer v = T W8, same quads: requested ahead of the GEMM too
+        zero_acc(acc);
+        nf = gemm_x3<XW_TH>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
+        T_MARK(2)
+        lds_barrier();
+        T_MARK(3)
+        // last forward layer: sdf_j = v . a4 + c from the accumulators; the planes receive the Jacobian seed v * lrelu'(h4)
+        fwd_epilogue_x3<1, WITH_JAC>(X, acc, bias, v5q, wave, lane, m4, ssum);
+        {
+            const int j = lane & 31, kg = lane >> 5;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float t = ssum[n] + __shfl_xor(ssum[n], 32);
+                if (kg == 0) red[wave][32 * n + j] = t;
+            }
+        }
+        T_MARK(6)
+        lds_barrier();
+        T_MARK(7)
+        if (tid < 64) {
+            const int q = tile * 64 + tid;
+            if (q < NP) pair_tmp[(size_t)q * PT_STRIDE + 1] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + pf[OFF_C];
+        }
+
+        if (WITH_JAC) {
+            // ---- Jacobian sweep: g_a3 = g_h4 W6 ; g_h3 = g_a3 * D3 ; ... ; J = g_h1 W0 ------------------------------------------
+            zero_acc(acc);
+            nf = gemm_x3<XW_TH>(X, w_bw4, lane, acc, nf, w_bw3);
+            T_MARK(10)
+            lds_barrier();
+            T_MARK(11)
+            bwd_epilogue_x3(X, acc, wave, lane, m3);
+            T_MARK(12)
+            lds_barrier();
+            T_MARK(13)
+            zero_acc(acc);
+            nf = gemm_x3<XW_TH>(X, w_bw3, lane, acc, nf, w_bw2);
+            T_MARK(10)
+            lds_barrier();
+            T_MARK(11)
+            bwd_epilogue_x3(X, acc, wave, lane, m2);
+            T_MARK(12)
+            lds_barrier();
+            T_MARK(13)
+            zero_acc(acc);
+            gemm_x3<XW_TH>(X, w_bw2, lane, acc, nf, nullptr);
+            T_MARK(10)
+            gx3 w_jw1 = frag + XW_JW1 + (wave >> 1) * (XW_TH * 3 * 64) + lane;
+            const WFrag1 frj = load_wfrag1(w_jw1);
+            lds_barrier();
+            T_MARK(11)
+            bwd_epilogue_x3(X, acc, wave, lane, m1);
+            T_MARK(12)
+            lds_barrier();
+            T_MARK(13)
+            // last step 256 -> 35 (padded 64): wave = (feature half m, row half n), one 32x32 tile each
+            {
+                const int m = wave >> 1, n = wave & 1, j = lane & 31, kg = lane >> 5;
+                const f32x16 aj = gemm_x3_tile<XW_TH>(X, n, w_jw1, lane, frj);
+                const int q = tile * 64 + 32 * n + j;
+                if (q < NP) {
+                    if (m == 0) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<f32x4*>(jac + (size_t)q * SPF_GEO_DIM + 8 * g + 4 * kg) = f32x4{aj[4 * g], aj[4 * g + 1], aj[4 * g + 2], aj[4 * g + 3]};
+                    } else if (kg == 0) {
+                        pair_tmp[(size_t)q * PT_STRIDE + 2] = aj[0];
+                        pair_tmp[(size_t)q * PT_STRIDE + 3] = aj[1];
+                        pair_tmp[(size_t)q * PT_STRIDE + 4] = aj[2];
+                    }
+                }
+            }
+        }
+        T_MARK(14)
+        lds_barrier();  // the planes are rewritten by the next tile's gather
+        T_MARK(15)
+    }
+    T_FLUSH
+    CLK_FLUSH(1, WITH_JAC ? 1 : 0)
 }
 
 }  // namespace
@@ -860,6 +1220,19 @@ extern "C" {
 
 int64_t spf_geo_packed_floats(void) { return PACKED_TOTAL; }
 
+int spf_geo_clock_read(uint64_t* out12, int32_t reset) {
+    if (!out12) return spf::fail(SPF_EINVAL, "spf_geo_clock_read: null pointer");
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(spf_geo_clock_buf), 12 * sizeof(uint64_t)) != hipSuccess)
+        return spf::fail(SPF_EHIP, "spf_geo_clock_read: hipMemcpyFromSymbol failed");
+    if (reset) {
+        const uint64_t z[12] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(spf_geo_clock_buf), z, sizeof(z)) != hipSuccess)
+            return spf::fail(SPF_EHIP, "spf_geo_clock_read: hipMemcpyToSymbol failed");
+    }
+    return SPF_OK;
+}
+
 int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
                  const float* w6, const float* b6, const float* w8, const float* b8, const float* wT, const float* bT,
                  float* packed, void* stream) {
@@ -868,6 +1241,7 @@ int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float*
     PackArgs a{w0, b0, w2, b2, w4, b4, w6, b6, w8, b8, wT, bT};
     geo_pack_kernel<<<spf::div_up(PACKED_FLOATS, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
     geo_pack_x3_kernel<<<spf::div_up(X3_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + PACKED_FLOATS));
+    geo_pack_x3w_kernel<<<spf::div_up(XW_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + XW_BASE));
     SPF_LAUNCH_CHECK("geo_pack_kernel");
     return SPF_OK;
 }
@@ -876,7 +1250,8 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
                     const int32_t* n_points, const int32_t* n_pairs, int32_t max_points, int32_t max_pairs, int32_t k, const float* pts,
                     const float* feat_geo, const float* packed, float rbf, float* sdf, float* grad, float* wn, float* jac,
                     float* pair_tmp, int32_t arith, void* stream) {
-    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_geo_forward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32 && arith != SPF_ARITH_SPLIT_W)
+        return spf::fail(SPF_EINVAL, "spf_geo_forward: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_SPLIT_W (2), got %d", arith);
     if (max_points < 0 || max_pairs < 0 || k < 1 || k > SPF_KMAX)
         return spf::fail(SPF_EINVAL, "spf_geo_forward: bad sizes (max_points=%d max_pairs=%d k=%d)", max_points, max_pairs, k);
     if (max_points == 0 || max_pairs == 0) return SPF_OK;
@@ -895,6 +1270,14 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
         else
             geo_pairs_x3_kernel<false><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
                                                           rbf, pair_tmp, nullptr);
+    } else if (arith == SPF_ARITH_SPLIT_W) {
+        const int b1 = tiles < 256 ? tiles : 256;
+        if (grad)
+            geo_pairs_x3w_kernel<true><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
+                                                          pair_tmp, jac);
+        else
+            geo_pairs_x3w_kernel<false><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
+                                                           rbf, pair_tmp, nullptr);
     } else if (grad)
         geo_pairs_kernel<true><<<blocks, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
                                                       pair_tmp, jac);

@@ -64,19 +64,24 @@ __global__ void tv_backward_kernel(const float* __restrict__ feat, const int32_t
         const float d = feat[(size_t)q * 32 + c] - fi;
         const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);   // d|d|/dd, 0 at 0 like torch.abs
         const float g = s * wj * sg;
-        if (g_fixed) fixed_add(&g_fixed[(size_t)q * 32 + c], g);
+        if (g_fixed) fixed_add(g_fixed, (size_t)q * 32 + c, g);
         else atomicAdd(&g_feat[(size_t)q * 32 + c], g);
         own -= g;
     }
-    if (g_fixed) fixed_add(&g_fixed[(size_t)i * 32 + c], own);
+    if (g_fixed) fixed_add(g_fixed, (size_t)i * 32 + c, own);
     else atomicAdd(&g_feat[(size_t)i * 32 + c], own);
 }
 
-// dst[i] += acc[i] * 2^-48 (the exact sum, rounded to fp32 once); acc[i] = 0 for the next use
+// dst[i] += acc[i] * 2^-48 (the exact sum, rounded to fp32 once); acc[i] = 0 for the next use.  A set status word (acc[-1]: some term
+// was non-finite, common.h) turns every dst[i] into NaN; the host side clears the word behind this kernel.
 __global__ void fixed_accumulate_kernel(long long* __restrict__ acc, float* __restrict__ dst, long long n) {
+    const bool poisoned = acc[-1] != 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long a = acc[i];
-        if (a != 0) {
+        if (poisoned) {
+            dst[i] = __builtin_nanf("");
+            acc[i] = 0;
+        } else if (a != 0) {
             const double d = (double)a;
             dst[i] += (fabs(d) >= 0.5 * FIXED_LIMIT) ? __builtin_nanf("") : (float)(d / FIXED_SCALE);
             acc[i] = 0;
@@ -132,6 +137,7 @@ int spf_fixed_accumulate(int64_t* acc, float* dst, int64_t n, void* stream) {
     if (blocks > 4096) blocks = 4096;
     fixed_accumulate_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<long long*>(acc), dst, (long long)n);
     SPF_LAUNCH_CHECK("fixed_accumulate_kernel");
+    SPF_HIP_CHECK(hipMemsetAsync(acc - 1, 0, sizeof(int64_t), (hipStream_t)stream));      // status word: clear for the next use
     return SPF_OK;
 }
 

@@ -1,4 +1,4 @@
-// Device helpers of the bf16-piece ("x3") tile engine shared by the geometry and colour kernels: fp32-exact products from three
+// Device helpers of the bf16-piece ("x3") tile engine shared by the geometry and colour kernels: fp32-class products (<= 2 ulp per product) from three
 // bf16 pieces per operand on v_mfma_f32_32x32x16_bf16 (see geo_mlp.hip for the arithmetic argument).
 // Activations live in LDS as three bf16 planes [piece][row][k] (row stride X3_LDP); weights stream from L2 as piece fragments
 // [wave][k16][m][piece][lane] x 8 bf16.  Transposed product D[feature][row] += W[feature][k] X[k][row].

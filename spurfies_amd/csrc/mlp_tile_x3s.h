@@ -1,5 +1,5 @@
 // The bf16-piece ("x3") tile engine on v_mfma_f32_16x16x32_bf16 — same arithmetic as mlp_tile_x3.h (three bf16 pieces per operand, the
-// six piece products with i + j <= 4, fp32 accumulate: fp32-exact products), same operand traffic, same 64 features x 64 rows per
+// six piece products with i + j <= 4, fp32 accumulate: fp32-class products (<= 2 ulp per product)), same operand traffic, same 64 features x 64 rows per
 // wave, but 4 x 4 tiles of 16 x 16 with K = 32 per instruction instead of 2 x 2 tiles of 32 x 32 with K = 16.
 // Why: under a dense matrix load the chip lowers its clock, and the clock it holds depends on the MFMA shape.  Measured with this
 // loop's operand traffic on random data (tools/micro/mfma_shape_rate.hip, one 4-wave workgroup per CU, layers of 256 -> 256):

@@ -109,14 +109,39 @@ class PairList:
 
 
 # Arithmetic of the MLP / weight-gradient kernels (include/spurfies_hip.h: SPF_ARITH_*), chosen per call; this table is host-side
-# state of the Python layer only — the C ABI itself keeps none.  'split' (default): fp32-exact products from three bf16 pieces per
+# state of the Python layer only — the C ABI itself keeps none.  'split' (default): fp32-class products (<= 2 ulp per product) from three bf16 pieces per
 # operand on the bf16 matrix pipe; 'f32': fp32 MFMA (the verification twin).
 _ARITH = {"geo": 0, "color": 0, "rhead": 0, "wgrad": 0}
 _ARITH_NAMES = {"split": 0, "f32": 1}
+_GEO_ARITH_NAMES = {"split": 0, "f32": 1, "split_w": 2}     # 'split_w': the split arithmetic on 32x32x16 MFMA tiles (SPF_ARITH_SPLIT_W)
 
 
 def set_geo_mode(mode: str):
-    _ARITH["geo"] = _ARITH_NAMES[mode]
+    """'split' (default: bf16-piece products on v_mfma_f32_16x16x32_bf16), 'split_w' (the same products on v_mfma_f32_32x32x16_bf16
+    tiles — bench.py times both on the box it runs on) or 'f32' (fp32 MFMA, verification twin)."""
+    _ARITH["geo"] = _GEO_ARITH_NAMES[mode]
+
+
+def geo_clock(reset=True):
+    """Shader clock the bf16-piece geometry kernels HELD since the last reset, measured by the kernels themselves
+    (include/spurfies_hip.h: spf_geo_clock_read; synchronises the device) ->
+    {('split' | 'split_w', with_jacobian): {'ghz', 'workgroups', 'mean_us_per_workgroup'}} for the combinations that ran."""
+    import ctypes
+
+    torch.cuda.synchronize()
+    buf = (ctypes.c_uint64 * 12)()
+    _lib.check(_lib.lib().spf_geo_clock_read(ctypes.cast(buf, ctypes.c_void_p), 1 if reset else 0), "spf_geo_clock_read")
+    out = {}
+    for e, name in enumerate(("split", "split_w")):
+        for j in (0, 1):
+            cyc, ticks, wgs = (int(buf[(e * 2 + j) * 3 + i]) for i in range(3))
+            if wgs:
+                out[(name, bool(j))] = {"ghz": 0.1 * cyc / max(ticks, 1), "workgroups": wgs, "mean_us_per_workgroup": ticks / wgs / 100.0}
+    return out
+
+
+def geo_mode() -> str:
+    return {v: k for k, v in _GEO_ARITH_NAMES.items()}[_ARITH["geo"]]
 
 
 def pack_geometry_weights(state: dict) -> torch.Tensor:
@@ -174,7 +199,8 @@ def _fixed_acc(like):
     leaves it zero again)."""
     key = (like.device.index, tuple(like.shape), torch.cuda.current_stream(like.device).cuda_stream)
     if key not in _fixed_bufs:
-        _fixed_bufs[key] = torch.zeros(like.shape, dtype=torch.int64, device=like.device)
+        # one int64 more IN FRONT of the accumulators: the buffer's status word (acc[-1], include/spurfies_hip.h: buffer contract)
+        _fixed_bufs[key] = torch.zeros((like.numel() + 1,), dtype=torch.int64, device=like.device)[1:].view(like.shape)
     return _fixed_bufs[key]
 
 

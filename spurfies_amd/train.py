@@ -35,6 +35,7 @@ class TrainStep:
         self.sync_free = sync_free
         self.use_graph = use_graph
         self._graph = None
+        self._warned_graph_local = False
         self._one = None
         self._graph_key = None
         model.sync_free = sync_free
@@ -69,7 +70,17 @@ class TrainStep:
     def __call__(self, model_input, ground_truth):
         """model_input: {'intrinsics','uv','pose','local_data'} for THIS rank's rays; returns (loss dict, model outputs)."""
         self.model.train()
-        if self.use_graph:
+        if self.use_graph and model_input.get("local_data") is not None:
+            # the captured graph holds no per-view feature maps: replaying it would silently drop the feature-consistency term
+            # (local_weight 0.5).  Steps that carry local_data run the eager sync-free path (same kernels, same loss).
+            if not self._warned_graph_local:
+                import warnings
+
+                warnings.warn("TrainStep(use_graph=True): this batch carries local_data — running the eager sync-free step for it "
+                              "(the hipGraph is captured without the per-view feature maps)")
+                self._warned_graph_local = True
+            losses, out = self._forward_backward(model_input, ground_truth)
+        elif self.use_graph:
             losses, out = self._graphed_forward_backward(model_input, ground_truth)
         else:
             losses, out = self._forward_backward(model_input, ground_truth)
@@ -95,6 +106,35 @@ class TrainStep:
         self.flat.zero_()
         losses["loss"].backward(gradient=self._root_grad(losses["loss"]))       # a cached 1 (autograd would launch a fill for its own)
         return losses, out
+
+    # ------------------------------------------------------------------ MFMA-shape selection of the dominant kernel
+    def autotune_geo_engine(self, model_input, ground_truth, reps=4):
+        """The geometry kernel exists on two MFMA shapes with the same arithmetic (ops.set_geo_mode: 'split' = 16x16x32, 'split_w' =
+        32x32x16).  Which one is faster is decided by the clock the chip holds under each, and that differs from box to box by as much
+        as the two differ: time the main-pass launch of both inside `reps` forward + backward passes of this batch
+        (order A B B A, HIP events; no optimiser step, the CPU generator is restored) and keep the faster.  -> {'split': ms, 'split_w': ms,
+        'selected': name}."""
+        from . import _prof
+
+        rng = torch.get_rng_state()
+        prev = ops.geo_mode()
+        R = model_input["uv"].shape[1]
+        ms = {"split": [], "split_w": []}
+        try:
+            for mode in ("split", "split_w", "split_w", "split"):
+                ops.set_geo_mode(mode)
+                self._forward_backward(model_input, ground_truth)          # first pass of a shape is not timed
+                _prof.start(("geo",))
+                for _ in range(reps):
+                    self._forward_backward(model_input, ground_truth)
+                ms[mode] += [p["ms"] for p in _prof.stop() if p["with_grad"] and p["rows"] >= 2 * R]
+        finally:
+            ops.set_geo_mode(prev)
+            torch.set_rng_state(rng)
+        res = {m: sum(v) / max(len(v), 1) for m, v in ms.items()}
+        res["selected"] = min(("split", "split_w"), key=lambda m: res[m])
+        ops.set_geo_mode(res["selected"])
+        return res
 
     # ------------------------------------------------------------------ hipGraph path
     def _graphed_forward_backward(self, model_input, ground_truth):
@@ -349,6 +389,9 @@ class VolOpt:
             prior = rename_prior_state_dict(torch.load(prior_path, map_location="cpu")["model_state_dict"])
         if prior is not None:
             self.model.load_state_dict(prior, strict=False)
+        init = kwargs.get("init_state_dict")               # e.g. fitted geometry latents: start values, applied BEFORE a checkpoint is restored
+        if init is not None:
+            self.model.load_state_dict(init, strict=False)
         self.num_pixels = self.conf.get_int("train.num_pixels", 1024)
         self.checkpoint_freq = self.conf.get_int("train.checkpoint_freq", 100)
         self.render_freq = self.conf.get_int("train.render_freq", 500)
@@ -411,10 +454,7 @@ class VolOpt:
         model_input = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in model_input.items()}
         local = model_input.get("local_data")
         if local is not None:          # train.py:339-343 moves the view's feature maps (tens of MB) every step; they never change: once per view
-            key = id(local)
-            if key not in self._local_cache:
-                self._local_cache[key] = (local, {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in local.items()})
-            model_input["local_data"] = self._local_cache[key][1]
+            model_input["local_data"] = self._local_to_device(local, indices, dev)
         ground_truth = {k: v.to(dev, non_blocking=True) for k, v in ground_truth.items()}
         self.step.iter_step = self.iter_step
         losses, out = self.step(model_input, ground_truth)
@@ -425,6 +465,24 @@ class VolOpt:
         self.iter_step += 1
         self.total_step += 1
         return losses
+
+    def _local_to_device(self, local, indices, dev):
+        """Device copy of a view's `local_data`, cached per VIEW INDEX (the reference's DTUDataset builds a fresh dict and freshly indexed
+        tensors on every __getitem__, datasets/dtu.py:268-291, so object identity is no key) in an LRU bounded by the number of views; an entry
+        is reused only while the host tensors have the shapes it was made from."""
+        idx = int(indices.reshape(-1)[0]) if torch.is_tensor(indices) else int(indices if not isinstance(indices, (list, tuple)) else indices[0])
+        sig = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(local.items()) if torch.is_tensor(v))
+        hit = self._local_cache.get(idx)
+        if hit is not None and hit[0] == sig:
+            self._local_cache[idx] = self._local_cache.pop(idx)          # most recently used last
+            return hit[1]
+        moved = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in local.items()}
+        self._local_cache.pop(idx, None)
+        self._local_cache[idx] = (sig, moved)
+        cap = max(1, int(getattr(self, "ds_len", 0) or len(self.train_dataset) if self.train_dataset is not None else 1))
+        while len(self._local_cache) > cap:
+            self._local_cache.pop(next(iter(self._local_cache)))
+        return moved
 
     def render_step(self, batch, epoch=0, dataset=None, fast=-1):
         """train.py:399-472 without the image files / TensorBoard: full-image render in `split_n_pixels` chunks."""

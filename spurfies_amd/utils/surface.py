@@ -18,14 +18,17 @@ SDF_FILL = 1000.0
 
 def get_grid(points, resolution, input_min=None, input_max=None, eps=0.1):
     """plots.py:302-333: cubic cells, `resolution` samples along the shortest axis of the bounding box, meshgrid in the
-    reference's (x, y, z) 'xy' indexing -> {'grid_points' [M,3] float32 tensor (CPU), 'xyz': [x, y, z], ...}."""
+    reference's (x, y, z) 'xy' indexing -> {'grid_points' [M,3] float32 tensor (CPU), 'xyz': [x, y, z], ...}.
+    Bit-for-bit the reference's arithmetic (tests/golden/mesh_grid.npz): the bounds keep the dtype they arrive in — float32 when they
+    come from a point tensor, as torch.min(...).numpy() gives — so the shortest axis is a float32 linspace, the step a float32 scalar, and
+    the two other axes float64 aranges of float32 scalars, exactly as numpy evaluates the reference's expressions."""
     if input_min is None or input_max is None:
         pts = torch.as_tensor(points)
         input_min, input_max = pts.min(0)[0].numpy(), pts.max(0)[0].numpy()
-    input_min, input_max = np.asarray(input_min, dtype=np.float64), np.asarray(input_max, dtype=np.float64)
+    input_min, input_max = np.asarray(input_min), np.asarray(input_max)
     s = int(np.argmin(input_max - input_min))
     lin = np.linspace(input_min[s] - eps, input_max[s] + eps, resolution)
-    length = lin.max() - lin.min()
+    length = np.max(lin) - np.min(lin)
     step = length / (lin.shape[0] - 1)
     axes = []
     for a in range(3):
@@ -33,6 +36,14 @@ def get_grid(points, resolution, input_min=None, input_max=None, eps=0.1):
     xx, yy, zz = np.meshgrid(*axes)
     grid_points = torch.tensor(np.vstack([xx.ravel(), yy.ravel(), zz.ravel()]).T, dtype=torch.float)
     return {"grid_points": grid_points, "shortest_axis_length": length, "xyz": axes, "shortest_axis_index": s}
+
+
+def get_grid_uniform(resolution, grid_boundary=(-2.0, 2.0)):
+    """plots.py:288-300: the same `resolution` samples of [lo, hi] on all three axes (the training-time plots' grid)."""
+    x = np.linspace(grid_boundary[0], grid_boundary[1], resolution)
+    xx, yy, zz = np.meshgrid(x, x, x)
+    grid_points = torch.tensor(np.vstack([xx.ravel(), yy.ravel(), zz.ravel()]).T, dtype=torch.float)
+    return {"grid_points": grid_points, "shortest_axis_length": 2.0, "xyz": [x, x, x], "shortest_axis_index": 0}
 
 
 def sdf_volume(sdf, grid, splitn=100000, device="cuda"):
@@ -249,17 +260,27 @@ def sample_mesh_points(verts, faces, thresh):
     tri, v1, v2, l1, l2, area2 = tri[ok], v1[ok], v2[ok], l1[ok], l2[ok], area2[ok]
     thr = thresh * np.sqrt(l1 * l2 / area2)
     n1, n2 = np.floor(l1 / thr), np.floor(l2 / thr)
-    out = [verts]
-    for key in np.unique(np.stack([n1, n2], 1), axis=0):     # triangles with the same lattice share the barycentric offsets
-        sel = (n1 == key[0]) & (n2 == key[1])
+    # triangles with the same lattice share the barycentric offsets: evaluated per lattice, laid out in the REFERENCE's order (the vertices,
+    # then triangle after triangle, each triangle's lattice points row-major) — the order matters downstream: the evaluation shuffles the
+    # samples with a seeded permutation and thins them greedily (downsample_points)
+    keys, inv = np.unique(np.stack([n1, n2], 1), axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    lattices = []
+    for key in keys:
         c = np.mgrid[: int(key[0]) + 1, : int(key[1]) + 1].astype(np.float64) + 0.5
         c[0] /= max(key[0], 1e-7)
         c[1] /= max(key[1], 1e-7)
         kk = c.reshape(2, -1).T
-        kk = kk[kk.sum(-1) < 1]
-        if len(kk):
-            out.append((v1[sel][:, None, :] * kk[None, :, :1] + v2[sel][:, None, :] * kk[None, :, 1:] + tri[sel][:, :1, :]).reshape(-1, 3))
-    return np.concatenate(out, 0)
+        lattices.append(kk[kk.sum(-1) < 1])
+    per_tri = np.asarray([len(lattices[g]) for g in range(len(keys))], np.int64)[inv]
+    start = np.concatenate([[0], np.cumsum(per_tri)])
+    new_pts = np.empty((int(start[-1]), 3), np.float64)
+    for g, kk in enumerate(lattices):
+        sel = np.nonzero(inv == g)[0]
+        if len(kk) and len(sel):
+            q = v1[sel][:, None, :] * kk[None, :, :1] + v2[sel][:, None, :] * kk[None, :, 1:] + tri[sel][:, :1, :]
+            new_pts[(start[sel][:, None] + np.arange(len(kk))[None, :]).reshape(-1)] = q.reshape(-1, 3)
+    return np.concatenate([verts, new_pts], 0)
 
 
 def downsample_points(points, thresh, seed=None):
@@ -277,39 +298,41 @@ def downsample_points(points, thresh, seed=None):
     return pts[mask]
 
 
-def chamfer_dtu(data_pts, gt_pts, max_dist=20.0, thresh=None, seed=0, bbox=None):
-    """evals/eval_dtu.py:110-232 without the scan-specific files (ObsMask / ground plane come with the DTU download): optional greedy
-    down-sampling of the reconstruction at `thresh`, optional axis-aligned `bbox` = (lo [3], hi [3]) in place of the observation
-    mask, then accuracy = mean distance data -> ground truth and completeness = ground truth -> data, each over the distances below
-    `max_dist`, and their mean.  Units are those of the inputs (the reference works in millimetres: thresh 0.2, max_dist 20).
-    -> dict(accuracy, completeness, overall, n_data, n_gt)."""
+def chamfer_dtu(data_pts, gt_pts, max_dist=20.0, thresh=None, seed=0, bbox=None, obs_mask=None, ground_plane=None, patch=60.0):
+    """evals/eval_dtu.py:118-254, pinned to the script itself by tests/golden/eval_dtu.npz: optional greedy down-sampling of the
+    reconstruction at `thresh` (:118-138), then
+      * `obs_mask` = {'ObsMask' bool [X,Y,Z], 'BB' [2,3], 'Res'} (the scan's ObsMask*.mat): points inside BB widened by `patch` below and
+        2 x `patch` above are `data_in` (:146-149); of those, the ones whose voxel round((p - BB[0]) / Res) lies in the grid and is observed
+        are `data_in_obs` (:151-159) — accuracy = mean distance data_in_obs -> ground truth over the distances below `max_dist` (:170-176);
+      * `ground_plane` P [4]: ground-truth points with P . (x, 1) > 0 (:200-202) — completeness = mean distance of those to **data_in**
+        (the in-bound set, NOT the observed subset and not the whole cloud, :204-208), again below `max_dist`;
+      * without `obs_mask`, an axis-aligned `bbox` = (lo [3], hi [3]) plays the role of the in-bound test and data_in_obs = data_in.
+    Units are those of the inputs (the reference works in millimetres: thresh 0.2, max_dist 20).
+    -> dict(accuracy, completeness, overall, n_data (= |data_in_obs|), n_down, n_gt)."""
     from scipy.spatial import cKDTree
 
     data = np.asarray(data_pts, np.float64)
     gt = np.asarray(gt_pts, np.float64)
     if thresh is not None:
         data = downsample_points(data, thresh, seed)
-    data_in = data
-    if bbox is not None:
+    data_in = data_obs = data
+    if obs_mask is not None:
+        mask, bb, res = np.asarray(obs_mask["ObsMask"]), np.asarray(obs_mask["BB"], np.float32), obs_mask["Res"]
+        inbound = ((data >= bb[:1] - patch) & (data < bb[1:] + patch * 2)).sum(axis=-1) == 3
+        data_in = data[inbound]
+        cell = np.around((data_in - bb[:1]) / res).astype(np.int32)
+        inside = ((cell >= 0) & (cell < np.expand_dims(mask.shape, 0))).sum(axis=-1) == 3
+        cell_in = cell[inside]
+        data_obs = data_in[inside][mask[cell_in[:, 0], cell_in[:, 1], cell_in[:, 2]].astype(bool)]
+    elif bbox is not None:
         lo, hi = np.asarray(bbox[0], np.float64), np.asarray(bbox[1], np.float64)
-        data_in = data[np.all((data >= lo) & (data < hi), axis=1)]
-    d2s = cKDTree(gt).query(data_in)[0]
-    s2d = cKDTree(data).query(gt)[0]
+        data_in = data_obs = data[np.all((data >= lo) & (data < hi), axis=1)]
+    gt_above = gt
+    if ground_plane is not None:
+        hom = np.concatenate([gt, np.ones_like(gt[:, :1])], -1)
+        gt_above = gt[(np.asarray(ground_plane, np.float64).reshape(1, 4) * hom).sum(-1) > 0]
+    d2s = cKDTree(gt).query(data_obs)[0]
+    s2d = cKDTree(data_in).query(gt_above)[0]
     acc = float(d2s[d2s < max_dist].mean()) if (d2s < max_dist).any() else float("nan")
     comp = float(s2d[s2d < max_dist].mean()) if (s2d < max_dist).any() else float("nan")
-    return {"accuracy": acc, "completeness": comp, "overall": 0.5 * (acc + comp), "n_data": len(data_in), "n_gt": len(gt)}
-
-
-def extract_surface(sdf, resolution, input_min, input_max, splitn=100000, device="cuda", keep_largest=True):
-    """get_surface_by_grid's plain branch (plots.py:188-287 with higher_res=False): reference-shaped grid over the box, chunked SDF
-    sweep, iso-surface at 0, largest component.  -> (verts, faces, volume, grid); (None, None, volume, grid) when the SDF does not
-    cross zero inside the box."""
-    grid = get_grid(None, resolution, input_min=np.asarray(input_min), input_max=np.asarray(input_max), eps=0.0)
-    vol = sdf_volume(sdf, grid, splitn=splitn, device=device)
-    ok = vol != SDF_FILL
-    if not ok.any() or vol[ok].min() > 0 or vol[ok].max() < 0:
-        return None, None, vol, grid
-    verts, faces = triangulate(vol, grid)
-    if keep_largest and len(faces):
-        verts, faces = largest_component(verts, faces)
-    return verts, faces, vol, grid
+    return {"accuracy": acc, "completeness": comp, "overall": 0.5 * (acc + comp), "n_data": len(data_obs), "n_down": len(data), "n_gt": len(gt_above)}

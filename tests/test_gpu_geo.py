@@ -1,6 +1,6 @@
 """GPU parity: fused geometry kernel (gather + RBF + F_geometry/T on the matrix cores + Jacobian sweep)
-vs the oracle's torch-CPU restatement (pointneus_disent.py:241-247, 300-323) — in both arithmetic modes: fp32-exact products
-from three bf16 pieces per operand (the default) and plain fp32 MFMA."""
+vs the oracle's torch-CPU restatement (pointneus_disent.py:241-247, 300-323) — in both arithmetic modes: fp32-class products
+from three bf16 pieces per operand (the default, on either MFMA shape) and plain fp32 MFMA."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +12,7 @@ from tests.helpers import assert_close_except_kinks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["split", "f32"])
+@pytest.fixture(params=["split", "split_w", "f32"])
 def geo_mode(request):
     from spurfies_amd import ops
 
@@ -144,7 +144,7 @@ def test_tv_and_row_scatter_match_torch():
     np.testing.assert_allclose(table.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.fixture(params=["split", "f32"])
+@pytest.fixture(params=["split", "split_w", "f32"])
 def color_mode(request):
     from spurfies_amd import ops
 
@@ -249,7 +249,7 @@ def test_rhead_forward_backward_match_torch(color_mode):
 
 
 def test_split_products_agree_with_fp32_mfma_kernel():
-    """The default kernel forms every fp32 product exactly from three bf16 pieces per operand; against the fp32-MFMA kernel on the
+    """The default kernel forms every fp32 product from three bf16 pieces per operand (six exact piece products, the three below 2^-24 dropped: fp32-class, <= 2 ulp per product); against the fp32-MFMA kernel on the
     same main-pass-shaped input the SDF agrees to summation-order noise and the Jacobian everywhere except isolated LeakyReLU
     kinks (tests/helpers.py)."""
     from spurfies_amd import ops
@@ -261,7 +261,7 @@ def test_split_products_agree_with_fp32_mfma_kernel():
     pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), ps, n)
     res = {}
     try:
-        for mode in ("f32", "split"):
+        for mode in ("f32", "split", "split_w"):
             ops.set_geo_mode(mode)
             out = ops.geo_forward(xt, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
             res[mode] = {k: out[k].clone().cpu().numpy() for k in ("sdf", "grad", "wn", "jac")}
@@ -271,3 +271,37 @@ def test_split_products_agree_with_fp32_mfma_kernel():
     np.testing.assert_array_equal(res["split"]["wn"], res["f32"]["wn"])
     assert_close_except_kinks(res["split"]["grad"], res["f32"]["grad"], rtol=2e-5, atol=2e-8, err_msg="d sdf / dx")
     assert_close_except_kinks(res["split"]["jac"], res["f32"]["jac"], rtol=2e-5, atol=2e-8, err_msg="latent Jacobian")
+    # the second MFMA shape of the same arithmetic (SPF_ARITH_SPLIT_W, bench.py's A/B twin): same products, other summation order
+    np.testing.assert_allclose(res["split_w"]["sdf"], res["split"]["sdf"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_array_equal(res["split_w"]["wn"], res["split"]["wn"])
+    assert_close_except_kinks(res["split_w"]["grad"], res["split"]["grad"], rtol=2e-5, atol=2e-8, err_msg="d sdf / dx (32x32x16 tiles)")
+    assert_close_except_kinks(res["split_w"]["jac"], res["split"]["jac"], rtol=2e-5, atol=2e-8, err_msg="latent Jacobian (32x32x16 tiles)")
+
+
+def test_fixed_point_scatter_reports_non_finite_terms_out_of_band():
+    """Scatter mode 'fixed': a non-finite gradient term must reach the optimiser's guard as NaN whatever the NUMBER and SIGNS of such
+    terms per entry (round-2 advisor finding: four in-band +2^62 markers wrapped to 0, two of opposite sign cancelled).  The status word
+    in front of the accumulators (include/spurfies_hip.h: buffer contract) records them; the flush turns the whole gradient into NaN and
+    clears the word, so the next use of the same buffer is clean."""
+    from spurfies_amd import ops
+
+    scene, st, cfg, x, dev, grid, packed = _setup(n_points=3000, n_query=2000, seed=2)
+    xt = torch.from_numpy(x).cuda()
+    q = grid.query_dense(xt.unsqueeze(1), cfg.k, cfg.r, 1)
+    ps, _, n = ops.compact_points(q["slot_valid"])
+    pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), ps, n)
+    res = ops.geo_forward(xt, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
+    g_ok = torch.ones(xt.shape[0], device="cuda")
+    ops.set_scatter_mode("fixed")
+    try:
+        want = ops.geo_backward_latents(g_ok, res["wn"], res["jac"], pl, torch.zeros_like(dev["neural_feats_geometry"])).clone()
+        assert torch.isfinite(want).all() and float(want.abs().max()) > 0
+        for bad in (float("inf"), float("nan")):
+            g_bad = g_ok.clone()
+            g_bad[::2] = bad                      # thousands of offending terms, both signs (the Jacobian entries change sign), many per latent entry
+            got = ops.geo_backward_latents(g_bad, res["wn"], res["jac"], pl, torch.zeros_like(dev["neural_feats_geometry"]))
+            assert torch.isnan(got).all(), "a non-finite term must poison the flushed gradient"
+            again = ops.geo_backward_latents(g_ok, res["wn"], res["jac"], pl, torch.zeros_like(dev["neural_feats_geometry"]))
+            assert torch.equal(again, want), "status word and accumulators must be clean after a poisoned flush"
+    finally:
+        ops.set_scatter_mode("atomic")

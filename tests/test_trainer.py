@@ -42,6 +42,76 @@ def test_checkpoint_layout_and_roundtrip_cpu(tmp_path):
     assert all(not p.requires_grad for n, p in t2.model.named_parameters() if n.startswith(("F_geometry", "T.")))
 
 
+def test_resume_keeps_checkpoint_latents_over_start_values(tmp_path):
+    """`init_state_dict` (runner.py: the fitted geometry latents) holds START values: on is_continue they are applied before the
+    checkpoint is restored, so a resumed run keeps its trained latents (round-2 advisor finding: they were reset to step 0)."""
+    t, scene = _volopt(tmp_path, "cpu")
+    with torch.no_grad():
+        t.model.neural_feats_geometry.add_(0.125)
+    trained = t.model.neural_feats_geometry.detach().clone()
+    t.iter_step = 5
+    t.save_checkpoints(1)
+    start = {"neural_feats_geometry": torch.zeros_like(trained)}
+    fresh, _ = _volopt(tmp_path / "other", "cpu", init_state_dict=start)        # no checkpoint there: the start values are used
+    assert float(fresh.model.neural_feats_geometry.abs().max()) == 0.0
+    t2, _ = _volopt(tmp_path, "cpu", is_continue=True, init_state_dict=start)
+    assert t2.iter_step == 5
+    assert torch.equal(t2.model.neural_feats_geometry, trained)
+
+
+def test_local_data_cache_is_keyed_by_view_and_bounded(tmp_path):
+    """The reference's dataset builds a NEW local_data dict with newly indexed tensors on every __getitem__ (datasets/dtu.py:268-291):
+    the device-copy cache must hit per view index and stay bounded by the number of views."""
+    t, scene = _volopt(tmp_path, "cpu")
+    t.gen_dataset(2)
+    dev = torch.device("cpu")
+    seen = []
+    for it in range(12):
+        v = it % 3
+        local = {"feat": torch.full((2, 4), float(v)), "feat_src": torch.full((2, 3, 4), float(v)), "scale": 1.0}     # fresh objects every time
+        moved = t._local_to_device(local, torch.as_tensor([v]), dev)
+        seen.append(id(moved))
+        assert float(moved["feat"][0, 0]) == float(v)
+    assert len(t._local_cache) == 3
+    assert seen[3:6] == seen[0:3] and seen[9:12] == seen[0:3]                   # cache hits although every dict was a new object
+    other = {"feat": torch.zeros((2, 8)), "feat_src": torch.zeros((2, 3, 8)), "scale": 1.0}
+    assert t._local_to_device(other, torch.as_tensor([0]), dev)["feat"].shape == (2, 8)     # a view whose maps changed shape is re-moved
+    assert len(t._local_cache) == 3
+
+
+@pytest.mark.gpu
+def test_graph_step_with_local_data_keeps_the_feature_consistency_term(tmp_path):
+    """use_graph=True with batches that carry local_data: the step must not drop the local term (round-2 advisor finding) — it runs
+    the eager sync-free path for those batches and agrees with a plain sync-free trainer."""
+    import warnings
+
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.conf import Conf
+    from spurfies_amd.train import SyntheticDataset, VolOpt
+
+    scene = syn.make_scene(3000, seed=6, prior="fitted")
+    prior = {k: torch.from_numpy(np.asarray(v)) for k, v in scene["state"].items() if k.startswith(("F_geometry", "T."))}
+    got = {}
+    for name, kw in (("graph", {"use_graph": True}), ("eager", {"sync_free": True})):
+        args = Conf(exps_folder="exps", grad_clip=True, vol=Conf(train=Conf(expname="ours", num_pixels=256, checkpoint_freq=0), dataset=Conf(data_dir="dtu")))
+        t = VolOpt(args=args, batch_size=1, scan="scan24", root=str(tmp_path / name), scene=scene, dataset=SyntheticDataset(scene, local=True),
+                   neural_points={"pts": scene["state"]["neural_pts"], "colors": scene["colors"]}, prior_state_dict=prior, device="cuda",
+                   init_state_dict={"neural_feats_geometry": torch.from_numpy(scene["state"]["neural_feats_geometry"])}, **kw)
+        t.gen_dataset(2)
+        torch.manual_seed(0)
+        t.train_dataset.change_sampling_idx(256)
+        batch = t.train_dataset.collate_fn([t.train_dataset[0]])
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            losses = t.train_step(batch)
+        if name == "graph":
+            assert any("local_data" in str(x.message) for x in w)
+        got[name] = {k: float(v.item()) for k, v in losses.items() if k in ("loss", "local_loss", "rgb_loss")}
+    assert got["graph"]["local_loss"] > 0.0
+    for k in got["eager"]:
+        np.testing.assert_allclose(got["graph"][k], got["eager"][k], rtol=1e-4, err_msg=k)
+
+
 @pytest.mark.gpu
 def test_short_run_reduces_the_loss(tmp_path):
     t, scene = _volopt(tmp_path, "cuda", sync_free=True)
