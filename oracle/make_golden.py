@@ -325,9 +325,22 @@ def golden_sampler(name, n_rays=192, seed=3):
         fake.sdf_importance = sdf_importance
         sampler = ErrorBoundSampler_pn(3.0, near=0.5, far=4.5, N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1,
                                        beta_iters=10, max_total_iters=5)
+        # every evaluation of the error bound B(beta) (ray_sampler.py:434-445: once at beta0, then `beta_iters` bisection steps per sampler
+        # iteration), per ray: a ray whose B lands within rounding of eps at one of them may legitimately take the neighbouring beta in
+        # another fp32 implementation — the per-ray rule of tests/test_gpu_stages.py::test_sampler_matches_reference_g4
+        bound_calls = []
+        inner = sampler.get_error_bound
+
+        def spy(beta, model, sdf, z_vals, dists, d_star, inner=inner, bound_calls=bound_calls):
+            err = inner(beta, model, sdf, z_vals, dists, d_star)
+            bound_calls.append(err.detach().clone().numpy().astype(np.float32))
+            return err
+
+        sampler.get_error_bound = spy
         torch.manual_seed(seed + 8)
         with DrawRecorder() as rec:
             z, z_eik = sampler.get_z_vals(dirs, cam, fake, fast=fast, iter_step=0)
+        fx[f"{tag}.bound_err"] = np.stack(bound_calls)            # [sampler iterations x (1 + beta_iters), rays]
         fx[f"{tag}.z_vals"] = z.detach().numpy()
         fx[f"{tag}.z_eik"] = z_eik.detach().numpy()
         fx[f"{tag}.calls"] = np.asarray(calls, np.int64)
@@ -441,6 +454,19 @@ def golden_trajectory(name, n_points, n_rays, steps, seed, local=False, cam_radi
         fx[f"loss.{k}"] = np.asarray(v, np.float64)
     for pname, p in trainable:
         fx.update(probes(f"delta.{pname}", p.detach() - before[pname]))
+    # "at equal Chamfer" (BASELINE.json): the reference's OWN geometry after the optimisation — get_sdf_eval (pointneus_disent.py:249-298) of
+    # the trained reference model over the reference's evaluation grid (plots.py:302-333 via the bit-equal surface.get_grid, 40 samples on
+    # the shortest axis of the cloud's bounding box, eps 0.1), in the reference's 100 000-point chunks (plots.py:249-253).  1000 = no neighbour.
+    from spurfies_amd.utils import surface
+
+    model.eval()
+    grid = surface.get_grid(torch.from_numpy(scene["state"]["neural_pts"]), 40, eps=0.1)
+    with torch.no_grad():
+        vol = torch.cat([model.get_sdf_eval(c).reshape(-1) for c in torch.split(grid["grid_points"], 100000, dim=0)]).numpy().astype(np.float32)
+    gx, gy, gz = grid["xyz"]
+    fx["final.sdf_volume"] = vol.reshape(len(gy), len(gx), len(gz))
+    fx["final.grid_resolution"], fx["final.grid_eps"] = np.int64(40), np.float64(0.1)
+    print(name, "final SDF volume", fx["final.sdf_volume"].shape, "defined", float((vol != 1000.0).mean()), "negative", float((vol < 0).mean()))
     np.savez_compressed(os.path.join(OUT, name), **fx)
     print(name, "loss", loss_rec["loss"][0], "->", loss_rec["loss"][-1], "psnr", rec["psnr"][0], "->", rec["psnr"][-1], "size", os.path.getsize(os.path.join(OUT, name)))
 

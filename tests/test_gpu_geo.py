@@ -144,7 +144,7 @@ def test_tv_and_row_scatter_match_torch():
     np.testing.assert_allclose(table.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.fixture(params=["split", "split_w", "f32"])
+@pytest.fixture(params=["split", "f32"])
 def color_mode(request):
     from spurfies_amd import ops
 

@@ -171,7 +171,8 @@ def test_multi_step_trajectory_tracks_the_reference(name):
     views in turn, ONE CPU-generator stream across all steps) replayed through the sync-free HIP step.  A step's random draws continue
     where the previous step stopped, so a single extra or missing draw would derail the run at step 2.  fp32 differences are amplified
     by Adam from step to step; measured on MI355X: total loss within 2.3e-7 over the first 10 steps, 1.1e-4 over the first 50, 2.3 %
-    at worst over 200; norms of the parameters' total change within 1 % (latents) to 11 % (the smallest bias vector).
+    at worst over 200; norms of the parameters' total change within 1.4 % (latents) to 5.6 % (a bias vector); the final get_sdf_eval volume
+    within 0.7 % of its range of the reference's, zero level sets 0.0006 grid steps apart (Chamfer).
     trajectory_local_ref.npz: 60 steps with `local_data` on every step (find_surface_points + get_local_loss at local_weight 0.5)."""
     from spurfies_amd import synthetic as syn
     from spurfies_amd.train import TrainStep
@@ -208,8 +209,41 @@ def test_multi_step_trajectory_tracks_the_reference(name):
     for pname, p in model.named_parameters():
         if p.requires_grad:
             norm = float((p.detach() - before[pname]).double().norm())
-            np.testing.assert_allclose(norm, float(fx[f"delta.{pname}.stats"][2]), rtol=0.25, err_msg=pname)
+            ref_norm = float(fx[f"delta.{pname}.stats"][2])
+            print(f"{name}: |delta {pname}| {norm:.6e} vs reference {ref_norm:.6e} ({(norm / ref_norm - 1) * 100:+.2f} %)")
+            # measured on MI355X over 200 steps: latents within 1.4 %, weights within 4 %, the two most drifting bias vectors -5.6 % / -5.1 %;
+            # the 60- and 30-step runs within 0.05 %
+            np.testing.assert_allclose(norm, ref_norm, rtol=0.05 if pname.startswith("neural_feats") else 0.10, err_msg=pname)
     np.testing.assert_allclose(float(model.density.get_beta().detach()), fx["step.beta"][-1], rtol=0.03)
+    # ---- "at equal Chamfer" (BASELINE.json): the geometry the optimisation ENDS with.  The fixture holds the reference model's get_sdf_eval
+    # volume after its last step, over the reference's evaluation grid (plots.py:302-333); the HIP-trained model is swept over the same grid.
+    from spurfies_amd.utils import surface
+
+    model.eval()
+    grid = surface.get_grid(torch.from_numpy(scene["state"]["neural_pts"]), int(fx["final.grid_resolution"]), eps=float(fx["final.grid_eps"]))
+    vol = surface.sdf_volume(model.get_sdf_eval, grid)
+    ref = fx["final.sdf_volume"]
+    assert vol.shape == ref.shape
+    defined = ref != 1000.0
+    assert np.array_equal(vol != 1000.0, defined)                       # the cloud is static: same support, bit for bit
+    d = np.abs(vol[defined] - ref[defined])
+    span = float(np.abs(ref[defined]).max())
+    h = float(grid["xyz"][0][1] - grid["xyz"][0][0])
+    pts_h, pts_r = surface.surface_points(vol, grid), surface.surface_points(ref, grid)
+    assert len(pts_r) > 500 and abs(len(pts_h) - len(pts_r)) <= 0.02 * len(pts_r)
+    cd, acc, comp = surface.chamfer(pts_h, pts_r)
+    print(f"{name}: final SDF after {n} steps: max |hip - ref| {d.max():.3e} (span {span:.3f}), mean {d.mean():.3e}; zero level sets: "
+          f"{len(pts_h)} vs {len(pts_r)} points, Chamfer {cd / h:.4f} grid steps (accuracy {acc / h:.4f}, completeness {comp / h:.4f})")
+    # SDF values agree to 2 % of the value + 0.2 % of the volume's range (fp32 drift through n Adam steps; kinks move single samples)
+    assert (d <= 0.02 * np.abs(ref[defined]) + 2e-3 * span).mean() >= 0.999
+    assert cd < 0.05 * h, cd / h                                         # the two surfaces coincide far below a grid step (bar: 0.3)
+    # ... and the comparison is not vacuous: against the geometry the run STARTED from, the optimisation moved the field by far more than
+    # the two implementations differ at the end
+    fresh = build_model(scene, train=False)
+    vol0 = surface.sdf_volume(fresh.get_sdf_eval, grid)
+    moved = float(np.abs(vol0[defined] - ref[defined]).mean())
+    print(f"{name}: mean |initial - reference final| {moved:.3e} vs mean |hip final - reference final| {d.mean():.3e}")
+    assert d.mean() < 0.2 * moved
 
 
 def test_sync_free_step_equals_default_step():

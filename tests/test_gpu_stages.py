@@ -148,15 +148,22 @@ def test_stages_behind_the_sampler_match_reference(name):
             check_probes(fx, f"grad.{pname}", p.grad, rtol=GRAD_RTOL, atol=GRAD_RTOL * scale + 1e-9)
     # the step tail (train.py:359-363, 548-564): clip_grad_norm_(1.0) + Adam(lr 5e-4) through the fused HIP optimiser
     before = {pname: p.detach().clone() for pname, p in model.named_parameters() if p.requires_grad}
+    grads_before = {pname: p.grad.detach().clone() for pname, p in model.named_parameters() if p.requires_grad}
+    grad_rms = {pname: float(g.double().pow(2).mean().sqrt()) for pname, g in grads_before.items()}
     state = step.optimizer.step(max_norm=1.0)
     np.testing.assert_allclose(float(state[2]), fx["adam.grad_norm"], rtol=1e-4)
     for pname, p in model.named_parameters():
         if p.requires_grad:
             delta = (p.detach() - before[pname]).reshape(-1).double().cpu()
             got, want = delta[torch.from_numpy(fx[f"adam.{pname}.idx"])].numpy(), fx[f"adam.{pname}.val"]
-            # Adam's first update is -lr g / (|g| + 1e-8): where |g| is within round-off of zero the sign of the noise decides
+            # Adam's first update is -lr g / (|g| + 1e-8): where |g| is within round-off of zero the sign of the noise decides.
+            # Per-probe rule: a probe may miss the tolerance only if its OWN gradient entry is below 1e-3 of the tensor's RMS gradient
+            # (there the update's sign / size is decided by the last bits of g); every other probe must match.
             bad = ~np.isclose(got, want, rtol=2e-2, atol=2e-6)
-            assert bad.mean() <= 0.03, (pname, int(bad.sum()), bad.size)
+            g_at = grads_before[pname].reshape(-1).double().cpu()[torch.from_numpy(fx[f"adam.{pname}.idx"])].abs().numpy()
+            tiny = g_at <= 1e-3 * grad_rms[pname] + 1e-12
+            assert not (bad & ~tiny).any(), (pname, int((bad & ~tiny).sum()), bad.size, g_at[bad & ~tiny][:5], grad_rms[pname])
+            assert bad.mean() <= 0.05, (pname, int(bad.sum()), bad.size)
             assert np.abs(got).max() <= 5.0e-4 * 1.0001
 
 
@@ -192,9 +199,23 @@ def test_sampler_matches_reference_g4():
         assert zg.shape == zr.shape == (dirs.shape[0], 98)
         finite = np.isfinite(zr).all(axis=1)
         assert np.array_equal(np.isfinite(zg).all(axis=1), finite), tag
-        # a ray whose beta bisection lands within rounding of eps may take the neighbouring beta: per-ray comparison
+        # Per-ray rule.  The bisection keeps beta_mid iff B(beta_mid) <= eps (ray_sampler.py:434-445): two fp32 implementations can only
+        # disagree on a ray where some evaluated B lies within rounding of eps — the fixture holds every B the reference evaluated
+        # (`bound_err` [calls, rays]).  Every ray must match within 2e-4 UNLESS one of its B values is that close to eps; the excused
+        # rays still hold a valid (sorted, in-range) sample set and stay a small minority.
         close = np.isclose(zg, zr, rtol=2e-4, atol=2e-4, equal_nan=True).all(axis=1)
-        assert close.mean() >= 0.97, (tag, close.mean())
+        eps = 0.1
+        err = fx[f"{tag}.bound_err"]
+        margin = np.nanmin(np.abs(err - eps), axis=0) / eps                    # per ray: the closest any evaluated B came to eps
+        BORDER = 5e-5        # fp32 evaluations of B differ by ~1e-5 relative between implementations; the closest the fixture's rays come to eps is 2e-5
+        unexplained = ~close & ~(margin <= BORDER)
+        assert not unexplained.any(), (tag, np.nonzero(unexplained)[0][:10], margin[unexplained][:10])
+        assert (~close).mean() <= 0.02, (tag, (~close).mean())
+        bad = ~close & finite
+        if bad.any():
+            assert (np.diff(zg[bad], axis=1) >= 0).all() and zg[bad].min() >= 0.5 - 1e-6 and zg[bad].max() <= 2 * 3.0 + 1e-4
+        print(f"sampler {tag}: {int((~close).sum())} of {len(close)} rays take a neighbouring beta; their margins |B - eps| / eps = "
+              f"{np.sort(margin[~close])[-5:] if (~close).any() else []}; rays within {BORDER} of eps overall: {int((margin <= BORDER).sum())}")
         if training:                                                      # the eikonal sample index came from the same generator state
             np.testing.assert_allclose(z_eik.cpu().numpy()[close], fx[f"{tag}.z_eik"][close], rtol=2e-4, atol=2e-4)
 

@@ -94,6 +94,7 @@ def test_graph_step_with_local_data_keeps_the_feature_consistency_term(tmp_path)
     got = {}
     for name, kw in (("graph", {"use_graph": True}), ("eager", {"sync_free": True})):
         args = Conf(exps_folder="exps", grad_clip=True, vol=Conf(train=Conf(expname="ours", num_pixels=256, checkpoint_freq=0), dataset=Conf(data_dir="dtu")))
+        torch.manual_seed(4)                      # the constructors draw F_color / R / latents from the global generator: same start for both
         t = VolOpt(args=args, batch_size=1, scan="scan24", root=str(tmp_path / name), scene=scene, dataset=SyntheticDataset(scene, local=True),
                    neural_points={"pts": scene["state"]["neural_pts"], "colors": scene["colors"]}, prior_state_dict=prior, device="cuda",
                    init_state_dict={"neural_feats_geometry": torch.from_numpy(scene["state"]["neural_feats_geometry"])}, **kw)
