@@ -62,6 +62,10 @@ def parse():
                     "step on MI355X: ~3 us of dependency handling per graph node; the eager launches run ahead of the GPU)")
     ap.add_argument("--no-graph", action="store_true", help="(default since the sync-free step became GPU-bound; kept for old command lines)")
     ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--mode", choices=["train", "eval"], default="train", help="train (the contract line): one optimisation step per step; eval: one evaluation-render chunk per "
+                    "step (PointVolSDF.forward(fast=-1) under no_grad: the full error-bounded sampler, kNN, SDF + normals, colour, compositing — SURVEY.md "
+                    "section 8(d): reported separately, with the realised sampler iterations), followed by the reference-sized get_sdf_eval grid sweep")
+    ap.add_argument("--sweep-resolution", type=int, default=512, help="eval mode: samples along the shortest axis of the mesh-extraction grid (the reference: 512); 0 = skip")
     ap.add_argument("--geo-engine", choices=["auto", "split", "split_w"], default="auto", help="MFMA shape of the dominant kernel: 16x16x32 (split), 32x32x16 "
                     "(split_w), or auto = time both on this box before the warm-up steps (TrainStep.autotune_geo_engine) and keep the faster")
     ap.add_argument("--ab-reps", type=int, default=10, help="forward+backward passes per leg of the A B B A engine comparison after the timed region (0 = skip)")
@@ -136,8 +140,159 @@ def build_scene_step(args, seed, device, world, use_graph):
     return scene, model, TrainStep(model, sync_free=not args.sync, use_graph=use_graph, draws="batch" if (args.exact_draws or world == 1) else "local")
 
 
+def eval_cpu_baseline(scene, n_rays):
+    """The oracle's evaluation render (forward, fast=-1, no_grad) on a bounded ray sample, host cores of this box."""
+    from oracle import path as P
+    from spurfies_amd import synthetic as syn
+
+    cfg = P.PathConfig(ranges=tuple(scene["ranges"]))
+    st = P.load_state(scene["state"], requires_grad=False)
+    grid = P.make_grid(cfg, st["neural_pts"])
+    g = torch.Generator().manual_seed(999)
+    cores = min(os.cpu_count() or 1, 8)
+    torch.set_num_threads(cores)
+    inp = {"intrinsics": torch.from_numpy(scene["intrinsics"])[None], "uv": torch.from_numpy(syn.make_pixels(n_rays, g))[None],
+           "pose": torch.from_numpy(scene["poses"][0])[None]}
+    stages = {}
+    t0 = time.time()
+    with torch.enable_grad():          # the oracle forms the normals through autograd, as the reference does (pointneus_disent.py:315-323)
+        P.forward(inp, st, cfg, grid=grid, training=False, fast=-1, stages=stages)
+    dt = time.time() - t0
+    iters = (stages.get("trace") or {}).get("iters")
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"one evaluation render of {n_rays} rays (fast=-1) on the same scene, {dt:.1f} s on {cores} threads", "sampler_iterations": iters}
+
+
+def main_eval(args):
+    """--mode eval: a step = one evaluation-render chunk of --rays rays per GPU; no collective (chunks of an image are independent)."""
+    from spurfies_amd import ops
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.conf import default_model_conf
+    from spurfies_amd.model.pointneus_disent import PointVolSDF
+    from spurfies_amd.utils import surface
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("SPF_DIST_BACKEND", "nccl")
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
+    scene = syn.make_scene(args.points, seed=0, spacing=args.spacing, prior=args.prior)
+    st = scene["state"]
+    model = PointVolSDF(default_model_conf(near=0.5, grid_ranges=list(scene["ranges"])), 24, "dtu",
+                        neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
+    model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
+    model.eval()
+    if args.geo_engine != "auto":
+        ops.set_geo_mode(args.geo_engine)
+    g = torch.Generator().manual_seed(777 + rank)
+    K = torch.from_numpy(scene["intrinsics"])[None].to(device)
+    n = args.warmup + args.steps
+    batches = [{"intrinsics": K, "uv": torch.from_numpy(syn.make_pixels(args.rays, g))[None].to(device),
+                "pose": torch.from_numpy(scene["poses"][i % len(scene["poses"])])[None].to(device), "local_data": None} for i in range(min(n, 64))]
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    torch.set_num_threads(1)
+    iters = []
+    with torch.no_grad():
+        for i in range(args.warmup):
+            model(dict(batches[i % len(batches)]), fast=-1)
+        ops.geo_clock(reset=True)
+        ops.profile_start(tags=("geo", "knn", "color_fwd", "render_fwd"))
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n):
+            out = model(dict(batches[i % len(batches)]), fast=-1)
+            iters.append(model.ray_sampler.last_iters)
+        sync()
+        dt = time.perf_counter() - t0
+        prof = ops.profile_stop()
+        clk = ops.geo_clock(reset=True)
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    samples = sum(args.rays * (128 * t + 98) for t in iters) * world         # every sampler iteration evaluates 128 new samples per ray, the main pass 98
+    # ---- roofline: the forward-only geometry kernel (sampler passes; 411 648 FLOP per pair) and the with-Jacobian launch of the main pass ----
+    fwd = [p for p in prof if p["tag"] == "geo" and not p["with_grad"] and p["pairs"] > 0]
+    jac = [p for p in prof if p["tag"] == "geo" and p["with_grad"] and p["pairs"] > 0]
+    engine = ops.geo_mode()
+    roof = None
+    if fwd:
+        ms, pairs = sum(p["ms"] for p in fwd), sum(p["pairs"] for p in fwd)
+        ach = pairs * F_FWD / (ms * 1e-3) / 1e12
+        ck = clk.get((engine, False))
+        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
+                "kernel": ("geo_pairs_x3_kernel<false>" if engine == "split" else "geo_pairs_x3w_kernel<false>") + " (sampler passes: SDF only)",
+                "launches": len(fwd), "avg_ms": ms / len(fwd), "pairs_per_launch": pairs / len(fwd), "flop_per_pair": F_FWD, "total_ms_per_step": ms / args.steps,
+                "held_clock": held_clock(ach, ck), "traffic": None, "timing": "HIP events over the timed region",
+                "peak_basis": "algorithmic fp32 FLOP/s against the dense bf16 MFMA peak / 6 (six exact bf16 piece products per fp32 product)"}
+        sec = []
+        if jac:
+            ms2, pairs2 = sum(p["ms"] for p in jac), sum(p["pairs"] for p in jac)
+            a2 = pairs2 * (F_FWD + F_JAC) / (ms2 * 1e-3) / 1e12
+            sec.append({"kernel": "geometry kernel with the Jacobian sweep (main pass: SDF + normals)", "bound": "mfma", "achieved": a2, "peak": PEAK_SPLIT_TFLOPS,
+                        "unit": "TFLOP/s", "frac": a2 / PEAK_SPLIT_TFLOPS, "avg_ms": ms2 / len(jac), "pairs_per_launch": pairs2 / len(jac), "total_ms_per_step": ms2 / args.steps})
+        col = [p for p in prof if p["tag"] == "color_fwd" and p["pairs"] > 0]
+        if col:
+            ms3, pairs3 = sum(p["ms"] for p in col), sum(p["pairs"] for p in col)
+            a3 = pairs3 * F_COLOR_FWD / (ms3 * 1e-3) / 1e12
+            sec.append({"kernel": "color_forward_x3_kernel<false>", "bound": "mfma", "achieved": a3, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
+                        "frac": a3 / PEAK_SPLIT_TFLOPS, "avg_ms": ms3 / len(col), "pairs_per_launch": pairs3 / len(col), "total_ms_per_step": ms3 / args.steps})
+        knn = [p for p in prof if p["tag"] == "knn"]
+        if knn:
+            sec.append({"kernel": "spf_grid_query (all passes)", "bound": "hbm", "total_ms_per_step": sum(p["ms"] for p in knn) / args.steps, "launches_per_step": len(knn) / args.steps})
+        roof["secondary"] = sec
+    res = {"metric": "ray-samples/sec (kNN+SDF+render, evaluation render fast=-1)", "value": samples / dt, "unit": "ray-samples/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"evaluation render (train.py:399-472 / eval_spurfies.py:276-292 chunks): {args.points} neural points, {args.rays} rays per chunk and GPU, "
+                                  f"full error-bounded sampler (up to 5 iterations of 128 samples/ray) + 98 main samples/ray, SDF + normals + colour + compositing, no_grad; prior = {args.prior}",
+                      "mode": "eval", "rays_per_gpu": args.rays, "neural_points": args.points, "prior": args.prior, "parallelism": f"chunk-sharded dp{world}",
+                      "sampler_iterations_realised": {"mean": float(np.mean(iters)), "min": int(min(iters)), "max": int(max(iters))},
+                      "rays_per_s": args.rays * world * args.steps / dt,
+                      "host_syncs_per_step": "one per sampler iteration (the reference's convergence test, ray_sampler.py:468) + one for the exact buffer sizes"},
+           "roofline": roof}
+    if rank == 0:
+        sweep = None
+        if args.sweep_resolution > 0:       # the mesh-extraction entry (plots.py:188-287): get_sdf_eval over the reference-sized grid, chunks back to back
+            b = scene["base_radius"] * 1.25
+            grid = surface.get_grid(None, args.sweep_resolution, input_min=np.asarray([-b] * 3), input_max=np.asarray([b] * 3), eps=0.0)
+            with torch.no_grad():
+                model.get_sdf_eval(grid["grid_points"][:100000].to(device))          # warm-up chunk (allocator pools)
+                torch.cuda.synchronize()
+                ops.profile_start(tags=("geo",))
+                t0 = time.perf_counter()
+                vol = surface.sdf_volume(model.get_sdf_eval, grid)
+                torch.cuda.synchronize()
+                ts = time.perf_counter() - t0
+                gp = [p for p in ops.profile_stop() if p["pairs"] > 0]
+            sweep = {"grid_points": int(vol.size), "resolution": args.sweep_resolution, "seconds": ts, "value": vol.size / ts, "unit": "points/s",
+                     "defined_fraction": float((vol != 1000.0).mean()),
+                     "note": "grid resident on the device, 100 000-point chunks evaluated back to back, one copy back (incl. the H2D of the grid and the D2H of the volume)"}
+            if gp:
+                ms, pairs = sum(p["ms"] for p in gp), sum(p["pairs"] for p in gp)
+                sweep["geo_kernel"] = {"achieved": pairs * F_FWD / (ms * 1e-3) / 1e12, "frac": pairs * F_FWD / (ms * 1e-3) / 1e12 / PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
+                                       "pairs": pairs, "kernel_ms_total": ms}
+        res["sdf_eval_sweep"] = sweep
+        res["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else eval_cpu_baseline(scene, min(args.cpu_rays, 128))
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.mode == "eval":
+        return main_eval(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -196,11 +196,14 @@ int spf_geo_clock_read(uint64_t* out12, int32_t reset);
 
 /* Backward of the weighted mean w.r.t. the geometry latents:
  *   g_feat_geo[nbr(q), :] += g_sdf[row(q)] * wn[q] * jac[q,:]   (float atomics)
- * (F_geometry / T are frozen in the reference's training, train.py:151-154.) */
+ * (F_geometry / T are frozen in the reference's training, train.py:151-154.)
+ * Optional, in the same launch: the gradient w.r.t. the query positions, g_x[row,:] = g_sdf[row] * grad_x[row,:] for row < n_rows
+ * (grad_x = spf_geo_forward's `grad`; the RBF weights are detached, pointneus_disent.py:242) — what autograd's backward of the
+ * pseudo-point SDF needs (pointneus_disent.py:765-780); g_x NULL: skipped. */
 int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* jac, const int32_t* nbr,
                              const int32_t* point_slot, const int32_t* pair_off, const int32_t* pair_point,
                              const int32_t* n_pairs, int32_t max_pairs, int32_t k, float* g_feat_geo,
-                             int64_t* g_feat_geo_fixed, void* stream);
+                             int64_t* g_feat_geo_fixed, const float* grad_x, float* g_x, int32_t n_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused colour-feature path — replaces the F_color half of get_color,
@@ -215,9 +218,11 @@ int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* j
 
 int64_t spf_color_packed_floats(void);
 
-/* Pack F_color.{0,2,4} ([out,in] row-major) into forward and transposed fragment order. */
+/* Pack F_color.{0,2,4} ([out,in] row-major) into forward and transposed fragment order.
+ * zero_buf (may be NULL; 16-byte aligned) / zero_floats: a buffer cleared in the same launch — the agg3 accumulator spf_color_forward adds
+ * into (the weights change every optimisation step, so this launch precedes every forward anyway). */
 int spf_color_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4,
-                   const float* b4, float* packed, void* stream);
+                   const float* b4, float* packed, float* zero_buf, int64_t zero_floats, void* stream);
 
 /* agg3[p, 256] += sum_j wn[q] * a3_q,  a3 = lrelu(F_color.4(lrelu(F_color.2(lrelu(F_color.0([posenc6(x[row] - pts[nbr]) |
  * feat_color[nbr]])))))) over the pairs q of the p-th valid point (pair lists from spf_build_pairs, wn from
@@ -251,8 +256,9 @@ int spf_color_backward(const float* g_agg3, const int32_t* nbr, const float* wn,
  * sums of g_agg / G1 / G2 and come from spf_wgrad's dbias output; with SPF_ARITH_F32 spf_rhead_backward accumulates them. */
 
 int64_t spf_rhead_packed_floats(void);
+/* zero_buf / zero_floats: as spf_color_pack — here the dense colors [rows,3] array spf_rhead_forward scatters into (0 at invalid slots). */
 int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const float* b0, const float* w2, const float* b2,
-                   const float* w4, const float* b4, float* packed, void* stream);
+                   const float* w4, const float* b4, float* packed, float* zero_buf, int64_t zero_floats, void* stream);
 
 /* colors[row,3] = sigmoid(R([direnc3(ray_dirs[row / SR]) | W6 agg3[p] + b6])) for the p-th valid point, row = point_slot[p]
  * (rows of invalid points untouched: pre-fill with 0).  Training mode (direnc != NULL) stores, per point
@@ -316,19 +322,25 @@ int spf_filter_points(const float* loc, const uint8_t* slot_valid, const float* 
 
 /* sigma = Laplace(sdf; *beta) at valid slots, E = delta sigma, w = (1 - e^-E) exp(-sum_{i<j} E_i);
  * rgb = sum w c, depth = sum w z / (sum w + 1e-8), dist = sum w z / (sum w + 1e-10), acc = sum w.
- * colors [R,SR,3] must be 0 at invalid slots; beta is a DEVICE scalar (|beta_param| + beta_min). */
+ * colors [R,SR,3] must be 0 at invalid slots; beta is a DEVICE scalar (|beta_param| + beta_min).
+ * pts_rendered [R,3] (may be NULL; needs cam_loc / ray_dirs [R,3]): the rendered surface points cam_loc + ray_dirs * dist the
+ * pseudo-point loss queries (pointneus_disent.py:765-767), formed here instead of by a separate elementwise launch. */
 int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas,
                        const float* colors, const float* beta, int32_t R, int32_t SR, float* weights,
-                       float* rgb, float* depth, float* dist, float* acc, void* stream);
+                       float* rgb, float* depth, float* dist, float* acc, const float* cam_loc, const float* ray_dirs,
+                       float* pts_rendered, void* stream);
 
 /* Gradients of a scalar loss given g_weights [R,SR] (may be NULL), g_rgb [R,3], g_depth [R] (may be
  * NULL), g_dist [R] (may be NULL): g_sdf [R,SR], g_colors [R,SR,3], and g_beta[0] += dL/d beta — or, when the raw
  * LaplaceDensity parameter is passed in beta_param (beta = |beta_param| + beta_min, spurfies/model/density.py:28-30),
- * g_beta[0] += sign(beta_param) dL/d beta, i.e. the parameter's own gradient. */
+ * g_beta[0] += sign(beta_param) dL/d beta, i.e. the parameter's own gradient.
+ * g_acc [R] (may be NULL): gradient of acc = sum_j w_j, added to every slot's g_weights; g_pts_rendered [R,3] (may be NULL; needs
+ * ray_dirs): gradient of spf_render_forward's pts_rendered, entering through dist (g_dist[r] += g_pts_rendered[r] . ray_dirs[r]). */
 int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas,
                         const float* colors, const float* beta, const float* weights, const float* g_weights,
                         const float* g_rgb, const float* g_depth, const float* g_dist, int32_t R, int32_t SR,
-                        float* g_sdf, float* g_colors, float* g_beta, const float* beta_param, void* stream);
+                        float* g_sdf, float* g_colors, float* g_beta, const float* beta_param, const float* g_acc,
+                        const float* g_pts_rendered, const float* ray_dirs, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight-gradient GEMM with a device-side row count — replaces autograd's AddmmBackward GEMMs for the
@@ -350,9 +362,14 @@ int64_t spf_wgrad_workspace_floats(int32_t C);
 #define SPF_WGRAD_G_TILES64 4
 
 /* dbias (may be NULL): float[256], dbias[o] += sum_rows G[row][o] — the bias gradient of the same layer, taken on the way
- * (free in the default arithmetic; a separate pass over G otherwise). */
+ * (free in the default arithmetic; a separate pass over G otherwise).
+ * col_rot / col_mod (0 / 0 = off; SPF_ARITH_SPLIT, C > 32): product column i < col_mod is accumulated into dW column
+ * (i + col_rot) mod col_mod, columns i >= col_mod are dropped (ldw >= col_mod).  F_color.0's input is held as [latent 64 | offset 3 |
+ * encoding 36 | pad] by the colour kernels and as [offset + encoding 39 | latent 64] by the reference (pointneus_disent.py:327-331): with
+ * col_rot 39, col_mod 103 the 104-wide product lands in the reference's column order without a permutation pass. */
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows,
-              float* dW, int32_t ldw, float* dbias, float* workspace, int32_t layout, int32_t arith, void* stream);
+              float* dW, int32_t ldw, float* dbias, float* workspace, int32_t layout, int32_t arith, int32_t col_rot,
+              int32_t col_mod, void* stream);
 
 /* Up to three C = 256 weight-gradient GEMMs over the SAME rows (n_rows / max_rows) in one pair of launches: dW_q += G_q^T A_q,
  * dbias_q += column sums of G_q (may be NULL).  The head stage's three GEMMs have K = valid points: launched one after the other
@@ -382,7 +399,8 @@ int spf_scatter_add_rows(const float* src, const int32_t* idx, int64_t m, int32_
  * (spurfies/model/utils.py:221-282): nbr[n,k] int32 (any valid index where w == 0), w[n,k] inverse-
  * distance weights (0 = absent), norm[n] = sum_j w.  tv[i] = sum_j w_ij |f_j - f_i|_1 / norm_i
  * (the caller takes the mean).  Backward accumulates into g_feat_geo[n,32] (float atomics); the upstream gradient of tv_i is
- * g_tv[i * g_tv_stride] * scale (stride 0 + scale 1/n: the gradient of the mean, one device scalar for all points). */
+ * g_tv[i * g_tv_stride] * scale (stride 0 + scale 1/n: the gradient of the mean, one device scalar for all points).
+ * The mean over the points (`tv_regul`'s return value, utils.py:282) is the caller's: spf_loss_forward takes the tv[n] array itself. */
 int spf_tv_forward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm, int32_t n,
                    int32_t k, float* tv, void* stream);
 int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, const float* norm,
@@ -412,9 +430,13 @@ int spf_fixed_accumulate(int64_t* acc, float* dst, int64_t n, void* stream);
  *   cam_loc [R,3]     the camera centre repeated per ray
  *   depth_scale [R]   z of the camera-space unit direction (the model's `depth_scale`)
  * Replaces rend_util.get_camera_params + lift (spurfies/utils/rend_util.py:60-95,143-156) as called twice per forward
- * at spurfies/model/pointneus_disent.py:640-650 (batch of one view, matrix poses). */
+ * at spurfies/model/pointneus_disent.py:640-650 (batch of one view, matrix poses).
+ * beta_out (DEVICE scalar, may be NULL; needs beta_param): the forward's effective Laplace scale |*beta_param| + beta_min
+ * (LaplaceDensity.get_beta, spurfies/model/density.py:28-30), which the sampler and the compositing kernels of the same forward read —
+ * formed by this first launch of the forward instead of two elementwise launches. */
 int spf_camera_rays(const float* uv, const float* pose, const float* intrinsics, int32_t k_stride, int32_t R,
-                    float* ray_dirs, float* cam_loc, float* depth_scale, void* stream);
+                    float* ray_dirs, float* cam_loc, float* depth_scale, const float* beta_param, float beta_min,
+                    float* beta_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Loss terms of one optimisation step — replaces VolSDFLoss.forward (spurfies/model/loss.py:42-49,
@@ -429,22 +451,24 @@ int64_t spf_loss_workspace_floats(void);
 
 /* rgb, rgb_gt [R,3]; acc [R] = sum_j w_j; mask_gt[r * mask_stride], r < R; grad [rows,3] + slot_valid [rows] (d sdf/dx of the shading slots;
  * NULL skips the eikonal term) with n_points[0] = number of valid slots (device); psdf [R] SDF at the rendered points with
- * pvalid / ray_valid [R] (NULL skips the pseudo term); tv = device scalar (NULL: 0); denom = NULL or device
+ * pvalid / ray_valid [R] (NULL skips the pseudo term); tv (NULL: 0) = the TV term: with n_tv = 0 a device scalar (the mean itself), with
+ * n_tv > 0 spf_tv_forward's per-point array tv[n_tv], whose mean (utils.py:282) is formed here; denom = NULL or device
  * {R_total, P_total, pseudo_count_total} (global counts of a ray-sharded batch).
  *   total[0]  the weighted loss;   terms[8] = {loss, rgb, eikonal, tv, mask, local, pseudo, local pseudo count}
  *   den[4]    normalisers for spf_loss_backward.   workspace: spf_loss_workspace_floats() floats. */
 int spf_loss_forward(const float* rgb, const float* rgb_gt, const float* acc, const float* mask_gt, int32_t mask_stride,
                      const float* grad, const uint8_t* slot_valid, int64_t rows, const int32_t* n_points, const float* psdf,
-                     const uint8_t* pvalid, const uint8_t* ray_valid, const float* tv, const float* denom, int32_t R,
+                     const uint8_t* pvalid, const uint8_t* ray_valid, const float* tv, int32_t n_tv, const float* denom, int32_t R,
                      const spf_loss_weights* weights, float* workspace, float* total, float* terms, float* den,
                      void* stream);
 
-/* g_total = dL/d total (device scalar) -> g_rgb [R,3], g_acc [R], g_psdf [R] (may be NULL), g_tv[0] (may be NULL).
+/* g_total = dL/d total (device scalar) -> g_rgb [R,3], g_acc [R], g_psdf [R] (may be NULL), g_tv[0] (may be NULL): the gradient w.r.t. the
+ * TV mean (n_tv = 0) or w.r.t. every tv[i] of the per-point array (n_tv > 0: the mean's gradient / n_tv, one scalar for all points).
  * The eikonal term has no gradient w.r.t. any trainable tensor. */
 int spf_loss_backward(const float* g_total, const float* den, const spf_loss_weights* weights, const float* rgb,
                       const float* rgb_gt, const float* acc, const float* mask_gt, int32_t mask_stride, const float* psdf,
                       const uint8_t* pvalid, const uint8_t* ray_valid, int32_t R, float* g_rgb, float* g_acc,
-                      float* g_psdf, float* g_tv, void* stream);
+                      float* g_psdf, float* g_tv, int32_t n_tv, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Parameter update — replaces the tail of the reference's train step (spurfies/train.py:359-363, 548-564):
@@ -456,10 +480,12 @@ int64_t spf_adam_workspace_floats(void);
  *   norm = |grad|_2.  Not finite: nothing is written except state[1] += 1 (the reference then "does not update").
  *   Otherwise grad *= min(1, max_norm / (norm + 1e-6)) in place (max_norm <= 0: no clipping), t = ++state[0], and
  *   exp_avg, exp_avg_sq, param advance as torch.optim.Adam does (no weight decay, no amsgrad).
+ * zero_grads != 0: grad is left ZERO instead (also when the update was skipped) — the next step's optimizer.zero_grad() (train.py:357)
+ *   folded into this sweep; the clipped gradient is then not observable afterwards.
  * state: device float[4] = {t, skipped steps, last norm, last clip coefficient}, zero-initialised by the caller.
- * workspace: spf_adam_workspace_floats() floats.  No host synchronisation. */
+ * workspace: spf_adam_workspace_floats() floats.  Three launches, no host synchronisation. */
 int spf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
-                  double beta2, double eps, double max_norm, float* state, float* workspace, void* stream);
+                  double beta2, double eps, double max_norm, int32_t zero_grads, float* state, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -54,34 +54,34 @@ SIGNATURES = {
     "spf_build_pairs": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "spf_geo_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P]),
     "spf_geo_clock_read": (C.c_int, [_P, _I]),
-    "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "spf_geo_backward_latents": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P]),
     "spf_color_packed_floats": (C.c_int64, []),
-    "spf_color_pack": (C.c_int, [_P] * 8),
+    "spf_color_pack": (C.c_int, [_P] * 8 + [C.c_int64, _P]),
     "spf_color_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_color_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_rhead_packed_floats": (C.c_int64, []),
-    "spf_rhead_pack": (C.c_int, [_P] * 10),
+    "spf_rhead_pack": (C.c_int, [_P] * 10 + [C.c_int64, _P]),
     "spf_rhead_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_rhead_backward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_sampler_uniform": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
     "spf_sampler_iter": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _I, _P, _P, _P, _P, _P]),
     "spf_sampler_finish": (C.c_int, [_P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _I, _P, _P, _P]),
     "spf_filter_points": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
-    "spf_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "spf_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "spf_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_wgrad_workspace_floats": (C.c_int64, [_I]),
-    "spf_wgrad": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P]),
+    "spf_wgrad": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "spf_wgrad_batched": (C.c_int, [C.POINTER(WgradProblem), _I, _P, _I, _P, _I, _P]),
     "spf_scatter_add_rows": (C.c_int, [_P, _P, C.c_int64, _I, _P, _P]),
     "spf_tv_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P]),
     "spf_fixed_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
-    "spf_camera_rays": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "spf_camera_rays": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P]),
     "spf_adam_workspace_floats": (C.c_int64, []),
-    "spf_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
+    "spf_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P, _P, _P]),
     "spf_loss_workspace_floats": (C.c_int64, []),
-    "spf_loss_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _I, C.POINTER(LossWeights), _P, _P, _P, _P, _P]),
-    "spf_loss_backward": (C.c_int, [_P, _P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "spf_loss_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _I, _P, _I, C.POINTER(LossWeights), _P, _P, _P, _P, _P]),
+    "spf_loss_backward": (C.c_int, [_P, _P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
 }
 
 _lib = None

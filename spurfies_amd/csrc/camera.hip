@@ -10,8 +10,10 @@ namespace {
 using namespace spf;
 
 __global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __restrict__ pose, const float* __restrict__ K, int kstride,
-                                   int R, float* __restrict__ ray_dirs, float* __restrict__ cam_loc, float* __restrict__ depth_scale) {
+                                   int R, float* __restrict__ ray_dirs, float* __restrict__ cam_loc, float* __restrict__ depth_scale,
+                                   const float* __restrict__ beta_param, float beta_min, float* __restrict__ beta_out) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0 && beta_out) *beta_out = fabsf(*beta_param) + beta_min;      // LaplaceDensity.get_beta (density.py:28-30), once per forward
     if (r >= R) return;
     const float fx = K[0], sk = K[1], cx = K[2], fy = K[kstride + 1], cy = K[kstride + 2];
     const float x = uv[2 * r], y = uv[2 * r + 1];
@@ -41,11 +43,13 @@ __global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __
 extern "C" {
 
 int spf_camera_rays(const float* uv, const float* pose, const float* intrinsics, int32_t k_stride, int32_t R, float* ray_dirs,
-                    float* cam_loc, float* depth_scale, void* stream) {
+                    float* cam_loc, float* depth_scale, const float* beta_param, float beta_min, float* beta_out, void* stream) {
     if (R < 0 || (k_stride != 3 && k_stride != 4)) return spf::fail(SPF_EINVAL, "spf_camera_rays: k_stride must be 3 or 4 (got %d)", k_stride);
     if (R == 0) return SPF_OK;
     if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || !depth_scale) return spf::fail(SPF_EINVAL, "spf_camera_rays: null pointer");
-    camera_rays_kernel<<<spf::div_up(R, 256), 256, 0, (hipStream_t)stream>>>(uv, pose, intrinsics, k_stride, R, ray_dirs, cam_loc, depth_scale);
+    if (beta_out && !beta_param) return spf::fail(SPF_EINVAL, "spf_camera_rays: beta_out needs beta_param");
+    camera_rays_kernel<<<spf::div_up(R, 256), 256, 0, (hipStream_t)stream>>>(uv, pose, intrinsics, k_stride, R, ray_dirs, cam_loc, depth_scale,
+                                                                             beta_param, beta_min, beta_out);
     SPF_LAUNCH_CHECK("camera_rays_kernel");
     return SPF_OK;
 }

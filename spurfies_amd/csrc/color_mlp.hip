@@ -1045,10 +1045,17 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
 
 
 // both images in one launch (the weights change every optimisation step: the packing is on the step's critical path)
-__global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out) {
+__global__ void color_pack_kernel(CPackArgs a, float* __restrict__ out, float* __restrict__ zero_buf, long long zero_floats) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     color_pack_kernel_body(a, out, e);
     color_pack_x3_kernel_body(a, reinterpret_cast<bf16x8*>(out + C_PACKED), e);
+    // optional: clear a buffer the following forward accumulates into (atomics) / scatters into — its fill launch rides along
+    if (zero_buf) {
+        f32x4* z4 = reinterpret_cast<f32x4*>(zero_buf);
+        const long long n4 = zero_floats >> 2, stride = (long long)gridDim.x * blockDim.x;
+        for (long long i = e; i < n4; i += stride) z4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (e < (int)(zero_floats & 3)) zero_buf[(n4 << 2) + e] = 0.f;
+    }
 }
 
 }  // namespace
@@ -1060,11 +1067,12 @@ extern "C" {
 int64_t spf_color_packed_floats(void) { return C_PACKED_TOTAL; }
 
 int spf_color_pack(const float* w0, const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
-                   float* packed, void* stream) {
+                   float* packed, float* zero_buf, int64_t zero_floats, void* stream) {
     if (!w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !packed) return spf::fail(SPF_EINVAL, "spf_color_pack: null pointer");
+    if (zero_floats < 0 || (zero_buf && ((uintptr_t)zero_buf & 15))) return spf::fail(SPF_EINVAL, "spf_color_pack: zero_buf must be 16-byte aligned, zero_floats >= 0");
     CPackArgs a{w0, b0, w2, b2, w4, b4};
     constexpr int NTH = C_PACKED > CX_FRAGS / 3 ? C_PACKED : CX_FRAGS / 3;
-    color_pack_kernel<<<spf::div_up(NTH, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
+    color_pack_kernel<<<spf::div_up(NTH, 256), 256, 0, (hipStream_t)stream>>>(a, packed, zero_buf, (long long)zero_floats);
     SPF_LAUNCH_CHECK("color_pack_kernel");
     return SPF_OK;
 }

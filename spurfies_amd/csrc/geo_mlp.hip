@@ -363,7 +363,11 @@ __global__ void __launch_bounds__(256)
 geo_backward_latents_kernel(const float* __restrict__ g_sdf, const float* __restrict__ wn, const float* __restrict__ jac,
                             const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off,
                             const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev, int max_pairs, int k,
-                            float* __restrict__ g_feat, long long* __restrict__ g_fixed) {
+                            float* __restrict__ g_feat, long long* __restrict__ g_fixed, const float* __restrict__ grad_x,
+                            float* __restrict__ g_x, int n_rows) {
+    if (g_x) {      // d L / d x[row] = g_sdf[row] * d sdf / d x[row] (the RBF weights are detached): rides along, one element per thread
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 3 * n_rows; e += gridDim.x * blockDim.x) g_x[e] = g_sdf[e / 3] * grad_x[e];
+    }
     constexpr int LDL = SPF_GEO_DIM + 4;                                  // row stride of L in floats (16-byte aligned, off the bank period)
     __shared__ __attribute__((aligned(16))) float L[64 * LDL];
     __shared__ __attribute__((aligned(16))) int s_idx[64];
@@ -1292,15 +1296,18 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
 
 int spf_geo_backward_latents(const float* g_sdf, const float* wn, const float* jac, const int32_t* nbr, const int32_t* point_slot,
                              const int32_t* pair_off, const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k,
-                             float* g_feat_geo, int64_t* g_feat_geo_fixed, void* stream) {
-    if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: bad sizes");
-    if (max_pairs == 0) return SPF_OK;
+                             float* g_feat_geo, int64_t* g_feat_geo_fixed, const float* grad_x, float* g_x, int32_t n_rows, void* stream) {
+    if (max_pairs < 0 || k < 1 || k > SPF_KMAX || n_rows < 0) return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: bad sizes");
+    if (g_x && !grad_x) return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: g_x needs grad_x");
+    if (max_pairs == 0 && !(g_x && n_rows > 0)) return SPF_OK;
     if (!g_sdf || !wn || !jac || !nbr || !pair_off || !pair_point || (!g_feat_geo && !g_feat_geo_fixed))
         return spf::fail(SPF_EINVAL, "spf_geo_backward_latents: null pointer");
     int blocks = spf::div_up(max_pairs, 64);                              // one workgroup per 64-pair tile, grid-strided
     if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
     geo_backward_latents_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_sdf, wn, jac, nbr, point_slot, pair_off, pair_point, n_pairs,
-                                                                         max_pairs, k, g_feat_geo, reinterpret_cast<long long*>(g_feat_geo_fixed));
+                                                                         max_pairs, k, g_feat_geo, reinterpret_cast<long long*>(g_feat_geo_fixed),
+                                                                         grad_x, g_x, n_rows);
     SPF_LAUNCH_CHECK("geo_backward_latents_kernel");
     return SPF_OK;
 }

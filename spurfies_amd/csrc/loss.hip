@@ -20,13 +20,13 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// partial[b] = {sum |rgb - gt|, sum BCE, sum_valid (|g| - 1)^2, sum_use |psdf|, sum use, 0, 0, 0} over block b's grid-stride share
+// partial[b] = {sum |rgb - gt|, sum BCE, sum_valid (|g| - 1)^2, sum_use |psdf|, sum use, sum tv_i, 0, 0} over block b's grid-stride share
 __global__ void __launch_bounds__(256)
 loss_partials_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb_gt, const float* __restrict__ acc,
                      const float* __restrict__ mask_gt, int mstride, const float* __restrict__ grad, const uint8_t* __restrict__ slot_valid,
                      const float* __restrict__ psdf, const uint8_t* __restrict__ pvalid, const uint8_t* __restrict__ ray_valid, int R,
-                     long long rows, float* __restrict__ partial) {
-    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+                     long long rows, const float* __restrict__ tv, int n_tv, float* __restrict__ partial) {
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (long long r = t0; r < R; r += stride) {
@@ -45,30 +45,31 @@ loss_partials_kernel(const float* __restrict__ rgb, const float* __restrict__ rg
                 const float d = sqrtf(gx * gx + gy * gy + gz * gz) - 1.f;
                 s[2] += d * d;
             }
-    __shared__ float red[4][5];
+    for (long long i = t0; i < n_tv; i += stride) s[5] += tv[i];            // the per-point TV terms (spf_tv_forward): their mean is formed here
+    __shared__ float red[4][6];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 6; ++i) {
         const float v = wave_sum(s[i]);
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
     if (threadIdx.x < NPART)
         partial[blockIdx.x * NPART + threadIdx.x] =
-            threadIdx.x < 5 ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
+            threadIdx.x < 6 ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
 }
 
 // out = {loss, rgb, eikonal, tv, mask, local, pseudo, pseudo count};  den = {1/(3 R), 1/R, 1/pseudo count or 0, 1/world}
 __global__ void __launch_bounds__(64)
-loss_finalize_kernel(const float* __restrict__ partial, int nblk, int R, const int32_t* __restrict__ n_points, const float* __restrict__ tv,
+loss_finalize_kernel(const float* __restrict__ partial, int nblk, int R, const int32_t* __restrict__ n_points, const float* __restrict__ tv, int n_tv,
                      const float* __restrict__ denom, spf_loss_weights w, float* __restrict__ total, float* __restrict__ out,
                      float* __restrict__ den) {
-    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < nblk; b += 64)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) s[i] += partial[b * NPART + i];
+        for (int i = 0; i < 6; ++i) s[i] += partial[b * NPART + i];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) s[i] = wave_sum(s[i]);
+    for (int i = 0; i < 6; ++i) s[i] = wave_sum(s[i]);
     if (threadIdx.x != 0) return;
     const float G = (float)(w.world > 0 ? w.world : 1);
     const float R_tot = denom ? denom[0] : (float)R;
@@ -77,7 +78,7 @@ loss_finalize_kernel(const float* __restrict__ partial, int nblk, int R, const i
     const float l_rgb = s[0] / (3.0f * R_tot);
     const float l_mask = s[1] / R_tot;
     const float l_eik = s[2] / P_tot;
-    const float l_tv = (tv && w.tv > 0.f) ? *tv / G : 0.f;
+    const float l_tv = (tv && w.tv > 0.f) ? (n_tv > 0 ? s[5] / (float)n_tv : *tv) / G : 0.f;      // n_tv > 0: tv is the per-point array, else the mean itself
     // no rendered point with a neighbour on any rank: the reference's constant 1000 (pointneus_disent.py:776-780)
     const float l_pseudo = w.pseudo > 0.f ? (ps_tot > 0.f ? s[3] / ps_tot : 1000.0f / G) : 0.f;
     const float l_local = 0.f;
@@ -91,10 +92,11 @@ __global__ void loss_backward_kernel(const float* __restrict__ g_total, const fl
                                      const float* __restrict__ rgb, const float* __restrict__ rgb_gt, const float* __restrict__ acc,
                                      const float* __restrict__ mask_gt, int mstride, const float* __restrict__ psdf, const uint8_t* __restrict__ pvalid,
                                      const uint8_t* __restrict__ ray_valid, int R, float* __restrict__ g_rgb, float* __restrict__ g_acc,
-                                     float* __restrict__ g_psdf, float* __restrict__ g_tv) {
+                                     float* __restrict__ g_psdf, float* __restrict__ g_tv, int n_tv) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const float g = *g_total;
-    if (r == 0 && g_tv) *g_tv = w.tv > 0.f ? g * w.tv * den[3] : 0.f;
+    // d loss / d (TV mean), or — n_tv > 0 — d loss / d tv_i, the same for every point
+    if (r == 0 && g_tv) *g_tv = w.tv > 0.f ? g * w.tv * den[3] / (n_tv > 0 ? (float)n_tv : 1.f) : 0.f;
     if (r >= R) return;
     const float c_rgb = g * w.rgb * den[0];
 #pragma unroll
@@ -125,30 +127,32 @@ int64_t spf_loss_workspace_floats(void) { return (int64_t)MAX_BLOCKS * NPART; }
 
 int spf_loss_forward(const float* rgb, const float* rgb_gt, const float* acc, const float* mask_gt, int32_t mask_stride, const float* grad,
                      const uint8_t* slot_valid, int64_t rows, const int32_t* n_points, const float* psdf, const uint8_t* pvalid,
-                     const uint8_t* ray_valid, const float* tv, const float* denom, int32_t R, const spf_loss_weights* weights,
+                     const uint8_t* ray_valid, const float* tv, int32_t n_tv, const float* denom, int32_t R, const spf_loss_weights* weights,
                      float* workspace, float* total, float* terms, float* den, void* stream) {
-    if (R <= 0 || rows < 0 || !weights || mask_stride < 1) return spf::fail(SPF_EINVAL, "spf_loss_forward: need R > 0, rows >= 0, mask_stride >= 1, weights");
+    if (R <= 0 || rows < 0 || !weights || mask_stride < 1 || n_tv < 0) return spf::fail(SPF_EINVAL, "spf_loss_forward: need R > 0, rows >= 0, mask_stride >= 1, n_tv >= 0, weights");
     if (!rgb || !rgb_gt || !acc || !mask_gt || !workspace || !total || !terms || !den)
         return spf::fail(SPF_EINVAL, "spf_loss_forward: null pointer");
     if (grad && !slot_valid) return spf::fail(SPF_EINVAL, "spf_loss_forward: grad needs slot_valid");
     if (psdf && (!pvalid || !ray_valid)) return spf::fail(SPF_EINVAL, "spf_loss_forward: psdf needs pvalid and ray_valid");
     hipStream_t s = (hipStream_t)stream;
-    const long long work = grad ? (rows > R ? rows : R) : R;
+    long long work = grad ? (rows > R ? rows : R) : R;
+    if (tv && n_tv > work) work = n_tv;
     int nblk = spf::div_up(work, 256 * 4);
     nblk = nblk < 1 ? 1 : (nblk > MAX_BLOCKS ? MAX_BLOCKS : nblk);
-    loss_partials_kernel<<<nblk, 256, 0, s>>>(rgb, rgb_gt, acc, mask_gt, mask_stride, grad, slot_valid, psdf, pvalid, ray_valid, R, rows, workspace);
-    loss_finalize_kernel<<<1, 64, 0, s>>>(workspace, nblk, R, n_points, tv, denom, *weights, total, terms, den);
+    loss_partials_kernel<<<nblk, 256, 0, s>>>(rgb, rgb_gt, acc, mask_gt, mask_stride, grad, slot_valid, psdf, pvalid, ray_valid, R, rows, tv, tv ? n_tv : 0,
+                                           workspace);
+    loss_finalize_kernel<<<1, 64, 0, s>>>(workspace, nblk, R, n_points, tv, n_tv, denom, *weights, total, terms, den);
     SPF_LAUNCH_CHECK("loss_forward");
     return SPF_OK;
 }
 
 int spf_loss_backward(const float* g_total, const float* den, const spf_loss_weights* weights, const float* rgb, const float* rgb_gt,
                       const float* acc, const float* mask_gt, int32_t mask_stride, const float* psdf, const uint8_t* pvalid, const uint8_t* ray_valid,
-                      int32_t R, float* g_rgb, float* g_acc, float* g_psdf, float* g_tv, void* stream) {
+                      int32_t R, float* g_rgb, float* g_acc, float* g_psdf, float* g_tv, int32_t n_tv, void* stream) {
     if (R <= 0 || !weights) return spf::fail(SPF_EINVAL, "spf_loss_backward: need R > 0, weights");
     if (!g_total || !den || !rgb || !rgb_gt || !acc || !mask_gt || !g_rgb || !g_acc) return spf::fail(SPF_EINVAL, "spf_loss_backward: null pointer");
     loss_backward_kernel<<<spf::div_up(R, 256), 256, 0, (hipStream_t)stream>>>(g_total, den, *weights, rgb, rgb_gt, acc, mask_gt, mask_stride, psdf, pvalid,
-                                                                               ray_valid, R, g_rgb, g_acc, g_psdf, g_tv);
+                                                                               ray_valid, R, g_rgb, g_acc, g_psdf, g_tv, n_tv);
     SPF_LAUNCH_CHECK("loss_backward_kernel");
     return SPF_OK;
 }

@@ -4,8 +4,11 @@
 //                    torch.nn.utils.clip_grad_norm_(parameters, 1.0)   -> grad *= min(1, max_norm / (|grad|_2 + 1e-6))
 //                    on_after_backward()  (NaN / Inf gradient guard)   -> the update is skipped, nothing changes
 //                    optimizer.step()     (torch.optim.Adam defaults)  -> exp_avg, exp_avg_sq, param
-//                  as three launches (partial sums of squares, one control block, one elementwise sweep) instead of
-//                  ~25 foreach / reduction launches; every decision stays on the device (no host synchronisation).
+//                  as three launches (partial sums of squares, one control block, one elementwise sweep) instead of ~25 foreach /
+//                  reduction launches; every decision stays on the device (no host synchronisation).  (Folding the control block into the
+//                  "last block to finish" of the first launch was measured SLOWER on MI355X: 21.7 us against 6.3 + 6.6 — a device-scope
+//                  release / acquire per block writes back and invalidates the XCD's L2, the eight XCDs have one each.)  zero_grads: the sweep also clears the gradient buffer behind itself — the next step's
+//                  optimizer.zero_grad() (train.py:357) without its fill launch.
 #include <math.h>
 
 #include "common.h"
@@ -15,6 +18,40 @@ using namespace spf;
 
 constexpr int NORM_BLOCKS = 512;
 
+struct AdamCtl {
+    double lr, beta1, beta2, max_norm;
+};
+
+// ctl = {clip coefficient, finite flag, step size lr / (1 - beta1^t), sqrt(1 - beta2^t)};  state = {t, skipped, norm, coefficient}
+__device__ void adam_control(const float* __restrict__ partial, int nblk, const AdamCtl& a, float* __restrict__ state, float* __restrict__ ctl) {
+    // one wave, fixed order: lane l sums partials l, l + 64, ... in double, then a butterfly
+    double s = 0.0;
+    const int lane = threadIdx.x & 63;
+    for (int b = lane; b < nblk; b += 64) s += (double)partial[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane != 0) return;
+    const float norm = (float)sqrt(s);
+    const bool finite = isfinite(norm);
+    float coef = 1.f;
+    if (a.max_norm > 0.0) coef = fminf((float)a.max_norm / (norm + 1e-6f), 1.0f);    // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+    float t = state[0];
+    if (finite) t += 1.f; else state[1] += 1.f;
+    state[0] = t;
+    state[2] = norm;
+    state[3] = coef;
+    const double tt = (double)(t > 0.f ? t : 1.f);
+    ctl[0] = coef;
+    ctl[1] = finite ? 1.f : 0.f;
+    ctl[2] = (float)(a.lr / (1.0 - pow(a.beta1, tt)));
+    ctl[3] = (float)sqrt(1.0 - pow(a.beta2, tt));
+}
+
+__global__ void __launch_bounds__(64) adam_control_kernel(const float* __restrict__ partial, int nblk, AdamCtl a, float* __restrict__ state, float* __restrict__ ctl) {
+    adam_control(partial, nblk, a, state, ctl);
+}
+
+// partial[b] = sum of squares of block b's share
 __global__ void __launch_bounds__(256)
 sumsq_partials_kernel(const float* __restrict__ g, long long n, float* __restrict__ partial) {
     float s = 0.f;
@@ -31,40 +68,19 @@ sumsq_partials_kernel(const float* __restrict__ g, long long n, float* __restric
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// ctl = {clip coefficient, finite flag, step size lr / (1 - beta1^t), sqrt(1 - beta2^t)};  state = {t, skipped, norm, coefficient}
-__global__ void __launch_bounds__(64)
-adam_control_kernel(const float* __restrict__ partial, int nblk, double lr, double beta1, double beta2, double max_norm,
-                    float* __restrict__ state, float* __restrict__ ctl) {
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += 64) s += (double)partial[b];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (threadIdx.x != 0) return;
-    const float norm = (float)sqrt(s);
-    const bool finite = isfinite(norm);
-    float coef = 1.f;
-    if (max_norm > 0.0) coef = fminf((float)max_norm / (norm + 1e-6f), 1.0f);        // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
-    float t = state[0];
-    if (finite) t += 1.f; else state[1] += 1.f;
-    state[0] = t;
-    state[2] = norm;
-    state[3] = coef;
-    const double tt = (double)(t > 0.f ? t : 1.f);
-    ctl[0] = coef;
-    ctl[1] = finite ? 1.f : 0.f;
-    ctl[2] = (float)(lr / (1.0 - pow(beta1, tt)));
-    ctl[3] = (float)sqrt(1.0 - pow(beta2, tt));
-}
-
 __global__ void __launch_bounds__(256)
 adam_update_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v, long long n,
-                   float w1 /* 1 - beta1 */, float b2, float w2 /* 1 - beta2 */, float eps, const float* __restrict__ ctl) {
-    if (ctl[1] == 0.f) return;                                    // non-finite gradient: not updating (train.py:560-564)
-    const float coef = ctl[0], step_size = ctl[2], bc2_sqrt = ctl[3];
+                   float w1 /* 1 - beta1 */, float b2, float w2 /* 1 - beta2 */, float eps, const float* __restrict__ ctl, int zero_grads) {
     const long long stride = (long long)gridDim.x * blockDim.x;
+    if (ctl[1] == 0.f) {                                          // non-finite gradient: not updating (train.py:560-564)
+        if (zero_grads)
+            for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) grad[i] = 0.f;
+        return;
+    }
+    const float coef = ctl[0], step_size = ctl[2], bc2_sqrt = ctl[3];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float g = grad[i] * coef;
-        grad[i] = g;                                              // clip_grad_norm_ scales the gradients in place
+        grad[i] = zero_grads ? 0.f : g;                           // clip_grad_norm_ scales the gradients in place; or: cleared for the next step
         float mi = m[i], vi = v[i];
         mi = mi + w1 * (g - mi);                                  // exp_avg.lerp_(grad, 1 - beta1)
         vi = vi * b2;                                             // exp_avg_sq.mul_(beta2)
@@ -83,7 +99,7 @@ extern "C" {
 int64_t spf_adam_workspace_floats(void) { return NORM_BLOCKS + 4; }
 
 int spf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
-                  double max_norm, float* state, float* workspace, void* stream) {
+                  double max_norm, int32_t zero_grads, float* state, float* workspace, void* stream) {
     if (n < 0 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0))
         return spf::fail(SPF_EINVAL, "spf_adam_step: need n >= 0, 0 <= beta < 1, eps >= 0");
     if (n == 0) return SPF_OK;
@@ -93,10 +109,10 @@ int spf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
     nblk = nblk < 1 ? 1 : (nblk > NORM_BLOCKS ? NORM_BLOCKS : nblk);
     float* ctl = workspace + NORM_BLOCKS;
     sumsq_partials_kernel<<<nblk, 256, 0, s>>>(grad, n, workspace);
-    adam_control_kernel<<<1, 64, 0, s>>>(workspace, nblk, lr, beta1, beta2, max_norm, state, ctl);
+    adam_control_kernel<<<1, 64, 0, s>>>(workspace, nblk, AdamCtl{lr, beta1, beta2, max_norm}, state, ctl);
     int ublk = spf::div_up(n, 256 * 4);
     ublk = ublk > 2048 ? 2048 : ublk;
-    adam_update_kernel<<<ublk, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, ctl);
+    adam_update_kernel<<<ublk, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, ctl, zero_grads ? 1 : 0);
     SPF_LAUNCH_CHECK("spf_adam_step");
     return SPF_OK;
 }

@@ -76,7 +76,9 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const float* __rest
                                                              const float* __restrict__ z, const float* __restrict__ deltas,
                                                              const float* __restrict__ colors, const float* __restrict__ beta_p,
                                                              int R, int SR, float* __restrict__ weights, float* __restrict__ rgb,
-                                                             float* __restrict__ depth, float* __restrict__ dist, float* __restrict__ acc) {
+                                                             float* __restrict__ depth, float* __restrict__ dist, float* __restrict__ acc,
+                                                             const float* __restrict__ cam_loc, const float* __restrict__ ray_dirs,
+                                                             float* __restrict__ pts_rendered) {
     const int lane = threadIdx.x & 63;
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= R) return;
@@ -113,8 +115,13 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const float* __rest
         rgb[3 * r + 1] = c1;
         rgb[3 * r + 2] = c2;
         depth[r] = N / (W + 1e-8f);
-        dist[r] = N / (W + 1e-10f);
+        const float dm = N / (W + 1e-10f);
+        dist[r] = dm;
         acc[r] = W;
+        if (pts_rendered) {       // pointneus_disent.py:765-767: the rendered surface point o + d * dist_map (multiply, then add)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pts_rendered[3 * r + c] = cam_loc[3 * r + c] + ray_dirs[3 * r + c] * dm;
+        }
     }
 }
 
@@ -129,13 +136,19 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
                                                               const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
                                                               const float* __restrict__ g_dist, int R, int SR,
                                                               float* __restrict__ g_sdf, float* __restrict__ g_colors,
-                                                              float* __restrict__ g_beta, const float* __restrict__ beta_param) {
+                                                              float* __restrict__ g_beta, const float* __restrict__ beta_param,
+                                                              const float* __restrict__ g_acc, const float* __restrict__ g_pts,
+                                                              const float* __restrict__ ray_dirs) {
     const int lane = threadIdx.x & 63;
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= R) return;
     const float beta = *beta_p;
     const float gr0 = g_rgb[3 * r], gr1 = g_rgb[3 * r + 1], gr2 = g_rgb[3 * r + 2];
-    const float gd = g_depth ? g_depth[r] : 0.f, gs = g_dist ? g_dist[r] : 0.f;
+    const float gd = g_depth ? g_depth[r] : 0.f;
+    float gs = g_dist ? g_dist[r] : 0.f;
+    if (g_pts)                    // pts_rendered = o + d * dist: d L / d dist += g_pts . d
+        gs += (g_pts[3 * r] * ray_dirs[3 * r] + g_pts[3 * r + 1] * ray_dirs[3 * r + 1]) + g_pts[3 * r + 2] * ray_dirs[3 * r + 2];
+    const float ga = g_acc ? g_acc[r] : 0.f;          // acc = sum_j w_j: the same gradient for every slot of the ray
     const int nch = (SR + 63) / 64;
     float w_[MAX_CH], z_[MAX_CH], gw_[MAX_CH];
     float W = 0.f, N = 0.f;
@@ -163,7 +176,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
         if (ch < nch && s < SR) {
             const size_t g = (size_t)r * SR + s;
             const float cdot = gr0 * colors[g * 3] + gr1 * colors[g * 3 + 1] + gr2 * colors[g * 3 + 2];
-            gw_[ch] = (g_weights ? g_weights[g] : 0.f) + cdot + gd * (z_[ch] * i8 - N * i8 * i8) + gs * (z_[ch] * i10 - N * i10 * i10);
+            gw_[ch] = ((g_weights ? g_weights[g] : 0.f) + ga) + cdot + gd * (z_[ch] * i8 - N * i8 * i8) + gs * (z_[ch] * i10 - N * i10 * i10);
             P_ += gw_[ch] * w_[ch];
             g_colors[g * 3] = w_[ch] * gr0;
             g_colors[g * 3 + 1] = w_[ch] * gr1;
@@ -230,13 +243,15 @@ int spf_filter_points(const float* loc, const uint8_t* slot_valid, const float* 
 
 int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas, const float* colors,
                        const float* beta, int32_t R, int32_t SR, float* weights, float* rgb, float* depth, float* dist, float* acc,
-                       void* stream) {
+                       const float* cam_loc, const float* ray_dirs, float* pts_rendered, void* stream) {
     if (R < 0 || SR < 1 || SR > 64 * MAX_CH) return spf::fail(SPF_EINVAL, "spf_render_forward: need 1 <= SR <= %d", 64 * MAX_CH);
     if (R == 0) return SPF_OK;
     if (!sdf || !slot_valid || !z || !deltas || !colors || !beta || !weights || !rgb || !depth || !dist || !acc)
         return spf::fail(SPF_EINVAL, "spf_render_forward: null pointer");
+    if (pts_rendered && (!cam_loc || !ray_dirs)) return spf::fail(SPF_EINVAL, "spf_render_forward: pts_rendered needs cam_loc and ray_dirs");
     render_forward_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, (hipStream_t)stream>>>(sdf, slot_valid, z, deltas, colors, beta, R,
-                                                                                                 SR, weights, rgb, depth, dist, acc);
+                                                                                                 SR, weights, rgb, depth, dist, acc, cam_loc,
+                                                                                                 ray_dirs, pts_rendered);
     SPF_LAUNCH_CHECK("render_forward_kernel");
     return SPF_OK;
 }
@@ -244,13 +259,15 @@ int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float*
 int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas, const float* colors,
                         const float* beta, const float* weights, const float* g_weights, const float* g_rgb, const float* g_depth,
                         const float* g_dist, int32_t R, int32_t SR, float* g_sdf, float* g_colors, float* g_beta, const float* beta_param,
-                        void* stream) {
+                        const float* g_acc, const float* g_pts_rendered, const float* ray_dirs, void* stream) {
     if (R < 0 || SR < 1 || SR > 64 * MAX_CH) return spf::fail(SPF_EINVAL, "spf_render_backward: need 1 <= SR <= %d", 64 * MAX_CH);
     if (R == 0) return SPF_OK;
     if (!sdf || !slot_valid || !z || !deltas || !colors || !beta || !weights || !g_rgb || !g_sdf || !g_colors || !g_beta)
         return spf::fail(SPF_EINVAL, "spf_render_backward: null pointer");
+    if (g_pts_rendered && !ray_dirs) return spf::fail(SPF_EINVAL, "spf_render_backward: g_pts_rendered needs ray_dirs");
     render_backward_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, (hipStream_t)stream>>>(
-        sdf, slot_valid, z, deltas, colors, beta, weights, g_weights, g_rgb, g_depth, g_dist, R, SR, g_sdf, g_colors, g_beta, beta_param);
+        sdf, slot_valid, z, deltas, colors, beta, weights, g_weights, g_rgb, g_depth, g_dist, R, SR, g_sdf, g_colors, g_beta, beta_param, g_acc,
+        g_pts_rendered, ray_dirs);
     SPF_LAUNCH_CHECK("render_backward_kernel");
     return SPF_OK;
 }

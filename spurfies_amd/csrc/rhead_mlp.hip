@@ -806,10 +806,17 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
 
 
 // both images in one launch (the weights change every optimisation step: the packing is on the step's critical path)
-__global__ void rhead_pack_kernel(RPackArgs a, float* __restrict__ out) {
+__global__ void rhead_pack_kernel(RPackArgs a, float* __restrict__ out, float* __restrict__ zero_buf, long long zero_floats) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     rhead_pack_kernel_body(a, out, e);
     rhead_pack_x3_kernel_body(a, reinterpret_cast<bf16x8*>(out + R_PACKED), e);
+    // optional: clear a buffer the following forward accumulates into (atomics) / scatters into — its fill launch rides along
+    if (zero_buf) {
+        f32x4* z4 = reinterpret_cast<f32x4*>(zero_buf);
+        const long long n4 = zero_floats >> 2, stride = (long long)gridDim.x * blockDim.x;
+        for (long long i = e; i < n4; i += stride) z4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (e < (int)(zero_floats & 3)) zero_buf[(n4 << 2) + e] = 0.f;
+    }
 }
 
 }  // namespace
@@ -821,11 +828,12 @@ extern "C" {
 int64_t spf_rhead_packed_floats(void) { return R_PACKED_TOTAL; }
 
 int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const float* b0, const float* w2, const float* b2, const float* w4,
-                   const float* b4, float* packed, void* stream) {
+                   const float* b4, float* packed, float* zero_buf, int64_t zero_floats, void* stream) {
     if (!w6 || !b6 || !w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !packed) return spf::fail(SPF_EINVAL, "spf_rhead_pack: null pointer");
+    if (zero_floats < 0 || (zero_buf && ((uintptr_t)zero_buf & 15))) return spf::fail(SPF_EINVAL, "spf_rhead_pack: zero_buf must be 16-byte aligned, zero_floats >= 0");
     RPackArgs a{w6, b6, w0, b0, w2, b2, w4, b4};
     constexpr int NTH = R_PACKED > RX_FRAGS / 3 ? R_PACKED : RX_FRAGS / 3;
-    rhead_pack_kernel<<<spf::div_up(NTH, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
+    rhead_pack_kernel<<<spf::div_up(NTH, 256), 256, 0, (hipStream_t)stream>>>(a, packed, zero_buf, (long long)zero_floats);
     SPF_LAUNCH_CHECK("rhead_pack_kernel");
     return SPF_OK;
 }

@@ -504,7 +504,8 @@ wgrad_split8_batched_kernel(WgradBatch pb, const int32_t* __restrict__ n_rows_de
 // slab of wgrad_split8_kernel: output row o = 32 wave + C-row(reg, lane), column = 32 t + (lane & 31)
 template <int NT>
 __device__ __forceinline__ void wgrad_split8_reduce_body(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev,
-                                                         int max_rows, int C, float* __restrict__ dW, int ldw, int align = 2) {
+                                                         int max_rows, int C, float* __restrict__ dW, int ldw, int align = 2, int col_rot = 0,
+                                                         int col_mod = 0) {
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
     if (n <= 0) return;
     int chunk = (n + nblk_launched - 1) / nblk_launched;
@@ -515,8 +516,13 @@ __device__ __forceinline__ void wgrad_split8_reduce_body(const float* __restrict
     if (e >= PER) return;
     const int lane = e & 63, r = (e >> 6) & 15, t = (e >> 10) % NT, wave = (e >> 10) / NT;
     const int o = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int i = 32 * t + (lane & 31);
+    int i = 32 * t + (lane & 31);
     if (i >= C) return;
+    if (col_mod > 0) {                                   // product column i lands in output column (i + col_rot) mod col_mod; columns >= col_mod are padding
+        if (i >= col_mod) return;
+        i += col_rot;
+        if (i >= col_mod) i -= col_mod;
+    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const int step = gridDim.y;
     int b = blockIdx.y;
@@ -532,8 +538,8 @@ __device__ __forceinline__ void wgrad_split8_reduce_body(const float* __restrict
 
 template <int NT>
 __global__ void wgrad_split8_reduce_kernel(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev, int max_rows,
-                                           int C, float* __restrict__ dW, int ldw, int align) {
-    wgrad_split8_reduce_body<NT>(slab, nblk_launched, n_rows_dev, max_rows, C, dW, ldw, align);
+                                           int C, float* __restrict__ dW, int ldw, int align, int col_rot, int col_mod) {
+    wgrad_split8_reduce_body<NT>(slab, nblk_launched, n_rows_dev, max_rows, C, dW, ldw, align, col_rot, col_mod);
 }
 __global__ void wgrad_split8_reduce_batched_kernel(const float* __restrict__ slabs, size_t slab_floats, int nblk_launched,
                                                    const int32_t* __restrict__ n_rows_dev, int max_rows, WgradBatch pb) {
@@ -634,9 +640,13 @@ static constexpr int RSPLIT = 16;
 int64_t spf_wgrad_workspace_floats(int32_t C) { return (int64_t)256 * 256 * (C > 128 ? 256 : (C > 32 ? 256 : 32)); }
 
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows, float* dW, int32_t ldw,
-              float* dbias, float* workspace, int32_t layout, int32_t arith, void* stream) {
+              float* dbias, float* workspace, int32_t layout, int32_t arith, int32_t col_rot, int32_t col_mod, void* stream) {
     if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_wgrad: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
-    if (max_rows < 0 || C < 1 || C > 256 || lda < C || ldw < C) return spf::fail(SPF_EINVAL, "spf_wgrad: need 1 <= C <= 256, lda >= C, ldw >= C");
+    if (col_mod < 0 || col_mod > C || col_rot < 0 || (col_mod > 0 && col_rot >= col_mod) || (col_mod == 0 && col_rot != 0))
+        return spf::fail(SPF_EINVAL, "spf_wgrad: need 0 <= col_rot < col_mod <= C (or both 0), got col_rot=%d col_mod=%d C=%d", col_rot, col_mod, C);
+    if (col_mod > 0 && !(arith == SPF_ARITH_SPLIT && C > 32)) return spf::fail(SPF_EINVAL, "spf_wgrad: the column rotation needs SPF_ARITH_SPLIT and C > 32");
+    if (max_rows < 0 || C < 1 || C > 256 || lda < C || ldw < (col_mod > 0 ? col_mod : C))
+        return spf::fail(SPF_EINVAL, "spf_wgrad: need 1 <= C <= 256, lda >= C, ldw >= C (col_mod with a column rotation)");
     if (max_rows == 0) return SPF_OK;
     if (!G || !A || !dW || !workspace) return spf::fail(SPF_EINVAL, "spf_wgrad: null pointer");
     const int NT = C > 128 ? 8 : (C > 32 ? 4 : 1);
@@ -662,14 +672,14 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
         else if (ak) wgrad_split8_kernel<8, 0, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         else wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         dbias = nullptr;
-        wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align);
+        wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align, col_rot, col_mod);
     } else if (arith == SPF_ARITH_SPLIT && NT == 4) {
         const int b8 = blocks > 256 ? 256 : blocks;
         if (g64) wgrad_split8_kernel<4, 2, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         else if (gk) wgrad_split8_kernel<4, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         else wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
         dbias = nullptr;
-        wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align);
+        wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align, col_rot, col_mod);
     } else if (NT == 8) {
         if (C == 256) wgrad_dma_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         else wgrad_lds_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
@@ -702,7 +712,7 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
     if (arith != SPF_ARITH_SPLIT || n_problems == 1) {      // fp32-MFMA verification mode / nothing to batch: the single-problem path
         for (int q = 0; q < n_problems; ++q) {
             const spf_wgrad_problem& p = problems[q];
-            const int rc = spf_wgrad(p.G, p.A, p.lda, 256, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, 0, arith, stream);
+            const int rc = spf_wgrad(p.G, p.A, p.lda, 256, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, 0, arith, 0, 0, stream);
             if (rc != SPF_OK) return rc;
         }
         return SPF_OK;

@@ -19,6 +19,7 @@ class LaplaceDensity(Density):
     def __init__(self, params_init={}, beta_min=0.0001):
         super().__init__(params_init=params_init)
         self.register_buffer("beta_min", torch.tensor(float(beta_min)), persistent=False)
+        self.beta_min_value = float(beta_min)            # host copy: reading the buffer back would synchronise (and cannot be captured)
 
     def density_func(self, sdf, beta=None):
         if beta is None:
@@ -31,6 +32,9 @@ class LaplaceDensity(Density):
     def get_beta_value(self):
         """get_beta().detach(), computed once per parameter version (the sampler and the compositing kernel of one step read the
         same value: two launches instead of four)."""
+        ext = getattr(self, "_beta_forward", None)
+        if ext is not None:              # the model's forward formed it in its first launch (ops.camera_rays) for this forward
+            return ext
         key = (self.beta._version, self.beta.data_ptr())
         capturing = self.beta.is_cuda and torch.cuda.is_current_stream_capturing()     # a graph replay must recompute it itself
         if capturing or getattr(self, "_beta_value_key", None) != key:

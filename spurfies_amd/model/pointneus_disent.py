@@ -163,6 +163,13 @@ class PointVolSDF(nn.Module):
                 p.requires_grad_(False)
         return self
 
+    def _zero_scalar(self, dev):
+        """A cached 0-dim zero (never written to): the `local_loss` value of steps without local_data, without a fill launch per step."""
+        z = getattr(self, "_zero", None)
+        if z is None or z.device != torch.device(dev):
+            self._zero = z = torch.zeros((), device=dev)
+        return z
+
     # ------------------------------------------------------------------ geometry at free points
     def _sdf_points(self, x, with_grad):
         """x [M,3] -> dict(sdf [M] (1000 where no neighbour), grad, valid u8 [M], pairs); no host sync."""
@@ -256,17 +263,25 @@ class PointVolSDF(nn.Module):
         SR, k = conf.max_shading_pts, conf.k
         grid = self._grid()
 
-        rays = ops.camera_rays(uv, pose, intrinsics)               # one launch; None for multi-view batches
-        if rays is not None:
-            ray_dirs, cam_loc, depth_scale = rays
-            self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast, iter_step)
-            points = self.ray_sampler.last_points
-        else:
-            ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
-            dirs_cam, _ = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], intrinsics)
-            depth_scale = dirs_cam[0, :, 2:]
-            points, _, cam_loc, ray_dirs = self.get_importance_rays(cam_loc, ray_dirs, self, fast, iter_step)
-        return self.render_points(points, ray_dirs, cam_loc, depth_scale, input.get("local_data"))
+        # one launch for the ray set-up (None for multi-view batches); in sync-free training it also forms this forward's effective
+        # Laplace scale |beta| + beta_min, which the sampler and the compositing kernels read (density.get_beta_value)
+        fuse_beta = self.sync_free and self.training and self.density.beta.is_cuda
+        beta_fwd = torch.empty((), dtype=torch.float32, device=dev) if fuse_beta else None
+        rays = ops.camera_rays(uv, pose, intrinsics, self.density.beta, self.density.beta_min_value, beta_fwd)
+        self.density._beta_forward = beta_fwd if rays is not None else None
+        try:
+            if rays is not None:
+                ray_dirs, cam_loc, depth_scale = rays
+                self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast, iter_step)
+                points = self.ray_sampler.last_points
+            else:
+                ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+                dirs_cam, _ = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], intrinsics)
+                depth_scale = dirs_cam[0, :, 2:]
+                points, _, cam_loc, ray_dirs = self.get_importance_rays(cam_loc, ray_dirs, self, fast, iter_step)
+            return self.render_points(points, ray_dirs, cam_loc, depth_scale, input.get("local_data"))
+        finally:
+            self.density._beta_forward = None
 
     def render_points(self, points, ray_dirs, cam_loc, depth_scale, local_data=None):
         """Everything of forward() behind the sampler (:654-892): main-pass kNN of the sample positions `points` [R,D,3] (the
@@ -309,12 +324,14 @@ class PointVolSDF(nn.Module):
         colors = colors.view(R, SR, 3)
 
         # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------
+        pts_rendered = None
         if static and ops._sink(self.density.beta) is not None:    # beta's gradient goes straight into its .grad buffer
-            weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta_value(), q["slot_valid"], z_slots,
-                                                                  deltas, self.density.beta)
+            # ... and the rendered surface points o + d * dist_map of the pseudo-point loss (:765-767) come out of the same launch
+            weights, rgb, depth, dist_map, acc, pts_rendered = ops.Render.apply(sdf, colors, self.density.get_beta_value(), q["slot_valid"], z_slots,
+                                                                                deltas, self.density.beta, cam_loc, ray_dirs)
         else:
             weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta(), q["slot_valid"], z_slots, deltas)
-        output = {"rgb_values": rgb, "weights": weights, "local_loss": torch.zeros((), device=dev)}
+        output = {"rgb_values": rgb, "weights": weights, "local_loss": self._zero_scalar(dev)}
         if self.keep_stages:        # stage tests: dense-row intermediates next to the reference's per-stage tensors
             self.stages = {"pidx": q["pidx"], "loc": q["loc"], "slot_valid": q["slot_valid"], "ray_valid": q["ray_valid"], "x": x, "z_slots": z_slots,
                            "deltas": deltas, "sdf": sdf, "gradients": gradients, "colors": colors, "dist_map": dist_map}
@@ -334,7 +351,7 @@ class PointVolSDF(nn.Module):
         # ---- pseudo-point loss (:765-780) --------------------------------------------------------
         if static:
             # SDF at the rendered points, dense [R] (1000 where no neighbour); the masked mean is formed by the loss kernels
-            pr = self._sdf_points(DistPoints.apply(cam_loc, ray_dirs, dist_map), with_grad=True)
+            pr = self._sdf_points(pts_rendered if pts_rendered is not None else DistPoints.apply(cam_loc, ray_dirs, dist_map), with_grad=True)
             output["_fused"] = {"acc": acc, "grad": gradients.detach(), "slot_valid": q["slot_valid"].view(-1), "n_points": pl.n_points,
                                 "psdf": pr["sdf"], "pvalid": pr["valid"], "ray_valid": q["ray_valid"]}
         else:
@@ -350,7 +367,8 @@ class PointVolSDF(nn.Module):
                 # no rendered point has a neighbour -> the reference's constant 1000 (no gradient)
                 pseudo_pts_loss = torch.where(cnt > 0, l1, torch.full_like(l1, SDF_FILL))
             output.update({"pseudo_pts_loss": pseudo_pts_loss, "pseudo_sum": pseudo_sum, "pseudo_count": pseudo_cnt})
-        output["tv_loss"] = self.tv_graph().loss(self.neural_feats_geometry)
+        # sync-free training: the per-point TV terms — their mean is formed inside the fused loss kernels (one reduction launch less)
+        output["tv_loss"] = self.tv_graph().loss(self.neural_feats_geometry, reduce=not static)
         if not self.training:
             g = gradients.view(R, SR, 3)
             nrm = torch.where(valid.unsqueeze(-1), g / g.norm(2, -1, keepdim=True), torch.zeros(1, device=dev))

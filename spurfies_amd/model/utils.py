@@ -76,10 +76,11 @@ class TVGraph:
         self.norm = self.w.sum(-1).contiguous()
         self.nbr = nbr.to(torch.int32).contiguous()
 
-    def loss(self, kp_feat):
+    def loss(self, kp_feat, reduce=True):
+        """reduce=False: the per-point terms [n] instead of their mean (for the fused loss kernels, which form the mean themselves)."""
         from .. import ops
 
-        return ops.TVLoss.apply(kp_feat, self.nbr, self.w, self.norm)
+        return ops.TVLoss.apply(kp_feat, self.nbr, self.w, self.norm, reduce)
 
 
 def tv_regul(voxel_grid, kp_pos, kp_feat, k, r):

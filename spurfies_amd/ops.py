@@ -209,12 +209,14 @@ def _fixed_flush(acc, dst):
         _lib.check(_lib.lib().spf_fixed_accumulate(_lib.ptr(acc), _lib.ptr(dst), dst.numel(), _lib.stream_ptr()), "spf_fixed_accumulate")
 
 
-def geo_backward_latents(g_sdf, wn, jac, pl: "PairList", g_feat_geo):
+def geo_backward_latents(g_sdf, wn, jac, pl: "PairList", g_feat_geo, grad_x=None, g_x=None):
+    """grad_x [rows,3] (the forward's d sdf / d x) + g_x [rows,3] (uninitialised): g_x = g_sdf[:, None] * grad_x is formed by the same launch."""
     acc = _fixed_acc(g_feat_geo) if _SCATTER["mode"] == "fixed" else None
     with torch.cuda.device(g_sdf.device):
         _lib.check(_lib.lib().spf_geo_backward_latents(_lib.ptr(g_sdf), _lib.ptr(wn), _lib.ptr(jac), _lib.ptr(pl.nbr), _lib.ptr(pl.point_slot),
                                                        _lib.ptr(pl.pair_off), _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), pl.max_pairs, pl.k,
-                                                       _lib.ptr(g_feat_geo), _lib.ptr(acc), _lib.stream_ptr()), "spf_geo_backward_latents")
+                                                       _lib.ptr(g_feat_geo), _lib.ptr(acc), _lib.ptr(grad_x), _lib.ptr(g_x),
+                                                       0 if g_x is None else g_x.shape[0], _lib.stream_ptr()), "spf_geo_backward_latents")
     if acc is not None:
         _fixed_flush(acc, g_feat_geo)
     return g_feat_geo
@@ -246,14 +248,17 @@ class GeoSDF(torch.autograd.Function):
             return (None,) * 8
         g_sdf = g_sdf.contiguous()
         g_x = g_feat = None
-        if ctx.needs_input_grad[0]:
-            g_x = g_sdf.unsqueeze(-1) * grad
+        want_x = ctx.needs_input_grad[0]
         if ctx.needs_input_grad[1]:
+            if want_x:                         # rides along in the latent-gradient launch
+                g_x = torch.empty_like(grad)
             if ctx.sink is not None:
-                geo_backward_latents(g_sdf, wn, jac, ctx.pl, ctx.sink)
+                geo_backward_latents(g_sdf, wn, jac, ctx.pl, ctx.sink, grad if want_x else None, g_x)
             else:
                 g_feat = torch.zeros((ctx.n_table, 32), dtype=torch.float32, device=g_sdf.device)
-                geo_backward_latents(g_sdf, wn, jac, ctx.pl, g_feat)
+                geo_backward_latents(g_sdf, wn, jac, ctx.pl, g_feat, grad if want_x else None, g_x)
+        elif want_x:
+            g_x = g_sdf.unsqueeze(-1) * grad
         return g_x, g_feat, None, None, None, None, None, None
 
 
@@ -289,7 +294,9 @@ class TVLoss(torch.autograd.Function):
     """mean_i tv_i over the static neighbour graph (spurfies/model/utils.py:221-282), HIP fwd + bwd."""
 
     @staticmethod
-    def forward(ctx, feat, nbr, w, norm):
+    def forward(ctx, feat, nbr, w, norm, reduce=True):
+        """reduce=True: mean_i tv_i (utils.py:282).  reduce=False: the per-point terms tv [n] — for FusedLoss, whose kernels form the mean
+        themselves (one reduction launch less) and hand back ONE gradient value for all points (an expanded, stride-0 tensor)."""
         n, k = nbr.shape
         feat_c = feat.detach().contiguous()
         tv = torch.empty((n,), dtype=torch.float32, device=feat.device)
@@ -298,21 +305,27 @@ class TVLoss(torch.autograd.Function):
                                                  _lib.stream_ptr()), "spf_tv_forward")
         ctx.save_for_backward(feat_c, nbr, w, norm)
         ctx.sink = _sink(feat)
-        return tv.mean()
+        ctx.reduce = reduce
+        return tv.mean() if reduce else tv
 
     @staticmethod
     def backward(ctx, g):
         feat, nbr, w, norm = ctx.saved_tensors
         n, k = nbr.shape
-        g_tv = g.detach().reshape(1).contiguous()          # one device scalar: d mean / d tv_i = g / n for every point (stride 0, scale 1/n)
+        if ctx.reduce:
+            g_tv, stride, scale = g.detach().reshape(1).contiguous(), 0, 1.0 / n      # one device scalar: d mean / d tv_i = g / n for every point
+        elif g.stride(0) == 0:
+            g_tv, stride, scale = g.detach()[:1].contiguous(), 0, 1.0                    # FusedLoss: the same d loss / d tv_i for every point
+        else:
+            g_tv, stride, scale = g.detach().contiguous(), 1, 1.0
         out = ctx.sink if ctx.sink is not None else torch.zeros_like(feat)
         acc = _fixed_acc(out) if _SCATTER["mode"] == "fixed" else None
         with torch.cuda.device(feat.device):
-            _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), _lib.ptr(g_tv), 0, 1.0 / n, n, k,
+            _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), _lib.ptr(g_tv), stride, scale, n, k,
                                                   _lib.ptr(out), _lib.ptr(acc), _lib.stream_ptr()), "spf_tv_backward")
         if acc is not None:
             _fixed_flush(acc, out)
-        return (None if ctx.sink is not None else out), None, None, None
+        return (None if ctx.sink is not None else out), None, None, None, None
 
 
 # ---- fused colour-feature path ------------------------------------------------------------------
@@ -328,13 +341,14 @@ def _color_col_perm(device):
     return _C_ORIG
 
 
-def pack_color_weights(ws):
-    """ws: [w0, b0, w2, b2, w4, b4] of F_color's three activated layers -> packed image."""
+def pack_color_weights(ws, zero=None):
+    """ws: [w0, b0, w2, b2, w4, b4] of F_color's three activated layers -> packed image.  zero: a float32 buffer cleared by the same launch."""
     args = [t.detach().contiguous().float() for t in ws]
     dev = args[0].device
     packed = torch.empty((int(_lib.lib().spf_color_packed_floats()),), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().spf_color_pack(*[_lib.ptr(a) for a in args], _lib.ptr(packed), _lib.stream_ptr()), "spf_color_pack")
+        _lib.check(_lib.lib().spf_color_pack(*[_lib.ptr(a) for a in args], _lib.ptr(packed), _lib.ptr(zero), 0 if zero is None else zero.numel(),
+                                             _lib.stream_ptr()), "spf_color_pack")
     return packed
 
 
@@ -368,8 +382,8 @@ class ColorAgg(_GradModeFunction):
         P, NP = (pl.max_points, pl.max_pairs) if ctx.static else (int(n_valid), int(n_pairs))
         tiles = (NP + 63) // 64
         rows = 64 * tiles
-        packed = pack_color_weights([w0, b0, w2, b2, w4, b4])
-        agg3 = torch.zeros((P, 256), dtype=torch.float32, device=dev)
+        agg3 = torch.empty((P, 256), dtype=torch.float32, device=dev)          # cleared by the packing launch
+        packed = pack_color_weights([w0, b0, w2, b2, w4, b4], zero=agg3)
         train = _GradModeFunction._outer_grad_mode and any(ctx.needs_input_grad[:7])     # no training stores under torch.no_grad()
         if train:
             bufs = [torch.empty((rows, 104), dtype=torch.float32, device=dev), torch.empty((rows, 256), dtype=torch.float32, device=dev),
@@ -422,14 +436,21 @@ class ColorAgg(_GradModeFunction):
         # the bf16-piece kernels write act1 / act2 as K-major 16-row blocks, G3 / G2 / G1 as K-major 64-row tiles (include/spurfies_hip.h: SPF_WGRAD_*)
         GT, AT, G64 = (WGRAD_G_TILES, WGRAD_A_TILES, WGRAD_G_TILES64) if ctx.arith == 0 else (0, 0, 0)
         if sk is not None:
-            # layer 0's [256,104] comes in the kernels' internal column order: one index_add_ into the reference order
-            sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=G64)[:, :103])
+            # layer 0's [256,104] product comes in the kernels' internal column order [latent 64 | encoding 39 | pad]: the reduce kernel
+            # rotates it into the reference order [encoding 39 | latent 64] on the way (no permutation pass)
+            if _ARITH["wgrad"] == 0 and ctx.arith == 0:
+                wgrad(G1, act0, pl.n_pairs, out=sk[1], dbias=kb(g_b0), layout=G64, col_rot=39, col_mod=103)
+            else:
+                sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=G64)[:, :103])
             wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2), layout=G64 | AT)
             wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=G64 | AT)
             return (None,) * 13
         # exact-size (default) and worst-case (sync-free) buffers alike: the weight-gradient kernel reads the row count on the device
-        dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
-        dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=G64)[:, :103]   # [256,104] comes in the kernels' internal column order
+        if ctx.arith == 0 and _ARITH["wgrad"] == 0:
+            dw0 = wgrad(G1, act0, pl.n_pairs, out=torch.zeros((256, 103), dtype=torch.float32, device=dev), dbias=kb(g_b0), layout=G64, col_rot=39, col_mod=103)
+        else:
+            dw0 = torch.empty((256, 103), dtype=torch.float32, device=dev)
+            dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=G64)[:, :103]   # [256,104] comes in the kernels' internal column order
         dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2), layout=G64 | AT), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4), layout=G64 | AT)
         grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4)
         return grads + (None,) * 6
@@ -455,9 +476,11 @@ class Render(torch.autograd.Function):
     effective beta (a 0-dim tensor); differentiable w.r.t. all three."""
 
     @staticmethod
-    def forward(ctx, sdf, colors, beta, slot_valid, z, deltas, beta_param=None):
+    def forward(ctx, sdf, colors, beta, slot_valid, z, deltas, beta_param=None, cam_loc=None, ray_dirs=None):
         """beta_param: the raw LaplaceDensity parameter (beta = |beta_param| + beta_min was formed from it, detached) when
-        its gradient should be accumulated straight into its .grad buffer (set_grad_sinks)."""
+        its gradient should be accumulated straight into its .grad buffer (set_grad_sinks).
+        cam_loc / ray_dirs [R,3] (optional): a sixth output pts_rendered = cam_loc + ray_dirs * dist (pointneus_disent.py:765-767; differentiable
+        through dist) comes out of the same launch and its gradient goes back through the same backward launch."""
         R, SR = sdf.shape
         dev = sdf.device
         ctx.set_materialize_grads(False)        # backward handles None: no zero tensors (fill launches) for the outputs the loss ignores
@@ -468,28 +491,30 @@ class Render(torch.autograd.Function):
         depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
         dist = torch.empty((R,), dtype=torch.float32, device=dev)
         acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        with_pts = cam_loc is not None
+        pts = torch.empty((R, 3), dtype=torch.float32, device=dev) if with_pts else None
+        dirs_c = ray_dirs.detach().contiguous() if with_pts else None
+        loc_c = cam_loc.detach().contiguous() if with_pts else None
         with torch.cuda.device(dev), _prof.span("render_fwd", rays=R, slots=SR):
             _lib.check(_lib.lib().spf_render_forward(_lib.ptr(sdf_c), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(col_c),
                                                      _lib.ptr(beta_c), R, SR, _lib.ptr(weights), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(dist),
-                                                     _lib.ptr(acc), _lib.stream_ptr()), "spf_render_forward")
-        ctx.save_for_backward(sdf_c, col_c, beta_c, slot_valid, z, deltas, weights)
+                                                     _lib.ptr(acc), _lib.ptr(loc_c), _lib.ptr(dirs_c), _lib.ptr(pts), _lib.stream_ptr()), "spf_render_forward")
+        ctx.save_for_backward(sdf_c, col_c, beta_c, slot_valid, z, deltas, weights, dirs_c)
+        ctx.with_pts = with_pts
         ctx.beta_param = beta_param.detach() if beta_param is not None else None
         ctx.beta_sink = _sink(beta_param) if beta_param is not None else None
         if beta_param is not None and ctx.beta_sink is None:
             raise RuntimeError("Render: beta_param needs a gradient sink (ops.set_grad_sinks)")
-        return weights, rgb, depth, dist, acc
+        return (weights, rgb, depth, dist, acc, pts) if with_pts else (weights, rgb, depth, dist, acc)
 
     @staticmethod
-    def backward(ctx, g_w, g_rgb, g_depth, g_dist, g_acc):
-        sdf, colors, beta, slot_valid, z, deltas, weights = ctx.saved_tensors
+    def backward(ctx, g_w, g_rgb, g_depth, g_dist, g_acc, g_pts=None):
+        sdf, colors, beta, slot_valid, z, deltas, weights, dirs = ctx.saved_tensors
         R, SR = sdf.shape
         dev = sdf.device
-        gw = None
-        if g_w is not None:
-            gw = g_w
-        if g_acc is not None:  # acc = sum_j w_j
-            gw = g_acc.expand(R, SR) if gw is None else gw + g_acc
-        gw = None if gw is None else gw.contiguous()
+        gw = None if g_w is None else g_w.contiguous()
+        g_acc = None if g_acc is None else g_acc.reshape(R).contiguous()     # acc = sum_j w_j: added to every slot's gradient inside the kernel
+        g_pts = None if (g_pts is None or not ctx.with_pts) else g_pts.contiguous()
         g_rgb = torch.zeros((R, 3), device=dev) if g_rgb is None else g_rgb.contiguous()
         g_depth = None if g_depth is None else g_depth.contiguous()
         g_dist = None if g_dist is None else g_dist.contiguous()
@@ -501,8 +526,9 @@ class Render(torch.autograd.Function):
             _lib.check(_lib.lib().spf_render_backward(_lib.ptr(sdf), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(colors),
                                                       _lib.ptr(beta), _lib.ptr(weights), _lib.ptr(gw), _lib.ptr(g_rgb), _lib.ptr(g_depth),
                                                       _lib.ptr(g_dist), R, SR, _lib.ptr(g_sdf), _lib.ptr(g_col), _lib.ptr(g_beta),
-                                                      _lib.ptr(ctx.beta_param), _lib.stream_ptr()), "spf_render_backward")
-        return g_sdf, g_col, (None if sink is not None else g_beta.reshape(())), None, None, None, None
+                                                      _lib.ptr(ctx.beta_param), _lib.ptr(g_acc), _lib.ptr(g_pts), _lib.ptr(dirs if g_pts is not None else None),
+                                                      _lib.stream_ptr()), "spf_render_backward")
+        return g_sdf, g_col, (None if sink is not None else g_beta.reshape(())), None, None, None, None, None, None
 
 
 # ---- sampler stages ---------------------------------------------------------------------------------
@@ -548,13 +574,14 @@ def sampler_finish(z_samples, z_vals, sel, near, far, cam_loc, ray_dirs):
 
 
 # ---- radiance head R -------------------------------------------------------------------------------
-def pack_rhead_weights(ws):
-    """ws: [F_color.6 w, b, R.0 w, b, R.2 w, b, R.4 w, b] -> packed image of the head stage."""
+def pack_rhead_weights(ws, zero=None):
+    """ws: [F_color.6 w, b, R.0 w, b, R.2 w, b, R.4 w, b] -> packed image of the head stage.  zero: a float32 buffer cleared by the same launch."""
     args = [t.detach().contiguous().float() for t in ws]
     dev = args[0].device
     packed = torch.empty((int(_lib.lib().spf_rhead_packed_floats()),), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().spf_rhead_pack(*[_lib.ptr(a) for a in args], _lib.ptr(packed), _lib.stream_ptr()), "spf_rhead_pack")
+        _lib.check(_lib.lib().spf_rhead_pack(*[_lib.ptr(a) for a in args], _lib.ptr(packed), _lib.ptr(zero), 0 if zero is None else zero.numel(),
+                                             _lib.stream_ptr()), "spf_rhead_pack")
     return packed
 
 
@@ -572,8 +599,8 @@ class RHead(_GradModeFunction):
         P = agg3.shape[0]
         tiles = (P + 63) // 64
         T = 64 * tiles
-        packed = pack_rhead_weights([w6, b6, w0, b0, w2, b2, w4, b4])
-        colors = torch.zeros((n_rows, 3), dtype=torch.float32, device=dev)
+        colors = torch.empty((n_rows, 3), dtype=torch.float32, device=dev)      # cleared by the packing launch
+        packed = pack_rhead_weights([w6, b6, w0, b0, w2, b2, w4, b4], zero=colors)
         train = _GradModeFunction._outer_grad_mode and any(ctx.needs_input_grad[:9])
         if train:
             bufs = [torch.empty((T, 256), dtype=torch.float32, device=dev), torch.empty((T, 24), dtype=torch.float32, device=dev),
@@ -658,9 +685,10 @@ def set_wgrad_mode(mode: str):
 WGRAD_G_TILES, WGRAD_A_TILES, WGRAD_G_TILES64 = 1, 2, 4      # spf_wgrad layout bits: operand stored as K-major blocks [block][256 features][16 | 64 rows]
 
 
-def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0):
+def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0, col_rot=0, col_mod=0):
     """out[256, :C] += G[:rows]^T A[:rows, :C] with the row count `n_rows` (int32 device tensor or None) read on the device;
-    dbias [256] (optional) += column sums of G[:rows] (the same layer's bias gradient)."""
+    dbias [256] (optional) += column sums of G[:rows] (the same layer's bias gradient).  col_rot / col_mod: product column i < col_mod is
+    accumulated into out column (i + col_rot) % col_mod (include/spurfies_hip.h: spf_wgrad)."""
     dev = G.device
     C = A.shape[1] if C is None else C
     if out is None:
@@ -672,7 +700,7 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0):
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_wgrad(_lib.ptr(G), _lib.ptr(A), A.stride(0), C, _lib.ptr(n_rows), min(G.shape[0], A.shape[0]), _lib.ptr(out), ldw, _lib.ptr(dbias),
-                                        _lib.ptr(_wgrad_ws[key]), int(layout), _ARITH["wgrad"], _lib.stream_ptr()), "spf_wgrad")
+                                        _lib.ptr(_wgrad_ws[key]), int(layout), _ARITH["wgrad"], int(col_rot), int(col_mod), _lib.stream_ptr()), "spf_wgrad")
     return out
 
 
@@ -700,10 +728,11 @@ def wgrad_batched(problems, n_rows):
 
 
 # ---- ray set-up and loss terms (one launch each instead of dozens of elementwise PyTorch kernels) ----------------
-def camera_rays(uv, pose, intrinsics):
+def camera_rays(uv, pose, intrinsics, beta_param=None, beta_min=0.0, beta_out=None):
     """uv [1,R,2], pose [1,4,4], intrinsics [1,3|4,3|4] -> (ray_dirs [R,3], cam_loc [R,3], depth_scale [R,1]) — the two
     rend_util.get_camera_params calls of pointneus_disent.py:640-650.  None when the batch holds several views or
-    quaternion poses (the caller then keeps the PyTorch formulation)."""
+    quaternion poses (the caller then keeps the PyTorch formulation).  beta_param / beta_min / beta_out (device scalars): the same launch
+    writes the forward's effective Laplace scale |beta_param| + beta_min into beta_out (density.py:28-30)."""
     if uv.dim() != 3 or uv.shape[0] != 1 or pose.shape[-2:] != (4, 4) or not uv.is_cuda:
         return None
     R, dev = uv.shape[1], uv.device
@@ -717,7 +746,8 @@ def camera_rays(uv, pose, intrinsics):
     scale = torch.empty((R, 1), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_camera_rays(_lib.ptr(uv_c), _lib.ptr(pose_c), _lib.ptr(K), ks, R, _lib.ptr(dirs), _lib.ptr(loc),
-                                              _lib.ptr(scale), _lib.stream_ptr()), "spf_camera_rays")
+                                              _lib.ptr(scale), _lib.ptr(None if beta_out is None else beta_param.detach()), float(beta_min),
+                                              _lib.ptr(beta_out), _lib.stream_ptr()), "spf_camera_rays")
     return dirs, loc, scale
 
 
@@ -734,7 +764,8 @@ class FusedLoss(torch.autograd.Function):
         R = rgb.shape[0]
         rgb_c, acc_c = rgb.detach().contiguous(), acc.detach().reshape(R).contiguous()
         psdf_c = None if psdf is None else psdf.detach().reshape(R).contiguous()
-        tv_c = None if tv is None else tv.detach().reshape(1)
+        n_tv = 0 if (tv is None or tv.dim() == 0 or tv.numel() == 1) else tv.numel()       # per-point array (TVLoss reduce=False) or the mean itself
+        tv_c = None if tv is None else (tv.detach().contiguous() if n_tv else tv.detach().reshape(1))
         key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
         if key not in _loss_ws:
             _loss_ws[key] = torch.empty((int(_lib.lib().spf_loss_workspace_floats()),), dtype=torch.float32, device=dev)
@@ -745,11 +776,11 @@ class FusedLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_loss_forward(_lib.ptr(rgb_c), _lib.ptr(rgb_gt), _lib.ptr(acc_c), _lib.ptr(mask_gt), mask_stride,
                                                    _lib.ptr(grad), _lib.ptr(slot_valid), rows, _lib.ptr(n_points), _lib.ptr(psdf_c),
-                                                   _lib.ptr(pvalid), _lib.ptr(ray_valid), _lib.ptr(tv_c), _lib.ptr(denom), R, weights,
+                                                   _lib.ptr(pvalid), _lib.ptr(ray_valid), _lib.ptr(tv_c), n_tv, _lib.ptr(denom), R, weights,
                                                    _lib.ptr(_loss_ws[key]), _lib.ptr(total), _lib.ptr(terms), _lib.ptr(den),
                                                    _lib.stream_ptr()), "spf_loss_forward")
         ctx.save_for_backward(rgb_c, acc_c, psdf_c, rgb_gt, mask_gt, pvalid, ray_valid, den)
-        ctx.misc = (mask_stride, weights, acc.shape, None if psdf is None else psdf.shape, tv is not None)
+        ctx.misc = (mask_stride, weights, acc.shape, None if psdf is None else psdf.shape, tv is not None, n_tv)
         ctx.mark_non_differentiable(terms)
         ctx.set_materialize_grads(False)
         return total, terms
@@ -757,7 +788,7 @@ class FusedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_terms):
         rgb, acc, psdf, rgb_gt, mask_gt, pvalid, ray_valid, den = ctx.saved_tensors
-        mask_stride, weights, acc_shape, psdf_shape, has_tv = ctx.misc
+        mask_stride, weights, acc_shape, psdf_shape, has_tv, n_tv = ctx.misc
         R, dev = rgb.shape[0], rgb.device
         if g_total is None:
             return (None,) * 14
@@ -769,7 +800,8 @@ class FusedLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_loss_backward(_lib.ptr(g), _lib.ptr(den), weights, _lib.ptr(rgb), _lib.ptr(rgb_gt), _lib.ptr(acc),
                                                     _lib.ptr(mask_gt), mask_stride, _lib.ptr(psdf), _lib.ptr(pvalid), _lib.ptr(ray_valid), R,
-                                                    _lib.ptr(g_rgb), _lib.ptr(g_acc), _lib.ptr(g_psdf), _lib.ptr(g_tv), _lib.stream_ptr()),
+                                                    _lib.ptr(g_rgb), _lib.ptr(g_acc), _lib.ptr(g_psdf), _lib.ptr(g_tv), n_tv, _lib.stream_ptr()),
                        "spf_loss_backward")
-        return (g_rgb, g_acc.view(acc_shape), None if g_psdf is None else g_psdf.view(psdf_shape), None if g_tv is None else g_tv.reshape(()),
+        g_tv_out = None if g_tv is None else (g_tv.expand(n_tv) if n_tv else g_tv.reshape(()))      # per-point array: one value, stride 0
+        return (g_rgb, g_acc.view(acc_shape), None if g_psdf is None else g_psdf.view(psdf_shape), g_tv_out,
                 None, None, None, None, None, None, None, None, None, None)

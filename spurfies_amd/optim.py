@@ -70,9 +70,10 @@ class FlatAdam(torch.optim.Adam):
             self._flatten()
 
     # ------------------------------------------------------------------ the step
-    def step(self, closure=None, max_norm=0.0):
+    def step(self, closure=None, max_norm=0.0, zero_grads=False):
         """CUDA parameters: gradient-norm clip (max_norm > 0), non-finite guard and the Adam update of every parameter in
-        three HIP launches (spf_adam_step), no host synchronisation; returns the device tensor
+        three HIP launches (spf_adam_step), no host synchronisation (zero_grads: the sweep leaves the flat gradient buffer zero for the
+        next step instead of holding the clipped gradient); returns the device tensor
         {t, skipped steps, gradient norm, clip coefficient}.  CPU parameters (host-side tests): torch's own clip + Adam."""
         if self._flat is None:
             ps = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
@@ -93,7 +94,7 @@ class FlatAdam(torch.optim.Adam):
         b1, b2 = g["betas"]
         with torch.cuda.device(grad.device):
             _lib.check(_lib.lib().spf_adam_step(_lib.ptr(f["param"]), _lib.ptr(grad), _lib.ptr(f["m"]), _lib.ptr(f["v"]), f["n"], float(g["lr"]),
-                                                float(b1), float(b2), float(g["eps"]), float(max_norm or 0.0), _lib.ptr(f["state"]),
+                                                float(b1), float(b2), float(g["eps"]), float(max_norm or 0.0), 1 if zero_grads else 0, _lib.ptr(f["state"]),
                                                 _lib.ptr(f["ws"]), _lib.stream_ptr()), "spf_adam_step")
         for p in g["params"]:             # the kernel wrote through raw pointers: let version-keyed caches see the change
             torch.autograd.graph.increment_version(p)

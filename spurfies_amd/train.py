@@ -25,7 +25,7 @@ def default_loss() -> VolSDFLoss:
 class TrainStep:
     N_STAGING = 4            # pinned staging buffers for the CPU-generator draws (sync-free steps run ahead of the GPU)
 
-    def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False, use_graph=False, draws="batch"):
+    def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False, use_graph=False, draws="batch", keep_grads=False):
         """sync_free: static shapes and device-side counts everywhere — no host synchronisation inside the step (the
         default path reads [P, n_pairs] back once per step to size the colour buffers exactly).
         use_graph (implies sync_free): forward + loss + backward (~230 kernel launches) are captured once into a hipGraph
@@ -66,6 +66,10 @@ class TrainStep:
             sdist.broadcast_model(model, self.optimizer, process_group)
         self.iter_step = 0
         self.skipped = 0
+        # sync-free steps: the Adam sweep clears the flat gradient buffer behind itself (the next step's optimizer.zero_grad(), train.py:357,
+        # without its fill launch); keep_grads=True leaves the clipped gradient readable after a step (tests, debugging)
+        self.zero_in_adam = sync_free and not keep_grads
+        self._grads_clean = False
 
     def __call__(self, model_input, ground_truth):
         """model_input: {'intrinsics','uv','pose','local_data'} for THIS rank's rays; returns (loss dict, model outputs)."""
@@ -88,7 +92,8 @@ class TrainStep:
             sdist.all_reduce_sum(self.flat.buffer, self.group)
         # train.py:359-363, 548-564 — clip_grad_norm_(1.0), skip the update when a gradient is not finite, Adam: one fused
         # device-side sequence (spurfies_amd/optim.py), no sync
-        self.optimizer.step(max_norm=1.0 if self.grad_clip else 0.0)
+        self.optimizer.step(max_norm=1.0 if self.grad_clip else 0.0, zero_grads=self.zero_in_adam)
+        self._grads_clean = self.zero_in_adam and self.optimizer._flat is not None
         self.scheduler.step()
         self.iter_step += 1
         return losses, out
@@ -103,7 +108,9 @@ class TrainStep:
             losses = sdist.sharded_loss(self.loss, out, ground_truth, self.group)
         else:
             losses = self.loss(out, ground_truth)
-        self.flat.zero_()
+        if not self._grads_clean:                                               # else: cleared by the previous step's Adam sweep
+            self.flat.zero_()
+        self._grads_clean = False
         losses["loss"].backward(gradient=self._root_grad(losses["loss"]))       # a cached 1 (autograd would launch a fill for its own)
         return losses, out
 

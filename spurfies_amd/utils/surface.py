@@ -336,3 +336,19 @@ def chamfer_dtu(data_pts, gt_pts, max_dist=20.0, thresh=None, seed=0, bbox=None,
     acc = float(d2s[d2s < max_dist].mean()) if (d2s < max_dist).any() else float("nan")
     comp = float(s2d[s2d < max_dist].mean()) if (s2d < max_dist).any() else float("nan")
     return {"accuracy": acc, "completeness": comp, "overall": 0.5 * (acc + comp), "n_data": len(data_obs), "n_down": len(data), "n_gt": len(gt_above)}
+
+
+
+def extract_surface(sdf, resolution, input_min, input_max, splitn=100000, device="cuda", keep_largest=True):
+    """get_surface_by_grid's plain branch (plots.py:188-287 with higher_res=False): reference-shaped grid over the box, chunked SDF
+    sweep, iso-surface at 0, largest component.  -> (verts, faces, volume, grid); (None, None, volume, grid) when the SDF does not
+    cross zero inside the box."""
+    grid = get_grid(None, resolution, input_min=np.asarray(input_min), input_max=np.asarray(input_max), eps=0.0)
+    vol = sdf_volume(sdf, grid, splitn=splitn, device=device)
+    ok = vol != SDF_FILL
+    if not ok.any() or vol[ok].min() > 0 or vol[ok].max() < 0:
+        return None, None, vol, grid
+    verts, faces = triangulate(vol, grid)
+    if keep_largest and len(faces):
+        verts, faces = largest_component(verts, faces)
+    return verts, faces, vol, grid

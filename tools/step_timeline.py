@@ -1,0 +1,39 @@
+"""One optimisation step as the GPU saw it: kernel sequence with durations and the idle gap in front of each launch, from a rocprofv3
+--kernel-trace CSV of `bench.py --steps N` (tools/step_timeline.sh).  Usage: python tools/step_timeline.py <kernel_trace.csv> [step index from the end]"""
+import csv
+import re
+import sys
+
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+
+
+def short(name):
+    m = re.search(r"(?:\(anonymous namespace\)::|at::native::)?([A-Za-z_0-9]+)(<[^(>]*>)?\(", name)
+    if not m:
+        return name[:60]
+    base, targ = m.group(1), m.group(2) or ""
+    if base in ("vectorized_elementwise_kernel", "elementwise_kernel_manual_unroll", "unrolled_elementwise_kernel", "reduce_kernel", "elementwise_kernel"):
+        f = re.search(r"at::native::(\w+Functor|\w+_kernel_cuda|\w+Ops|\w+_kernel_impl)", name)
+        targ = "<" + (f.group(1) if f else "") + ">"
+    return (base + targ)[:60]
+
+
+# a step starts at camera_rays_kernel
+starts = [i for i, r in enumerate(rows) if "camera_rays_kernel" in r["Kernel_Name"]]
+a, b = starts[-back - 1], starts[-back]
+seq = rows[a:b]
+t0 = int(seq[0]["Start_Timestamp"])
+prev_end = t0
+busy = gap_total = 0
+small = 0
+for r in seq:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    gap = max(0, s - prev_end)
+    busy += e - s
+    gap_total += gap
+    small += (e - s) if (e - s) < 15000 else 0
+    print(f"{(s - t0) / 1e3:9.1f} us  +{gap / 1e3:6.1f} gap  {(e - s) / 1e3:8.1f} us  {short(r['Kernel_Name'])}")
+    prev_end = max(prev_end, e)
+print(f"launches {len(seq)}, busy {busy / 1e3:.1f} us, gaps {gap_total / 1e3:.1f} us, span {(prev_end - t0) / 1e3:.1f} us, kernels < 15 us: "
+      f"{sum(1 for r in seq if int(r['End_Timestamp']) - int(r['Start_Timestamp']) < 15000)} launches = {small / 1e3:.1f} us")
