@@ -272,11 +272,12 @@ int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* p
  * g_agg [T,256] = dL/d agg (F_color.6's weight gradient is g_agg^T agg3) and g_agg3 [T,256] = g_agg W6 (input of
  * spf_color_backward); rows >= P are scratch.  ADDS into g_b6 [256] (F_color.6.bias), g_b0, g_b2 [256], g_w4 [3,256],
  * g_b4 [3] (R.0.bias, R.2.bias, R.4.weight, R.4.bias; float atomics — the caller zeroes them or points them at its
- * gradient buffers). */
+ * gradient buffers).  g_w4_fixed [768] / g_b4_fixed [3] (both or neither; SPF_ARITH_SPLIT): fixed-point accumulators (see "Reproducible
+ * gradients" below) that receive the tiles' terms instead of g_w4 / g_b4. */
 int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t* point_slot, const int32_t* n_points,
                        int32_t max_points, const float* packed, const float* act2, const uint32_t* masks,
                        float* G1, float* G2, float* g_agg, float* g_agg3, float* g_b6, float* g_b0, float* g_b2,
-                       float* g_w4, float* g_b4, int32_t arith, void* stream);
+                       float* g_w4, float* g_b4, int64_t* g_w4_fixed, int64_t* g_b4_fixed, int32_t arith, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * VolSDF error-bounded sampler — replaces UniformSampler.get_z_vals (spurfies/model/ray_sampler.py:33-59),
@@ -335,12 +336,14 @@ int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float*
  * LaplaceDensity parameter is passed in beta_param (beta = |beta_param| + beta_min, spurfies/model/density.py:28-30),
  * g_beta[0] += sign(beta_param) dL/d beta, i.e. the parameter's own gradient.
  * g_acc [R] (may be NULL): gradient of acc = sum_j w_j, added to every slot's g_weights; g_pts_rendered [R,3] (may be NULL; needs
- * ray_dirs): gradient of spf_render_forward's pts_rendered, entering through dist (g_dist[r] += g_pts_rendered[r] . ray_dirs[r]). */
+ * ray_dirs): gradient of spf_render_forward's pts_rendered, entering through dist (g_dist[r] += g_pts_rendered[r] . ray_dirs[r]).
+ * g_beta_fixed (may be NULL): a one-entry fixed-point accumulator (see "Reproducible gradients" below) that receives the rays' terms
+ * instead of g_beta's float atomics. */
 int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas,
                         const float* colors, const float* beta, const float* weights, const float* g_weights,
                         const float* g_rgb, const float* g_depth, const float* g_dist, int32_t R, int32_t SR,
                         float* g_sdf, float* g_colors, float* g_beta, const float* beta_param, const float* g_acc,
-                        const float* g_pts_rendered, const float* ray_dirs, void* stream);
+                        const float* g_pts_rendered, const float* ray_dirs, int64_t* g_beta_fixed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight-gradient GEMM with a device-side row count — replaces autograd's AddmmBackward GEMMs for the
@@ -360,6 +363,10 @@ int64_t spf_wgrad_workspace_floats(int32_t C);
 #define SPF_WGRAD_G_TILES 1
 #define SPF_WGRAD_A_TILES 2
 #define SPF_WGRAD_G_TILES64 4
+/* or-ed into `layout` (spf_wgrad) / passed as `flags` (spf_wgrad_batched): the workgroups' partial slabs are summed in block order by ONE
+ * reduce slice and added onto dW with a plain add, the bias gradient likewise from per-workgroup column sums — bit-reproducible run to run
+ * (the default sums 16 slices with float atomics; ~4x the reduce time, < 0.3 ms per step).  SPF_ARITH_SPLIT for C > 32. */
+#define SPF_WGRAD_DETERMINISTIC 8
 
 /* dbias (may be NULL): float[256], dbias[o] += sum_rows G[row][o] — the bias gradient of the same layer, taken on the way
  * (free in the default arithmetic; a separate pass over G otherwise).
@@ -384,7 +391,7 @@ struct spf_wgrad_problem {
     float* dbias;
 };
 int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_problems, const int32_t* n_rows, int32_t max_rows,
-                      float* workspace, int32_t arith, void* stream);
+                      float* workspace, int32_t arith, int32_t flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Latent tables
@@ -407,7 +414,7 @@ int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, c
                     const float* g_tv, int32_t g_tv_stride, float scale, int32_t n, int32_t k, float* g_feat_geo,
                     int64_t* g_feat_geo_fixed, void* stream);
 
-/* Reproducible latent gradients.  The three latent-gradient scatters (spf_color_backward -> g_feat_color, spf_geo_backward_latents and
+/* Reproducible gradients.  The three latent-gradient scatters (spf_color_backward -> g_feat_color, spf_geo_backward_latents and
  * spf_tv_backward -> g_feat_geo) and the forward's weighted mean (spf_color_forward -> agg3, up to four partial sums per entry) add
  * with float atomics by default: the sum depends on the order the atomics land in (run-to-run
  * noise in the last bits).  With a non-NULL `*_fixed` argument (int64 [N, 64 | 32], zero before the first use) they instead add
@@ -418,7 +425,10 @@ int spf_tv_backward(const float* feat_geo, const int32_t* nbr, const float* w, c
  * BUFFER CONTRACT (ABI 3): every `*_fixed` pointer addresses the accumulators of an allocation that holds ONE MORE int64 directly in
  * front of them — the status word acc[-1], zero before the first use.  A non-finite term (NaN, Inf, |v| >= 2^14) adds nothing and sets
  * the status word instead; spf_fixed_accumulate then writes NaN to ALL n destination entries (so the optimiser's non-finite guard skips
- * the update, train.py:548-564, whatever the number and signs of the offending terms) and clears the word. */
+ * the update, train.py:548-564, whatever the number and signs of the offending terms) and clears the word.
+ * The remaining atomically summed gradients have the same option: spf_rhead_backward (R.4's weight / bias), spf_render_backward (beta) take
+ * `*_fixed` accumulators, and spf_wgrad / spf_wgrad_batched sum their partial slabs and column sums in a fixed order with
+ * SPF_WGRAD_DETERMINISTIC — with all of them on, one optimisation step's gradients are bit-identical from run to run. */
 int spf_fixed_accumulate(int64_t* acc, float* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------

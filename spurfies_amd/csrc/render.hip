@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
                                                               float* __restrict__ g_sdf, float* __restrict__ g_colors,
                                                               float* __restrict__ g_beta, const float* __restrict__ beta_param,
                                                               const float* __restrict__ g_acc, const float* __restrict__ g_pts,
-                                                              const float* __restrict__ ray_dirs) {
+                                                              const float* __restrict__ ray_dirs, long long* __restrict__ g_beta_fixed) {
     const int lane = threadIdx.x & 63;
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= R) return;
@@ -222,7 +222,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
     gb = wave_sum(gb);
     if (lane == 0 && gb != 0.f) {   // beta = |beta_param| + beta_min: chain through the abs when the raw parameter is given
         if (beta_param) gb *= *beta_param > 0.f ? 1.f : (*beta_param < 0.f ? -1.f : 0.f);
-        atomicAdd(g_beta, gb);
+        if (g_beta_fixed) fixed_add(g_beta_fixed, 0, gb);         // order-independent (common.h): one term per ray
+        else atomicAdd(g_beta, gb);
     }
 }
 
@@ -259,7 +260,7 @@ int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float*
 int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas, const float* colors,
                         const float* beta, const float* weights, const float* g_weights, const float* g_rgb, const float* g_depth,
                         const float* g_dist, int32_t R, int32_t SR, float* g_sdf, float* g_colors, float* g_beta, const float* beta_param,
-                        const float* g_acc, const float* g_pts_rendered, const float* ray_dirs, void* stream) {
+                        const float* g_acc, const float* g_pts_rendered, const float* ray_dirs, int64_t* g_beta_fixed, void* stream) {
     if (R < 0 || SR < 1 || SR > 64 * MAX_CH) return spf::fail(SPF_EINVAL, "spf_render_backward: need 1 <= SR <= %d", 64 * MAX_CH);
     if (R == 0) return SPF_OK;
     if (!sdf || !slot_valid || !z || !deltas || !colors || !beta || !weights || !g_rgb || !g_sdf || !g_colors || !g_beta)
@@ -267,7 +268,7 @@ int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float
     if (g_pts_rendered && !ray_dirs) return spf::fail(SPF_EINVAL, "spf_render_backward: g_pts_rendered needs ray_dirs");
     render_backward_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, (hipStream_t)stream>>>(
         sdf, slot_valid, z, deltas, colors, beta, weights, g_weights, g_rgb, g_depth, g_dist, R, SR, g_sdf, g_colors, g_beta, beta_param, g_acc,
-        g_pts_rendered, ray_dirs);
+        g_pts_rendered, ray_dirs, reinterpret_cast<long long*>(g_beta_fixed));
     SPF_LAUNCH_CHECK("render_backward_kernel");
     return SPF_OK;
 }

@@ -695,7 +695,8 @@ __global__ void __launch_bounds__(256, 1)
 rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __restrict__ colors, const int32_t* __restrict__ point_slot,
                          const int32_t* __restrict__ n_points_dev, int max_points, const float* packed, const float* __restrict__ act2,
                          const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ g_agg,
-                         float* __restrict__ g_agg3, float* __restrict__ g_w4 /* [3,256] */, float* __restrict__ g_b4 /* [3] */) {
+                         float* __restrict__ g_agg3, float* __restrict__ g_w4 /* [3,256] */, float* __restrict__ g_b4 /* [3] */,
+                         long long* __restrict__ g_w4_fixed, long long* __restrict__ g_b4_fixed) {
     __shared__ __attribute__((aligned(16))) __bf16 X[3 * 64 * RX_LDP];
     __shared__ __attribute__((aligned(16))) float s_g3[64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kg = lane >> 5;
@@ -737,13 +738,20 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
                 a1 += s_g3[row * 4 + 1] * a;
                 a2v += s_g3[row * 4 + 2] * a;
             }
-            atomicAdd(&g_w4[tid], a0);
-            atomicAdd(&g_w4[256 + tid], a1);
-            atomicAdd(&g_w4[512 + tid], a2v);
+            if (g_w4_fixed) {                 // order-independent fixed-point accumulation (common.h): bit-reproducible
+                fixed_add(g_w4_fixed, tid, a0);
+                fixed_add(g_w4_fixed, 256 + tid, a1);
+                fixed_add(g_w4_fixed, 512 + tid, a2v);
+            } else {
+                atomicAdd(&g_w4[tid], a0);
+                atomicAdd(&g_w4[256 + tid], a1);
+                atomicAdd(&g_w4[512 + tid], a2v);
+            }
             if (tid < 3) {
                 float s = 0.f;
                 for (int row = 0; row < 64; ++row) s += s_g3[row * 4 + tid];
-                atomicAdd(&g_b4[tid], s);
+                if (g_b4_fixed) fixed_add(g_b4_fixed, tid, s);
+                else atomicAdd(&g_b4[tid], s);
             }
         }
         {   // G2 = (g3 W3) * lrelu'(h2), formed in the transposed accumulator arrangement -> planes
@@ -872,9 +880,12 @@ int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* p
 
 int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
                        const float* packed, const float* act2, const uint32_t* masks, float* G1, float* G2, float* g_agg, float* g_agg3,
-                       float* g_b6, float* g_b0, float* g_b2, float* g_w4, float* g_b4, int32_t arith, void* stream) {
+                       float* g_b6, float* g_b0, float* g_b2, float* g_w4, float* g_b4, int64_t* g_w4_fixed, int64_t* g_b4_fixed, int32_t arith,
+                       void* stream) {
     if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_rhead_backward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (max_points < 0) return spf::fail(SPF_EINVAL, "spf_rhead_backward: bad sizes");
+    if ((g_w4_fixed || g_b4_fixed) && (arith != SPF_ARITH_SPLIT || !g_w4_fixed || !g_b4_fixed))
+        return spf::fail(SPF_EINVAL, "spf_rhead_backward: the fixed-point accumulators come as a pair and need SPF_ARITH_SPLIT");
     if (max_points == 0) return SPF_OK;
     if (!g_colors || !colors || !packed || !act2 || !masks || !G1 || !G2 || !g_agg || !g_agg3 || !g_b6 || !g_b0 || !g_b2 || !g_w4 || !g_b4)
         return spf::fail(SPF_EINVAL, "spf_rhead_backward: null pointer");
@@ -883,7 +894,8 @@ int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t
     if (arith == SPF_ARITH_SPLIT) {    // g_b6 / g_b0 / g_b2 are not touched in this mode: spf_wgrad's dbias output provides them
         const int b1 = tiles < 256 ? tiles : 256;
         rhead_backward_x3_kernel<<<b1, 256, 0, (hipStream_t)stream>>>(g_colors, colors, point_slot, n_points, max_points, packed, act2, masks, G1, G2,
-                                                                      g_agg, g_agg3, g_w4, g_b4);
+                                                                      g_agg, g_agg3, g_w4, g_b4, reinterpret_cast<long long*>(g_w4_fixed),
+                                                                      reinterpret_cast<long long*>(g_b4_fixed));
         SPF_LAUNCH_CHECK("rhead_backward_x3_kernel");
         return SPF_OK;
     }

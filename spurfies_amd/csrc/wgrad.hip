@@ -15,6 +15,7 @@
 #include "mlp_tile.h"
 
 namespace {
+constexpr long long COLSUM_OFF = 256LL * 256 * 256;      // workspace: [256 workgroups][256 x 256] partial slabs, then [256 workgroups][256] column sums of G
 using namespace spf;
 
 // Operand maps:
@@ -286,7 +287,7 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
 template <int NT, int GK = 0, bool AK = false>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
 __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, const float* __restrict__ A, int lda, int C,
                                                   const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slab,
-                                                  float* __restrict__ dbias, const int bid, const int nblk) {
+                                                  float* __restrict__ dbias, const int bid, const int nblk, float* __restrict__ colsum = nullptr) {
     constexpr int ROWS = 16, NB = 3, CA = 32 * NT;
     constexpr int NDMA = 2 + (NT == 8 ? 2 : 1);                           // requests per wave per stage
     constexpr int PLANE = 3 * CA * 2;                                     // bf16x8 items of one plane set: [3][CA][2]
@@ -465,7 +466,10 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
 #endif
     if (dbias) {
         gsum += __shfl_xor(gsum, 32);
-        if (h == 0) atomicAdd(&dbias[32 * wave + ci], gsum);
+        if (h == 0) {
+            if (colsum) colsum[(size_t)bid * 256 + 32 * wave + ci] = gsum;      // deterministic mode: summed in block order by the reduce kernel
+            else atomicAdd(&dbias[32 * wave + ci], gsum);
+        }
     }
     float* out = slab + ((size_t)bid * 8 + wave) * (NT * 16 * 64) + lane;     // slab[block][wave 8][t][reg][lane]
 #pragma unroll
@@ -481,8 +485,8 @@ __device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, c
 template <int NT, int GK = 0, bool AK = false>
 __global__ void __launch_bounds__(512, 1)
 wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
-                    int max_rows, float* __restrict__ slab, float* __restrict__ dbias) {
-    wgrad_split8_body<NT, GK, AK>(G, A, lda, C, n_rows_dev, max_rows, slab, dbias, (int)blockIdx.x, (int)gridDim.x);
+                    int max_rows, float* __restrict__ slab, float* __restrict__ dbias, float* __restrict__ colsum) {
+    wgrad_split8_body<NT, GK, AK>(G, A, lda, C, n_rows_dev, max_rows, slab, dbias, (int)blockIdx.x, (int)gridDim.x, colsum);
 }
 
 // up to three C = 256 problems over the same rows in one launch: blockIdx.y = problem, each with gridDim.x workgroups and its own slab
@@ -495,23 +499,31 @@ struct WgradBatch {
     float* dbias[3];
 };
 __global__ void __launch_bounds__(512, 1)
-wgrad_split8_batched_kernel(WgradBatch pb, const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slabs, size_t slab_floats) {
+wgrad_split8_batched_kernel(WgradBatch pb, const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slabs, size_t slab_floats,
+                            int det) {
     const int q = blockIdx.y;
-    wgrad_split8_body<8>(pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slabs + (size_t)q * slab_floats, pb.dbias[q], (int)blockIdx.x,
-                         (int)gridDim.x);
+    float* slab = slabs + (size_t)q * slab_floats;
+    wgrad_split8_body<8>(pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], (int)blockIdx.x, (int)gridDim.x,
+                         det ? slab + COLSUM_OFF : nullptr);
 }
 
 // slab of wgrad_split8_kernel: output row o = 32 wave + C-row(reg, lane), column = 32 t + (lane & 31)
 template <int NT>
 __device__ __forceinline__ void wgrad_split8_reduce_body(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev,
                                                          int max_rows, int C, float* __restrict__ dW, int ldw, int align = 2, int col_rot = 0,
-                                                         int col_mod = 0) {
+                                                         int col_mod = 0, float* __restrict__ dbias_det = nullptr) {
     const int n = n_rows_dev ? min(*n_rows_dev, max_rows) : max_rows;
     if (n <= 0) return;
     int chunk = (n + nblk_launched - 1) / nblk_launched;
     chunk = (chunk + align - 1) / align * align;        // the row split of wgrad_split8_body
     const int active = (n + chunk - 1) / chunk;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dbias_det && blockIdx.y == 0 && e < 256) {      // deterministic mode: the workgroups' column sums of G, added in block order
+        const float* cs = slab + COLSUM_OFF;
+        float s = 0.f;
+        for (int b = 0; b < active; ++b) s += cs[(size_t)b * 256 + e];
+        dbias_det[e] += s;
+    }
     constexpr int PER = 8 * NT * 16 * 64;
     if (e >= PER) return;
     const int lane = e & 63, r = (e >> 6) & 15, t = (e >> 10) % NT, wave = (e >> 10) / NT;
@@ -538,13 +550,14 @@ __device__ __forceinline__ void wgrad_split8_reduce_body(const float* __restrict
 
 template <int NT>
 __global__ void wgrad_split8_reduce_kernel(const float* __restrict__ slab, int nblk_launched, const int32_t* __restrict__ n_rows_dev, int max_rows,
-                                           int C, float* __restrict__ dW, int ldw, int align, int col_rot, int col_mod) {
-    wgrad_split8_reduce_body<NT>(slab, nblk_launched, n_rows_dev, max_rows, C, dW, ldw, align, col_rot, col_mod);
+                                           int C, float* __restrict__ dW, int ldw, int align, int col_rot, int col_mod, float* __restrict__ dbias_det) {
+    wgrad_split8_reduce_body<NT>(slab, nblk_launched, n_rows_dev, max_rows, C, dW, ldw, align, col_rot, col_mod, dbias_det);
 }
 __global__ void wgrad_split8_reduce_batched_kernel(const float* __restrict__ slabs, size_t slab_floats, int nblk_launched,
-                                                   const int32_t* __restrict__ n_rows_dev, int max_rows, WgradBatch pb) {
+                                                   const int32_t* __restrict__ n_rows_dev, int max_rows, WgradBatch pb, int det) {
     const int q = blockIdx.z;
-    wgrad_split8_reduce_body<8>(slabs + (size_t)q * slab_floats, nblk_launched, n_rows_dev, max_rows, 256, pb.dW[q], pb.ldw[q]);
+    wgrad_split8_reduce_body<8>(slabs + (size_t)q * slab_floats, nblk_launched, n_rows_dev, max_rows, 256, pb.dW[q], pb.ldw[q], 2, 0, 0,
+                                det ? pb.dbias[q] : nullptr);
 }
 
 // NT = 1 (C <= 32: the 21 view-encoding columns, a ones column for a bias gradient): direct loads, nothing to share
@@ -637,7 +650,7 @@ extern "C" {
 
 static constexpr int RSPLIT = 16;
 // slabs: 256 workgroups x [256 x 256] (C > 128), 512 x [256 x 128] (two workgroups per CU), 256 x [256 x 32]
-int64_t spf_wgrad_workspace_floats(int32_t C) { return (int64_t)256 * 256 * (C > 128 ? 256 : (C > 32 ? 256 : 32)); }
+int64_t spf_wgrad_workspace_floats(int32_t C) { return COLSUM_OFF + (int64_t)256 * 256; }      // slabs, then 256 workgroups x 256 column sums
 
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows, float* dW, int32_t ldw,
               float* dbias, float* workspace, int32_t layout, int32_t arith, int32_t col_rot, int32_t col_mod, void* stream) {
@@ -651,7 +664,13 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     if (!G || !A || !dW || !workspace) return spf::fail(SPF_EINVAL, "spf_wgrad: null pointer");
     const int NT = C > 128 ? 8 : (C > 32 ? 4 : 1);
     const bool g64 = layout & SPF_WGRAD_G_TILES64, gk = (layout & SPF_WGRAD_G_TILES) || g64, ak = layout & SPF_WGRAD_A_TILES;
-    if (layout & ~(SPF_WGRAD_G_TILES | SPF_WGRAD_A_TILES | SPF_WGRAD_G_TILES64)) return spf::fail(SPF_EINVAL, "spf_wgrad: unknown layout bits %d", layout);
+    const bool det = layout & SPF_WGRAD_DETERMINISTIC;
+    if (layout & ~(SPF_WGRAD_G_TILES | SPF_WGRAD_A_TILES | SPF_WGRAD_G_TILES64 | SPF_WGRAD_DETERMINISTIC)) return spf::fail(SPF_EINVAL, "spf_wgrad: unknown layout bits %d", layout);
+    if (det && arith != SPF_ARITH_SPLIT && C > 32) return spf::fail(SPF_EINVAL, "spf_wgrad: SPF_WGRAD_DETERMINISTIC needs SPF_ARITH_SPLIT for C > 32");
+    if (det && dbias && C <= 32) return spf::fail(SPF_EINVAL, "spf_wgrad: SPF_WGRAD_DETERMINISTIC with dbias needs C > 32");
+    const int rsplit = det ? 1 : RSPLIT;               // one slice = every element's slabs summed in block order, one plain add onto dW
+    float* colsum = (det && dbias) ? workspace + COLSUM_OFF : nullptr;
+    float* dbias_det = det ? dbias : nullptr;
     if ((layout & SPF_WGRAD_G_TILES) && g64) return spf::fail(SPF_EINVAL, "spf_wgrad: G is either in 16-row blocks or in 64-row tiles");
     if ((gk || ak) && (arith != SPF_ARITH_SPLIT || NT < 4 || (max_rows % (g64 ? 64 : 16)) || (ak && C != 256)))
         return spf::fail(SPF_EINVAL, "spf_wgrad: blocked operands need SPF_ARITH_SPLIT, C > 32, max_rows a multiple of 16 (64 for SPF_WGRAD_G_TILES64: whole "
@@ -665,31 +684,31 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     const int align = g64 ? 64 : ((gk || ak) ? 16 : 2);
     if (arith == SPF_ARITH_SPLIT && NT == 8 && C == 256) {
         const int b8 = blocks > 256 ? 256 : blocks;      // one 8-wave workgroup per CU
-        if (g64 && ak) wgrad_split8_kernel<8, 2, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
-        else if (g64) wgrad_split8_kernel<8, 2, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
-        else if (gk && ak) wgrad_split8_kernel<8, 1, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
-        else if (gk) wgrad_split8_kernel<8, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
-        else if (ak) wgrad_split8_kernel<8, 0, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
-        else wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        if (g64 && ak) wgrad_split8_kernel<8, 2, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
+        else if (g64) wgrad_split8_kernel<8, 2, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
+        else if (gk && ak) wgrad_split8_kernel<8, 1, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
+        else if (gk) wgrad_split8_kernel<8, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
+        else if (ak) wgrad_split8_kernel<8, 0, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
+        else wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
         dbias = nullptr;
-        wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align, col_rot, col_mod);
+        wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), rsplit), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align, col_rot, col_mod, dbias_det);
     } else if (arith == SPF_ARITH_SPLIT && NT == 4) {
         const int b8 = blocks > 256 ? 256 : blocks;
-        if (g64) wgrad_split8_kernel<4, 2, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
-        else if (gk) wgrad_split8_kernel<4, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
-        else wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias);
+        if (g64) wgrad_split8_kernel<4, 2, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
+        else if (gk) wgrad_split8_kernel<4, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
+        else wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
         dbias = nullptr;
-        wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align, col_rot, col_mod);
+        wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), rsplit), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align, col_rot, col_mod, dbias_det);
     } else if (NT == 8) {
         if (C == 256) wgrad_dma_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
         else wgrad_lds_kernel<8><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
-        wgrad_reduce_kernel<8><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
+        wgrad_reduce_kernel<8><<<dim3(spf::div_up(per, 256), rsplit), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     } else if (NT == 4) {
         wgrad_dma_kernel<4><<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
-        wgrad_reduce_kernel<4><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
+        wgrad_reduce_kernel<4><<<dim3(spf::div_up(per, 256), rsplit), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     } else {
         wgrad_narrow_kernel<<<blocks, 256, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace);
-        wgrad_reduce_kernel<1><<<dim3(spf::div_up(per, 256), RSPLIT), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
+        wgrad_reduce_kernel<1><<<dim3(spf::div_up(per, 256), rsplit), 256, 0, s>>>(workspace, blocks, n_rows, max_rows, C, dW, ldw);
     }
     if (dbias) colsum256_kernel<<<512, 256, 0, s>>>(G, n_rows, max_rows, dbias);
     SPF_LAUNCH_CHECK("wgrad_kernel");
@@ -698,7 +717,9 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
 
 
 int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_problems, const int32_t* n_rows, int32_t max_rows, float* workspace,
-                      int32_t arith, void* stream) {
+                      int32_t arith, int32_t flags, void* stream) {
+    if (flags & ~SPF_WGRAD_DETERMINISTIC) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: flags may only hold SPF_WGRAD_DETERMINISTIC");
+    const int det = (flags & SPF_WGRAD_DETERMINISTIC) ? 1 : 0;
     if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
     if (!problems || n_problems < 1 || n_problems > 3 || max_rows < 0) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: 1 to 3 problems");
     if (max_rows == 0) return SPF_OK;
@@ -712,7 +733,7 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
     if (arith != SPF_ARITH_SPLIT || n_problems == 1) {      // fp32-MFMA verification mode / nothing to batch: the single-problem path
         for (int q = 0; q < n_problems; ++q) {
             const spf_wgrad_problem& p = problems[q];
-            const int rc = spf_wgrad(p.G, p.A, p.lda, 256, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, 0, arith, 0, 0, stream);
+            const int rc = spf_wgrad(p.G, p.A, p.lda, 256, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, flags, arith, 0, 0, stream);
             if (rc != SPF_OK) return rc;
         }
         return SPF_OK;
@@ -729,9 +750,9 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
     const int cap = 256 / n_problems;
     if (blocks > cap) blocks = cap;
     const int per = 4 * 2 * 8 * 16 * 64;
-    wgrad_split8_batched_kernel<<<dim3(blocks, n_problems), 512, 0, s>>>(pb, n_rows, max_rows, workspace, (size_t)slab_floats);
-    wgrad_split8_reduce_batched_kernel<<<dim3(spf::div_up(per, 256), RSPLIT, n_problems), 256, 0, s>>>(workspace, (size_t)slab_floats, blocks, n_rows,
-                                                                                                     max_rows, pb);
+    wgrad_split8_batched_kernel<<<dim3(blocks, n_problems), 512, 0, s>>>(pb, n_rows, max_rows, workspace, (size_t)slab_floats, det);
+    wgrad_split8_reduce_batched_kernel<<<dim3(spf::div_up(per, 256), det ? 1 : RSPLIT, n_problems), 256, 0, s>>>(workspace, (size_t)slab_floats, blocks,
+                                                                                                               n_rows, max_rows, pb, det);
     SPF_LAUNCH_CHECK("wgrad_split8_batched_kernel");
     return SPF_OK;
 }

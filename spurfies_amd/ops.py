@@ -22,6 +22,21 @@ def _sink(p):
     g = getattr(p, "_spf_grad_sink", None)
     return g if (g is not None and g.shape == p.shape and g.is_contiguous() and g.device == p.device) else None
 
+# ---- gradient buckets (ray-sharded steps): a callback announces that a group of gradients is final -------------------------------------
+_BUCKET_HOOK = [None]
+
+
+def set_bucket_hook(fn):
+    """fn(name) is called by the backward code right after the launch that completes a gradient bucket ('head', 'color_latents',
+    'color_weights'; spurfies_amd/dist.py:BucketedAllReduce) — only when the gradients go straight into their sinks.  None: off."""
+    _BUCKET_HOOK[0] = fn
+
+
+def _bucket(name):
+    if _BUCKET_HOOK[0] is not None:
+        _BUCKET_HOOK[0](name)
+
+
 # ---- optional per-launch timing (bench.py roofline): spurfies_amd/_prof.py -----------------------
 def profile_start(tags=None):
     _prof.start(tags)
@@ -431,6 +446,8 @@ class ColorAgg(_GradModeFunction):
                                                      _lib.ptr(g_feat), _lib.ptr(acc), ctx.arith, _lib.stream_ptr()), "spf_color_backward")
         if acc is not None:
             _fixed_flush(acc, g_feat)
+        if sk is not None:
+            _bucket("color_latents")         # final: its all-reduce may overlap the weight-gradient GEMMs below
         # split-product kernels (the default) leave the bias gradients to the weight-gradient GEMM (column sums of G)
         kb = (lambda b: b) if ctx.arith == 0 else (lambda b: None)
         # the bf16-piece kernels write act1 / act2 as K-major 16-row blocks, G3 / G2 / G1 as K-major 64-row tiles (include/spurfies_hip.h: SPF_WGRAD_*)
@@ -444,6 +461,7 @@ class ColorAgg(_GradModeFunction):
                 sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=G64)[:, :103])
             wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2), layout=G64 | AT)
             wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=G64 | AT)
+            _bucket("color_weights")
             return (None,) * 13
         # exact-size (default) and worst-case (sync-free) buffers alike: the weight-gradient kernel reads the row count on the device
         if ctx.arith == 0 and _ARITH["wgrad"] == 0:
@@ -522,12 +540,15 @@ class Render(torch.autograd.Function):
         g_col = torch.empty((R, SR, 3), dtype=torch.float32, device=dev)
         sink = ctx.beta_sink
         g_beta = sink.reshape(1) if sink is not None else torch.zeros((1,), dtype=torch.float32, device=dev)
+        acc_b = _fixed_acc(g_beta) if _SCATTER["mode"] == "fixed" else None        # one term per ray: order-independent in this mode
         with torch.cuda.device(dev), _prof.span("render_bwd", rays=R, slots=SR):
             _lib.check(_lib.lib().spf_render_backward(_lib.ptr(sdf), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(colors),
                                                       _lib.ptr(beta), _lib.ptr(weights), _lib.ptr(gw), _lib.ptr(g_rgb), _lib.ptr(g_depth),
                                                       _lib.ptr(g_dist), R, SR, _lib.ptr(g_sdf), _lib.ptr(g_col), _lib.ptr(g_beta),
                                                       _lib.ptr(ctx.beta_param), _lib.ptr(g_acc), _lib.ptr(g_pts), _lib.ptr(dirs if g_pts is not None else None),
-                                                      _lib.stream_ptr()), "spf_render_backward")
+                                                      _lib.ptr(acc_b), _lib.stream_ptr()), "spf_render_backward")
+        if acc_b is not None:
+            _fixed_flush(acc_b, g_beta)
         return g_sdf, g_col, (None if sink is not None else g_beta.reshape(())), None, None, None, None, None, None
 
 
@@ -634,11 +655,16 @@ class RHead(_GradModeFunction):
             g_b6, g_b0, g_b2, g_w4, g_b4 = (g_small[:256], g_small[256:512], g_small[512:768], g_small[768:1536].view(3, 256),
                                             g_small[1536:1539])
         g_colors = g_colors.contiguous()
+        fixed = _SCATTER["mode"] == "fixed" and ctx.arith == 0
+        acc_w, acc_b = (_fixed_acc(g_w4), _fixed_acc(g_b4)) if fixed else (None, None)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_rhead_backward(_lib.ptr(g_colors), _lib.ptr(colors), _lib.ptr(point_slot), _lib.ptr(n_points), P, _lib.ptr(packed),
                                                      _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_agg3),
-                                                     _lib.ptr(g_b6), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_w4), _lib.ptr(g_b4),
-                                                     ctx.arith, _lib.stream_ptr()), "spf_rhead_backward")
+                                                     _lib.ptr(g_b6), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_w4), _lib.ptr(g_b4), _lib.ptr(acc_w),
+                                                     _lib.ptr(acc_b), ctx.arith, _lib.stream_ptr()), "spf_rhead_backward")
+        if fixed:
+            _fixed_flush(acc_w, g_w4)
+            _fixed_flush(acc_b, g_b4)
         # split-product kernels (the default) leave the 256-wide layers' bias gradients to the weight-gradient GEMMs (column sums)
         split = ctx.arith == 0
         kb = (lambda b: b) if split else (lambda b: None)
@@ -646,6 +672,7 @@ class RHead(_GradModeFunction):
             # F_color.6 (K = points, not pairs), R.0's agg block (reference column order [dir-enc | agg]) and R.2: side by side
             wgrad_batched([(g_agg, agg3, sk[0], kb(g_b6)), (G1, agg, sk[2][:, 21:], kb(g_b0)), (G2, act1, sk[4], kb(g_b2))], n_points)
             wgrad(G1, direnc, n_points, C=21, out=sk[2])
+            _bucket("head")                  # F_color.6, R.*, and density.beta (written by the compositing backward before this node ran)
             return (g_agg3[:P],) + (None,) * 14
         dw6 = wgrad(g_agg, agg3, n_points, dbias=kb(g_b6))
         dw0 = torch.zeros((256, 277), dtype=torch.float32, device=dev)        # reference column order [dir-enc | agg]
@@ -683,6 +710,12 @@ def set_wgrad_mode(mode: str):
 
 
 WGRAD_G_TILES, WGRAD_A_TILES, WGRAD_G_TILES64 = 1, 2, 4      # spf_wgrad layout bits: operand stored as K-major blocks [block][256 features][16 | 64 rows]
+WGRAD_DETERMINISTIC = 8                                       # fixed-order slab / column-sum reduce (set_scatter_mode("fixed"))
+
+
+def _wgrad_det(C):
+    """The deterministic reduce is part of scatter mode 'fixed' (bit-reproducible steps); wide operands need the default arithmetic for it."""
+    return WGRAD_DETERMINISTIC if (_SCATTER["mode"] == "fixed" and (_ARITH["wgrad"] == 0 or C <= 32)) else 0
 
 
 def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0, col_rot=0, col_mod=0):
@@ -700,7 +733,8 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0, col_ro
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_wgrad(_lib.ptr(G), _lib.ptr(A), A.stride(0), C, _lib.ptr(n_rows), min(G.shape[0], A.shape[0]), _lib.ptr(out), ldw, _lib.ptr(dbias),
-                                        _lib.ptr(_wgrad_ws[key]), int(layout), _ARITH["wgrad"], int(col_rot), int(col_mod), _lib.stream_ptr()), "spf_wgrad")
+                                        _lib.ptr(_wgrad_ws[key]), int(layout) | _wgrad_det(C), _ARITH["wgrad"], int(col_rot), int(col_mod), _lib.stream_ptr()),
+                   "spf_wgrad")
     return out
 
 
@@ -723,7 +757,7 @@ def wgrad_batched(problems, n_rows):
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_wgrad_batched(arr, len(problems), _lib.ptr(n_rows), max_rows, _lib.ptr(_wgrad_ws[key]), _ARITH["wgrad"],
-                                                    _lib.stream_ptr()),
+                                                    _wgrad_det(256), _lib.stream_ptr()),
                    "spf_wgrad_batched")
 
 

@@ -60,10 +60,14 @@ class TrainStep:
             raise ValueError(draws)
         self.draw_world = self.world if draws == "batch" else 1
         model.ray_sampler.shard = (self.rank, self.world) if self.draw_world > 1 else None
+        self.buckets = None
         if self.world > 1:
             # the all-reduce sums gradients only: replicas must START identical (latents and MLPs are drawn from the local
             # generators in the constructors).  Rank 0's parameters, frozen prior and cloud win.
             sdist.broadcast_model(model, self.optimizer, process_group)
+            if sync_free:      # gradients go straight into the flat buffer: bucket by bucket, each all-reduced as soon as it is final
+                names = [n for n, p in model.named_parameters() if p.requires_grad]
+                self.buckets = sdist.BucketedAllReduce(self.flat, names, process_group)
         self.iter_step = 0
         self.skipped = 0
         # sync-free steps: the Adam sweep clears the flat gradient buffer behind itself (the next step's optimizer.zero_grad(), train.py:357,
@@ -89,7 +93,10 @@ class TrainStep:
         else:
             losses, out = self._forward_backward(model_input, ground_truth)
         if self.world > 1:
-            sdist.all_reduce_sum(self.flat.buffer, self.group)
+            if self.buckets is not None and not self.use_graph:
+                self.buckets.finish()                    # the buckets the backward has not announced (geometry latents: last), then wait for all
+            else:
+                sdist.all_reduce_sum(self.flat.buffer, self.group)
         # train.py:359-363, 548-564 — clip_grad_norm_(1.0), skip the update when a gradient is not finite, Adam: one fused
         # device-side sequence (spurfies_amd/optim.py), no sync
         self.optimizer.step(max_norm=1.0 if self.grad_clip else 0.0, zero_grads=self.zero_in_adam)
@@ -111,7 +118,13 @@ class TrainStep:
         if not self._grads_clean:                                               # else: cleared by the previous step's Adam sweep
             self.flat.zero_()
         self._grads_clean = False
-        losses["loss"].backward(gradient=self._root_grad(losses["loss"]))       # a cached 1 (autograd would launch a fill for its own)
+        if self.buckets is not None:
+            self.buckets.begin()
+            ops.set_bucket_hook(self.buckets.ready)
+        try:
+            losses["loss"].backward(gradient=self._root_grad(losses["loss"]))   # a cached 1 (autograd would launch a fill for its own)
+        finally:
+            ops.set_bucket_hook(None)
         return losses, out
 
     # ------------------------------------------------------------------ MFMA-shape selection of the dominant kernel

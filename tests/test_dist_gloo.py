@@ -129,3 +129,53 @@ def test_multi_scene_trainer_round_robin_cpu():
     assert seen == [(s, f"in{s}.{r}", f"gt{s}.{r}") for r in range(2) for s in range(11)]
     with pytest.raises(ValueError):
         multi.step([("a", "b")])
+
+
+PARAM_NAMES = ["neural_feats_color", "neural_feats_geometry", "F_color.0.weight", "F_color.0.bias", "F_color.2.weight", "F_color.2.bias",
+               "F_color.4.weight", "F_color.4.bias", "F_color.6.weight", "F_color.6.bias", "R.0.weight", "R.0.bias", "R.2.weight", "R.2.bias",
+               "R.4.weight", "R.4.bias", "density.beta"]
+
+
+def _bucket_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        params = [torch.zeros(int(n), requires_grad=True) for n in (640, 320, 96, 8, 64, 8, 64, 8, 64, 8, 72, 8, 64, 8, 24, 3, 1)]
+        flat = sdist.FlatGrads(params)
+        flat.buffer.copy_(torch.randn(flat.buffer.shape, generator=g))
+        mine = flat.buffer.clone()
+        buckets = sdist.BucketedAllReduce(flat, PARAM_NAMES)
+        buckets.begin()
+        for name in ("head", "color_latents", "color_weights"):          # the order the backward announces them; geo_latents is left to finish()
+            buckets.ready(name)
+        buckets.ready("head")                                            # announcing a bucket twice must not reduce it twice
+        buckets.finish()
+        out_q.put((rank, mine.numpy(), flat.buffer.clone().numpy(), list(buckets.log), {k: [tuple(r) for r in v] for k, v in buckets.ranges.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_equals_one_flat_all_reduce():
+    """spurfies_amd/dist.py:BucketedAllReduce — the four gradient buckets, reduced one by one in the order the backward completes them,
+    give exactly the sum one flat all-reduce gives; every element belongs to exactly one bucket."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = res[0][1] + res[1][1]
+    for _, _, summed, log, ranges in res:
+        np.testing.assert_array_equal(summed, total)
+        assert log == ["head", "color_latents", "color_weights", "geo_latents"]
+        cover = np.zeros(len(total), np.int32)
+        for rs in ranges.values():
+            for lo, hi in rs:
+                cover[lo:hi] += 1
+        assert (cover == 1).all()
+        assert ranges["color_latents"] == [(0, 640)] and ranges["geo_latents"] == [(640, 960)] and len(ranges["color_weights"]) == 1 and len(ranges["head"]) == 1

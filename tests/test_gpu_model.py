@@ -305,36 +305,55 @@ def test_sync_free_steps_run_ahead_without_tearing_draws():
     np.testing.assert_allclose(traj[1], traj[0], rtol=5e-4)
 
 
-def test_fixed_point_scatter_makes_latent_gradients_reproducible():
-    """ops.set_scatter_mode('fixed'): the three latent-gradient scatters (colour backward, geometry backward, TV) accumulate 2^-48
-    fixed-point integers with 64-bit integer atomics — order-independent — so the latent gradients of a step are bit-identical run to
-    run, and agree with the float-atomic default to summation noise."""
+def test_fixed_scatter_mode_makes_the_whole_step_bit_reproducible():
+    """ops.set_scatter_mode('fixed') — every atomically summed quantity of a step becomes order-independent: the three latent-gradient
+    scatters (colour backward, geometry backward, TV), the forward's RBF-weighted mean, R.4's weight / bias and beta accumulate 2^-48
+    fixed-point integers with 64-bit integer atomics; the weight-gradient GEMMs reduce their partial slabs and column sums in block order
+    (SPF_WGRAD_DETERMINISTIC).  Two runs of the same step then agree BIT FOR BIT in every loss term and in the gradient of EVERY trainable
+    tensor — and in the parameters after three optimisation steps; against the float-atomic default they differ by summation noise only."""
     from spurfies_amd import ops
     from spurfies_amd import synthetic as syn
     from spurfies_amd.train import TrainStep
 
     scene = syn.make_scene(4000, seed=15, prior="fitted")
     g = torch.Generator().manual_seed(5)
-    uv = torch.from_numpy(syn.make_pixels(512, g))[None].cuda()
-    K, pose = torch.from_numpy(scene["intrinsics"])[None].cuda(), torch.from_numpy(scene["poses"][0])[None].cuda()
-    gt = {"rgb": torch.rand((512, 3), generator=g)[None].cuda(), "mask": torch.ones((1, 512, 3)).cuda()}
+    K = torch.from_numpy(scene["intrinsics"])[None].cuda()
+    batches = []
+    for it in range(3):
+        uv = torch.from_numpy(syn.make_pixels(512, g))[None].cuda()
+        pose = torch.from_numpy(scene["poses"][it % 3])[None].cuda()
+        batches.append(({"intrinsics": K, "uv": uv, "pose": pose, "local_data": None},
+                        {"rgb": torch.rand((512, 3), generator=g)[None].cuda(), "mask": (torch.rand((512,), generator=g) > 0.2).float()[None, :, None].repeat(1, 1, 3).cuda()}))
     runs = {}
     try:
         for mode in ("fixed", "fixed", "atomic"):
             ops.set_scatter_mode(mode)
             model = build_model(scene)
-            step = TrainStep(model, sync_free=True)
+            step = TrainStep(model, sync_free=True, keep_grads=True)
             torch.manual_seed(31)
-            step._forward_backward({"intrinsics": K, "uv": uv, "pose": pose, "local_data": None}, gt)
-            runs.setdefault(mode, []).append((model.neural_feats_color.grad.clone(), model.neural_feats_geometry.grad.clone()))
+            losses, _ = step._forward_backward(dict(batches[0][0]), batches[0][1])
+            grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad}
+            terms = {k: v.detach().clone() for k, v in losses.items()}
+            torch.manual_seed(31)
+            for b in batches:                                 # three full optimisation steps (clip + Adam included)
+                step(dict(b[0]), b[1])
+            params = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+            runs.setdefault(mode, []).append((grads, terms, params))
     finally:
         ops.set_scatter_mode("atomic")
-    (c0, g0), (c1, g1) = runs["fixed"]
-    assert torch.equal(c0, c1) and torch.equal(g0, g1), "fixed-point accumulation must be bit-reproducible"
-    ca, ga = runs["atomic"][0]
-    assert float(c0.abs().max()) > 0 and float(g0.abs().max()) > 0
-    np.testing.assert_allclose(c0.cpu().numpy(), ca.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(ca.abs().max()))
-    np.testing.assert_allclose(g0.cpu().numpy(), ga.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(ga.abs().max()))
+    (g0, t0, p0), (g1, t1, p1) = runs["fixed"]
+    assert set(g0) >= {"neural_feats_color", "neural_feats_geometry", "F_color.0.weight", "F_color.0.bias", "F_color.4.weight", "F_color.6.weight",
+                       "R.0.weight", "R.0.bias", "R.2.weight", "R.4.weight", "R.4.bias", "density.beta"}
+    for n in g0:
+        assert float(g0[n].abs().max()) > 0, n
+        assert torch.equal(g0[n], g1[n]), f"gradient of {n} must be bit-reproducible in scatter mode 'fixed'"
+        assert torch.equal(p0[n], p1[n]), f"{n} after three optimisation steps must be bit-reproducible in scatter mode 'fixed'"
+    for k in t0:
+        assert torch.equal(t0[k], t1[k]), k
+    ga = runs["atomic"][0][0]
+    for n in g0:                                              # same sums as the float-atomic default, up to its summation noise
+        a, b = g0[n].cpu().numpy(), ga[n].cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6 * float(np.abs(b).max()), err_msg=n)
 
 
 def test_graphed_step_tracks_eager_step():
