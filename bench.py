@@ -186,8 +186,6 @@ def main_eval(args):
                         neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
     model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
     model.eval()
-    if args.geo_engine != "auto":
-        ops.set_geo_mode(args.geo_engine)
     g = torch.Generator().manual_seed(777 + rank)
     K = torch.from_numpy(scene["intrinsics"])[None].to(device)
     n = args.warmup + args.steps
@@ -201,7 +199,20 @@ def main_eval(args):
 
     torch.set_num_threads(1)
     iters = []
+    tune = None
     with torch.no_grad():
+        if args.geo_engine == "auto":          # MFMA shape of the geometry kernels: both timed on one chunk on THIS box (untimed), the faster kept
+            tune = {}
+            for mode in ("split", "split_w", "split_w", "split"):
+                ops.set_geo_mode(mode)
+                model(dict(batches[0]), fast=-1)
+                ops.profile_start(tags=("geo",))
+                model(dict(batches[0]), fast=-1)
+                tune[mode] = tune.get(mode, 0.0) + sum(p["ms"] for p in ops.profile_stop())
+            ops.set_geo_mode(min(tune, key=tune.get))
+            tune = {**{k: v / 2 for k, v in tune.items()}, "selected": ops.geo_mode(), "what": "geometry-kernel ms per chunk (all passes)"}
+        else:
+            ops.set_geo_mode(args.geo_engine)
         for i in range(args.warmup):
             model(dict(batches[i % len(batches)]), fast=-1)
         ops.geo_clock(reset=True)
@@ -233,6 +244,7 @@ def main_eval(args):
                 "kernel": ("geo_pairs_x3_kernel<false>" if engine == "split" else "geo_pairs_x3w_kernel<false>") + " (sampler passes: SDF only)",
                 "launches": len(fwd), "avg_ms": ms / len(fwd), "pairs_per_launch": pairs / len(fwd), "flop_per_pair": F_FWD, "total_ms_per_step": ms / args.steps,
                 "held_clock": held_clock(ach, ck), "traffic": None, "timing": "HIP events over the timed region",
+                "engine": {"selected": engine, "autotune_ms": tune},
                 "peak_basis": "algorithmic fp32 FLOP/s against the dense bf16 MFMA peak / 6 (six exact bf16 piece products per fp32 product)"}
         sec = []
         if jac:
