@@ -130,10 +130,12 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
 
 /* spf_compact_points + spf_build_pairs in ONE pair of launches (what the model's passes use: the four-launch form costs more in
  * dispatch than in work at 10^5 slots): nbr [R*SR, k] is indexed by SLOT (the kNN output as it is); outputs as above, with
- * counts[2] = {n_points, n_pairs} on the device and the same optional fillers.  scratch: >= 2 * (R*SR / 2048 + 1) int32. */
+ * counts[2] = {n_points, n_pairs} on the device and the same optional fillers.  scratch: >= 2 * (R*SR / 2048 + 1) int32.
+ * gate (DEVICE int32, may be NULL): when *gate == 0 the counts are reported as {0, 0} (the fillers are still laid down), so the MLP kernels
+ * behind this pass do no work — how a sampler iteration the loop did not reach is skipped without a host round trip (spf_sampler_iter). */
 int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot,
                       int32_t* slot_point, int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch,
-                      float* fill_sdf, float fill_value, float* fill_grad, void* stream);
+                      float* fill_sdf, float fill_value, float* fill_grad, const int32_t* gate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused geometry path — replaces get_keypoint_data + compute_weights + get_sdf (+ the value of
@@ -296,17 +298,24 @@ int spf_sampler_uniform(const float* tlin, const float* t_rand, const float* cam
  *   more == 0: the rendering weights + 1e-5           (final sample set, :491-503)
  *   more != 0: the per-interval error bound + add_tiny (:470-489), and z_merged [R,n+N] =
  *              sort(cat(z, samples)) with merged_idx [R,n+N] indexing into cat(z, samples).
- * u: [N] (u_per_ray == 0) or [R,N].  N may be 0 (beta only).  beta_out [R]. */
+ * u: [N] (u_per_ray == 0) or [R,N].  N may be 0 (beta only).  beta_out [R].
+ * flags / it — DEVICE-SIDE LOOP CONTROL (flags NULL: off).  The reference decides after every iteration on the host whether another one follows
+ * (`not_converge = beta.max() > beta0`, ray_sampler.py:468: one synchronisation per iteration).  Every iteration's shapes are static (n = 128 (it + 1)),
+ * so a caller may instead enqueue ALL iterations with flags [>= max iterations + 1] int32, flags[0] = 1, the rest 0: flags[i] != 0 <=> the loop
+ * reaches iteration i.  A call for iteration `it` returns at once unless flags[it] != 0; the beta-only call (N == 0) sets flags[it + 1] when some
+ * ray's beta exceeds beta0; a merging call (more != 0) runs iff flags[it + 1] != 0, a final call (more == 0, N > 0) iff flags[it + 1] == 0 —
+ * so exactly the calls the reference's loop would have made do work.  spf_sampler_finish takes the same pair and runs behind the final call;
+ * spf_compact_pairs' gate = &flags[it] empties the SDF pass of an iteration that is not reached.  sum(flags) = iterations realised. */
 int spf_sampler_iter(const float* z, const float* sdf, const float* beta_in, const float* beta0, int32_t R,
                      int32_t n, float eps, float bound_coef, int32_t beta_iters, int32_t more, float add_tiny,
                      const float* u, int32_t u_per_ray, int32_t N, float* samples, float* beta_out,
-                     float* z_merged, int32_t* merged_idx, void* stream);
+                     float* z_merged, int32_t* merged_idx, int32_t* flags, int32_t it, void* stream);
 
 /* z_out [R,Ns+2+Ne] = sort(cat(z_samples [R,Ns], near, far, z_vals[:, sel])) and the main-pass points
  * points[r,i,:] = cam_loc[r] + z_out ray_dirs[r]  (:535-559). */
 int spf_sampler_finish(const float* z_samples, int32_t Ns, const float* z_vals, int32_t n, const int32_t* sel,
                        int32_t Ne, float near, float far, const float* cam_loc, const float* ray_dirs, int32_t R,
-                       float* z_out, float* points, void* stream);
+                       float* z_out, float* points, const int32_t* flags, int32_t it, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-ray compositing — replaces filter_points (spurfies/model/pointneus_disent.py:207-239),

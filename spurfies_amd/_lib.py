@@ -47,7 +47,7 @@ SIGNATURES = {
     "spf_grid_get_info": (C.c_int, [_P, C.POINTER(GridInfo)]),
     "spf_grid_query": (C.c_int, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
     "spf_compact_points": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P]),
-    "spf_compact_pairs": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
+    "spf_compact_pairs": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
     "spf_voxel_cells": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_float * 3), _F, _P, _P]),
     "spf_geo_packed_floats": (C.c_int64, []),
     "spf_geo_pack": (C.c_int, [_P] * 14),
@@ -64,8 +64,8 @@ SIGNATURES = {
     "spf_rhead_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_rhead_backward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_sampler_uniform": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
-    "spf_sampler_iter": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "spf_sampler_finish": (C.c_int, [_P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _I, _P, _P, _P]),
+    "spf_sampler_iter": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "spf_sampler_finish": (C.c_int, [_P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _I, _P, _P, _P, _I, _P]),
     "spf_filter_points": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "spf_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

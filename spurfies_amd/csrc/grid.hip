@@ -553,7 +553,8 @@ __global__ void __launch_bounds__(256) cp_write_kernel(const uint8_t* __restrict
                                                        int k, const int32_t* __restrict__ chunk_counts, int32_t* __restrict__ point_slot,
                                                        int32_t* __restrict__ slot_point, int32_t* __restrict__ pair_off,
                                                        int32_t* __restrict__ pair_point, int32_t* __restrict__ counts /* [n_points, n_pairs] */,
-                                                       float* __restrict__ fill_sdf, float fill_value, float* __restrict__ fill_grad) {
+                                                       float* __restrict__ fill_sdf, float fill_value, float* __restrict__ fill_grad,
+                                                       const int32_t* __restrict__ gate) {
     __shared__ int32_t wsum[4];
     __shared__ int32_t wsum2[4];
     int bp = 0, bq = 0;
@@ -602,8 +603,9 @@ __global__ void __launch_bounds__(256) cp_write_kernel(const uint8_t* __restrict
             }
         }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        counts[0] = base_p + tp;
-        counts[1] = base_q + tq;
+        const bool open_ = !gate || *gate != 0;      // a closed gate reports no points / pairs: the MLP kernels behind it do nothing
+        counts[0] = open_ ? base_p + tp : 0;
+        counts[1] = open_ ? base_q + tq : 0;
         pair_off[base_p + tp] = base_q + tq;         // closes the list
     }
 }
@@ -872,7 +874,7 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
 
 int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot, int32_t* slot_point,
                       int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch, float* fill_sdf, float fill_value,
-                      float* fill_grad, void* stream_) {
+                      float* fill_grad, const int32_t* gate, void* stream_) {
     if (R < 0 || SR < 1 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_compact_pairs: bad sizes");
     if (!counts || !pair_off) return spf::fail(SPF_EINVAL, "spf_compact_pairs: null counts / pair_off");
     hipStream_t stream = (hipStream_t)stream_;
@@ -887,7 +889,7 @@ int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, 
     cp_count_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nbr, nslot, k, scratch);
     SPF_LAUNCH_CHECK("cp_count_kernel");
     cp_write_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nbr, nslot, k, scratch, point_slot, slot_point, pair_off, pair_point, counts, fill_sdf,
-                                                fill_value, fill_grad);
+                                                fill_value, fill_grad, gate);
     SPF_LAUNCH_CHECK("cp_write_kernel");
     return SPF_OK;
 }

@@ -68,7 +68,16 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
                                                            float eps, float bound_coef, int beta_iters, int more, float add_tiny,
                                                            const float* __restrict__ u, int u_per_ray, int N, float* __restrict__ samples,
                                                            float* __restrict__ beta_out, float* __restrict__ z_merged,
-                                                           int32_t* __restrict__ merged_idx) {
+                                                           int32_t* __restrict__ merged_idx, int32_t* __restrict__ flags, int it) {
+    // Device-side loop control (evaluation mode without a host sync per iteration): flags[i] != 0 <=> the sampler loop reaches iteration i.
+    // Every pass of iteration `it` needs flags[it]; the sampling passes are additionally tied to the convergence test of the SAME iteration,
+    // flags[it + 1] ("beta.max() > beta0", ray_sampler.py:468, set below by the beta-only pass): the merging pass runs iff it is set, the final
+    // pass iff it is clear.  A pass whose turn it is not returns at once.
+    if (flags) {
+        bool live = flags[it] != 0;
+        if (N > 0) live = live && ((flags[it + 1] != 0) == (more != 0));
+        if (!live) return;
+    }
     constexpr int NMAX = 64 * E;
     __shared__ float smem[4 * (3 * NMAX + 128)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,7 +161,10 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
         if (err > eps) bmin = mid;
     }
     beta = bmax;
-    if (active && lane == 0) beta_out[r] = beta;
+    if (active && lane == 0) {
+        beta_out[r] = beta;
+        if (flags && N == 0 && beta > beta0) atomicOr(&flags[it + 1], 1);      // the beta-only pass is the convergence test: another iteration follows
+    }
 
     // ---- pdf over the n-1 intervals with the final beta -------------------------------------------
     float p[E];
@@ -240,7 +252,9 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
 __global__ void __launch_bounds__(256) sampler_finish_kernel(const float* __restrict__ z_samples, int Ns, const float* __restrict__ z_vals,
                                                              int n, const int32_t* __restrict__ sel, int Ne, float near, float far,
                                                              const float* __restrict__ cam_loc, const float* __restrict__ ray_dirs, int R,
-                                                             float* __restrict__ z_out, float* __restrict__ points) {
+                                                             float* __restrict__ z_out, float* __restrict__ points, const int32_t* __restrict__ flags,
+                                                             int it) {
+    if (flags && !(flags[it] != 0 && flags[it + 1] == 0)) return;      // runs behind the final sampling pass of the iteration the loop ends in
     __shared__ float smem[4 * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wave;
@@ -288,8 +302,9 @@ int spf_sampler_uniform(const float* tlin, const float* t_rand, const float* cam
 
 int spf_sampler_iter(const float* z, const float* sdf, const float* beta_in, const float* beta0, int32_t R, int32_t n, float eps,
                      float bound_coef, int32_t beta_iters, int32_t more, float add_tiny, const float* u, int32_t u_per_ray, int32_t N,
-                     float* samples, float* beta_out, float* z_merged, int32_t* merged_idx, void* stream) {
+                     float* samples, float* beta_out, float* z_merged, int32_t* merged_idx, int32_t* flags, int32_t it, void* stream) {
     if (R < 0 || n < 2 || n > 640 || N < 0 || (more && (N < 1 || N > 128))) return spf::fail(SPF_EINVAL, "spf_sampler_iter: need 2<=n<=640, N>=0 (1..128 when merging)");
+    if (flags && (it < 0 || it > 30)) return spf::fail(SPF_EINVAL, "spf_sampler_iter: iteration index out of range");
     if (R == 0) return SPF_OK;
     if (!z || !sdf || !beta0 || !beta_out || (N > 0 && (!u || !samples)) || (more && (!z_merged || !merged_idx)))
         return spf::fail(SPF_EINVAL, "spf_sampler_iter: null pointer");
@@ -297,22 +312,23 @@ int spf_sampler_iter(const float* z, const float* sdf, const float* beta_in, con
     hipStream_t s = (hipStream_t)stream;
     if (n <= 128)
         sampler_iter_kernel<2><<<blocks, 256, 0, s>>>(z, sdf, beta_in, beta0, R, n, eps, bound_coef, beta_iters, more, add_tiny, u, u_per_ray, N,
-                                                       samples, beta_out, z_merged, merged_idx);
+                                                       samples, beta_out, z_merged, merged_idx, flags, it);
     else
         sampler_iter_kernel<10><<<blocks, 256, 0, s>>>(z, sdf, beta_in, beta0, R, n, eps, bound_coef, beta_iters, more, add_tiny, u, u_per_ray, N,
-                                                        samples, beta_out, z_merged, merged_idx);
+                                                        samples, beta_out, z_merged, merged_idx, flags, it);
     SPF_LAUNCH_CHECK("sampler_iter_kernel");
     return SPF_OK;
 }
 
 int spf_sampler_finish(const float* z_samples, int32_t Ns, const float* z_vals, int32_t n, const int32_t* sel, int32_t Ne, float near,
-                       float far, const float* cam_loc, const float* ray_dirs, int32_t R, float* z_out, float* points, void* stream) {
+                       float far, const float* cam_loc, const float* ray_dirs, int32_t R, float* z_out, float* points, const int32_t* flags,
+                       int32_t it, void* stream) {
     if (R < 0 || Ns < 0 || Ne < 0 || Ns + 2 + Ne > 256) return spf::fail(SPF_EINVAL, "spf_sampler_finish: need Ns + 2 + Ne <= 256");
     if (R == 0) return SPF_OK;
     if (!z_samples || !z_vals || (Ne > 0 && !sel) || !cam_loc || !ray_dirs || !z_out || !points)
         return spf::fail(SPF_EINVAL, "spf_sampler_finish: null pointer");
     sampler_finish_kernel<<<spf::div_up(R, 4), 256, 0, (hipStream_t)stream>>>(z_samples, Ns, z_vals, n, sel, Ne, near, far, cam_loc, ray_dirs, R,
-                                                                              z_out, points);
+                                                                              z_out, points, flags, it);
     SPF_LAUNCH_CHECK("sampler_finish_kernel");
     return SPF_OK;
 }

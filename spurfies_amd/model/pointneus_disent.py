@@ -171,15 +171,17 @@ class PointVolSDF(nn.Module):
         return z
 
     # ------------------------------------------------------------------ geometry at free points
-    def _sdf_points(self, x, with_grad):
-        """x [M,3] -> dict(sdf [M] (1000 where no neighbour), grad, valid u8 [M], pairs); no host sync."""
+    def _sdf_points(self, x, with_grad, gate=None):
+        """x [M,3] -> dict(sdf [M] (1000 where no neighbour), grad, valid u8 [M], pairs); no host sync.
+        gate: device int32 [1] — 0 makes the pass a no-op on the MLP side (every row gets the 1000 filler): a sampler iteration the
+        device-controlled loop did not reach (ray_sampler.py)."""
         grid = self._grid()
         x = x.contiguous()
         q = grid.query_dense(x.detach().unsqueeze(1), self.conf.k, self.conf.r, 1)
         M = x.shape[0]          # the compaction pass also lays down the 1000 filler / zero gradient of the rows without a neighbour
         sdf_buf = torch.empty((M,), dtype=torch.float32, device=x.device)
         grad_buf = torch.empty((M, 3), dtype=torch.float32, device=x.device) if with_grad else None
-        pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(-1, self.conf.k), fill_sdf=sdf_buf, fill_grad=grad_buf)
+        pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(-1, self.conf.k), fill_sdf=sdf_buf, fill_grad=grad_buf, gate=gate)
         if with_grad:
             sdf, grad, _ = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(self.conf.rbf), sdf_buf, grad_buf)
         else:
@@ -191,6 +193,10 @@ class PointVolSDF(nn.Module):
     def sdf_importance(self, inputs):
         """:348-421 — SDF at sampler points, 1000 where a point has no neighbour (callers wrap in no_grad)."""
         return self._sdf_points(inputs, with_grad=False)["sdf"]
+
+    def sdf_importance_gated(self, inputs, gate):
+        """sdf_importance behind a device-side gate (int32 [1]; 0 = skip the MLP work): the sampler's sync-free evaluation loop."""
+        return self._sdf_points(inputs, with_grad=False, gate=gate)["sdf"]
 
     def get_sdf_eval(self, inputs):
         """:249-298 — mesh-extraction entry."""

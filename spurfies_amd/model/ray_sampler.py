@@ -64,14 +64,28 @@ class ErrorBoundSampler_pn(RaySampler):
         self.max_total_iters = max_total_iters
         self.scene_bounding_sphere = scene_bounding_sphere
         self.add_tiny = add_tiny
-        self.last_iters = 0
+        self._last_iters, self._flags = 0, None
         self.last_points = None
+        # evaluation mode: enqueue all iterations with device-side loop control instead of one host synchronisation per iteration
+        # (spf_sampler_iter: flags / it); used when the model offers `sdf_importance_gated`.  False = the reference's host-side loop.
+        self.device_loop = True
         self.shard = None   # (rank, world) for ray-sharded batches: CPU-generator draws are made for the whole batch, this rank's rows kept
         self.draws = None   # sync-free / graph mode: {'t_rand' [R,128], 'u' [R,N_samples], 'sel' int32 [N_extra]} device tensors the
         #                     caller fills from the CPU generator (same calls, same order) before every step
         # Lemma-2 constant exactly as the reference forms it in float32 (ray_sampler.py:389)
         self._bound_coef = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
         self._lin = {}
+
+    @property
+    def last_iters(self):
+        """Sampler iterations realised by the last get_z_vals call (reading it after a device-controlled loop synchronises once)."""
+        if self._flags is not None:
+            self._last_iters, self._flags = int(self._flags[0][: self._flags[1]].sum().item()), None
+        return self._last_iters
+
+    @last_iters.setter
+    def last_iters(self, v):
+        self._last_iters, self._flags = int(v), None
 
     def _linspace(self, n, dev):
         key = (n, str(dev))
@@ -99,6 +113,8 @@ class ErrorBoundSampler_pn(RaySampler):
         max_total_iters = fast if fast >= 0 else self.max_total_iters
         beta0 = (model.density.get_beta_value() if hasattr(model.density, "get_beta_value") else model.density.get_beta().detach()).reshape(1).contiguous()
         n0 = self.N_samples_eval
+        if (not model.training and self.device_loop and max_total_iters > 1 and hasattr(model, "sdf_importance_gated") and ray_dirs.is_cuda):
+            return self._z_vals_device_loop(ray_dirs, cam_loc, model, max_total_iters, beta0)
         ext = self.draws if (self.draws is not None and model.training) else None
         if ext is not None:
             t_rand = ext["t_rand"]
@@ -155,3 +171,57 @@ class ErrorBoundSampler_pn(RaySampler):
         idx = torch.randint(z_out.shape[-1], (z_out.shape[0] * world,))[rank::world].to(dev)   # consumes the generator like :562
         z_samples_eik = torch.gather(z_out, 1, idx.unsqueeze(-1))
         return z_out, z_samples_eik
+
+    # ------------------------------------------------------------------ evaluation: the same loop, controlled on the device
+    def _z_vals_device_loop(self, ray_dirs, cam_loc, model, max_iters, beta0):
+        """get_z_vals for evaluation (:377-574, no random draws) WITHOUT the host-side convergence test of :468.  The iteration count is
+        data-dependent but every iteration's shapes are static (128 (it + 1) samples per ray), so all `max_iters` iterations are enqueued and
+        a device flag per iteration decides which of their launches do work (include/spurfies_hip.h: spf_sampler_iter) — exactly the passes the
+        reference's loop would have run, bit for bit the same kernels on the same inputs; an iteration that is not reached costs its (empty)
+        launches, a reached one no pipeline drain."""
+        from .. import ops
+
+        dev, R = ray_dirs.device, ray_dirs.shape[0]
+        n0, Nf, Ne = self.N_samples_eval, self.N_samples, self.N_samples_extra
+        key = ("flags", max_iters, str(dev))
+        if key not in self._lin:
+            t = torch.zeros((max_iters + 2,), dtype=torch.int32)
+            t[0] = 1
+            self._lin[key] = t.to(dev)
+        flags = self._lin[key].clone()                                   # flags[i] != 0 <=> the loop reaches iteration i
+        z_vals, points = ops.sampler_uniform(self._linspace(n0, dev), None, cam_loc, ray_dirs, self.near, self.far)
+        z_out = torch.empty((R, Nf + 2 + Ne), dtype=torch.float32, device=dev)
+        pts_out = torch.empty((R, Nf + 2 + Ne, 3), dtype=torch.float32, device=dev)
+        beta = torch.zeros((R,), dtype=torch.float32, device=dev)      # one buffer, updated in place by the passes that run
+        sdf, samples_idx = None, None
+        u_more, u_fin = self._linspace(n0, dev), self._linspace(Nf, dev)
+        for it in range(max_iters):
+            with torch.no_grad():
+                s_sdf = model.sdf_importance_gated(points.view(-1, 3), flags[it: it + 1]).view(R, -1)
+            sdf = s_sdf if samples_idx is None else torch.gather(torch.cat([sdf, s_sdf], -1), 1, samples_idx)
+            n = z_vals.shape[1]
+            skey = ("sel", n, Ne, str(dev))
+            if Ne > 0 and skey not in self._lin:
+                self._lin[skey] = torch.linspace(0, n - 1, Ne).long().to(torch.int32).to(dev)
+            sel = self._lin[skey] if Ne > 0 else None
+            beta_in = None if it == 0 else beta
+            if it < max_iters - 1:
+                # the convergence test (:468) = a beta-only pass that sets flags[it + 1]; then BOTH continuations are enqueued: the merging
+                # pass runs iff the flag is set, the final pass + finish iff it is clear
+                ops.sampler_iter(z_vals, sdf, beta_in, beta0, self.eps, self._bound_coef, self.beta_iters, False, 0.0, None, 0, flags=flags, it=it, beta_out=beta)
+                samples, _, zm, mi = ops.sampler_iter(z_vals, sdf, beta, beta0, self.eps, self._bound_coef, 0, True, self.add_tiny, u_more, n0,
+                                                      flags=flags, it=it, beta_out=beta)
+                fin, _, _, _ = ops.sampler_iter(z_vals, sdf, beta, beta0, self.eps, self._bound_coef, 0, False, self.add_tiny, u_fin, Nf,
+                                                flags=flags, it=it, beta_out=beta)
+                ops.sampler_finish(fin, z_vals, sel, self.near, self.far, cam_loc, ray_dirs, flags=flags, it=it, out=(z_out, pts_out))
+                z_vals, samples_idx = zm, mi.long()
+                points = cam_loc.unsqueeze(1) + samples.unsqueeze(2) * ray_dirs.unsqueeze(1)
+            else:                                                       # the last iteration samples with a full bisection (:434-445), no test
+                fin, _, _, _ = ops.sampler_iter(z_vals, sdf, beta_in, beta0, self.eps, self._bound_coef, self.beta_iters, False, self.add_tiny, u_fin, Nf,
+                                                flags=flags, it=it, beta_out=beta)
+                ops.sampler_finish(fin, z_vals, sel, self.near, self.far, cam_loc, ray_dirs, flags=flags, it=it, out=(z_out, pts_out))
+        self._flags = (flags, max_iters)
+        self.last_points = pts_out
+        # evaluation draws no eikonal index from the CPU generator in the reference either way it is unused by the caller (:562-563)
+        idx = torch.randint(z_out.shape[-1], (z_out.shape[0],)).to(dev)
+        return z_out, torch.gather(z_out, 1, idx.unsqueeze(-1))

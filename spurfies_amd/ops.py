@@ -95,9 +95,10 @@ class PairList:
                                                   _lib.ptr(scratch), _lib.stream_ptr()), "spf_build_pairs")
 
     @classmethod
-    def from_slots(cls, slot_valid, nbr, fill_sdf=None, fill_grad=None):
+    def from_slots(cls, slot_valid, nbr, fill_sdf=None, fill_grad=None, gate=None):
         """Valid-point compaction AND the pair list of a kNN result in one pair of launches (spf_compact_pairs): slot_valid uint8 [R,SR],
-        nbr int32 [R*SR,k] indexed by slot; optional uninitialised fill_sdf [R*SR] / fill_grad [R*SR,3] receive the 1000 filler / zeros."""
+        nbr int32 [R*SR,k] indexed by slot; optional uninitialised fill_sdf [R*SR] / fill_grad [R*SR,3] receive the 1000 filler / zeros.
+        gate: device int32 [1]; 0 reports empty lists (the MLP kernels behind this pass then do nothing)."""
         R, SR = slot_valid.shape
         rows, k = nbr.shape
         dev = nbr.device
@@ -114,7 +115,7 @@ class PairList:
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_compact_pairs(_lib.ptr(slot_valid), _lib.ptr(nbr), R, SR, k, _lib.ptr(self.point_slot), _lib.ptr(self.slot_point),
                                                     _lib.ptr(self.pair_off), _lib.ptr(self.pair_point), _lib.ptr(self.counts), _lib.ptr(scratch),
-                                                    _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad), _lib.stream_ptr()), "spf_compact_pairs")
+                                                    _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad), _lib.ptr(gate), _lib.stream_ptr()), "spf_compact_pairs")
         return self
 
     def host_counts(self):
@@ -564,33 +565,36 @@ def sampler_uniform(tlin, t_rand, cam_loc, ray_dirs, near, far):
     return z, pts
 
 
-def sampler_iter(z, sdf, beta_in, beta0, eps, bound_coef, beta_iters, more, add_tiny, u, N):
-    """-> (samples [R,N] | None, beta [R], z_merged [R,n+N] | None, merged_idx [R,n+N] | None)."""
+def sampler_iter(z, sdf, beta_in, beta0, eps, bound_coef, beta_iters, more, add_tiny, u, N, flags=None, it=0, beta_out=None):
+    """-> (samples [R,N] | None, beta [R], z_merged [R,n+N] | None, merged_idx [R,n+N] | None).
+    flags / it: device-side loop control (include/spurfies_hip.h: spf_sampler_iter) — a call whose turn it is not leaves its outputs
+    untouched, so with flags they are ZERO-initialised (a later gather must find valid indices) and beta_out may be passed in."""
     R, n = z.shape
     dev = z.device
-    samples = torch.empty((R, N), dtype=torch.float32, device=dev) if N > 0 else None
-    beta = torch.empty((R,), dtype=torch.float32, device=dev)
-    zm = torch.empty((R, n + N), dtype=torch.float32, device=dev) if more else None
-    mi = torch.empty((R, n + N), dtype=torch.int32, device=dev) if more else None
+    new = torch.empty if flags is None else torch.zeros
+    samples = new((R, N), dtype=torch.float32, device=dev) if N > 0 else None
+    beta = beta_out if beta_out is not None else new((R,), dtype=torch.float32, device=dev)
+    zm = new((R, n + N), dtype=torch.float32, device=dev) if more else None
+    mi = new((R, n + N), dtype=torch.int32, device=dev) if more else None
     per_ray = 1 if (u is not None and u.dim() == 2) else 0
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_sampler_iter(_lib.ptr(z), _lib.ptr(sdf), _lib.ptr(beta_in), _lib.ptr(beta0), R, n, float(eps), float(bound_coef),
                                                int(beta_iters), int(bool(more)), float(add_tiny), _lib.ptr(u), per_ray, N, _lib.ptr(samples),
-                                               _lib.ptr(beta), _lib.ptr(zm), _lib.ptr(mi), _lib.stream_ptr()), "spf_sampler_iter")
+                                               _lib.ptr(beta), _lib.ptr(zm), _lib.ptr(mi), _lib.ptr(flags), int(it), _lib.stream_ptr()), "spf_sampler_iter")
     return samples, beta, zm, mi
 
 
-def sampler_finish(z_samples, z_vals, sel, near, far, cam_loc, ray_dirs):
+def sampler_finish(z_samples, z_vals, sel, near, far, cam_loc, ray_dirs, flags=None, it=0, out=None):
+    """flags / it: runs only behind the final sampling pass of iteration `it` (spf_sampler_iter); out = (z_out, points) to write into."""
     R, Ns = z_samples.shape
     n, Ne = z_vals.shape[1], (0 if sel is None else sel.shape[0])
     dev = z_samples.device
     M = Ns + 2 + Ne
-    z_out = torch.empty((R, M), dtype=torch.float32, device=dev)
-    pts = torch.empty((R, M, 3), dtype=torch.float32, device=dev)
+    z_out, pts = out if out is not None else (torch.empty((R, M), dtype=torch.float32, device=dev), torch.empty((R, M, 3), dtype=torch.float32, device=dev))
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_sampler_finish(_lib.ptr(z_samples), Ns, _lib.ptr(z_vals), n, _lib.ptr(sel), Ne, float(near), float(far),
-                                                 _lib.ptr(cam_loc), _lib.ptr(ray_dirs), R, _lib.ptr(z_out), _lib.ptr(pts), _lib.stream_ptr()),
-                   "spf_sampler_finish")
+                                                 _lib.ptr(cam_loc), _lib.ptr(ray_dirs), R, _lib.ptr(z_out), _lib.ptr(pts), _lib.ptr(flags), int(it),
+                                                 _lib.stream_ptr()), "spf_sampler_finish")
     return z_out, pts
 
 
