@@ -270,7 +270,7 @@ def main_eval(args):
                       "mode": "eval", "rays_per_gpu": args.rays, "neural_points": args.points, "prior": args.prior, "parallelism": f"chunk-sharded dp{world}",
                       "sampler_iterations_realised": {"mean": float(np.mean(iters)), "min": int(min(iters)), "max": int(max(iters))},
                       "rays_per_s": args.rays * world * args.steps / dt,
-                      "host_syncs_per_step": "one per sampler iteration (the reference's convergence test, ray_sampler.py:468) + one for the exact buffer sizes"},
+                      "host_syncs_per_step": "none inside the forward (device-side loop control of the sampler, worst-case buffers + device counts); this bench reads the realised iteration count back once per chunk"},
            "roofline": roof}
     if rank == 0:
         sweep = None

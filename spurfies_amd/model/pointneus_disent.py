@@ -301,7 +301,9 @@ class PointVolSDF(nn.Module):
 
         # ---- kNN of the main pass, dense [R,SR] ------------------------------------------------
         q = grid.query_dense(points.detach(), k, conf.r, SR)
-        static = self.sync_free and self.training
+        static = self.sync_free and self.training                 # fused-loss mode of the optimisation step
+        # evaluation needs no exact-size training buffers either: worst-case colour buffers + device-side counts, no host read-back
+        dense = static or not self.training
         # the bool forms of the two masks are read by the reference-shaped outputs only (two conversion launches)
         valid = None if static else q["slot_valid"].bool()        # [R,SR]  == reference `mask`
         ray_mask = None if static else q["ray_valid"].bool()      # [R]
@@ -318,7 +320,7 @@ class PointVolSDF(nn.Module):
         sdf = sdf_flat.view(R, SR)                                # gradients: [R*SR,3], zero rows where not a point
 
         # ---- colours (PyTorch ops on the P valid points; one host sync for P) -------------------
-        if static:       # no host round trip: worst-case buffers, counts stay on the device
+        if dense:        # no host round trip: worst-case buffers, counts stay on the device
             P, n_pairs, rows = 1, None, None
             self.stats = {"rays": R, "counts": pl.counts}
             colors = self._colors(None, x, wn, pl, None, ray_dirs, SR)
