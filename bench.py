@@ -450,7 +450,9 @@ def main():
         "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"BASELINE.json configs[3] shape: {args.scenes} scenes optimised concurrently (round-robin, one ray-sharded group), each " if args.scenes > 1 else
-                                "BASELINE.json configs[1] shape (DTU scan24 3-view optimisation, 1024-ray batches) on a synthetic scene: ") +
+                                ("BASELINE.json configs[4] shape (dense cloud, large ray batches) on a synthetic scene: " if args.points >= 100000 else
+                                 "BASELINE.json configs[2] shape (garden-like cloud in the +-2 grid) on a synthetic scene: " if args.points >= 40000 else
+                                 "BASELINE.json configs[1] shape (DTU scan24 3-view optimisation, 1024-ray batches) on a synthetic scene: ")) +
                                f"{args.points} neural points, {rays_total} rays/step over {world} GPU(s) x (128 sampler + 98 main) samples, fast=1 optimisation step "
                                f"(fwd+bwd+clip+Adam); prior = {args.prior}",
                    "rays_per_gpu": rays_local, "rays_per_step": rays_total, "scenes": args.scenes, "neural_points": args.points, "k": 8, "max_shading_pts": 80,

@@ -87,11 +87,11 @@ class TrainStep:
                 warnings.warn("TrainStep(use_graph=True): this batch carries local_data — running the eager sync-free step for it "
                               "(the hipGraph is captured without the per-view feature maps)")
                 self._warned_graph_local = True
-            losses, out = self._forward_backward(model_input, ground_truth)
+            losses, out = self._forward_backward(model_input, ground_truth, reduce_buckets=True)
         elif self.use_graph:
             losses, out = self._graphed_forward_backward(model_input, ground_truth)
         else:
-            losses, out = self._forward_backward(model_input, ground_truth)
+            losses, out = self._forward_backward(model_input, ground_truth, reduce_buckets=True)
         if self.world > 1:
             if self.buckets is not None and not self.use_graph:
                 self.buckets.finish()                    # the buckets the backward has not announced (geometry latents: last), then wait for all
@@ -105,7 +105,9 @@ class TrainStep:
         self.iter_step += 1
         return losses, out
 
-    def _forward_backward(self, model_input, ground_truth):
+    def _forward_backward(self, model_input, ground_truth, reduce_buckets=False):
+        """reduce_buckets: announce finished gradient buckets to the asynchronous all-reduce (only the optimisation step itself does; timing
+        passes that call this directly leave the gradients local)."""
         model_input = dict(model_input)
         model_input["iter_step"] = self.iter_step
         if self.sync_free:
@@ -120,7 +122,8 @@ class TrainStep:
         self._grads_clean = False
         if self.buckets is not None:
             self.buckets.begin()
-            ops.set_bucket_hook(self.buckets.ready)
+            if reduce_buckets:
+                ops.set_bucket_hook(self.buckets.ready)
         try:
             losses["loss"].backward(gradient=self._root_grad(losses["loss"]))   # a cached 1 (autograd would launch a fill for its own)
         finally:
