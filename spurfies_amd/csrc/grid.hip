@@ -290,14 +290,22 @@ __device__ __forceinline__ void cmpx(unsigned long long& a, unsigned long long& 
 template <bool LAYERED>
 __global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ raypos, int R, int D, int SR, int k,
                                                   float rad2, GridDev g, int hkx, int hky, int hkz,
-                                                  const int32_t* __restrict__ slot_sample, int32_t* __restrict__ pidx,
-                                                  float* __restrict__ loc, uint8_t* __restrict__ slot_valid, uint8_t* __restrict__ ray_valid1) {
+                                                  int32_t* __restrict__ slot_sample, int32_t* __restrict__ pidx,
+                                                  float* __restrict__ loc, uint8_t* __restrict__ slot_valid, uint8_t* __restrict__ ray_valid1,
+                                                  int inline_slots) {
     constexpr unsigned long long NONE = ~0ull;
     const size_t t8 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t gid = t8 >> 3;
     const int sub = (int)(t8 & 7);
     if (gid >= (size_t)R * SR) return;                       // whole octets leave together
-    const int samp = slot_sample[gid];
+    int samp;
+    if (inline_slots) {      // point queries (D == 1, SR == 1): the dilated-occupancy test of point_slots_kernel, done here (one launch less per pass)
+        const float* p = raypos + gid * 3;
+        samp = dil_hit(g, p[0], p[1], p[2]) ? 0 : -1;
+        if (sub == 0) slot_sample[gid] = samp;
+    } else {
+        samp = slot_sample[gid];
+    }
     unsigned long long key[SPF_KMAX];
 #pragma unroll
     for (int t = 0; t < SPF_KMAX; ++t) key[t] = NONE;
@@ -797,7 +805,10 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
     float rad = (float)((double)radius_limit_scale * (double)vmax);
     float rad2 = rad * rad;
     GridDev d = dev_view(g);
-    if (D == 1) {
+    const int inline_slots = (D == 1 && SR == 1) ? 1 : 0;
+    if (inline_slots) {
+        // the slot test rides inside knn_kernel
+    } else if (D == 1) {
         point_slots_kernel<<<spf::div_up(R, 256), 256, 0, stream>>>(raypos, R, SR, d, slot_sample);
         SPF_LAUNCH_CHECK("point_slots_kernel");
     } else {
@@ -807,11 +818,11 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
     if (g->cfg.compat & SPF_KNN_LAYERED)
         knn_kernel<true><<<spf::div_up((long long)nslot * 8, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
                                                                                  g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
-                                                                                 slot_sample, pidx, loc, slot_valid, SR == 1 ? ray_valid : nullptr);
+                                                                                 slot_sample, pidx, loc, slot_valid, SR == 1 ? ray_valid : nullptr, inline_slots);
     else
         knn_kernel<false><<<spf::div_up((long long)nslot * 8, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
                                                                                   g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
-                                                                                  slot_sample, pidx, loc, slot_valid, SR == 1 ? ray_valid : nullptr);
+                                                                                  slot_sample, pidx, loc, slot_valid, SR == 1 ? ray_valid : nullptr, inline_slots);
     SPF_LAUNCH_CHECK("knn_kernel");
     if (SR > 1) {
         ray_valid_kernel<<<spf::div_up(R, 256), 256, 0, stream>>>(slot_valid, R, SR, ray_valid);

@@ -502,7 +502,8 @@ class VolOpt:
         moved = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in local.items()}
         self._local_cache.pop(idx, None)
         self._local_cache[idx] = (sig, moved)
-        cap = max(1, int(getattr(self, "ds_len", 0) or len(self.train_dataset) if self.train_dataset is not None else 1))
+        n_views = getattr(self, "ds_len", 0) or (len(self.train_dataset) if self.train_dataset is not None else 0)
+        cap = max(1, int(n_views))
         while len(self._local_cache) > cap:
             self._local_cache.pop(next(iter(self._local_cache)))
         return moved
