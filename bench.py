@@ -352,9 +352,12 @@ def main():
     # milliseconds (thread wake-ups); the reference pins one thread as well (train.py:24).  cpu_baseline sets its own thread counts.
     torch.set_num_threads(1)
     # --exact-draws: the same CPU-generator stream on every rank (each draws batch-wide and keeps its rays' rows); otherwise one stream per rank
-    # MFMA shape of the dominant kernel: chosen on THIS box, before the warm-up steps (untimed)
+    # MFMA shape of the dominant kernel: chosen on THIS box on a warm chip — a few untimed steps first (the clock each shape holds differs
+    # between a cold and a loaded chip), then both shapes timed A B B A twice (TrainStep.autotune_geo_engine); all before the W warm-up steps
     tune = None
     if args.geo_engine == "auto":
+        for i in range(10):                        # forward + backward passes only: no optimiser step, nothing captured yet in --graph mode
+            step._forward_backward(dict(batches[0][i % len(batches[0])][0]), batches[0][i % len(batches[0])][1])
         tune = step.autotune_geo_engine(*batches[0][0])
     else:
         ops.set_geo_mode(args.geo_engine)
@@ -410,12 +413,13 @@ def main():
     # HBM bytes per launch need a rocprofv3 --pmc pass around the process: they cannot be collected from inside this run.  The figure
     # below is the committed collection of THIS code (tools/pmc_traffic.py) on the box it was profiled on — labelled as such.
     traffic, traffic_src = None, None
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r03_z_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if traffic is None and os.path.exists(pmc):
             rec = json.load(open(pmc))
             if rec["config"].get("points") == args.points and rec["config"].get("rays") == rays_local and rec["config"].get("prior", "kaiming") == args.prior:
-                hit = [v for k, v in rec["kernels"].items() if "geo_pairs_x3_kernel<true>" in k or "geo_pairs_x3w_kernel<true>" in k]
+                want = "geo_pairs_x3_kernel<true>" if ops.geo_mode() == "split" else "geo_pairs_x3w_kernel<true>"
+                hit = [v for k, v in rec["kernels"].items() if want in k] or [v for k, v in rec["kernels"].items() if "geo_pairs_x3" in k and "<true>" in k]
                 if hit:
                     traffic = hit[0]["hbm_bytes_max_corrected"]
                     traffic_src = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 corrections) of the same workload, "
@@ -434,7 +438,7 @@ def main():
                                        "at 90 % matrix-pipe duty and 2.2 GHz at 66-76 %, i.e. 240-290 algorithmic TFLOP/s is what this instruction mix "
                                        "can draw (DESIGN.md section 6)",
                 "held_clock": held_clock(ach, clk),
-                "engine": {"selected": engine, "mfma": shape, "how": ("timed both shapes on this box before the warm-up steps (main-pass launch, A B B A)" if tune else "--geo-engine"),
+                "engine": {"selected": engine, "mfma": shape, "how": ("timed both shapes on this box, warm chip, before the warm-up steps (main-pass launch, A B B A twice)" if tune else "--geo-engine"),
                            "autotune_ms": tune},
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": kname + " (+ geo_point_reduce_kernel, < 1 % of the launch)",
                 "timing": ("HIP events over eager passes of the timed batches, right after the timed region (events cannot sit inside a "

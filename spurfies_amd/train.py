@@ -131,12 +131,13 @@ class TrainStep:
         return losses, out
 
     # ------------------------------------------------------------------ MFMA-shape selection of the dominant kernel
-    def autotune_geo_engine(self, model_input, ground_truth, reps=4):
+    def autotune_geo_engine(self, model_input, ground_truth, reps=5, rounds=2):
         """The geometry kernel exists on two MFMA shapes with the same arithmetic (ops.set_geo_mode: 'split' = 16x16x32, 'split_w' =
         32x32x16).  Which one is faster is decided by the clock the chip holds under each, and that differs from box to box by as much
         as the two differ: time the main-pass launch of both inside `reps` forward + backward passes of this batch
-        (order A B B A, HIP events; no optimiser step, the CPU generator is restored) and keep the faster.  -> {'split': ms, 'split_w': ms,
-        'selected': name}."""
+        (order A B B A, `rounds` times, HIP events; no optimiser step, the CPU generator is restored) and keep the faster.  Call it on a WARM
+        chip (after a few steps): the clock each shape holds differs between a cold and a loaded chip, and the loaded one is what the run sees
+        (measured: the cold ranking was the opposite of the steady-state one on one box of six).  -> {'split': ms, 'split_w': ms, 'selected': name}."""
         from . import _prof
 
         rng = torch.get_rng_state()
@@ -144,7 +145,7 @@ class TrainStep:
         R = model_input["uv"].shape[1]
         ms = {"split": [], "split_w": []}
         try:
-            for mode in ("split", "split_w", "split_w", "split"):
+            for mode in ("split", "split_w", "split_w", "split") * max(1, int(rounds)):
                 ops.set_geo_mode(mode)
                 self._forward_backward(model_input, ground_truth)          # first pass of a shape is not timed
                 _prof.start(("geo",))
