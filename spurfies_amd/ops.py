@@ -210,14 +210,18 @@ def scatter_mode() -> str:
     return _SCATTER["mode"]
 
 
-def _fixed_acc(like):
-    """Zero int64 accumulator shaped like the latent-gradient buffer `like` (one per device / shape / stream; spf_fixed_accumulate
-    leaves it zero again)."""
-    key = (like.device.index, tuple(like.shape), torch.cuda.current_stream(like.device).cuda_stream)
-    if key not in _fixed_bufs:
+def _fixed_acc(like, role):
+    """Zero int64 accumulator shaped like the gradient buffer `like`: a view of ONE flat buffer per (device, stream, role) that grows to the
+    largest size asked for (exact-size buffers change shape from step to step in the default mode: a buffer per shape would grow without bound).
+    spf_fixed_accumulate leaves every entry it flushed zero again, so any prefix is ready for the next use; two accumulators that are alive at
+    the same time must have different roles."""
+    key = (like.device.index, torch.cuda.current_stream(like.device).cuda_stream, role)
+    n = like.numel()
+    buf = _fixed_bufs.get(key)
+    if buf is None or buf.numel() < n + 1:
         # one int64 more IN FRONT of the accumulators: the buffer's status word (acc[-1], include/spurfies_hip.h: buffer contract)
-        _fixed_bufs[key] = torch.zeros((like.numel() + 1,), dtype=torch.int64, device=like.device)[1:].view(like.shape)
-    return _fixed_bufs[key]
+        buf = _fixed_bufs[key] = torch.zeros((n + 1,), dtype=torch.int64, device=like.device)
+    return buf[1: n + 1].view(like.shape)
 
 
 def _fixed_flush(acc, dst):
@@ -227,7 +231,7 @@ def _fixed_flush(acc, dst):
 
 def geo_backward_latents(g_sdf, wn, jac, pl: "PairList", g_feat_geo, grad_x=None, g_x=None):
     """grad_x [rows,3] (the forward's d sdf / d x) + g_x [rows,3] (uninitialised): g_x = g_sdf[:, None] * grad_x is formed by the same launch."""
-    acc = _fixed_acc(g_feat_geo) if _SCATTER["mode"] == "fixed" else None
+    acc = _fixed_acc(g_feat_geo, "geo_latents") if _SCATTER["mode"] == "fixed" else None
     with torch.cuda.device(g_sdf.device):
         _lib.check(_lib.lib().spf_geo_backward_latents(_lib.ptr(g_sdf), _lib.ptr(wn), _lib.ptr(jac), _lib.ptr(pl.nbr), _lib.ptr(pl.point_slot),
                                                        _lib.ptr(pl.pair_off), _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), pl.max_pairs, pl.k,
@@ -335,7 +339,7 @@ class TVLoss(torch.autograd.Function):
         else:
             g_tv, stride, scale = g.detach().contiguous(), 1, 1.0
         out = ctx.sink if ctx.sink is not None else torch.zeros_like(feat)
-        acc = _fixed_acc(out) if _SCATTER["mode"] == "fixed" else None
+        acc = _fixed_acc(out, "geo_latents") if _SCATTER["mode"] == "fixed" else None
         with torch.cuda.device(feat.device):
             _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(w), _lib.ptr(norm), _lib.ptr(g_tv), stride, scale, n, k,
                                                   _lib.ptr(out), _lib.ptr(acc), _lib.stream_ptr()), "spf_tv_backward")
@@ -406,7 +410,7 @@ class ColorAgg(_GradModeFunction):
                     torch.empty((rows, 256), dtype=torch.float32, device=dev), torch.empty((tiles, 3, 512), dtype=torch.int32, device=dev)]
         else:
             bufs = [None] * 4
-        acc = _fixed_acc(agg3) if (_SCATTER["mode"] == "fixed" and _ARITH["color"] == 0) else None
+        acc = _fixed_acc(agg3, "agg3") if (_SCATTER["mode"] == "fixed" and _ARITH["color"] == 0) else None
         with torch.cuda.device(dev), _prof.span("color_fwd", pairs=pl.n_pairs, train=bool(train)):
             _lib.check(_lib.lib().spf_color_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                     _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), NP, pl.k, _lib.ptr(pts),
@@ -437,7 +441,7 @@ class ColorAgg(_GradModeFunction):
             g_b0, g_b2, g_b4 = g_bias[0], g_bias[1], g_bias[2]
             g_feat = torch.zeros((ctx.n_table, 64), dtype=torch.float32, device=dev)
         g_agg3 = g_agg3.contiguous()
-        acc = _fixed_acc(g_feat) if (_SCATTER["mode"] == "fixed" and ctx.arith == 0) else None
+        acc = _fixed_acc(g_feat, "color_latents") if (_SCATTER["mode"] == "fixed" and ctx.arith == 0) else None
         if _SCATTER["mode"] == "fixed" and ctx.arith != 0:
             raise RuntimeError("scatter mode 'fixed' needs the default ('split') colour kernels")
         with torch.cuda.device(dev), _prof.span("color_bwd", pairs=pl.n_pairs):
@@ -541,7 +545,7 @@ class Render(torch.autograd.Function):
         g_col = torch.empty((R, SR, 3), dtype=torch.float32, device=dev)
         sink = ctx.beta_sink
         g_beta = sink.reshape(1) if sink is not None else torch.zeros((1,), dtype=torch.float32, device=dev)
-        acc_b = _fixed_acc(g_beta) if _SCATTER["mode"] == "fixed" else None        # one term per ray: order-independent in this mode
+        acc_b = _fixed_acc(g_beta, "beta") if _SCATTER["mode"] == "fixed" else None        # one term per ray: order-independent in this mode
         with torch.cuda.device(dev), _prof.span("render_bwd", rays=R, slots=SR):
             _lib.check(_lib.lib().spf_render_backward(_lib.ptr(sdf), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(colors),
                                                       _lib.ptr(beta), _lib.ptr(weights), _lib.ptr(gw), _lib.ptr(g_rgb), _lib.ptr(g_depth),
@@ -660,7 +664,7 @@ class RHead(_GradModeFunction):
                                             g_small[1536:1539])
         g_colors = g_colors.contiguous()
         fixed = _SCATTER["mode"] == "fixed" and ctx.arith == 0
-        acc_w, acc_b = (_fixed_acc(g_w4), _fixed_acc(g_b4)) if fixed else (None, None)
+        acc_w, acc_b = (_fixed_acc(g_w4, "r4_weight"), _fixed_acc(g_b4, "r4_bias")) if fixed else (None, None)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_rhead_backward(_lib.ptr(g_colors), _lib.ptr(colors), _lib.ptr(point_slot), _lib.ptr(n_points), P, _lib.ptr(packed),
                                                      _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_agg3),
