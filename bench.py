@@ -200,6 +200,7 @@ def main_eval(args):
     torch.set_num_threads(1)
     iters = []
     tune = None
+    render = lambda b: model(dict(b), fast=-1)
     with torch.no_grad():
         if args.geo_engine == "auto":          # MFMA shape of the geometry kernels: both timed on one chunk on THIS box (untimed), the faster kept
             tune = {}
@@ -213,19 +214,29 @@ def main_eval(args):
             tune = {**{k: v / 2 for k, v in tune.items()}, "selected": ops.geo_mode(), "what": "geometry-kernel ms per chunk (all passes)"}
         else:
             ops.set_geo_mode(args.geo_engine)
+        if args.graph:                             # one hipGraph replay per chunk (spurfies_amd/eval_graph.py)
+            from spurfies_amd.eval_graph import GraphedRenderer
+
+            render = GraphedRenderer(model, args.rays)
         for i in range(args.warmup):
-            model(dict(batches[i % len(batches)]), fast=-1)
+            render(batches[i % len(batches)])
         ops.geo_clock(reset=True)
-        ops.profile_start(tags=("geo", "knn", "color_fwd", "render_fwd"))
+        if not args.graph:
+            ops.profile_start(tags=("geo", "knn", "color_fwd", "render_fwd"))
         sync()
         t0 = time.perf_counter()
         for i in range(args.warmup, n):
-            out = model(dict(batches[i % len(batches)]), fast=-1)
+            out = render(batches[i % len(batches)])
             iters.append(model.ray_sampler.last_iters)
         sync()
         dt = time.perf_counter() - t0
-        prof = ops.profile_stop()
         clk = ops.geo_clock(reset=True)
+        if args.graph:                             # events cannot sit inside a replay: per-kernel timing over eager passes of the same chunks afterwards
+            ops.profile_start(tags=("geo", "knn", "color_fwd", "render_fwd"))
+            for i in range(args.warmup, n):
+                model(dict(batches[i % len(batches)]), fast=-1)
+            sync()
+        prof = ops.profile_stop()
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -267,7 +278,7 @@ def main_eval(args):
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"evaluation render (train.py:399-472 / eval_spurfies.py:276-292 chunks): {args.points} neural points, {args.rays} rays per chunk and GPU, "
                                   f"full error-bounded sampler (up to 5 iterations of 128 samples/ray) + 98 main samples/ray, SDF + normals + colour + compositing, no_grad; prior = {args.prior}",
-                      "mode": "eval", "rays_per_gpu": args.rays, "neural_points": args.points, "prior": args.prior, "parallelism": f"chunk-sharded dp{world}",
+                      "mode": "eval", "launch": "one hipGraph replay per chunk" if args.graph else "eager launches", "rays_per_gpu": args.rays, "neural_points": args.points, "prior": args.prior, "parallelism": f"chunk-sharded dp{world}",
                       "sampler_iterations_realised": {"mean": float(np.mean(iters)), "min": int(min(iters)), "max": int(max(iters))},
                       "rays_per_s": args.rays * world * args.steps / dt,
                       "host_syncs_per_step": "none inside the forward (device-side loop control of the sampler, worst-case buffers + device counts); this bench reads the realised iteration count back once per chunk"},

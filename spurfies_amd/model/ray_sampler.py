@@ -222,6 +222,8 @@ class ErrorBoundSampler_pn(RaySampler):
                 ops.sampler_finish(fin, z_vals, sel, self.near, self.far, cam_loc, ray_dirs, flags=flags, it=it, out=(z_out, pts_out))
         self._flags = (flags, max_iters)
         self.last_points = pts_out
-        # evaluation draws no eikonal index from the CPU generator in the reference either way it is unused by the caller (:562-563)
+        if torch.cuda.is_current_stream_capturing():         # hipGraph capture (eval_graph.py): the CPU-generator draw below is the replayer's job
+            return z_out, None
+        # the eikonal sample (:562-563, unused by the caller) consumes the CPU generator as in the reference
         idx = torch.randint(z_out.shape[-1], (z_out.shape[0],)).to(dev)
         return z_out, torch.gather(z_out, 1, idx.unsqueeze(-1))

@@ -509,17 +509,26 @@ class VolOpt:
             self._local_cache.pop(next(iter(self._local_cache)))
         return moved
 
-    def render_step(self, batch, epoch=0, dataset=None, fast=-1):
-        """train.py:399-472 without the image files / TensorBoard: full-image render in `split_n_pixels` chunks."""
+    def render_step(self, batch, epoch=0, dataset=None, fast=-1, graph=False):
+        """train.py:399-472 without the image files / TensorBoard: full-image render in `split_n_pixels` chunks.
+        graph=True: full-size chunks are replayed as one hipGraph each (spurfies_amd/eval_graph.py); a smaller last chunk runs eagerly."""
         self.model.eval()
         indices, model_input, ground_truth = batch
         dev = self.model.neural_pts.device
         model_input = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in model_input.items()}
         total = model_input["uv"].shape[1]
         res = []
+        renderer = None
+        if graph and torch.device(dev).type == "cuda" and fast != 1:
+            from .eval_graph import GraphedRenderer
+
+            if getattr(self, "_renderer", None) is None or self._renderer.n_rays != self.split_n_pixels or self._renderer.fast != fast:
+                self._renderer = GraphedRenderer(self.model, self.split_n_pixels, fast=fast)
+            renderer = self._renderer
         for s in utils.split_input(model_input, total, n_pixels=self.split_n_pixels):
-            out = self.model(s, fast=fast)
-            res.append({k: out[k].detach() for k in ("rgb_values", "depth_values", "normal_map")})
+            with torch.no_grad():
+                out = renderer(s) if (renderer is not None and s["uv"].shape[1] == renderer.n_rays) else self.model(s, fast=fast)
+            res.append({k: out[k].detach().clone() for k in ("rgb_values", "depth_values", "normal_map")})
         merged = utils.merge_output(res, total, 1)
         merged["psnr"] = rend_util.get_psnr(merged["rgb_values"], ground_truth["rgb"].to(dev).reshape(-1, 3))
         return merged

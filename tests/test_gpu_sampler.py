@@ -107,3 +107,39 @@ def test_device_controlled_eval_loop_equals_the_host_controlled_loop(prior, expe
     for k in o0:      # the colour path sums its weighted mean with float atomics: rendered values agree to that run-to-run noise
         assert torch.allclose(o0[k], o1[k], rtol=1e-4, atol=1e-6, equal_nan=True), k
     assert float(o0["weights"].sum()) > 0
+
+
+def test_graphed_eval_render_equals_eager_render():
+    """spurfies_amd/eval_graph.py: an evaluation chunk replayed as one hipGraph gives the eager forward's outputs (same kernels, same order; the
+    colour path's float atomics aside), the same realised sampler iterations, and advances the CPU generator exactly as the eager forward."""
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.eval_graph import GraphedRenderer
+    from tests.test_gpu_model import build_model
+
+    scene = syn.make_scene(6000, seed=2, prior="fitted")
+    model = build_model(scene, train=False)
+    g = torch.Generator().manual_seed(12)
+    K = torch.from_numpy(scene["intrinsics"])[None].cuda()
+    chunks = [{"intrinsics": K, "uv": torch.from_numpy(syn.make_pixels(256, g))[None].cuda(), "pose": torch.from_numpy(scene["poses"][i % 3])[None].cuda()}
+              for i in range(3)]
+    renderer = GraphedRenderer(model, 256)
+    with torch.no_grad():
+        torch.manual_seed(9)
+        eager = []
+        for c in chunks:
+            o = model(dict(c, local_data=None), fast=-1)
+            eager.append(({k: o[k].clone() for k in ("rgb_values", "depth_values", "normal_map", "weights")}, model.ray_sampler.last_iters))
+        after_eager = torch.rand(1).item()
+        torch.manual_seed(9)
+        graphed = []
+        for c in chunks:
+            o = renderer(c)
+            graphed.append(({k: o[k].clone() for k in ("rgb_values", "depth_values", "normal_map", "weights")}, model.ray_sampler.last_iters))
+        after_graph = torch.rand(1).item()
+    assert after_eager == after_graph, "the replay must consume the CPU generator like the eager forward"
+    for (oe, ie), (og, ig) in zip(eager, graphed):
+        assert ie == ig
+        for k in oe:
+            assert torch.allclose(oe[k], og[k], rtol=1e-4, atol=1e-6, equal_nan=True), k
+    with pytest.raises(ValueError):
+        renderer({"intrinsics": K, "uv": chunks[0]["uv"][:, :100], "pose": chunks[0]["pose"]})

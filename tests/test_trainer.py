@@ -131,6 +131,10 @@ def test_short_run_reduces_the_loss(tmp_path):
     sample["uv"], gt["rgb"] = sample["uv"][:, :1500], gt["rgb"][:, :1500]
     img = t.render_step((idx, sample, gt))
     assert img["rgb_values"].shape == (1500, 3) and torch.isfinite(img["rgb_values"]).all() and torch.isfinite(img["psnr"])
+    # the same image with every full chunk replayed as one hipGraph (spurfies_amd/eval_graph.py): three chunks of 500 pixels
+    img_g = t.render_step((idx, sample, gt), graph=True)
+    for k in ("rgb_values", "depth_values", "normal_map"):
+        assert torch.allclose(img_g[k], img[k], rtol=1e-4, atol=1e-5, equal_nan=True), k
 
 
 def test_prior_checkpoint_renaming_follows_the_reference(tmp_path):
