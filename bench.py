@@ -367,7 +367,7 @@ def main():
     # between a cold and a loaded chip), then both shapes timed A B B A twice (TrainStep.autotune_geo_engine); all before the W warm-up steps
     tune = None
     if args.geo_engine == "auto":
-        for i in range(10):                        # forward + backward passes only: no optimiser step, nothing captured yet in --graph mode
+        for i in range(40):                        # forward + backward passes only: no optimiser step, nothing captured yet in --graph mode
             step._forward_backward(dict(batches[0][i % len(batches[0])][0]), batches[0][i % len(batches[0])][1])
         tune = step.autotune_geo_engine(*batches[0][0])
     else:
@@ -449,7 +449,7 @@ def main():
                                        "at 90 % matrix-pipe duty and 2.2 GHz at 66-76 %, i.e. 240-290 algorithmic TFLOP/s is what this instruction mix "
                                        "can draw (DESIGN.md section 6)",
                 "held_clock": held_clock(ach, clk),
-                "engine": {"selected": engine, "mfma": shape, "how": ("timed both shapes on this box, warm chip, before the warm-up steps (main-pass launch, A B B A twice)" if tune else "--geo-engine"),
+                "engine": {"selected": engine, "mfma": shape, "how": ("timed both shapes on this box after 40 untimed passes, before the warm-up steps (main-pass launch; the shape alternates every pass, A B B A x 10)" if tune else "--geo-engine"),
                            "autotune_ms": tune},
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": kname + " (+ geo_point_reduce_kernel, < 1 % of the launch)",
                 "timing": ("HIP events over eager passes of the timed batches, right after the timed region (events cannot sit inside a "

@@ -131,13 +131,14 @@ class TrainStep:
         return losses, out
 
     # ------------------------------------------------------------------ MFMA-shape selection of the dominant kernel
-    def autotune_geo_engine(self, model_input, ground_truth, reps=5, rounds=2):
+    def autotune_geo_engine(self, model_input, ground_truth, reps=10):
         """The geometry kernel exists on two MFMA shapes with the same arithmetic (ops.set_geo_mode: 'split' = 16x16x32, 'split_w' =
         32x32x16).  Which one is faster is decided by the clock the chip holds under each, and that differs from box to box by as much
         as the two differ: time the main-pass launch of both inside `reps` forward + backward passes of this batch
-        (order A B B A, `rounds` times, HIP events; no optimiser step, the CPU generator is restored) and keep the faster.  Call it on a WARM
-        chip (after a few steps): the clock each shape holds differs between a cold and a loaded chip, and the loaded one is what the run sees
-        (measured: the cold ranking was the opposite of the steady-state one on one box of six).  -> {'split': ms, 'split_w': ms, 'selected': name}."""
+        (no optimiser step, the CPU generator is restored) and keep the faster.  The shape alternates EVERY pass in the order A B B A (4 x reps
+        timed passes after four untimed ones), so that the slow clock drift of a chip that is still warming up — larger than the difference
+        between the shapes — cancels; call it on a loaded chip (after a few steps): the cold ranking was the opposite of the steady-state one on
+        two boxes of eleven.  -> {'split': ms, 'split_w': ms, 'selected': name}."""
         from . import _prof
 
         rng = torch.get_rng_state()
@@ -145,13 +146,15 @@ class TrainStep:
         R = model_input["uv"].shape[1]
         ms = {"split": [], "split_w": []}
         try:
-            for mode in ("split", "split_w", "split_w", "split") * max(1, int(rounds)):
+            order = ("split", "split_w", "split_w", "split")
+            for i in range(4 * (int(reps) + 1)):
+                mode = order[i % 4]
                 ops.set_geo_mode(mode)
-                self._forward_backward(model_input, ground_truth)          # first pass of a shape is not timed
-                _prof.start(("geo",))
-                for _ in range(reps):
-                    self._forward_backward(model_input, ground_truth)
-                ms[mode] += [p["ms"] for p in _prof.stop() if p["with_grad"] and p["rows"] >= 2 * R]
+                if i >= 4:
+                    _prof.start(("geo",))
+                self._forward_backward(model_input, ground_truth)
+                if i >= 4:
+                    ms[mode] += [p["ms"] for p in _prof.stop() if p["with_grad"] and p["rows"] >= 2 * R]
         finally:
             ops.set_geo_mode(prev)
             torch.set_rng_state(rng)
