@@ -158,6 +158,9 @@ int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, 
 #define SPF_ARITH_SPLIT 0
 #define SPF_ARITH_F32 1
 #define SPF_ARITH_SPLIT_W 2
+/* spf_geo_forward only, OR-ed into arith: the bf16-piece kernels of THIS launch stamp the held-clock counters (spf_geo_clock_read).  Without
+ * the bit a launch touches no state outside its arguments. */
+#define SPF_ARITH_CLOCK 0x100
 
 /* Number of floats of the packed F_geometry/T weight image. */
 
@@ -190,7 +193,10 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
                     float* pair_tmp, int32_t arith, void* stream);
 
 /* Diagnostics (no reference counterpart; bench.py's `roofline.held_clock`): the shader clock the chip held while the bf16-piece
- * geometry kernels ran since the last reset, measured by the kernels themselves (s_memtime / s_memrealtime stamps of every workgroup).
+ * geometry kernels ran since the last reset, measured by the kernels themselves (s_memtime / s_memrealtime stamps of every workgroup) —
+ * only by launches that asked for it (spf_geo_forward's arith | SPF_ARITH_CLOCK).  The counters are the library's ONE piece of device-global
+ * state: one array per device and process, shared by every stream and caller (two measuring callers see each other's launches; a reset
+ * wipes both) and read from the CURRENT device — a diagnostic for a single measuring caller (bench.py), off by default.
  * out12 (HOST, 12 x uint64) = [mfma shape: 0 = 16x16x32 (SPF_ARITH_SPLIT), 1 = 32x32x16 (SPF_ARITH_SPLIT_W)][0 = without, 1 = with the
  * Jacobian sweep][shader cycles, 100 MHz ticks, workgroups], summed over workgroups; clock [GHz] = 0.1 * cycles / ticks.  Synchronous
  * (a device-to-host copy of the current device's counters); reset != 0 zeroes them afterwards. */

@@ -644,16 +644,18 @@ __device__ __forceinline__ void bwd_epilogue_xs(__bf16* X, const f32x4 (&acc)[4]
 
 constexpr int X3_LDS_BF16 = 3 * X3_PLANE;
 
-// Held-clock counters of the bf16-piece kernels, ALWAYS compiled in (spf_geo_clock_read): thread 0 of every workgroup stamps the
+// Held-clock counters of the bf16-piece kernels, compiled in but OFF unless the call asks for them (arith | SPF_ARITH_CLOCK; the counters
+// are one process-wide array per device, shared by every stream: a diagnostic for one measuring caller, documented as such in the header —
+// a launch without the flag touches no global state).  With the flag (spf_geo_clock_read): thread 0 of every workgroup stamps the
 // shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) at kernel entry and exit and adds the two
 // differences to a per-(MFMA shape, with / without Jacobian sweep) triple {cycles, ticks, workgroups}: sum(cycles) / sum(ticks) x 100 MHz
 // is the shader clock the chip HELD while these kernels ran (DVFS give-back under MFMA-dense load, MI355X_MICROARCH.md) — measured in
 // the run that reports it, not read from a file.  Cost: two scalar-memory reads and three atomics per workgroup per launch
 // (256 workgroups x ~1.5 ms).
 __device__ unsigned long long spf_geo_clock_buf[2][2][3];
-#define CLK_DECL const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#define CLK_DECL const unsigned long long clk_c0 = clk ? __builtin_amdgcn_s_memtime() : 0ull, clk_r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #define CLK_FLUSH(ENGINE, JAC)                                                                            \
-    if (threadIdx.x == 0) {                                                                               \
+    if (clk && threadIdx.x == 0) {                                                                        \
         atomicAdd(&spf_geo_clock_buf[ENGINE][JAC][0], __builtin_amdgcn_s_memtime() - clk_c0);             \
         atomicAdd(&spf_geo_clock_buf[ENGINE][JAC][1], __builtin_amdgcn_s_memrealtime() - clk_r0);         \
         atomicAdd(&spf_geo_clock_buf[ENGINE][JAC][2], 1ull);                                              \
@@ -687,7 +689,7 @@ __global__ void __launch_bounds__(256, 1)
 geo_pairs_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
                     const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
                     int max_pairs, int k, const float* __restrict__ pts, const float* __restrict__ feat_geo, const float* packed,
-                    float rbf, float* __restrict__ pair_tmp, float* __restrict__ jac) {
+                    float rbf, float* __restrict__ pair_tmp, float* __restrict__ jac, int clk) {
     __shared__ __attribute__((aligned(16))) __bf16 X[X3_LDS_BF16];
     __shared__ float red[4][64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1035,7 +1037,7 @@ __global__ void __launch_bounds__(256, 1)
 geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
                     const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
                     int max_pairs, int k, const float* __restrict__ pts, const float* __restrict__ feat_geo, const float* packed,
-                    float rbf, float* __restrict__ pair_tmp, float* __restrict__ jac) {
+                    float rbf, float* __restrict__ pair_tmp, float* __restrict__ jac, int clk) {
     __shared__ __attribute__((aligned(16))) __bf16 X[X3_LDS_BF16];
     __shared__ float red[4][64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1254,8 +1256,10 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
                     const int32_t* n_points, const int32_t* n_pairs, int32_t max_points, int32_t max_pairs, int32_t k, const float* pts,
                     const float* feat_geo, const float* packed, float rbf, float* sdf, float* grad, float* wn, float* jac,
                     float* pair_tmp, int32_t arith, void* stream) {
+    const int clk = (arith & SPF_ARITH_CLOCK) ? 1 : 0;      // opt-in held-clock stamps (spf_geo_clock_read); ignored by the fp32-MFMA twin
+    arith &= ~SPF_ARITH_CLOCK;
     if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32 && arith != SPF_ARITH_SPLIT_W)
-        return spf::fail(SPF_EINVAL, "spf_geo_forward: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_SPLIT_W (2), got %d", arith);
+        return spf::fail(SPF_EINVAL, "spf_geo_forward: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_SPLIT_W (2) [| SPF_ARITH_CLOCK], got %d", arith);
     if (max_points < 0 || max_pairs < 0 || k < 1 || k > SPF_KMAX)
         return spf::fail(SPF_EINVAL, "spf_geo_forward: bad sizes (max_points=%d max_pairs=%d k=%d)", max_points, max_pairs, k);
     if (max_points == 0 || max_pairs == 0) return SPF_OK;
@@ -1270,18 +1274,18 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
         const int b1 = tiles < 256 ? tiles : 256;   // one workgroup per CU (the bf16 planes take 101 KB of LDS)
         if (grad)
             geo_pairs_x3_kernel<true><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
-                                                         pair_tmp, jac);
+                                                         pair_tmp, jac, clk);
         else
             geo_pairs_x3_kernel<false><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
-                                                          rbf, pair_tmp, nullptr);
+                                                          rbf, pair_tmp, nullptr, clk);
     } else if (arith == SPF_ARITH_SPLIT_W) {
         const int b1 = tiles < 256 ? tiles : 256;
         if (grad)
             geo_pairs_x3w_kernel<true><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
-                                                          pair_tmp, jac);
+                                                          pair_tmp, jac, clk);
         else
             geo_pairs_x3w_kernel<false><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
-                                                           rbf, pair_tmp, nullptr);
+                                                           rbf, pair_tmp, nullptr, clk);
     } else if (grad)
         geo_pairs_kernel<true><<<blocks, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
                                                       pair_tmp, jac);

@@ -110,6 +110,8 @@ class BucketedAllReduce:
         self.ranges = ranges
         self._pending, self._done = [], set()
         self.log = []                                     # bucket names in the order they were reduced during the last step (tests)
+        self.armed = False                                # begin() .. finish(): hooks may have started reductions that finish() must wait for
+        self.timing = None                                # list -> finish() appends (event before, event after) pairs on the compute stream
 
     @staticmethod
     def bucket_of(name: str) -> str:
@@ -119,10 +121,18 @@ class BucketedAllReduce:
             return "geo_latents"
         if name.startswith(("F_color.0.", "F_color.2.", "F_color.4.")):
             return "color_weights"
-        return "head"                                     # F_color.6, R.*, density.beta (written by the compositing backward, before the head's)
+        if name.startswith(("F_color.6.", "R.")) or name == "density.beta":
+            return "head"                                 # final after the head's weight-gradient GEMMs (beta: the compositing backward, earlier)
+        # anything else (an unfrozen prior layer, learnable points, a new module): no hook knows when its gradient is complete, so it is
+        # only ever reduced by finish(), after the whole backward
+        return "rest"
+
+    def bytes_per_step(self) -> dict:
+        return {b: 4 * sum(hi - lo for lo, hi in r) for b, r in self.ranges.items()}
 
     def begin(self):
         self._pending, self._done, self.log = [], set(), []
+        self.armed = True
 
     def ready(self, name):
         if world_size(self.group) == 1 or name in self._done or name not in self.ranges:
@@ -133,11 +143,28 @@ class BucketedAllReduce:
             self._pending.append(dist.all_reduce(self.flat.buffer[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
+        """Reduce the buckets no hook announced, then make the compute stream wait for every reduction of this step."""
+        ev = None
+        if self.timing is not None and self.flat.buffer.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for name in self.ranges:
             self.ready(name)
         for w in self._pending:
             w.wait()
         self._pending = []
+        self.armed = False
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
+
+    def exposed_ms(self):
+        """Per step: how long the compute stream sat in finish() (launch of the last buckets + waiting for all of them) — the part of the
+        gradient exchange that did NOT hide behind the backward.  Call after a synchronisation; clears the record."""
+        out = [a.elapsed_time(b) for a, b in (self.timing or [])]
+        if self.timing is not None:
+            self.timing = []
+        return out
 
 
 def sharded_loss(loss_mod, out, ground_truth, group=None):

@@ -146,7 +146,10 @@ class PointVolSDF(nn.Module):
         """Identity of everything the cached device state (cell table, TV graph, packed prior image) was derived from; a
         captured hipGraph holds pointers into that state and must be dropped when the key changes (train.py:TrainStep)."""
         self._packed()
-        return (self.neural_pts.data_ptr(), self.neural_pts._version, self.neural_pts.shape[0], self._packed_key)
+        # ... and the storage of every parameter the forward reads: a captured graph bakes those addresses in, and FlatAdam._flatten (after
+        # optimizer.load_state_dict) or module.to() re-point p.data — a replay would then render from the old, possibly freed, storage
+        return (self.neural_pts.data_ptr(), self.neural_pts._version, self.neural_pts.shape[0], self._packed_key,
+                tuple(p.data_ptr() for p in self.parameters()))
 
     def tv_graph(self):
         """Static neighbour graph of tv_regul (utils.py:221-282), rebuilt only when the cloud (or k / r) changes."""

@@ -138,6 +138,15 @@ def set_geo_mode(mode: str):
     _ARITH["geo"] = _GEO_ARITH_NAMES[mode]
 
 
+_GEO_CLOCK = [False]
+
+
+def geo_clock_enable(on=True):
+    """Ask the bf16-piece geometry launches of THIS process to stamp the library's held-clock counters (arith | SPF_ARITH_CLOCK).  Off by
+    default: the counters are process-wide per device (include/spurfies_hip.h), so only a single measuring caller (bench.py) turns them on."""
+    _GEO_CLOCK[0] = bool(on)
+
+
 def geo_clock(reset=True):
     """Shader clock the bf16-piece geometry kernels HELD since the last reset, measured by the kernels themselves
     (include/spurfies_hip.h: spf_geo_clock_read; synchronises the device) ->
@@ -188,7 +197,7 @@ def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_ou
         _lib.check(_lib.lib().spf_geo_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off), _lib.ptr(pl.pair_point),
                                               _lib.ptr(pl.n_points), _lib.ptr(pl.n_pairs), pl.max_points, pl.max_pairs, pl.k, _lib.ptr(pts),
                                               _lib.ptr(feat_geo), _lib.ptr(packed), float(rbf), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(wn),
-                                              _lib.ptr(jac), _lib.ptr(tmp), _ARITH["geo"], _lib.stream_ptr()), "spf_geo_forward")
+                                              _lib.ptr(jac), _lib.ptr(tmp), _ARITH["geo"] | (0x100 if _GEO_CLOCK[0] else 0), _lib.stream_ptr()), "spf_geo_forward")
     return {"sdf": sdf, "wn": wn, "grad": grad, "jac": jac}
 
 

@@ -93,8 +93,11 @@ class TrainStep:
         else:
             losses, out = self._forward_backward(model_input, ground_truth, reduce_buckets=True)
         if self.world > 1:
-            if self.buckets is not None and not self.use_graph:
-                self.buckets.finish()                    # the buckets the backward has not announced (geometry latents: last), then wait for all
+            if self.buckets is not None and self.buckets.armed:
+                # the backward that just ran had the bucket hooks (eager sync-free step, also the eager fallback of a use_graph step that
+                # carries local_data): reduce the buckets nobody announced (geometry latents: last), then wait for all of them — never a
+                # second, dense reduce on top (that summed three buckets twice: round-3 advisor finding)
+                self.buckets.finish()
             else:
                 sdist.all_reduce_sum(self.flat.buffer, self.group)
         # train.py:359-363, 548-564 — clip_grad_norm_(1.0), skip the update when a gradient is not finite, Adam: one fused
@@ -444,6 +447,7 @@ class VolOpt:
     # ---- data -----------------------------------------------------------------------------------------------
     def gen_dataset(self, stg):
         self.stg = stg
+        self._local_cache = {}           # device copies of the views' feature maps belong to the dataset that is being replaced
         if self.train_dataset is None:
             if self.scene is None:
                 raise RuntimeError("no dataset: pass dataset=... or scene=... (the reference's DTU / MipNeRF-360 loaders need its data download)")
@@ -498,7 +502,9 @@ class VolOpt:
         tensors on every __getitem__, datasets/dtu.py:268-291, so object identity is no key) in an LRU bounded by the number of views; an entry
         is reused only while the host tensors have the shapes it was made from."""
         idx = int(indices.reshape(-1)[0]) if torch.is_tensor(indices) else int(indices if not isinstance(indices, (list, tuple)) else indices[0])
-        sig = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(local.items()) if torch.is_tensor(v))
+        # identity of the dataset object rides in the signature: the same view index of ANOTHER dataset (new scene / stage, same
+        # resolution) must not hit the old view's maps
+        sig = (id(self.train_dataset),) + tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(local.items()) if torch.is_tensor(v))
         hit = self._local_cache.get(idx)
         if hit is not None and hit[0] == sig:
             self._local_cache[idx] = self._local_cache.pop(idx)          # most recently used last

@@ -179,3 +179,33 @@ def test_bucketed_all_reduce_equals_one_flat_all_reduce():
                 cover[lo:hi] += 1
         assert (cover == 1).all()
         assert ranges["color_latents"] == [(0, 640)] and ranges["geo_latents"] == [(640, 960)] and len(ranges["color_weights"]) == 1 and len(ranges["head"]) == 1
+
+
+def test_unknown_parameters_are_only_reduced_by_finish():
+    """Round-3 advisor finding: a trainable tensor outside the head whitelist (an unfrozen prior layer, learnable points, a new module) must not
+    ride in 'head' — the bucket reduced earliest — but in one only finish() reduces, after the whole backward."""
+    B = sdist.BucketedAllReduce.bucket_of
+    assert [B(n) for n in PARAM_NAMES] == (["color_latents", "geo_latents"] + ["color_weights"] * 6 + ["head"] * 9)
+    for n in ("F_geometry.0.weight", "T.0.bias", "neural_pts", "extra.module.weight"):
+        assert B(n) == "rest"
+    params = [torch.zeros(4, requires_grad=True) for _ in range(3)]
+    flat = sdist.FlatGrads(params)
+    b = sdist.BucketedAllReduce(flat, ["R.0.weight", "F_geometry.0.weight", "density.beta"])
+    assert b.ranges == {"head": [[0, 4], [8, 12]], "rest": [[4, 8]]} and b.bytes_per_step() == {"head": 32, "rest": 16}
+    b.begin()
+    assert b.armed
+    b.finish()                       # world 1: nothing to reduce, but the step is disarmed
+    assert not b.armed
+
+
+def test_bench_without_launcher_refuses_rccl_ranks_it_has_no_gpus_for():
+    """bench.py --gpus N with no WORLD_SIZE starts its own ranks; over RCCL it first checks that N GPUs are visible (none in this container)
+    and says so instead of dying inside the first collective."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SPF_DIST_BACKEND")}
+    n = torch.cuda.device_count() + 1 if torch.cuda.device_count() else 2
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "visible GPUs" in out.stderr and not out.stdout.strip()

@@ -5,6 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../spurfies_amd/csrc -I../../include x3_loop_rate.hip -o x3_loop_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include "mlp_tile_x3.h"
 using namespace spf;
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(256, 1) k(const bf16x8* __restrict__ wfrag, co
     if (keep == 123.456f || bits[0] == 0x12345u) cyc[1000] = 1;     // keep the results alive
 }
 
-int main() {
+int main(int argc, char** argv) {
     const size_t nfrag = (size_t)4 * 16 * 2 * 3 * 64;
     std::vector<unsigned short> h(nfrag * 8);
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (unsigned short)((i * 7) % 64);     // small bf16 values
@@ -100,6 +101,32 @@ int main() {
     const int layers = 600;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float ms; unsigned long long c0;
+    if (argc >= 3) {
+        // sustained mode for tools/power_probe.py: `x3_loop_rate <0|1|2> <seconds>` runs ONE loop body back to back for that long (after 1 s of
+        // untimed load) and prints the averages, so that a power sampler beside it sees a steady state
+        const int mode = atoi(argv[1]);
+        const double secs = atof(argv[2]);
+        auto launch = [&]() {
+            if (mode == 0) k<0><<<256, 256>>>(dW, dB, layers, dC);
+            else if (mode == 1) k<1><<<256, 256>>>(dW, dB, layers, dC);
+            else k<2><<<256, 256>>>(dW, dB, layers, dC);
+        };
+        double tot_ms = 0, tot_cyc = 0; int n = 0;
+        for (int phase = 0; phase < 2; ++phase) {
+            const double want = phase == 0 ? 1000.0 : secs * 1000.0;
+            double got = 0;
+            while (got < want) {
+                (void)hipEventRecord(e0); launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&ms, e0, e1); (void)hipMemcpy(&c0, dC, 8, hipMemcpyDeviceToHost);
+                got += ms;
+                if (phase == 1) { tot_ms += ms; tot_cyc += (double)c0; ++n; }
+            }
+        }
+        printf("{\"mode\": %d, \"launches\": %d, \"ms_per_launch\": %.4f, \"tflops_fp32_equiv\": %.2f, \"cycles_per_kstep\": %.1f, \"ghz\": %.4f, \"mfma_duty\": %.4f}\n",
+               mode, n, tot_ms / n, 256.0 * layers * 2.0 * 64 * 256 * 256 * n / (tot_ms * 1e-3) / 1e12, tot_cyc / n / layers / 16.0, tot_cyc / (tot_ms * 1e6),
+               768.0 / (tot_cyc / n / layers / 16.0));
+        return 0;
+    }
 #define RUN(M, label)                                                                                                              \
     k<M><<<256, 256>>>(dW, dB, layers, dC);                                                                                        \
     (void)hipEventRecord(e0); k<M><<<256, 256>>>(dW, dB, layers, dC); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);     \

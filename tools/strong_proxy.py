@@ -1,0 +1,94 @@
+"""Strong-scaling proxy on ONE GPU: the per-rank workload an 8-GPU strong-scaled run of BASELINE.json configs[1] / configs[4] implies
+(R / N rays of the batch per rank, full replica of the cloud), timed as the optimisation step before communication.
+
+    python3 tools/strong_proxy.py [--out gpurun_out/strong_proxy.json] [--dense] [--steps 60]
+
+Per ray count: ms/step eager (sync-free launches), ms/step with the forward + loss + backward replayed as one hipGraph, the host's time to
+ENQUEUE an eager step (if that exceeds the GPU's step time the eager mode is host-bound), launches per step.
+"""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+from spurfies_amd import ops  # noqa: E402
+from spurfies_amd import synthetic as syn  # noqa: E402
+from spurfies_amd.conf import default_model_conf  # noqa: E402
+from spurfies_amd.model.pointneus_disent import PointVolSDF  # noqa: E402
+from spurfies_amd.train import TrainStep  # noqa: E402
+
+
+def build(scene, device, **kw):
+    st = scene["state"]
+    conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
+    model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
+    model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
+    return model, TrainStep(model, **kw)
+
+
+def timed(step, batches, warm, n):
+    for i in range(warm):
+        step(*batches[i % len(batches)])
+    torch.cuda.synchronize()
+    enq = []
+    t0 = time.perf_counter()
+    for i in range(warm, warm + n):
+        t1 = time.perf_counter()
+        step(*batches[i % len(batches)])
+        enq.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt / n * 1e3, 1e3 * float(np.median(enq[:3])), 1e3 * float(np.median(enq))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/strong_proxy.json")
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--dense", action="store_true", help="configs[4]: 2e5 points, spacing 0.0125, 4096 rays per batch")
+    ap.add_argument("--engine", default="split_w")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    torch.set_num_threads(1)
+    ops.set_geo_mode(a.engine)
+    if a.dense:
+        points, spacing, rays_list, name = 200000, 0.0125, [4096, 2048, 1024, 512], "configs[4]"
+    else:
+        points, spacing, rays_list, name = 10000, 0.025, [1024, 512, 256, 128], "configs[1]"
+    scene = syn.make_scene(points, seed=0, spacing=spacing, prior="fitted")
+    rows = []
+    for rays in rays_list:
+        batches = bench.make_batches(scene, 32, rays, 0, 1, dev)
+        row = {"rays_per_rank": rays, "ranks_implied": rays_list[0] // rays}
+        for mode, kw in (("eager", dict(sync_free=True)), ("graph", dict(sync_free=True, use_graph=True))):
+            torch.manual_seed(1)
+            model, step = build(scene, dev, **kw)
+            ms, enq_first, enq_med = timed(step, batches, 12, a.steps)
+            row[mode] = {"ms_per_step": ms, "host_enqueue_ms_first3": enq_first, "host_enqueue_ms_median": enq_med,
+                         "ray_samples_per_s": bench.SAMPLES_PER_RAY * rays / (ms * 1e-3)}
+            counts = model.stats.get("counts")
+            if counts is not None:
+                row["valid_points"], row["pairs"] = int(counts[0].item()), int(counts[1].item())
+            del model, step
+            torch.cuda.empty_cache()
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+    base = rows[0]
+    for r in rows:
+        for mode in ("eager", "graph"):
+            r[mode]["speedup_vs_full_batch"] = base[mode]["ms_per_step"] / r[mode]["ms_per_step"]
+    res = {"what": f"strong-scaling proxy, {name} shape: one rank's share of the batch on one MI355X, optimisation step before communication "
+                   "(fwd + loss + bwd + clip + Adam), fitted prior", "neural_points": points, "engine": a.engine, "steps_timed": a.steps,
+           "device": torch.cuda.get_device_name(0), "rows": rows}
+    json.dump(res, open(a.out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
