@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--sync", action="store_true", help="default (reference-shaped) step with one host read-back per step")
     ap.add_argument("--graph", action="store_true", help="replay forward + loss + backward as one hipGraph (measured no faster than the eager sync-free "
                     "step on MI355X: ~3 us of dependency handling per graph node; the eager launches run ahead of the GPU)")
-    ap.add_argument("--no-graph", action="store_true", help="(default since the sync-free step became GPU-bound; kept for old command lines)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches even at <= 256 rays per GPU (where the graph replay is the default: the eager step is host-bound there)")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--mode", choices=["train", "eval"], default="train", help="train (the contract line): one optimisation step per step; eval: one evaluation-render chunk per "
                     "step (PointVolSDF.forward(fast=-1) under no_grad: the full error-bounded sampler, kNN, SDF + normals, colour, compositing — SURVEY.md "
@@ -414,7 +414,9 @@ def main():
     rays_total = args.global_rays if strong else args.rays * world
     rays_local = rays_total // world
     torch.manual_seed(0)
-    use_graph = args.graph and not args.sync and world == 1 and args.scenes == 1
+    # small per-rank batches are host-bound in eager mode (the host needs ~2 ms to enqueue the ~50 launches of a step the GPU runs in ~1 ms
+    # at 128 rays: profiles/r04_strong_proxy.json): forward + loss + backward replay as hipGraphs there unless --no-graph
+    use_graph = (args.graph or (rays_local <= 256 and not args.no_graph)) and not args.sync and args.scenes == 1
     scenes = [build_scene_step(args, seed, device, world, use_graph) for seed in range(args.scenes)]
     scene, model, step = scenes[0]
     n_batches = args.warmup + args.steps + max(args.sustained, 0)
@@ -468,10 +470,11 @@ def main():
         nbytes = 4 * step.flat.buffer.numel()
         dist_info.update({
             "allreduce_bytes_per_step": (nbytes + 16) * args.scenes,
-            "allreduce_what": f"one flat fp32 gradient buffer of {nbytes} B per scene step (4 buckets, reduced asynchronously as the backward completes them) "
-                              "+ 16 B of loss normalisers between forward and loss",
+            "allreduce_what": f"one flat fp32 gradient buffer of {nbytes} B per scene step (" +
+                              ("ONE dense all-reduce behind the two graph replays" if use_graph else "4 buckets, reduced asynchronously as the backward completes them") +
+                              ") + 16 B of loss normalisers between forward and loss",
             "buckets_bytes": step.buckets.bytes_per_step() if step.buckets is not None else None,
-            "bucket_order_last_step": list(step.buckets.log) if step.buckets is not None else None,
+            "bucket_order_last_step": list(step.buckets.log) if (step.buckets is not None and not use_graph) else None,
             "finish_ms_per_step": (sum(exposed) / args.steps) if exposed else None,
             "finish_what": "HIP events on rank 0's compute stream around BucketedAllReduce.finish() (launch of the last bucket + wait for all): "
                            "the part of the exchange not hidden behind the backward"})
@@ -568,7 +571,8 @@ def main():
                    "sampler_draws": "CPU generator, reference call order" + ("" if world == 1 else ("; batch-wide per rank, own rows kept (--exact-draws)" if args.exact_draws
                                                                                                    else "; per-rank streams, own rays only")),
                    "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product from three bf16 pieces per operand (6 exact bf16 piece products, fp32 accumulate: fp32-class, <= 2 ulp per product)",
-                   "launch": "hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~80 per step: 52 library kernels + torch's small elementwise / copy / fill launches)")},
+                   "launch": ("hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if world == 1 else
+                              "two hipGraph replays ([forward + counts] | 16-byte count all-reduce | [loss + backward]), dense gradient all-reduce, 3 eager launches (clip + guard + Adam)") if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~80 per step: 52 library kernels + torch's small elementwise / copy / fill launches)")},
         "roofline": roof, "dist": dist_info,
         "sustained_ms_per_step": sustained, "sustained_steps": args.sustained if sustained is not None else 0,
         "loss_last": loss_last,

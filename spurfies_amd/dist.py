@@ -130,9 +130,10 @@ class BucketedAllReduce:
     def bytes_per_step(self) -> dict:
         return {b: 4 * sum(hi - lo for lo, hi in r) for b, r in self.ranges.items()}
 
-    def begin(self):
+    def begin(self, armed=True):
+        """armed=False: a backward whose gradients stay local (timing passes, graph warm-up): no hook fires, nothing for finish() to wait for."""
         self._pending, self._done, self.log = [], set(), []
-        self.armed = True
+        self.armed = bool(armed)
 
     def ready(self, name):
         if world_size(self.group) == 1 or name in self._done or name not in self.ranges:
@@ -167,6 +168,17 @@ class BucketedAllReduce:
         return out
 
 
+def fused_counts(out):
+    """This rank's share of the normalisers of the mean-type losses, device float [4] = {rays, valid points, valid pseudo points, surface hits
+    of the local loss}: all-reduced (16 bytes) between the forward and the fused loss kernels.  A separate function because a graphed
+    multi-GPU step ends its first captured segment here (train.py)."""
+    f = out["_fused"]
+    dev = out["rgb_values"].device
+    cnt = (f["pvalid"].bool() & f["ray_valid"].bool()).sum().float()
+    lcnt = out["local_count"] if "local_count" in out else torch.zeros((), device=dev)
+    return torch.stack([torch.full((), float(out["rgb_values"].shape[0]), device=dev), f["n_points"][0].float(), cnt, lcnt])
+
+
 def sharded_loss(loss_mod, out, ground_truth, group=None):
     """VolSDFLoss (spurfies/model/loss.py:51-101) on one rank's rays with GLOBAL normalisers.
 
@@ -176,10 +188,7 @@ def sharded_loss(loss_mod, out, ground_truth, group=None):
     dev = out["rgb_values"].device
     G = world_size(group)
     if "_fused" in out:                          # sync-free mode: fused loss kernels with the all-reduced counts as normalisers
-        f = out["_fused"]
-        cnt = (f["pvalid"].bool() & f["ray_valid"].bool()).sum().float()
-        lcnt = out["local_count"] if "local_count" in out else torch.zeros((), device=dev)
-        counts = torch.stack([torch.full((), float(out["rgb_values"].shape[0]), device=dev), f["n_points"][0].float(), cnt, lcnt])
+        counts = fused_counts(out)
         all_reduce_sum(counts, group)
         return loss_mod.fused_forward(out, ground_truth, denom=counts, world=G)
     rgb_gt = ground_truth["rgb"].to(dev).reshape(-1, 3)

@@ -28,8 +28,10 @@ class TrainStep:
     def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False, use_graph=False, draws="batch", keep_grads=False):
         """sync_free: static shapes and device-side counts everywhere — no host synchronisation inside the step (the
         default path reads [P, n_pairs] back once per step to size the colour buffers exactly).
-        use_graph (implies sync_free): forward + loss + backward (~230 kernel launches) are captured once into a hipGraph
-        and replayed; the gradient all-reduce, clipping and Adam stay eager."""
+        use_graph (implies sync_free): forward + loss + backward (~50 kernel launches) are captured once into a hipGraph
+        and replayed; the gradient all-reduce, clipping and Adam stay eager.  Ray-sharded (world > 1): two graphs around the eager
+        16-byte count all-reduce, then ONE dense all-reduce of the flat gradient buffer — the mode for small per-rank batches, where
+        the host cannot enqueue ~50 launches as fast as the GPU runs them (strong scaling)."""
         self.model = model
         sync_free = sync_free or use_graph
         self.sync_free = sync_free
@@ -124,7 +126,7 @@ class TrainStep:
             self.flat.zero_()
         self._grads_clean = False
         if self.buckets is not None:
-            self.buckets.begin()
+            self.buckets.begin(armed=reduce_buckets)
             if reduce_buckets:
                 ops.set_bucket_hook(self.buckets.ready)
         try:
@@ -173,8 +175,6 @@ class TrainStep:
         key = self.model.cache_key()
         if self._graph is None or self._static_in["uv"].shape != model_input["uv"].shape or key != self._graph_key:
             self._graph_key = key
-            if self.world > 1:
-                raise NotImplementedError("use_graph with ray sharding: the count all-reduce inside the loss is not captured yet")
             self._static_in = {k: model_input[k].clone() for k in keys_in}
             self._static_gt = {k: ground_truth[k].to(dev).clone() for k in ("rgb", "mask")}
             # warm-up on a side stream (builds the cell table, TV graph, workspaces, allocator pools) without touching the
@@ -190,11 +190,30 @@ class TrainStep:
             self._refresh_draws(model_input["uv"].shape[1], dev)      # allocates the persistent draw buffers
             torch.set_rng_state(rng)
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
-                losses = self.loss(out, self._static_gt)
-                self.flat.zero_()
-                losses["loss"].backward(gradient=self._root_grad(losses["loss"]))
+            self._graph_tail, self._counts = None, None
+            if self.world == 1:
+                with torch.cuda.graph(self._graph):
+                    out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
+                    losses = self.loss(out, self._static_gt)
+                    self.flat.zero_()
+                    losses["loss"].backward(gradient=self._root_grad(losses["loss"]))
+            else:
+                # ray-sharded: the step has one exchange INSIDE forward + backward — the 16 bytes of loss normalisers between the forward and
+                # the loss kernels (dist.sharded_loss).  No collective is captured (a mis-captured one hangs every rank): the step is TWO
+                # graphs over one memory pool, [forward + this rank's counts] and [loss + backward], with the count all-reduce issued eagerly
+                # between the replays and the gradient all-reduce after them.  The autograd graph spans both captures; its saved tensors
+                # live in the shared pool.  During capture nothing executes, so the eager all-reduce below sums unwritten memory on
+                # every rank alike — its result is never used.
+                pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(self._graph, pool=pool):
+                    out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
+                    self._counts = sdist.fused_counts(out)
+                sdist.all_reduce_sum(self._counts, self.group)
+                self._graph_tail = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph_tail, pool=pool):
+                    losses = self.loss.fused_forward(out, self._static_gt, denom=self._counts, world=self.world)
+                    self.flat.zero_()
+                    losses["loss"].backward(gradient=self._root_grad(losses["loss"]))
             self._static_out = (losses, out)
         for k in keys_in:
             self._static_in[k].copy_(model_input[k], non_blocking=True)
@@ -202,6 +221,9 @@ class TrainStep:
             self._static_gt[k].copy_(ground_truth[k], non_blocking=True)
         self._refresh_draws(model_input["uv"].shape[1], dev)
         self._graph.replay()
+        if self._graph_tail is not None:
+            sdist.all_reduce_sum(self._counts, self.group)
+            self._graph_tail.replay()
         return self._static_out
 
     def _root_grad(self, loss):

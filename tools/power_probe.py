@@ -37,7 +37,21 @@ class Sensors:
     def __init__(self):
         self.kind, self.detail = None, {}
         self.power_file = self.sclk_file = self.cap_file = self.temp_file = None
-        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        # the node holds several GPUs and the box shows one of them to HIP: take the card whose PCI address is HIP device 0's
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(0)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception as e:
+            self.detail["pci_error"] = repr(e)[:200]
+        self.detail["hip_device_pci"] = want
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        self.detail["cards"] = {hw: os.path.basename(os.path.realpath(os.path.join(hw, "..", ".."))) for hw in cards}
+        if want is not None:
+            match = [hw for hw in cards if self.detail["cards"][hw].lower().startswith(want)]
+            self.detail["matched"] = match
+            cards = match or cards
+        for hw in cards:
             names = sorted(os.listdir(hw))
             self.detail[hw] = {n: _read(os.path.join(hw, n)) for n in names if n.startswith(("power", "freq", "temp", "name", "in"))}
             for cand in ("power1_average", "power1_input"):
@@ -163,7 +177,8 @@ def main():
     sensors = Sensors()
     res = {"sensor": sensors.kind, "sensor_files": {"power": sensors.power_file, "sclk": sensors.sclk_file},
            "power_cap_w": (int(_read(sensors.cap_file)) / 1e6 if sensors.cap_file else None), "loads": {}}
-    print("sensor:", sensors.kind, sensors.power_file, flush=True)
+    res["sensor_detail"] = {k: sensors.detail.get(k) for k in ("hip_device_pci", "cards", "matched", "pci_error")}
+    print("sensor:", sensors.kind, sensors.power_file, res["sensor_detail"], flush=True)
     if sensors.kind is None:
         res["sensor_detail"] = sensors.detail
         json.dump(res, open(a.out, "w"), indent=1)
@@ -235,6 +250,7 @@ def main():
         ops.geo_clock(reset=True)
         row = run_for(lambda: ops.geo_forward(x, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, 45.0, with_grad=True), a.secs, smp, "geo_" + mode)
         clk = ops.geo_clock(reset=True).get((mode, True))
+        row["every_card_power_w_right_after"] = {hw: (int(_read(os.path.join(hw, "power1_input")) or 0) / 1e6) for hw in sensors.detail.get("cards", {})}
         row.update({"what": f"geo_pairs kernel, main-pass form (SDF + Jacobian sweep), v_mfma_f32_{shape}_bf16, {NP} pairs", "ghz_in_kernel": clk["ghz"] if clk else None,
                     "tflops_algorithmic": NP * (bench.F_FWD + bench.F_JAC) / (row["ms_per_launch"] * 1e-3) / 1e12})
         row["frac_of_peak"] = row["tflops_algorithmic"] / bench.PEAK_SPLIT_TFLOPS
