@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--mode", choices=["train", "eval"], default="train", help="train (the contract line): one optimisation step per step; eval: one evaluation-render chunk per "
                     "step (PointVolSDF.forward(fast=-1) under no_grad: the full error-bounded sampler, kNN, SDF + normals, colour, compositing — SURVEY.md "
                     "section 8(d): reported separately, with the realised sampler iterations), followed by the reference-sized get_sdf_eval grid sweep")
+    ap.add_argument("--image", type=int, nargs=2, default=[576, 768], metavar=("H", "W"), help="eval mode: also render ONE full image of this size as a stream of "
+                    "--rays-pixel chunks (eval_graph.ImageRenderer: train.py:399-433 / eval_spurfies.py:276-292 without per-chunk host work) and report images/s; 0 0 = skip")
     ap.add_argument("--sweep-resolution", type=int, default=512, help="eval mode: samples along the shortest axis of the mesh-extraction grid (the reference: 512); 0 = skip")
     ap.add_argument("--geo-engine", choices=["auto", "split", "split_w"], default="auto", help="MFMA shape of the dominant kernel: 16x16x32 (split), 32x32x16 "
                     "(split_w), or auto = time both on this box before the warm-up steps (TrainStep.autotune_geo_engine) and keep the faster")
@@ -387,6 +389,28 @@ def main_eval(args):
                 sweep["geo_kernel"] = {"achieved": pairs * F_FWD / (ms * 1e-3) / 1e12, "frac": pairs * F_FWD / (ms * 1e-3) / 1e12 / PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
                                        "pairs": pairs, "kernel_ms_total": ms}
         res["sdf_eval_sweep"] = sweep
+        image = None
+        if args.image[0] > 0 and args.image[1] > 0:       # the full-image evaluation loop (864 chunks of 512 pixels at 576 x 768) as a stream
+            from spurfies_amd.eval_graph import ImageRenderer
+
+            H, W = args.image
+            ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+            uv_all = torch.stack([xs, ys], -1).reshape(1, -1, 2).float().to(device)              # datasets/dtu.py:100-103 pixel order, uv = (x, y)
+            r = ImageRenderer(model, args.rays, fast=-1, graph=args.graph)
+            view = {"uv": uv_all, "pose": torch.from_numpy(scene["poses"][0])[None].to(device), "intrinsics": K}
+            r(dict(view, uv=uv_all[:, : 4 * args.rays]), 4 * args.rays)                           # warm-up (capture, allocator pools) on four chunks
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            img = r(view, H * W)
+            torch.cuda.synchronize()
+            ti = time.perf_counter() - t0
+            acc = img["depth_values"]
+            image = {"height": H, "width": W, "pixels": H * W, "chunks": (H * W + args.rays - 1) // args.rays, "rays_per_chunk": args.rays, "seconds": ti,
+                     "images_per_s": 1.0 / ti, "rays_per_s": H * W / ti, "ms_per_chunk": ti / ((H * W + args.rays - 1) // args.rays) * 1e3,
+                     "launch": "one hipGraph launch per chunk (cursor + uv gather + forward + scatter into the merged image)" if args.graph else "eager launches per chunk",
+                     "finite": bool(torch.isfinite(img["rgb_values"]).all().item()), "mean_depth": float(acc.mean().item()),
+                     "note": "pixel coordinates resident on the device, outputs written into pre-allocated [H*W, ...] tensors by the chunk itself; no per-chunk host copy / list / cat"}
+        res["image_render"] = image
         res["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else eval_cpu_baseline(scene, min(args.cpu_rays, 128))
         print(json.dumps(res), flush=True)
     if world > 1:

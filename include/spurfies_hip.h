@@ -32,7 +32,7 @@ extern "C" {
 #define SPF_ENOMEM (-12)
 #define SPF_EHIP (-5)
 
-#define SPF_ABI_VERSION 3
+#define SPF_ABI_VERSION 4
 #define SPF_KMAX 8          /* neighbours per point (config/vol/dtu_pn.yaml:27, k: 8) */
 #define SPF_GEO_DIM 32      /* geometry latent width = feature_vector_size/2 (pointneus_disent.py:172) */
 #define SPF_COL_DIM 64      /* colour latent width  = feature_vector_size   (pointneus_disent.py:161) */
@@ -132,10 +132,15 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
  * dispatch than in work at 10^5 slots): nbr [R*SR, k] is indexed by SLOT (the kNN output as it is); outputs as above, with
  * counts[2] = {n_points, n_pairs} on the device and the same optional fillers.  scratch: >= 2 * (R*SR / 2048 + 1) int32.
  * gate (DEVICE int32, may be NULL): when *gate == 0 the counts are reported as {0, 0} (the fillers are still laid down), so the MLP kernels
- * behind this pass do no work — how a sampler iteration the loop did not reach is skipped without a host round trip (spf_sampler_iter). */
+ * behind this pass do no work — how a sampler iteration the loop did not reach is skipped without a host round trip (spf_sampler_iter).
+ * sync (DEVICE uint64, may be NULL; ABI 4): spf_compact_sync_words(R*SR) words that are ALL ZERO on entry (e.g. hipMemset once) and are left
+ * all zero — the pass then runs as ONE launch in which the 2048-slot chunks publish their totals to each other through these words
+ * (relaxed agent-scope atomics, value and flag in one word; the last chunk to have read clears them).  One buffer per stream that may run
+ * this call concurrently; passes of more than 2048 chunks (4 M slots) and sync == NULL take the two-launch form. */
+int64_t spf_compact_sync_words(int64_t n_slots);
 int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot,
                       int32_t* slot_point, int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch,
-                      float* fill_sdf, float fill_value, float* fill_grad, const int32_t* gate, void* stream);
+                      float* fill_sdf, float fill_value, float* fill_grad, const int32_t* gate, uint64_t* sync, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused geometry path — replaces get_keypoint_data + compute_weights + get_sdf (+ the value of
@@ -393,10 +398,15 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
               float* dW, int32_t ldw, float* dbias, float* workspace, int32_t layout, int32_t arith, int32_t col_rot,
               int32_t col_mod, void* stream);
 
-/* Up to three C = 256 weight-gradient GEMMs over the SAME rows (n_rows / max_rows) in one pair of launches: dW_q += G_q^T A_q,
- * dbias_q += column sums of G_q (may be NULL).  The head stage's three GEMMs have K = valid points: launched one after the other
- * each pays the pipeline ramp and a tail on a mostly idle chip; side by side they share the CUs.  `problems` is a HOST array;
- * workspace: n_problems * spf_wgrad_workspace_floats(256) floats. */
+/* Up to three weight-gradient GEMMs over the SAME rows (n_rows / max_rows) in one pair of launches, side by side on the chip (each
+ * problem gets a share of the workgroups proportional to its work): dW_q += G_q^T A_q, dbias_q += column sums of G_q (may be NULL).
+ * Launched one after the other each GEMM pays the pipeline ramp, a tail on a mostly idle chip and a dispatch gap — the head stage's three
+ * (K = valid points) and, since ABI 4, the colour trunk's three (K = pairs).  Per problem (C, layout) must be one of
+ *   (256, 0)                                         both operands row-major                      (C == 0 means 256)
+ *   (256, SPF_WGRAD_G_TILES64 | SPF_WGRAD_A_TILES)   what spf_color_backward / spf_color_forward write for layers 2 and 4
+ *   (36..128 step 4, SPF_WGRAD_G_TILES64)            the trunk's first layer (C = 104), A row-major with leading dimension lda
+ * with spf_wgrad's col_rot / col_mod per problem; anything else: spf_wgrad.  `problems` is a HOST array; workspace:
+ * n_problems * spf_wgrad_workspace_floats(256) floats; tiled operands need max_rows % 64 == 0. */
 struct spf_wgrad_problem {
     const float* G;
     const float* A;
@@ -404,6 +414,10 @@ struct spf_wgrad_problem {
     float* dW;
     int32_t ldw;
     float* dbias;
+    int32_t C;          /* ABI 4 */
+    int32_t layout;
+    int32_t col_rot;
+    int32_t col_mod;
 };
 int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_problems, const int32_t* n_rows, int32_t max_rows,
                       float* workspace, int32_t arith, int32_t flags, void* stream);
@@ -508,7 +522,7 @@ int64_t spf_adam_workspace_floats(void);
  * zero_grads != 0: grad is left ZERO instead (also when the update was skipped) — the next step's optimizer.zero_grad() (train.py:357)
  *   folded into this sweep; the clipped gradient is then not observable afterwards.
  * state: device float[4] = {t, skipped steps, last norm, last clip coefficient}, zero-initialised by the caller.
- * workspace: spf_adam_workspace_floats() floats.  Three launches, no host synchronisation. */
+ * workspace: spf_adam_workspace_floats() floats.  Two launches, no host synchronisation. */
 int spf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
                   double beta2, double eps, double max_norm, int32_t zero_grads, float* state, float* workspace, void* stream);
 

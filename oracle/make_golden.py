@@ -221,6 +221,55 @@ def golden_eval_step(name, n_points, n_rays, view, seed):
     print(name, "sampler calls", n_calls)
 
 
+def image_pixels(h, w):
+    """A coarse h x w sub-grid of the 576 x 768 image in the reference's full-image pixel order (datasets/dtu.py:100-103: uv = (x, y), rows of
+    the image one after the other): pixel centres of the stride-(576/h, 768/w) blocks, same intrinsics."""
+    sy, sx = syn.IMG_H // h, syn.IMG_W // w
+    ys, xs = np.meshgrid(np.arange(h) * sy + sy // 2, np.arange(w) * sx + sx // 2, indexing="ij")
+    return np.stack([xs, ys], -1).reshape(-1, 2).astype(np.float32)
+
+
+def golden_eval_image(name, n_points, h, w, chunk, view, seed, near=0.0):
+    """A full (small) image the way the reference evaluates one: eval_spurfies.py:276-292 / train.py:399-433 — `utils.split_input` chunks of
+    `chunk` pixels (the last one shorter), `model(s)` with fast=-1 per chunk, `utils.merge_output` — with the EVALUATION sampler range of
+    config/confs/dtu_pn.conf:48 (near = 0.0; training uses 0.5) on the fitted-prior scene (rays cross a real zero level set)."""
+    ref_shim.enter_reference()
+    from spurfies.utils import general as ref_utils
+
+    scene = syn.make_scene(n_points, seed=seed, prior="fitted")
+    model, _ = ref_shim.build_reference_model(scene, near=near)
+    model.eval()
+    uv = image_pixels(h, w)
+    total = uv.shape[0]
+    inp = {"intrinsics": torch.from_numpy(scene["intrinsics"])[None], "uv": torch.from_numpy(uv)[None],
+           "pose": torch.from_numpy(scene["poses"][view])[None], "local_data": None, "iter_step": 0}
+    iters = []
+    orig = model.sdf_importance
+    calls = []
+
+    def spy(x):
+        calls.append(int(x.shape[0]))
+        return orig(x)
+
+    model.sdf_importance = spy
+    torch.manual_seed(seed + 7)
+    res = []
+    for s in ref_utils.split_input(inp, total, n_pixels=chunk):
+        n0 = len(calls)
+        out = model(s)                       # fast defaults to -1: the full error-bounded loop
+        iters.append(len(calls) - n0)
+        res.append({k: out[k].detach() for k in ("rgb_values", "normal_map", "depth_values", "weights")})
+    merged = ref_utils.merge_output(res, total, 1)
+    fx = {"meta.n_points": n_points, "meta.h": h, "meta.w": w, "meta.chunk": chunk, "meta.view": view, "meta.seed": seed, "meta.near": np.float32(near),
+          "meta.prior": "fitted", "meta.checksum": scene_checksum(scene), "in.uv": uv, "meta.sampler_calls_per_chunk": np.asarray(iters, np.int64)}
+    for k, v in merged.items():
+        fx[f"out.{k}"] = v.numpy() if k != "weights" else v.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, name), **fx)
+    acc = merged["weights"].sum(-1)
+    print(name, "pixels", total, "chunks", len(res), "sampler sdf calls per chunk", iters, "pixels with acc > 0.5:", int((acc > 0.5).sum()),
+          "size", os.path.getsize(os.path.join(OUT, name)))
+
+
 def golden_sdf_eval(name, n_points, seed, res=20):
     scene = syn.make_scene(n_points, seed=seed)
     model, _ = ref_shim.build_reference_model(scene)
@@ -656,6 +705,8 @@ def main():
         golden_train_step("step_train_local.npz", n_points=6000, n_rays=96, view=0, seed=6, prior="fitted", local=True)
     if want("step_eval_r24.npz"):
         golden_eval_step("step_eval_r24.npz", n_points=6000, n_rays=24, view=2, seed=2)
+    if want("eval_image_near0.npz"):        # the reference's EVALUATION sampler range (dtu_pn.conf:48, near 0.0) + split_input / merge_output
+        golden_eval_image("eval_image_near0.npz", n_points=6000, h=32, w=48, chunk=500, view=1, seed=12, near=0.0)
     if want("sdf_eval_grid.npz"):
         golden_sdf_eval("sdf_eval_grid.npz", n_points=6000, seed=0, res=32)
     if want("sampler_g4.npz"):

@@ -35,7 +35,8 @@ class LossWeights(C.Structure):
 
 class WgradProblem(C.Structure):
     """spf_wgrad_problem"""
-    _fields_ = [("G", C.c_void_p), ("A", C.c_void_p), ("lda", C.c_int32), ("dW", C.c_void_p), ("ldw", C.c_int32), ("dbias", C.c_void_p)]
+    _fields_ = [("G", C.c_void_p), ("A", C.c_void_p), ("lda", C.c_int32), ("dW", C.c_void_p), ("ldw", C.c_int32), ("dbias", C.c_void_p),
+                ("C", C.c_int32), ("layout", C.c_int32), ("col_rot", C.c_int32), ("col_mod", C.c_int32)]
 
 
 SIGNATURES = {
@@ -47,7 +48,8 @@ SIGNATURES = {
     "spf_grid_get_info": (C.c_int, [_P, C.POINTER(GridInfo)]),
     "spf_grid_query": (C.c_int, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
     "spf_compact_points": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P]),
-    "spf_compact_pairs": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "spf_compact_sync_words": (C.c_int64, [C.c_int64]),
+    "spf_compact_pairs": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P]),
     "spf_voxel_cells": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_float * 3), _F, _P, _P]),
     "spf_geo_packed_floats": (C.c_int64, []),
     "spf_geo_pack": (C.c_int, [_P] * 14),

@@ -44,19 +44,24 @@ def build_variant(name: str, flags: str, verbose: bool = False) -> str:
     return out
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = True, incremental: bool = False) -> str:
+    """incremental (developer loop): recompile only the sources that are newer than their object (a header change recompiles everything)."""
+    if not force and not incremental and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "spurfies_hip.h")]
+    t_hdr = max(os.path.getmtime(h) for h in headers)
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if incremental and not force and os.path.exists(obj) and os.path.getmtime(obj) > max(t_hdr, os.path.getmtime(os.path.join(CSRC, src))):
+            continue
         cmd = [hipcc, *FLAGS, *os.environ.get("SPF_EXTRA_HIPCC_FLAGS", "").split(), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -69,5 +74,5 @@ if __name__ == "__main__":
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2] if len(sys.argv) > i + 2 else ""))
     else:
-        build(force="--force" in sys.argv)
+        build(force="--force" in sys.argv, incremental="--incremental" in sys.argv)
         print(LIB)

@@ -618,6 +618,91 @@ __global__ void __launch_bounds__(256) cp_write_kernel(const uint8_t* __restrict
     }
 }
 
+// ---- spf_compact_pairs in ONE launch (round 4) -----------------------------------------------------------------------------
+// The two launches above exist because a chunk needs the totals of every chunk before it.  Here each chunk PUBLISHES its own totals
+// and reads its predecessors' (a decoupled look-back without the chain: every block adds up all earlier aggregates itself): one 64-bit
+// word per chunk, {published bit, points, pairs}, written and read with relaxed agent-scope atomics.  Value and flag travel in the same
+// word, so no release / acquire fence is needed (a device-scope fence writes back and invalidates the XCD's L2 - what made "last block"
+// reductions slower than a second launch).  A block only ever waits for LOWER block ids, which the dispatcher
+// starts no later than itself, so the wait cannot deadlock even when the grid is not co-resident.  `sync` (chunks + 1 words) must be all
+// zero on entry and is left all zero: the last block to finish its look-back clears it (word 0 counts the blocks that have).
+constexpr unsigned long long CPF_PUBLISHED = 1ull << 62;
+constexpr int CPF_MAX_CHUNKS = 2048;      // 2048 blocks of 256 threads are co-resident on 256 CUs; larger passes keep the two-launch form
+__global__ void __launch_bounds__(256) cp_fused_kernel(const uint8_t* __restrict__ slot_valid, const int32_t* __restrict__ nbr, long long nslot,
+                                                       int k, unsigned long long* __restrict__ sync, int32_t* __restrict__ point_slot,
+                                                       int32_t* __restrict__ slot_point, int32_t* __restrict__ pair_off,
+                                                       int32_t* __restrict__ pair_point, int32_t* __restrict__ counts /* [n_points, n_pairs] */,
+                                                       float* __restrict__ fill_sdf, float fill_value, float* __restrict__ fill_grad,
+                                                       const int32_t* __restrict__ gate) {
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t wsum2[4];
+    __shared__ int32_t wsum3[4];
+    __shared__ int32_t wsum4[4];
+    __shared__ int32_t i_clear;
+    const long long base = (long long)blockIdx.x * CMP_CHUNK + (long long)threadIdx.x * CMP_PER_THREAD;
+    int c[CMP_PER_THREAD], np = 0, nq = 0;
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u) {
+        c[u] = -1;                                   // -1: not a valid point
+        if (base + u < nslot && slot_valid[base + u]) {
+            c[u] = nbr_count(nbr + (size_t)(base + u) * k, k);
+            ++np;
+            nq += c[u];
+        }
+    }
+    int tp, tq;
+    const int lp = block_excl_scan_256(np, tp, wsum);
+    const int lq = block_excl_scan_256(nq, tq, wsum2);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&sync[1 + blockIdx.x], CPF_PUBLISHED | ((unsigned long long)tp << 32) | (unsigned long long)tq, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    int bp = 0, bq = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) {
+        unsigned long long v;
+        while (!((v = __hip_atomic_load(&sync[1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & CPF_PUBLISHED)) __builtin_amdgcn_s_sleep(1);
+        bp += (int)((v >> 32) & 0x3fffffffu);
+        bq += (int)(v & 0xffffffffu);
+    }
+    int base_p, base_q;
+    block_excl_scan_256(bp, base_p, wsum3);         // totals over the block = sums over all earlier chunks
+    block_excl_scan_256(bq, base_q, wsum4);
+    if (threadIdx.x == 0) {
+        // this block has read everything it needs; the last one to say so clears the words for the next launch
+        const unsigned long long done = __hip_atomic_fetch_add(&sync[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        i_clear = (done == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
+    }
+    int p = base_p + lp, q = base_q + lq;
+#pragma unroll
+    for (int u = 0; u < CMP_PER_THREAD; ++u)
+        if (base + u < nslot) {
+            if (c[u] >= 0) {
+                point_slot[p] = (int32_t)(base + u);
+                slot_point[base + u] = p;
+                pair_off[p] = q;
+                for (int j = 0; j < c[u]; ++j) pair_point[q + j] = p;
+                q += c[u];
+                ++p;
+            } else {
+                slot_point[base + u] = -1;
+            }
+            if (fill_sdf) fill_sdf[base + u] = fill_value;
+            if (fill_grad) {
+                fill_grad[3 * (base + u)] = 0.f;
+                fill_grad[3 * (base + u) + 1] = 0.f;
+                fill_grad[3 * (base + u) + 2] = 0.f;
+            }
+        }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const bool open_ = !gate || *gate != 0;      // a closed gate reports no points / pairs: the MLP kernels behind it do nothing
+        counts[0] = open_ ? base_p + tp : 0;
+        counts[1] = open_ ? base_q + tq : 0;
+        pair_off[base_p + tp] = base_q + tq;         // closes the list
+    }
+    __syncthreads();
+    if (i_clear)
+        for (int b = threadIdx.x; b <= (int)gridDim.x; b += 256) __hip_atomic_store(&sync[b], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 GridDev dev_view(const spf_grid* g) {
     GridDev d;
     d.ox = g->origin[0], d.oy = g->origin[1], d.oz = g->origin[2];
@@ -883,9 +968,11 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
     return SPF_OK;
 }
 
+int64_t spf_compact_sync_words(int64_t n_slots) { return spf::div_up(n_slots, (int64_t)CMP_CHUNK) + 1; }
+
 int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot, int32_t* slot_point,
                       int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch, float* fill_sdf, float fill_value,
-                      float* fill_grad, const int32_t* gate, void* stream_) {
+                      float* fill_grad, const int32_t* gate, uint64_t* sync, void* stream_) {
     if (R < 0 || SR < 1 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_compact_pairs: bad sizes");
     if (!counts || !pair_off) return spf::fail(SPF_EINVAL, "spf_compact_pairs: null counts / pair_off");
     hipStream_t stream = (hipStream_t)stream_;
@@ -897,6 +984,12 @@ int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, 
     if (!slot_valid || !nbr || !point_slot || !slot_point || !pair_point || !scratch) return spf::fail(SPF_EINVAL, "spf_compact_pairs: null buffer");
     const long long nslot = (long long)R * SR;
     const int chunks = spf::div_up(nslot, CMP_CHUNK);
+    if (sync && chunks <= CPF_MAX_CHUNKS) {          // one launch: chunks publish their totals to each other (cp_fused_kernel)
+        cp_fused_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nbr, nslot, k, reinterpret_cast<unsigned long long*>(sync), point_slot, slot_point,
+                                                    pair_off, pair_point, counts, fill_sdf, fill_value, fill_grad, gate);
+        SPF_LAUNCH_CHECK("cp_fused_kernel");
+        return SPF_OK;
+    }
     cp_count_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nbr, nslot, k, scratch);
     SPF_LAUNCH_CHECK("cp_count_kernel");
     cp_write_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nbr, nslot, k, scratch, point_slot, slot_point, pair_off, pair_point, counts, fill_sdf,

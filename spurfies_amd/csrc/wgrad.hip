@@ -284,14 +284,19 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
 #ifndef SPF_WGRAD_LATE_MASK
 #define SPF_WGRAD_LATE_MASK 0
 #endif
+// LDS of the body below, in floats: a 3-stage fp32 ring of [G 16 x 256 | A 16 x CA] + two sets of three bf16 planes of A.  Declared by the
+// KERNEL and handed in, so that one kernel can hold several instantiations (the batched launch) over one allocation.
+template <int NT>
+constexpr int wgrad_split8_lds_floats() { return 3 * 16 * (256 + 32 * NT) + 2 * (3 * 32 * NT * 2) * 4; }
+
 template <int NT, int GK = 0, bool AK = false>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
-__device__ __forceinline__ void wgrad_split8_body(const float* __restrict__ G, const float* __restrict__ A, int lda, int C,
+__device__ __forceinline__ void wgrad_split8_body(float* sm, const float* __restrict__ G, const float* __restrict__ A, int lda, int C,
                                                   const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slab,
                                                   float* __restrict__ dbias, const int bid, const int nblk, float* __restrict__ colsum = nullptr) {
     constexpr int ROWS = 16, NB = 3, CA = 32 * NT;
     constexpr int NDMA = 2 + (NT == 8 ? 2 : 1);                           // requests per wave per stage
     constexpr int PLANE = 3 * CA * 2;                                     // bf16x8 items of one plane set: [3][CA][2]
-    __shared__ __attribute__((aligned(16))) float sm[NB * ROWS * (256 + CA) + 2 * PLANE * 4];
+    static_assert(wgrad_split8_lds_floats<NT>() == NB * ROWS * (256 + CA) + 2 * PLANE * 4, "LDS size");
     bf16x8* planes = reinterpret_cast<bf16x8*>(sm + NB * ROWS * (256 + CA));     // [2][3][CA][2]
     const int tid = threadIdx.x, lane = tid & 63, ci = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // 0..7
@@ -486,10 +491,15 @@ template <int NT, int GK = 0, bool AK = false>
 __global__ void __launch_bounds__(512, 1)
 wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
                     int max_rows, float* __restrict__ slab, float* __restrict__ dbias, float* __restrict__ colsum) {
-    wgrad_split8_body<NT, GK, AK>(G, A, lda, C, n_rows_dev, max_rows, slab, dbias, (int)blockIdx.x, (int)gridDim.x, colsum);
+    __shared__ __attribute__((aligned(16))) float sm[wgrad_split8_lds_floats<NT>()];
+    wgrad_split8_body<NT, GK, AK>(sm, G, A, lda, C, n_rows_dev, max_rows, slab, dbias, (int)blockIdx.x, (int)gridDim.x, colsum);
 }
 
-// up to three C = 256 problems over the same rows in one launch: blockIdx.y = problem, each with gridDim.x workgroups and its own slab
+// Up to three problems over the same rows in ONE launch, side by side: workgroups [first[q], first[q] + nblk[q]) of the 1-D grid belong to
+// problem q (shares proportional to the problems' work), each problem with its own slab.  Three operand forms are compiled in, chosen per
+// problem: row-major C = 256 (the head stage: K = valid points), G in 64-row tiles x A in 16-row blocks (the colour trunk's layers 2 and 4,
+// C = 256) and G in 64-row tiles x row-major A with C <= 128 (the trunk's first layer, C = 104) — round 4: the trunk's three GEMMs were three
+// launches + three reduces (each paying pipeline ramp, tail and a dispatch gap; at K = 49 k pairs, 128 rays, 174 us for 80 us of work).
 struct WgradBatch {
     const float* G[3];
     const float* A[3];
@@ -497,14 +507,21 @@ struct WgradBatch {
     float* dW[3];
     int ldw[3];
     float* dbias[3];
+    int C[3], kind[3], first[3], nblk[3], col_rot[3], col_mod[3];     // kind: 0 = <8, rows, rows>, 1 = <8, G64, A16>, 2 = <4, G64, rows>
 };
 __global__ void __launch_bounds__(512, 1)
-wgrad_split8_batched_kernel(WgradBatch pb, const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slabs, size_t slab_floats,
-                            int det) {
-    const int q = blockIdx.y;
+wgrad_split8_batched_kernel(WgradBatch pb, int n_problems, const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slabs,
+                            size_t slab_floats, int det) {
+    __shared__ __attribute__((aligned(16))) float sm[wgrad_split8_lds_floats<8>()];
+    int q = 0;
+    if (n_problems > 1 && (int)blockIdx.x >= pb.first[1]) q = 1;
+    if (n_problems > 2 && (int)blockIdx.x >= pb.first[2]) q = 2;
+    const int bid = (int)blockIdx.x - pb.first[q], nblk = pb.nblk[q];
     float* slab = slabs + (size_t)q * slab_floats;
-    wgrad_split8_body<8>(pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], (int)blockIdx.x, (int)gridDim.x,
-                         det ? slab + COLSUM_OFF : nullptr);
+    float* colsum = det ? slab + COLSUM_OFF : nullptr;
+    if (pb.kind[q] == 0) wgrad_split8_body<8>(sm, pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
+    else if (pb.kind[q] == 1) wgrad_split8_body<8, 2, true>(sm, pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
+    else wgrad_split8_body<4, 2, false>(sm, pb.G[q], pb.A[q], pb.lda[q], pb.C[q], n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
 }
 
 // slab of wgrad_split8_kernel: output row o = 32 wave + C-row(reg, lane), column = 32 t + (lane & 31)
@@ -553,11 +570,13 @@ __global__ void wgrad_split8_reduce_kernel(const float* __restrict__ slab, int n
                                            int C, float* __restrict__ dW, int ldw, int align, int col_rot, int col_mod, float* __restrict__ dbias_det) {
     wgrad_split8_reduce_body<NT>(slab, nblk_launched, n_rows_dev, max_rows, C, dW, ldw, align, col_rot, col_mod, dbias_det);
 }
-__global__ void wgrad_split8_reduce_batched_kernel(const float* __restrict__ slabs, size_t slab_floats, int nblk_launched,
-                                                   const int32_t* __restrict__ n_rows_dev, int max_rows, WgradBatch pb, int det) {
+__global__ void wgrad_split8_reduce_batched_kernel(const float* __restrict__ slabs, size_t slab_floats, const int32_t* __restrict__ n_rows_dev,
+                                                   int max_rows, WgradBatch pb, int det) {
     const int q = blockIdx.z;
-    wgrad_split8_reduce_body<8>(slabs + (size_t)q * slab_floats, nblk_launched, n_rows_dev, max_rows, 256, pb.dW[q], pb.ldw[q], 2, 0, 0,
-                                det ? pb.dbias[q] : nullptr);
+    const float* slab = slabs + (size_t)q * slab_floats;
+    float* db = det ? pb.dbias[q] : nullptr;
+    if (pb.kind[q] == 2) wgrad_split8_reduce_body<4>(slab, pb.nblk[q], n_rows_dev, max_rows, pb.C[q], pb.dW[q], pb.ldw[q], 64, pb.col_rot[q], pb.col_mod[q], db);
+    else wgrad_split8_reduce_body<8>(slab, pb.nblk[q], n_rows_dev, max_rows, 256, pb.dW[q], pb.ldw[q], pb.kind[q] == 1 ? 64 : 2, pb.col_rot[q], pb.col_mod[q], db);
 }
 
 // NT = 1 (C <= 32: the 21 view-encoding columns, a ones column for a bias gradient): direct loads, nothing to share
@@ -649,6 +668,10 @@ SPF_DEFINE_TIMING_ENTRY(spf_debug_timing_wgrad)
 extern "C" {
 
 static constexpr int RSPLIT = 16;
+static constexpr int WGRAD_MIN_ROWS = 128;       // rows per workgroup below which a launch uses fewer workgroups
+// slices of the slab reduce (atomically combined): ~16 slabs per thread — 16 slices for 256 slabs; with the batched launches' 60 - 99 slabs per
+// problem 16 slices were 12 k workgroups of 6 additions each (18 us, mostly dispatch)
+static int reduce_slices(int nblk) { const int r = nblk / 16; return r < 1 ? 1 : (r > RSPLIT ? RSPLIT : r); }
 // slabs: 256 workgroups x [256 x 256] (C > 128), 512 x [256 x 128] (two workgroups per CU), 256 x [256 x 32]
 int64_t spf_wgrad_workspace_floats(int32_t C) { return COLSUM_OFF + (int64_t)256 * 256; }      // slabs, then 256 workgroups x 256 column sums
 
@@ -668,7 +691,7 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     if (layout & ~(SPF_WGRAD_G_TILES | SPF_WGRAD_A_TILES | SPF_WGRAD_G_TILES64 | SPF_WGRAD_DETERMINISTIC)) return spf::fail(SPF_EINVAL, "spf_wgrad: unknown layout bits %d", layout);
     if (det && arith != SPF_ARITH_SPLIT && C > 32) return spf::fail(SPF_EINVAL, "spf_wgrad: SPF_WGRAD_DETERMINISTIC needs SPF_ARITH_SPLIT for C > 32");
     if (det && dbias && C <= 32) return spf::fail(SPF_EINVAL, "spf_wgrad: SPF_WGRAD_DETERMINISTIC with dbias needs C > 32");
-    const int rsplit = det ? 1 : RSPLIT;               // one slice = every element's slabs summed in block order, one plain add onto dW
+    const int rsplit = det ? 1 : reduce_slices(spf::div_up(max_rows, WGRAD_MIN_ROWS) < 256 ? spf::div_up(max_rows, WGRAD_MIN_ROWS) : 256);   // det: one slice = slabs summed in block order, one plain add onto dW
     float* colsum = (det && dbias) ? workspace + COLSUM_OFF : nullptr;
     float* dbias_det = det ? dbias : nullptr;
     if ((layout & SPF_WGRAD_G_TILES) && g64) return spf::fail(SPF_EINVAL, "spf_wgrad: G is either in 16-row blocks or in 64-row tiles");
@@ -677,7 +700,9 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
                                      "blocks) and C = 256 for a blocked A");
     if (NT >= 4 && ((C % 4) || (lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad: C and lda must be multiples of 4 for C > 32 (C=%d lda=%d)", C, lda);
     hipStream_t s = (hipStream_t)stream;
-    int blocks = spf::div_up(max_rows, 512);
+    // >= 128 rows (8 stages) per workgroup: with 512 a small-K call (the head stage at 128 rays: 6.5 k points) ran on 13 workgroups of 32
+    // stages each, latency-bound at 55 us for 20 us of work; the extra slabs (256 KB each) are noise at that size
+    int blocks = spf::div_up(max_rows, WGRAD_MIN_ROWS);
     const int cap = NT == 4 ? 512 : 256;   // NT = 4: half the accumulators, two workgroups per CU; else one per CU, one wave per SIMD
     if (blocks > cap) blocks = cap;
     const int per = 4 * 2 * NT * 16 * 64;
@@ -725,34 +750,62 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
     if (max_rows == 0) return SPF_OK;
     if (!workspace) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: null workspace");
     const int64_t slab_floats = spf_wgrad_workspace_floats(256);
+    const int g64a16 = SPF_WGRAD_G_TILES64 | SPF_WGRAD_A_TILES;
+    int kind[3] = {0, 0, 0};
     for (int q = 0; q < n_problems; ++q) {
         const spf_wgrad_problem& p = problems[q];
-        if (!p.G || !p.A || !p.dW || p.lda < 256 || (p.lda % 4) || p.ldw < 256)
-            return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: need G, A, dW, lda >= 256 (multiple of 4), ldw >= 256", q);
+        const int C = p.C > 0 ? p.C : 256;
+        if (!p.G || !p.A || !p.dW) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: null G / A / dW", q);
+        // the three operand forms the side-by-side kernel holds (anything else: call spf_wgrad)
+        if (C == 256 && p.layout == 0) kind[q] = 0;
+        else if (C == 256 && p.layout == g64a16) kind[q] = 1;
+        else if (C > 32 && C <= 128 && (C % 4) == 0 && p.layout == SPF_WGRAD_G_TILES64) kind[q] = 2;
+        else return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: (C, layout) = (%d, %d) is not one of (256, 0), (256, G_TILES64 | A_TILES), "
+                                          "(36..128 step 4, G_TILES64)", q, C, p.layout);
+        if (kind[q] != 1 && (p.lda < C || (p.lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: lda >= C and a multiple of 4", q);
+        if (kind[q] != 0 && (max_rows % 64)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: tiled operands need max_rows %% 64 == 0", q);
+        if (p.col_mod < 0 || p.col_mod > C || p.col_rot < 0 || (p.col_mod > 0 && p.col_rot >= p.col_mod) || (p.col_mod == 0 && p.col_rot != 0))
+            return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: need 0 <= col_rot < col_mod <= C (or both 0)", q);
+        if (p.ldw < (p.col_mod > 0 ? p.col_mod : C)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: ldw too small", q);
     }
     if (arith != SPF_ARITH_SPLIT || n_problems == 1) {      // fp32-MFMA verification mode / nothing to batch: the single-problem path
         for (int q = 0; q < n_problems; ++q) {
             const spf_wgrad_problem& p = problems[q];
-            const int rc = spf_wgrad(p.G, p.A, p.lda, 256, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, flags, arith, 0, 0, stream);
+            const int C = p.C > 0 ? p.C : 256;
+            if (arith != SPF_ARITH_SPLIT && (p.layout || p.col_mod)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: tiled operands / column rotation need SPF_ARITH_SPLIT");
+            const int rc = spf_wgrad(p.G, p.A, p.lda, C, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, p.layout | flags, arith,
+                                     p.col_rot, p.col_mod, stream);
             if (rc != SPF_OK) return rc;
         }
         return SPF_OK;
     }
     WgradBatch pb{};
+    // one 8-wave workgroup per CU over ALL problems, shares proportional to the work (a C <= 128 problem stages and multiplies half the
+    // columns: measured 0.62 of a C = 256 one), so that the problems run side by side and end together
+    double w[3], wsum = 0.0;
+    for (int q = 0; q < n_problems; ++q) wsum += (w[q] = kind[q] == 2 ? 0.62 : 1.0);
+    const int want = spf::div_up(max_rows, WGRAD_MIN_ROWS);
+    int first = 0, used = 0;
     for (int q = 0; q < n_problems; ++q) {
+        int share = (int)(256.0 * w[q] / wsum);
+        if (q == n_problems - 1) share = 256 - used;     // the remainder goes to the last problem
+        used += share;
+        if (share < 1) share = 1;
+        const int nb = want < share ? want : share;
+        const int C = problems[q].C > 0 ? problems[q].C : 256;
         pb.G[q] = problems[q].G; pb.A[q] = problems[q].A; pb.lda[q] = problems[q].lda;
         pb.dW[q] = problems[q].dW; pb.ldw[q] = problems[q].ldw; pb.dbias[q] = problems[q].dbias;
+        pb.C[q] = C; pb.kind[q] = kind[q]; pb.first[q] = first; pb.nblk[q] = nb;
+        pb.col_rot[q] = problems[q].col_rot; pb.col_mod[q] = problems[q].col_mod;
+        first += nb;
     }
     hipStream_t s = (hipStream_t)stream;
-    // one 8-wave workgroup per CU over ALL problems: each problem gets 256 / n_problems of them, so that the problems run side by side
-    // with n_problems times longer (better amortised) pipelines instead of one after the other
-    int blocks = spf::div_up(max_rows, 512);
-    const int cap = 256 / n_problems;
-    if (blocks > cap) blocks = cap;
     const int per = 4 * 2 * 8 * 16 * 64;
-    wgrad_split8_batched_kernel<<<dim3(blocks, n_problems), 512, 0, s>>>(pb, n_rows, max_rows, workspace, (size_t)slab_floats, det);
-    wgrad_split8_reduce_batched_kernel<<<dim3(spf::div_up(per, 256), det ? 1 : RSPLIT, n_problems), 256, 0, s>>>(workspace, (size_t)slab_floats, blocks,
-                                                                                                               n_rows, max_rows, pb, det);
+    wgrad_split8_batched_kernel<<<first, 512, 0, s>>>(pb, n_problems, n_rows, max_rows, workspace, (size_t)slab_floats, det);
+    int nb_max = 1;
+    for (int q = 0; q < n_problems; ++q) nb_max = pb.nblk[q] > nb_max ? pb.nblk[q] : nb_max;
+    wgrad_split8_reduce_batched_kernel<<<dim3(spf::div_up(per, 256), det ? 1 : reduce_slices(nb_max), n_problems), 256, 0, s>>>(workspace, (size_t)slab_floats, n_rows,
+                                                                                                                             max_rows, pb, det);
     SPF_LAUNCH_CHECK("wgrad_split8_batched_kernel");
     return SPF_OK;
 }

@@ -54,3 +54,103 @@ class GraphedRenderer:
         self._graph.replay()
         self.model.ray_sampler._flags = self._flags             # last_iters reads this replay's flags (lazily)
         return self._out
+
+
+class ImageRenderer:
+    """A full image as a STREAM of fixed-size chunks with the outputs merged on the device — the reference's evaluation loop
+    (spurfies/train.py:414-433, eval_spurfies.py:276-292: `utils.split_input` into ~864 chunks of 500 / 512 pixels, `model(s)` per chunk, a
+    `.detach().cpu()` of every output per chunk, `utils.merge_output` = torch.cat over the list) without its per-chunk host work:
+
+      * all pixel coordinates live on the device; a chunk's `uv` is gathered by row indices formed ON the device (a device-side cursor that the
+        chunk itself advances), and the chunk's outputs are written straight into their rows of pre-allocated [H*W, ...] tensors
+        (`index_copy_`): no list of per-chunk tensors, no clone, no cat, no host copy until the caller asks for one;
+      * with graph=True cursor + gather + forward + scatter are ONE hipGraph, so the host issues one graph launch per chunk (plus the
+        CPU-generator draw the reference's forward makes, to keep the generator in step);
+      * a last chunk that is shorter than `n_rays` is filled up with copies of the image's last pixel, whose results land on that same pixel:
+        the per-chunk convergence test of the sampler (`beta.max() > beta0`, ray_sampler.py:468) sees no new value, so every pixel gets
+        exactly what the reference's shorter chunk gives it.
+    Outputs: rgb_values [HW,3], depth_values [HW,1], normal_map [HW,3], weights [HW,SR] (optional)."""
+
+    KEYS = ("rgb_values", "depth_values", "normal_map")
+
+    def __init__(self, model, n_rays, fast=-1, graph=True, keep_weights=False):
+        if model.training:
+            raise ValueError("ImageRenderer renders in evaluation mode: call model.eval() first")
+        self.model, self.n_rays, self.fast, self.use_graph = model, int(n_rays), fast, bool(graph)
+        self.keys = self.KEYS + (("weights",) if keep_weights else ())
+        self.dev = model.neural_pts.device
+        self._graph, self._key, self._total = None, None, -1
+        self.last_iters = []
+
+    # ---- static state of one image size -------------------------------------------------------------------------------------------
+    def _alloc(self, total, inp):
+        dev, n = self.dev, self.n_rays
+        self._total = total
+        self._chunks = (total + n - 1) // n
+        self._uv = torch.zeros((1, total, 2), dtype=torch.float32, device=dev)
+        self._pose = inp["pose"].detach().to(dev).float().clone()
+        self._K = inp["intrinsics"].detach().to(dev).float().clone()
+        self._cursor = torch.zeros((1,), dtype=torch.int64, device=dev)
+        self._lane = torch.arange(n, dtype=torch.int64, device=dev)
+        self._last = torch.full((1,), total - 1, dtype=torch.int64, device=dev)
+        SR = int(self.model.conf.max_shading_pts)
+        widths = {"rgb_values": 3, "depth_values": 1, "normal_map": 3, "weights": SR}
+        self.out = {k: torch.zeros((total, widths[k]), dtype=torch.float32, device=dev) for k in self.keys}
+        self._graph = None
+
+    def _chunk(self):
+        """One chunk at the cursor: gather uv, forward, scatter, advance — every tensor op on the device, shapes static."""
+        rows = torch.minimum(self._cursor + self._lane, self._last)         # a short last chunk repeats the last pixel
+        uv = self._uv.index_select(1, rows)
+        out = self.model({"uv": uv, "pose": self._pose, "intrinsics": self._K, "local_data": None}, fast=self.fast)
+        for k in self.keys:
+            self.out[k].index_copy_(0, rows, out[k].reshape(self.n_rays, -1))
+        self._cursor.add_(self.n_rays)
+
+    def _capture(self):
+        dev = self.dev
+        rng = torch.get_rng_state()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():          # warm-up: cell table, caches, allocator pools (generator and cursor restored)
+            for _ in range(2):
+                self._chunk()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.set_rng_state(rng)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self._graph):
+            self._chunk()
+        self._flags = self.model.ray_sampler._flags
+        self._key = self.model.cache_key()
+
+    def __call__(self, model_input, total_pixels=None, iters=False):
+        """model_input: {'uv' [1,HW,2], 'pose' [1,4,4], 'intrinsics'} of ONE view -> dict of merged device tensors (valid until the next call).
+        iters=True also records the realised sampler iterations per chunk in `.last_iters` (one small read-back per chunk)."""
+        uv = model_input["uv"]
+        total = int(total_pixels if total_pixels is not None else uv.shape[1])
+        if uv.dim() != 3 or uv.shape[0] != 1 or uv.shape[1] != total:
+            raise ValueError(f"ImageRenderer: uv must be [1, {total}, 2], got {tuple(uv.shape)}")
+        if total != self._total or model_input["intrinsics"].shape != self._K.shape:
+            self._alloc(total, model_input)
+        self._uv.copy_(uv, non_blocking=True)
+        self._pose.copy_(model_input["pose"], non_blocking=True)
+        self._K.copy_(model_input["intrinsics"], non_blocking=True)
+        graph = self.use_graph and torch.device(self.dev).type == "cuda"
+        if graph and (self._graph is None or self._key != self.model.cache_key()):
+            self._capture()
+        self._cursor.zero_()
+        smp = self.model.ray_sampler
+        self.last_iters = []
+        with torch.no_grad():
+            for _ in range(self._chunks):
+                if graph:
+                    # the reference's evaluation forward consumes one torch.randint from the CPU generator per call (ray_sampler.py:562,
+                    # unused by the caller): drawn here, outside the graph, so the generator advances exactly as in the eager forward
+                    torch.randint(smp.N_samples + 2 + smp.N_samples_extra, (self.n_rays,))
+                    self._graph.replay()
+                    smp._flags = self._flags
+                else:
+                    self._chunk()
+                if iters:
+                    self.last_iters.append(smp.last_iters)
+        return self.out

@@ -66,6 +66,28 @@ def compact_points(slot_valid, fill_sdf=None, fill_grad=None):
     return point_slot, slot_point, n_points
 
 
+_COMPACT_SYNC = {}
+_COMPACT_ONE_LAUNCH = [True]
+
+
+def set_compact_one_launch(on=True):
+    """spf_compact_pairs as one launch (chunks publish their totals to each other; default) or as the count + write pair (tests compare both)."""
+    _COMPACT_ONE_LAUNCH[0] = bool(on)
+
+
+def _compact_sync(dev, n_slots):
+    """The zero-on-entry / zero-on-exit word buffer of the one-launch compaction (include/spurfies_hip.h: spf_compact_pairs): one per
+    (device, stream) — scenes stepped on different streams must not share it — grown on demand, cleared once when allocated."""
+    if not _COMPACT_ONE_LAUNCH[0]:
+        return None
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    need = int(_lib.lib().spf_compact_sync_words(int(n_slots)))
+    buf = _COMPACT_SYNC.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _COMPACT_SYNC[key] = torch.zeros((max(need, 2049),), dtype=torch.int64, device=dev)
+    return buf
+
+
 class PairList:
     """Device-side lists of the valid points and of their (point, neighbour) pairs — the rows of the MLP kernels
     (utils.py:96-113, 172-183 without the masked_select host syncs).  `counts` = [n_points, n_pairs] on the device."""
@@ -115,7 +137,8 @@ class PairList:
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_compact_pairs(_lib.ptr(slot_valid), _lib.ptr(nbr), R, SR, k, _lib.ptr(self.point_slot), _lib.ptr(self.slot_point),
                                                     _lib.ptr(self.pair_off), _lib.ptr(self.pair_point), _lib.ptr(self.counts), _lib.ptr(scratch),
-                                                    _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad), _lib.ptr(gate), _lib.stream_ptr()), "spf_compact_pairs")
+                                                    _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad), _lib.ptr(gate), _lib.ptr(_compact_sync(dev, rows)),
+                                                    _lib.stream_ptr()), "spf_compact_pairs")
         return self
 
     def host_counts(self):
@@ -469,12 +492,17 @@ class ColorAgg(_GradModeFunction):
         if sk is not None:
             # layer 0's [256,104] product comes in the kernels' internal column order [latent 64 | encoding 39 | pad]: the reduce kernel
             # rotates it into the reference order [encoding 39 | latent 64] on the way (no permutation pass)
-            if _ARITH["wgrad"] == 0 and ctx.arith == 0:
-                wgrad(G1, act0, pl.n_pairs, out=sk[1], dbias=kb(g_b0), layout=G64, col_rot=39, col_mod=103)
+            if _ARITH["wgrad"] == 0 and ctx.arith == 0 and _TRUNK_BATCHED[0]:
+                # the three GEMMs side by side in one launch + one reduce (round 4; they were three + three)
+                wgrad_batched([(G1, act0, sk[1], g_b0, 104, G64, 39, 103), (G2, act1, sk[3], g_b2, 256, G64 | AT, 0, 0),
+                               (G3, act2, sk[5], g_b4, 256, G64 | AT, 0, 0)], pl.n_pairs)
             else:
-                sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=G64)[:, :103])
-            wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2), layout=G64 | AT)
-            wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=G64 | AT)
+                if _ARITH["wgrad"] == 0 and ctx.arith == 0:
+                    wgrad(G1, act0, pl.n_pairs, out=sk[1], dbias=kb(g_b0), layout=G64, col_rot=39, col_mod=103)
+                else:
+                    sk[1].index_add_(1, _color_col_perm(dev), wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=G64)[:, :103])
+                wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2), layout=G64 | AT)
+                wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=G64 | AT)
             _bucket("color_weights")
             return (None,) * 13
         # exact-size (default) and worst-case (sync-free) buffers alike: the weight-gradient kernel reads the row count on the device
@@ -700,6 +728,12 @@ class RHead(_GradModeFunction):
 
 
 _wgrad_ws = {}
+_TRUNK_BATCHED = [True]
+
+
+def set_trunk_wgrad_batched(on=True):
+    """The colour trunk's three weight-gradient GEMMs as one side-by-side launch (default) or one after the other (tests / A-B runs)."""
+    _TRUNK_BATCHED[0] = bool(on)
 
 
 def set_color_mode(mode: str):
@@ -756,16 +790,20 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0, col_ro
 
 
 def wgrad_batched(problems, n_rows):
-    """problems: up to three (G, A, out [256, >= 256 row stride], dbias | None) with A [rows, 256]: out += G[:rows]^T A[:rows],
-    dbias += column sums of G[:rows], all in one pair of launches (spf_wgrad_batched)."""
+    """problems: up to three (G, A, out, dbias | None[, C, layout, col_rot, col_mod]): out[256, :C] += G[:rows]^T A[:rows, :C], dbias += column
+    sums of G[:rows], all in ONE pair of launches, side by side on the chip (spf_wgrad_batched).  Short tuples are row-major [rows,256]
+    operands; the long form carries spf_wgrad's layout / column rotation per problem (the colour trunk's tiled operands)."""
     dev = problems[0][0].device
     arr = (_lib.WgradProblem * len(problems))()
     max_rows = None
-    for q, (G, A, out, dbias) in enumerate(problems):
-        if A.shape[1] != 256 or G.shape[1] != 256 or out.shape != (256, 256):
-            raise ValueError("wgrad_batched: every problem is [rows,256]^T x [rows,256] -> [256,256]")
+    for q, prob in enumerate(problems):
+        G, A, out, dbias = prob[:4]
+        C, layout, col_rot, col_mod = (tuple(prob[4:]) + (256, 0, 0, 0)[len(prob) - 4:]) if len(prob) > 4 else (256, 0, 0, 0)
+        if layout == 0 and (A.shape[1] != 256 or G.shape[1] != 256 or out.shape != (256, 256)):
+            raise ValueError("wgrad_batched: a row-major problem is [rows,256]^T x [rows,256] -> [256,256]")
         arr[q].G, arr[q].A, arr[q].lda = _lib.ptr(G), _lib.ptr(A), A.stride(0)
         arr[q].dW, arr[q].ldw, arr[q].dbias = _lib.ptr(out), out.stride(0), _lib.ptr(dbias)
+        arr[q].C, arr[q].layout, arr[q].col_rot, arr[q].col_mod = int(C), int(layout), int(col_rot), int(col_mod)
         rows = min(G.shape[0], A.shape[0])
         max_rows = rows if max_rows is None else min(max_rows, rows)
     nws = int(_lib.lib().spf_wgrad_workspace_floats(256)) * len(problems)

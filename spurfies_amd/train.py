@@ -541,26 +541,22 @@ class VolOpt:
         return moved
 
     def render_step(self, batch, epoch=0, dataset=None, fast=-1, graph=False):
-        """train.py:399-472 without the image files / TensorBoard: full-image render in `split_n_pixels` chunks.
-        graph=True: full-size chunks are replayed as one hipGraph each (spurfies_amd/eval_graph.py); a smaller last chunk runs eagerly."""
+        """train.py:399-472 without the image files / TensorBoard: full-image render in `split_n_pixels` chunks, streamed
+        (spurfies_amd/eval_graph.py:ImageRenderer): pixel coordinates resident on the device, every chunk's outputs written straight into
+        their rows of pre-allocated [H*W, ...] tensors — no per-chunk list / clone / cat (`utils.split_input` + `utils.merge_output` remain
+        available under their reference names).  graph=True: one hipGraph launch per chunk."""
+        from .eval_graph import ImageRenderer
+
         self.model.eval()
         indices, model_input, ground_truth = batch
         dev = self.model.neural_pts.device
         model_input = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in model_input.items()}
         total = model_input["uv"].shape[1]
-        res = []
-        renderer = None
-        if graph and torch.device(dev).type == "cuda" and fast != 1:
-            from .eval_graph import GraphedRenderer
-
-            if getattr(self, "_renderer", None) is None or self._renderer.n_rays != self.split_n_pixels or self._renderer.fast != fast:
-                self._renderer = GraphedRenderer(self.model, self.split_n_pixels, fast=fast)
-            renderer = self._renderer
-        for s in utils.split_input(model_input, total, n_pixels=self.split_n_pixels):
-            with torch.no_grad():
-                out = renderer(s) if (renderer is not None and s["uv"].shape[1] == renderer.n_rays) else self.model(s, fast=fast)
-            res.append({k: out[k].detach().clone() for k in ("rgb_values", "depth_values", "normal_map")})
-        merged = utils.merge_output(res, total, 1)
+        use_graph = bool(graph) and torch.device(dev).type == "cuda" and fast != 1
+        r = getattr(self, "_renderer", None)
+        if r is None or r.n_rays != self.split_n_pixels or r.fast != fast or r.use_graph != use_graph:
+            r = self._renderer = ImageRenderer(self.model, self.split_n_pixels, fast=fast, graph=use_graph)
+        merged = {k: v.clone() for k, v in r(model_input, total).items()}      # once per IMAGE: the renderer's buffers are reused by the next one
         merged["psnr"] = rend_util.get_psnr(merged["rgb_values"], ground_truth["rgb"].to(dev).reshape(-1, 3))
         return merged
 

@@ -181,9 +181,55 @@ def test_fused_compaction_and_pair_list_equal_the_two_step_form():
         old = ops.PairList(nbt, ps, n)
         sdf = torch.empty((R * SR,), device="cuda")
         grad = torch.empty((R * SR, 3), device="cuda")
-        new = ops.PairList.from_slots(svt, nbt, fill_sdf=sdf, fill_grad=grad)
         P, NP = old.host_counts()
-        assert new.host_counts() == (P, NP) and P == int(sv.sum()) and NP == int(cnt[sv.reshape(-1) == 1].sum())
-        assert torch.equal(new.point_slot[:P], ps[:P]) and torch.equal(new.slot_point, sp)
-        assert torch.equal(new.pair_off[:P + 1], old.pair_off[:P + 1]) and torch.equal(new.pair_point[:NP], old.pair_point[:NP])
-        assert bool((sdf == 1000.0).all()) and bool((grad == 0).all())
+        # the two-launch form (count + write) and the one-launch form (round 4: chunks publish their totals to each other), the latter three
+        # times in a row: its word buffer must come back all zero
+        for one_launch, reps in ((False, 1), (True, 3)):
+            ops.set_compact_one_launch(one_launch)
+            try:
+                for _ in range(reps):
+                    sdf.fill_(7.0)
+                    grad.fill_(7.0)
+                    new = ops.PairList.from_slots(svt, nbt, fill_sdf=sdf, fill_grad=grad)
+                    assert new.host_counts() == (P, NP) and P == int(sv.sum()) and NP == int(cnt[sv.reshape(-1) == 1].sum())
+                    assert torch.equal(new.point_slot[:P], ps[:P]) and torch.equal(new.slot_point, sp)
+                    assert torch.equal(new.pair_off[:P + 1], old.pair_off[:P + 1]) and torch.equal(new.pair_point[:NP], old.pair_point[:NP])
+                    assert bool((sdf == 1000.0).all()) and bool((grad == 0).all())
+            finally:
+                ops.set_compact_one_launch(True)
+        for buf in ops._COMPACT_SYNC.values():
+            assert not bool(buf.any()), "the one-launch compaction must leave its word buffer all zero"
+
+
+def test_one_launch_compaction_is_independent_per_stream_and_at_the_largest_pass():
+    """Two streams compact different inputs at the same time (MultiSceneTrainer steps scenes on alternating streams): each stream has its own
+    word buffer; and the 4096-ray sampler pass (524 288 slots = 256 chunks, the largest pass of BASELINE configs[4])."""
+    from spurfies_amd import ops
+
+    rng = np.random.default_rng(5)
+
+    def make(R, SR, frac):
+        sv = (rng.uniform(size=(R, SR)) < frac).astype(np.uint8)
+        cnt = rng.integers(1, 9, size=(R * SR,))
+        nb = np.where(np.arange(8)[None, :] < cnt[:, None], rng.integers(0, 5000, size=(R * SR, 8)), -1).astype(np.int32)
+        nb[sv.reshape(-1) == 0] = -1
+        return torch.from_numpy(sv).cuda(), torch.from_numpy(nb).cuda(), int(sv.sum()), int(cnt[sv.reshape(-1) == 1].sum())
+
+    a, b, big = make(2048, 80, 0.5), make(2048, 80, 0.3), make(4096, 128, 0.05)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for it in range(20):
+        with torch.cuda.stream(s1):
+            pa = ops.PairList.from_slots(a[0], a[1])
+        with torch.cuda.stream(s2):
+            pb = ops.PairList.from_slots(b[0], b[1])
+        outs.append((pa, pb))
+    torch.cuda.synchronize()
+    for pa, pb in outs:
+        assert pa.host_counts() == (a[2], a[3]) and pb.host_counts() == (b[2], b[3])
+    assert len({k for k in ops._COMPACT_SYNC}) >= 2
+    pbig = ops.PairList.from_slots(big[0].view(-1, 1), big[1])
+    assert pbig.host_counts() == (big[2], big[3])
+    ref = ops.PairList(big[1], *ops.compact_points(big[0].view(-1, 1))[::2])
+    assert torch.equal(pbig.pair_off[:big[2] + 1], ref.pair_off[:big[2] + 1])

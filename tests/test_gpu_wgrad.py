@@ -146,3 +146,43 @@ def test_tiled_operands_match_row_major(rows, layout):
         A104 = A[:, :104].contiguous()
         got4 = ops.wgrad(Gx, A104, n, layout=layout)
         assert _err(got4, G[:rows].double().t() @ A104[:rows].double()) < 1e-5
+
+
+@pytest.mark.parametrize("rows", [391000, 49000, 700, 64, 5])
+def test_colour_trunk_problems_side_by_side_equal_three_calls(rows):
+    """Round 4: the colour trunk's three weight-gradient GEMMs in ONE launch (spf_wgrad_batched with per-problem operand forms): layer 0 =
+    G in 64-row tiles x row-major 104-column A with the column rotation into the reference order, layers 2 / 4 = G in 64-row tiles x A in
+    16-row blocks; against float64 and against the single-problem entry point; bias sums ride along; row counts inside the last tile."""
+    from spurfies_amd import ops
+
+    g = torch.Generator().manual_seed(rows)
+    alloc = (rows + 63) // 64 * 64
+    Gs = [torch.randn((alloc, 256), generator=g).cuda() for _ in range(3)]
+    A0 = torch.randn((alloc, 104), generator=g).cuda()
+    As = [A0] + [torch.randn((alloc, 256), generator=g).cuda() for _ in range(2)]
+    n = torch.tensor([rows], dtype=torch.int32, device="cuda")
+    G64 = [_to_tiles(G_, 64) for G_ in Gs]
+    A16 = [A0, _to_tiles(As[1]), _to_tiles(As[2])]
+    outs = [torch.zeros((256, 103), device="cuda"), torch.ones((256, 256), device="cuda"), torch.zeros((256, 256), device="cuda")]
+    dbs = [torch.zeros(256, device="cuda") for _ in range(3)]
+    ops.wgrad_batched([(G64[0], A16[0], outs[0], dbs[0], 104, 4, 39, 103), (G64[1], A16[1], outs[1], dbs[1], 256, 4 | 2, 0, 0),
+                       (G64[2], A16[2], outs[2], dbs[2], 256, 4 | 2, 0, 0)], n)
+    # single-problem calls on the same operands
+    one = [ops.wgrad(G64[0], A16[0], n, out=torch.zeros((256, 103), device="cuda"), layout=4, col_rot=39, col_mod=103),
+           ops.wgrad(G64[1], A16[1], n, layout=6), ops.wgrad(G64[2], A16[2], n, layout=6)]
+    ref0 = Gs[0][:rows].double().t() @ A0[:rows].double()                 # product column i lands in output column (i + 39) mod 103; column 103 is padding
+    ref0 = torch.cat([ref0[:, 64:103], ref0[:, :64]], 1)
+    refs = [ref0, Gs[1][:rows].double().t() @ As[1][:rows].double(), Gs[2][:rows].double().t() @ As[2][:rows].double()]
+    for q in range(3):
+        base = 1.0 if q == 1 else 0.0
+        assert _err(outs[q] - base, refs[q]) < 2e-6 + 2.0 * _err(one[q], refs[q]), q
+        np.testing.assert_allclose(dbs[q].double().cpu().numpy(), Gs[q][:rows].double().sum(0).cpu().numpy(), rtol=1e-5, atol=2e-5 * rows ** 0.5 + 1e-5)
+
+
+def test_batched_entry_rejects_operand_forms_it_does_not_hold():
+    from spurfies_amd import _lib, ops
+
+    G = torch.zeros((128, 256), device="cuda")
+    n = torch.tensor([128], dtype=torch.int32, device="cuda")
+    with pytest.raises(_lib.SpurfiesHipError, match="is not one of"):
+        ops.wgrad_batched([(G, G, torch.zeros((256, 256), device="cuda"), None, 256, 1, 0, 0), (G, G, torch.zeros((256, 256), device="cuda"), None)], n)

@@ -197,3 +197,27 @@ def test_oracle_tracks_reference_trajectory(name):
             np.testing.assert_allclose(v.item(), fx[f"loss.{k}"][i], rtol=2e-5, atol=1e-7, err_msg=f"step {i} {k}")
         np.testing.assert_allclose(float(norm), fx["step.grad_norm"][i], rtol=1e-4, err_msg=f"step {i} grad norm")
     np.testing.assert_allclose(float(P.get_beta(st, cfg).detach()), fx["step.beta"][7], rtol=1e-5)      # step.beta[i]: after step i's update
+
+
+def test_eval_image_chunks_match_the_reference_in_its_evaluation_configuration():
+    """eval_image_near0.npz: a 32 x 48 image rendered by the imported reference the way eval_spurfies.py:276-292 does (split_input chunks of
+    500 pixels, fast = -1, merge_output) with the EVALUATION sampler range of config/confs/dtu_pn.conf:48 (near = 0.0).  The oracle renders
+    the first full chunk and the short last one (36 pixels); the eval forward draws nothing that reaches the outputs."""
+    fx = load_golden("eval_image_near0.npz")
+    scene = scene_of(fx)
+    st = P.load_state(scene["state"], requires_grad=False)
+    cfg = P.PathConfig(ranges=tuple(scene["ranges"]), near=float(fx["meta.near"]))
+    assert cfg.near == 0.0
+    grid = P.make_grid(cfg, st["neural_pts"])
+    uv = torch.from_numpy(fx["in.uv"])
+    total, chunk = uv.shape[0], int(fx["meta.chunk"])
+    assert total == int(fx["meta.h"]) * int(fx["meta.w"]) and total % chunk != 0
+    base = {"intrinsics": torch.from_numpy(scene["intrinsics"])[None], "pose": torch.from_numpy(scene["poses"][int(fx["meta.view"])])[None]}
+    for lo in (0, (total // chunk) * chunk):
+        hi = min(lo + chunk, total)
+        stages = {}
+        with torch.enable_grad():
+            out = P.forward(dict(base, uv=uv[None, lo:hi]), st, cfg, grid=grid, training=False, fast=-1, stages=stages)
+        for k in ("rgb_values", "depth_values", "normal_map", "weights"):
+            np.testing.assert_allclose(out[k].detach().numpy().reshape(hi - lo, -1), fx[f"out.{k}"][lo:hi].reshape(hi - lo, -1), err_msg=f"{k} rows {lo}:{hi}",
+                                       rtol=2e-4, atol=2e-5)
