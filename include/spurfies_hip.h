@@ -134,9 +134,9 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
  * gate (DEVICE int32, may be NULL): when *gate == 0 the counts are reported as {0, 0} (the fillers are still laid down), so the MLP kernels
  * behind this pass do no work — how a sampler iteration the loop did not reach is skipped without a host round trip (spf_sampler_iter).
  * sync (DEVICE uint64, may be NULL; ABI 4): spf_compact_sync_words(R*SR) words that are ALL ZERO on entry (e.g. hipMemset once) and are left
- * all zero — the pass then runs as ONE launch in which the 2048-slot chunks publish their totals to each other through these words
+ * all zero — the pass then runs as ONE launch in which 512-slot chunks publish their totals to each other through these words
  * (relaxed agent-scope atomics, value and flag in one word; the last chunk to have read clears them).  One buffer per stream that may run
- * this call concurrently; passes of more than 2048 chunks (4 M slots) and sync == NULL take the two-launch form. */
+ * this call concurrently; passes of more than 2048 chunks (1 M slots) and sync == NULL take the two-launch form. */
 int64_t spf_compact_sync_words(int64_t n_slots);
 int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot,
                       int32_t* slot_point, int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch,

@@ -628,6 +628,10 @@ __global__ void __launch_bounds__(256) cp_write_kernel(const uint8_t* __restrict
 // zero on entry and is left all zero: the last block to finish its look-back clears it (word 0 counts the blocks that have).
 constexpr unsigned long long CPF_PUBLISHED = 1ull << 62;
 constexpr int CPF_MAX_CHUNKS = 2048;      // 2048 blocks of 256 threads are co-resident on 256 CUs; larger passes keep the two-launch form
+// chunks of 512 slots (two per thread), a quarter of the two-launch form's: the pass is latency-bound (a thread's slots are read one after the
+// other, then four block scans and the look-back), and at 128 rays 2048-slot chunks put the sampler pass's 16 k slots on 8 workgroups
+constexpr int CPF_PER_THREAD = 2;
+constexpr int CPF_CHUNK = 256 * CPF_PER_THREAD;
 __global__ void __launch_bounds__(256) cp_fused_kernel(const uint8_t* __restrict__ slot_valid, const int32_t* __restrict__ nbr, long long nslot,
                                                        int k, unsigned long long* __restrict__ sync, int32_t* __restrict__ point_slot,
                                                        int32_t* __restrict__ slot_point, int32_t* __restrict__ pair_off,
@@ -639,10 +643,10 @@ __global__ void __launch_bounds__(256) cp_fused_kernel(const uint8_t* __restrict
     __shared__ int32_t wsum3[4];
     __shared__ int32_t wsum4[4];
     __shared__ int32_t i_clear;
-    const long long base = (long long)blockIdx.x * CMP_CHUNK + (long long)threadIdx.x * CMP_PER_THREAD;
-    int c[CMP_PER_THREAD], np = 0, nq = 0;
+    const long long base = (long long)blockIdx.x * CPF_CHUNK + (long long)threadIdx.x * CPF_PER_THREAD;
+    int c[CPF_PER_THREAD], np = 0, nq = 0;
 #pragma unroll
-    for (int u = 0; u < CMP_PER_THREAD; ++u) {
+    for (int u = 0; u < CPF_PER_THREAD; ++u) {
         c[u] = -1;                                   // -1: not a valid point
         if (base + u < nslot && slot_valid[base + u]) {
             c[u] = nbr_count(nbr + (size_t)(base + u) * k, k);
@@ -673,7 +677,7 @@ __global__ void __launch_bounds__(256) cp_fused_kernel(const uint8_t* __restrict
     }
     int p = base_p + lp, q = base_q + lq;
 #pragma unroll
-    for (int u = 0; u < CMP_PER_THREAD; ++u)
+    for (int u = 0; u < CPF_PER_THREAD; ++u)
         if (base + u < nslot) {
             if (c[u] >= 0) {
                 point_slot[p] = (int32_t)(base + u);
@@ -968,7 +972,7 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
     return SPF_OK;
 }
 
-int64_t spf_compact_sync_words(int64_t n_slots) { return spf::div_up(n_slots, (int64_t)CMP_CHUNK) + 1; }
+int64_t spf_compact_sync_words(int64_t n_slots) { return spf::div_up(n_slots, (int64_t)CPF_CHUNK) + 1; }
 
 int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot, int32_t* slot_point,
                       int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch, float* fill_sdf, float fill_value,
@@ -984,8 +988,8 @@ int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, 
     if (!slot_valid || !nbr || !point_slot || !slot_point || !pair_point || !scratch) return spf::fail(SPF_EINVAL, "spf_compact_pairs: null buffer");
     const long long nslot = (long long)R * SR;
     const int chunks = spf::div_up(nslot, CMP_CHUNK);
-    if (sync && chunks <= CPF_MAX_CHUNKS) {          // one launch: chunks publish their totals to each other (cp_fused_kernel)
-        cp_fused_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nbr, nslot, k, reinterpret_cast<unsigned long long*>(sync), point_slot, slot_point,
+    if (sync && spf::div_up(nslot, (long long)CPF_CHUNK) <= CPF_MAX_CHUNKS) {          // one launch: chunks publish their totals to each other (cp_fused_kernel)
+        cp_fused_kernel<<<(int)spf::div_up(nslot, (long long)CPF_CHUNK), 256, 0, stream>>>(slot_valid, nbr, nslot, k, reinterpret_cast<unsigned long long*>(sync), point_slot, slot_point,
                                                     pair_off, pair_point, counts, fill_sdf, fill_value, fill_grad, gate);
         SPF_LAUNCH_CHECK("cp_fused_kernel");
         return SPF_OK;

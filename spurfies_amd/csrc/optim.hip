@@ -16,7 +16,7 @@
 namespace {
 using namespace spf;
 
-constexpr int NORM_BLOCKS = 512;
+constexpr int NORM_BLOCKS = 512;      // partial sums: every block of the update sweep re-adds them (one wave, eight per lane; 128 blocks made the norm launch 2.3x slower)
 
 struct AdamCtl {
     double lr, beta1, beta2, max_norm;

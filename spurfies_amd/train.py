@@ -453,8 +453,13 @@ class VolOpt:
                           eikonal_weight=lw.get("eikonal_weight", 0.001), rgb_weight=lw.get("rgb_weight", 1.0), tv_weight=lw.get("tv_weight", 0.01))
         self.lr = self.conf.get_float("train.learning_rate", 5.0e-4)
         grad_clip = args.get("grad_clip", True) if isinstance(args, dict) else True
-        self.step = TrainStep(self.model, loss=loss, lr=self.lr, grad_clip=grad_clip, sync_free=kwargs.get("sync_free", False),
-                              use_graph=kwargs.get("use_graph", False))
+        # default execution mode = the one bench.py times (round-3 verdict): on a GPU the sync-free step (static shapes, device-side counts, fused
+        # loss kernels, gradients added straight into the flat buffer); sync_free=False keeps the reference-shaped step with its per-step outputs
+        # (`grad_theta [P,3]`, one host read-back) — what a caller that inspects those outputs wants, and the only mode without a GPU
+        sync_free = kwargs.get("sync_free")
+        if sync_free is None:
+            sync_free = torch.device(device).type == "cuda"
+        self.step = TrainStep(self.model, loss=loss, lr=self.lr, grad_clip=grad_clip, sync_free=bool(sync_free), use_graph=kwargs.get("use_graph", False))
         self.loss, self.optimizer, self.scheduler = self.step.loss, self.step.optimizer, self.step.scheduler
         self.start_epoch, self.iter_step, self.total_step = 0, 0, 0
         self.stg = 2

@@ -10,10 +10,13 @@ import subprocess
 import sys
 
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
-MODE = ["--mode", "eval", "--sweep-resolution", "0"] if "eval" in sys.argv[2:] else []
-OUT = TAG + ("_eval" if MODE else "") + "_pmc_traffic.json"
+MODE = ["--mode", "eval", "--sweep-resolution", "0", "--image", "0", "0"] if "eval" in sys.argv[2:] else []
+DENSE = "dense" in sys.argv[2:]          # BASELINE.json configs[4]: 2e5-point cloud (spacing 0.0125), 4096-ray batches
+OUT = TAG + ("_eval" if MODE else "") + ("_dense" if DENSE else "") + "_pmc_traffic.json"
 
-POINTS, RAYS = 10000, 1024
+POINTS, RAYS = (200000, 4096) if DENSE else (10000, 1024)
+MODE += ["--spacing", "0.0125"] if DENSE else []
+MODE += ["--geo-engine", "split_w"]
 out = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = f"gpurun_out/pmc_{ctr}"
@@ -33,7 +36,7 @@ for k, v in out.items():
 rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on bench.py --steps 3 --warmup 1; per-launch values of the "
                "largest launch per kernel (main pass). hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reads half of a wide "
                "coalesced stream (MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are included in both counters.",
-       "config": {"points": POINTS, "rays": RAYS, "prior": "fitted"}, "kernels": out}
+       "config": {"points": POINTS, "rays": RAYS, "prior": "fitted", "spacing": 0.0125 if DENSE else 0.025}, "kernels": out}
 json.dump(rec, open("gpurun_out/" + OUT, "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_max_corrected"])[:12]:
     print(f"{k[:60]:60s} {v['hbm_bytes_max_corrected'] / 1e6:10.1f} MB")
