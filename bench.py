@@ -119,7 +119,7 @@ def init_ranks(args):
     """RANK / LOCAL_RANK / WORLD_SIZE from the launcher's environment -> (world, rank, device, dist_info).  N > 1: the process group over RCCL
     ("nccl" IS RCCL on ROCm; SPF_DIST_BACKEND=gloo for plumbing checks on a single-GPU box) and one all-reduce through it, under a watchdog —
     an RCCL bring-up that hangs (xGMI / IPC misconfiguration) ends the rank with a message and a non-zero code after SPF_DIST_INIT_TIMEOUT
-    seconds (default 60) instead of sitting in the driver's clock."""
+    seconds (default 120: the slowest rank may still be paging in torch when the first one arrives) instead of sitting in the driver's clock."""
     import datetime
     import threading
 
@@ -133,7 +133,7 @@ def init_ranks(args):
         return world, rank, device, None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = os.environ.get("SPF_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only for single-GPU plumbing tests
-    limit = float(os.environ.get("SPF_DIST_INIT_TIMEOUT", "60"))
+    limit = float(os.environ.get("SPF_DIST_INIT_TIMEOUT", "120"))
 
     def bail():
         sys.stderr.write(f"[bench] rank {rank}/{world} on {device}: process-group bring-up over '{backend}' (init + first all-reduce) did not "
