@@ -433,6 +433,10 @@ def main():
 
     ops.geo_clock_enable(True)                    # this process is the one measuring caller of the library's held-clock counters
     strong = args.global_rays > 0
+    # strong scaling = ONE batch shared by the ranks: the ranks then draw the sampler's CPU random numbers batch-wide and keep their rows, so the
+    # N-GPU run is the same optimisation as the 1-GPU run of that batch (cheap there: the batch does not grow with N).  Weak scaling grows the
+    # batch with N; batch-wide draws would cost every rank N times the host-side random numbers (5 ms at 8 x 1024 rays): per-rank streams.
+    args.exact_draws = bool(args.exact_draws or strong)
     if strong and args.global_rays % world:
         raise SystemExit(f"--global-rays {args.global_rays} must be a multiple of the {world} ranks")
     rays_total = args.global_rays if strong else args.rays * world

@@ -241,10 +241,11 @@ __device__ __forceinline__ bool dil_hit(const GridDev& g, float x, float y, floa
 // ---- slot assignment ------------------------------------------------------------------------
 // D > 1: one wave per ray; samples are tested 64 at a time, hits get consecutive slots.
 __global__ void __launch_bounds__(256) hit_slots_kernel(const float* __restrict__ raypos, int R, int D, int SR,
-                                                        GridDev g, int32_t* __restrict__ slot_sample) {
+                                                        GridDev g, int32_t* __restrict__ slot_sample, uint8_t* __restrict__ ray_valid) {
     const int lane = threadIdx.x & 63;
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= R) return;
+    if (lane == 0) ray_valid[r] = 0;          // knn_kernel raises it when one of the ray's slots finds a neighbour (round 4: no ray_valid launch)
     int count = 0;
     for (int base = 0; base < D && count < SR; base += 64) {
         int d = base + lane;
@@ -384,7 +385,12 @@ __global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ rayp
         loc[gid * 3 + 1] = y;
         loc[gid * 3 + 2] = z;
         slot_valid[gid] = key[0] != NONE;
-        if (ray_valid1) ray_valid1[gid] = key[0] != NONE;      // SR == 1: the ray's validity is its only slot's (no ray_valid_kernel launch)
+        // the ray's validity = "some slot has a neighbour".  SR == 1: its only slot's.  SR > 1: hit_slots_kernel cleared it; every slot with a
+        // neighbour stores the same 1 (a benign same-value race), so no pass over the slots is needed afterwards
+        if (ray_valid1) {
+            if (SR == 1) ray_valid1[gid] = key[0] != NONE;
+            else if (key[0] != NONE) ray_valid1[gid / SR] = 1;
+        }
     }
 }
 
@@ -901,19 +907,19 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
         point_slots_kernel<<<spf::div_up(R, 256), 256, 0, stream>>>(raypos, R, SR, d, slot_sample);
         SPF_LAUNCH_CHECK("point_slots_kernel");
     } else {
-        hit_slots_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, stream>>>(raypos, R, D, SR, d, slot_sample);
+        hit_slots_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, stream>>>(raypos, R, D, SR, d, slot_sample, ray_valid);
         SPF_LAUNCH_CHECK("hit_slots_kernel");
     }
     if (g->cfg.compat & SPF_KNN_LAYERED)
         knn_kernel<true><<<spf::div_up((long long)nslot * 8, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
                                                                                  g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
-                                                                                 slot_sample, pidx, loc, slot_valid, SR == 1 ? ray_valid : nullptr, inline_slots);
+                                                                                 slot_sample, pidx, loc, slot_valid, ray_valid, inline_slots);
     else
         knn_kernel<false><<<spf::div_up((long long)nslot * 8, 256), 256, 0, stream>>>(raypos, R, D, SR, k, rad2, d, g->cfg.kernel_size[0] / 2,
                                                                                   g->cfg.kernel_size[1] / 2, g->cfg.kernel_size[2] / 2,
-                                                                                  slot_sample, pidx, loc, slot_valid, SR == 1 ? ray_valid : nullptr, inline_slots);
+                                                                                  slot_sample, pidx, loc, slot_valid, ray_valid, inline_slots);
     SPF_LAUNCH_CHECK("knn_kernel");
-    if (SR > 1) {
+    if (SR > 1 && D == 1) {      // (a shape no pass of the model uses: point queries with several slots; rays go through hit_slots + knn above)
         ray_valid_kernel<<<spf::div_up(R, 256), 256, 0, stream>>>(slot_valid, R, SR, ray_valid);
         SPF_LAUNCH_CHECK("ray_valid_kernel");
     }
