@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
-MODE = ["--mode", "eval", "--sweep-resolution", "0"] if "eval" in sys.argv[2:] else []
+MODE = ["--mode", "eval", "--sweep-resolution", "0", "--image", "0", "0"] if "eval" in sys.argv[2:] else []
 OUT = TAG + ("_eval" if MODE else "") + "_pmc_mfma.json"
 
 d = "gpurun_out/pmc_mfma"
