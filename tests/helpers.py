@@ -50,6 +50,24 @@ def check_probes(fx, name, t, rtol, atol):
     np.testing.assert_allclose(flat.norm().item(), stats[2], rtol=max(rtol, 1e-4), atol=atol, err_msg=name + " l2")
 
 
+def check_probes_tight(fx, name, t, rtol, atol, outlier_frac=0.0, outlier_rtol=0.0):
+    """check_probes for the END-TO-END gradients (sampler in the loop).  Measured on MI355X (tools/probe_errors.py, round 4): every probe of every
+    trainable tensor agrees with the reference to <= 1.1e-4 of (|ref| + the tensor's RMS gradient) — EXCEPT, in one fixture, the rows of a latent
+    table that belong to a sample whose neighbour set differs by a point at the radius boundary (GPU transcendentals move sample positions in
+    the last bits): a deterministic handful of probes, 1.4e-2 off, the same with float atomics and in the bit-reproducible mode.  So: all probes
+    within (rtol, atol) except at most `outlier_frac` of them, which must still be within `outlier_rtol`; the gradient's L2 norm to 1e-4."""
+    flat = t.detach().reshape(-1).double().cpu()
+    idx = torch.from_numpy(fx[f"{name}.idx"])
+    got, want = flat[idx].numpy(), fx[f"{name}.val"].astype(np.float64)
+    err = np.abs(got - want)
+    bad = err > rtol * np.abs(want) + atol
+    assert bad.mean() <= outlier_frac, f"{name}: {int(bad.sum())} of {bad.size} probes outside rtol={rtol} atol={atol:.3e} (worst {err.max():.3e})"
+    if bad.any():
+        assert (err[bad] <= outlier_rtol * (np.abs(want[bad]) + atol / max(rtol, 1e-30))).all(), f"{name}: an outlier probe is off by more than {outlier_rtol}"
+    stats = fx[f"{name}.stats"]
+    np.testing.assert_allclose(flat.norm().item(), stats[2], rtol=1e-4, atol=atol, err_msg=name + " l2")
+
+
 def assert_close_except_kinks(actual, desired, rtol, atol, max_frac=1e-3, err_msg=""):
     """Derivatives of a LeakyReLU network are discontinuous where a pre-activation is zero: when a pre-activation lies within
     rounding of zero, two correct fp32 evaluations that sum in a different order pick different slopes (1 vs 0.01) for that unit.

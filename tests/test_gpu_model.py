@@ -4,14 +4,16 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import assert_close_except_kinks, check_probes, draws_of, inputs_of, load_golden, scene_of
+from tests.helpers import check_probes_tight, assert_close_except_kinks, check_probes, draws_of, inputs_of, load_golden, scene_of
 
 pytestmark = pytest.mark.gpu
 
 # End-to-end tolerances (fp32): sample positions differ from the CPU run in the
 # last bits (GPU transcendental / fma differences in the sampler), which moves SDF and colours by
 # O(1e-5) and, rarely, flips a neighbour at the radius boundary.
-OUT_TOL = dict(rtol=2e-3, atol=2e-4)
+# end-to-end outputs WITH the sampler in the loop.  Measured on MI355X (tools/e2e_errors.py, round 4): max |hip - reference| 5e-6 over rgb / depth /
+# weights / xyz / normals of the three single-step fixtures (train fast=1 and the full evaluation loop) — the bound keeps a 4 x margin
+OUT_TOL = dict(rtol=1e-4, atol=2e-5)
 
 
 def build_model(scene, train=True, near=0.5):
@@ -44,7 +46,7 @@ def test_train_step_matches_reference_golden(name):
     for k in ("rgb_values", "depth_values", "depth_vals", "weights", "xyz"):
         np.testing.assert_allclose(out[k].detach().cpu().numpy(), fx[f"out.{k}"], err_msg=k, **OUT_TOL)
     np.testing.assert_allclose(out["tv_loss"].item(), fx["out.tv_loss"], rtol=1e-5)
-    np.testing.assert_allclose(out["pseudo_pts_loss"].item(), fx["out.pseudo_pts_loss"], rtol=5e-3, atol=1e-5)
+    np.testing.assert_allclose(out["pseudo_pts_loss"].item(), fx["out.pseudo_pts_loss"], rtol=5e-4, atol=1e-6)
     # number of valid points may differ by a boundary flip or two, never by more
     assert abs(out["grad_theta"].shape[0] - fx["out.grad_theta"].shape[0]) <= 3
     if out["grad_theta"].shape == fx["out.grad_theta"].shape:
@@ -53,14 +55,15 @@ def test_train_step_matches_reference_golden(name):
     gt = {"rgb": torch.from_numpy(fx["in.rgb_gt"])[None], "mask": torch.from_numpy(fx["in.mask_gt"])[None, :, None].repeat(1, 1, 3)}
     losses = loss_fn(out, gt)
     for k, v in losses.items():
-        np.testing.assert_allclose(v.item(), fx[f"loss.{k}"], rtol=2e-3, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(v.item(), fx[f"loss.{k}"], rtol=2e-4, atol=2e-6, err_msg=k)
     model.zero_grad()
     losses["loss"].backward()
     for pname, p in model.named_parameters():
         if p.requires_grad:
             g = p.grad if p.grad is not None else torch.zeros_like(p)
             scale = float(fx[f"grad.{pname}.stats"][2]) / max(np.sqrt(g.numel()), 1.0)
-            check_probes(fx, f"grad.{pname}", g, rtol=2e-2, atol=2e-2 * scale + 1e-9)
+            latent = pname.startswith("neural_feats")
+            check_probes_tight(fx, f"grad.{pname}", g, rtol=1e-3, atol=1e-3 * scale + 1e-9, outlier_frac=0.02 if latent else 0.0, outlier_rtol=5e-2)
 
 
 @pytest.mark.parametrize("name", ["step_train_r128.npz", "step_train_far.npz"])
@@ -81,11 +84,12 @@ def test_sync_free_train_step_matches_reference_golden(name):
     for k in ("rgb_values", "weights"):
         np.testing.assert_allclose(out[k].detach().cpu().numpy(), fx[f"out.{k}"], err_msg=k, **OUT_TOL)
     for k, v in losses.items():
-        np.testing.assert_allclose(v.item(), fx[f"loss.{k}"], rtol=2e-3, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(v.item(), fx[f"loss.{k}"], rtol=2e-4, atol=2e-6, err_msg=k)
     for pname, p in model.named_parameters():
         if p.requires_grad:
             scale = float(fx[f"grad.{pname}.stats"][2]) / max(np.sqrt(p.numel()), 1.0)
-            check_probes(fx, f"grad.{pname}", p.grad, rtol=2e-2, atol=2e-2 * scale + 1e-9)
+            latent = pname.startswith("neural_feats")
+            check_probes_tight(fx, f"grad.{pname}", p.grad, rtol=1e-3, atol=1e-3 * scale + 1e-9, outlier_frac=0.02 if latent else 0.0, outlier_rtol=5e-2)
 
 
 def test_eval_step_matches_reference_golden():
@@ -97,7 +101,7 @@ def test_eval_step_matches_reference_golden():
     out = model(inp, fast=-1)
     assert model.ray_sampler.last_iters == len(fx["meta.sampler_calls"])
     for k in ("rgb_values", "depth_values", "depth_vals", "weights", "xyz", "normal_map"):
-        np.testing.assert_allclose(out[k].detach().cpu().numpy(), fx[f"out.{k}"], err_msg=k, rtol=5e-3, atol=5e-4)
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), fx[f"out.{k}"], err_msg=k, **OUT_TOL)      # measured: 5e-6 (tools/e2e_errors.py)
 
 
 def test_sdf_eval_matches_reference_golden():
@@ -578,9 +582,8 @@ def test_full_image_stream_matches_the_reference_in_its_evaluation_configuration
     """eval_image_near0.npz (the imported reference: eval_spurfies.py:276-292 loop, sampler range of config/confs/dtu_pn.conf:48, near = 0.0,
     split_input chunks of 500 + a short last chunk, merge_output) against the streamed renderer (spurfies_amd/eval_graph.py:ImageRenderer:
     device-side cursor, outputs scattered into pre-allocated [H*W, ...] tensors, one hipGraph launch per chunk with graph=True).  Per pixel:
-    rgb / depth / compositing weights at the end-to-end evaluation bound on >= 99 % of the pixels (GPU transcendentals move sample
-    positions in the last bits, which can flip a neighbour at the radius boundary), normals on >= 98 %; the realised sampler iterations of
-    every chunk are the reference's."""
+    most pixels at the single-step end-to-end bound, every pixel within 3e-2 (numbers below); the realised sampler iterations of every chunk
+    are the reference's."""
     from spurfies_amd.eval_graph import ImageRenderer
 
     fx = load_golden("eval_image_near0.npz")
@@ -594,12 +597,17 @@ def test_full_image_stream_matches_the_reference_in_its_evaluation_configuration
     torch.cuda.synchronize()
     # sdf_importance calls of the reference's loop per chunk (ray_sampler.py:403) = the realised iterations as this build counts them
     assert r.last_iters == [int(c) for c in fx["meta.sampler_calls_per_chunk"]], (r.last_iters, fx["meta.sampler_calls_per_chunk"])
-    for k, frac, tol in (("rgb_values", 0.99, dict(rtol=5e-3, atol=1e-3)), ("depth_values", 0.99, dict(rtol=5e-3, atol=1e-3)),
-                         ("weights", 0.99, dict(rtol=5e-3, atol=1e-3)), ("normal_map", 0.98, dict(rtol=2e-2, atol=2e-2))):
+    # Measured on MI355X (tools/e2e_errors.py, round 4; eager and graphed identical): pixels (all channels / slots) within the single-step end-to-end
+    # bound rtol 1e-4 / atol 2e-5: rgb 96.8 %, depth 99.3 %, normals 90.6 %, the 80 compositing weights 83.3 %; largest deviation of any pixel
+    # 5.7e-3 (rgb), 9.8e-3 (depth), 1.1e-2 (normal), 1.25e-2 (one weight).  The full evaluation loop runs up to five sampler iterations of
+    # exp / log / bisection per ray (the HIP sampler alone: 2e-4 per ray on >= 97 % of the rays against the reference's, test_gpu_stages),
+    # so sample positions differ in more than the last bits on some rays; the 24-ray evaluation fixture (near 0.5) agrees to 5e-6.
+    for k, tight_frac, loose in (("rgb_values", 0.94, 3e-2), ("depth_values", 0.97, 3e-2), ("weights", 0.75, 3e-2), ("normal_map", 0.85, 3e-2)):
         got, want = out[k].cpu().numpy().reshape(total, -1), fx[f"out.{k}"].reshape(total, -1)
-        ok = np.isclose(got, want, **tol).all(axis=1)
-        assert ok.mean() >= frac, f"{k}: {int((~ok).sum())} of {total} pixels outside {tol}"
         assert np.isfinite(got).all(), k
+        ok = np.isclose(got, want, rtol=1e-4, atol=2e-5).all(axis=1)
+        assert ok.mean() >= tight_frac, f"{k}: only {ok.mean():.3f} of the pixels within rtol 1e-4 / atol 2e-5"
+        assert float(np.abs(got - want).max()) <= loose, f"{k}: a pixel is off by {float(np.abs(got - want).max()):.3e}"
     # a second image through the same renderer (cursor reset, buffers reused) is the same image up to the float atomics of the forward's
     # RBF-weighted mean (last-bit run-to-run noise in the default scatter mode)
     first = {k: v.clone() for k, v in out.items()}
