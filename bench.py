@@ -598,7 +598,7 @@ def main():
                                                                                                    else "; per-rank streams, own rays only")),
                    "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product from three bf16 pieces per operand (6 exact bf16 piece products, fp32 accumulate: fp32-class, <= 2 ulp per product)",
                    "launch": ("hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if world == 1 else
-                              "two hipGraph replays ([forward + counts] | 16-byte count all-reduce | [loss + backward]), dense gradient all-reduce, 3 eager launches (clip + guard + Adam)") if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (~80 per step: 52 library kernels + torch's small elementwise / copy / fill launches)")},
+                              "two hipGraph replays ([forward + counts] | 16-byte count all-reduce | [loss + backward]), dense gradient all-reduce, 3 eager launches (clip + guard + Adam)") if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (41 library kernels per step + one host-to-device copy of the sampler's CPU random draws)")},
         "roofline": roof, "dist": dist_info,
         "sustained_ms_per_step": sustained, "sustained_steps": args.sustained if sustained is not None else 0,
         "loss_last": loss_last,
