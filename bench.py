@@ -43,9 +43,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (config/ours.yaml:14 num_pixels); weak scaling")
-    ap.add_argument("--global-rays", type=int, default=0, help="strong scaling: ONE batch of this many rays per step, rank r renders rays r::N of it "
-                    "(SURVEY.md section 8(e)); 0 = weak scaling with --rays per GPU")
+    ap.add_argument("--rays", type=int, default=1024, help="rays per step (config/ours.yaml:14 num_pixels).  N > 1: ONE batch of this many rays, rank r renders "
+                    "rays r::N of it (strong scaling of BASELINE.json configs[1] — the default); with --weak: rays PER GPU")
+    ap.add_argument("--global-rays", type=int, default=0, help="strong scaling with this many rays per step instead of --rays (kept for older command lines)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --rays rays per GPU, the batch grows with N (no BASELINE config has such batches; "
+                    "reported as an `extra` record of the default run at N > 1)")
+    ap.add_argument("--extras", choices=["auto", "on", "off"], default="auto", help="extra records in the same JSON line (`extra`): BASELINE.json configs[4] "
+                    "strong-scaled (2e5 points, 4096 rays per step) and the weak-scaling figure (1024 rays per GPU); auto = at N > 1")
+    ap.add_argument("--c4-points", type=int, default=200000, help="neural points of the configs[4] extra record (tests shrink it)")
+    ap.add_argument("--c4-rays", type=int, default=4096, help="rays per step of the configs[4] extra record")
+    ap.add_argument("--local", action="store_true", help="also time the DTU recipe's real step: synthetic local_data on every batch (find_surface_points + "
+                    "feature-consistency loss, local_weight 0.5) -> extra record + ms_per_step_with_local")
+    ap.add_argument("--gc", choices=["off", "on"], default="off", help="Python's cyclic garbage collector during the timed regions (off: collected once before them)")
+    ap.add_argument("--settle", type=float, default=1.0, help="seconds of the same step run UNTIMED behind the --warmup steps, before the timed region, so that "
+                    "the chip's clock has settled under load (the 20-step region read 6.7 %% faster than the sustained one without it)")
     ap.add_argument("--points", type=int, default=10000, help="neural points (DTU-like cloud)")
     ap.add_argument("--spacing", type=float, default=0.025, help="nearest-neighbour spacing of the synthetic cloud (0.0125 = dense stress cloud)")
     ap.add_argument("--prior", choices=["fitted", "kaiming"], default="fitted", help="fitted: F_geometry/T + latents reproduce the signed distance to the "
@@ -61,6 +72,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay forward + loss + backward as one hipGraph (measured no faster than the eager sync-free "
                     "step on MI355X: ~3 us of dependency handling per graph node; the eager launches run ahead of the GPU)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches even at <= 256 rays per GPU (where the graph replay is the default: the eager step is host-bound there)")
+    ap.add_argument("--no-fork", action="store_true", help="graph-replayed steps on ONE stream (default: independent passes as forked branches of the graph)")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--mode", choices=["train", "eval"], default="train", help="train (the contract line): one optimisation step per step; eval: one evaluation-render chunk per "
                     "step (PointVolSDF.forward(fast=-1) under no_grad: the full error-bounded sampler, kNN, SDF + normals, colour, compositing — SURVEY.md "
@@ -163,20 +175,26 @@ def init_ranks(args):
     return world, rank, device, info
 
 
-def make_batches(scene, n_steps, rays_total, rank, world, device, seed=12345):
-    """Seeded synthetic batches of `rays_total` rays, resident on the device before the timed region; rank r keeps rays r::world."""
+def make_batches(scene, n_steps, rays_total, rank, world, device, seed=12345, local=False):
+    """Seeded synthetic batches of `rays_total` rays, resident on the device before the timed region; rank r keeps rays r::world.
+    local: every batch carries its view's synthetic `local_data` (feature maps + MVS camera packs of the shapes datasets/dtu.py:268-291
+    provides; resident on the device, one dict per view)."""
     from spurfies_amd import synthetic as syn
 
     g = torch.Generator().manual_seed(seed)
     K = torch.from_numpy(scene["intrinsics"])[None].to(device)
     out = []
+    views = None
+    if local:
+        views = [{k: (torch.from_numpy(np.asarray(v)).to(device) if isinstance(v, (np.ndarray, np.floating)) else v)
+                  for k, v in syn.make_local_data(scene, v_, seed=0).items()} for v_ in range(len(scene["poses"]))]
     for s in range(n_steps):
         uv = torch.from_numpy(syn.make_pixels(rays_total, g))
         rgb = torch.rand((rays_total, 3), generator=g)
         mask = (torch.rand((rays_total,), generator=g) > 0.1).float()
         sel = torch.arange(rank, rays_total, world)
         pose = torch.from_numpy(scene["poses"][s % len(scene["poses"])])[None].to(device)
-        out.append(({"intrinsics": K, "uv": uv[sel][None].to(device), "pose": pose, "local_data": None},
+        out.append(({"intrinsics": K, "uv": uv[sel][None].to(device), "pose": pose, "local_data": None if views is None else views[s % len(views)]},
                     {"rgb": rgb[sel][None].to(device), "mask": mask[sel][None, :, None].repeat(1, 1, 3).to(device)}))
     return out
 
@@ -228,7 +246,8 @@ def build_scene_step(args, seed, device, world, use_graph):
     conf = default_model_conf(near=0.5, grid_ranges=list(scene["ranges"]))
     model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
     model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
-    return scene, model, TrainStep(model, sync_free=not args.sync, use_graph=use_graph, draws="batch" if (args.exact_draws or world == 1) else "local")
+    return scene, model, TrainStep(model, sync_free=not args.sync, use_graph=use_graph, draws="batch" if (args.exact_draws or world == 1) else "local",
+                                   fork=False if args.no_fork else None)
 
 
 def eval_cpu_baseline(scene, n_rays):
@@ -418,38 +437,77 @@ def main_eval(args):
         torch.distributed.destroy_process_group()
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # the driver's command shape: `python bench.py --gpus N` — start the ranks ourselves
-        raise SystemExit(self_launch(args))
-    if args.mode == "eval":
-        return main_eval(args)
-    world, rank, device, dist_info = init_ranks(args)
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+def csrc_digest():
+    """sha256 over the library's sources (spurfies_amd/csrc/*, include/spurfies_hip.h): the identity of the KERNEL code of this tree.  The
+    counter / power collections under profiles/ record it (tools/pmc_traffic.py, tools/power_probe.py); a collection whose digest differs from
+    the running tree's is stale evidence and is not quoted (round-4 verdict item 8)."""
+    import hashlib
 
+    h = hashlib.sha256()
+    files = sorted(os.path.join(ROOT, "spurfies_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "spurfies_amd", "csrc")))
+    for path in files + [os.path.join(ROOT, "include", "spurfies_hip.h")]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def committed_evidence(kind):
+    """Newest profiles/r*_{kind}.json whose recorded `csrc_sha256` is the running tree's -> (record, file name), else (None, reason)."""
+    want = csrc_digest()
+    pdir = os.path.join(ROOT, "profiles")
+    names = sorted((n for n in os.listdir(pdir) if n.endswith(kind + ".json")), reverse=True) if os.path.isdir(pdir) else []
+    stale = []
+    for name in names:
+        try:
+            rec = json.load(open(os.path.join(pdir, name)))
+        except Exception:
+            continue
+        if rec.get("csrc_sha256") == want:
+            return rec, name
+        stale.append(name)
+    return None, (f"no profiles/*{kind}.json was collected on this tree's kernel sources (csrc sha256 {want[:12]}...; "
+                  f"{len(stale)} older collection(s) ignored as stale)")
+
+
+def workload_name(points, scenes):
+    if scenes > 1:
+        return f"BASELINE.json configs[3] shape: {scenes} scenes optimised concurrently (round-robin, one ray-sharded group), each "
+    if points >= 100000:
+        return "BASELINE.json configs[4] shape (dense cloud, large ray batches) on a synthetic scene: "
+    if points >= 40000:
+        return "BASELINE.json configs[2] shape (garden-like cloud in the +-2 grid) on a synthetic scene: "
+    return "BASELINE.json configs[1] shape (DTU scan24 3-view optimisation, 1024-ray batches) on a synthetic scene: "
+
+
+def measure_train(args, ctx, w):
+    """One workload `w` = {points, spacing, rays_total, scenes, steps, warmup, sustained, light, strong, local} on the ranks of `ctx`
+    -> the contract's result dict.  light: an `extra` record — no MFMA-shape autotune (the main record's choice stands), no A/B, no secondary
+    rooflines, no CPU baseline."""
     from spurfies_amd import ops
     from spurfies_amd.train import MultiSceneTrainer
 
-    ops.geo_clock_enable(True)                    # this process is the one measuring caller of the library's held-clock counters
-    strong = args.global_rays > 0
+    world, rank, device, dist_info = ctx["world"], ctx["rank"], ctx["device"], ctx["dist"]
+    a = argparse.Namespace(**vars(args))
+    a.points, a.spacing, a.scenes = w["points"], w["spacing"], w["scenes"]
+    strong, light = w["strong"], w["light"]
+    steps, warmup, n_sust = w["steps"], w["warmup"], w["sustained"]
+    rays_total = w["rays_total"]
+    if rays_total % world:
+        raise SystemExit(f"{rays_total} rays per step must be a multiple of the {world} ranks")
+    rays_local = rays_total // world
     # strong scaling = ONE batch shared by the ranks: the ranks then draw the sampler's CPU random numbers batch-wide and keep their rows, so the
     # N-GPU run is the same optimisation as the 1-GPU run of that batch (cheap there: the batch does not grow with N).  Weak scaling grows the
     # batch with N; batch-wide draws would cost every rank N times the host-side random numbers (5 ms at 8 x 1024 rays): per-rank streams.
-    args.exact_draws = bool(args.exact_draws or strong)
-    if strong and args.global_rays % world:
-        raise SystemExit(f"--global-rays {args.global_rays} must be a multiple of the {world} ranks")
-    rays_total = args.global_rays if strong else args.rays * world
-    rays_local = rays_total // world
+    a.exact_draws = bool(args.exact_draws or strong)
     torch.manual_seed(0)
-    # small per-rank batches are host-bound in eager mode (the host needs ~2 ms to enqueue the ~50 launches of a step the GPU runs in ~1 ms
+    # small per-rank batches are host-bound in eager mode (the host needs ~2 ms to enqueue the ~40 launches of a step the GPU runs in ~1 ms
     # at 128 rays: profiles/r04_strong_proxy.json): forward + loss + backward replay as hipGraphs there unless --no-graph
-    use_graph = (args.graph or (rays_local <= 256 and not args.no_graph)) and not args.sync and args.scenes == 1
-    scenes = [build_scene_step(args, seed, device, world, use_graph) for seed in range(args.scenes)]
+    use_graph = (args.graph or (rays_local <= 256 and not args.no_graph)) and not args.sync and not w["local"]
+    scenes = [build_scene_step(a, seed, device, world, use_graph) for seed in range(a.scenes)]
     scene, model, step = scenes[0]
-    n_batches = args.warmup + args.steps + max(args.sustained, 0)
-    batches = [make_batches(sc, min(n_batches, 64), rays_total, rank, world, device, seed=12345 + i) for i, (sc, _, _) in enumerate(scenes)]
-    multi = MultiSceneTrainer([st for _, _, st in scenes], n_streams=2, device=device) if args.scenes > 1 else None
+    n_batches = warmup + steps + max(n_sust, 0)
+    batches = [make_batches(sc, min(n_batches, 64), rays_total, rank, world, device, seed=12345 + i, local=w["local"]) for i, (sc, _, _) in enumerate(scenes)]
+    multi = MultiSceneTrainer([st for _, _, st in scenes], n_streams=2, device=device) if a.scenes > 1 else None
 
     def run_step(i):
         if multi is not None:
@@ -464,56 +522,84 @@ def main():
     # host side of the step = a few hundred tiny torch ops: with the intra-op pool enabled a strided slice of the draws costs tens of
     # milliseconds (thread wake-ups); the reference pins one thread as well (train.py:24).  cpu_baseline sets its own thread counts.
     torch.set_num_threads(1)
-    # --exact-draws: the same CPU-generator stream on every rank (each draws batch-wide and keeps its rays' rows); otherwise one stream per rank
     # MFMA shape of the dominant kernel: chosen on THIS box on a warm chip — a few untimed steps first (the clock each shape holds differs
     # between a cold and a loaded chip), then both shapes timed A B B A twice (TrainStep.autotune_geo_engine); all before the W warm-up steps
     tune = None
-    if args.geo_engine == "auto":
+    if args.geo_engine == "auto" and not light:
         for i in range(40):                        # forward + backward passes only: no optimiser step, nothing captured yet in --graph mode
             step._forward_backward(dict(batches[0][i % len(batches[0])][0]), batches[0][i % len(batches[0])][1])
         tune = step.autotune_geo_engine(*batches[0][0])
-    else:
+    elif args.geo_engine != "auto":
         ops.set_geo_mode(args.geo_engine)
     engine = ops.geo_mode()
-    torch.manual_seed(1 if (args.exact_draws or world == 1) else 1 + rank)
-    for i in range(args.warmup):
+    torch.manual_seed(1 if (a.exact_draws or world == 1) else 1 + rank)
+    t_w = time.perf_counter()
+    for i in range(warmup):
         run_step(i)
+    # ---- settle: the chip's clock under a continuous load is lower than in the first tenths of a second (power-averaging window); a 20-step
+    # region right behind a short warm-up read 6.7 % faster than the 200-step region behind it (BENCH_r04).  So the same step runs UNTIMED
+    # for >= args.settle seconds more (extra warm-up, whatever --warmup says) before the contract region; both figures stay in the line.
+    sync()
+    per = max((time.perf_counter() - t_w) / max(warmup, 1), 1e-4)
+    settle = 0
+    if args.settle > 0:
+        t_s = time.perf_counter()
+        while time.perf_counter() - t_s < args.settle:
+            for _ in range(max(1, int(0.05 / per))):
+                run_step(warmup + settle)
+                settle += 1
+            sync()
+    first = warmup + settle
     ops.geo_clock(reset=True)                     # in-kernel clock counters of the dominant kernel: zeroed before the timed region
     if not use_graph:
         ops.profile_start(tags=("geo",))          # HIP events around the dominant kernel's launches of the timed region
     for _, _, st_ in scenes:
         if st_.buckets is not None:
             st_.buckets.timing = []               # an event pair around every finish(): the exposed part of the gradient exchange
+    # Python's cyclic collector is kept out of the timed regions (a generation-2 pass over this process's ~10^6 objects takes ~0.1 s: one of
+    # them inside a 40-step region doubled its reading); collected once here, re-enabled at the end of the measurement
+    import gc
+
+    gc_was = gc.isenabled()
+    if args.gc == "off":
+        gc.collect()
+        gc.disable()
     sync()
+    host_max = 0.0
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
+    for i in range(first, first + steps):
+        th = time.perf_counter()
         losses, out = run_step(i)
+        host_max = max(host_max, time.perf_counter() - th)
     sync()
     dt = time.perf_counter() - t0
+    dinfo = None
     if dist_info is not None:
+        dinfo = dict(dist_info)
         exposed = [ms for _, _, st_ in scenes if st_.buckets is not None for ms in st_.buckets.exposed_ms()]
         for _, _, st_ in scenes:
             if st_.buckets is not None:
                 st_.buckets.timing = None
         nbytes = 4 * step.flat.buffer.numel()
-        dist_info.update({
-            "allreduce_bytes_per_step": (nbytes + 16) * args.scenes,
+        dinfo.update({
+            "allreduce_bytes_per_step": (nbytes + 16) * a.scenes,
             "allreduce_what": f"one flat fp32 gradient buffer of {nbytes} B per scene step (" +
                               ("ONE dense all-reduce behind the two graph replays" if use_graph else "4 buckets, reduced asynchronously as the backward completes them") +
                               ") + 16 B of loss normalisers between forward and loss",
             "buckets_bytes": step.buckets.bytes_per_step() if step.buckets is not None else None,
             "bucket_order_last_step": list(step.buckets.log) if (step.buckets is not None and not use_graph) else None,
-            "finish_ms_per_step": (sum(exposed) / args.steps) if exposed else None,
+            "finish_ms_per_step": (sum(exposed) / steps) if exposed else None,
             "finish_what": "HIP events on rank 0's compute stream around BucketedAllReduce.finish() (launch of the last bucket + wait for all): "
                            "the part of the exchange not hidden behind the backward"})
     loss_last = float(losses["loss"].item())
     clk = ops.geo_clock(reset=True).get((engine, True))       # the clock the chip held under the dominant kernel DURING the timed region
-    if use_graph:
+    if use_graph and a.scenes == 1:
         # events cannot be placed inside a hipGraph replay: time the dominant kernel over eager forward+backward passes of
         # the SAME batches right after the timed region (same kernels, same inputs; no optimiser step)
         ops.profile_start(tags=("geo",))
-        for i in range(args.warmup, args.warmup + args.steps):
-            step._forward_backward(dict(batches[0][i][0]), batches[0][i][1])
+        nb = len(batches[0])
+        for i in range(first, first + steps):
+            step._forward_backward(dict(batches[0][i % nb][0]), batches[0][i % nb][1])
         sync()
     prof = ops.profile_stop()
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -521,44 +607,49 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     sustained = None
-    if args.sustained > 0:        # clocks settle under a continuous load: the same step over a >= 1 s region, reported beside the contract region
+    if n_sust > 0:        # the same step over a >= 1 s region, reported beside the contract region
         sync()
         t1 = time.perf_counter()
-        for i in range(args.warmup + args.steps, args.warmup + args.steps + args.sustained):
+        for i in range(first + steps, first + steps + n_sust):
             run_step(i)
         sync()
         ts = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
         if world > 1:
             torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
-        sustained = float(ts.item()) / args.sustained * 1e3
+        sustained = float(ts.item()) / n_sust * 1e3
+    if gc_was:
+        gc.enable()
 
-    if not use_graph and args.scenes == 1:          # the other regimes' kernels, timed over separate steps (outside both timed regions)
+    if not use_graph and a.scenes == 1 and not light:          # the other regimes' kernels, timed over separate steps (outside both timed regions)
         ops.profile_start(tags=("color_fwd", "color_bwd", "knn", "render_fwd", "render_bwd"))
-        for i in range(args.warmup, args.warmup + min(args.steps, 10)):
+        for i in range(first, first + min(steps, 10)):
             run_step(i)
         prof += ops.profile_stop()
 
     # ---- roofline: dominant kernel = geo_pairs_x3_kernel<true> of the main pass (the largest with-Jacobian launch per step) ----
     geo = [p for p in prof if p["tag"] == "geo"]
-    main = [p for p in geo if p["with_grad"] and p["rows"] >= rays_local * 2]
+    main_ = [p for p in geo if p["with_grad"] and p["rows"] >= rays_local * 2]
     roof = None
-    # HBM bytes per launch need a rocprofv3 --pmc pass around the process: they cannot be collected from inside this run.  The figure
-    # below is the committed collection of THIS code (tools/pmc_traffic.py) on the box it was profiled on — labelled as such.
+    # HBM bytes per launch need a rocprofv3 --pmc pass around the process: they cannot be collected from inside this run.  The figure below
+    # is a committed collection (tools/pmc_traffic.py) — quoted ONLY when it was collected on this tree's kernel sources (csrc digest), on
+    # the same workload; otherwise null, with the reason.
     traffic, traffic_src = None, None
-    for name in ("r04_dense_pmc_traffic.json", "r04_pmc_traffic.json", "r03_z_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
-        pmc = os.path.join(ROOT, "profiles", name)
-        if traffic is None and os.path.exists(pmc):
-            rec = json.load(open(pmc))
-            if rec["config"].get("points") == args.points and rec["config"].get("rays") == rays_local and rec["config"].get("prior", "kaiming") == args.prior:
-                want = "geo_pairs_x3_kernel<true>" if ops.geo_mode() == "split" else "geo_pairs_x3w_kernel<true>"
-                hit = [v for k, v in rec["kernels"].items() if want in k] or [v for k, v in rec["kernels"].items() if "geo_pairs_x3" in k and "<true>" in k]
-                if hit:
-                    traffic = hit[0]["hbm_bytes_max_corrected"]
-                    traffic_src = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 corrections) of the same workload, "
-                                   "collected on ANOTHER box and committed — not measured in this run")
-    if main:
-        ms = sum(p["ms"] for p in main)
-        pairs = sum(p["pairs"] for p in main)
+    if not light:
+        rec, name = committed_evidence("pmc_traffic")
+        if rec is None:
+            traffic_src = name
+        elif not (rec["config"].get("points") == a.points and rec["config"].get("rays") == rays_local and rec["config"].get("prior", "kaiming") == a.prior):
+            traffic_src = f"profiles/{name} is of this code but of another workload ({rec['config']}): not quoted"
+        else:
+            want = "geo_pairs_x3_kernel<true>" if ops.geo_mode() == "split" else "geo_pairs_x3w_kernel<true>"
+            hit = [v for k, v in rec["kernels"].items() if want in k] or [v for k, v in rec["kernels"].items() if "geo_pairs_x3" in k and "<true>" in k]
+            if hit:
+                traffic = hit[0]["hbm_bytes_max_corrected"]
+                traffic_src = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 corrections) of the same workload on THIS "
+                               "tree's kernel sources (csrc sha256 matches), collected on another box and committed — not measured in this run")
+    if main_:
+        ms = sum(p["ms"] for p in main_)
+        pairs = sum(p["pairs"] for p in main_)
         ach = pairs * (F_FWD + F_JAC) / (ms * 1e-3) / 1e12
         kname = "geo_pairs_x3_kernel<true>" if engine == "split" else "geo_pairs_x3w_kernel<true>"
         shape = "v_mfma_f32_16x16x32_bf16" if engine == "split" else "v_mfma_f32_32x32x16_bf16"
@@ -566,43 +657,98 @@ def main():
                 "peak_basis": f"algorithmic fp32 FLOP/s; each fp32 product = 6 exact bf16 piece products on the bf16 matrix pipe (this run: {shape}), so the "
                               "ceiling is the dense bf16 MFMA peak (2516.6 TFLOP/s) / 6; for scale, the fp32-MFMA peak is 157.3 TFLOP/s",
                 "achieved_over_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
-                "sustainable": sustainable_ceiling(ach),
+                "sustainable": None if light else sustainable_ceiling(ach),
                 "held_clock": held_clock(ach, clk),
-                "engine": {"selected": engine, "mfma": shape, "how": ("timed both shapes on this box after 40 untimed passes, before the warm-up steps (main-pass launch; the shape alternates every pass, A B B A x 10)" if tune else "--geo-engine"),
+                "engine": {"selected": engine, "mfma": shape, "how": ("timed both shapes on this box after 40 untimed passes, before the warm-up steps (main-pass launch; the shape alternates every pass, A B B A x 10)" if tune else ("the main record's choice" if light else "--geo-engine")),
                            "autotune_ms": tune},
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": kname + " (+ geo_point_reduce_kernel, < 1 % of the launch)",
                 "timing": ("HIP events over eager passes of the timed batches, right after the timed region (events cannot sit inside a "
-                           "hipGraph replay)") if use_graph else "HIP events over the timed region", "launches": len(main), "avg_ms": ms / len(main),
-                "pairs_per_launch": pairs / len(main), "flop_per_pair": F_FWD + F_JAC}
-        roof["secondary"] = secondary_rooflines(prof, rays_local)
-        if args.ab_reps > 0 and args.scenes == 1:
-            roof["ab"] = engine_ab(step, batches[0], args.warmup, args.ab_reps, rays_local, sync)
-    spr = SAMPLES_PER_RAY * rays_total * args.scenes
+                           "hipGraph replay)") if use_graph else "HIP events over the timed region", "launches": len(main_), "avg_ms": ms / len(main_),
+                "pairs_per_launch": pairs / len(main_), "flop_per_pair": F_FWD + F_JAC}
+        if not light:
+            roof["secondary"] = secondary_rooflines(prof, rays_local)
+            if args.ab_reps > 0 and a.scenes == 1:
+                roof["ab"] = engine_ab(step, batches[0], first, args.ab_reps, rays_local, sync)
+    spr = SAMPLES_PER_RAY * rays_total * a.scenes
     counts = model.stats.get("counts")
+    if use_graph:
+        launch = ("hipGraph replay (fwd+loss+bwd, independent passes on forked branches) + 2 eager launches (clip + non-finite guard + Adam)" if world == 1 else
+                  "two hipGraph replays ([forward + counts] | 16-byte count all-reduce | [loss + backward]), dense gradient all-reduce, 2 eager launches (clip + guard + Adam)")
+    else:
+        launch = "eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (one host-to-device copy of the sampler's CPU random draws per step)"
     res = {
-        "metric": "ray-samples/sec (kNN+SDF+render, train step)", "value": spr * args.steps / dt,
-        "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "metric": "ray-samples/sec (kNN+SDF+render, train step)", "value": spr * steps / dt,
+        "unit": "ray-samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (f"BASELINE.json configs[3] shape: {args.scenes} scenes optimised concurrently (round-robin, one ray-sharded group), each " if args.scenes > 1 else
-                                ("BASELINE.json configs[4] shape (dense cloud, large ray batches) on a synthetic scene: " if args.points >= 100000 else
-                                 "BASELINE.json configs[2] shape (garden-like cloud in the +-2 grid) on a synthetic scene: " if args.points >= 40000 else
-                                 "BASELINE.json configs[1] shape (DTU scan24 3-view optimisation, 1024-ray batches) on a synthetic scene: ")) +
-                               f"{args.points} neural points, {rays_total} rays/step over {world} GPU(s) x (128 sampler + 98 main) samples, fast=1 optimisation step "
-                               f"(fwd+bwd+clip+Adam); prior = {args.prior}",
-                   "rays_per_gpu": rays_local, "rays_per_step": rays_total, "scenes": args.scenes, "neural_points": args.points, "k": 8, "max_shading_pts": 80,
-                   "prior": args.prior, "parallelism": f"ray-sharded dp{world}",
+        "config": {"workload": workload_name(a.points, a.scenes) +
+                               f"{a.points} neural points, {rays_total} rays/step over {world} GPU(s) x (128 sampler + 98 main) samples, fast=1 optimisation step "
+                               f"(fwd+bwd+clip+Adam)" + (" incl. find_surface_points + the multi-view feature-consistency loss on synthetic local_data (the DTU recipe's local_weight 0.5)" if w["local"] else "") +
+                               f"; prior = {a.prior}",
+                   "rays_per_gpu": rays_local, "rays_per_step": rays_total, "scenes": a.scenes, "neural_points": a.points, "k": 8, "max_shading_pts": 80,
+                   "prior": a.prior, "parallelism": f"ray-sharded dp{world}", "local_data": bool(w["local"]),
                    "valid_points_last_step": model.stats.get("valid_points", int(counts[0].item()) if counts is not None else None),
                    "pairs_last_step": model.stats.get("pairs", int(counts[1].item()) if counts is not None else None),
                    "host_syncs_per_step": 1 if args.sync else 0,
-                   "sampler_draws": "CPU generator, reference call order" + ("" if world == 1 else ("; batch-wide per rank, own rows kept (--exact-draws)" if args.exact_draws
+                   "settle_steps_untimed": settle, "settle_seconds": args.settle,
+                   "sampler_draws": "CPU generator, reference call order" + ("" if world == 1 else ("; batch-wide per rank, own rows kept (--exact-draws)" if a.exact_draws
                                                                                                    else "; per-rank streams, own rays only")),
                    "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product from three bf16 pieces per operand (6 exact bf16 piece products, fp32 accumulate: fp32-class, <= 2 ulp per product)",
-                   "launch": ("hipGraph replay (fwd+loss+bwd) + 3 eager launches (clip + non-finite guard + Adam)" if world == 1 else
-                              "two hipGraph replays ([forward + counts] | 16-byte count all-reduce | [loss + backward]), dense gradient all-reduce, 3 eager launches (clip + guard + Adam)") if use_graph else ("eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (41 library kernels per step + one host-to-device copy of the sampler's CPU random draws)")},
-        "roofline": roof, "dist": dist_info,
-        "sustained_ms_per_step": sustained, "sustained_steps": args.sustained if sustained is not None else 0,
-        "loss_last": loss_last,
+                   "launch": launch},
+        "roofline": roof, "dist": dinfo,
+        "sustained_ms_per_step": sustained, "sustained_steps": n_sust if sustained is not None else 0,
+        "loss_last": loss_last, "host_enqueue_ms_max": host_max * 1e3,
     }
+    del scenes, batches, multi, step, model
+    torch.cuda.empty_cache()
+    return res, scene
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # the driver's command shape: `python bench.py --gpus N` — start the ranks ourselves
+        raise SystemExit(self_launch(args))
+    if args.mode == "eval":
+        return main_eval(args)
+    world, rank, device, dist_info = init_ranks(args)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+
+    from spurfies_amd import ops
+
+    ops.geo_clock_enable(True)                    # this process is the one measuring caller of the library's held-clock counters
+    ctx = {"world": world, "rank": rank, "device": device, "dist": dist_info}
+    # ---- what N GPUs measure: by default the SAME workload as N = 1 — BASELINE.json configs[1], one 1024-ray batch per step, rank r renders
+    # rays r::N of it (strong scaling) — so that the driver's N = 1, 2, 4, 8 lines are one scaling curve of a
+    # BASELINE config (round-4 verdict item 4).  --weak: --rays rays PER GPU (the batch grows with N).
+    strong = not args.weak
+    rays_total = (args.global_rays or args.rays) if strong else args.rays * world
+    main_w = {"points": args.points, "spacing": args.spacing, "scenes": args.scenes, "rays_total": rays_total, "steps": args.steps, "warmup": args.warmup,
+              "sustained": args.sustained, "light": False, "strong": strong, "local": False}
+    res, scene = measure_train(args, ctx, main_w)
+    extras = []
+    want_extras = args.extras == "on" or (args.extras == "auto" and world > 1)
+    if want_extras and args.scenes == 1:
+        es, ew = max(5, args.steps // 2), 2
+        # BASELINE.json configs[4]: the dense cloud with 4096-ray batches, strong-scaled over the same ranks
+        extras.append({"points": args.c4_points, "spacing": 0.0125, "scenes": 1, "rays_total": args.c4_rays, "steps": es, "warmup": ew, "sustained": 0, "light": True,
+                       "strong": True, "local": False, "record": "BASELINE.json configs[4], strong-scaled over the same ranks"})
+        # the weak-scaling figure of the main workload (1024 rays PER GPU)
+        extras.append({"points": args.points, "spacing": args.spacing, "scenes": 1, "rays_total": args.rays * world, "steps": es, "warmup": ew, "sustained": 0,
+                       "light": True, "strong": False, "local": False, "record": "weak scaling of the main workload (--rays rays PER GPU; no BASELINE config has such batches)"})
+    if args.local and args.scenes == 1:
+        # the DTU recipe's real step (pointneus_disent.py:727-763, feat_utils.py:377-451; config/ours.yaml local_weight 0.5): find_surface_points + the
+        # feature-consistency loss on synthetic per-view feature maps, every step
+        extras.append({"points": args.points, "spacing": args.spacing, "scenes": 1, "rays_total": rays_total, "steps": args.steps, "warmup": args.warmup,
+                       "sustained": 0, "light": True, "strong": strong, "local": True,
+                       "record": "the main workload with the DTU recipe's feature-consistency loss (local_weight 0.5) on every step"})
+    res["extra"] = []
+    for w in extras:
+        r, _ = measure_train(args, ctx, w)
+        keep = {"record": w["record"], **{k: r[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "dist", "loss_last")}}
+        keep["roofline"] = None if r["roofline"] is None else {k: r["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_ms", "pairs_per_launch", "kernel")}
+        res["extra"].append(keep)
+        if w["local"]:
+            res["ms_per_step_with_local"] = r["ms_per_step"]
     if rank == 0:
         res["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(scene, args.cpu_rays)     # N = 1 only
         print(json.dumps(res), flush=True)
@@ -613,23 +759,25 @@ def main():
 
 def sustainable_ceiling(achieved_tflops):
     """`frac` is priced against the 2.4 GHz data-sheet peak.  What the chip SUSTAINS on this instruction mix was measured with socket power beside
-    it (tools/power_probe.py -> profiles/r04_power.json, round 4; another box, labelled): every dense kernel of the step runs at 1.30 - 1.36 kW of
-    the 1.40 kW cap with the clock pulled down to ~2.0 GHz (power-limited); the library's own GEMM loop run alone peaks at 75 % matrix-pipe duty /
-    2.34 GHz / 0.99 kW with the lightest epilogue and loses clock faster than it gains duty when made denser (90 % duty: 1.68 GHz at 1.29 kW)."""
-    path = os.path.join(ROOT, "profiles", "r04_power.json")
-    if not os.path.exists(path):
-        return None
-    loads = json.load(open(path)).get("loads", {})
+    it (tools/power_probe.py -> profiles/r*_power.json; another box, labelled): every dense kernel of the step runs near the 1.40 kW cap with
+    the clock pulled down to ~2.0 GHz (power-limited); the library's own GEMM loop run alone peaks at ~75 % matrix-pipe duty / full clock with
+    the lightest epilogue and loses clock faster than it gains duty when made denser.  Quoted only from a collection made on THIS tree's kernel
+    sources (csrc digest); otherwise {'peak': None, 'why': ...}."""
+    rec, name = committed_evidence("power")
+    if rec is None:
+        return {"peak": None, "frac": None, "why": name}
+    loads = rec.get("loads", {})
     best = max((v.get("tflops_fp32_equiv", 0.0) for k, v in loads.items() if k.startswith("x3_loop_")), default=0.0)
     if best <= 0.0:
-        return None
+        return {"peak": None, "frac": None, "why": f"profiles/{name} holds no x3_loop_* load"}
     geo = loads.get("geo_split_w", {})
     return {"peak": best, "unit": "TFLOP/s", "frac": achieved_tflops / best,
             "what": "highest algorithmic fp32 rate the library's bf16-piece GEMM loop sustained when run ALONE (tools/micro/x3_loop_rate.hip, three epilogue "
                     "variants), with socket power sampled beside it",
-            "power_cap_w": json.load(open(path)).get("power_cap_w"), "geo_kernel_power_w": geo.get("power_w_mean"), "geo_kernel_ghz": geo.get("ghz_in_kernel"),
+            "power_cap_w": rec.get("power_cap_w"), "geo_kernel_power_w": geo.get("power_w_mean"), "geo_kernel_ghz": geo.get("ghz_in_kernel"),
             "loop_variants": {k: {kk: v.get(kk) for kk in ("what", "tflops_fp32_equiv", "mfma_duty", "ghz", "power_w_mean")} for k, v in loads.items() if k.startswith("x3_loop_")},
-            "source": "profiles/r04_power.json — collected on ANOTHER box (hwmon power1_input of the HIP device's PCI card, 100 Hz), committed; not measured in this run"}
+            "source": f"profiles/{name} — collected on ANOTHER box (hwmon power1_input of the HIP device's PCI card, 100 Hz) on this tree's kernel sources "
+                      "(csrc sha256 matches), committed; not measured in this run"}
 
 
 def held_clock(achieved_tflops, clk):

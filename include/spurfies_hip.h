@@ -32,7 +32,7 @@ extern "C" {
 #define SPF_ENOMEM (-12)
 #define SPF_EHIP (-5)
 
-#define SPF_ABI_VERSION 4
+#define SPF_ABI_VERSION 5
 #define SPF_KMAX 8          /* neighbours per point (config/vol/dtu_pn.yaml:27, k: 8) */
 #define SPF_GEO_DIM 32      /* geometry latent width = feature_vector_size/2 (pointneus_disent.py:172) */
 #define SPF_COL_DIM 64      /* colour latent width  = feature_vector_size   (pointneus_disent.py:161) */
@@ -135,8 +135,11 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
  * behind this pass do no work — how a sampler iteration the loop did not reach is skipped without a host round trip (spf_sampler_iter).
  * sync (DEVICE uint64, may be NULL; ABI 4): spf_compact_sync_words(R*SR) words that are ALL ZERO on entry (e.g. hipMemset once) and are left
  * all zero — the pass then runs as ONE launch in which 512-slot chunks publish their totals to each other through these words
- * (relaxed agent-scope atomics, value and flag in one word; the last chunk to have read clears them).  One buffer per stream that may run
- * this call concurrently; passes of more than 2048 chunks (1 M slots) and sync == NULL take the two-launch form. */
+ * (relaxed agent-scope atomics, value and flag in one word; the last chunk to have read clears them; the last chunk itself publishes
+ * nothing, so every word that was written has provably been read before the clear).  The buffer must not be used by two launches that can
+ * run at the same time (the launch spins on words its own blocks publish): one buffer per OWNER of a pass — a stream is not an owner
+ * once launches are captured into graphs that replay anywhere.  Passes of more than 2048 chunks (1 M slots) and sync == NULL take the
+ * two-launch form. */
 int64_t spf_compact_sync_words(int64_t n_slots);
 int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot,
                       int32_t* slot_point, int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch,
@@ -351,6 +354,16 @@ int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float*
                        float* rgb, float* depth, float* dist, float* acc, const float* cam_loc, const float* ray_dirs,
                        float* pts_rendered, void* stream);
 
+/* ABI 5 — the colour composite on its own.  spf_render_forward with colors == rgb == NULL is the WEIGHTS-ONLY form: everything that depends
+ * on the SDF alone (weights, depth, dist, acc, pts_rendered — and with them the whole pseudo-point pass, pointneus_disent.py:765-780) can then
+ * be issued right behind the geometry kernel, beside the colour MLPs instead of behind them (a forked hipGraph branch of the optimisation
+ * step); spf_render_rgb then forms rgb [R,3] = sum_j weights[r,j] colors[r,j,:] with the fused kernel's lane assignment and reduction
+ * tree (same bits).  spf_render_rgb_backward: g_colors [R,SR,3] = weights g_rgb and g_weights [R,SR] = colors . g_rgb — the latter is what
+ * spf_render_backward takes as g_weights when it is called with g_rgb == colors == g_colors == NULL (the same sum as the fused form). */
+int spf_render_rgb(const float* weights, const float* colors, int32_t R, int32_t SR, float* rgb, void* stream);
+int spf_render_rgb_backward(const float* weights, const float* colors, const float* g_rgb, int32_t R, int32_t SR, float* g_colors,
+                            float* g_weights, void* stream);
+
 /* Gradients of a scalar loss given g_weights [R,SR] (may be NULL), g_rgb [R,3], g_depth [R] (may be
  * NULL), g_dist [R] (may be NULL): g_sdf [R,SR], g_colors [R,SR,3], and g_beta[0] += dL/d beta — or, when the raw
  * LaplaceDensity parameter is passed in beta_param (beta = |beta_param| + beta_min, spurfies/model/density.py:28-30),
@@ -398,15 +411,17 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
               float* dW, int32_t ldw, float* dbias, float* workspace, int32_t layout, int32_t arith, int32_t col_rot,
               int32_t col_mod, void* stream);
 
-/* Up to three weight-gradient GEMMs over the SAME rows (n_rows / max_rows) in one pair of launches, side by side on the chip (each
- * problem gets a share of the workgroups proportional to its work): dW_q += G_q^T A_q, dbias_q += column sums of G_q (may be NULL).
+/* Up to SIX weight-gradient GEMMs (three before ABI 5) in one pair of launches, side by side on the chip (each problem gets a share of the
+ * workgroups proportional to its work): dW_q += G_q^T A_q, dbias_q += column sums of G_q (may be NULL).  The problems share the call's row
+ * count (n_rows / max_rows) unless a problem names its own (ABI 5: spf_wgrad_problem.max_rows > 0, with its n_rows): the head stage's GEMMs
+ * (K = valid points) then ride in the colour trunk's launch (K = pairs) — one pipeline ramp, tail and slab reduce per step.
  * Launched one after the other each GEMM pays the pipeline ramp, a tail on a mostly idle chip and a dispatch gap — the head stage's three
  * (K = valid points) and, since ABI 4, the colour trunk's three (K = pairs).  Per problem (C, layout) must be one of
  *   (256, 0)                                         both operands row-major                      (C == 0 means 256)
  *   (256, SPF_WGRAD_G_TILES64 | SPF_WGRAD_A_TILES)   what spf_color_backward / spf_color_forward write for layers 2 and 4
  *   (36..128 step 4, SPF_WGRAD_G_TILES64)            the trunk's first layer (C = 104), A row-major with leading dimension lda
  * with spf_wgrad's col_rot / col_mod per problem; anything else: spf_wgrad.  `problems` is a HOST array; workspace:
- * n_problems * spf_wgrad_workspace_floats(256) floats; tiled operands need max_rows % 64 == 0. */
+ * n_problems * spf_wgrad_workspace_floats(256) floats; tiled operands need (their) max_rows % 64 == 0. */
 struct spf_wgrad_problem {
     const float* G;
     const float* A;
@@ -418,6 +433,8 @@ struct spf_wgrad_problem {
     int32_t layout;
     int32_t col_rot;
     int32_t col_mod;
+    const int32_t* n_rows;   /* ABI 5: this problem's own row count (device, may be NULL = max_rows), used when max_rows > 0 */
+    int32_t max_rows;        /* ABI 5: 0 = the call's n_rows / max_rows */
 };
 int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_problems, const int32_t* n_rows, int32_t max_rows,
                       float* workspace, int32_t arith, int32_t flags, void* stream);

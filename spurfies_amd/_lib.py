@@ -36,7 +36,7 @@ class LossWeights(C.Structure):
 class WgradProblem(C.Structure):
     """spf_wgrad_problem"""
     _fields_ = [("G", C.c_void_p), ("A", C.c_void_p), ("lda", C.c_int32), ("dW", C.c_void_p), ("ldw", C.c_int32), ("dbias", C.c_void_p),
-                ("C", C.c_int32), ("layout", C.c_int32), ("col_rot", C.c_int32), ("col_mod", C.c_int32)]
+                ("C", C.c_int32), ("layout", C.c_int32), ("col_rot", C.c_int32), ("col_mod", C.c_int32), ("n_rows", C.c_void_p), ("max_rows", C.c_int32)]
 
 
 SIGNATURES = {
@@ -70,6 +70,8 @@ SIGNATURES = {
     "spf_sampler_finish": (C.c_int, [_P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _I, _P, _P, _P, _I, _P]),
     "spf_filter_points": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "spf_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_render_rgb": (C.c_int, [_P, _P, _I, _I, _P, _P]),
+    "spf_render_rgb_backward": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "spf_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_wgrad_workspace_floats": (C.c_int64, [_I]),
     "spf_wgrad": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),

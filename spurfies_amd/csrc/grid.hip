@@ -663,7 +663,11 @@ __global__ void __launch_bounds__(256) cp_fused_kernel(const uint8_t* __restrict
     int tp, tq;
     const int lp = block_excl_scan_256(np, tp, wsum);
     const int lq = block_excl_scan_256(nq, tq, wsum2);
-    if (threadIdx.x == 0)
+    // The LAST block publishes nothing: nobody reads its word, so nothing would prove that its store has landed before some other block
+    // (the last to finish its look-back) clears the buffer — a publish overtaken by the clear would leave a stale PUBLISHED word for the next
+    // launch.  Every other block's word has been READ by block gridDim.x - 1 before that block counts itself in `sync[0]`, and the clear only
+    // happens after all gridDim.x blocks have counted themselves: those stores have provably landed.
+    if (threadIdx.x == 0 && blockIdx.x != gridDim.x - 1)
         __hip_atomic_store(&sync[1 + blockIdx.x], CPF_PUBLISHED | ((unsigned long long)tp << 32) | (unsigned long long)tq, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     int bp = 0, bq = 0;

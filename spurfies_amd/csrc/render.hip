@@ -100,20 +100,26 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const float* __rest
             weights[g] = w;
             W += w;
             N += w * zz;
-            c0 += w * colors[g * 3];
-            c1 += w * colors[g * 3 + 1];
-            c2 += w * colors[g * 3 + 2];
+            if (colors) {
+                c0 += w * colors[g * 3];
+                c1 += w * colors[g * 3 + 1];
+                c2 += w * colors[g * 3 + 2];
+            }
         }
     }
     W = wave_sum(W);
     N = wave_sum(N);
-    c0 = wave_sum(c0);
-    c1 = wave_sum(c1);
-    c2 = wave_sum(c2);
+    if (colors) {               // colors == NULL: the weights-only form (spf_render_rgb composites later, behind the colour MLPs)
+        c0 = wave_sum(c0);
+        c1 = wave_sum(c1);
+        c2 = wave_sum(c2);
+    }
     if (lane == 0) {
-        rgb[3 * r] = c0;
-        rgb[3 * r + 1] = c1;
-        rgb[3 * r + 2] = c2;
+        if (colors) {
+            rgb[3 * r] = c0;
+            rgb[3 * r + 1] = c1;
+            rgb[3 * r + 2] = c2;
+        }
         depth[r] = N / (W + 1e-8f);
         const float dm = N / (W + 1e-10f);
         dist[r] = dm;
@@ -123,6 +129,49 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const float* __rest
             for (int c = 0; c < 3; ++c) pts_rendered[3 * r + c] = cam_loc[3 * r + c] + ray_dirs[3 * r + c] * dm;
         }
     }
+}
+
+// ---- the colour composite on its own: rgb = sum_j w_j c_j (same lane assignment and reduction tree as render_forward_kernel: the two
+//      forms give the same bits), and its backward g_c = w g_rgb, g_w = c . g_rgb.  They exist so that everything that depends on the
+//      WEIGHTS only (depth, dist_map, the rendered points of the pseudo-point loss and the whole pass behind them) need not wait for the
+//      colour MLPs, and so that the colour branch of the backward need not wait for the pseudo-point pass's gradient.
+__global__ void __launch_bounds__(256) render_rgb_kernel(const float* __restrict__ weights, const float* __restrict__ colors, int R, int SR,
+                                                         float* __restrict__ rgb) {
+    const int lane = threadIdx.x & 63;
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= R) return;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int base = 0; base < SR; base += 64) {
+        const int s = base + lane;
+        if (s < SR) {
+            const size_t g = (size_t)r * SR + s;
+            const float w = weights[g];
+            c0 += w * colors[g * 3];
+            c1 += w * colors[g * 3 + 1];
+            c2 += w * colors[g * 3 + 2];
+        }
+    }
+    c0 = wave_sum(c0);
+    c1 = wave_sum(c1);
+    c2 = wave_sum(c2);
+    if (lane == 0) {
+        rgb[3 * r] = c0;
+        rgb[3 * r + 1] = c1;
+        rgb[3 * r + 2] = c2;
+    }
+}
+
+__global__ void render_rgb_backward_kernel(const float* __restrict__ weights, const float* __restrict__ colors, const float* __restrict__ g_rgb,
+                                           int R, int SR, float* __restrict__ g_colors, float* __restrict__ g_weights) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (size_t)R * SR) return;
+    const int r = (int)(g / SR);
+    const float gr0 = g_rgb[3 * r], gr1 = g_rgb[3 * r + 1], gr2 = g_rgb[3 * r + 2];
+    const float w = weights[g];
+    g_weights[g] = gr0 * colors[g * 3] + gr1 * colors[g * 3 + 1] + gr2 * colors[g * 3 + 2];      // the fused kernel's `cdot`
+    g_colors[g * 3] = w * gr0;
+    g_colors[g * 3 + 1] = w * gr1;
+    g_colors[g * 3 + 2] = w * gr2;
 }
 
 // ---- backward ------------------------------------------------------------------------------------
@@ -143,7 +192,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= R) return;
     const float beta = *beta_p;
-    const float gr0 = g_rgb[3 * r], gr1 = g_rgb[3 * r + 1], gr2 = g_rgb[3 * r + 2];
+    // g_rgb == NULL: the colour composite ran on its own (spf_render_rgb) and its backward already put c . g_rgb into g_weights
+    const float gr0 = g_rgb ? g_rgb[3 * r] : 0.f, gr1 = g_rgb ? g_rgb[3 * r + 1] : 0.f, gr2 = g_rgb ? g_rgb[3 * r + 2] : 0.f;
     const float gd = g_depth ? g_depth[r] : 0.f;
     float gs = g_dist ? g_dist[r] : 0.f;
     if (g_pts)                    // pts_rendered = o + d * dist: d L / d dist += g_pts . d
@@ -175,12 +225,14 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
         const int s = ch * 64 + lane;
         if (ch < nch && s < SR) {
             const size_t g = (size_t)r * SR + s;
-            const float cdot = gr0 * colors[g * 3] + gr1 * colors[g * 3 + 1] + gr2 * colors[g * 3 + 2];
+            const float cdot = g_rgb ? gr0 * colors[g * 3] + gr1 * colors[g * 3 + 1] + gr2 * colors[g * 3 + 2] : 0.f;
             gw_[ch] = ((g_weights ? g_weights[g] : 0.f) + ga) + cdot + gd * (z_[ch] * i8 - N * i8 * i8) + gs * (z_[ch] * i10 - N * i10 * i10);
             P_ += gw_[ch] * w_[ch];
-            g_colors[g * 3] = w_[ch] * gr0;
-            g_colors[g * 3 + 1] = w_[ch] * gr1;
-            g_colors[g * 3 + 2] = w_[ch] * gr2;
+            if (g_colors) {
+                g_colors[g * 3] = w_[ch] * gr0;
+                g_colors[g * 3 + 1] = w_[ch] * gr1;
+                g_colors[g * 3 + 2] = w_[ch] * gr2;
+            }
         }
     }
     P_ = wave_sum(P_);
@@ -247,13 +299,33 @@ int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float*
                        const float* cam_loc, const float* ray_dirs, float* pts_rendered, void* stream) {
     if (R < 0 || SR < 1 || SR > 64 * MAX_CH) return spf::fail(SPF_EINVAL, "spf_render_forward: need 1 <= SR <= %d", 64 * MAX_CH);
     if (R == 0) return SPF_OK;
-    if (!sdf || !slot_valid || !z || !deltas || !colors || !beta || !weights || !rgb || !depth || !dist || !acc)
+    if (!sdf || !slot_valid || !z || !deltas || !beta || !weights || !depth || !dist || !acc)
         return spf::fail(SPF_EINVAL, "spf_render_forward: null pointer");
+    if ((colors == nullptr) != (rgb == nullptr)) return spf::fail(SPF_EINVAL, "spf_render_forward: colors and rgb are given (or left out) together");
     if (pts_rendered && (!cam_loc || !ray_dirs)) return spf::fail(SPF_EINVAL, "spf_render_forward: pts_rendered needs cam_loc and ray_dirs");
     render_forward_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, (hipStream_t)stream>>>(sdf, slot_valid, z, deltas, colors, beta, R,
                                                                                                  SR, weights, rgb, depth, dist, acc, cam_loc,
                                                                                                  ray_dirs, pts_rendered);
     SPF_LAUNCH_CHECK("render_forward_kernel");
+    return SPF_OK;
+}
+
+int spf_render_rgb(const float* weights, const float* colors, int32_t R, int32_t SR, float* rgb, void* stream) {
+    if (R < 0 || SR < 1 || SR > 64 * MAX_CH) return spf::fail(SPF_EINVAL, "spf_render_rgb: need 1 <= SR <= %d", 64 * MAX_CH);
+    if (R == 0) return SPF_OK;
+    if (!weights || !colors || !rgb) return spf::fail(SPF_EINVAL, "spf_render_rgb: null pointer");
+    render_rgb_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, (hipStream_t)stream>>>(weights, colors, R, SR, rgb);
+    SPF_LAUNCH_CHECK("render_rgb_kernel");
+    return SPF_OK;
+}
+
+int spf_render_rgb_backward(const float* weights, const float* colors, const float* g_rgb, int32_t R, int32_t SR, float* g_colors,
+                            float* g_weights, void* stream) {
+    if (R < 0 || SR < 1) return spf::fail(SPF_EINVAL, "spf_render_rgb_backward: bad sizes");
+    if (R == 0) return SPF_OK;
+    if (!weights || !colors || !g_rgb || !g_colors || !g_weights) return spf::fail(SPF_EINVAL, "spf_render_rgb_backward: null pointer");
+    render_rgb_backward_kernel<<<spf::div_up((long long)R * SR, 256), 256, 0, (hipStream_t)stream>>>(weights, colors, g_rgb, R, SR, g_colors, g_weights);
+    SPF_LAUNCH_CHECK("render_rgb_backward_kernel");
     return SPF_OK;
 }
 
@@ -263,8 +335,10 @@ int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float
                         const float* g_acc, const float* g_pts_rendered, const float* ray_dirs, int64_t* g_beta_fixed, void* stream) {
     if (R < 0 || SR < 1 || SR > 64 * MAX_CH) return spf::fail(SPF_EINVAL, "spf_render_backward: need 1 <= SR <= %d", 64 * MAX_CH);
     if (R == 0) return SPF_OK;
-    if (!sdf || !slot_valid || !z || !deltas || !colors || !beta || !weights || !g_rgb || !g_sdf || !g_colors || !g_beta)
+    if (!sdf || !slot_valid || !z || !deltas || !beta || !weights || !g_sdf || !g_beta)
         return spf::fail(SPF_EINVAL, "spf_render_backward: null pointer");
+    if (g_rgb && (!colors || !g_colors)) return spf::fail(SPF_EINVAL, "spf_render_backward: g_rgb needs colors and g_colors");
+    if (!g_rgb && g_colors) return spf::fail(SPF_EINVAL, "spf_render_backward: g_colors needs g_rgb");
     if (g_pts_rendered && !ray_dirs) return spf::fail(SPF_EINVAL, "spf_render_backward: g_pts_rendered needs ray_dirs");
     render_backward_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, (hipStream_t)stream>>>(
         sdf, slot_valid, z, deltas, colors, beta, weights, g_weights, g_rgb, g_depth, g_dist, R, SR, g_sdf, g_colors, g_beta, beta_param, g_acc,

@@ -500,23 +500,98 @@ wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, in
 // problem: row-major C = 256 (the head stage: K = valid points), G in 64-row tiles x A in 16-row blocks (the colour trunk's layers 2 and 4,
 // C = 256) and G in 64-row tiles x row-major A with C <= 128 (the trunk's first layer, C = 104) — round 4: the trunk's three GEMMs were three
 // launches + three reduces (each paying pipeline ramp, tail and a dispatch gap; at K = 49 k pairs, 128 rays, 174 us for 80 us of work).
+// Round 5: up to SIX problems, each with its OWN row count (n_rows / max_rows): the head stage's three GEMMs (K = valid points) ride in the
+// colour trunk's launch (K = pairs) — one pipeline ramp / tail / slab reduce for all the 256-wide weight gradients of a step.
+constexpr int WG_MAXP = 6;
 struct WgradBatch {
-    const float* G[3];
-    const float* A[3];
-    int lda[3];
-    float* dW[3];
-    int ldw[3];
-    float* dbias[3];
-    int C[3], kind[3], first[3], nblk[3], col_rot[3], col_mod[3];     // kind: 0 = <8, rows, rows>, 1 = <8, G64, A16>, 2 = <4, G64, rows>
+    const float* G[WG_MAXP];
+    const float* A[WG_MAXP];
+    int lda[WG_MAXP];
+    float* dW[WG_MAXP];
+    int ldw[WG_MAXP];
+    float* dbias[WG_MAXP];
+    const int32_t* n_rows[WG_MAXP];
+    int max_rows[WG_MAXP];
+    int C[WG_MAXP], kind[WG_MAXP], first[WG_MAXP], nblk[WG_MAXP], col_rot[WG_MAXP], col_mod[WG_MAXP];     // kind: 0 = <8, rows, rows>, 1 = <8, G64, A16>, 2 = <4, G64, rows>
 };
+// Workgroups per problem, from the ACTUAL row counts (they live on the device: the host only knows the buffers' capacities, and a share cut
+// from capacities left the head stage's problems — 69 % full at 128 rays against the trunk's 60 % — as the launch's long pole: 124 us for
+// 100 us of work).  Every workgroup of the GEMM launch and of the reduce launch derives the same split from the same counts: shares
+// proportional to rows x width (a C <= 128 problem costs 0.62 of a C = 256 one), at least one workgroup per non-empty problem, at most one
+// per WGRAD_MIN_ROWS_DEV rows; the rounding remainder goes, one workgroup at a time, to the problem with the most rows per workgroup.
+constexpr int WGRAD_MIN_ROWS_DEV = 128;
+__device__ __forceinline__ void wg_assign(const WgradBatch& pb, int n_problems, int B, int* first, int* nblk) {
+    float w[WG_MAXP];
+    int cap[WG_MAXP];
+    float total = 0.f;
+#pragma unroll
+    for (int q = 0; q < WG_MAXP; ++q) {
+        w[q] = 0.f;
+        cap[q] = 0;
+        nblk[q] = 0;
+        if (q < n_problems) {
+            const int n = pb.n_rows[q] ? min(*pb.n_rows[q], pb.max_rows[q]) : pb.max_rows[q];
+            w[q] = (pb.kind[q] == 2 ? 0.62f : 1.0f) * (float)max(n, 0);
+            cap[q] = (max(n, 0) + WGRAD_MIN_ROWS_DEV - 1) / WGRAD_MIN_ROWS_DEV;
+            total += w[q];
+        }
+    }
+    int used = 0;
+#pragma unroll
+    for (int q = 0; q < WG_MAXP; ++q)
+        if (cap[q] > 0) {
+            int nb = (int)((float)B * w[q] / total);
+            nb = max(1, min(nb, cap[q]));
+            nblk[q] = nb;
+            used += nb;
+        }
+    for (int it = 0; it < 2 * WG_MAXP && used < B; ++it) {      // the rounding remainder (< one workgroup per problem) — and nothing when caps bind
+        int best = -1;
+        float load = 0.f;
+#pragma unroll
+        for (int q = 0; q < WG_MAXP; ++q)
+            if (nblk[q] > 0 && nblk[q] < cap[q] && w[q] / (float)nblk[q] > load) {
+                load = w[q] / (float)nblk[q];
+                best = q;
+            }
+        if (best < 0) break;
+#pragma unroll
+        for (int q = 0; q < WG_MAXP; ++q)
+            if (q == best) ++nblk[q];
+        ++used;
+    }
+    while (used > B) {                                          // (minimum shares of tiny problems pushed the sum over the grid: take from the largest)
+        int best = 0;
+#pragma unroll
+        for (int q = 1; q < WG_MAXP; ++q)
+            if (nblk[q] > nblk[best]) best = q;
+#pragma unroll
+        for (int q = 0; q < WG_MAXP; ++q)
+            if (q == best) --nblk[q];
+        --used;
+    }
+    int f = 0;
+#pragma unroll
+    for (int q = 0; q < WG_MAXP; ++q) {
+        first[q] = f;
+        f += nblk[q];
+    }
+}
+
 __global__ void __launch_bounds__(512, 1)
-wgrad_split8_batched_kernel(WgradBatch pb, int n_problems, const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slabs,
-                            size_t slab_floats, int det) {
+wgrad_split8_batched_kernel(WgradBatch pb, int n_problems, float* __restrict__ slabs, size_t slab_floats, int det) {
     __shared__ __attribute__((aligned(16))) float sm[wgrad_split8_lds_floats<8>()];
-    int q = 0;
-    if (n_problems > 1 && (int)blockIdx.x >= pb.first[1]) q = 1;
-    if (n_problems > 2 && (int)blockIdx.x >= pb.first[2]) q = 2;
-    const int bid = (int)blockIdx.x - pb.first[q], nblk = pb.nblk[q];
+    __shared__ int s_first[WG_MAXP], s_nblk[WG_MAXP];
+    if (threadIdx.x == 0) wg_assign(pb, n_problems, (int)gridDim.x, s_first, s_nblk);
+    __syncthreads();
+    int q = -1;
+#pragma unroll
+    for (int t = 0; t < WG_MAXP; ++t)
+        if (t < n_problems && (int)blockIdx.x >= s_first[t] && (int)blockIdx.x < s_first[t] + s_nblk[t]) q = t;
+    if (q < 0) return;                                          // more workgroups than the rows need
+    const int bid = (int)blockIdx.x - s_first[q], nblk = s_nblk[q];
+    const int32_t* __restrict__ n_rows_dev = pb.n_rows[q];
+    const int max_rows = pb.max_rows[q];
     float* slab = slabs + (size_t)q * slab_floats;
     float* colsum = det ? slab + COLSUM_OFF : nullptr;
     if (pb.kind[q] == 0) wgrad_split8_body<8>(sm, pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
@@ -570,13 +645,18 @@ __global__ void wgrad_split8_reduce_kernel(const float* __restrict__ slab, int n
                                            int C, float* __restrict__ dW, int ldw, int align, int col_rot, int col_mod, float* __restrict__ dbias_det) {
     wgrad_split8_reduce_body<NT>(slab, nblk_launched, n_rows_dev, max_rows, C, dW, ldw, align, col_rot, col_mod, dbias_det);
 }
-__global__ void wgrad_split8_reduce_batched_kernel(const float* __restrict__ slabs, size_t slab_floats, const int32_t* __restrict__ n_rows_dev,
-                                                   int max_rows, WgradBatch pb, int det) {
+__global__ void wgrad_split8_reduce_batched_kernel(const float* __restrict__ slabs, size_t slab_floats, WgradBatch pb, int n_problems, int n_blocks, int det) {
+    __shared__ int s_first[WG_MAXP], s_nblk[WG_MAXP];
+    if (threadIdx.x == 0) wg_assign(pb, n_problems, n_blocks, s_first, s_nblk);       // the GEMM launch's split, from the same counts
+    __syncthreads();
     const int q = blockIdx.z;
+    if (s_nblk[q] == 0) return;
+    const int32_t* __restrict__ n_rows_dev = pb.n_rows[q];
+    const int max_rows = pb.max_rows[q];
     const float* slab = slabs + (size_t)q * slab_floats;
     float* db = det ? pb.dbias[q] : nullptr;
-    if (pb.kind[q] == 2) wgrad_split8_reduce_body<4>(slab, pb.nblk[q], n_rows_dev, max_rows, pb.C[q], pb.dW[q], pb.ldw[q], 64, pb.col_rot[q], pb.col_mod[q], db);
-    else wgrad_split8_reduce_body<8>(slab, pb.nblk[q], n_rows_dev, max_rows, 256, pb.dW[q], pb.ldw[q], pb.kind[q] == 1 ? 64 : 2, pb.col_rot[q], pb.col_mod[q], db);
+    if (pb.kind[q] == 2) wgrad_split8_reduce_body<4>(slab, s_nblk[q], n_rows_dev, max_rows, pb.C[q], pb.dW[q], pb.ldw[q], 64, pb.col_rot[q], pb.col_mod[q], db);
+    else wgrad_split8_reduce_body<8>(slab, s_nblk[q], n_rows_dev, max_rows, 256, pb.dW[q], pb.ldw[q], pb.kind[q] == 1 ? 64 : 2, pb.col_rot[q], pb.col_mod[q], db);
 }
 
 // NT = 1 (C <= 32: the 21 view-encoding columns, a ones column for a bias gradient): direct loads, nothing to share
@@ -746,15 +826,22 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
     if (flags & ~SPF_WGRAD_DETERMINISTIC) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: flags may only hold SPF_WGRAD_DETERMINISTIC");
     const int det = (flags & SPF_WGRAD_DETERMINISTIC) ? 1 : 0;
     if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
-    if (!problems || n_problems < 1 || n_problems > 3 || max_rows < 0) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: 1 to 3 problems");
-    if (max_rows == 0) return SPF_OK;
+    if (!problems || n_problems < 1 || n_problems > WG_MAXP || max_rows < 0) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: 1 to %d problems", WG_MAXP);
     if (!workspace) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: null workspace");
     const int64_t slab_floats = spf_wgrad_workspace_floats(256);
     const int g64a16 = SPF_WGRAD_G_TILES64 | SPF_WGRAD_A_TILES;
-    int kind[3] = {0, 0, 0};
+    int kind[WG_MAXP] = {0, 0, 0, 0, 0, 0};
+    int rows_of[WG_MAXP];
+    const int32_t* cnt_of[WG_MAXP];
+    int any_rows = 0;
     for (int q = 0; q < n_problems; ++q) {
         const spf_wgrad_problem& p = problems[q];
         const int C = p.C > 0 ? p.C : 256;
+        // a problem's own row count (ABI 5) or the call's
+        rows_of[q] = p.max_rows > 0 ? p.max_rows : max_rows;
+        cnt_of[q] = p.max_rows > 0 ? p.n_rows : n_rows;
+        if (p.max_rows < 0) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: max_rows < 0", q);
+        any_rows |= rows_of[q];
         if (!p.G || !p.A || !p.dW) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: null G / A / dW", q);
         // the three operand forms the side-by-side kernel holds (anything else: call spf_wgrad)
         if (C == 256 && p.layout == 0) kind[q] = 0;
@@ -763,49 +850,43 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
         else return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: (C, layout) = (%d, %d) is not one of (256, 0), (256, G_TILES64 | A_TILES), "
                                           "(36..128 step 4, G_TILES64)", q, C, p.layout);
         if (kind[q] != 1 && (p.lda < C || (p.lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: lda >= C and a multiple of 4", q);
-        if (kind[q] != 0 && (max_rows % 64)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: tiled operands need max_rows %% 64 == 0", q);
+        if (kind[q] != 0 && (rows_of[q] % 64)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: tiled operands need max_rows %% 64 == 0", q);
         if (p.col_mod < 0 || p.col_mod > C || p.col_rot < 0 || (p.col_mod > 0 && p.col_rot >= p.col_mod) || (p.col_mod == 0 && p.col_rot != 0))
             return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: need 0 <= col_rot < col_mod <= C (or both 0)", q);
         if (p.ldw < (p.col_mod > 0 ? p.col_mod : C)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: ldw too small", q);
     }
+    if (!any_rows) return SPF_OK;
     if (arith != SPF_ARITH_SPLIT || n_problems == 1) {      // fp32-MFMA verification mode / nothing to batch: the single-problem path
         for (int q = 0; q < n_problems; ++q) {
             const spf_wgrad_problem& p = problems[q];
             const int C = p.C > 0 ? p.C : 256;
             if (arith != SPF_ARITH_SPLIT && (p.layout || p.col_mod)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: tiled operands / column rotation need SPF_ARITH_SPLIT");
-            const int rc = spf_wgrad(p.G, p.A, p.lda, C, n_rows, max_rows, p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, p.layout | flags, arith,
+            if (rows_of[q] == 0) continue;
+            const int rc = spf_wgrad(p.G, p.A, p.lda, C, cnt_of[q], rows_of[q], p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, p.layout | flags, arith,
                                      p.col_rot, p.col_mod, stream);
             if (rc != SPF_OK) return rc;
         }
         return SPF_OK;
     }
     WgradBatch pb{};
-    // one 8-wave workgroup per CU over ALL problems, shares proportional to the work (a C <= 128 problem stages and multiplies half the
-    // columns: measured 0.62 of a C = 256 one), so that the problems run side by side and end together
-    double w[3], wsum = 0.0;
-    for (int q = 0; q < n_problems; ++q) wsum += (w[q] = kind[q] == 2 ? 0.62 : 1.0);
-    const int want = spf::div_up(max_rows, WGRAD_MIN_ROWS);
-    int first = 0, used = 0;
+    // one 8-wave workgroup per CU over ALL problems; how many each problem gets is decided ON THE DEVICE from the actual row counts
+    // (wg_assign) — the host only sizes the grid: one workgroup per WGRAD_MIN_ROWS rows of capacity, at most one per CU
+    long long want = 0;
     for (int q = 0; q < n_problems; ++q) {
-        int share = (int)(256.0 * w[q] / wsum);
-        if (q == n_problems - 1) share = 256 - used;     // the remainder goes to the last problem
-        used += share;
-        if (share < 1) share = 1;
-        const int nb = want < share ? want : share;
         const int C = problems[q].C > 0 ? problems[q].C : 256;
         pb.G[q] = problems[q].G; pb.A[q] = problems[q].A; pb.lda[q] = problems[q].lda;
         pb.dW[q] = problems[q].dW; pb.ldw[q] = problems[q].ldw; pb.dbias[q] = problems[q].dbias;
-        pb.C[q] = C; pb.kind[q] = kind[q]; pb.first[q] = first; pb.nblk[q] = nb;
+        pb.n_rows[q] = cnt_of[q]; pb.max_rows[q] = rows_of[q];
+        pb.C[q] = C; pb.kind[q] = kind[q]; pb.first[q] = 0; pb.nblk[q] = 0;
         pb.col_rot[q] = problems[q].col_rot; pb.col_mod[q] = problems[q].col_mod;
-        first += nb;
+        want += spf::div_up(rows_of[q], WGRAD_MIN_ROWS);
     }
+    const int nblocks = want < 256 ? (want < n_problems ? n_problems : (int)want) : 256;
     hipStream_t s = (hipStream_t)stream;
     const int per = 4 * 2 * 8 * 16 * 64;
-    wgrad_split8_batched_kernel<<<first, 512, 0, s>>>(pb, n_problems, n_rows, max_rows, workspace, (size_t)slab_floats, det);
-    int nb_max = 1;
-    for (int q = 0; q < n_problems; ++q) nb_max = pb.nblk[q] > nb_max ? pb.nblk[q] : nb_max;
-    wgrad_split8_reduce_batched_kernel<<<dim3(spf::div_up(per, 256), det ? 1 : reduce_slices(nb_max), n_problems), 256, 0, s>>>(workspace, (size_t)slab_floats, n_rows,
-                                                                                                                             max_rows, pb, det);
+    wgrad_split8_batched_kernel<<<nblocks, 512, 0, s>>>(pb, n_problems, workspace, (size_t)slab_floats, det);
+    wgrad_split8_reduce_batched_kernel<<<dim3(spf::div_up(per, 256), det ? 1 : reduce_slices((nblocks + n_problems - 1) / n_problems * 2), n_problems), 256, 0, s>>>(
+        workspace, (size_t)slab_floats, pb, n_problems, nblocks, det);
     SPF_LAUNCH_CHECK("wgrad_split8_batched_kernel");
     return SPF_OK;
 }

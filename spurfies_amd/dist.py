@@ -179,8 +179,11 @@ def fused_counts(out):
     return torch.stack([torch.full((), float(out["rgb_values"].shape[0]), device=dev), f["n_points"][0].float(), cnt, lcnt])
 
 
-def sharded_loss(loss_mod, out, ground_truth, group=None):
+def sharded_loss(loss_mod, out, ground_truth, group=None, reduce=True):
     """VolSDFLoss (spurfies/model/loss.py:51-101) on one rank's rays with GLOBAL normalisers.
+
+    reduce=False: the counts stay this rank's own (no collective is issued) — for passes whose result is thrown away (graph warm-up /
+    capture), so that a rank that re-captures on its own does not issue collectives its peers do not (round-4 advisor finding).
 
     Means over data-dependent counts become local sums divided by all-reduced counts:
       rgb L1 over 3R, mask BCE over R, eikonal over P, pseudo L1 over valid rendered points;
@@ -189,7 +192,8 @@ def sharded_loss(loss_mod, out, ground_truth, group=None):
     G = world_size(group)
     if "_fused" in out:                          # sync-free mode: fused loss kernels with the all-reduced counts as normalisers
         counts = fused_counts(out)
-        all_reduce_sum(counts, group)
+        if reduce:
+            all_reduce_sum(counts, group)
         return loss_mod.fused_forward(out, ground_truth, denom=counts, world=G)
     rgb_gt = ground_truth["rgb"].to(dev).reshape(-1, 3)
     mask_gt = ground_truth["mask"].to(dev).squeeze()[:, 0][..., None]
@@ -200,7 +204,8 @@ def sharded_loss(loss_mod, out, ground_truth, group=None):
     pseudo_cnt = out.get("pseudo_count", torch.ones((), device=dev))
     lcnt = out["local_count"] if "local_count" in out else torch.zeros((), device=dev)
     counts = torch.stack([torch.full((), float(R_loc), device=dev), P_loc, pseudo_cnt.float(), lcnt])
-    all_reduce_sum(counts, group)
+    if reduce:
+        all_reduce_sum(counts, group)
     R_tot, P_tot, ps_tot = counts[0], counts[1].clamp(min=1), counts[2]
     zero = torch.zeros((), device=dev)
     res = {"rgb_loss": (out["rgb_values"] - rgb_gt).abs().sum() / (3.0 * R_tot)}

@@ -36,6 +36,7 @@ class GraphedRenderer:
         self._graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self._graph):
             self._out = self.model(dict(self._in, local_data=None), fast=self.fast)
+        torch.set_rng_state(rng)            # the captured forward drew from the CPU generator too (ray_sampler.py:562): only __call__'s draws count
         self._flags = self.model.ray_sampler._flags
         self._key = self.model.cache_key()
 
@@ -43,7 +44,8 @@ class GraphedRenderer:
         """inp: {'uv' [1,n_rays,2], 'pose' [1,4,4], 'intrinsics' [1,3|4,3|4]} -> the model's output dict (static tensors: valid until the next call)."""
         if inp["uv"].shape[1] != self.n_rays:
             raise ValueError(f"GraphedRenderer was built for chunks of {self.n_rays} rays, got {inp['uv'].shape[1]}")
-        if self._graph is None or self._key != self.model.cache_key() or inp["intrinsics"].shape != self._in["intrinsics"].shape:
+        if (self._graph is None or self._key != self.model.cache_key() or inp["intrinsics"].shape != self._in["intrinsics"].shape
+                or inp["pose"].shape != self._in["pose"].shape):
             self._capture(inp)
         for k in ("uv", "pose", "intrinsics"):
             self._in[k].copy_(inp[k], non_blocking=True)
@@ -120,6 +122,9 @@ class ImageRenderer:
         self._graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self._graph):
             self._chunk()
+        # the captured _chunk() ran the forward's CPU-generator draw once more (ray_sampler.py:562): restored, so that a first or re-captured
+        # image advances the generator by exactly one draw per chunk, as the eager path does (round-4 advisor finding)
+        torch.set_rng_state(rng)
         self._flags = self.model.ray_sampler._flags
         self._key = self.model.cache_key()
 
@@ -130,8 +135,8 @@ class ImageRenderer:
         total = int(total_pixels if total_pixels is not None else uv.shape[1])
         if uv.dim() != 3 or uv.shape[0] != 1 or uv.shape[1] != total:
             raise ValueError(f"ImageRenderer: uv must be [1, {total}, 2], got {tuple(uv.shape)}")
-        if total != self._total or model_input["intrinsics"].shape != self._K.shape:
-            self._alloc(total, model_input)
+        if total != self._total or model_input["intrinsics"].shape != self._K.shape or model_input["pose"].shape != self._pose.shape:
+            self._alloc(total, model_input)          # (a different pose layout, e.g. quaternion [1,7] vs [1,4,4], must not broadcast into a graph-baked buffer)
         self._uv.copy_(uv, non_blocking=True)
         self._pose.copy_(model_input["pose"], non_blocking=True)
         self._K.copy_(model_input["intrinsics"], non_blocking=True)

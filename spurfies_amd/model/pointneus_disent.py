@@ -87,6 +87,7 @@ class PointVolSDF(nn.Module):
         self.keep_stages = False
         self.stages = None
         self.sync_free = False   # training only: static shapes, no host synchronisation (spurfies_amd/train.py sets it)
+        self._cp_sync = ops.CompactSync()     # this model's own word buffers of the one-launch compaction, one per kNN pass
 
     # ------------------------------------------------------------------ initialisation (:116-205)
     @staticmethod
@@ -174,17 +175,19 @@ class PointVolSDF(nn.Module):
         return z
 
     # ------------------------------------------------------------------ geometry at free points
-    def _sdf_points(self, x, with_grad, gate=None):
+    def _sdf_points(self, x, with_grad, gate=None, role="points"):
         """x [M,3] -> dict(sdf [M] (1000 where no neighbour), grad, valid u8 [M], pairs); no host sync.
         gate: device int32 [1] — 0 makes the pass a no-op on the MLP side (every row gets the 1000 filler): a sampler iteration the
-        device-controlled loop did not reach (ray_sampler.py)."""
+        device-controlled loop did not reach (ray_sampler.py).  role: which of the model's compaction word buffers the pass uses (passes
+        that may overlap in time — forked graph branches — must not share one)."""
         grid = self._grid()
         x = x.contiguous()
         q = grid.query_dense(x.detach().unsqueeze(1), self.conf.k, self.conf.r, 1)
         M = x.shape[0]          # the compaction pass also lays down the 1000 filler / zero gradient of the rows without a neighbour
         sdf_buf = torch.empty((M,), dtype=torch.float32, device=x.device)
         grad_buf = torch.empty((M, 3), dtype=torch.float32, device=x.device) if with_grad else None
-        pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(-1, self.conf.k), fill_sdf=sdf_buf, fill_grad=grad_buf, gate=gate)
+        pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(-1, self.conf.k), fill_sdf=sdf_buf, fill_grad=grad_buf, gate=gate,
+                                     sync=self._cp_sync.get(role, x.device, M))
         if with_grad:
             sdf, grad, _ = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(self.conf.rbf), sdf_buf, grad_buf)
         else:
@@ -195,11 +198,11 @@ class PointVolSDF(nn.Module):
 
     def sdf_importance(self, inputs):
         """:348-421 — SDF at sampler points, 1000 where a point has no neighbour (callers wrap in no_grad)."""
-        return self._sdf_points(inputs, with_grad=False)["sdf"]
+        return self._sdf_points(inputs, with_grad=False, role="sampler")["sdf"]
 
     def sdf_importance_gated(self, inputs, gate):
         """sdf_importance behind a device-side gate (int32 [1]; 0 = skip the MLP work): the sampler's sync-free evaluation loop."""
-        return self._sdf_points(inputs, with_grad=False, gate=gate)["sdf"]
+        return self._sdf_points(inputs, with_grad=False, gate=gate, role="sampler")["sdf"]
 
     def get_sdf_eval(self, inputs):
         """:249-298 — mesh-extraction entry."""
@@ -249,19 +252,19 @@ class PointVolSDF(nn.Module):
         transmittance = torch.exp(-torch.cumsum(shifted, dim=-1))
         return alpha * transmittance
 
-    def _colors(self, n_valid, x, wn, pl, n_pairs, ray_dirs, SR):
+    def _colors(self, n_valid, x, wn, pl, n_pairs, ray_dirs, SR, pre=(None, None)):
         """n_valid / n_pairs = None selects the sync-free (worst-case buffers, device-side counts) mode."""
-        return self._colors_impl(n_valid, x, wn, pl, n_pairs, ray_dirs, SR)
+        return self._colors_impl(n_valid, x, wn, pl, n_pairs, ray_dirs, SR, pre)
 
-    def _colors_impl(self, n_valid, x, wn, pl, n_pairs, ray_dirs, SR):
+    def _colors_impl(self, n_valid, x, wn, pl, n_pairs, ray_dirs, SR, pre=(None, None)):
         """:325-346 — colours of the P valid points, written at their slot rows of a dense [R*SR,3] array (0 elsewhere).
         F_color's activated layers + RBF-weighted mean (per pair), then F_color's linear last layer + the R head (per
-        point) are fused HIP kernels (spf_color_*, spf_rhead_*)."""
+        point) are fused HIP kernels (spf_color_*, spf_rhead_*).  pre: weight images packed ahead of time (ops.prepack_*)."""
         fc, rh = self.F_color, self.R
         agg3 = ops.ColorAgg.apply(self.neural_feats_color, fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight,
-                                  fc[4].bias, x, wn, pl, self.neural_pts, n_valid, n_pairs)
+                                  fc[4].bias, x, wn, pl, self.neural_pts, n_valid, n_pairs, pre[0])
         return ops.RHead.apply(agg3, fc[6].weight, fc[6].bias, rh[0].weight, rh[0].bias, rh[2].weight, rh[2].bias, rh[4].weight,
-                               rh[4].bias, ray_dirs.detach().contiguous(), pl.point_slot, pl.n_points, SR, x.shape[0], n_valid is None)
+                               rh[4].bias, ray_dirs.detach().contiguous(), pl.point_slot, pl.n_points, SR, x.shape[0], n_valid is None, pre[1])
 
     # ------------------------------------------------------------------ forward (:614-892)
     def forward(self, input, fast=-1):
@@ -302,9 +305,20 @@ class PointVolSDF(nn.Module):
         grid = self._grid()
         R = ray_dirs.shape[0]
 
+        static = self.sync_free and self.training                 # fused-loss mode of the optimisation step
+        # forked step (ops.branch; TrainStep(fork=True), the default of graph-replayed steps): passes that do not depend on each other are
+        # issued on side streams = parallel branches of the step's hipGraph.  Branch "aux": the two weight-packing launches (they only read
+        # the parameters) and the TV term, beside the main pass's kNN / geometry kernel.
+        fork = static and ops.fork_enabled() and local_data is None and ops._sink(self.density.beta) is not None
+        pre, ev_pack, tv_early = (None, None), None, None
+        if fork:
+            with ops.branch("aux", dev) as aux:
+                pre = (ops.prepack_color(self.F_color, R * SR, dev), ops.prepack_rhead(self.F_color[6], self.R, R * SR, dev))
+                ev_pack = aux.record()
+                tv_early = self.tv_graph().loss(self.neural_feats_geometry, reduce=False)
+
         # ---- kNN of the main pass, dense [R,SR] ------------------------------------------------
         q = grid.query_dense(points.detach(), k, conf.r, SR)
-        static = self.sync_free and self.training                 # fused-loss mode of the optimisation step
         # evaluation needs no exact-size training buffers either: worst-case colour buffers + device-side counts, no host read-back
         dense = static or not self.training
         # the bool forms of the two masks are read by the reference-shaped outputs only (two conversion launches)
@@ -312,7 +326,8 @@ class PointVolSDF(nn.Module):
         ray_mask = None if static else q["ray_valid"].bool()      # [R]
         sdf_buf = torch.empty((R * SR,), dtype=torch.float32, device=dev)
         grad_buf = torch.empty((R * SR, 3), dtype=torch.float32, device=dev)
-        pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(R * SR, k), fill_sdf=sdf_buf, fill_grad=grad_buf)
+        pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(R * SR, k), fill_sdf=sdf_buf, fill_grad=grad_buf,
+                                     sync=self._cp_sync.get("main", dev, R * SR))
         point_slot = pl.point_slot
 
         # ---- filter_points (:207-239) on dense rows (HIP) ---------------------------------------
@@ -322,25 +337,42 @@ class PointVolSDF(nn.Module):
         sdf_flat, gradients, wn = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(conf.rbf), sdf_buf, grad_buf)
         sdf = sdf_flat.view(R, SR)                                # gradients: [R*SR,3], zero rows where not a point
 
+        # ---- forked step, branch "pseudo": everything that needs the compositing WEIGHTS only — depth, dist_map, the rendered surface
+        #      points and the whole pseudo-point pass behind them (:765-780: kNN, compaction, geometry kernel with the Jacobian sweep on R
+        #      points) — beside the colour stage instead of behind it; the colour composite follows on its own (ops.RenderRGB)
+        pr, ev_w = None, None
+        ev_geo = ops.mark(dev) if fork else None                  # the pseudo branch starts HERE, but is issued behind this stream's own
+        ops.wait(ev_pack)                                         # continuation (the colour stage): see ops.branch(after=...)
+
         # ---- colours (PyTorch ops on the P valid points; one host sync for P) -------------------
         if dense:        # no host round trip: worst-case buffers, counts stay on the device
             P, n_pairs, rows = 1, None, None
             self.stats = {"rays": R, "counts": pl.counts}
-            colors = self._colors(None, x, wn, pl, None, ray_dirs, SR)
+            colors = self._colors(None, x, wn, pl, None, ray_dirs, SR, pre)
         else:
             P, n_pairs = pl.host_counts()
             rows = point_slot[:P].long()
             self.stats = {"valid_points": P, "pairs": n_pairs, "rays": R}
             colors = self._colors(P, x, wn, pl, n_pairs, ray_dirs, SR) if P > 0 else torch.zeros((R * SR, 3), device=dev)
+        if fork:
+            with ops.branch("pseudo", dev, after=ev_geo) as br:
+                weights, depth, dist_map, acc, pts_rendered = ops.RenderW.apply(sdf, self.density.get_beta_value(), q["slot_valid"], z_slots, deltas,
+                                                                                self.density.beta, cam_loc, ray_dirs)
+                ev_w = br.record()
+                pr = self._sdf_points(pts_rendered, with_grad=True, role="pseudo")
         colors = colors.view(R, SR, 3)
 
         # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------
-        pts_rendered = None
-        if static and ops._sink(self.density.beta) is not None:    # beta's gradient goes straight into its .grad buffer
+        if fork:
+            ops.wait(ev_w)
+            rgb = ops.RenderRGB.apply(weights, colors)
+            ops.join(dev)                                         # the pseudo-point pass and the TV term: read by the loss kernels next
+        elif static and ops._sink(self.density.beta) is not None:    # beta's gradient goes straight into its .grad buffer
             # ... and the rendered surface points o + d * dist_map of the pseudo-point loss (:765-767) come out of the same launch
             weights, rgb, depth, dist_map, acc, pts_rendered = ops.Render.apply(sdf, colors, self.density.get_beta_value(), q["slot_valid"], z_slots,
                                                                                 deltas, self.density.beta, cam_loc, ray_dirs)
         else:
+            pts_rendered = None
             weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta(), q["slot_valid"], z_slots, deltas)
         output = {"rgb_values": rgb, "weights": weights, "local_loss": self._zero_scalar(dev)}
         if self.keep_stages:        # stage tests: dense-row intermediates next to the reference's per-stage tensors
@@ -362,7 +394,8 @@ class PointVolSDF(nn.Module):
         # ---- pseudo-point loss (:765-780) --------------------------------------------------------
         if static:
             # SDF at the rendered points, dense [R] (1000 where no neighbour); the masked mean is formed by the loss kernels
-            pr = self._sdf_points(pts_rendered if pts_rendered is not None else DistPoints.apply(cam_loc, ray_dirs, dist_map), with_grad=True)
+            if pr is None:
+                pr = self._sdf_points(pts_rendered if pts_rendered is not None else DistPoints.apply(cam_loc, ray_dirs, dist_map), with_grad=True, role="pseudo")
             output["_fused"] = {"acc": acc, "grad": gradients.detach(), "slot_valid": q["slot_valid"].view(-1), "n_points": pl.n_points,
                                 "psdf": pr["sdf"], "pvalid": pr["valid"], "ray_valid": q["ray_valid"]}
         else:
@@ -370,7 +403,7 @@ class PointVolSDF(nn.Module):
             pseudo_sum, pseudo_cnt = pseudo_pts_loss, pseudo_pts_loss
             if P > 0:
                 pts_rendered = cam_loc + ray_dirs * dist_map[:, None]
-                pr = self._sdf_points(pts_rendered, with_grad=True)
+                pr = self._sdf_points(pts_rendered, with_grad=True, role="pseudo")
                 use = pr["valid"].bool() & ray_mask
                 cnt = use.sum()
                 pseudo_sum, pseudo_cnt = torch.where(use, pr["sdf"].abs(), torch.zeros_like(pr["sdf"])).sum(), cnt
@@ -379,7 +412,7 @@ class PointVolSDF(nn.Module):
                 pseudo_pts_loss = torch.where(cnt > 0, l1, torch.full_like(l1, SDF_FILL))
             output.update({"pseudo_pts_loss": pseudo_pts_loss, "pseudo_sum": pseudo_sum, "pseudo_count": pseudo_cnt})
         # sync-free training: the per-point TV terms — their mean is formed inside the fused loss kernels (one reduction launch less)
-        output["tv_loss"] = self.tv_graph().loss(self.neural_feats_geometry, reduce=not static)
+        output["tv_loss"] = tv_early if tv_early is not None else self.tv_graph().loss(self.neural_feats_geometry, reduce=not static)
         if not self.training:
             g = gradients.view(R, SR, 3)
             nrm = torch.where(valid.unsqueeze(-1), g / g.norm(2, -1, keepdim=True), torch.zeros(1, device=dev))

@@ -37,6 +37,139 @@ def _bucket(name):
         _BUCKET_HOOK[0](name)
 
 
+# ---- who owns the scratch buffers of the launches being issued ------------------------------------------------------------------------
+# Workspaces (weight-gradient slabs, loss partials, fixed-point accumulators) are cached across steps.  Two steps that may run at the same
+# time must not share one: eager launches are told apart by their stream, but a hipGraph is captured on torch's capture stream whatever
+# stream it is later replayed on, so a stream key would bake ONE buffer into every graph of the process.  An optimisation step therefore
+# names itself as the owner of everything it launches (TrainStep: `with ops.scratch_owner(self): ...`, capture and eager alike).
+_SCRATCH_OWNER = [None]
+
+
+class scratch_owner:
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __enter__(self):
+        self.prev, _SCRATCH_OWNER[0] = _SCRATCH_OWNER[0], id(self.owner)
+        return self
+
+    def __exit__(self, *exc):
+        _SCRATCH_OWNER[0] = self.prev
+        return False
+
+
+def _scratch_key(dev):
+    """(device, owner[, branch]) of the scratch buffers of the launch being issued: the naming optimisation step (and the forked branch the
+    launch is issued on: two branches of one step may run at the same time), else the current stream."""
+    own = _SCRATCH_OWNER[0]
+    if own is None:
+        return (dev.index, ("stream", torch.cuda.current_stream(dev).cuda_stream))
+    return (dev.index, ("owner", own, _BRANCH[0]))
+
+
+# ---- forked branches of one step -------------------------------------------------------------------------------------------------------
+# Passes of the optimisation step that do not depend on each other are issued on side streams: captured into the step's hipGraph they become
+# parallel branches, so that the latency-bound chains of a SMALL per-GPU batch (strong scaling: 128 rays per rank) overlap instead of queueing
+# behind each other — the pseudo-point pass (kNN + compaction + geometry kernel on 128 points: one tile pass on 16 CUs) and the TV term beside
+# the per-point head (102 of 256 CUs), the head's weight-gradient GEMMs beside the colour backward, the latent scatters of the geometry passes
+# beside the colour trunk.  Off by default (TrainStep(fork=...) turns it on for its own launches); with it off every `branch` is a no-op
+# and the launches stay on the caller's stream in program order.
+_FORK = [False]
+_BRANCH = [None]
+_FORK_STREAMS = {}
+_FORK_USED = {}
+_KEEP = []
+
+
+def set_fork(on=True):
+    prev, _FORK[0] = _FORK[0], bool(on)
+    return prev
+
+
+def fork_enabled() -> bool:
+    """(the bit-reproducible mode keeps one stream: its fixed-point accumulators are flushed in program order)"""
+    return _FORK[0] and _SCATTER["mode"] != "fixed"
+
+
+def keep(*tensors):
+    """Hold tensors that a launch on ANOTHER stream than their allocation's reads until the step's branches have been joined: the caching
+    allocator hands a freed block to the next allocation on its own stream straight away (also during hipGraph capture), which may run beside
+    the side-stream reader."""
+    if fork_enabled():
+        _KEEP.append(tensors)
+
+
+class branch:
+    """`with ops.branch(name, device) as b:` — the enclosed launches go to the side stream `name` of the current step (it first waits for the
+    caller's stream).  b.record() -> an event the caller's stream can wait for (`ops.wait(ev)`) without waiting for the rest of the
+    branch; ops.join(device) makes the caller's stream wait for every branch used since the last join."""
+
+    def __init__(self, name, dev, after=None):
+        """after: an event of the caller's stream (ops.mark) the branch starts behind, instead of the caller's current position — the caller
+        can then issue its OWN continuation first and the branch afterwards: in a captured graph the node issued first stays on the parent's
+        queue and later children get queues of their own (ROCm's graph executor, measured: profiles/r05_fork_*.txt)."""
+        self.name, self.dev, self.after = name, torch.device(dev), after
+        self.on = fork_enabled() and self.dev.type == "cuda" and _BRANCH[0] is None        # no nested forks
+        self.stream = None
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        key = (_SCRATCH_OWNER[0], self.dev.index, self.name)
+        st = _FORK_STREAMS.get(key)
+        if st is None:
+            st = _FORK_STREAMS[key] = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream(self.dev)
+        if self.after is not None:
+            st.wait_event(self.after)
+        else:
+            st.wait_stream(main)
+        self.stream = st
+        _FORK_USED.setdefault((_SCRATCH_OWNER[0], self.dev.index), {})[self.name] = st
+        self._prev_branch, _BRANCH[0] = _BRANCH[0], self.name
+        self._ctx = torch.cuda.stream(st)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+            _BRANCH[0] = self._prev_branch
+        return False
+
+    def record(self):
+        if not self.on:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+
+def wait(ev):
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+
+
+def mark(dev):
+    """An event at the caller's current position (None when forking is off): `branch(..., after=ev)` starts there."""
+    if not (fork_enabled() and torch.device(dev).type == "cuda"):
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(torch.device(dev)))
+    return ev
+
+
+def join(dev):
+    """The caller's stream waits for every branch of the current step used since the last join (no-op when none was)."""
+    dev = torch.device(dev)
+    used = _FORK_USED.pop((_SCRATCH_OWNER[0], dev.index), None)
+    if used:
+        main = torch.cuda.current_stream(dev)
+        for st in used.values():
+            main.wait_stream(st)
+    _KEEP.clear()
+
+
 # ---- optional per-launch timing (bench.py roofline): spurfies_amd/_prof.py -----------------------
 def profile_start(tags=None):
     _prof.start(tags)
@@ -75,16 +208,43 @@ def set_compact_one_launch(on=True):
     _COMPACT_ONE_LAUNCH[0] = bool(on)
 
 
+def compact_sync_words(n_slots) -> int:
+    """Words of the zero-on-entry / zero-on-exit buffer spf_compact_pairs' one-launch form needs for `n_slots` slots."""
+    return max(int(_lib.lib().spf_compact_sync_words(int(n_slots))), 2049)
+
+
+class CompactSync:
+    """OWNED word buffers of the one-launch compaction (include/spurfies_hip.h: spf_compact_pairs, `sync`): one per (owner, role).  A buffer
+    must never be shared by two compaction launches that may run at the same time — the launch spins on words its own blocks publish and the
+    last block clears them, so a second launch on the same words hangs or mixes the lists.  A stream-keyed global cannot promise that once
+    launches are captured into hipGraphs (every capture sees torch's capture stream, the replays run wherever they are launched: round-4
+    advisor finding), so the model owns one buffer per kNN pass ('sampler', 'main', 'points', ...) and hands it to PairList.from_slots."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, role, dev, n_slots):
+        if not _COMPACT_ONE_LAUNCH[0]:
+            return None
+        need = compact_sync_words(n_slots)
+        key = (role, torch.device(dev).index)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < need:
+            buf = self._bufs[key] = torch.zeros((need,), dtype=torch.int64, device=dev)
+        return buf
+
+
 def _compact_sync(dev, n_slots):
-    """The zero-on-entry / zero-on-exit word buffer of the one-launch compaction (include/spurfies_hip.h: spf_compact_pairs): one per
-    (device, stream) — scenes stepped on different streams must not share it — grown on demand, cleared once when allocated."""
-    if not _COMPACT_ONE_LAUNCH[0]:
+    """Fallback for callers that own no CompactSync (tests, one-off queries): one buffer per (device, stream), eager launches only — under
+    hipGraph capture the stream is torch's capture stream whatever stream the replay will run on, so the two-launch form (sync = NULL)
+    is used there instead of a buffer some other graph may share."""
+    if not _COMPACT_ONE_LAUNCH[0] or torch.cuda.is_current_stream_capturing():
         return None
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    need = int(_lib.lib().spf_compact_sync_words(int(n_slots)))
+    need = compact_sync_words(n_slots)
     buf = _COMPACT_SYNC.get(key)
     if buf is None or buf.numel() < need:
-        buf = _COMPACT_SYNC[key] = torch.zeros((max(need, 2049),), dtype=torch.int64, device=dev)
+        buf = _COMPACT_SYNC[key] = torch.zeros((need,), dtype=torch.int64, device=dev)
     return buf
 
 
@@ -117,10 +277,12 @@ class PairList:
                                                   _lib.ptr(scratch), _lib.stream_ptr()), "spf_build_pairs")
 
     @classmethod
-    def from_slots(cls, slot_valid, nbr, fill_sdf=None, fill_grad=None, gate=None):
+    def from_slots(cls, slot_valid, nbr, fill_sdf=None, fill_grad=None, gate=None, sync=None):
         """Valid-point compaction AND the pair list of a kNN result in one pair of launches (spf_compact_pairs): slot_valid uint8 [R,SR],
         nbr int32 [R*SR,k] indexed by slot; optional uninitialised fill_sdf [R*SR] / fill_grad [R*SR,3] receive the 1000 filler / zeros.
-        gate: device int32 [1]; 0 reports empty lists (the MLP kernels behind this pass then do nothing)."""
+        gate: device int32 [1]; 0 reports empty lists (the MLP kernels behind this pass then do nothing).
+        sync: the caller's OWN zero-on-entry word buffer for the one-launch form (CompactSync.get); None = a per-stream fallback buffer
+        (eager launches) or the two-launch form (under graph capture)."""
         R, SR = slot_valid.shape
         rows, k = nbr.shape
         dev = nbr.device
@@ -137,7 +299,8 @@ class PairList:
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_compact_pairs(_lib.ptr(slot_valid), _lib.ptr(nbr), R, SR, k, _lib.ptr(self.point_slot), _lib.ptr(self.slot_point),
                                                     _lib.ptr(self.pair_off), _lib.ptr(self.pair_point), _lib.ptr(self.counts), _lib.ptr(scratch),
-                                                    _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad), _lib.ptr(gate), _lib.ptr(_compact_sync(dev, rows)),
+                                                    _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad), _lib.ptr(gate),
+                                                    _lib.ptr(sync if (sync is not None and _COMPACT_ONE_LAUNCH[0]) else _compact_sync(dev, rows)),
                                                     _lib.stream_ptr()), "spf_compact_pairs")
         return self
 
@@ -247,7 +410,7 @@ def _fixed_acc(like, role):
     largest size asked for (exact-size buffers change shape from step to step in the default mode: a buffer per shape would grow without bound).
     spf_fixed_accumulate leaves every entry it flushed zero again, so any prefix is ready for the next use; two accumulators that are alive at
     the same time must have different roles."""
-    key = (like.device.index, torch.cuda.current_stream(like.device).cuda_stream, role)
+    key = _scratch_key(like.device) + (role,)
     n = like.numel()
     buf = _fixed_bufs.get(key)
     if buf is None or buf.numel() < n + 1:
@@ -304,7 +467,12 @@ class GeoSDF(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if want_x:                         # rides along in the latent-gradient launch
                 g_x = torch.empty_like(grad)
-            if ctx.sink is not None:
+            if ctx.sink is not None and not want_x and _BRANCH[0] is None:
+                # a forked step: the main pass's latent scatter (nothing on this stream reads its result before the optimiser) on a branch
+                with branch("geo_scatter", g_sdf.device):
+                    geo_backward_latents(g_sdf, wn, jac, ctx.pl, ctx.sink, None, None)
+                    keep(g_sdf, wn, jac, ctx.pl)
+            elif ctx.sink is not None:
                 geo_backward_latents(g_sdf, wn, jac, ctx.pl, ctx.sink, grad if want_x else None, g_x)
             else:
                 g_feat = torch.zeros((ctx.n_table, 32), dtype=torch.float32, device=g_sdf.device)
@@ -393,6 +561,19 @@ def _color_col_perm(device):
     return _C_ORIG
 
 
+def prepack_color(fc, n_points, dev):
+    """The colour trunk's weight image + the zeroed [n_points,256] accumulator of the RBF-weighted mean, formed AHEAD of the forward's
+    colour stage (a forked branch packs while the geometry kernel runs) -> `pre` of ColorAgg.apply."""
+    agg3 = torch.empty((n_points, 256), dtype=torch.float32, device=dev)
+    return pack_color_weights([fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias], zero=agg3), agg3
+
+
+def prepack_rhead(fc6, rh, n_rows, dev):
+    """The head stage's weight image + the zeroed dense colour array [n_rows,3] -> `pre` of RHead.apply."""
+    colors = torch.empty((n_rows, 3), dtype=torch.float32, device=dev)
+    return pack_rhead_weights([fc6.weight, fc6.bias, rh[0].weight, rh[0].bias, rh[2].weight, rh[2].bias, rh[4].weight, rh[4].bias], zero=colors), colors
+
+
 def pack_color_weights(ws, zero=None):
     """ws: [w0, b0, w2, b2, w4, b4] of F_color's three activated layers -> packed image.  zero: a float32 buffer cleared by the same launch."""
     args = [t.detach().contiguous().float() for t in ws]
@@ -426,16 +607,20 @@ class ColorAgg(_GradModeFunction):
     weight gradients are spf_wgrad launches over the activation / pre-activation-gradient buffers the kernels store."""
 
     @staticmethod
-    def forward(ctx, feat_col, w0, b0, w2, b2, w4, b4, x, wn, pl, pts, n_valid, n_pairs):
+    def forward(ctx, feat_col, w0, b0, w2, b2, w4, b4, x, wn, pl, pts, n_valid, n_pairs, pre=None):
         """n_valid / n_pairs: host ints (buffers sized exactly), or None = sync-free mode: worst-case buffers, every
-        kernel (incl. the wgrad GEMMs) reads the counts from device memory."""
+        kernel (incl. the wgrad GEMMs) reads the counts from device memory.  pre: (packed image, zeroed agg3 [max_points,256]) from
+        prepack_color (sync-free mode only)."""
         dev = x.device
         ctx.static = n_valid is None
         P, NP = (pl.max_points, pl.max_pairs) if ctx.static else (int(n_valid), int(n_pairs))
         tiles = (NP + 63) // 64
         rows = 64 * tiles
-        agg3 = torch.empty((P, 256), dtype=torch.float32, device=dev)          # cleared by the packing launch
-        packed = pack_color_weights([w0, b0, w2, b2, w4, b4], zero=agg3)
+        if pre is not None and ctx.static and pre[1].shape[0] == P:
+            packed, agg3 = pre
+        else:
+            agg3 = torch.empty((P, 256), dtype=torch.float32, device=dev)          # cleared by the packing launch
+            packed = pack_color_weights([w0, b0, w2, b2, w4, b4], zero=agg3)
         train = _GradModeFunction._outer_grad_mode and any(ctx.needs_input_grad[:7])     # no training stores under torch.no_grad()
         if train:
             bufs = [torch.empty((rows, 104), dtype=torch.float32, device=dev), torch.empty((rows, 256), dtype=torch.float32, device=dev),
@@ -493,9 +678,14 @@ class ColorAgg(_GradModeFunction):
             # layer 0's [256,104] product comes in the kernels' internal column order [latent 64 | encoding 39 | pad]: the reduce kernel
             # rotates it into the reference order [encoding 39 | latent 64] on the way (no permutation pass)
             if _ARITH["wgrad"] == 0 and ctx.arith == 0 and _TRUNK_BATCHED[0]:
-                # the three GEMMs side by side in one launch + one reduce (round 4; they were three + three)
+                # the three GEMMs side by side in one launch + one reduce (round 4; they were three + three) — and with them the head stage's
+                # three, deferred by RHead.backward (round 5)
+                pend = [p for ps, _ in _PENDING_WGRAD for p in ps]
+                _PENDING_WGRAD.clear()
                 wgrad_batched([(G1, act0, sk[1], g_b0, 104, G64, 39, 103), (G2, act1, sk[3], g_b2, 256, G64 | AT, 0, 0),
-                               (G3, act2, sk[5], g_b4, 256, G64 | AT, 0, 0)], pl.n_pairs)
+                               (G3, act2, sk[5], g_b4, 256, G64 | AT, 0, 0)] + pend, pl.n_pairs)
+                if pend:
+                    _bucket("head")
             else:
                 if _ARITH["wgrad"] == 0 and ctx.arith == 0:
                     wgrad(G1, act0, pl.n_pairs, out=sk[1], dbias=kb(g_b0), layout=G64, col_rot=39, col_mod=103)
@@ -504,7 +694,7 @@ class ColorAgg(_GradModeFunction):
                 wgrad(G2, act1, pl.n_pairs, out=sk[3], dbias=kb(g_b2), layout=G64 | AT)
                 wgrad(G3, act2, pl.n_pairs, out=sk[5], dbias=kb(g_b4), layout=G64 | AT)
             _bucket("color_weights")
-            return (None,) * 13
+            return (None,) * 14
         # exact-size (default) and worst-case (sync-free) buffers alike: the weight-gradient kernel reads the row count on the device
         if ctx.arith == 0 and _ARITH["wgrad"] == 0:
             dw0 = wgrad(G1, act0, pl.n_pairs, out=torch.zeros((256, 103), dtype=torch.float32, device=dev), dbias=kb(g_b0), layout=G64, col_rot=39, col_mod=103)
@@ -513,7 +703,7 @@ class ColorAgg(_GradModeFunction):
             dw0[:, _color_col_perm(dev)] = wgrad(G1, act0, pl.n_pairs, dbias=kb(g_b0), layout=G64)[:, :103]   # [256,104] comes in the kernels' internal column order
         dw2, dw4 = wgrad(G2, act1, pl.n_pairs, dbias=kb(g_b2), layout=G64 | AT), wgrad(G3, act2, pl.n_pairs, dbias=kb(g_b4), layout=G64 | AT)
         grads = (g_feat, dw0, g_b0, dw2, g_b2, dw4, g_b4)
-        return grads + (None,) * 6
+        return grads + (None,) * 7
 
 
 # ---- per-ray compositing --------------------------------------------------------------------------
@@ -594,6 +784,84 @@ class Render(torch.autograd.Function):
         return g_sdf, g_col, (None if sink is not None else g_beta.reshape(())), None, None, None, None, None, None
 
 
+class RenderW(torch.autograd.Function):
+    """The part of `Render` that depends on the SDF alone: (weights [R,SR], depth [R,1], dist_map [R], acc [R,1], pts_rendered [R,3]) —
+    spf_render_forward's weights-only form.  With `RenderRGB` behind the colour MLPs it replaces `Render` in a forked optimisation step:
+    the pseudo-point pass (which needs pts_rendered) then runs beside the colour stage, and in the backward the colour branch does not wait
+    for the pseudo-point pass's gradient.  Same sums as the fused form (tests/test_gpu_render.py)."""
+
+    @staticmethod
+    def forward(ctx, sdf, beta, slot_valid, z, deltas, beta_param, cam_loc, ray_dirs):
+        R, SR = sdf.shape
+        dev = sdf.device
+        ctx.set_materialize_grads(False)
+        sdf_c, beta_c = sdf.detach().contiguous(), beta.detach().reshape(1).contiguous()
+        weights = torch.empty((R, SR), dtype=torch.float32, device=dev)
+        depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        dist = torch.empty((R,), dtype=torch.float32, device=dev)
+        acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        pts = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        dirs_c, loc_c = ray_dirs.detach().contiguous(), cam_loc.detach().contiguous()
+        with torch.cuda.device(dev), _prof.span("render_fwd", rays=R, slots=SR):
+            _lib.check(_lib.lib().spf_render_forward(_lib.ptr(sdf_c), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), None, _lib.ptr(beta_c), R, SR,
+                                                     _lib.ptr(weights), None, _lib.ptr(depth), _lib.ptr(dist), _lib.ptr(acc), _lib.ptr(loc_c),
+                                                     _lib.ptr(dirs_c), _lib.ptr(pts), _lib.stream_ptr()), "spf_render_forward")
+        ctx.save_for_backward(sdf_c, beta_c, slot_valid, z, deltas, weights, dirs_c)
+        ctx.beta_param = beta_param.detach()
+        ctx.beta_sink = _sink(beta_param)
+        if ctx.beta_sink is None:
+            raise RuntimeError("RenderW: beta_param needs a gradient sink (ops.set_grad_sinks)")
+        return weights, depth, dist, acc, pts
+
+    @staticmethod
+    def backward(ctx, g_w, g_depth, g_dist, g_acc, g_pts):
+        sdf, beta, slot_valid, z, deltas, weights, dirs = ctx.saved_tensors
+        R, SR = sdf.shape
+        dev = sdf.device
+        c = lambda t: None if t is None else t.contiguous()
+        g_w, g_depth, g_dist, g_pts = c(g_w), c(g_depth), c(g_dist), c(g_pts)
+        g_acc = None if g_acc is None else g_acc.reshape(R).contiguous()
+        g_sdf = torch.empty((R, SR), dtype=torch.float32, device=dev)
+        g_beta = ctx.beta_sink.reshape(1)
+        acc_b = _fixed_acc(g_beta, "beta") if _SCATTER["mode"] == "fixed" else None
+        with torch.cuda.device(dev), _prof.span("render_bwd", rays=R, slots=SR):
+            _lib.check(_lib.lib().spf_render_backward(_lib.ptr(sdf), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), None, _lib.ptr(beta),
+                                                      _lib.ptr(weights), _lib.ptr(g_w), None, _lib.ptr(g_depth), _lib.ptr(g_dist), R, SR, _lib.ptr(g_sdf),
+                                                      None, _lib.ptr(g_beta), _lib.ptr(ctx.beta_param), _lib.ptr(g_acc), _lib.ptr(g_pts),
+                                                      _lib.ptr(dirs if g_pts is not None else None), _lib.ptr(acc_b), _lib.stream_ptr()), "spf_render_backward")
+        if acc_b is not None:
+            _fixed_flush(acc_b, g_beta)
+        return g_sdf, None, None, None, None, None, None, None
+
+
+class RenderRGB(torch.autograd.Function):
+    """rgb [R,3] = sum_j weights[r,j] colors[r,j,:] (spf_render_rgb; backward: g_colors = weights g_rgb, g_weights = colors . g_rgb)."""
+
+    @staticmethod
+    def forward(ctx, weights, colors):
+        R, SR = weights.shape
+        dev = weights.device
+        w_c, col_c = weights.detach().contiguous(), colors.detach().contiguous()
+        rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_render_rgb(_lib.ptr(w_c), _lib.ptr(col_c), R, SR, _lib.ptr(rgb), _lib.stream_ptr()), "spf_render_rgb")
+        ctx.save_for_backward(w_c, col_c)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        w, col = ctx.saved_tensors
+        R, SR = w.shape
+        dev = w.device
+        g_rgb = g_rgb.contiguous()
+        g_col = torch.empty((R, SR, 3), dtype=torch.float32, device=dev)
+        g_w = torch.empty((R, SR), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().spf_render_rgb_backward(_lib.ptr(w), _lib.ptr(col), _lib.ptr(g_rgb), R, SR, _lib.ptr(g_col), _lib.ptr(g_w),
+                                                          _lib.stream_ptr()), "spf_render_rgb_backward")
+        return g_w, g_col
+
+
 # ---- sampler stages ---------------------------------------------------------------------------------
 def sampler_uniform(tlin, t_rand, cam_loc, ray_dirs, near, far):
     R, n = cam_loc.shape[0], tlin.shape[0]
@@ -658,15 +926,19 @@ class RHead(_GradModeFunction):
     layers' weight gradients are spf_wgrad launches over [P,256] buffers."""
 
     @staticmethod
-    def forward(ctx, agg3, w6, b6, w0, b0, w2, b2, w4, b4, ray_dirs, point_slot, n_points, SR, n_rows, static=False):
-        """agg3 has exactly P rows (host-known), or — static=True — worst-case rows with the count read on the device."""
+    def forward(ctx, agg3, w6, b6, w0, b0, w2, b2, w4, b4, ray_dirs, point_slot, n_points, SR, n_rows, static=False, pre=None):
+        """agg3 has exactly P rows (host-known), or — static=True — worst-case rows with the count read on the device.
+        pre: (packed image, zeroed colors [n_rows,3]) from prepack_rhead."""
         dev = agg3.device
         ctx.static = static
         P = agg3.shape[0]
         tiles = (P + 63) // 64
         T = 64 * tiles
-        colors = torch.empty((n_rows, 3), dtype=torch.float32, device=dev)      # cleared by the packing launch
-        packed = pack_rhead_weights([w6, b6, w0, b0, w2, b2, w4, b4], zero=colors)
+        if pre is not None and pre[1].shape[0] == n_rows:
+            packed, colors = pre
+        else:
+            colors = torch.empty((n_rows, 3), dtype=torch.float32, device=dev)      # cleared by the packing launch
+            packed = pack_rhead_weights([w6, b6, w0, b0, w2, b2, w4, b4], zero=colors)
         train = _GradModeFunction._outer_grad_mode and any(ctx.needs_input_grad[:9])
         if train:
             bufs = [torch.empty((T, 256), dtype=torch.float32, device=dev), torch.empty((T, 24), dtype=torch.float32, device=dev),
@@ -714,17 +986,28 @@ class RHead(_GradModeFunction):
         split = ctx.arith == 0
         kb = (lambda b: b) if split else (lambda b: None)
         if sk is not None:
-            # F_color.6 (K = points, not pairs), R.0's agg block (reference column order [dir-enc | agg]) and R.2: side by side
-            wgrad_batched([(g_agg, agg3, sk[0], kb(g_b6)), (G1, agg, sk[2][:, 21:], kb(g_b0)), (G2, act1, sk[4], kb(g_b2))], n_points)
-            wgrad(G1, direnc, n_points, C=21, out=sk[2])
-            _bucket("head")                  # F_color.6, R.*, and density.beta (written by the compositing backward before this node ran)
-            return (g_agg3[:P],) + (None,) * 14
+            # F_color.6 (K = points, not pairs), R.0's agg block (reference column order [dir-enc | agg]) and R.2: side by side — and, in a
+            # forked step, on a branch of their own: nothing behind them on this stream (the colour backward) reads what they write
+            probs = [(g_agg, agg3, sk[0], kb(g_b6)), (G1, agg, sk[2][:, 21:], kb(g_b0)), (G2, act1, sk[4], kb(g_b2))]
+            if _MERGE_HEAD[0] and split and _ARITH["wgrad"] == 0 and _ARITH["color"] == 0 and _TRUNK_BATCHED[0] and _SCATTER["mode"] != "fixed":
+                # round 5: these three GEMMs (K = valid points: a dozen workgroups' worth of rows at 128 rays) ride in the colour trunk's batched
+                # launch, which autograd issues next (ColorAgg.backward) — one pipeline ramp / tail / slab reduce for all six
+                rows = min(g_agg.shape[0], agg3.shape[0])
+                _PENDING_WGRAD.append(([pr + (256, 0, 0, 0, n_points, rows) for pr in probs], (g_agg, agg3, G1, agg, G2, act1, n_points)))
+                wgrad(G1, direnc, n_points, C=21, out=sk[2])
+            else:
+                with branch("wgrad_head", dev):
+                    wgrad_batched(probs, n_points)
+                    wgrad(G1, direnc, n_points, C=21, out=sk[2])
+                    keep(g_agg, agg3, G1, agg, G2, act1, direnc, n_points)
+                    _bucket("head")              # F_color.6, R.*, and density.beta (written by the compositing backward before this node ran)
+            return (g_agg3[:P],) + (None,) * 15
         dw6 = wgrad(g_agg, agg3, n_points, dbias=kb(g_b6))
         dw0 = torch.zeros((256, 277), dtype=torch.float32, device=dev)        # reference column order [dir-enc | agg]
         wgrad(G1, direnc, n_points, C=21, out=dw0)
         wgrad(G1, agg, n_points, out=dw0[:, 21:], dbias=kb(g_b0))
         dw2 = wgrad(G2, act1, n_points, dbias=kb(g_b2))
-        return (g_agg3[:P], dw6, g_b6, dw0, g_b0, dw2, g_b2, g_w4, g_b4, None, None, None, None, None, None)
+        return (g_agg3[:P], dw6, g_b6, dw0, g_b0, dw2, g_b2, g_w4, g_b4, None, None, None, None, None, None, None)
 
 
 _wgrad_ws = {}
@@ -779,7 +1062,7 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0, col_ro
         out = torch.zeros((256, C), dtype=torch.float32, device=dev)
     ldw = out.stride(0) if ldw is None else ldw
     nws = int(_lib.lib().spf_wgrad_workspace_floats(C))
-    key = (dev.index, nws, torch.cuda.current_stream(dev).cuda_stream)      # scenes stepped on different streams must not share scratch
+    key = _scratch_key(dev) + (nws,)      # scenes stepped at the same time must not share scratch
     if key not in _wgrad_ws:
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -789,29 +1072,55 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0, col_ro
     return out
 
 
+_PENDING_WGRAD = []          # (problems with their own row counts, tensors to keep alive): the head stage's GEMMs, waiting for the trunk's launch
+_MERGE_HEAD = [True]
+
+
+def set_head_wgrad_merged(on=True):
+    """The head stage's three 256-wide weight-gradient GEMMs ride in the colour trunk's batched launch (default) or run as a launch pair of
+    their own right behind the head's backward kernel (tests / A-B runs)."""
+    _MERGE_HEAD[0] = bool(on)
+
+
+def flush_pending_wgrad():
+    """Launch weight-gradient problems that were deferred to a later batched launch which never came (a backward without the colour trunk)."""
+    if _PENDING_WGRAD:
+        probs = [p for ps, _ in _PENDING_WGRAD for p in ps]
+        _PENDING_WGRAD.clear()
+        wgrad_batched(probs, None)
+        _bucket("head")
+
+
 def wgrad_batched(problems, n_rows):
-    """problems: up to three (G, A, out, dbias | None[, C, layout, col_rot, col_mod]): out[256, :C] += G[:rows]^T A[:rows, :C], dbias += column
-    sums of G[:rows], all in ONE pair of launches, side by side on the chip (spf_wgrad_batched).  Short tuples are row-major [rows,256]
-    operands; the long form carries spf_wgrad's layout / column rotation per problem (the colour trunk's tiled operands)."""
+    """problems: up to six (G, A, out, dbias | None[, C, layout, col_rot, col_mod[, own_n_rows, own_max_rows]]): out[256, :C] += G[:rows]^T A[:rows, :C],
+    dbias += column sums of G[:rows], all in ONE pair of launches, side by side on the chip (spf_wgrad_batched).  Short tuples are row-major
+    [rows,256] operands; the long form carries spf_wgrad's layout / column rotation per problem (the colour trunk's tiled operands) and,
+    optionally, the problem's OWN row count (device int32 tensor or None, and the buffer's row capacity) instead of the call's `n_rows`."""
     dev = problems[0][0].device
     arr = (_lib.WgradProblem * len(problems))()
     max_rows = None
     for q, prob in enumerate(problems):
         G, A, out, dbias = prob[:4]
-        C, layout, col_rot, col_mod = (tuple(prob[4:]) + (256, 0, 0, 0)[len(prob) - 4:]) if len(prob) > 4 else (256, 0, 0, 0)
+        rest = tuple(prob[4:])
+        C, layout, col_rot, col_mod = (rest[:4] + (256, 0, 0, 0)[len(rest[:4]):]) if rest else (256, 0, 0, 0)
+        own = rest[4:6] if len(rest) >= 6 else None
         if layout == 0 and (A.shape[1] != 256 or G.shape[1] != 256 or out.shape != (256, 256)):
             raise ValueError("wgrad_batched: a row-major problem is [rows,256]^T x [rows,256] -> [256,256]")
         arr[q].G, arr[q].A, arr[q].lda = _lib.ptr(G), _lib.ptr(A), A.stride(0)
         arr[q].dW, arr[q].ldw, arr[q].dbias = _lib.ptr(out), out.stride(0), _lib.ptr(dbias)
         arr[q].C, arr[q].layout, arr[q].col_rot, arr[q].col_mod = int(C), int(layout), int(col_rot), int(col_mod)
         rows = min(G.shape[0], A.shape[0])
-        max_rows = rows if max_rows is None else min(max_rows, rows)
+        if own is not None:
+            arr[q].n_rows, arr[q].max_rows = _lib.ptr(own[0]), int(min(rows, own[1]))
+        else:
+            arr[q].n_rows, arr[q].max_rows = None, 0
+            max_rows = rows if max_rows is None else min(max_rows, rows)
     nws = int(_lib.lib().spf_wgrad_workspace_floats(256)) * len(problems)
-    key = (dev.index, nws, torch.cuda.current_stream(dev).cuda_stream)
+    key = _scratch_key(dev) + (nws,)
     if key not in _wgrad_ws:
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().spf_wgrad_batched(arr, len(problems), _lib.ptr(n_rows), max_rows, _lib.ptr(_wgrad_ws[key]), _ARITH["wgrad"],
+        _lib.check(_lib.lib().spf_wgrad_batched(arr, len(problems), _lib.ptr(n_rows), 0 if max_rows is None else max_rows, _lib.ptr(_wgrad_ws[key]), _ARITH["wgrad"],
                                                     _wgrad_det(256), _lib.stream_ptr()),
                    "spf_wgrad_batched")
 
@@ -855,7 +1164,7 @@ class FusedLoss(torch.autograd.Function):
         psdf_c = None if psdf is None else psdf.detach().reshape(R).contiguous()
         n_tv = 0 if (tv is None or tv.dim() == 0 or tv.numel() == 1) else tv.numel()       # per-point array (TVLoss reduce=False) or the mean itself
         tv_c = None if tv is None else (tv.detach().contiguous() if n_tv else tv.detach().reshape(1))
-        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        key = _scratch_key(dev)
         if key not in _loss_ws:
             _loss_ws[key] = torch.empty((int(_lib.lib().spf_loss_workspace_floats()),), dtype=torch.float32, device=dev)
         total = torch.empty((), dtype=torch.float32, device=dev)

@@ -25,14 +25,20 @@ def default_loss() -> VolSDFLoss:
 class TrainStep:
     N_STAGING = 4            # pinned staging buffers for the CPU-generator draws (sync-free steps run ahead of the GPU)
 
-    def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False, use_graph=False, draws="batch", keep_grads=False):
+    def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False, use_graph=False, draws="batch", keep_grads=False,
+                 fork=None):
         """sync_free: static shapes and device-side counts everywhere — no host synchronisation inside the step (the
         default path reads [P, n_pairs] back once per step to size the colour buffers exactly).
         use_graph (implies sync_free): forward + loss + backward (~50 kernel launches) are captured once into a hipGraph
         and replayed; the gradient all-reduce, clipping and Adam stay eager.  Ray-sharded (world > 1): two graphs around the eager
         16-byte count all-reduce, then ONE dense all-reduce of the flat gradient buffer — the mode for small per-rank batches, where
-        the host cannot enqueue ~50 launches as fast as the GPU runs them (strong scaling)."""
+        the host cannot enqueue ~50 launches as fast as the GPU runs them (strong scaling).
+        fork (default: = use_graph): independent passes of the step are issued on side streams (ops.branch) and become parallel branches of
+        the captured graph — the pseudo-point pass and the TV term beside the colour stage, the weight packing beside the geometry kernel,
+        the head's weight-gradient GEMMs and the geometry passes' latent scatters beside the colour backward: what a small per-GPU batch
+        (latency-bound chains on a mostly idle chip) needs; same kernels, same sums."""
         self.model = model
+        self.fork = bool(use_graph if fork is None else fork)
         sync_free = sync_free or use_graph
         self.sync_free = sync_free
         self.use_graph = use_graph
@@ -79,6 +85,10 @@ class TrainStep:
 
     def __call__(self, model_input, ground_truth):
         """model_input: {'intrinsics','uv','pose','local_data'} for THIS rank's rays; returns (loss dict, model outputs)."""
+        with ops.scratch_owner(self):      # this step's workspaces are its own, whatever stream (or graph) its launches run in
+            return self._step(model_input, ground_truth)
+
+    def _step(self, model_input, ground_truth):
         self.model.train()
         if self.use_graph and model_input.get("local_data") is not None:
             # the captured graph holds no per-view feature maps: replaying it would silently drop the feature-consistency term
@@ -110,16 +120,29 @@ class TrainStep:
         self.iter_step += 1
         return losses, out
 
-    def _forward_backward(self, model_input, ground_truth, reduce_buckets=False):
+    def _forward_backward(self, model_input, ground_truth, reduce_buckets=False, collectives=True):
         """reduce_buckets: announce finished gradient buckets to the asynchronous all-reduce (only the optimisation step itself does; timing
-        passes that call this directly leave the gradients local)."""
+        passes that call this directly leave the gradients local).  collectives=False: not even the 16-byte count all-reduce is issued (the
+        loss is normalised by this rank's own counts): graph warm-up passes, whose results are discarded — a rank that (re)captures on its
+        own must not issue collectives its peers do not."""
+        with ops.scratch_owner(self):
+            return self._forward_backward_impl(model_input, ground_truth, reduce_buckets, collectives)
+
+    def _forward_backward_impl(self, model_input, ground_truth, reduce_buckets, collectives):
+        prev_fork = ops.set_fork(self.fork)
+        try:
+            return self._forward_backward_body(model_input, ground_truth, reduce_buckets, collectives)
+        finally:
+            ops.set_fork(prev_fork)
+
+    def _forward_backward_body(self, model_input, ground_truth, reduce_buckets, collectives):
         model_input = dict(model_input)
         model_input["iter_step"] = self.iter_step
         if self.sync_free:
             self._refresh_draws(model_input["uv"].shape[1], model_input["uv"].device)
         out = self.model(model_input, fast=1)
         if self.world > 1:
-            losses = sdist.sharded_loss(self.loss, out, ground_truth, self.group)
+            losses = sdist.sharded_loss(self.loss, out, ground_truth, self.group, reduce=collectives)
         else:
             losses = self.loss(out, ground_truth)
         if not self._grads_clean:                                               # else: cleared by the previous step's Adam sweep
@@ -131,6 +154,8 @@ class TrainStep:
                 ops.set_bucket_hook(self.buckets.ready)
         try:
             losses["loss"].backward(gradient=self._root_grad(losses["loss"]))   # a cached 1 (autograd would launch a fill for its own)
+            ops.flush_pending_wgrad()                                           # (no-op: the colour trunk's launch took the head's GEMMs along)
+            ops.join(losses["loss"].device)                                     # forked step: the backward's side branches (no-op otherwise)
         finally:
             ops.set_bucket_hook(None)
         return losses, out
@@ -170,6 +195,13 @@ class TrainStep:
 
     # ------------------------------------------------------------------ hipGraph path
     def _graphed_forward_backward(self, model_input, ground_truth):
+        prev_fork = ops.set_fork(self.fork)
+        try:
+            return self._graphed_forward_backward_body(model_input, ground_truth)
+        finally:
+            ops.set_fork(prev_fork)
+
+    def _graphed_forward_backward_body(self, model_input, ground_truth):
         dev = model_input["uv"].device
         keys_in = ("intrinsics", "uv", "pose")
         key = self.model.cache_key()
@@ -183,8 +215,8 @@ class TrainStep:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                for _ in range(2):
-                    self._forward_backward(dict(self._static_in, local_data=None), self._static_gt)
+                for _ in range(2):       # no collective in the warm-up: ranks may (re)capture independently of each other
+                    self._forward_backward(dict(self._static_in, local_data=None), self._static_gt, collectives=False)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.set_rng_state(rng)
             self._refresh_draws(model_input["uv"].shape[1], dev)      # allocates the persistent draw buffers
@@ -195,31 +227,46 @@ class TrainStep:
                 with torch.cuda.graph(self._graph):
                     out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
                     losses = self.loss(out, self._static_gt)
-                    self.flat.zero_()
+                    if not self.zero_in_adam:      # else the previous step's Adam sweep left the gradient buffer zero: no fill node in the graph
+                        self.flat.zero_()
                     losses["loss"].backward(gradient=self._root_grad(losses["loss"]))
+                    ops.flush_pending_wgrad()
+                    ops.join(dev)                  # the backward's forked branches end inside the capture
             else:
                 # ray-sharded: the step has one exchange INSIDE forward + backward — the 16 bytes of loss normalisers between the forward and
                 # the loss kernels (dist.sharded_loss).  No collective is captured (a mis-captured one hangs every rank): the step is TWO
                 # graphs over one memory pool, [forward + this rank's counts] and [loss + backward], with the count all-reduce issued eagerly
                 # between the replays and the gradient all-reduce after them.  The autograd graph spans both captures; its saved tensors
-                # live in the shared pool.  During capture nothing executes, so the eager all-reduce below sums unwritten memory on
-                # every rank alike — its result is never used.
+                # live in the shared pool.  Nothing executes during capture and NO collective is issued around it (nor in the warm-up above):
+                # whether and when a rank (re)captures — first step, a new batch shape, parameters re-pointed by load_state_dict — is then
+                # invisible to its peers, whose collective sequences stay aligned (round-4 advisor finding: a lone re-capture used to issue
+                # three extra all-reduces and hang the group).
                 pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(self._graph, pool=pool):
                     out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
                     self._counts = sdist.fused_counts(out)
-                sdist.all_reduce_sum(self._counts, self.group)
                 self._graph_tail = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph_tail, pool=pool):
                     losses = self.loss.fused_forward(out, self._static_gt, denom=self._counts, world=self.world)
-                    self.flat.zero_()
+                    if not self.zero_in_adam:
+                        self.flat.zero_()
                     losses["loss"].backward(gradient=self._root_grad(losses["loss"]))
+                    ops.flush_pending_wgrad()
+                    ops.join(dev)
             self._static_out = (losses, out)
-        for k in keys_in:
-            self._static_in[k].copy_(model_input[k], non_blocking=True)
-        for k in ("rgb", "mask"):
-            self._static_gt[k].copy_(ground_truth[k], non_blocking=True)
+            self._grads_clean = False              # the warm-up passes left gradients behind (nothing ran during the capture)
+        # the batch -> the graph's static input buffers: ONE multi-tensor copy launch (five D2D copies were 24 us of a 1 ms step at 128 rays)
+        src = [model_input[k] for k in keys_in] + [ground_truth[k] for k in ("rgb", "mask")]
+        dst = [self._static_in[k] for k in keys_in] + [self._static_gt[k] for k in ("rgb", "mask")]
+        if all(a.is_cuda and a.dtype == b.dtype and a.shape == b.shape for a, b in zip(src, dst)):
+            torch._foreach_copy_(dst, src)
+        else:
+            for a, b in zip(src, dst):
+                b.copy_(a, non_blocking=True)
         self._refresh_draws(model_input["uv"].shape[1], dev)
+        if self.zero_in_adam and not self._grads_clean:        # only behind passes that ran without an optimiser step (warm-up, timing passes)
+            self.flat.zero_()
+        self._grads_clean = False
         self._graph.replay()
         if self._graph_tail is not None:
             sdist.all_reduce_sum(self._counts, self.group)
@@ -567,8 +614,15 @@ class VolOpt:
 
     def run(self, opt_stepN):
         """train.py:496-546: epochs over the image loader until `opt_stepN` steps; returns the epoch reached."""
+        import gc
+
         epoch = self.start_epoch
         self.train_dataset.change_sampling_idx(self.num_pixels)
+        # everything built so far (model, dataset, torch's module tables: ~10^6 objects) moves to the collector's permanent generation: a
+        # full collection inside the loop then walks the loop's own garbage only, instead of stalling the host for ~0.1 s (measured in bench.py:
+        # 78 - 142 ms, i.e. 15 - 30 steps of GPU work that the launch queue may or may not cover)
+        gc.collect()
+        gc.freeze()
         while self.iter_step < opt_stepN:
             if self.checkpoint_freq > 0 and epoch % self.checkpoint_freq == 0 and epoch > self.start_epoch:
                 self.save_checkpoints(epoch)

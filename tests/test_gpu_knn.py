@@ -233,3 +233,54 @@ def test_one_launch_compaction_is_independent_per_stream_and_at_the_largest_pass
     assert pbig.host_counts() == (big[2], big[3])
     ref = ops.PairList(big[1], *ops.compact_points(big[0].view(-1, 1))[::2])
     assert torch.equal(pbig.pair_off[:big[2] + 1], ref.pair_off[:big[2] + 1])
+
+
+def test_two_captured_compactions_replayed_on_two_streams_do_not_share_words():
+    """Round-4 advisor finding: under hipGraph capture every graph saw torch's capture stream, so a stream-keyed word buffer was baked into
+    ALL graphs of the process; two graphs replayed at the same time then ran cp_fused_kernel on shared words (hang, or mixed lists).  Now the
+    owner of a pass hands its own buffer (ops.CompactSync), and a capture without an owner takes the two-launch form.  Two graphs with
+    different inputs, replayed 200 times on two streams at once, must each reproduce their own lists; the owned buffers come back zero."""
+    from spurfies_amd import ops
+
+    rng = np.random.default_rng(9)
+
+    def make(R, SR, frac):
+        sv = (rng.uniform(size=(R, SR)) < frac).astype(np.uint8)
+        cnt = rng.integers(1, 9, size=(R * SR,))
+        nb = np.where(np.arange(8)[None, :] < cnt[:, None], rng.integers(0, 5000, size=(R * SR, 8)), -1).astype(np.int32)
+        nb[sv.reshape(-1) == 0] = -1
+        return torch.from_numpy(sv).cuda(), torch.from_numpy(nb).cuda(), int(sv.sum()), int(cnt[sv.reshape(-1) == 1].sum())
+
+    cases = [make(1024, 80, 0.5), make(1024, 80, 0.25)]
+    owners = [ops.CompactSync(), ops.CompactSync()]
+    refs = [ops.PairList(c[1], *ops.compact_points(c[0])[::2]) for c in cases]
+    graphs, lists = [], []
+    for c, own in zip(cases, owners):
+        sync = own.get("main", c[0].device, c[0].numel())           # allocated (and zeroed) before the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            pl = ops.PairList.from_slots(c[0], c[1], sync=sync)
+        graphs.append(g)
+        lists.append(pl)
+    # a capture WITHOUT an owner must not bake a shared buffer in: it records the two-launch form
+    n_before = len(ops._COMPACT_SYNC)
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3):
+        pl3 = ops.PairList.from_slots(cases[0][0], cases[0][1])
+    assert len(ops._COMPACT_SYNC) == n_before
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for it in range(200):
+        for g, st in zip(graphs, streams):
+            with torch.cuda.stream(st):
+                g.replay()
+    g3.replay()
+    torch.cuda.synchronize()
+    for c, pl, ref in zip(cases, lists, refs):
+        assert pl.host_counts() == (c[2], c[3])
+        assert torch.equal(pl.pair_off[:c[2] + 1], ref.pair_off[:c[2] + 1]) and torch.equal(pl.pair_point[:c[3]], ref.pair_point[:c[3]])
+    assert pl3.host_counts() == (cases[0][2], cases[0][3])
+    for own in owners:
+        for buf in own._bufs.values():
+            assert not bool(buf.any()), "an owned word buffer must come back all zero"

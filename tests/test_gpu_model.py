@@ -390,6 +390,90 @@ def test_graphed_step_tracks_eager_step():
         np.testing.assert_allclose(s1[k].cpu().numpy(), s0[k].cpu().numpy(), rtol=0, atol=2e-5, err_msg=k)
 
 
+def test_forked_step_equals_the_single_stream_step():
+    """Round 5: TrainStep(fork=True) issues independent passes on side streams (parallel branches of the captured graph): weight packing + TV
+    beside the geometry kernel, the pseudo-point pass beside the colour stage (split compositing), the head's weight-gradient GEMMs and the
+    geometry passes' latent scatters beside the colour backward.  Same kernels, same sums: losses, rendered colours and the whole gradient
+    buffer agree with the single-stream step (float-atomic order noise only), eagerly and as a graph; the CPU generator advances alike."""
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.train import TrainStep
+
+    scene = syn.make_scene(3000, seed=17, prior="fitted")
+    g = torch.Generator().manual_seed(6)
+    uv = torch.from_numpy(syn.make_pixels(128, g))[None].cuda()
+    K, pose = torch.from_numpy(scene["intrinsics"])[None].cuda(), torch.from_numpy(scene["poses"][1])[None].cuda()
+    gt = {"rgb": torch.rand((128, 3), generator=g)[None].cuda(), "mask": (torch.rand((128,), generator=g) > 0.2).float()[None, :, None].repeat(1, 1, 3).cuda()}
+    res = {}
+    for name, kw in (("plain", dict(sync_free=True, fork=False)), ("fork", dict(sync_free=True, fork=True)),
+                     ("graph", dict(use_graph=True, fork=False)), ("graph_fork", dict(use_graph=True))):
+        model = build_model(scene)
+        step = TrainStep(model, keep_grads=True, **kw)
+        assert step.fork == (name in ("fork", "graph_fork"))
+        torch.manual_seed(5)
+        for _ in range(3 if "graph" in name else 1):          # a graph replays the capture's buffers: three replays, same inputs
+            torch.manual_seed(5)
+            losses, out = step({"intrinsics": K, "uv": uv, "pose": pose, "local_data": None}, gt)
+        after = torch.rand(1).item()
+        torch.cuda.synchronize()
+        res[name] = ({k: float(v.item()) for k, v in losses.items()}, step.flat.buffer.clone(), after, out["rgb_values"].detach().clone())
+    l0, g0, a0, rgb0 = res["plain"]
+    assert float(g0.abs().max()) > 0
+    for name in ("fork", "graph_fork"):
+        l1, g1, a1, rgb1 = res[name]
+        base = res["plain"] if name == "fork" else res["graph"]
+        assert a1 == base[2], name
+        for k in l0:
+            np.testing.assert_allclose(l1[k], base[0][k], rtol=1e-5, atol=1e-7, err_msg=f"{name}: {k}")
+        np.testing.assert_allclose(rgb1.cpu().numpy(), base[3].cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=name)
+        np.testing.assert_allclose(g1.cpu().numpy(), base[1].cpu().numpy(), rtol=2e-3, atol=2e-5 * float(g0.abs().max()), err_msg=name)
+
+
+def test_two_forked_graphs_replayed_on_two_streams_do_not_share_scratch():
+    """Two scenes with graph-replayed, forked steps on two streams (MultiSceneTrainer; configs[3] at strong-scaled batch sizes): every
+    workspace (compaction words, weight-gradient slabs, loss partials) belongs to its step, so each scene's three-step trajectory is the one
+    it has when trained alone (round-4 advisor finding: stream-keyed caches were baked into every captured graph)."""
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.train import MultiSceneTrainer, TrainStep
+
+    def make(seed):
+        scene = syn.make_scene(2500, seed=seed, prior="fitted")
+        model = build_model(scene)
+        g = torch.Generator().manual_seed(seed + 50)
+        K = torch.from_numpy(scene["intrinsics"])[None].cuda()
+        bs = []
+        for it in range(3):
+            uv = torch.from_numpy(syn.make_pixels(128, g))[None].cuda()
+            gt = {"rgb": torch.rand((128, 3), generator=g)[None].cuda(), "mask": torch.ones((1, 128, 3)).cuda()}
+            bs.append(({"intrinsics": K, "uv": uv, "pose": torch.from_numpy(scene["poses"][it])[None].cuda(), "local_data": None}, gt))
+        return model, bs
+
+    class Seeded:
+        def __init__(self, step, sd):
+            self.step, self.sd, self.it = step, sd, 0
+
+        def __call__(self, *b):
+            torch.manual_seed(1000 * self.sd + self.it)
+            self.it += 1
+            return self.step(*b)
+
+    seeds = (41, 42, 43, 44)
+    alone = []
+    for sd in seeds:
+        model, bs = make(sd)
+        step = Seeded(TrainStep(model, use_graph=True), sd)
+        alone.append([float(step(*b)[0]["loss"].item()) for b in bs])
+    built = [make(sd) for sd in seeds]
+    multi = MultiSceneTrainer([Seeded(TrainStep(m, use_graph=True), sd) for (m, _), sd in zip(built, seeds)], n_streams=2, device="cuda")
+    together = [[] for _ in seeds]
+    for it in range(3):
+        out = multi.step([bs[it] for _, bs in built])
+        torch.cuda.synchronize()
+        for s, l in enumerate(out):
+            together[s].append(float(l["loss"].item()))       # read before the next replay overwrites the graph's static output
+    for s in range(len(seeds)):
+        np.testing.assert_allclose(together[s], alone[s], rtol=2e-5)
+
+
 @pytest.mark.parametrize("n_points,spacing,n_rays", [(50000, 0.025, 1024), (200000, 0.0125, 4096)])
 def test_large_configs_run_and_paths_agree(n_points, spacing, n_rays):
     """BASELINE configs 3 and 5 shapes (garden-like 5e4 points in the +-2 grid; dense 2e5-point cloud with 4096-ray batches):

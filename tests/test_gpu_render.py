@@ -82,3 +82,38 @@ def test_render_forward_backward_match_oracle(SR):
     np.testing.assert_allclose(s_g.grad.cpu().numpy(), s_o.grad.numpy(), rtol=2e-4, atol=2e-5 * gs, err_msg="g_sdf")
     np.testing.assert_allclose(c_g.grad.cpu().numpy(), c_o.grad.numpy(), rtol=2e-5, atol=2e-6, err_msg="g_colors")
     np.testing.assert_allclose(b_g.grad.item(), b_o.grad.item(), rtol=5e-4, err_msg="g_beta")
+
+
+@pytest.mark.parametrize("SR", [80, 130])
+def test_split_compositing_equals_the_fused_kernels_bit_for_bit(SR):
+    """Round 5: the weights-only form of spf_render_forward + spf_render_rgb (and their backwards) — what a forked optimisation step uses so
+    that the pseudo-point pass need not wait for the colour MLPs — give the SAME BITS as the fused kernels: same lane assignment, same
+    reduction tree, the colour term enters the weight gradient as the same two-term sum."""
+    from spurfies_amd import ops
+
+    valid, o, d, loc, sdf, colors = _inputs(R=200, SR=SR, seed=3 + SR)
+    z, deltas = _oracle_filter(valid, o, d, loc)
+    gen = torch.Generator().manual_seed(2)
+    coef = {k: torch.randn(s, generator=gen).cuda() for k, s in dict(rgb=(200, 3), depth=(200, 1), dist=(200,), acc=(200, 1), pts=(200, 3)).items()}
+    sv, zc, dc = valid.to(torch.uint8).cuda(), z.cuda().contiguous(), deltas.cuda().contiguous()
+    oc, dirc = o.cuda(), d.cuda()
+    res = []
+    for split in (False, True):
+        s_g, c_g = sdf.cuda().requires_grad_(True), colors.cuda().requires_grad_(True)
+        beta_p = torch.nn.Parameter(torch.tensor(0.07, device="cuda"))
+        beta_p.grad = torch.zeros_like(beta_p)
+        ops.set_grad_sinks([beta_p])
+        beta = (beta_p.abs() + 1e-4).detach()
+        if split:
+            w, depth, dist, acc, pts = ops.RenderW.apply(s_g, beta, sv, zc, dc, beta_p, oc, dirc)
+            rgb = ops.RenderRGB.apply(w, c_g)
+        else:
+            w, rgb, depth, dist, acc, pts = ops.Render.apply(s_g, c_g, beta, sv, zc, dc, beta_p, oc, dirc)
+        loss = sum((t * coef[k]).sum() for k, t in dict(rgb=rgb, depth=depth, dist=dist, acc=acc, pts=pts).items())
+        loss.backward()
+        res.append([t.detach().clone() for t in (w, rgb, depth, dist, acc, pts, s_g.grad, c_g.grad, beta_p.grad)])
+    for a, b, nm in zip(res[0], res[1], ("weights", "rgb", "depth", "dist", "acc", "pts", "g_sdf", "g_colors", "g_beta")):
+        if nm == "g_beta":                      # one float atomic per ray: order noise only
+            np.testing.assert_allclose(b.item(), a.item(), rtol=1e-5)
+        else:
+            assert torch.equal(a, b), nm

@@ -186,3 +186,40 @@ def test_batched_entry_rejects_operand_forms_it_does_not_hold():
     n = torch.tensor([128], dtype=torch.int32, device="cuda")
     with pytest.raises(_lib.SpurfiesHipError, match="is not one of"):
         ops.wgrad_batched([(G, G, torch.zeros((256, 256), device="cuda"), None, 256, 1, 0, 0), (G, G, torch.zeros((256, 256), device="cuda"), None)], n)
+
+
+@pytest.mark.parametrize("rows_trunk,rows_head", [(49000, 7100), (391000, 56000), (700, 90), (64, 5)])
+def test_six_problems_with_their_own_row_counts_in_one_launch(rows_trunk, rows_head):
+    """Round 5 (ABI 5): the head stage's three GEMMs (K = valid points) ride in the colour trunk's batched launch (K = pairs) — six problems,
+    two row counts, three operand forms, one pair of launches; every product against float64 and no worse than the single-problem calls."""
+    from spurfies_amd import ops
+
+    g = torch.Generator().manual_seed(rows_trunk)
+    at, ah = (rows_trunk + 63) // 64 * 64, (rows_head + 63) // 64 * 64 + 128        # (the head's buffers are larger than its row count: worst-case allocation)
+    Gt = [torch.randn((at, 256), generator=g).cuda() for _ in range(3)]
+    A0 = torch.randn((at, 104), generator=g).cuda()
+    At = [A0] + [torch.randn((at, 256), generator=g).cuda() for _ in range(2)]
+    Gh = [torch.randn((ah, 256), generator=g).cuda() for _ in range(3)]
+    Ah = [torch.randn((ah, 256), generator=g).cuda() for _ in range(3)]
+    nt = torch.tensor([rows_trunk], dtype=torch.int32, device="cuda")
+    nh = torch.tensor([rows_head], dtype=torch.int32, device="cuda")
+    G64 = [_to_tiles(G_, 64) for G_ in Gt]
+    A16 = [A0, _to_tiles(At[1]), _to_tiles(At[2])]
+    outs_t = [torch.zeros((256, 103), device="cuda"), torch.zeros((256, 256), device="cuda"), torch.zeros((256, 256), device="cuda")]
+    wide = torch.zeros((256, 277), device="cuda")
+    outs_h = [torch.zeros((256, 256), device="cuda"), wide[:, 21:], torch.zeros((256, 256), device="cuda")]
+    dbs = [torch.zeros(256, device="cuda") for _ in range(6)]
+    ops.wgrad_batched([(G64[0], A16[0], outs_t[0], dbs[0], 104, 4, 39, 103), (G64[1], A16[1], outs_t[1], dbs[1], 256, 6, 0, 0),
+                       (G64[2], A16[2], outs_t[2], dbs[2], 256, 6, 0, 0)] +
+                      [(Gh[q], Ah[q], outs_h[q], dbs[3 + q], 256, 0, 0, 0, nh, ah) for q in range(3)], nt)
+    ref0 = Gt[0][:rows_trunk].double().t() @ A0[:rows_trunk].double()
+    ref0 = torch.cat([ref0[:, 64:103], ref0[:, :64]], 1)
+    refs = [ref0] + [Gt[q][:rows_trunk].double().t() @ At[q][:rows_trunk].double() for q in (1, 2)] + [Gh[q][:rows_head].double().t() @ Ah[q][:rows_head].double() for q in range(3)]
+    one = [ops.wgrad(G64[0], A16[0], nt, out=torch.zeros((256, 103), device="cuda"), layout=4, col_rot=39, col_mod=103), ops.wgrad(G64[1], A16[1], nt, layout=6),
+           ops.wgrad(G64[2], A16[2], nt, layout=6)] + [ops.wgrad(Gh[q], Ah[q], nh) for q in range(3)]
+    for q, (got, ref) in enumerate(zip(outs_t + outs_h, refs)):
+        assert _err(got, ref) < 2e-6 + 2.0 * _err(one[q], ref), q
+        rows = rows_trunk if q < 3 else rows_head
+        Gq = (Gt + Gh)[q]
+        np.testing.assert_allclose(dbs[q].double().cpu().numpy(), Gq[:rows].double().sum(0).cpu().numpy(), rtol=1e-5, atol=2e-5 * rows ** 0.5 + 1e-5, err_msg=str(q))
+    assert float(wide[:, :21].abs().max()) == 0.0

@@ -16,7 +16,7 @@ OUT = TAG + ("_eval" if MODE else "") + "_pmc_mfma.json"
 
 d = "gpurun_out/pmc_mfma"
 subprocess.run(["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-                "python3", "bench.py", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--ab-reps", "0", "--sustained", "0"] + MODE, check=True, stdout=subprocess.DEVNULL,
+                "python3", "bench.py", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--ab-reps", "0", "--sustained", "0", "--settle", "0", "--extras", "off"] + MODE, check=True, stdout=subprocess.DEVNULL,
                stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"))
 f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
 per = collections.defaultdict(dict)
@@ -34,7 +34,10 @@ for name, vs in agg.items():
     out[name] = {"launches": len(big), "avg_us": sum(v["ns"] for v in big) / len(big) / 1e3,
                  "mfma_duty": sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in big) / len(big) / (gui * 1024.0),
                  "clock_ghz": gui / (sum(v["ns"] for v in big) / len(big))}
-rec = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace on bench.py --steps 4 --warmup 2; per kernel, mean over its large "
+sys.path.insert(0, ".")
+import bench  # noqa: E402  (csrc_digest: identity of the kernel sources this collection was made on; bench.py refuses a stale one)
+
+rec = {"csrc_sha256": bench.csrc_digest(), "note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace on bench.py --steps 4 --warmup 2; per kernel, mean over its large "
                "launches. mfma_duty = MFMA_BUSY / (GUI_ACTIVE / 8 XCDs x 1024 SIMDs); clock_ghz = GUI_ACTIVE / 8 / duration (durations under counter "
                "collection are longer than in a plain run).", "kernels": out}
 json.dump(rec, open("gpurun_out/" + OUT, "w"), indent=1)

@@ -21,7 +21,7 @@ out = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = f"gpurun_out/pmc_{ctr}"
     subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", "python3", "bench.py",
-                    "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--points", str(POINTS), "--rays", str(RAYS), "--ab-reps", "0", "--sustained", "0"] + MODE,
+                    "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--points", str(POINTS), "--rays", str(RAYS), "--ab-reps", "0", "--sustained", "0", "--settle", "0", "--extras", "off"] + MODE,
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"))
     f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(list)
@@ -33,7 +33,10 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         out[k][f"{ctr}_KB_max"] = max(v)
 for k, v in out.items():
     v["hbm_bytes_max_corrected"] = (2.0 * v.get("FETCH_SIZE_KB_max", 0.0) + v.get("WRITE_SIZE_KB_max", 0.0)) * 1024.0
-rec = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on bench.py --steps 3 --warmup 1; per-launch values of the "
+sys.path.insert(0, ".")
+import bench  # noqa: E402  (csrc_digest: identity of the kernel sources this collection was made on; bench.py refuses a stale one)
+
+rec = {"csrc_sha256": bench.csrc_digest(), "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on bench.py --steps 3 --warmup 1; per-launch values of the "
                "largest launch per kernel (main pass). hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reads half of a wide "
                "coalesced stream (MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are included in both counters.",
        "config": {"points": POINTS, "rays": RAYS, "prior": "fitted", "spacing": 0.0125 if DENSE else 0.025}, "kernels": out}

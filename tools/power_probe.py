@@ -172,10 +172,13 @@ def run_for(fn, secs, sampler, label, ramp=1.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--secs", type=float, default=4.0)
-    ap.add_argument("--out", default="gpurun_out/r04_power.json")
+    ap.add_argument("--out", default="gpurun_out/r05_power.json")
     a = ap.parse_args()
     sensors = Sensors()
-    res = {"sensor": sensors.kind, "sensor_files": {"power": sensors.power_file, "sclk": sensors.sclk_file},
+    sys.path.insert(0, ".")
+    import bench  # noqa: E402  (csrc_digest: bench.py quotes this collection only while the kernel sources are the ones it was made on)
+
+    res = {"csrc_sha256": bench.csrc_digest(), "sensor": sensors.kind, "sensor_files": {"power": sensors.power_file, "sclk": sensors.sclk_file},
            "power_cap_w": (int(_read(sensors.cap_file)) / 1e6 if sensors.cap_file else None), "loads": {}}
     res["sensor_detail"] = {k: sensors.detail.get(k) for k in ("hip_device_pci", "cards", "matched", "pci_error")}
     print("sensor:", sensors.kind, sensors.power_file, res["sensor_detail"], flush=True)

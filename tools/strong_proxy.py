@@ -3,8 +3,11 @@
 
     python3 tools/strong_proxy.py [--out gpurun_out/strong_proxy.json] [--dense] [--steps 60]
 
-Per ray count: ms/step eager (sync-free launches), ms/step with the forward + loss + backward replayed as one hipGraph, the host's time to
-ENQUEUE an eager step (if that exceeds the GPU's step time the eager mode is host-bound), launches per step.
+Per ray count: ms/step eager (sync-free launches), ms/step with the forward + loss + backward replayed as one hipGraph (single stream, and
+FORKED: independent passes as parallel branches — TrainStep(fork=True), the default of graphed steps since round 5), the host's time to
+ENQUEUE an eager step (if that exceeds the GPU's step time the eager mode is host-bound).
+--scenes S: the configs[3] proxy — S scenes stepped round-robin on two streams (MultiSceneTrainer), every scene with rays/8 rays of its batch
+(what one rank of the 8-GPU run does), graph replays; against the same S scenes at the full batch.
 """
 import argparse
 import json
@@ -20,7 +23,7 @@ from spurfies_amd import ops  # noqa: E402
 from spurfies_amd import synthetic as syn  # noqa: E402
 from spurfies_amd.conf import default_model_conf  # noqa: E402
 from spurfies_amd.model.pointneus_disent import PointVolSDF  # noqa: E402
-from spurfies_amd.train import TrainStep  # noqa: E402
+from spurfies_amd.train import MultiSceneTrainer, TrainStep  # noqa: E402
 
 
 def build(scene, device, **kw):
@@ -46,12 +49,47 @@ def timed(step, batches, warm, n):
     return dt / n * 1e3, 1e3 * float(np.median(enq[:3])), 1e3 * float(np.median(enq))
 
 
+def multi_scene(a, dev):
+    """configs[3] on one rank of an 8-GPU group: S scenes x 128 rays, graph-replayed forked steps on two streams; baseline: S x 1024 rays eager."""
+    S = a.scenes
+    scenes = [syn.make_scene(10000, seed=s, prior="fitted") for s in range(S)]
+    rows = []
+    for rays, kw, mode in ((1024, dict(sync_free=True), "eager"), (128, dict(sync_free=True, use_graph=True, fork=False), "graph_single_stream"),
+                           (128, dict(sync_free=True, use_graph=True), "graph")):
+        built = []
+        for s, sc in enumerate(scenes):
+            torch.manual_seed(1 + s)
+            built.append(build(sc, dev, **kw))
+        batches = [bench.make_batches(sc, 16, rays, 0, 1, dev, seed=12345 + s) for s, sc in enumerate(scenes)]
+        multi = MultiSceneTrainer([st for _, st in built], n_streams=2, device=dev)
+        for i in range(6):
+            multi.step([b[i % len(b)] for b in batches])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(6, 6 + a.steps):
+            multi.step([b[i % len(b)] for b in batches])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / a.steps * 1e3
+        rows.append({"rays_per_scene": rays, "mode": mode, "ms_per_round": ms, "ray_samples_per_s": bench.SAMPLES_PER_RAY * rays * S / (ms * 1e-3)})
+        print(json.dumps(rows[-1]), flush=True)
+        del built, multi, batches
+        torch.cuda.empty_cache()
+    for r in rows:
+        r["speedup_vs_full_batch"] = rows[0]["ms_per_round"] / r["ms_per_round"]
+    res = {"what": f"strong-scaling proxy, configs[3] shape: {S} scenes round-robin on one MI355X (two streams), each with 128 rays per step = one rank's "
+                   "share of 1024-ray batches over 8 GPUs, against the same scenes at 1024 rays; optimisation steps before communication",
+           "scenes": S, "steps_timed": a.steps, "device": torch.cuda.get_device_name(0), "rows": rows}
+    json.dump(res, open(a.out, "w"), indent=1)
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/strong_proxy.json")
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--dense", action="store_true", help="configs[4]: 2e5 points, spacing 0.0125, 4096 rays per batch")
     ap.add_argument("--engine", default="split_w")
+    ap.add_argument("--scenes", type=int, default=0, help="configs[3] proxy: this many scenes round-robin on one GPU (two streams)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -61,12 +99,15 @@ def main():
         points, spacing, rays_list, name = 200000, 0.0125, [4096, 2048, 1024, 512], "configs[4]"
     else:
         points, spacing, rays_list, name = 10000, 0.025, [1024, 512, 256, 128], "configs[1]"
+    if a.scenes > 0:
+        return multi_scene(a, dev)
     scene = syn.make_scene(points, seed=0, spacing=spacing, prior="fitted")
     rows = []
     for rays in rays_list:
         batches = bench.make_batches(scene, 32, rays, 0, 1, dev)
         row = {"rays_per_rank": rays, "ranks_implied": rays_list[0] // rays}
-        for mode, kw in (("eager", dict(sync_free=True)), ("graph", dict(sync_free=True, use_graph=True))):
+        for mode, kw in (("eager", dict(sync_free=True)), ("graph_single_stream", dict(sync_free=True, use_graph=True, fork=False)),
+                         ("graph", dict(sync_free=True, use_graph=True))):
             torch.manual_seed(1)
             model, step = build(scene, dev, **kw)
             ms, enq_first, enq_med = timed(step, batches, 12, a.steps)
@@ -81,7 +122,7 @@ def main():
         print(json.dumps(row), flush=True)
     base = rows[0]
     for r in rows:
-        for mode in ("eager", "graph"):
+        for mode in ("eager", "graph_single_stream", "graph"):
             r[mode]["speedup_vs_full_batch"] = base[mode]["ms_per_step"] / r[mode]["ms_per_step"]
     res = {"what": f"strong-scaling proxy, {name} shape: one rank's share of the batch on one MI355X, optimisation step before communication "
                    "(fwd + loss + bwd + clip + Adam), fitted prior", "neural_points": points, "engine": a.engine, "steps_timed": a.steps,
