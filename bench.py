@@ -73,6 +73,7 @@ def parse():
                     "step on MI355X: ~3 us of dependency handling per graph node; the eager launches run ahead of the GPU)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches even at <= 256 rays per GPU (where the graph replay is the default: the eager step is host-bound there)")
     ap.add_argument("--no-fork", action="store_true", help="graph-replayed steps on ONE stream (default: independent passes as forked branches of the graph)")
+    ap.add_argument("--off", default="", help="comma list of round-5 launch fusions to switch OFF for same-box A/B runs: fused_sampler, defer_loss, merge_head")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--mode", choices=["train", "eval"], default="train", help="train (the contract line): one optimisation step per step; eval: one evaluation-render chunk per "
                     "step (PointVolSDF.forward(fast=-1) under no_grad: the full error-bounded sampler, kNN, SDF + normals, colour, compositing — SURVEY.md "
@@ -716,6 +717,12 @@ def main():
     from spurfies_amd import ops
 
     ops.geo_clock_enable(True)                    # this process is the one measuring caller of the library's held-clock counters
+    off = {t.strip() for t in args.off.split(",") if t.strip()}
+    if off - {"fused_sampler", "defer_loss", "merge_head"}:
+        raise SystemExit(f"--off: unknown switches {sorted(off)}")
+    ops.set_fused_sampler("fused_sampler" not in off)
+    ops.set_loss_finalize_deferred("defer_loss" not in off)
+    ops.set_head_wgrad_merged("merge_head" not in off)
     ctx = {"world": world, "rank": rank, "device": device, "dist": dist_info}
     # ---- what N GPUs measure: by default the SAME workload as N = 1 — BASELINE.json configs[1], one 1024-ray batch per step, rank r renders
     # rays r::N of it (strong scaling) — so that the driver's N = 1, 2, 4, 8 lines are one scaling curve of a

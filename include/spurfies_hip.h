@@ -102,6 +102,12 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
                    float radius_limit_scale, int32_t SR, int32_t* pidx, float* loc,
                    int32_t* slot_sample, uint8_t* slot_valid, uint8_t* ray_valid, void* stream);
 
+/* ABI 5: the neighbour search of spf_grid_query alone, for slots that were assigned elsewhere: slot_sample [R,SR] (INPUT: sample index of
+ * each slot or -1, a ray's first SR dilated-occupancy hits in sample order) and ray_valid [R] cleared to 0 come from the caller —
+ * spf_sampler_train assigns the slots while it still holds the ray's sorted samples.  Same outputs as spf_grid_query. */
+int spf_grid_knn(const spf_grid* g, const float* raypos, int32_t R, int32_t D, int32_t k, float radius_limit_scale, int32_t SR,
+                 const int32_t* slot_sample, int32_t* pidx, float* loc, uint8_t* slot_valid, uint8_t* ray_valid, void* stream);
+
 /* Device-side compaction of valid points (replaces the masked_select host syncs of
  * spurfies/model/utils.py:107-112 and mask_to_batch_ray_idx :172-183).
  *   point_slot [R*SR] int32  flat slot id (r*SR+s) of the p-th valid point, ray-major order
@@ -144,6 +150,12 @@ int64_t spf_compact_sync_words(int64_t n_slots);
 int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot,
                       int32_t* slot_point, int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch,
                       float* fill_sdf, float fill_value, float* fill_grad, const int32_t* gate, uint64_t* sync, void* stream);
+/* ABI 5: the same pass with spf_filter_points (pointneus_disent.py:207-239) riding along in the same launch: loc [R*SR,3] (spf_grid_query),
+ * cam_loc / ray_dirs [R,3] -> z, deltas [R*SR], x [R*SR,3], bit for bit spf_filter_points' values (one launch less on the main pass). */
+int spf_compact_pairs_filter(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot,
+                             int32_t* slot_point, int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch,
+                             float* fill_sdf, float fill_value, float* fill_grad, const int32_t* gate, uint64_t* sync,
+                             const float* loc, const float* cam_loc, const float* ray_dirs, float* z, float* deltas, float* x, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused geometry path — replaces get_keypoint_data + compute_weights + get_sdf (+ the value of
@@ -193,7 +205,9 @@ int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float*
  *   grad  [rows,3]       d sdf / d x  (NULL: skip the Jacobian sweep — sampler / eval mode)
  *   wn    [max_pairs]    normalised RBF weight of each pair, w_j / sum_j w_j (may be NULL when grad is NULL)
  *   jac   [max_pairs,32] d sdf_j / d latent_j per pair (NULL iff grad is NULL)
- *   pair_tmp [max_pairs,5] scratch */
+ *   pair_tmp [max_pairs,5] scratch: {w_j, sdf_j, d sdf_j / d x (3)} per pair.
+ * ABI 5: sdf == NULL (only with grad == NULL) skips the per-point reduction — pair_tmp is then the result, reduced by the consumer
+ * (spf_sampler_train forms sum_j w_j sdf_j / sum_j w_j per sample on its way, in the same order). */
 int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slot, const int32_t* pair_off,
                     const int32_t* pair_point, const int32_t* n_points, const int32_t* n_pairs,
                     int32_t max_points, int32_t max_pairs, int32_t k, const float* pts, const float* feat_geo,
@@ -330,6 +344,19 @@ int spf_sampler_iter(const float* z, const float* sdf, const float* beta_in, con
 int spf_sampler_finish(const float* z_samples, int32_t Ns, const float* z_vals, int32_t n, const int32_t* sel,
                        int32_t Ne, float near, float far, const float* cam_loc, const float* ray_dirs, int32_t R,
                        float* z_out, float* points, const int32_t* flags, int32_t it, void* stream);
+
+/* ABI 5 — the optimisation step's sampler pass (ErrorBoundSampler_pn.get_z_vals with fast = 1: one iteration, final sampling; ray_sampler.py:
+ * 377-574) behind the SDF kernel as ONE launch, wave per ray: (i) the per-sample SDF from the geometry kernel's per-pair scratch (spf_geo_forward
+ * with sdf == NULL: pair_tmp, pair_off, slot_point [R*n] = point id of a sample or -1; 1000 where a sample has no neighbour), (ii) beta by
+ * bisection and the N samples by inverse-CDF (spf_sampler_iter's final pass; u [R,N] per-ray uniforms), (iii) spf_sampler_finish (z_out
+ * [R, N + 2 + Ne] sorted, points [R, N + 2 + Ne, 3]) and (iv) the slot assignment of the main pass's kNN (spf_grid_query's first stage):
+ * slot_sample [R,SR] = the ray's first SR samples inside the grid's dilated occupancy, ray_valid [R] cleared (-> spf_grid_knn).
+ * Same values as the four separate launches. */
+int spf_sampler_train(const float* z, const float* pair_tmp, const int32_t* pair_off, const int32_t* slot_point, const float* beta0,
+                      int32_t R, int32_t n, float eps, float bound_coef, int32_t beta_iters, const float* u, int32_t N,
+                      const int32_t* sel, int32_t Ne, float near, float far, const float* cam_loc, const float* ray_dirs,
+                      const spf_grid* grid, int32_t SR, float* beta_out, float* z_out, float* points, int32_t* slot_sample,
+                      uint8_t* ray_valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-ray compositing — replaces filter_points (spurfies/model/pointneus_disent.py:207-239),
@@ -494,6 +521,13 @@ int spf_camera_rays(const float* uv, const float* pose, const float* intrinsics,
                     float* ray_dirs, float* cam_loc, float* depth_scale, const float* beta_param, float beta_min,
                     float* beta_out, void* stream);
 
+/* ABI 5: spf_camera_rays and spf_sampler_uniform in one launch (the first two launches of every optimisation step): the same ray arrays,
+ * plus z [R,n] and points [R,n,3] of UniformSampler.get_z_vals (ray_sampler.py:33-59; t_rand [R,n] may be NULL). */
+int spf_camera_uniform(const float* uv, const float* pose, const float* intrinsics, int32_t k_stride, int32_t R,
+                       float* ray_dirs, float* cam_loc, float* depth_scale, const float* beta_param, float beta_min,
+                       float* beta_out, const float* tlin, const float* t_rand, int32_t n, float near, float far, float* z,
+                       float* points, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Loss terms of one optimisation step — replaces VolSDFLoss.forward (spurfies/model/loss.py:42-49,
  * 51-101) and the pseudo-point term of spurfies/model/pointneus_disent.py:765-780.
@@ -511,7 +545,9 @@ int64_t spf_loss_workspace_floats(void);
  * n_tv > 0 spf_tv_forward's per-point array tv[n_tv], whose mean (utils.py:282) is formed here; denom = NULL or device
  * {R_total, P_total, pseudo_count_total} (global counts of a ray-sharded batch).
  *   total[0]  the weighted loss;   terms[8] = {loss, rgb, eikonal, tv, mask, local, pseudo, local pseudo count}
- *   den[4]    normalisers for spf_loss_backward.   workspace: spf_loss_workspace_floats() floats. */
+ *   den[4]    normalisers for spf_loss_backward.   workspace: spf_loss_workspace_floats() floats.
+ * ABI 5: total == terms == den == NULL runs the partial-sum launch only; spf_loss_backward_finalize then forms the terms on its way (the
+ * workspace must stay untouched in between). */
 int spf_loss_forward(const float* rgb, const float* rgb_gt, const float* acc, const float* mask_gt, int32_t mask_stride,
                      const float* grad, const uint8_t* slot_valid, int64_t rows, const int32_t* n_points, const float* psdf,
                      const uint8_t* pvalid, const uint8_t* ray_valid, const float* tv, int32_t n_tv, const float* denom, int32_t R,
@@ -525,6 +561,16 @@ int spf_loss_backward(const float* g_total, const float* den, const spf_loss_wei
                       const float* rgb_gt, const float* acc, const float* mask_gt, int32_t mask_stride, const float* psdf,
                       const uint8_t* pvalid, const uint8_t* ray_valid, int32_t R, float* g_rgb, float* g_acc,
                       float* g_psdf, float* g_tv, int32_t n_tv, void* stream);
+
+/* ABI 5: spf_loss_backward behind a partial-sums-only spf_loss_forward — every workgroup derives the normalisers from the workspace's partial
+ * sums itself and the first one also writes total / terms / den (the forward's outputs), so the step has no single-block finalize launch
+ * between the partial sums and the backward (3 launches -> 2).  rows / n_points / tv / n_tv / denom: as given to spf_loss_forward (rows = 0
+ * when it had no grad). */
+int spf_loss_backward_finalize(const float* g_total, const spf_loss_weights* weights, const float* rgb, const float* rgb_gt,
+                               const float* acc, const float* mask_gt, int32_t mask_stride, const float* psdf, const uint8_t* pvalid,
+                               const uint8_t* ray_valid, int32_t R, float* g_rgb, float* g_acc, float* g_psdf, float* g_tv, int32_t n_tv,
+                               const float* workspace, int64_t rows, const int32_t* n_points, const float* tv, const float* denom,
+                               float* total, float* terms, float* den, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Parameter update — replaces the tail of the reference's train step (spurfies/train.py:359-363, 548-564):

@@ -47,9 +47,11 @@ SIGNATURES = {
     "spf_grid_build": (C.c_int, [_P, _P, _I, _P]),
     "spf_grid_get_info": (C.c_int, [_P, C.POINTER(GridInfo)]),
     "spf_grid_query": (C.c_int, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
+    "spf_grid_knn": (C.c_int, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
     "spf_compact_points": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P]),
     "spf_compact_sync_words": (C.c_int64, [C.c_int64]),
     "spf_compact_pairs": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P]),
+    "spf_compact_pairs_filter": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_voxel_cells": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_float * 3), _F, _P, _P]),
     "spf_geo_packed_floats": (C.c_int64, []),
     "spf_geo_pack": (C.c_int, [_P] * 14),
@@ -68,6 +70,7 @@ SIGNATURES = {
     "spf_sampler_uniform": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
     "spf_sampler_iter": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "spf_sampler_finish": (C.c_int, [_P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _I, _P, _P, _P, _I, _P]),
+    "spf_sampler_train": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _I, _P, _I, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "spf_filter_points": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "spf_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_render_rgb": (C.c_int, [_P, _P, _I, _I, _P, _P]),
@@ -81,10 +84,12 @@ SIGNATURES = {
     "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P]),
     "spf_fixed_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
     "spf_camera_rays": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P]),
+    "spf_camera_uniform": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _I, _F, _F, _P, _P, _P]),
     "spf_adam_workspace_floats": (C.c_int64, []),
     "spf_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P, _P, _P]),
     "spf_loss_workspace_floats": (C.c_int64, []),
     "spf_loss_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _I, _P, _I, C.POINTER(LossWeights), _P, _P, _P, _P, _P]),
+    "spf_loss_backward_finalize": (C.c_int, [_P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "spf_loss_backward": (C.c_int, [_P, _P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
 }
 

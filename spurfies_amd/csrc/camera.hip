@@ -38,9 +38,70 @@ __global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __
     depth_scale[r] = zl / fmaxf(sqrtf(xl * xl + yl * yl + zl * zl), 1e-12f);
 }
 
+// camera_rays_kernel + sampler.hip's uniform_kernel in one launch (round 5: the first two launches of every optimisation step, 4.6 + 5.1 us
+// at 128 rays): thread = (ray, sample); every thread forms its ray (the arithmetic of camera_rays_kernel, so every sample of a ray sees the
+// bits the ray arrays hold), sample 0 of a ray writes the ray arrays.
+__global__ void camera_uniform_kernel(const float* __restrict__ uv, const float* __restrict__ pose, const float* __restrict__ K, int kstride,
+                                      int R, float* __restrict__ ray_dirs, float* __restrict__ cam_loc, float* __restrict__ depth_scale,
+                                      const float* __restrict__ beta_param, float beta_min, float* __restrict__ beta_out,
+                                      const float* __restrict__ tlin, const float* __restrict__ t_rand, int n, float near, float far,
+                                      float* __restrict__ z_out, float* __restrict__ points) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid == 0 && beta_out) *beta_out = fabsf(*beta_param) + beta_min;
+    if (gid >= (size_t)R * n) return;
+    const int r = (int)(gid / n), i = (int)(gid % n);
+    const float fx = K[0], sk = K[1], cx = K[2], fy = K[kstride + 1], cy = K[kstride + 2];
+    const float x = uv[2 * r], y = uv[2 * r + 1];
+    const float xl = (x - cx + cy * sk / fy - sk * y / fy) / fx * 1.0f;
+    const float yl = (y - cy) / fy * 1.0f;
+    const float zl = 1.0f;
+    const float t[3] = {pose[3], pose[7], pose[11]};
+    float d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float w = (pose[4 * c] * xl + pose[4 * c + 1] * yl + pose[4 * c + 2] * zl) + t[c];
+        d[c] = w - t[c];
+    }
+    const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = d[c] / nrm;
+    if (i == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ray_dirs[3 * r + c] = d[c];
+            cam_loc[3 * r + c] = t[c];
+        }
+        depth_scale[r] = zl / fmaxf(sqrtf(xl * xl + yl * yl + zl * zl), 1e-12f);
+    }
+    // UniformSampler.get_z_vals (ray_sampler.py:33-59), as sampler.hip's uniform_kernel
+    auto zlin = [&](int k) { return near * (1.0f - tlin[k]) + far * tlin[k]; };
+    float z = zlin(i);
+    if (t_rand) {
+        const float up = i + 1 < n ? 0.5f * (zlin(i + 1) + z) : z;
+        const float lo = i > 0 ? 0.5f * (z + zlin(i - 1)) : z;
+        z = lo + (up - lo) * t_rand[gid];
+    }
+    z_out[gid] = z;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) points[gid * 3 + c] = t[c] + z * d[c];
+}
+
 }  // namespace
 
 extern "C" {
+
+int spf_camera_uniform(const float* uv, const float* pose, const float* intrinsics, int32_t k_stride, int32_t R, float* ray_dirs, float* cam_loc,
+                       float* depth_scale, const float* beta_param, float beta_min, float* beta_out, const float* tlin, const float* t_rand,
+                       int32_t n, float near, float far, float* z, float* points, void* stream) {
+    if (R < 0 || n < 1 || (k_stride != 3 && k_stride != 4)) return spf::fail(SPF_EINVAL, "spf_camera_uniform: need R >= 0, n >= 1, k_stride 3 or 4");
+    if (R == 0) return SPF_OK;
+    if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || !depth_scale || !tlin || !z || !points) return spf::fail(SPF_EINVAL, "spf_camera_uniform: null pointer");
+    if (beta_out && !beta_param) return spf::fail(SPF_EINVAL, "spf_camera_uniform: beta_out needs beta_param");
+    camera_uniform_kernel<<<spf::div_up((long long)R * n, 256), 256, 0, (hipStream_t)stream>>>(uv, pose, intrinsics, k_stride, R, ray_dirs, cam_loc, depth_scale,
+                                                                                                beta_param, beta_min, beta_out, tlin, t_rand, n, near, far, z, points);
+    SPF_LAUNCH_CHECK("camera_uniform_kernel");
+    return SPF_OK;
+}
 
 int spf_camera_rays(const float* uv, const float* pose, const float* intrinsics, int32_t k_stride, int32_t R, float* ray_dirs,
                     float* cam_loc, float* depth_scale, const float* beta_param, float beta_min, float* beta_out, void* stream) {

@@ -22,6 +22,7 @@
 //   d sdf_j / d in = (((v * D4) W6 * D3) W4 * D2) W2 * D1) W0,  D_l = lrelu'(h_l) in {1, 0.01}
 //   sdf(p) = sum_j w_j sdf_j / sum_j w_j,  w_j = exp(-(rbf * max(|x_pi|, 1e-12))^2)  (detached)
 //   d sdf / d x(p) = sum_j (w_j / norm) d sdf_j / d x_pi
+#include "grid_dev.h"
 #include "mlp_tile.h"
 #include "mlp_tile_x3s.h"
 
@@ -57,7 +58,7 @@ constexpr int L_X = 0;
 constexpr int L_TOTAL = 64 * LDA;
 
 // per-pair scratch written by the MLP kernel and consumed by the point reduction: [w, sdf_j, dsdf_j/dx (3)]
-constexpr int PT_STRIDE = 5;
+constexpr int PT_STRIDE = spf::GEO_PT_STRIDE;
 
 // forward epilogue: + bias, record sign bits, LeakyReLU, write this wave's 64x64 block back to X
 __device__ __forceinline__ void fwd_epilogue(float* X, const f32x16 (&acc)[2][2], const float (&bv)[2], int wave,
@@ -1263,8 +1264,9 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
     if (max_points < 0 || max_pairs < 0 || k < 1 || k > SPF_KMAX)
         return spf::fail(SPF_EINVAL, "spf_geo_forward: bad sizes (max_points=%d max_pairs=%d k=%d)", max_points, max_pairs, k);
     if (max_points == 0 || max_pairs == 0) return SPF_OK;
-    if (!x || !nbr || !pair_off || !pair_point || !pts || !feat_geo || !packed || !sdf || !pair_tmp)
+    if (!x || !nbr || !pair_off || !pair_point || !pts || !feat_geo || !packed || !pair_tmp)
         return spf::fail(SPF_EINVAL, "spf_geo_forward: null pointer");
+    if (!sdf && grad) return spf::fail(SPF_EINVAL, "spf_geo_forward: sdf may only be left out (per-pair scratch for the caller's own reduction) without grad / jac");
     if ((grad == nullptr) != (jac == nullptr)) return spf::fail(SPF_EINVAL, "spf_geo_forward: grad and jac must be given together");
     if (grad && !wn) return spf::fail(SPF_EINVAL, "spf_geo_forward: wn is required with grad/jac");
     const int tiles = spf::div_up(max_pairs, 64);
@@ -1293,6 +1295,7 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
         geo_pairs_kernel<false><<<blocks, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
                                                        rbf, pair_tmp, nullptr);
     SPF_LAUNCH_CHECK("geo_pairs_kernel");
+    if (!sdf) return SPF_OK;      // ABI 5: pair_tmp = [w, sdf_j, ...] per pair is the result; spf_sampler_train forms the per-point means on its way
     geo_point_reduce_kernel<<<spf::div_up(max_points, 256), 256, 0, s>>>(pair_tmp, pair_off, point_slot, n_points, max_points, sdf, grad, wn);
     SPF_LAUNCH_CHECK("geo_point_reduce_kernel");
     return SPF_OK;

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "common.h"
+#include "grid_dev.h"
 
 namespace spf {
 
@@ -34,32 +35,9 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace spf
 
-struct spf_grid {
-    spf_grid_config cfg;
-    float cell[3];
-    float origin[3];
-    int32_t dims[3];
-    int32_t ncell;
-    int32_t n_points, n_in, n_occ, max_cell;
-    int32_t* cell_start;  // [ncell+1]
-    float4* sorted;       // [n_in] xyz + original index (bit pattern in .w), grouped by cell
-    uint32_t* dil;        // [(ncell+63)/64*2] dilated-occupancy bitmask
-    int32_t* cursor;      // [ncell] scratch
-    uint32_t* stats;      // [8] device scratch: min xyz, max xyz (ordered-uint), n_in, n_occ
-};
-
 namespace {
 
 using namespace spf;
-
-struct GridDev {
-    float ox, oy, oz;
-    float cx, cy, cz;
-    int dx, dy, dz;
-    const int32_t* cell_start;
-    const float4* sorted;
-    const uint32_t* dil;
-};
 
 __device__ __forceinline__ uint32_t ord_enc(float f) {
     uint32_t u = __float_as_uint(f);
@@ -106,16 +84,6 @@ __global__ void bbox_kernel(const float* __restrict__ pts, int n, float lx, floa
         }
         atomicAdd(&stats[6], (uint32_t)cnt);
     }
-}
-
-// cell of a position; returns false when outside the grid (also for NaN)
-__device__ __forceinline__ bool cell_of(const GridDev& g, float x, float y, float z, int& cx, int& cy, int& cz) {
-    float qx = (x - g.ox) / g.cx, qy = (y - g.oy) / g.cy, qz = (z - g.oz) / g.cz;
-    bool in = qx >= 0.f && qx < (float)g.dx && qy >= 0.f && qy < (float)g.dy && qz >= 0.f && qz < (float)g.dz;
-    cx = (int)floorf(qx);
-    cy = (int)floorf(qy);
-    cz = (int)floorf(qz);
-    return in;
 }
 
 __device__ __forceinline__ int point_cell(const GridDev& g, float x, float y, float z) {
@@ -229,13 +197,6 @@ __global__ void dilate_kernel(GridDev g, int ncell, int hkx, int hky, int hkz, u
         if (bs) atomicAdd(&stats[7], (uint32_t)__popcll(bs));
     }
     if (c < ncell && self) atomicMax(&stats[6], (uint32_t)(g.cell_start[c + 1] - g.cell_start[c]));      // fullest cell
-}
-
-__device__ __forceinline__ bool dil_hit(const GridDev& g, float x, float y, float z) {
-    int cx, cy, cz;
-    if (!cell_of(g, x, y, z, cx, cy, cz)) return false;
-    int lin = (cx * g.dy + cy) * g.dz + cz;
-    return (g.dil[lin >> 5] >> (lin & 31)) & 1u;
 }
 
 // ---- slot assignment ------------------------------------------------------------------------
@@ -643,12 +604,19 @@ __global__ void __launch_bounds__(256) cp_fused_kernel(const uint8_t* __restrict
                                                        int32_t* __restrict__ slot_point, int32_t* __restrict__ pair_off,
                                                        int32_t* __restrict__ pair_point, int32_t* __restrict__ counts /* [n_points, n_pairs] */,
                                                        float* __restrict__ fill_sdf, float fill_value, float* __restrict__ fill_grad,
-                                                       const int32_t* __restrict__ gate) {
+                                                       const int32_t* __restrict__ gate, FilterArgs filt) {
     __shared__ int32_t wsum[4];
     __shared__ int32_t wsum2[4];
     __shared__ int32_t wsum3[4];
     __shared__ int32_t wsum4[4];
     __shared__ int32_t i_clear;
+    if (filt.loc) {          // filter_points of this thread's slots rides along (independent of the lists; issued first so that its loads overlap the scans)
+#pragma unroll
+        for (int u = 0; u < CPF_PER_THREAD; ++u) {
+            const long long g = (long long)blockIdx.x * CPF_CHUNK + (long long)threadIdx.x * CPF_PER_THREAD + u;
+            if (g < nslot) filter_slot((size_t)g, slot_valid, filt);
+        }
+    }
     const long long base = (long long)blockIdx.x * CPF_CHUNK + (long long)threadIdx.x * CPF_PER_THREAD;
     int c[CPF_PER_THREAD], np = 0, nq = 0;
 #pragma unroll
@@ -715,17 +683,6 @@ __global__ void __launch_bounds__(256) cp_fused_kernel(const uint8_t* __restrict
     __syncthreads();
     if (i_clear)
         for (int b = threadIdx.x; b <= (int)gridDim.x; b += 256) __hip_atomic_store(&sync[b], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-GridDev dev_view(const spf_grid* g) {
-    GridDev d;
-    d.ox = g->origin[0], d.oy = g->origin[1], d.oz = g->origin[2];
-    d.cx = g->cell[0], d.cy = g->cell[1], d.cz = g->cell[2];
-    d.dx = g->dims[0], d.dy = g->dims[1], d.dz = g->dims[2];
-    d.cell_start = g->cell_start;
-    d.sorted = g->sorted;
-    d.dil = g->dil;
-    return d;
 }
 
 void free_tables(spf_grid* g) {
@@ -881,9 +838,22 @@ int spf_grid_get_info(const spf_grid* g, spf_grid_info* out) {
     return SPF_OK;
 }
 
+static int grid_query_impl(const spf_grid* g, const float* raypos, int32_t R, int32_t D, int32_t k, float radius_limit_scale, int32_t SR, int32_t* pidx,
+                           float* loc, int32_t* slot_sample, uint8_t* slot_valid, uint8_t* ray_valid, bool have_slots, void* stream_);
+
 int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D, int32_t k, float radius_limit_scale,
                    int32_t SR, int32_t* pidx, float* loc, int32_t* slot_sample, uint8_t* slot_valid, uint8_t* ray_valid,
                    void* stream_) {
+    return grid_query_impl(g, raypos, R, D, k, radius_limit_scale, SR, pidx, loc, slot_sample, slot_valid, ray_valid, false, stream_);
+}
+
+int spf_grid_knn(const spf_grid* g, const float* raypos, int32_t R, int32_t D, int32_t k, float radius_limit_scale, int32_t SR,
+                 const int32_t* slot_sample, int32_t* pidx, float* loc, uint8_t* slot_valid, uint8_t* ray_valid, void* stream_) {
+    return grid_query_impl(g, raypos, R, D, k, radius_limit_scale, SR, pidx, loc, const_cast<int32_t*>(slot_sample), slot_valid, ray_valid, true, stream_);
+}
+
+static int grid_query_impl(const spf_grid* g, const float* raypos, int32_t R, int32_t D, int32_t k, float radius_limit_scale, int32_t SR, int32_t* pidx,
+                           float* loc, int32_t* slot_sample, uint8_t* slot_valid, uint8_t* ray_valid, bool have_slots, void* stream_) {
     if (!g) return spf::fail(SPF_EINVAL, "spf_grid_query: null grid");
     if (R < 0 || D < 1 || SR < 1 || k < 1 || k > SPF_KMAX)
         return spf::fail(SPF_EINVAL, "spf_grid_query: need R>=0, D>=1, SR>=1, 1<=k<=%d (got R=%d D=%d SR=%d k=%d)", SPF_KMAX, R, D, SR, k);
@@ -904,8 +874,10 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
     float rad = (float)((double)radius_limit_scale * (double)vmax);
     float rad2 = rad * rad;
     GridDev d = dev_view(g);
-    const int inline_slots = (D == 1 && SR == 1) ? 1 : 0;
-    if (inline_slots) {
+    const int inline_slots = (D == 1 && SR == 1 && !have_slots) ? 1 : 0;
+    if (have_slots) {
+        // slot_sample (and the cleared ray_valid) come from the caller: spf_sampler_train assigned the slots on its way
+    } else if (inline_slots) {
         // the slot test rides inside knn_kernel
     } else if (D == 1) {
         point_slots_kernel<<<spf::div_up(R, 256), 256, 0, stream>>>(raypos, R, SR, d, slot_sample);
@@ -984,9 +956,35 @@ int spf_build_pairs(const int32_t* nbr, const int32_t* point_slot, const int32_t
 
 int64_t spf_compact_sync_words(int64_t n_slots) { return spf::div_up(n_slots, (int64_t)CPF_CHUNK) + 1; }
 
+static int compact_pairs_impl(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot, int32_t* slot_point,
+                              int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch, float* fill_sdf, float fill_value,
+                              float* fill_grad, const int32_t* gate, uint64_t* sync, FilterArgs filt, void* stream_);
+
 int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot, int32_t* slot_point,
                       int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch, float* fill_sdf, float fill_value,
                       float* fill_grad, const int32_t* gate, uint64_t* sync, void* stream_) {
+    return compact_pairs_impl(slot_valid, nbr, R, SR, k, point_slot, slot_point, pair_off, pair_point, counts, scratch, fill_sdf, fill_value, fill_grad, gate, sync,
+                              FilterArgs{}, stream_);
+}
+
+int spf_compact_pairs_filter(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot, int32_t* slot_point,
+                             int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch, float* fill_sdf, float fill_value,
+                             float* fill_grad, const int32_t* gate, uint64_t* sync, const float* loc, const float* cam_loc, const float* ray_dirs,
+                             float* z, float* deltas, float* x, void* stream_) {
+    if (!loc || !cam_loc || !ray_dirs || !z || !deltas || !x) return spf::fail(SPF_EINVAL, "spf_compact_pairs_filter: null filter_points buffer");
+    return compact_pairs_impl(slot_valid, nbr, R, SR, k, point_slot, slot_point, pair_off, pair_point, counts, scratch, fill_sdf, fill_value, fill_grad, gate, sync,
+                              FilterArgs{loc, cam_loc, ray_dirs, z, deltas, x, SR}, stream_);
+}
+
+// filter_points on its own (the two-launch form of the compaction, or passes of more than 1 M slots)
+__global__ void filter_slots_kernel(const uint8_t* __restrict__ valid, long long nslot, FilterArgs filt) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < nslot) filter_slot((size_t)g, valid, filt);
+}
+
+static int compact_pairs_impl(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, int32_t SR, int32_t k, int32_t* point_slot, int32_t* slot_point,
+                              int32_t* pair_off, int32_t* pair_point, int32_t* counts, int32_t* scratch, float* fill_sdf, float fill_value,
+                              float* fill_grad, const int32_t* gate, uint64_t* sync, FilterArgs filt, void* stream_) {
     if (R < 0 || SR < 1 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_compact_pairs: bad sizes");
     if (!counts || !pair_off) return spf::fail(SPF_EINVAL, "spf_compact_pairs: null counts / pair_off");
     hipStream_t stream = (hipStream_t)stream_;
@@ -1000,9 +998,13 @@ int spf_compact_pairs(const uint8_t* slot_valid, const int32_t* nbr, int32_t R, 
     const int chunks = spf::div_up(nslot, CMP_CHUNK);
     if (sync && spf::div_up(nslot, (long long)CPF_CHUNK) <= CPF_MAX_CHUNKS) {          // one launch: chunks publish their totals to each other (cp_fused_kernel)
         cp_fused_kernel<<<(int)spf::div_up(nslot, (long long)CPF_CHUNK), 256, 0, stream>>>(slot_valid, nbr, nslot, k, reinterpret_cast<unsigned long long*>(sync), point_slot, slot_point,
-                                                    pair_off, pair_point, counts, fill_sdf, fill_value, fill_grad, gate);
+                                                    pair_off, pair_point, counts, fill_sdf, fill_value, fill_grad, gate, filt);
         SPF_LAUNCH_CHECK("cp_fused_kernel");
         return SPF_OK;
+    }
+    if (filt.loc) {
+        filter_slots_kernel<<<spf::div_up(nslot, 256), 256, 0, stream>>>(slot_valid, nslot, filt);
+        SPF_LAUNCH_CHECK("filter_slots_kernel");
     }
     cp_count_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nbr, nslot, k, scratch);
     SPF_LAUNCH_CHECK("cp_count_kernel");

@@ -60,17 +60,18 @@ loss_partials_kernel(const float* __restrict__ rgb, const float* __restrict__ rg
 }
 
 // out = {loss, rgb, eikonal, tv, mask, local, pseudo, pseudo count};  den = {1/(3 R), 1/R, 1/pseudo count or 0, 1/world}
-__global__ void __launch_bounds__(64)
-loss_finalize_kernel(const float* __restrict__ partial, int nblk, int R, const int32_t* __restrict__ n_points, const float* __restrict__ tv, int n_tv,
-                     const float* __restrict__ denom, spf_loss_weights w, float* __restrict__ total, float* __restrict__ out,
-                     float* __restrict__ den) {
+// (the first wave of the calling block; lane 0 writes.  den_out: 4 floats anywhere — global memory, or LDS for the fused backward)
+__device__ __forceinline__ void loss_finalize_wave(const float* __restrict__ partial, int nblk, int R, const int32_t* __restrict__ n_points,
+                                                   const float* __restrict__ tv, int n_tv, const float* __restrict__ denom, const spf_loss_weights& w,
+                                                   float* __restrict__ total, float* __restrict__ out, float* den, float* den2) {
+    const int lane = threadIdx.x & 63;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = threadIdx.x; b < nblk; b += 64)
+    for (int b = lane; b < nblk; b += 64)
 #pragma unroll
         for (int i = 0; i < 6; ++i) s[i] += partial[b * NPART + i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) s[i] = wave_sum(s[i]);
-    if (threadIdx.x != 0) return;
+    if (lane != 0) return;
     const float G = (float)(w.world > 0 ? w.world : 1);
     const float R_tot = denom ? denom[0] : (float)R;
     const float P_tot = fmaxf(denom ? denom[1] : (n_points ? (float)*n_points : 0.f), 1.f);
@@ -83,16 +84,48 @@ loss_finalize_kernel(const float* __restrict__ partial, int nblk, int R, const i
     const float l_pseudo = w.pseudo > 0.f ? (ps_tot > 0.f ? s[3] / ps_tot : 1000.0f / G) : 0.f;
     const float l_local = 0.f;
     const float loss = w.rgb * l_rgb + w.eikonal * l_eik + w.tv * l_tv + w.local * l_local + w.pseudo * l_pseudo + l_mask;
-    *total = loss;
-    out[0] = loss; out[1] = l_rgb; out[2] = l_eik; out[3] = l_tv; out[4] = l_mask; out[5] = l_local; out[6] = l_pseudo; out[7] = s[4];
-    den[0] = 1.0f / (3.0f * R_tot); den[1] = 1.0f / R_tot; den[2] = ps_tot > 0.f ? 1.0f / ps_tot : 0.f; den[3] = 1.0f / G;
+    if (total) {
+        *total = loss;
+        out[0] = loss; out[1] = l_rgb; out[2] = l_eik; out[3] = l_tv; out[4] = l_mask; out[5] = l_local; out[6] = l_pseudo; out[7] = s[4];
+    }
+    const float d0 = 1.0f / (3.0f * R_tot), d1 = 1.0f / R_tot, d2 = ps_tot > 0.f ? 1.0f / ps_tot : 0.f, d3 = 1.0f / G;
+    if (den) { den[0] = d0; den[1] = d1; den[2] = d2; den[3] = d3; }
+    if (den2) { den2[0] = d0; den2[1] = d1; den2[2] = d2; den2[3] = d3; }
 }
 
-__global__ void loss_backward_kernel(const float* __restrict__ g_total, const float* __restrict__ den, spf_loss_weights w,
+__global__ void __launch_bounds__(64)
+loss_finalize_kernel(const float* __restrict__ partial, int nblk, int R, const int32_t* __restrict__ n_points, const float* __restrict__ tv, int n_tv,
+                     const float* __restrict__ denom, spf_loss_weights w, float* __restrict__ total, float* __restrict__ out,
+                     float* __restrict__ den) {
+    loss_finalize_wave(partial, nblk, R, n_points, tv, n_tv, denom, w, total, out, den, nullptr);
+}
+
+// fin.partial != NULL: the forward ran its partial-sum launch only (spf_loss_forward with total == NULL); every block of this launch then forms
+// the normalisers itself from the <= 256 partial rows (first wave, into LDS) and block 0 also writes the loss terms — the single-block
+// finalize launch between the partial sums and the backward is gone (round 5: 3 launches -> 2 per step).
+struct LossFin {
+    const float* partial;
+    int nblk, R;
+    const int32_t* n_points;
+    const float* tv;
+    int n_tv;
+    const float* denom;
+    float *total, *terms, *den_out;
+};
+__global__ void loss_backward_kernel(const float* __restrict__ g_total, const float* __restrict__ den_in, spf_loss_weights w,
                                      const float* __restrict__ rgb, const float* __restrict__ rgb_gt, const float* __restrict__ acc,
                                      const float* __restrict__ mask_gt, int mstride, const float* __restrict__ psdf, const uint8_t* __restrict__ pvalid,
                                      const uint8_t* __restrict__ ray_valid, int R, float* __restrict__ g_rgb, float* __restrict__ g_acc,
-                                     float* __restrict__ g_psdf, float* __restrict__ g_tv, int n_tv) {
+                                     float* __restrict__ g_psdf, float* __restrict__ g_tv, int n_tv, LossFin fin) {
+    __shared__ float s_den[4];
+    const float* den = den_in;
+    if (fin.partial) {
+        if (threadIdx.x < 64)
+            loss_finalize_wave(fin.partial, fin.nblk, fin.R, fin.n_points, fin.tv, fin.n_tv, fin.denom, w, blockIdx.x == 0 ? fin.total : nullptr, fin.terms,
+                               blockIdx.x == 0 ? fin.den_out : nullptr, s_den);
+        __syncthreads();
+        den = s_den;
+    }
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const float g = *g_total;
     // d loss / d (TV mean), or — n_tv > 0 — d loss / d tv_i, the same for every point
@@ -125,23 +158,29 @@ extern "C" {
 
 int64_t spf_loss_workspace_floats(void) { return (int64_t)MAX_BLOCKS * NPART; }
 
+// workgroups of the partial-sum launch (both entry points derive it from the same sizes)
+static int loss_blocks(int R, long long rows, int n_tv) {
+    long long work = rows > R ? rows : R;
+    if (n_tv > work) work = n_tv;
+    int nblk = spf::div_up(work, 256 * 4);
+    return nblk < 1 ? 1 : (nblk > MAX_BLOCKS ? MAX_BLOCKS : nblk);
+}
+
 int spf_loss_forward(const float* rgb, const float* rgb_gt, const float* acc, const float* mask_gt, int32_t mask_stride, const float* grad,
                      const uint8_t* slot_valid, int64_t rows, const int32_t* n_points, const float* psdf, const uint8_t* pvalid,
                      const uint8_t* ray_valid, const float* tv, int32_t n_tv, const float* denom, int32_t R, const spf_loss_weights* weights,
                      float* workspace, float* total, float* terms, float* den, void* stream) {
     if (R <= 0 || rows < 0 || !weights || mask_stride < 1 || n_tv < 0) return spf::fail(SPF_EINVAL, "spf_loss_forward: need R > 0, rows >= 0, mask_stride >= 1, n_tv >= 0, weights");
-    if (!rgb || !rgb_gt || !acc || !mask_gt || !workspace || !total || !terms || !den)
-        return spf::fail(SPF_EINVAL, "spf_loss_forward: null pointer");
+    if (!rgb || !rgb_gt || !acc || !mask_gt || !workspace) return spf::fail(SPF_EINVAL, "spf_loss_forward: null pointer");
+    if ((total == nullptr) != (terms == nullptr) || (total == nullptr) != (den == nullptr))
+        return spf::fail(SPF_EINVAL, "spf_loss_forward: total, terms and den are given (or all left out: partial sums only) together");
     if (grad && !slot_valid) return spf::fail(SPF_EINVAL, "spf_loss_forward: grad needs slot_valid");
     if (psdf && (!pvalid || !ray_valid)) return spf::fail(SPF_EINVAL, "spf_loss_forward: psdf needs pvalid and ray_valid");
     hipStream_t s = (hipStream_t)stream;
-    long long work = grad ? (rows > R ? rows : R) : R;
-    if (tv && n_tv > work) work = n_tv;
-    int nblk = spf::div_up(work, 256 * 4);
-    nblk = nblk < 1 ? 1 : (nblk > MAX_BLOCKS ? MAX_BLOCKS : nblk);
+    const int nblk = loss_blocks(R, grad ? rows : 0, tv ? n_tv : 0);
     loss_partials_kernel<<<nblk, 256, 0, s>>>(rgb, rgb_gt, acc, mask_gt, mask_stride, grad, slot_valid, psdf, pvalid, ray_valid, R, rows, tv, tv ? n_tv : 0,
                                            workspace);
-    loss_finalize_kernel<<<1, 64, 0, s>>>(workspace, nblk, R, n_points, tv, n_tv, denom, *weights, total, terms, den);
+    if (total) loss_finalize_kernel<<<1, 64, 0, s>>>(workspace, nblk, R, n_points, tv, n_tv, denom, *weights, total, terms, den);
     SPF_LAUNCH_CHECK("loss_forward");
     return SPF_OK;
 }
@@ -152,8 +191,22 @@ int spf_loss_backward(const float* g_total, const float* den, const spf_loss_wei
     if (R <= 0 || !weights) return spf::fail(SPF_EINVAL, "spf_loss_backward: need R > 0, weights");
     if (!g_total || !den || !rgb || !rgb_gt || !acc || !mask_gt || !g_rgb || !g_acc) return spf::fail(SPF_EINVAL, "spf_loss_backward: null pointer");
     loss_backward_kernel<<<spf::div_up(R, 256), 256, 0, (hipStream_t)stream>>>(g_total, den, *weights, rgb, rgb_gt, acc, mask_gt, mask_stride, psdf, pvalid,
-                                                                               ray_valid, R, g_rgb, g_acc, g_psdf, g_tv, n_tv);
+                                                                               ray_valid, R, g_rgb, g_acc, g_psdf, g_tv, n_tv, LossFin{});
     SPF_LAUNCH_CHECK("loss_backward_kernel");
+    return SPF_OK;
+}
+
+int spf_loss_backward_finalize(const float* g_total, const spf_loss_weights* weights, const float* rgb, const float* rgb_gt, const float* acc,
+                               const float* mask_gt, int32_t mask_stride, const float* psdf, const uint8_t* pvalid, const uint8_t* ray_valid, int32_t R,
+                               float* g_rgb, float* g_acc, float* g_psdf, float* g_tv, int32_t n_tv, const float* workspace, int64_t rows,
+                               const int32_t* n_points, const float* tv, const float* denom, float* total, float* terms, float* den, void* stream) {
+    if (R <= 0 || !weights || rows < 0 || n_tv < 0) return spf::fail(SPF_EINVAL, "spf_loss_backward_finalize: need R > 0, rows >= 0, n_tv >= 0, weights");
+    if (!g_total || !rgb || !rgb_gt || !acc || !mask_gt || !g_rgb || !g_acc || !workspace || !total || !terms || !den)
+        return spf::fail(SPF_EINVAL, "spf_loss_backward_finalize: null pointer");
+    LossFin fin{workspace, loss_blocks(R, rows, tv ? n_tv : 0), R, n_points, tv, n_tv, denom, total, terms, den};
+    loss_backward_kernel<<<spf::div_up(R, 256), 256, 0, (hipStream_t)stream>>>(g_total, nullptr, *weights, rgb, rgb_gt, acc, mask_gt, mask_stride, psdf, pvalid,
+                                                                               ray_valid, R, g_rgb, g_acc, g_psdf, g_tv, n_tv, fin);
+    SPF_LAUNCH_CHECK("loss_backward_kernel<finalize>");
     return SPF_OK;
 }
 

@@ -9,43 +9,18 @@
 //   composites        spurfies/model/pointneus_disent.py:765-795 (dist_map, rgb, depth, acc)
 // and autograd's backward through them (the reference runs ~60 elementwise / cumsum launches).
 #include "common.h"
+#include "grid_dev.h"
 
 namespace {
 using namespace spf;
 
-// ---- filter_points: t = nanmean_xyz((p - o)/d), z = t at valid slots else 0, delta_j = max(z_{j+1} - z_j, 0)
-//      (z_SR := 0; delta = 0 at invalid slots), x = o + z d.  One thread per slot.
-__device__ __forceinline__ float slot_t(const float* __restrict__ loc, const float* o, const float* d) {
-    float s = 0.f;
-    int n = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v = (loc[c] - o[c]) / d[c];
-        if (v == v) {  // nanmean skips NaN (0/0 when a direction component is exactly 0)
-            s += v;
-            ++n;
-        }
-    }
-    return s / (float)n;  // n == 0 -> NaN, as torch.nanmean
-}
-
+// ---- filter_points: one thread per slot (grid_dev.h: filter_slot) -----------------------------------------------------------------
 __global__ void filter_points_kernel(const float* __restrict__ loc, const uint8_t* __restrict__ valid,
                                      const float* __restrict__ cam_loc, const float* __restrict__ ray_dirs, int R, int SR,
                                      float* __restrict__ z, float* __restrict__ deltas, float* __restrict__ x) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)R * SR) return;
-    const int r = (int)(gid / SR), s = (int)(gid % SR);
-    const float o[3] = {cam_loc[3 * r], cam_loc[3 * r + 1], cam_loc[3 * r + 2]};
-    const float d[3] = {ray_dirs[3 * r], ray_dirs[3 * r + 1], ray_dirs[3 * r + 2]};
-    const bool v = valid[gid] != 0;
-    const float t = v ? slot_t(loc + gid * 3, o, d) : 0.f;
-    float tn = 0.f;
-    if (s + 1 < SR && valid[gid + 1]) tn = slot_t(loc + (gid + 1) * 3, o, d);
-    z[gid] = t;
-    deltas[gid] = v ? fmaxf(tn - t, 0.f) : 0.f;
-    x[gid * 3] = o[0] + t * d[0];
-    x[gid * 3 + 1] = o[1] + t * d[1];
-    x[gid * 3 + 2] = o[2] + t * d[2];
+    filter_slot(gid, valid, FilterArgs{loc, cam_loc, ray_dirs, z, deltas, x, SR});
 }
 
 __device__ __forceinline__ float wave_excl_scan(float v, int lane, float& total) {

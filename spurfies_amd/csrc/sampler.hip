@@ -10,6 +10,7 @@
 #include <cfloat>
 
 #include "common.h"
+#include "grid_dev.h"
 
 namespace {
 using namespace spf;
@@ -61,14 +62,37 @@ __global__ void uniform_kernel(const float* __restrict__ tlin, const float* __re
     for (int c = 0; c < 3; ++c) points[gid * 3 + c] = cam_loc[3 * r + c] + z * ray_dirs[3 * r + c];
 }
 
-// ---- stage 1: d*, beta bisection, weights, pdf/cdf, inverse CDF (+ merge when another iteration follows) ----
-template <int E>
+// Round 5, the optimisation step's sampler pass (fast = 1: ONE iteration that goes straight to the final sampling) as one launch instead of
+// four: FUSED adds, in front, the per-point reduction of the geometry kernel's per-pair scratch (geo_point_reduce_kernel's sums, same order:
+// sdf = sum_j w_j sdf_j / sum_j w_j over the sample's pairs, 1000 where the sample has no neighbour) and, behind the inverse CDF, the work of
+// sampler_finish_kernel (rank sort of [samples | near | far | z[sel]], the main-pass points o + z d) and of grid.hip's hit_slots_kernel (the
+// ray's first SR samples inside the dilated occupancy get slots 0..): the chain reduce -> iterate -> finish -> hit_slots was 4 launches of
+// 5 - 18 us each on the critical path of a 1 ms step (128 rays per GPU).
+struct SamplerTail {
+    const float* pair_tmp;        // [pairs, GEO_PT_STRIDE] = {w, sdf_j, ...} from spf_geo_forward(sdf = NULL)
+    const int32_t* pair_off;      // [points + 1]
+    const int32_t* slot_point;    // [R * n]: point id of a sample or -1
+    const int32_t* sel;           // [Ne] extra samples of the current z
+    int Ne;
+    float near, far;
+    const float* cam_loc;
+    const float* ray_dirs;
+    float* z_out;                 // [R, N + 2 + Ne]
+    float* points;                // [R, N + 2 + Ne, 3]
+    GridDev grid;
+    int SR;
+    int32_t* slot_sample;         // [R, SR]
+    uint8_t* ray_valid;           // [R] (cleared; the kNN kernel raises it)
+};
+
+template <int E, bool FUSED = false>
 __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restrict__ z_in, const float* __restrict__ sdf_in,
                                                            const float* __restrict__ beta_in, const float* __restrict__ beta0_p, int R, int n,
                                                            float eps, float bound_coef, int beta_iters, int more, float add_tiny,
                                                            const float* __restrict__ u, int u_per_ray, int N, float* __restrict__ samples,
                                                            float* __restrict__ beta_out, float* __restrict__ z_merged,
-                                                           int32_t* __restrict__ merged_idx, int32_t* __restrict__ flags, int it) {
+                                                           int32_t* __restrict__ merged_idx, int32_t* __restrict__ flags, int it,
+                                                           SamplerTail tail) {
     // Device-side loop control (evaluation mode without a host sync per iteration): flags[i] != 0 <=> the sampler loop reaches iteration i.
     // Every pass of iteration `it` needs flags[it]; the sampling passes are additionally tied to the convergence test of the SAME iteration,
     // flags[it + 1] ("beta.max() > beta0", ray_sampler.py:468, set below by the beta-only pass): the merging pass runs iff it is set, the final
@@ -90,7 +114,23 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
     if (active)
         for (int k = lane; k < n; k += 64) {
             zs[k] = z_in[(size_t)r * n + k];
-            ds[k] = sdf_in[(size_t)r * n + k];
+            if (FUSED) {          // geo_point_reduce_kernel's weighted mean of this sample's pairs (same order of additions)
+                const int p = tail.slot_point[(size_t)r * n + k];
+                float v = 1000.0f;                                    // pointneus_disent.py:371 filler
+                if (p >= 0) {
+                    const int q0 = tail.pair_off[p], q1 = tail.pair_off[p + 1];
+                    float nrm = 0.f, acc = 0.f;
+                    for (int q = q0; q < q1; ++q) {
+                        const float w = tail.pair_tmp[(size_t)q * GEO_PT_STRIDE];
+                        nrm += w;
+                        acc += w * tail.pair_tmp[(size_t)q * GEO_PT_STRIDE + 1];
+                    }
+                    v = acc / nrm;
+                }
+                ds[k] = v;
+            } else {
+                ds[k] = sdf_in[(size_t)r * n + k];
+            }
         }
     __syncthreads();
     const float beta0 = *beta0_p;
@@ -224,9 +264,68 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
             if (denom < 1e-5f) denom = 1.f;
             const float t = (uu - cdf[below]) / denom;
             const float s = zs[below] + t * (zs[above] - zs[below]);
-            samples[(size_t)r * N + m] = s;
-            if (more) sm[m] = s;
+            if (!FUSED) samples[(size_t)r * N + m] = s;
+            if (more || FUSED) sm[m] = s;
         }
+    if (FUSED) {
+        // ---- sampler_finish_kernel: z_final = sort([samples | near | far | z[sel]]) by rank counting, points = o + z d -----------------
+        __syncthreads();                                           // cdf is dead from here on: its LDS holds the candidates
+        const int M = N + 2 + tail.Ne;
+        float* c = cdf;                                            // [<= 128] candidates (M <= 128 is checked by the host)
+        float* srt = ds;                                           // [<= 128] sorted (the SDF values are in registers)
+        if (active)
+            for (int q = lane; q < M; q += 64) {
+                float v;
+                if (q < N) v = sm[q];
+                else if (q == N) v = tail.near;
+                else if (q == N + 1) v = tail.far;
+                else v = zs[tail.sel[q - N - 2]];
+                c[q] = v;
+            }
+        __syncthreads();
+        float o3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                o3[k] = tail.cam_loc[3 * r + k];
+                d3[k] = tail.ray_dirs[3 * r + k];
+            }
+            for (int q = lane; q < M; q += 64) {
+                const float v = c[q], kv = okey(v);
+                int rank = 0;
+                for (int pth = 0; pth < M; ++pth) {
+                    const float w = okey(c[pth]);
+                    rank += (w < kv) || (w == kv && pth < q);
+                }
+                const size_t o = (size_t)r * M + rank;
+                tail.z_out[o] = v;
+                srt[rank] = v;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) tail.points[o * 3 + k] = o3[k] + v * d3[k];
+            }
+        }
+        __syncthreads();
+        // ---- hit_slots_kernel: samples are tested 64 at a time in depth order, hits get consecutive slots ----------------------------
+        if (active) {
+            const int SR = tail.SR;
+            if (lane == 0) tail.ray_valid[r] = 0;
+            int count = 0;
+            for (int base = 0; base < M && count < SR; base += 64) {
+                const int d = base + lane;
+                bool hit = false;
+                if (d < M) {
+                    const float v = srt[d];
+                    hit = dil_hit(tail.grid, o3[0] + v * d3[0], o3[1] + v * d3[1], o3[2] + v * d3[2]);
+                }
+                const unsigned long long b = __ballot(hit);
+                const int slot = count + __popcll(b & ((1ull << lane) - 1ull));
+                if (hit && slot < SR) tail.slot_sample[(size_t)r * SR + slot] = d;
+                count += __popcll(b);
+            }
+            for (int sl = min(count, SR) + lane; sl < SR; sl += 64) tail.slot_sample[(size_t)r * SR + sl] = -1;
+        }
+        return;
+    }
     if (more) {  // z_new = sort(cat(z, samples)) as a merge of two sorted lists (:532-533)
         __syncthreads();
         if (active) {
@@ -312,11 +411,29 @@ int spf_sampler_iter(const float* z, const float* sdf, const float* beta_in, con
     hipStream_t s = (hipStream_t)stream;
     if (n <= 128)
         sampler_iter_kernel<2><<<blocks, 256, 0, s>>>(z, sdf, beta_in, beta0, R, n, eps, bound_coef, beta_iters, more, add_tiny, u, u_per_ray, N,
-                                                       samples, beta_out, z_merged, merged_idx, flags, it);
+                                                       samples, beta_out, z_merged, merged_idx, flags, it, SamplerTail{});
     else
         sampler_iter_kernel<10><<<blocks, 256, 0, s>>>(z, sdf, beta_in, beta0, R, n, eps, bound_coef, beta_iters, more, add_tiny, u, u_per_ray, N,
-                                                        samples, beta_out, z_merged, merged_idx, flags, it);
+                                                        samples, beta_out, z_merged, merged_idx, flags, it, SamplerTail{});
     SPF_LAUNCH_CHECK("sampler_iter_kernel");
+    return SPF_OK;
+}
+
+int spf_sampler_train(const float* z, const float* pair_tmp, const int32_t* pair_off, const int32_t* slot_point, const float* beta0, int32_t R,
+                      int32_t n, float eps, float bound_coef, int32_t beta_iters, const float* u, int32_t N, const int32_t* sel, int32_t Ne,
+                      float near, float far, const float* cam_loc, const float* ray_dirs, const spf_grid* grid, int32_t SR, float* beta_out,
+                      float* z_out, float* points, int32_t* slot_sample, uint8_t* ray_valid, void* stream) {
+    if (R < 0 || n < 2 || n > 128 || N < 1 || N > 128 || Ne < 0 || N + 2 + Ne > 128 || SR < 1)
+        return spf::fail(SPF_EINVAL, "spf_sampler_train: need 2 <= n <= 128, 1 <= N, N + 2 + Ne <= 128, SR >= 1");
+    if (R == 0) return SPF_OK;
+    if (!z || !pair_tmp || !pair_off || !slot_point || !beta0 || !u || (Ne > 0 && !sel) || !cam_loc || !ray_dirs || !grid || !beta_out || !z_out || !points ||
+        !slot_sample || !ray_valid)
+        return spf::fail(SPF_EINVAL, "spf_sampler_train: null pointer");
+    if (grid->n_in == 0) return spf::fail(SPF_EINVAL, "spf_sampler_train: the grid holds no points");
+    SamplerTail t{pair_tmp, pair_off, slot_point, sel, Ne, near, far, cam_loc, ray_dirs, z_out, points, spf::dev_view(grid), SR, slot_sample, ray_valid};
+    sampler_iter_kernel<2, true><<<spf::div_up(R, 4), 256, 0, (hipStream_t)stream>>>(z, nullptr, nullptr, beta0, R, n, eps, bound_coef, beta_iters, 0, 0.f, u, 1, N,
+                                                                                     nullptr, beta_out, nullptr, nullptr, nullptr, 0, t);
+    SPF_LAUNCH_CHECK("sampler_iter_kernel<fused>");
     return SPF_OK;
 }
 

@@ -279,6 +279,12 @@ class PointVolSDF(nn.Module):
         # Laplace scale |beta| + beta_min, which the sampler and the compositing kernels read (density.get_beta_value)
         fuse_beta = self.sync_free and self.training and self.density.beta.is_cuda
         beta_fwd = torch.empty((), dtype=torch.float32, device=dev) if fuse_beta else None
+        smp = self.ray_sampler
+        if (fuse_beta and fast == 1 and ops._FUSED_SAMPLER[0] and smp.draws is not None and smp.N_samples_extra > 0
+                and smp.N_samples_eval <= 128 and smp.N_samples + 2 + smp.N_samples_extra <= 128):
+            out = self._forward_train_fused(input, beta_fwd)
+            if out is not None:
+                return out
         rays = ops.camera_rays(uv, pose, intrinsics, self.density.beta, self.density.beta_min_value, beta_fwd)
         self.density._beta_forward = beta_fwd if rays is not None else None
         try:
@@ -295,7 +301,40 @@ class PointVolSDF(nn.Module):
         finally:
             self.density._beta_forward = None
 
-    def render_points(self, points, ray_dirs, cam_loc, depth_scale, local_data=None):
+    def _forward_train_fused(self, input, beta_fwd):
+        """The optimisation step's forward (sync-free, fast = 1) with the sampler chain as fused launches (round 5): camera rays + uniform
+        samples in one launch; the SDF kernel without its per-point reduction; then ONE launch that reduces, finds beta, draws the samples,
+        sorts them, forms the main-pass points and assigns the main pass's kNN slots (spf_sampler_train) — 12 launches -> 7 between the start of
+        the step and the main pass's geometry kernel, same values (tests/test_gpu_sampler.py).  None: shapes the fused form does not cover."""
+        dev = self.neural_pts.device
+        conf, smp = self.conf, self.ray_sampler
+        ext = smp.draws
+        n0 = smp.N_samples_eval
+        res = ops.camera_uniform(input["uv"], input["pose"], input["intrinsics"], self.density.beta, self.density.beta_min_value, beta_fwd,
+                                 smp._linspace(n0, dev), ext["t_rand"], smp.near, smp.far)
+        if res is None:
+            return None
+        ray_dirs, cam_loc, depth_scale, z_vals, pts0 = res
+        R = ray_dirs.shape[0]
+        grid = self._grid()
+        self.density._beta_forward = beta_fwd
+        try:
+            with torch.no_grad():
+                x0 = pts0.view(-1, 3)
+                q0 = grid.query_dense(x0.unsqueeze(1), conf.k, conf.r, 1)
+                pl0 = ops.PairList.from_slots(q0["slot_valid"], q0["pidx"].view(-1, conf.k), sync=self._cp_sync.get("sampler", dev, x0.shape[0]))
+                tmp = ops.geo_forward(x0, pl0, self.neural_pts, self.neural_feats_geometry.detach(), self._packed(), float(conf.rbf), with_grad=False,
+                                      reduce=False)["pair_tmp"]
+                _, z_out, points, slot_sample, ray_valid = ops.sampler_train(z_vals, tmp, pl0, beta_fwd.reshape(1), smp.eps, smp._bound_coef, smp.beta_iters,
+                                                                              ext["u"], ext["sel"], smp.near, smp.far, cam_loc, ray_dirs, grid._h,
+                                                                              conf.max_shading_pts)
+            smp.last_iters = 1
+            smp.last_points = points
+            return self.render_points(points, ray_dirs, cam_loc, depth_scale, input.get("local_data"), slots=(slot_sample, ray_valid))
+        finally:
+            self.density._beta_forward = None
+
+    def render_points(self, points, ray_dirs, cam_loc, depth_scale, local_data=None, slots=None):
         """Everything of forward() behind the sampler (:654-892): main-pass kNN of the sample positions `points` [R,D,3] (the
         sampler's o + z d), filter_points, SDF + normals + colours at the hits, compositing, the pseudo-point / local / TV terms
         and the output dict.  Split out so that a stage test can feed recorded sample positions."""
@@ -318,7 +357,7 @@ class PointVolSDF(nn.Module):
                 tv_early = self.tv_graph().loss(self.neural_feats_geometry, reduce=False)
 
         # ---- kNN of the main pass, dense [R,SR] ------------------------------------------------
-        q = grid.query_dense(points.detach(), k, conf.r, SR)
+        q = grid.query_dense(points.detach(), k, conf.r, SR, slots=slots)
         # evaluation needs no exact-size training buffers either: worst-case colour buffers + device-side counts, no host read-back
         dense = static or not self.training
         # the bool forms of the two masks are read by the reference-shaped outputs only (two conversion launches)
@@ -326,12 +365,13 @@ class PointVolSDF(nn.Module):
         ray_mask = None if static else q["ray_valid"].bool()      # [R]
         sdf_buf = torch.empty((R * SR,), dtype=torch.float32, device=dev)
         grad_buf = torch.empty((R * SR, 3), dtype=torch.float32, device=dev)
+        fuse_filter = static and ops._FUSED_SAMPLER[0]            # filter_points (:207-239) rides in the compaction launch
         pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(R * SR, k), fill_sdf=sdf_buf, fill_grad=grad_buf,
-                                     sync=self._cp_sync.get("main", dev, R * SR))
+                                     sync=self._cp_sync.get("main", dev, R * SR), filt=(q["loc"], cam_loc, ray_dirs) if fuse_filter else None)
         point_slot = pl.point_slot
 
         # ---- filter_points (:207-239) on dense rows (HIP) ---------------------------------------
-        z_slots, deltas, x = ops.filter_points(q["loc"], q["slot_valid"], cam_loc.detach(), ray_dirs.detach())
+        z_slots, deltas, x = pl.filtered if pl.filtered is not None else ops.filter_points(q["loc"], q["slot_valid"], cam_loc.detach(), ray_dirs.detach())
 
         # ---- geometry: sdf, d sdf/d x, normalised RBF weights (HIP) -----------------------------
         sdf_flat, gradients, wn = ops.GeoSDF.apply(x, self.neural_feats_geometry, pl, self.neural_pts, self._packed(), float(conf.rbf), sdf_buf, grad_buf)

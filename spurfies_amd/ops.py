@@ -277,12 +277,14 @@ class PairList:
                                                   _lib.ptr(scratch), _lib.stream_ptr()), "spf_build_pairs")
 
     @classmethod
-    def from_slots(cls, slot_valid, nbr, fill_sdf=None, fill_grad=None, gate=None, sync=None):
+    def from_slots(cls, slot_valid, nbr, fill_sdf=None, fill_grad=None, gate=None, sync=None, filt=None):
         """Valid-point compaction AND the pair list of a kNN result in one pair of launches (spf_compact_pairs): slot_valid uint8 [R,SR],
         nbr int32 [R*SR,k] indexed by slot; optional uninitialised fill_sdf [R*SR] / fill_grad [R*SR,3] receive the 1000 filler / zeros.
         gate: device int32 [1]; 0 reports empty lists (the MLP kernels behind this pass then do nothing).
         sync: the caller's OWN zero-on-entry word buffer for the one-launch form (CompactSync.get); None = a per-stream fallback buffer
-        (eager launches) or the two-launch form (under graph capture)."""
+        (eager launches) or the two-launch form (under graph capture).
+        filt: (loc [R,SR,3], cam_loc [R,3], ray_dirs [R,3]) — filter_points (pointneus_disent.py:207-239) rides in the same launch;
+        its outputs land in self.filtered = (z [R,SR], deltas [R,SR], x [R*SR,3])."""
         R, SR = slot_valid.shape
         rows, k = nbr.shape
         dev = nbr.device
@@ -296,12 +298,25 @@ class PairList:
         self.pair_off = torch.empty((rows + 1,), dtype=torch.int32, device=dev)
         self.pair_point = torch.empty((self.max_pairs,), dtype=torch.int32, device=dev)
         scratch = torch.empty((2 * (rows // 2048 + 2),), dtype=torch.int32, device=dev)
+        sync_buf = sync if (sync is not None and _COMPACT_ONE_LAUNCH[0]) else _compact_sync(dev, rows)
+        self.filtered = None
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().spf_compact_pairs(_lib.ptr(slot_valid), _lib.ptr(nbr), R, SR, k, _lib.ptr(self.point_slot), _lib.ptr(self.slot_point),
-                                                    _lib.ptr(self.pair_off), _lib.ptr(self.pair_point), _lib.ptr(self.counts), _lib.ptr(scratch),
-                                                    _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad), _lib.ptr(gate),
-                                                    _lib.ptr(sync if (sync is not None and _COMPACT_ONE_LAUNCH[0]) else _compact_sync(dev, rows)),
-                                                    _lib.stream_ptr()), "spf_compact_pairs")
+            if filt is not None:
+                loc, cam_loc, ray_dirs = (t.detach().contiguous() for t in filt)
+                z = torch.empty((R, SR), dtype=torch.float32, device=dev)
+                deltas = torch.empty((R, SR), dtype=torch.float32, device=dev)
+                xs = torch.empty((R * SR, 3), dtype=torch.float32, device=dev)
+                _lib.check(_lib.lib().spf_compact_pairs_filter(_lib.ptr(slot_valid), _lib.ptr(nbr), R, SR, k, _lib.ptr(self.point_slot), _lib.ptr(self.slot_point),
+                                                               _lib.ptr(self.pair_off), _lib.ptr(self.pair_point), _lib.ptr(self.counts), _lib.ptr(scratch),
+                                                               _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad), _lib.ptr(gate), _lib.ptr(sync_buf),
+                                                               _lib.ptr(loc), _lib.ptr(cam_loc), _lib.ptr(ray_dirs), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(xs),
+                                                               _lib.stream_ptr()), "spf_compact_pairs_filter")
+                self.filtered = (z, deltas, xs)
+            else:
+                _lib.check(_lib.lib().spf_compact_pairs(_lib.ptr(slot_valid), _lib.ptr(nbr), R, SR, k, _lib.ptr(self.point_slot), _lib.ptr(self.slot_point),
+                                                        _lib.ptr(self.pair_off), _lib.ptr(self.pair_point), _lib.ptr(self.counts), _lib.ptr(scratch),
+                                                        _lib.ptr(fill_sdf), SDF_FILL, _lib.ptr(fill_grad), _lib.ptr(gate), _lib.ptr(sync_buf),
+                                                        _lib.stream_ptr()), "spf_compact_pairs")
         return self
 
     def host_counts(self):
@@ -369,13 +384,19 @@ def pack_geometry_weights(state: dict) -> torch.Tensor:
     return packed
 
 
-def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_out=None, grad_out=None):
+def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_out=None, grad_out=None, reduce=True):
     """Rows = first dim of x / nbr.  Returns dict(sdf [rows] (1000 where not a valid point), grad [rows,3] | None,
-    wn [max_pairs], jac [max_pairs,32] | None).  sdf_out / grad_out: buffers already holding the filler (compact_points(fill_*))."""
+    wn [max_pairs], jac [max_pairs,32] | None).  sdf_out / grad_out: buffers already holding the filler (compact_points(fill_*)).
+    reduce=False (no grad): the per-point reduction is left to the consumer (sampler_train); the result is 'pair_tmp' [max_pairs,5]."""
     rows = pl.nbr.shape[0]
     dev = x.device
-    sdf = sdf_out if sdf_out is not None else torch.full((rows,), SDF_FILL, dtype=torch.float32, device=dev)
-    wn = torch.empty((pl.max_pairs,), dtype=torch.float32, device=dev)
+    if not reduce:
+        if with_grad:
+            raise ValueError("geo_forward(reduce=False) is the SDF-only form")
+        sdf = None
+    else:
+        sdf = sdf_out if sdf_out is not None else torch.full((rows,), SDF_FILL, dtype=torch.float32, device=dev)
+    wn = torch.empty((pl.max_pairs,), dtype=torch.float32, device=dev) if reduce else None
     grad = (grad_out if grad_out is not None else torch.zeros((rows, 3), dtype=torch.float32, device=dev)) if with_grad else None
     jac = torch.empty((pl.max_pairs, 32), dtype=torch.float32, device=dev) if with_grad else None
     tmp = torch.empty((pl.max_pairs, 5), dtype=torch.float32, device=dev)
@@ -384,7 +405,7 @@ def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_ou
                                               _lib.ptr(pl.n_points), _lib.ptr(pl.n_pairs), pl.max_points, pl.max_pairs, pl.k, _lib.ptr(pts),
                                               _lib.ptr(feat_geo), _lib.ptr(packed), float(rbf), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(wn),
                                               _lib.ptr(jac), _lib.ptr(tmp), _ARITH["geo"] | (0x100 if _GEO_CLOCK[0] else 0), _lib.stream_ptr()), "spf_geo_forward")
-    return {"sdf": sdf, "wn": wn, "grad": grad, "jac": jac}
+    return {"sdf": sdf, "wn": wn, "grad": grad, "jac": jac, "pair_tmp": tmp}
 
 
 # ---- latent-gradient scatter: float atomics (default) or order-independent fixed-point accumulation --------------------------
@@ -893,6 +914,28 @@ def sampler_iter(z, sdf, beta_in, beta0, eps, bound_coef, beta_iters, more, add_
     return samples, beta, zm, mi
 
 
+def sampler_train(z, pair_tmp, pl, beta0, eps, bound_coef, beta_iters, u, sel, near, far, cam_loc, ray_dirs, grid_handle, SR):
+    """The optimisation step's sampler pass behind the SDF kernel as ONE launch (include/spurfies_hip.h: spf_sampler_train): per-sample SDF from
+    the geometry kernel's per-pair scratch, beta + inverse-CDF samples, the sorted z / main-pass points and the main pass's slot assignment.
+    -> (beta [R], z_out [R,M], points [R,M,3], slot_sample int32 [R,SR], ray_valid uint8 [R] (cleared))."""
+    R, n = z.shape
+    N = u.shape[1]
+    Ne = 0 if sel is None else sel.shape[0]
+    M = N + 2 + Ne
+    dev = z.device
+    beta = torch.empty((R,), dtype=torch.float32, device=dev)
+    z_out = torch.empty((R, M), dtype=torch.float32, device=dev)
+    pts = torch.empty((R, M, 3), dtype=torch.float32, device=dev)
+    slot_sample = torch.empty((R, SR), dtype=torch.int32, device=dev)
+    ray_valid = torch.empty((R,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_sampler_train(_lib.ptr(z), _lib.ptr(pair_tmp), _lib.ptr(pl.pair_off), _lib.ptr(pl.slot_point), _lib.ptr(beta0), R, n, float(eps),
+                                                float(bound_coef), int(beta_iters), _lib.ptr(u), N, _lib.ptr(sel), Ne, float(near), float(far), _lib.ptr(cam_loc),
+                                                _lib.ptr(ray_dirs), grid_handle, int(SR), _lib.ptr(beta), _lib.ptr(z_out), _lib.ptr(pts), _lib.ptr(slot_sample),
+                                                _lib.ptr(ray_valid), _lib.stream_ptr()), "spf_sampler_train")
+    return beta, z_out, pts, slot_sample, ray_valid
+
+
 def sampler_finish(z_samples, z_vals, sel, near, far, cam_loc, ray_dirs, flags=None, it=0, out=None):
     """flags / it: runs only behind the final sampling pass of iteration `it` (spf_sampler_iter); out = (z_out, points) to write into."""
     R, Ns = z_samples.shape
@@ -1149,15 +1192,59 @@ def camera_rays(uv, pose, intrinsics, beta_param=None, beta_min=0.0, beta_out=No
     return dirs, loc, scale
 
 
+def camera_uniform(uv, pose, intrinsics, beta_param, beta_min, beta_out, tlin, t_rand, near, far):
+    """camera_rays + sampler_uniform in one launch (spf_camera_uniform) -> (ray_dirs, cam_loc, depth_scale, z [R,n], points [R,n,3]); None for
+    multi-view batches / quaternion poses (as camera_rays)."""
+    if uv.dim() != 3 or uv.shape[0] != 1 or pose.shape[-2:] != (4, 4) or not uv.is_cuda:
+        return None
+    R, dev, n = uv.shape[1], uv.device, tlin.shape[0]
+    uv_c = uv.detach().reshape(R, 2).float().contiguous()
+    pose_c = pose.detach().reshape(4, 4).float().contiguous()
+    K = intrinsics.detach().float()
+    ks = K.shape[-1]
+    K = K.reshape(ks, ks).contiguous()
+    dirs = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    loc = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    scale = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    z = torch.empty((R, n), dtype=torch.float32, device=dev)
+    pts = torch.empty((R, n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_camera_uniform(_lib.ptr(uv_c), _lib.ptr(pose_c), _lib.ptr(K), ks, R, _lib.ptr(dirs), _lib.ptr(loc), _lib.ptr(scale),
+                                                 _lib.ptr(None if beta_out is None else beta_param.detach()), float(beta_min), _lib.ptr(beta_out), _lib.ptr(tlin),
+                                                 _lib.ptr(t_rand), n, float(near), float(far), _lib.ptr(z), _lib.ptr(pts), _lib.stream_ptr()), "spf_camera_uniform")
+    return dirs, loc, scale, z, pts
+
+
+_FUSED_SAMPLER = [True]
+
+
+def set_fused_sampler(on=True):
+    """The optimisation step's sampler chain as fused launches (camera + uniform; reduce + iterate + finish + slot assignment; compaction +
+    filter_points) — default — or as the separate launches (tests compare both: same bits)."""
+    _FUSED_SAMPLER[0] = bool(on)
+
+
 _loss_ws = {}
 
 
-class FusedLoss(torch.autograd.Function):
+_DEFER_LOSS = [True]
+
+
+def set_loss_finalize_deferred(on=True):
+    """FusedLoss: form the loss terms inside the backward launch (default; 2 launches per step) or in a finalize launch of the forward (3)."""
+    _DEFER_LOSS[0] = bool(on)
+
+
+class FusedLoss(_GradModeFunction):
     """(total [], terms [8]) = spf_loss_forward(...); differentiable w.r.t. rgb, acc, psdf and tv (spf_loss_backward).
-    terms = {loss, rgb, eikonal, tv, mask, local, pseudo, pseudo count} (values only)."""
+    terms = {loss, rgb, eikonal, tv, mask, local, pseudo, pseudo count} (values only).
+    When a backward can follow (grad mode on, a differentiable input), the forward only launches the partial sums and the BACKWARD launch forms
+    the terms on its way (spf_loss_backward_finalize): `total` / `terms` then hold their values once the backward has run — an optimisation step
+    always runs it; a caller that wants the loss without a backward calls this under torch.no_grad()."""
 
     @staticmethod
-    def forward(ctx, rgb, acc, psdf, tv, grad, slot_valid, n_points, pvalid, ray_valid, rgb_gt, mask_gt, mask_stride, weights, denom):
+    def forward(ctx, rgb, acc, psdf, tv, grad, slot_valid, n_points, pvalid, ray_valid, rgb_gt, mask_gt, mask_stride, weights, denom, allow_defer=True):
+        """allow_defer=False: `total` is read by further forward ops (the feature-consistency term is added to it): finalize in the forward."""
         dev = rgb.device
         R = rgb.shape[0]
         rgb_c, acc_c = rgb.detach().contiguous(), acc.detach().reshape(R).contiguous()
@@ -1171,14 +1258,16 @@ class FusedLoss(torch.autograd.Function):
         terms = torch.empty((8,), dtype=torch.float32, device=dev)
         den = torch.empty((4,), dtype=torch.float32, device=dev)
         rows = 0 if grad is None else grad.shape[0]
+        defer = bool(allow_defer) and _DEFER_LOSS[0] and _GradModeFunction._outer_grad_mode and any(ctx.needs_input_grad[:4])
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_loss_forward(_lib.ptr(rgb_c), _lib.ptr(rgb_gt), _lib.ptr(acc_c), _lib.ptr(mask_gt), mask_stride,
                                                    _lib.ptr(grad), _lib.ptr(slot_valid), rows, _lib.ptr(n_points), _lib.ptr(psdf_c),
                                                    _lib.ptr(pvalid), _lib.ptr(ray_valid), _lib.ptr(tv_c), n_tv, _lib.ptr(denom), R, weights,
-                                                   _lib.ptr(_loss_ws[key]), _lib.ptr(total), _lib.ptr(terms), _lib.ptr(den),
-                                                   _lib.stream_ptr()), "spf_loss_forward")
+                                                   _lib.ptr(_loss_ws[key]), None if defer else _lib.ptr(total), None if defer else _lib.ptr(terms),
+                                                   None if defer else _lib.ptr(den), _lib.stream_ptr()), "spf_loss_forward")
         ctx.save_for_backward(rgb_c, acc_c, psdf_c, rgb_gt, mask_gt, pvalid, ray_valid, den)
         ctx.misc = (mask_stride, weights, acc.shape, None if psdf is None else psdf.shape, tv is not None, n_tv)
+        ctx.fin = (_loss_ws[key], rows, n_points, tv_c, denom, total, terms) if defer else None
         ctx.mark_non_differentiable(terms)
         ctx.set_materialize_grads(False)
         return total, terms
@@ -1189,17 +1278,25 @@ class FusedLoss(torch.autograd.Function):
         mask_stride, weights, acc_shape, psdf_shape, has_tv, n_tv = ctx.misc
         R, dev = rgb.shape[0], rgb.device
         if g_total is None:
-            return (None,) * 14
+            return (None,) * 15
         g = g_total.detach().reshape(1).contiguous()
         g_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
         g_acc = torch.empty((R,), dtype=torch.float32, device=dev)
         g_psdf = None if psdf is None else torch.empty((R,), dtype=torch.float32, device=dev)
         g_tv = torch.empty((1,), dtype=torch.float32, device=dev) if has_tv else None
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().spf_loss_backward(_lib.ptr(g), _lib.ptr(den), weights, _lib.ptr(rgb), _lib.ptr(rgb_gt), _lib.ptr(acc),
-                                                    _lib.ptr(mask_gt), mask_stride, _lib.ptr(psdf), _lib.ptr(pvalid), _lib.ptr(ray_valid), R,
-                                                    _lib.ptr(g_rgb), _lib.ptr(g_acc), _lib.ptr(g_psdf), _lib.ptr(g_tv), n_tv, _lib.stream_ptr()),
-                       "spf_loss_backward")
+            if ctx.fin is not None:
+                ws, rows, n_points, tv_c, denom, total, terms = ctx.fin
+                _lib.check(_lib.lib().spf_loss_backward_finalize(_lib.ptr(g), weights, _lib.ptr(rgb), _lib.ptr(rgb_gt), _lib.ptr(acc), _lib.ptr(mask_gt), mask_stride,
+                                                                 _lib.ptr(psdf), _lib.ptr(pvalid), _lib.ptr(ray_valid), R, _lib.ptr(g_rgb), _lib.ptr(g_acc),
+                                                                 _lib.ptr(g_psdf), _lib.ptr(g_tv), n_tv, _lib.ptr(ws), rows, _lib.ptr(n_points), _lib.ptr(tv_c),
+                                                                 _lib.ptr(denom), _lib.ptr(total), _lib.ptr(terms), _lib.ptr(den), _lib.stream_ptr()),
+                           "spf_loss_backward_finalize")
+            else:
+                _lib.check(_lib.lib().spf_loss_backward(_lib.ptr(g), _lib.ptr(den), weights, _lib.ptr(rgb), _lib.ptr(rgb_gt), _lib.ptr(acc),
+                                                        _lib.ptr(mask_gt), mask_stride, _lib.ptr(psdf), _lib.ptr(pvalid), _lib.ptr(ray_valid), R,
+                                                        _lib.ptr(g_rgb), _lib.ptr(g_acc), _lib.ptr(g_psdf), _lib.ptr(g_tv), n_tv, _lib.stream_ptr()),
+                           "spf_loss_backward")
         g_tv_out = None if g_tv is None else (g_tv.expand(n_tv) if n_tv else g_tv.reshape(()))      # per-point array: one value, stride 0
         return (g_rgb, g_acc.view(acc_shape), None if g_psdf is None else g_psdf.view(psdf_shape), g_tv_out,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)

@@ -98,9 +98,10 @@ class VoxelGrid:
         return d["pidx"][keep].unsqueeze(0), d["loc"][keep].unsqueeze(0), d["ray_valid"].to(torch.int8).unsqueeze(0)
 
     # ------------------------------------------------------------------ native (no-sync) form
-    def query_dense(self, raypos, k, radius_limit_scale, max_shading_points_per_ray):
+    def query_dense(self, raypos, k, radius_limit_scale, max_shading_points_per_ray, slots=None):
         """raypos float32 [R,D,3] -> dict of worst-case-sized device tensors (no host sync):
-        pidx [R,SR,k] i32, loc [R,SR,3] f32, slot_sample [R,SR] i32, slot_valid [R,SR] u8, ray_valid [R] u8."""
+        pidx [R,SR,k] i32, loc [R,SR,3] f32, slot_sample [R,SR] i32, slot_valid [R,SR] u8, ray_valid [R] u8.
+        slots: (slot_sample int32 [R,SR], ray_valid uint8 [R] cleared) assigned by the caller (spf_sampler_train): only the neighbour search runs."""
         if self._built_for is None:
             raise RuntimeError("VoxelGrid.query before set_pointset")
         x = raypos
@@ -113,15 +114,22 @@ class VoxelGrid:
         out = {
             "pidx": torch.empty((R, SR, k), dtype=torch.int32, device=dev),
             "loc": torch.empty((R, SR, 3), dtype=torch.float32, device=dev),
-            "slot_sample": torch.empty((R, SR), dtype=torch.int32, device=dev),
+            "slot_sample": torch.empty((R, SR), dtype=torch.int32, device=dev) if slots is None else slots[0],
             "slot_valid": torch.empty((R, SR), dtype=torch.uint8, device=dev),
-            "ray_valid": torch.empty((R,), dtype=torch.uint8, device=dev),
+            "ray_valid": torch.empty((R,), dtype=torch.uint8, device=dev) if slots is None else slots[1],
         }
         with torch.cuda.device(dev), _prof.span("knn", rays=R, samples_per_ray=D, slots=SR, k=k, hit_slots=out["slot_valid"]):
-            _lib.check(_lib.lib().spf_grid_query(self._h, _lib.ptr(x), R, D, k, float(radius_limit_scale), SR,
-                                                 _lib.ptr(out["pidx"]), _lib.ptr(out["loc"]), _lib.ptr(out["slot_sample"]),
-                                                 _lib.ptr(out["slot_valid"]), _lib.ptr(out["ray_valid"]), _lib.stream_ptr()),
-                       "spf_grid_query")
+            if slots is None:
+                _lib.check(_lib.lib().spf_grid_query(self._h, _lib.ptr(x), R, D, k, float(radius_limit_scale), SR,
+                                                     _lib.ptr(out["pidx"]), _lib.ptr(out["loc"]), _lib.ptr(out["slot_sample"]),
+                                                     _lib.ptr(out["slot_valid"]), _lib.ptr(out["ray_valid"]), _lib.stream_ptr()),
+                           "spf_grid_query")
+            else:
+                if tuple(slots[0].shape) != (R, SR) or slots[0].dtype != torch.int32 or tuple(slots[1].shape) != (R,):
+                    raise ValueError("query_dense: slots = (int32 [R,SR], uint8 [R])")
+                _lib.check(_lib.lib().spf_grid_knn(self._h, _lib.ptr(x), R, D, k, float(radius_limit_scale), SR, _lib.ptr(slots[0]),
+                                                   _lib.ptr(out["pidx"]), _lib.ptr(out["loc"]), _lib.ptr(out["slot_valid"]), _lib.ptr(out["ray_valid"]),
+                                                   _lib.stream_ptr()), "spf_grid_knn")
         return out
 
     def info(self):

@@ -143,3 +143,52 @@ def test_graphed_eval_render_equals_eager_render():
             assert torch.allclose(oe[k], og[k], rtol=1e-4, atol=1e-6, equal_nan=True), k
     with pytest.raises(ValueError):
         renderer({"intrinsics": K, "uv": chunks[0]["uv"][:, :100], "pose": chunks[0]["pose"]})
+
+
+def test_fused_training_sampler_chain_gives_the_bits_of_the_separate_launches():
+    """Round 5: the optimisation step's sampler chain as fused launches — camera rays + uniform samples; per-point reduce + beta + inverse CDF +
+    finish + slot assignment (spf_sampler_train); compaction + filter_points; loss terms formed inside the backward launch — against the
+    separate launches on the same batch and draws: sample positions, slots, neighbours, filter_points outputs, SDF and compositing weights
+    bit for bit; colours / loss / gradients up to float-atomic order."""
+    from spurfies_amd import ops
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.conf import default_model_conf
+    from spurfies_amd.model.pointneus_disent import PointVolSDF
+    from spurfies_amd.train import TrainStep
+
+    scene = syn.make_scene(4000, seed=21, prior="fitted")
+    st = scene["state"]
+    g = torch.Generator().manual_seed(2)
+    uv = torch.from_numpy(syn.make_pixels(200, g))[None].cuda()
+    K, pose = torch.from_numpy(scene["intrinsics"])[None].cuda(), torch.from_numpy(scene["poses"][0])[None].cuda()
+    gt = {"rgb": torch.rand((200, 3), generator=g)[None].cuda(), "mask": (torch.rand((200,), generator=g) > 0.2).float()[None, :, None].repeat(1, 1, 3).cuda()}
+    res = []
+    try:
+        for fused in (False, True):
+            ops.set_fused_sampler(fused)
+            ops.set_loss_finalize_deferred(fused)
+            model = PointVolSDF(default_model_conf(near=0.5, grid_ranges=list(scene["ranges"])), 24, "dtu",
+                                neural_points={"pts": st["neural_pts"], "colors": scene["colors"]})
+            model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
+            model.keep_stages = True
+            step = TrainStep(model, sync_free=True, keep_grads=True)
+            torch.manual_seed(7)
+            losses, out = step({"intrinsics": K, "uv": uv, "pose": pose, "local_data": None}, gt)
+            after = torch.rand(1).item()
+            torch.cuda.synchronize()
+            res.append((model.ray_sampler.last_points.clone(), {k: v.clone() for k, v in model.stages.items()}, out["weights"].detach().clone(),
+                        {k: float(v.item()) for k, v in losses.items()}, step.flat.buffer.clone(), after, out["rgb_values"].detach().clone()))
+    finally:
+        ops.set_fused_sampler(True)
+        ops.set_loss_finalize_deferred(True)
+    (p0, s0, w0, l0, g0, a0, rgb0), (p1, s1, w1, l1, g1, a1, rgb1) = res
+    assert a0 == a1, "the fused chain must consume the CPU generator like the separate launches"
+    assert torch.equal(p0, p1), "main-pass sample positions"
+    for k in ("pidx", "loc", "slot_valid", "ray_valid", "x", "z_slots", "deltas", "sdf", "gradients"):
+        assert torch.equal(s0[k], s1[k]), k
+    assert torch.equal(w0, w1), "compositing weights"
+    assert int(s0["slot_valid"].sum()) > 1000
+    np.testing.assert_allclose(rgb1.cpu().numpy(), rgb0.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    for k in l0:
+        np.testing.assert_allclose(l1[k], l0[k], rtol=1e-5, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=2e-3, atol=2e-5 * float(g0.abs().max()))

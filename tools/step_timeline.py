@@ -19,8 +19,8 @@ def short(name):
     return (base + targ)[:60]
 
 
-# a step starts at camera_rays_kernel
-starts = [i for i, r in enumerate(rows) if "camera_rays_kernel" in r["Kernel_Name"]]
+# a step starts at the ray set-up launch (camera_rays_kernel, or camera_uniform_kernel since round 5)
+starts = [i for i, r in enumerate(rows) if "camera_rays_kernel" in r["Kernel_Name"] or "camera_uniform_kernel" in r["Kernel_Name"]]
 a, b = starts[-back - 1], starts[-back]
 seq = rows[a:b]
 t0 = int(seq[0]["Start_Timestamp"])
