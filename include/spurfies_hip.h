@@ -438,7 +438,7 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
               float* dW, int32_t ldw, float* dbias, float* workspace, int32_t layout, int32_t arith, int32_t col_rot,
               int32_t col_mod, void* stream);
 
-/* Up to SIX weight-gradient GEMMs (three before ABI 5) in one pair of launches, side by side on the chip (each problem gets a share of the
+/* Up to SEVEN weight-gradient GEMMs (three before ABI 5) in one pair of launches, side by side on the chip (each problem gets a share of the
  * workgroups proportional to its work): dW_q += G_q^T A_q, dbias_q += column sums of G_q (may be NULL).  The problems share the call's row
  * count (n_rows / max_rows) unless a problem names its own (ABI 5: spf_wgrad_problem.max_rows > 0, with its n_rows): the head stage's GEMMs
  * (K = valid points) then ride in the colour trunk's launch (K = pairs) — one pipeline ramp, tail and slab reduce per step.
@@ -447,6 +447,7 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
  *   (256, 0)                                         both operands row-major                      (C == 0 means 256)
  *   (256, SPF_WGRAD_G_TILES64 | SPF_WGRAD_A_TILES)   what spf_color_backward / spf_color_forward write for layers 2 and 4
  *   (36..128 step 4, SPF_WGRAD_G_TILES64)            the trunk's first layer (C = 104), A row-major with leading dimension lda
+ *   (4..128 step 4, 0)                               ABI 5: both row-major, narrow A (R.0's view-encoding columns: C = 24, col_mod = 21)
  * with spf_wgrad's col_rot / col_mod per problem; anything else: spf_wgrad.  `problems` is a HOST array; workspace:
  * n_problems * spf_wgrad_workspace_floats(256) floats; tiled operands need (their) max_rows % 64 == 0. */
 struct spf_wgrad_problem {
@@ -522,11 +523,25 @@ int spf_camera_rays(const float* uv, const float* pose, const float* intrinsics,
                     float* beta_out, void* stream);
 
 /* ABI 5: spf_camera_rays and spf_sampler_uniform in one launch (the first two launches of every optimisation step): the same ray arrays,
- * plus z [R,n] and points [R,n,3] of UniformSampler.get_z_vals (ray_sampler.py:33-59; t_rand [R,n] may be NULL). */
+ * plus z [R,n] and points [R,n,3] of UniformSampler.get_z_vals (ray_sampler.py:33-59; t_rand [R,n] may be NULL).
+ * tv_feat != NULL: spf_tv_forward (tv_feat [tv_n,32], tv_nbr / tv_w [tv_n,tv_k], tv_norm [tv_n] -> tv_out [tv_n]) rides in the same launch —
+ * the TV term depends on nothing the step computes.  packs != NULL: so do spf_color_pack and spf_rhead_pack (weights as in those entry
+ * points, `*_zero` = the buffer each of them clears on the way) — the "step prologue": everything that only reads parameters and the batch. */
+typedef struct spf_prologue_packs {
+    const float *cw0, *cb0, *cw2, *cb2, *cw4, *cb4;                 /* F_color.0 / 2 / 4 (spf_color_pack) */
+    float* c_packed;
+    float* c_zero;
+    int64_t c_zero_floats;
+    const float *rw6, *rb6, *rw0, *rb0, *rw2, *rb2, *rw4, *rb4;     /* F_color.6, R.0 / 2 / 4 (spf_rhead_pack) */
+    float* r_packed;
+    float* r_zero;
+    int64_t r_zero_floats;
+} spf_prologue_packs;
 int spf_camera_uniform(const float* uv, const float* pose, const float* intrinsics, int32_t k_stride, int32_t R,
                        float* ray_dirs, float* cam_loc, float* depth_scale, const float* beta_param, float beta_min,
                        float* beta_out, const float* tlin, const float* t_rand, int32_t n, float near, float far, float* z,
-                       float* points, void* stream);
+                       float* points, const float* tv_feat, const int32_t* tv_nbr, const float* tv_w, const float* tv_norm,
+                       int32_t tv_n, int32_t tv_k, float* tv_out, const spf_prologue_packs* packs, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Loss terms of one optimisation step — replaces VolSDFLoss.forward (spurfies/model/loss.py:42-49,
@@ -565,12 +580,14 @@ int spf_loss_backward(const float* g_total, const float* den, const spf_loss_wei
 /* ABI 5: spf_loss_backward behind a partial-sums-only spf_loss_forward — every workgroup derives the normalisers from the workspace's partial
  * sums itself and the first one also writes total / terms / den (the forward's outputs), so the step has no single-block finalize launch
  * between the partial sums and the backward (3 launches -> 2).  rows / n_points / tv / n_tv / denom: as given to spf_loss_forward (rows = 0
- * when it had no grad). */
+ * when it had no grad).  tv_g_feat != NULL (needs the per-point TV form, n_tv > 0): spf_tv_backward with the TV term's gradient rides in the
+ * same launch — tv_g_feat [n_tv,32] += d loss / d tv_i * d tv_i / d latents (float atomics), graph = tv_feat, tv_nbr, tv_w, tv_norm, tv_k. */
 int spf_loss_backward_finalize(const float* g_total, const spf_loss_weights* weights, const float* rgb, const float* rgb_gt,
                                const float* acc, const float* mask_gt, int32_t mask_stride, const float* psdf, const uint8_t* pvalid,
                                const uint8_t* ray_valid, int32_t R, float* g_rgb, float* g_acc, float* g_psdf, float* g_tv, int32_t n_tv,
                                const float* workspace, int64_t rows, const int32_t* n_points, const float* tv, const float* denom,
-                               float* total, float* terms, float* den, void* stream);
+                               float* total, float* terms, float* den, const float* tv_feat, const int32_t* tv_nbr, const float* tv_w,
+                               const float* tv_norm, int32_t tv_k, float* tv_g_feat, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Parameter update — replaces the tail of the reference's train step (spurfies/train.py:359-363, 548-564):

@@ -39,6 +39,12 @@ class WgradProblem(C.Structure):
                 ("C", C.c_int32), ("layout", C.c_int32), ("col_rot", C.c_int32), ("col_mod", C.c_int32), ("n_rows", C.c_void_p), ("max_rows", C.c_int32)]
 
 
+class ProloguePacks(C.Structure):
+    """spf_prologue_packs"""
+    _fields_ = ([(n, C.c_void_p) for n in ("cw0", "cb0", "cw2", "cb2", "cw4", "cb4", "c_packed", "c_zero")] + [("c_zero_floats", C.c_int64)] +
+                [(n, C.c_void_p) for n in ("rw6", "rb6", "rw0", "rb0", "rw2", "rb2", "rw4", "rb4", "r_packed", "r_zero")] + [("r_zero_floats", C.c_int64)])
+
+
 SIGNATURES = {
     "spf_abi_version": (C.c_int, []),
     "spf_last_error": (C.c_char_p, []),
@@ -84,12 +90,13 @@ SIGNATURES = {
     "spf_tv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P]),
     "spf_fixed_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
     "spf_camera_rays": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P]),
-    "spf_camera_uniform": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _I, _F, _F, _P, _P, _P]),
+    "spf_camera_uniform": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _P, C.POINTER(ProloguePacks), _P]),
     "spf_adam_workspace_floats": (C.c_int64, []),
     "spf_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P, _P, _P]),
     "spf_loss_workspace_floats": (C.c_int64, []),
     "spf_loss_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _I, _P, _I, C.POINTER(LossWeights), _P, _P, _P, _P, _P]),
-    "spf_loss_backward_finalize": (C.c_int, [_P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_loss_backward_finalize": (C.c_int, [_P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, C.c_int64, _P, _P, _P, _P, _P, _P,
+                                             _P, _P, _P, _P, _I, _P, _P]),
     "spf_loss_backward": (C.c_int, [_P, _P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
 }
 

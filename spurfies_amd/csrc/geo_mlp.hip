@@ -974,11 +974,12 @@ __device__ __forceinline__ Bias3 load_bias3(gfp bias, int wave, int lane) {
 
 // forward epilogue: a = lrelu(acc + b) -> planes; sign bits pushed into mask[n] in the order (m, g, e) (32 per word).
 // MODE 1 (last layer): sdf partial sums s[n] += v . a, and the planes receive the Jacobian seed v * lrelu'(h) instead.
-template <int MODE, bool WITH_JAC>
-__device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], const Bias3& bias, const Bias3& v5, int wave, int lane,
-                                                uint32_t (&mask)[2], float (&s)[2]) {
+template <int MODE, bool WITH_JAC, int NT = 2>
+__device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][NT], const Bias3& bias, const Bias3& v5, int wave, int lane,
+                                                uint32_t (&mask)[NT], float (&s)[NT]) {
     const int j = lane & 31, kg = lane >> 5;
-    mask[0] = mask[1] = 0u;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) mask[n] = 0u;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -991,7 +992,7 @@ __device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
                 vs = vv * 0.01f;
             }
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 f32x4 h, hs;
                 bias_scale4(acc[m][n], g, bv, h, hs);
                 f32x4 out;
@@ -1012,16 +1013,19 @@ __device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
 }
 
 // backward epilogue: g_h = g_a * lrelu'(h) -> planes (pops the words the forward epilogue filled, in the same order)
-__device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mask_in)[2]) {
+template <int NT = 2>
+__device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][NT], int wave, int lane, const uint32_t (&mask_in)[NT]) {
     const int j = lane & 31, kg = lane >> 5;
-    uint32_t mask[2] = {mask_in[0], mask_in[1]};
+    uint32_t mask[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) mask[n] = mask_in[n];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 f32x4 v, vs;
                 scale4(acc[m][n], g, v, vs);
                 f32x4 out;
@@ -1033,26 +1037,27 @@ __device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
 }
 
 
-template <bool WITH_JAC>
-__global__ void __launch_bounds__(256, 1)
-geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
-                    const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
-                    int max_pairs, int k, const float* __restrict__ pts, const float* __restrict__ feat_geo, const float* packed,
-                    float rbf, float* __restrict__ pair_tmp, float* __restrict__ jac, int clk) {
-    __shared__ __attribute__((aligned(16))) __bf16 X[X3_LDS_BF16];
-    __shared__ float red[4][64];
+// One workgroup's tiles.  NT = 2: tiles of 64 consecutive valid pairs (the round-1..4 kernel, unchanged); NT = 1 (round 5): HALF-HEIGHT tiles of 32
+// pairs — the weights stream as for a 64-row tile (the k-step becomes L1-fill-bound instead of matrix-pipe-bound: mlp_tile_x3.h), so a tile
+// takes ~55 % of a full one's time and twice as many workgroups have work: chosen by the kernel when all the launch's pairs fit ONE pass of
+// half tiles over the grid (the sampler pass and the pseudo-point pass of a 128-ray step: 64 resp. 16 full tiles on a 256-CU chip).
+template <bool WITH_JAC, int NT>
+__device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const float* __restrict__ x, const int32_t* __restrict__ nbr,
+                                             const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off,
+                                             const int32_t* __restrict__ pair_point, const int NP, int k, const float* __restrict__ pts,
+                                             const float* __restrict__ feat_geo, const float* packed, float rbf, float* __restrict__ pair_tmp,
+                                             float* __restrict__ jac) {
+    constexpr int ROWS = 32 * NT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
-    const int ntiles = (NP + 63) / 64;
+    const int ntiles = (NP + ROWS - 1) / ROWS;
     const float* packed0 = packed;
     T_DECL
-    CLK_DECL
     GxRow cur;
     {
-        const int q = blockIdx.x * 64 + (tid >> 2);
+        const int q = blockIdx.x * ROWS + (tid >> 2);
         int srow = 0, idx = -1;
-        if (q < NP) {
+        if ((tid >> 2) < ROWS && q < NP) {
             const int p = pair_point[q];
             srow = point_slot ? point_slot[p] : p;
             idx = nbr[(size_t)srow * k + (q - pair_off[p])];
@@ -1069,8 +1074,8 @@ geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         // ---- gather: thread = (row, quarter of the 32-d latent); pieces straight into the planes.  The operands were requested
         //      during the previous tile (lookup chain pair -> point -> slot -> neighbour -> latent row).
         const int row0 = tid >> 2, q40 = tid & 3;
-        {
-            const int q = tile * 64 + row0;
+        if (row0 < ROWS) {
+            const int q = tile * ROWS + row0;
             const float lo[4] = {cur.f0[0], cur.f0[1], cur.f0[2], cur.f0[3]}, hi[4] = {cur.f1[0], cur.f1[1], cur.f1[2], cur.f1[3]};
             store_quad_x3(X, row0, q40 * 8, lo);
             store_quad_x3(X, row0, q40 * 8 + 4, hi);
@@ -1088,26 +1093,27 @@ geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
                 store_quad_x3(X, row0, 44, z);
             }
         }
-        const int qn = (tile + (int)gridDim.x) * 64 + row0;       // this thread's row in the workgroup's next tile
-        int n_p = qn < NP ? pair_point[qn] : -1, n_srow = 0, n_off = 0, n_idx = -1;
+        const int qn = (tile + (int)gridDim.x) * ROWS + row0;     // this thread's row in the workgroup's next tile
+        int n_p = (row0 < ROWS && qn < NP) ? pair_point[qn] : -1, n_srow = 0, n_off = 0, n_idx = -1;
         T_MARK(0)
         lds_barrier();
         T_MARK(1)
 
-        f32x16 acc[2][2];
-        uint32_t m1[2], m2[2], m3[2], m4[2];
-        float ssum[2] = {0.f, 0.f};
+        f32x16 acc[2][NT];
+        uint32_t m1[NT], m2[NT], m3[NT], m4[NT];
+        float ssum[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ssum[n] = 0.f;
         // ---- forward: 35 -> 256 -> 256 -> 256 -> 256 ---------------------------------------------------------------------------
         gx3 w_fw2 = frag + XW_FW2 + wave * (XW_TH * 2 * 3 * 64) + lane, w_fw3 = frag + XW_FW3 + wave * (XW_TH * 2 * 3 * 64) + lane;
         gx3 w_fw4 = frag + XW_FW4 + wave * (XW_TH * 2 * 3 * 64) + lane, w_bw4 = frag + XW_BW4 + wave * (XW_TH * 2 * 3 * 64) + lane;
         gx3 w_bw3 = frag + XW_BW3 + wave * (XW_TH * 2 * 3 * 64) + lane, w_bw2 = frag + XW_BW2 + wave * (XW_TH * 2 * 3 * 64) + lane;
         Bias3 bias = load_bias3(pf + OFF_B1, wave, lane);
-        zero_acc(acc);
-        WFrag3 nf = gemm_x3<XW_T1>(X, w_fw1, lane, acc, fr1, w_fw2);
+                WFrag3 nf = gemm_x3<XW_T1, false, X3_LDP, NT>(X, w_fw1, lane, acc, fr1, w_fw2);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m1, ssum);
+        fwd_epilogue_x3<0, WITH_JAC, NT>(X, acc, bias, bias, wave, lane, m1, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
@@ -1116,40 +1122,37 @@ geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
             n_off = pair_off[n_p];
         }
         bias = load_bias3(pf + OFF_B2, wave, lane);
-        zero_acc(acc);
-        nf = gemm_x3<XW_TH>(X, w_fw2, lane, acc, nf, w_fw3);
+                nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw2, lane, acc, nf, w_fw3);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m2, ssum);
+        fwd_epilogue_x3<0, WITH_JAC, NT>(X, acc, bias, bias, wave, lane, m2, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
         bias = load_bias3(pf + OFF_B3, wave, lane);
-        zero_acc(acc);
-        nf = gemm_x3<XW_TH>(X, w_fw3, lane, acc, nf, w_fw4);
+                nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw3, lane, acc, nf, w_fw4);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC>(X, acc, bias, bias, wave, lane, m3, ssum);
+        fwd_epilogue_x3<0, WITH_JAC, NT>(X, acc, bias, bias, wave, lane, m3, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
         cur = gx_fetch_row(n_idx, n_srow, q40, x, pts, feat_geo);
         bias = load_bias3(pf + OFF_B4, wave, lane);
         const Bias3 v5q = load_bias3(pf + OFF_V5, wave, lane);       // folded last layer v = T W8, same quads: requested ahead of the GEMM too
-        zero_acc(acc);
-        nf = gemm_x3<XW_TH>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
+                nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
         // last forward layer: sdf_j = v . a4 + c from the accumulators; the planes receive the Jacobian seed v * lrelu'(h4)
-        fwd_epilogue_x3<1, WITH_JAC>(X, acc, bias, v5q, wave, lane, m4, ssum);
+        fwd_epilogue_x3<1, WITH_JAC, NT>(X, acc, bias, v5q, wave, lane, m4, ssum);
         {
             const int j = lane & 31, kg = lane >> 5;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 const float t = ssum[n] + __shfl_xor(ssum[n], 32);
                 if (kg == 0) red[wave][32 * n + j] = t;
             }
@@ -1157,47 +1160,44 @@ geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         T_MARK(6)
         lds_barrier();
         T_MARK(7)
-        if (tid < 64) {
-            const int q = tile * 64 + tid;
+        if (tid < ROWS) {
+            const int q = tile * ROWS + tid;
             if (q < NP) pair_tmp[(size_t)q * PT_STRIDE + 1] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + pf[OFF_C];
         }
 
         if (WITH_JAC) {
             // ---- Jacobian sweep: g_a3 = g_h4 W6 ; g_h3 = g_a3 * D3 ; ... ; J = g_h1 W0 ------------------------------------------
-            zero_acc(acc);
-            nf = gemm_x3<XW_TH>(X, w_bw4, lane, acc, nf, w_bw3);
+                        nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_bw4, lane, acc, nf, w_bw3);
             T_MARK(10)
             lds_barrier();
             T_MARK(11)
-            bwd_epilogue_x3(X, acc, wave, lane, m3);
+            bwd_epilogue_x3<NT>(X, acc, wave, lane, m3);
             T_MARK(12)
             lds_barrier();
             T_MARK(13)
-            zero_acc(acc);
-            nf = gemm_x3<XW_TH>(X, w_bw3, lane, acc, nf, w_bw2);
+                        nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_bw3, lane, acc, nf, w_bw2);
             T_MARK(10)
             lds_barrier();
             T_MARK(11)
-            bwd_epilogue_x3(X, acc, wave, lane, m2);
+            bwd_epilogue_x3<NT>(X, acc, wave, lane, m2);
             T_MARK(12)
             lds_barrier();
             T_MARK(13)
-            zero_acc(acc);
-            gemm_x3<XW_TH>(X, w_bw2, lane, acc, nf, nullptr);
+                        gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_bw2, lane, acc, nf, nullptr);
             T_MARK(10)
             gx3 w_jw1 = frag + XW_JW1 + (wave >> 1) * (XW_TH * 3 * 64) + lane;
             const WFrag1 frj = load_wfrag1(w_jw1);
             lds_barrier();
             T_MARK(11)
-            bwd_epilogue_x3(X, acc, wave, lane, m1);
+            bwd_epilogue_x3<NT>(X, acc, wave, lane, m1);
             T_MARK(12)
             lds_barrier();
             T_MARK(13)
             // last step 256 -> 35 (padded 64): wave = (feature half m, row half n), one 32x32 tile each
-            {
+            if (NT == 2 || (wave & 1) == 0) {                   // (half tiles: the two waves of the second row half have nothing to multiply)
                 const int m = wave >> 1, n = wave & 1, j = lane & 31, kg = lane >> 5;
                 const f32x16 aj = gemm_x3_tile<XW_TH>(X, n, w_jw1, lane, frj);
-                const int q = tile * 64 + 32 * n + j;
+                const int q = tile * ROWS + 32 * n + j;
                 if (q < NP) {
                     if (m == 0) {
 #pragma unroll
@@ -1216,6 +1216,22 @@ geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
         T_MARK(15)
     }
     T_FLUSH
+}
+
+template <bool WITH_JAC>
+__global__ void __launch_bounds__(256, 1)
+geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
+                    const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
+                    int max_pairs, int k, const float* __restrict__ pts, const float* __restrict__ feat_geo, const float* packed,
+                    float rbf, float* __restrict__ pair_tmp, float* __restrict__ jac, int clk) {
+    __shared__ __attribute__((aligned(16))) __bf16 X[X3_LDS_BF16];
+    __shared__ float red[4][64];
+    const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
+    CLK_DECL
+    if (NP <= 32 * (int)gridDim.x)      // everything fits one pass of half-height tiles
+        geo_x3w_body<WITH_JAC, 1>(X, red, x, nbr, point_slot, pair_off, pair_point, NP, k, pts, feat_geo, packed, rbf, pair_tmp, jac);
+    else
+        geo_x3w_body<WITH_JAC, 2>(X, red, x, nbr, point_slot, pair_off, pair_point, NP, k, pts, feat_geo, packed, rbf, pair_tmp, jac);
     CLK_FLUSH(1, WITH_JAC ? 1 : 0)
 }
 
@@ -1281,7 +1297,8 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
             geo_pairs_x3_kernel<false><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
                                                           rbf, pair_tmp, nullptr, clk);
     } else if (arith == SPF_ARITH_SPLIT_W) {
-        const int b1 = tiles < 256 ? tiles : 256;
+        const int half = spf::div_up(max_pairs, 32);          // the kernel takes half-height (32-pair) tiles when they all fit one pass
+        const int b1 = half < 256 ? half : 256;
         if (grad)
             geo_pairs_x3w_kernel<true><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
                                                           pair_tmp, jac, clk);

@@ -280,17 +280,27 @@ __global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ rayp
         z = p[2];
         int cx, cy, cz;
         cell_of(g, x, y, z, cx, cy, cz);  // a slot's sample is always inside the grid
-        auto scan = [&](int s, int e) {
-            for (int j = s + sub; j < e; j += 8) {
-                const float4 q = g.sorted[j];
-                const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
-                const float d2 = (dx * dx + dy * dy) + dz * dz;
-                const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(q.w);
-                if (d2 <= rad2 && kk < key[SPF_KMAX - 1]) {
-                    key[SPF_KMAX - 1] = kk;
+        // a lane's candidates of one run, four at a time: the four float4 reads are independent (issued back to back, ONE L2 round trip), then
+        // inserted — a run of 3 z-cells holds ~25 candidates = ~3 per lane, so a column costs one round trip instead of three or four
+        // (round 5: the kernel is a chain of dependent L2 reads, 15 - 18 us at 128 rays where the launch floor is 5)
+        auto insert = [&](const float4 q) {
+            const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(q.w);
+            if (d2 <= rad2 && kk < key[SPF_KMAX - 1]) {
+                key[SPF_KMAX - 1] = kk;
 #pragma unroll
-                    for (int t = SPF_KMAX - 1; t > 0; --t) cmpx(key[t - 1], key[t]);
-                }
+                for (int t = SPF_KMAX - 1; t > 0; --t) cmpx(key[t - 1], key[t]);
+            }
+        };
+        auto scan = [&](int s, int e) {
+            for (int j = s + sub; j < e; j += 32) {
+                float4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = g.sorted[j + 8 * u < e ? j + 8 * u : j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j + 8 * u < e) insert(q[u]);
             }
         };
         // merge the octet's eight sorted lists: min(mine[t], partner[7 - t]) is a bitonic sequence holding the 8 smallest of both
@@ -328,11 +338,27 @@ __global__ void __launch_bounds__(256) knn_kernel(const float* __restrict__ rayp
             }
         }
         if (!done) {
-            for (int ax = max(cx - hkx, 0); ax <= min(cx + hkx, g.dx - 1); ++ax)
-                for (int ay = max(cy - hky, 0); ay <= min(cy + hky, g.dy - 1); ++ay) {
-                    const int col = (ax * g.dy + ay) * g.dz;
-                    scan(g.cell_start[col + max(cz - hkz, 0)], g.cell_start[col + min(cz + hkz, g.dz - 1) + 1]);
+            // the runs' bounds are requested one column ahead of their scan (two dependent reads per column otherwise)
+            const int ax0 = max(cx - hkx, 0), ax1 = min(cx + hkx, g.dx - 1), ay0 = max(cy - hky, 0), ay1 = min(cy + hky, g.dy - 1);
+            const int zlo = max(cz - hkz, 0), zhi = min(cz + hkz, g.dz - 1) + 1;
+            int ax = ax0, ay = ay0;
+            int col = (ax * g.dy + ay) * g.dz;
+            int rs = g.cell_start[col + zlo], re = g.cell_start[col + zhi];
+            while (true) {
+                const int cs = rs, ce = re;
+                int nax = ax, nay = ay + 1;
+                if (nay > ay1) { nay = ay0; ++nax; }
+                const bool more = nax <= ax1;
+                if (more) {
+                    col = (nax * g.dy + nay) * g.dz;
+                    rs = g.cell_start[col + zlo];
+                    re = g.cell_start[col + zhi];
                 }
+                scan(cs, ce);
+                if (!more) break;
+                ax = nax;
+                ay = nay;
+            }
             merge();
         }
     }

@@ -7,6 +7,7 @@
 // For ray-sharded steps the caller passes the all-reduced (global) counts in `denom`, so that the ranks' losses sum to the
 // single-GPU batch loss (spurfies_amd/dist.py).  ~70 elementwise / reduction launches of the PyTorch formulation -> 3.
 #include "common.h"
+#include "tv_body.h"
 
 namespace {
 using namespace spf;
@@ -116,7 +117,7 @@ __global__ void loss_backward_kernel(const float* __restrict__ g_total, const fl
                                      const float* __restrict__ rgb, const float* __restrict__ rgb_gt, const float* __restrict__ acc,
                                      const float* __restrict__ mask_gt, int mstride, const float* __restrict__ psdf, const uint8_t* __restrict__ pvalid,
                                      const uint8_t* __restrict__ ray_valid, int R, float* __restrict__ g_rgb, float* __restrict__ g_acc,
-                                     float* __restrict__ g_psdf, float* __restrict__ g_tv, int n_tv, LossFin fin) {
+                                     float* __restrict__ g_psdf, float* __restrict__ g_tv, int n_tv, LossFin fin, int ray_blocks, TvArgs tvb) {
     __shared__ float s_den[4];
     const float* den = den_in;
     if (fin.partial) {
@@ -129,7 +130,12 @@ __global__ void loss_backward_kernel(const float* __restrict__ g_total, const fl
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const float g = *g_total;
     // d loss / d (TV mean), or — n_tv > 0 — d loss / d tv_i, the same for every point
-    if (r == 0 && g_tv) *g_tv = w.tv > 0.f ? g * w.tv * den[3] / (n_tv > 0 ? (float)n_tv : 1.f) : 0.f;
+    const float gtv = w.tv > 0.f ? g * w.tv * den[3] / (n_tv > 0 ? (float)n_tv : 1.f) : 0.f;
+    if ((int)blockIdx.x >= ray_blocks) {       // the TV term's backward rides behind the ray blocks (tv_body.h): one launch less per step
+        if (gtv != 0.f) tv_backward_body(tvb, (long long)((int)blockIdx.x - ray_blocks) * blockDim.x + threadIdx.x, gtv);
+        return;
+    }
+    if (r == 0 && g_tv) *g_tv = gtv;
     if (r >= R) return;
     const float c_rgb = g * w.rgb * den[0];
 #pragma unroll
@@ -191,7 +197,7 @@ int spf_loss_backward(const float* g_total, const float* den, const spf_loss_wei
     if (R <= 0 || !weights) return spf::fail(SPF_EINVAL, "spf_loss_backward: need R > 0, weights");
     if (!g_total || !den || !rgb || !rgb_gt || !acc || !mask_gt || !g_rgb || !g_acc) return spf::fail(SPF_EINVAL, "spf_loss_backward: null pointer");
     loss_backward_kernel<<<spf::div_up(R, 256), 256, 0, (hipStream_t)stream>>>(g_total, den, *weights, rgb, rgb_gt, acc, mask_gt, mask_stride, psdf, pvalid,
-                                                                               ray_valid, R, g_rgb, g_acc, g_psdf, g_tv, n_tv, LossFin{});
+                                                                               ray_valid, R, g_rgb, g_acc, g_psdf, g_tv, n_tv, LossFin{}, spf::div_up(R, 256), TvArgs{});
     SPF_LAUNCH_CHECK("loss_backward_kernel");
     return SPF_OK;
 }
@@ -199,13 +205,23 @@ int spf_loss_backward(const float* g_total, const float* den, const spf_loss_wei
 int spf_loss_backward_finalize(const float* g_total, const spf_loss_weights* weights, const float* rgb, const float* rgb_gt, const float* acc,
                                const float* mask_gt, int32_t mask_stride, const float* psdf, const uint8_t* pvalid, const uint8_t* ray_valid, int32_t R,
                                float* g_rgb, float* g_acc, float* g_psdf, float* g_tv, int32_t n_tv, const float* workspace, int64_t rows,
-                               const int32_t* n_points, const float* tv, const float* denom, float* total, float* terms, float* den, void* stream) {
+                               const int32_t* n_points, const float* tv, const float* denom, float* total, float* terms, float* den,
+                               const float* tv_feat, const int32_t* tv_nbr, const float* tv_w, const float* tv_norm, int32_t tv_k, float* tv_g_feat,
+                               void* stream) {
     if (R <= 0 || !weights || rows < 0 || n_tv < 0) return spf::fail(SPF_EINVAL, "spf_loss_backward_finalize: need R > 0, rows >= 0, n_tv >= 0, weights");
     if (!g_total || !rgb || !rgb_gt || !acc || !mask_gt || !g_rgb || !g_acc || !workspace || !total || !terms || !den)
         return spf::fail(SPF_EINVAL, "spf_loss_backward_finalize: null pointer");
     LossFin fin{workspace, loss_blocks(R, rows, tv ? n_tv : 0), R, n_points, tv, n_tv, denom, total, terms, den};
-    loss_backward_kernel<<<spf::div_up(R, 256), 256, 0, (hipStream_t)stream>>>(g_total, nullptr, *weights, rgb, rgb_gt, acc, mask_gt, mask_stride, psdf, pvalid,
-                                                                               ray_valid, R, g_rgb, g_acc, g_psdf, g_tv, n_tv, fin);
+    TvArgs tvb{};
+    int tv_blocks = 0;
+    if (tv_g_feat) {          // the TV term's backward in the same launch: g_feat += d loss / d tv_i * d tv_i / d latents
+        if (!tv_feat || !tv_nbr || !tv_w || !tv_norm || tv_k < 1 || n_tv < 1 || !tv) return spf::fail(SPF_EINVAL, "spf_loss_backward_finalize: incomplete TV arguments (need the per-point form, n_tv > 0)");
+        tvb = TvArgs{tv_feat, tv_nbr, tv_w, tv_norm, n_tv, tv_k, nullptr, tv_g_feat};
+        tv_blocks = spf::div_up((long long)n_tv * 32, 256);
+    }
+    const int ray_blocks = spf::div_up(R, 256);
+    loss_backward_kernel<<<ray_blocks + tv_blocks, 256, 0, (hipStream_t)stream>>>(g_total, nullptr, *weights, rgb, rgb_gt, acc, mask_gt, mask_stride, psdf, pvalid,
+                                                                                  ray_valid, R, g_rgb, g_acc, g_psdf, g_tv, n_tv, fin, ray_blocks, tvb);
     SPF_LAUNCH_CHECK("loss_backward_kernel<finalize>");
     return SPF_OK;
 }

@@ -502,7 +502,7 @@ wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, in
 // launches + three reduces (each paying pipeline ramp, tail and a dispatch gap; at K = 49 k pairs, 128 rays, 174 us for 80 us of work).
 // Round 5: up to SIX problems, each with its OWN row count (n_rows / max_rows): the head stage's three GEMMs (K = valid points) ride in the
 // colour trunk's launch (K = pairs) — one pipeline ramp / tail / slab reduce for all the 256-wide weight gradients of a step.
-constexpr int WG_MAXP = 6;
+constexpr int WG_MAXP = 7;
 struct WgradBatch {
     const float* G[WG_MAXP];
     const float* A[WG_MAXP];
@@ -512,7 +512,7 @@ struct WgradBatch {
     float* dbias[WG_MAXP];
     const int32_t* n_rows[WG_MAXP];
     int max_rows[WG_MAXP];
-    int C[WG_MAXP], kind[WG_MAXP], first[WG_MAXP], nblk[WG_MAXP], col_rot[WG_MAXP], col_mod[WG_MAXP];     // kind: 0 = <8, rows, rows>, 1 = <8, G64, A16>, 2 = <4, G64, rows>
+    int C[WG_MAXP], kind[WG_MAXP], first[WG_MAXP], nblk[WG_MAXP], col_rot[WG_MAXP], col_mod[WG_MAXP];     // kind: 0 = <8, rows, rows>, 1 = <8, G64, A16>, 2 = <4, G64, rows>, 3 = <4, rows, rows>
 };
 // Workgroups per problem, from the ACTUAL row counts (they live on the device: the host only knows the buffers' capacities, and a share cut
 // from capacities left the head stage's problems — 69 % full at 128 rays against the trunk's 60 % — as the launch's long pole: 124 us for
@@ -531,7 +531,7 @@ __device__ __forceinline__ void wg_assign(const WgradBatch& pb, int n_problems, 
         nblk[q] = 0;
         if (q < n_problems) {
             const int n = pb.n_rows[q] ? min(*pb.n_rows[q], pb.max_rows[q]) : pb.max_rows[q];
-            w[q] = (pb.kind[q] == 2 ? 0.62f : 1.0f) * (float)max(n, 0);
+            w[q] = (pb.kind[q] >= 2 ? 0.62f : 1.0f) * (float)max(n, 0);
             cap[q] = (max(n, 0) + WGRAD_MIN_ROWS_DEV - 1) / WGRAD_MIN_ROWS_DEV;
             total += w[q];
         }
@@ -596,7 +596,8 @@ wgrad_split8_batched_kernel(WgradBatch pb, int n_problems, float* __restrict__ s
     float* colsum = det ? slab + COLSUM_OFF : nullptr;
     if (pb.kind[q] == 0) wgrad_split8_body<8>(sm, pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
     else if (pb.kind[q] == 1) wgrad_split8_body<8, 2, true>(sm, pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
-    else wgrad_split8_body<4, 2, false>(sm, pb.G[q], pb.A[q], pb.lda[q], pb.C[q], n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
+    else if (pb.kind[q] == 2) wgrad_split8_body<4, 2, false>(sm, pb.G[q], pb.A[q], pb.lda[q], pb.C[q], n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
+    else wgrad_split8_body<4>(sm, pb.G[q], pb.A[q], pb.lda[q], pb.C[q], n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);      // row-major, C <= 128 (R.0's view-encoding columns)
 }
 
 // slab of wgrad_split8_kernel: output row o = 32 wave + C-row(reg, lane), column = 32 t + (lane & 31)
@@ -655,7 +656,7 @@ __global__ void wgrad_split8_reduce_batched_kernel(const float* __restrict__ sla
     const int max_rows = pb.max_rows[q];
     const float* slab = slabs + (size_t)q * slab_floats;
     float* db = det ? pb.dbias[q] : nullptr;
-    if (pb.kind[q] == 2) wgrad_split8_reduce_body<4>(slab, s_nblk[q], n_rows_dev, max_rows, pb.C[q], pb.dW[q], pb.ldw[q], 64, pb.col_rot[q], pb.col_mod[q], db);
+    if (pb.kind[q] >= 2) wgrad_split8_reduce_body<4>(slab, s_nblk[q], n_rows_dev, max_rows, pb.C[q], pb.dW[q], pb.ldw[q], pb.kind[q] == 2 ? 64 : 2, pb.col_rot[q], pb.col_mod[q], db);
     else wgrad_split8_reduce_body<8>(slab, s_nblk[q], n_rows_dev, max_rows, 256, pb.dW[q], pb.ldw[q], pb.kind[q] == 1 ? 64 : 2, pb.col_rot[q], pb.col_mod[q], db);
 }
 
@@ -830,7 +831,7 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
     if (!workspace) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: null workspace");
     const int64_t slab_floats = spf_wgrad_workspace_floats(256);
     const int g64a16 = SPF_WGRAD_G_TILES64 | SPF_WGRAD_A_TILES;
-    int kind[WG_MAXP] = {0, 0, 0, 0, 0, 0};
+    int kind[WG_MAXP] = {0, 0, 0, 0, 0, 0, 0};
     int rows_of[WG_MAXP];
     const int32_t* cnt_of[WG_MAXP];
     int any_rows = 0;
@@ -847,8 +848,9 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
         if (C == 256 && p.layout == 0) kind[q] = 0;
         else if (C == 256 && p.layout == g64a16) kind[q] = 1;
         else if (C > 32 && C <= 128 && (C % 4) == 0 && p.layout == SPF_WGRAD_G_TILES64) kind[q] = 2;
+        else if (C >= 4 && C <= 128 && (C % 4) == 0 && p.layout == 0) kind[q] = 3;
         else return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: (C, layout) = (%d, %d) is not one of (256, 0), (256, G_TILES64 | A_TILES), "
-                                          "(36..128 step 4, G_TILES64)", q, C, p.layout);
+                                          "(36..128 step 4, G_TILES64), (4..128 step 4, 0)", q, C, p.layout);
         if (kind[q] != 1 && (p.lda < C || (p.lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: lda >= C and a multiple of 4", q);
         if (kind[q] != 0 && (rows_of[q] % 64)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: tiled operands need max_rows %% 64 == 0", q);
         if (p.col_mod < 0 || p.col_mod > C || p.col_rot < 0 || (p.col_mod > 0 && p.col_rot >= p.col_mod) || (p.col_mod == 0 && p.col_rot != 0))

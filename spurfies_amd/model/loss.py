@@ -47,7 +47,8 @@ class VolSDFLoss(nn.Module):
         psdf = f["psdf"] if self.pseudo_weight > 0 else None
         has_local = "local_sum" in model_outputs and self.local_weight > 0       # then `total` is read by an add below: no deferred finalize
         total, t = ops.FusedLoss.apply(model_outputs["rgb_values"], f["acc"], psdf, tv, f["grad"], f["slot_valid"], f["n_points"],
-                                       f["pvalid"], f["ray_valid"], rgb_gt, mask, mask.stride(0), w, denom, not has_local)
+                                       f["pvalid"], f["ray_valid"], rgb_gt, mask, mask.stride(0), w, denom, not has_local,
+                                       f.get("tv_ctx") if self.tv_weight > 0 else None)
         self.iter_step += 1
         local = t[5]
         if "local_sum" in model_outputs and self.local_weight > 0:

@@ -310,11 +310,15 @@ class PointVolSDF(nn.Module):
         conf, smp = self.conf, self.ray_sampler
         ext = smp.draws
         n0 = smp.N_samples_eval
+        # ... and the per-point TV terms of the geometry latents in the same launch (their backward rides in the loss backward launch)
+        tv_in = (ops.scatter_mode() != "fixed" and ops._sink(self.neural_feats_geometry) is not None and input.get("local_data") is None)
         res = ops.camera_uniform(input["uv"], input["pose"], input["intrinsics"], self.density.beta, self.density.beta_min_value, beta_fwd,
-                                 smp._linspace(n0, dev), ext["t_rand"], smp.near, smp.far)
+                                 smp._linspace(n0, dev), ext["t_rand"], smp.near, smp.far, tv_graph=self.tv_graph() if tv_in else None,
+                                 tv_feat=self.neural_feats_geometry if tv_in else None,
+                                 pack=(self.F_color, self.R, input["uv"].shape[1] * conf.max_shading_pts))
         if res is None:
             return None
-        ray_dirs, cam_loc, depth_scale, z_vals, pts0 = res
+        ray_dirs, cam_loc, depth_scale, z_vals, pts0, tv_pre, pre = res
         R = ray_dirs.shape[0]
         grid = self._grid()
         self.density._beta_forward = beta_fwd
@@ -330,11 +334,11 @@ class PointVolSDF(nn.Module):
                                                                               conf.max_shading_pts)
             smp.last_iters = 1
             smp.last_points = points
-            return self.render_points(points, ray_dirs, cam_loc, depth_scale, input.get("local_data"), slots=(slot_sample, ray_valid))
+            return self.render_points(points, ray_dirs, cam_loc, depth_scale, input.get("local_data"), slots=(slot_sample, ray_valid), tv_pre=tv_pre, pre=pre)
         finally:
             self.density._beta_forward = None
 
-    def render_points(self, points, ray_dirs, cam_loc, depth_scale, local_data=None, slots=None):
+    def render_points(self, points, ray_dirs, cam_loc, depth_scale, local_data=None, slots=None, tv_pre=None, pre=None):
         """Everything of forward() behind the sampler (:654-892): main-pass kNN of the sample positions `points` [R,D,3] (the
         sampler's o + z d), filter_points, SDF + normals + colours at the hits, compositing, the pseudo-point / local / TV terms
         and the output dict.  Split out so that a stage test can feed recorded sample positions."""
@@ -349,12 +353,16 @@ class PointVolSDF(nn.Module):
         # issued on side streams = parallel branches of the step's hipGraph.  Branch "aux": the two weight-packing launches (they only read
         # the parameters) and the TV term, beside the main pass's kNN / geometry kernel.
         fork = static and ops.fork_enabled() and local_data is None and ops._sink(self.density.beta) is not None
-        pre, ev_pack, tv_early = (None, None), None, None
-        if fork:
+        ev_pack, tv_early = None, None
+        if fork and (pre is None or tv_pre is None):
             with ops.branch("aux", dev) as aux:
-                pre = (ops.prepack_color(self.F_color, R * SR, dev), ops.prepack_rhead(self.F_color[6], self.R, R * SR, dev))
-                ev_pack = aux.record()
-                tv_early = self.tv_graph().loss(self.neural_feats_geometry, reduce=False)
+                if pre is None:
+                    pre = (ops.prepack_color(self.F_color, R * SR, dev), ops.prepack_rhead(self.F_color[6], self.R, R * SR, dev))
+                    ev_pack = aux.record()
+                if tv_pre is None:
+                    tv_early = self.tv_graph().loss(self.neural_feats_geometry, reduce=False)
+        if pre is None:
+            pre = (None, None)
 
         # ---- kNN of the main pass, dense [R,SR] ------------------------------------------------
         q = grid.query_dense(points.detach(), k, conf.r, SR, slots=slots)
@@ -452,7 +460,11 @@ class PointVolSDF(nn.Module):
                 pseudo_pts_loss = torch.where(cnt > 0, l1, torch.full_like(l1, SDF_FILL))
             output.update({"pseudo_pts_loss": pseudo_pts_loss, "pseudo_sum": pseudo_sum, "pseudo_count": pseudo_cnt})
         # sync-free training: the per-point TV terms — their mean is formed inside the fused loss kernels (one reduction launch less)
-        output["tv_loss"] = tv_early if tv_early is not None else self.tv_graph().loss(self.neural_feats_geometry, reduce=not static)
+        if tv_pre is not None:         # per-point values from the step's first launch; FusedLoss runs their backward (tv_ctx)
+            output["tv_loss"] = tv_pre
+            output["_fused"]["tv_ctx"] = (self.neural_feats_geometry, self.tv_graph())
+        else:
+            output["tv_loss"] = tv_early if tv_early is not None else self.tv_graph().loss(self.neural_feats_geometry, reduce=not static)
         if not self.training:
             g = gradients.view(R, SR, 3)
             nrm = torch.where(valid.unsqueeze(-1), g / g.norm(2, -1, keepdim=True), torch.zeros(1, device=dev))

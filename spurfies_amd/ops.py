@@ -1036,8 +1036,9 @@ class RHead(_GradModeFunction):
                 # round 5: these three GEMMs (K = valid points: a dozen workgroups' worth of rows at 128 rays) ride in the colour trunk's batched
                 # launch, which autograd issues next (ColorAgg.backward) — one pipeline ramp / tail / slab reduce for all six
                 rows = min(g_agg.shape[0], agg3.shape[0])
-                _PENDING_WGRAD.append(([pr + (256, 0, 0, 0, n_points, rows) for pr in probs], (g_agg, agg3, G1, agg, G2, act1, n_points)))
-                wgrad(G1, direnc, n_points, C=21, out=sk[2])
+                # ... and with them R.0's 21 view-encoding columns (direnc [rows,24], its three padding columns are zero): a fourth, narrow problem
+                _PENDING_WGRAD.append(([pr + (256, 0, 0, 0, n_points, rows) for pr in probs] + [(G1, direnc, sk[2], None, 24, 0, 0, 21, n_points, rows)],
+                                       (g_agg, agg3, G1, agg, G2, act1, direnc, n_points)))
             else:
                 with branch("wgrad_head", dev):
                     wgrad_batched(probs, n_points)
@@ -1147,8 +1148,8 @@ def wgrad_batched(problems, n_rows):
         rest = tuple(prob[4:])
         C, layout, col_rot, col_mod = (rest[:4] + (256, 0, 0, 0)[len(rest[:4]):]) if rest else (256, 0, 0, 0)
         own = rest[4:6] if len(rest) >= 6 else None
-        if layout == 0 and (A.shape[1] != 256 or G.shape[1] != 256 or out.shape != (256, 256)):
-            raise ValueError("wgrad_batched: a row-major problem is [rows,256]^T x [rows,256] -> [256,256]")
+        if layout == 0 and C == 256 and (A.shape[1] != 256 or G.shape[1] != 256 or out.shape != (256, 256)):
+            raise ValueError("wgrad_batched: a row-major problem is [rows,256]^T x [rows,256] -> [256,256] (or C <= 128 columns of a narrower A)")
         arr[q].G, arr[q].A, arr[q].lda = _lib.ptr(G), _lib.ptr(A), A.stride(0)
         arr[q].dW, arr[q].ldw, arr[q].dbias = _lib.ptr(out), out.stride(0), _lib.ptr(dbias)
         arr[q].C, arr[q].layout, arr[q].col_rot, arr[q].col_mod = int(C), int(layout), int(col_rot), int(col_mod)
@@ -1192,9 +1193,12 @@ def camera_rays(uv, pose, intrinsics, beta_param=None, beta_min=0.0, beta_out=No
     return dirs, loc, scale
 
 
-def camera_uniform(uv, pose, intrinsics, beta_param, beta_min, beta_out, tlin, t_rand, near, far):
-    """camera_rays + sampler_uniform in one launch (spf_camera_uniform) -> (ray_dirs, cam_loc, depth_scale, z [R,n], points [R,n,3]); None for
-    multi-view batches / quaternion poses (as camera_rays)."""
+def camera_uniform(uv, pose, intrinsics, beta_param, beta_min, beta_out, tlin, t_rand, near, far, tv_graph=None, tv_feat=None, pack=None):
+    """camera_rays + sampler_uniform in one launch (spf_camera_uniform) -> (ray_dirs, cam_loc, depth_scale, z [R,n], points [R,n,3], tv | None);
+    None for multi-view batches / quaternion poses (as camera_rays).  tv_graph (model.utils.TVGraph) + tv_feat [n,32]: the per-point TV terms
+    ride in the same launch (values only: their backward rides in the loss backward launch, FusedLoss(tv_ctx=...)).
+    pack = (F_color, R, n_rows): both weight-packing jobs ride along too; a seventh result `pre` = ((colour image, zeroed agg3 [n_rows,256]),
+    (head image, zeroed colors [n_rows,3])) for ColorAgg / RHead (the step prologue: everything that reads only parameters and the batch)."""
     if uv.dim() != 3 or uv.shape[0] != 1 or pose.shape[-2:] != (4, 4) or not uv.is_cuda:
         return None
     R, dev, n = uv.shape[1], uv.device, tlin.shape[0]
@@ -1208,11 +1212,38 @@ def camera_uniform(uv, pose, intrinsics, beta_param, beta_min, beta_out, tlin, t
     scale = torch.empty((R, 1), dtype=torch.float32, device=dev)
     z = torch.empty((R, n), dtype=torch.float32, device=dev)
     pts = torch.empty((R, n, 3), dtype=torch.float32, device=dev)
+    tv, g = None, tv_graph
+    feat_c = None
+    if g is not None:
+        feat_c = tv_feat.detach().contiguous()
+        tv = torch.empty((feat_c.shape[0],), dtype=torch.float32, device=dev)
+    pk, pre, hold = None, None, None
+    if pack is not None:
+        import ctypes
+
+        fc, rh, n_rows = pack
+        ws = [t.detach().contiguous().float() for t in (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias,
+                                                         fc[6].weight, fc[6].bias, rh[0].weight, rh[0].bias, rh[2].weight, rh[2].bias, rh[4].weight, rh[4].bias)]
+        c_packed = torch.empty((int(_lib.lib().spf_color_packed_floats()),), dtype=torch.float32, device=dev)
+        r_packed = torch.empty((int(_lib.lib().spf_rhead_packed_floats()),), dtype=torch.float32, device=dev)
+        agg3 = torch.empty((n_rows, 256), dtype=torch.float32, device=dev)
+        colors = torch.empty((n_rows, 3), dtype=torch.float32, device=dev)
+        pk = _lib.ProloguePacks()
+        for name, t in zip(("cw0", "cb0", "cw2", "cb2", "cw4", "cb4", "rw6", "rb6", "rw0", "rb0", "rw2", "rb2", "rw4", "rb4"), ws):
+            setattr(pk, name, t.data_ptr())
+        pk.c_packed, pk.c_zero, pk.c_zero_floats = c_packed.data_ptr(), agg3.data_ptr(), agg3.numel()
+        pk.r_packed, pk.r_zero, pk.r_zero_floats = r_packed.data_ptr(), colors.data_ptr(), colors.numel()
+        pre, hold = ((c_packed, agg3), (r_packed, colors)), ws
+        pk = ctypes.byref(pk)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_camera_uniform(_lib.ptr(uv_c), _lib.ptr(pose_c), _lib.ptr(K), ks, R, _lib.ptr(dirs), _lib.ptr(loc), _lib.ptr(scale),
                                                  _lib.ptr(None if beta_out is None else beta_param.detach()), float(beta_min), _lib.ptr(beta_out), _lib.ptr(tlin),
-                                                 _lib.ptr(t_rand), n, float(near), float(far), _lib.ptr(z), _lib.ptr(pts), _lib.stream_ptr()), "spf_camera_uniform")
-    return dirs, loc, scale, z, pts
+                                                 _lib.ptr(t_rand), n, float(near), float(far), _lib.ptr(z), _lib.ptr(pts), _lib.ptr(feat_c),
+                                                 _lib.ptr(None if g is None else g.nbr), _lib.ptr(None if g is None else g.w), _lib.ptr(None if g is None else g.norm),
+                                                 0 if g is None else feat_c.shape[0], 1 if g is None else g.nbr.shape[1], _lib.ptr(tv), pk, _lib.stream_ptr()),
+                   "spf_camera_uniform")
+    del hold
+    return dirs, loc, scale, z, pts, tv, pre
 
 
 _FUSED_SAMPLER = [True]
@@ -1243,8 +1274,11 @@ class FusedLoss(_GradModeFunction):
     always runs it; a caller that wants the loss without a backward calls this under torch.no_grad()."""
 
     @staticmethod
-    def forward(ctx, rgb, acc, psdf, tv, grad, slot_valid, n_points, pvalid, ray_valid, rgb_gt, mask_gt, mask_stride, weights, denom, allow_defer=True):
-        """allow_defer=False: `total` is read by further forward ops (the feature-consistency term is added to it): finalize in the forward."""
+    def forward(ctx, rgb, acc, psdf, tv, grad, slot_valid, n_points, pvalid, ray_valid, rgb_gt, mask_gt, mask_stride, weights, denom, allow_defer=True,
+                tv_ctx=None):
+        """allow_defer=False: `total` is read by further forward ops (the feature-consistency term is added to it): finalize in the forward.
+        tv_ctx = (geometry latent parameter, TVGraph): `tv` are per-point VALUES formed outside autograd (the step's first launch); their
+        backward is this function's job — it rides in the loss backward launch and adds straight into the parameter's gradient sink."""
         dev = rgb.device
         R = rgb.shape[0]
         rgb_c, acc_c = rgb.detach().contiguous(), acc.detach().reshape(R).contiguous()
@@ -1268,6 +1302,12 @@ class FusedLoss(_GradModeFunction):
         ctx.save_for_backward(rgb_c, acc_c, psdf_c, rgb_gt, mask_gt, pvalid, ray_valid, den)
         ctx.misc = (mask_stride, weights, acc.shape, None if psdf is None else psdf.shape, tv is not None, n_tv)
         ctx.fin = (_loss_ws[key], rows, n_points, tv_c, denom, total, terms) if defer else None
+        ctx.tv_ctx = None
+        if tv_ctx is not None:
+            sink = _sink(tv_ctx[0])
+            if sink is None or n_tv == 0:
+                raise RuntimeError("FusedLoss(tv_ctx): needs the per-point TV form and a gradient sink on the latent table (ops.set_grad_sinks)")
+            ctx.tv_ctx = (tv_ctx[0].detach(), tv_ctx[1], sink)
         ctx.mark_non_differentiable(terms)
         ctx.set_materialize_grads(False)
         return total, terms
@@ -1278,25 +1318,35 @@ class FusedLoss(_GradModeFunction):
         mask_stride, weights, acc_shape, psdf_shape, has_tv, n_tv = ctx.misc
         R, dev = rgb.shape[0], rgb.device
         if g_total is None:
-            return (None,) * 15
+            return (None,) * 16
         g = g_total.detach().reshape(1).contiguous()
         g_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
         g_acc = torch.empty((R,), dtype=torch.float32, device=dev)
         g_psdf = None if psdf is None else torch.empty((R,), dtype=torch.float32, device=dev)
         g_tv = torch.empty((1,), dtype=torch.float32, device=dev) if has_tv else None
+        tvc = ctx.tv_ctx
         with torch.cuda.device(dev):
             if ctx.fin is not None:
                 ws, rows, n_points, tv_c, denom, total, terms = ctx.fin
+                feat, graph, sink = tvc if tvc is not None else (None, None, None)
                 _lib.check(_lib.lib().spf_loss_backward_finalize(_lib.ptr(g), weights, _lib.ptr(rgb), _lib.ptr(rgb_gt), _lib.ptr(acc), _lib.ptr(mask_gt), mask_stride,
                                                                  _lib.ptr(psdf), _lib.ptr(pvalid), _lib.ptr(ray_valid), R, _lib.ptr(g_rgb), _lib.ptr(g_acc),
                                                                  _lib.ptr(g_psdf), _lib.ptr(g_tv), n_tv, _lib.ptr(ws), rows, _lib.ptr(n_points), _lib.ptr(tv_c),
-                                                                 _lib.ptr(denom), _lib.ptr(total), _lib.ptr(terms), _lib.ptr(den), _lib.stream_ptr()),
-                           "spf_loss_backward_finalize")
+                                                                 _lib.ptr(denom), _lib.ptr(total), _lib.ptr(terms), _lib.ptr(den), _lib.ptr(feat),
+                                                                 _lib.ptr(None if graph is None else graph.nbr), _lib.ptr(None if graph is None else graph.w),
+                                                                 _lib.ptr(None if graph is None else graph.norm), 1 if graph is None else graph.nbr.shape[1],
+                                                                 _lib.ptr(sink), _lib.stream_ptr()), "spf_loss_backward_finalize")
             else:
                 _lib.check(_lib.lib().spf_loss_backward(_lib.ptr(g), _lib.ptr(den), weights, _lib.ptr(rgb), _lib.ptr(rgb_gt), _lib.ptr(acc),
                                                         _lib.ptr(mask_gt), mask_stride, _lib.ptr(psdf), _lib.ptr(pvalid), _lib.ptr(ray_valid), R,
                                                         _lib.ptr(g_rgb), _lib.ptr(g_acc), _lib.ptr(g_psdf), _lib.ptr(g_tv), n_tv, _lib.stream_ptr()),
                            "spf_loss_backward")
+                if tvc is not None:          # (finalize was not deferred: the TV backward as its own launch, one gradient value for all points)
+                    feat, graph, sink = tvc
+                    _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(graph.nbr), _lib.ptr(graph.w), _lib.ptr(graph.norm), _lib.ptr(g_tv), 0, 1.0,
+                                                          feat.shape[0], graph.nbr.shape[1], _lib.ptr(sink), None, _lib.stream_ptr()), "spf_tv_backward")
+        if tvc is not None:
+            g_tv = None                       # the latent gradient has been accumulated: nothing for autograd
         g_tv_out = None if g_tv is None else (g_tv.expand(n_tv) if n_tv else g_tv.reshape(()))      # per-point array: one value, stride 0
         return (g_rgb, g_acc.view(acc_shape), None if g_psdf is None else g_psdf.view(psdf_shape), g_tv_out,
-                None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None)

@@ -201,6 +201,8 @@ def test_six_problems_with_their_own_row_counts_in_one_launch(rows_trunk, rows_h
     At = [A0] + [torch.randn((at, 256), generator=g).cuda() for _ in range(2)]
     Gh = [torch.randn((ah, 256), generator=g).cuda() for _ in range(3)]
     Ah = [torch.randn((ah, 256), generator=g).cuda() for _ in range(3)]
+    An = torch.randn((ah, 24), generator=g).cuda()
+    An[:, 21:] = 0.0
     nt = torch.tensor([rows_trunk], dtype=torch.int32, device="cuda")
     nh = torch.tensor([rows_head], dtype=torch.int32, device="cuda")
     G64 = [_to_tiles(G_, 64) for G_ in Gt]
@@ -211,7 +213,8 @@ def test_six_problems_with_their_own_row_counts_in_one_launch(rows_trunk, rows_h
     dbs = [torch.zeros(256, device="cuda") for _ in range(6)]
     ops.wgrad_batched([(G64[0], A16[0], outs_t[0], dbs[0], 104, 4, 39, 103), (G64[1], A16[1], outs_t[1], dbs[1], 256, 6, 0, 0),
                        (G64[2], A16[2], outs_t[2], dbs[2], 256, 6, 0, 0)] +
-                      [(Gh[q], Ah[q], outs_h[q], dbs[3 + q], 256, 0, 0, 0, nh, ah) for q in range(3)], nt)
+                      [(Gh[q], Ah[q], outs_h[q], dbs[3 + q], 256, 0, 0, 0, nh, ah) for q in range(3)] +
+                      [(Gh[1], An, wide, None, 24, 0, 0, 21, nh, ah)], nt)            # the seventh: R.0's 21 view-encoding columns (row-major, narrow)
     ref0 = Gt[0][:rows_trunk].double().t() @ A0[:rows_trunk].double()
     ref0 = torch.cat([ref0[:, 64:103], ref0[:, :64]], 1)
     refs = [ref0] + [Gt[q][:rows_trunk].double().t() @ At[q][:rows_trunk].double() for q in (1, 2)] + [Gh[q][:rows_head].double().t() @ Ah[q][:rows_head].double() for q in range(3)]
@@ -222,4 +225,5 @@ def test_six_problems_with_their_own_row_counts_in_one_launch(rows_trunk, rows_h
         rows = rows_trunk if q < 3 else rows_head
         Gq = (Gt + Gh)[q]
         np.testing.assert_allclose(dbs[q].double().cpu().numpy(), Gq[:rows].double().sum(0).cpu().numpy(), rtol=1e-5, atol=2e-5 * rows ** 0.5 + 1e-5, err_msg=str(q))
-    assert float(wide[:, :21].abs().max()) == 0.0
+    refn = Gh[1][:rows_head].double().t() @ An[:rows_head, :21].double()
+    assert _err(wide[:, :21], refn) < 1e-5

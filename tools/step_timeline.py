@@ -36,5 +36,9 @@ for r in seq:
     q = r.get("Queue_Id", r.get("Stream_Id", ""))
     print(f"{(s - t0) / 1e3:9.1f} us  +{gap / 1e3:6.1f} gap  {(e - s) / 1e3:8.1f} us  q{q}  {short(r['Kernel_Name'])}" + ("   (starts before the previous kernel ended)" if s < prev_end else ""))
     prev_end = max(prev_end, e)
+if back >= 2:
+    nxt = int(rows[starts[-back + 1]]["Start_Timestamp"]) if -back + 1 < 0 else None
+    if nxt:
+        print(f"period (start of this step -> start of the next): {(int(rows[b]['Start_Timestamp']) - t0) / 1e3:.1f} us")
 print(f"launches {len(seq)}, busy {busy / 1e3:.1f} us, gaps {gap_total / 1e3:.1f} us, span {(prev_end - t0) / 1e3:.1f} us, kernels < 15 us: "
       f"{sum(1 for r in seq if int(r['End_Timestamp']) - int(r['Start_Timestamp']) < 15000)} launches = {small / 1e3:.1f} us")

@@ -34,9 +34,15 @@ def build(scene, device, **kw):
     return model, TrainStep(model, **kw)
 
 
-def timed(step, batches, warm, n):
+def timed(step, batches, warm, n, settle=1.0):
+    """-> (ms/step over n steps right behind `warm` warm-up steps [round 4's figure: the chip's clock has not settled yet], host enqueue times,
+    ms/step over n steps behind another `settle` seconds of the same step [the settled clock: what a long run sees; bench.py's --settle])."""
+    import gc
+
     for i in range(warm):
         step(*batches[i % len(batches)])
+    gc.collect()
+    gc.disable()
     torch.cuda.synchronize()
     enq = []
     t0 = time.perf_counter()
@@ -46,7 +52,20 @@ def timed(step, batches, warm, n):
         enq.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return dt / n * 1e3, 1e3 * float(np.median(enq[:3])), 1e3 * float(np.median(enq))
+    i = warm + n
+    t1 = time.perf_counter()
+    while time.perf_counter() - t1 < settle:
+        for _ in range(20):
+            step(*batches[i % len(batches)])
+            i += 1
+        torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for k in range(n):
+        step(*batches[(i + k) % len(batches)])
+    torch.cuda.synchronize()
+    dts = time.perf_counter() - t2
+    gc.enable()
+    return dt / n * 1e3, 1e3 * float(np.median(enq[:3])), 1e3 * float(np.median(enq)), dts / n * 1e3
 
 
 def multi_scene(a, dev):
@@ -62,14 +81,24 @@ def multi_scene(a, dev):
             built.append(build(sc, dev, **kw))
         batches = [bench.make_batches(sc, 16, rays, 0, 1, dev, seed=12345 + s) for s, sc in enumerate(scenes)]
         multi = MultiSceneTrainer([st for _, st in built], n_streams=2, device=dev)
-        for i in range(6):
+        import gc
+
+        i = 0
+        t1 = time.perf_counter()
+        while i < 6 or time.perf_counter() - t1 < 1.0:                 # warm-up incl. captures, then ~1 s of settling
             multi.step([b[i % len(b)] for b in batches])
+            i += 1
+            if i % 4 == 0:
+                torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(6, 6 + a.steps):
-            multi.step([b[i % len(b)] for b in batches])
+        for k in range(a.steps):
+            multi.step([b[(i + k) % len(b)] for b in batches])
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / a.steps * 1e3
+        gc.enable()
         rows.append({"rays_per_scene": rays, "mode": mode, "ms_per_round": ms, "ray_samples_per_s": bench.SAMPLES_PER_RAY * rays * S / (ms * 1e-3)})
         print(json.dumps(rows[-1]), flush=True)
         del built, multi, batches
@@ -110,8 +139,8 @@ def main():
                          ("graph", dict(sync_free=True, use_graph=True))):
             torch.manual_seed(1)
             model, step = build(scene, dev, **kw)
-            ms, enq_first, enq_med = timed(step, batches, 12, a.steps)
-            row[mode] = {"ms_per_step": ms, "host_enqueue_ms_first3": enq_first, "host_enqueue_ms_median": enq_med,
+            ms, enq_first, enq_med, ms_settled = timed(step, batches, 12, a.steps)
+            row[mode] = {"ms_per_step": ms, "ms_per_step_settled": ms_settled, "host_enqueue_ms_first3": enq_first, "host_enqueue_ms_median": enq_med,
                          "ray_samples_per_s": bench.SAMPLES_PER_RAY * rays / (ms * 1e-3)}
             counts = model.stats.get("counts")
             if counts is not None:
@@ -124,6 +153,7 @@ def main():
     for r in rows:
         for mode in ("eager", "graph_single_stream", "graph"):
             r[mode]["speedup_vs_full_batch"] = base[mode]["ms_per_step"] / r[mode]["ms_per_step"]
+            r[mode]["speedup_vs_full_batch_settled"] = base[mode]["ms_per_step_settled"] / r[mode]["ms_per_step_settled"]
     res = {"what": f"strong-scaling proxy, {name} shape: one rank's share of the batch on one MI355X, optimisation step before communication "
                    "(fwd + loss + bwd + clip + Adam), fitted prior", "neural_points": points, "engine": a.engine, "steps_timed": a.steps,
            "device": torch.cuda.get_device_name(0), "rows": rows}
