@@ -72,7 +72,9 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay forward + loss + backward as one hipGraph (measured no faster than the eager sync-free "
                     "step on MI355X: ~3 us of dependency handling per graph node; the eager launches run ahead of the GPU)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches even at <= 256 rays per GPU (where the graph replay is the default: the eager step is host-bound there)")
-    ap.add_argument("--no-fork", action="store_true", help="graph-replayed steps on ONE stream (default: independent passes as forked branches of the graph)")
+    ap.add_argument("--fork", action="store_true", help="graph-replayed steps with independent passes as forked branches of the graph (TrainStep(fork=True); measured "
+                    "within +-1 %% of the single-stream graph on ROCm 7.2, default off)")
+    ap.add_argument("--no-fork", action="store_true", help="(kept for older command lines: the default)")
     ap.add_argument("--off", default="", help="comma list of round-5 launch fusions to switch OFF for same-box A/B runs: fused_sampler, defer_loss, merge_head")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--mode", choices=["train", "eval"], default="train", help="train (the contract line): one optimisation step per step; eval: one evaluation-render chunk per "
@@ -248,7 +250,7 @@ def build_scene_step(args, seed, device, world, use_graph):
     model = PointVolSDF(conf, 24, "dtu", neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
     model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
     return scene, model, TrainStep(model, sync_free=not args.sync, use_graph=use_graph, draws="batch" if (args.exact_draws or world == 1) else "local",
-                                   fork=False if args.no_fork else None)
+                                   fork=bool(args.fork) and not args.no_fork)
 
 
 def eval_cpu_baseline(scene, n_rays):
@@ -673,7 +675,7 @@ def measure_train(args, ctx, w):
     spr = SAMPLES_PER_RAY * rays_total * a.scenes
     counts = model.stats.get("counts")
     if use_graph:
-        launch = ("hipGraph replay (fwd+loss+bwd, independent passes on forked branches) + 2 eager launches (clip + non-finite guard + Adam)" if world == 1 else
+        launch = ("hipGraph replay (fwd+loss+bwd) + 2 eager launches (clip + non-finite guard + Adam)" if world == 1 else
                   "two hipGraph replays ([forward + counts] | 16-byte count all-reduce | [loss + backward]), dense gradient all-reduce, 2 eager launches (clip + guard + Adam)")
     else:
         launch = "eager, reference-shaped (one host read-back)" if args.sync else "eager launches, no host synchronisation (one host-to-device copy of the sampler's CPU random draws per step)"

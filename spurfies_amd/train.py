@@ -33,12 +33,14 @@ class TrainStep:
         and replayed; the gradient all-reduce, clipping and Adam stay eager.  Ray-sharded (world > 1): two graphs around the eager
         16-byte count all-reduce, then ONE dense all-reduce of the flat gradient buffer — the mode for small per-rank batches, where
         the host cannot enqueue ~50 launches as fast as the GPU runs them (strong scaling).
-        fork (default: = use_graph): independent passes of the step are issued on side streams (ops.branch) and become parallel branches of
-        the captured graph — the pseudo-point pass and the TV term beside the colour stage, the weight packing beside the geometry kernel,
-        the head's weight-gradient GEMMs and the geometry passes' latent scatters beside the colour backward: what a small per-GPU batch
-        (latency-bound chains on a mostly idle chip) needs; same kernels, same sums."""
+        fork (default off): independent passes of the step are issued on side streams (ops.branch) and become parallel branches of the
+        captured graph — the pseudo-point pass beside the colour stage (split compositing), the geometry passes' latent scatters beside the
+        colour backward; same kernels, same sums.  Measured on MI355X / ROCm 7.2 (profiles/r05_fork_*.txt): the graph executor
+        serialises child branches onto a few queues in capture order and every cross-queue edge costs 5 - 10 us, so at 128 rays the forked
+        graph is within +-1 % of the single-stream one (0.965 vs 0.957 ms) and LOSES when several scenes' graphs already share the chip
+        (11 scenes: 9.4 vs 8.3 ms per round) — what did pay was folding the independent small launches into launches that exist anyway."""
         self.model = model
-        self.fork = bool(use_graph if fork is None else fork)
+        self.fork = bool(fork) if fork is not None else False
         sync_free = sync_free or use_graph
         self.sync_free = sync_free
         self.use_graph = use_graph

@@ -405,7 +405,7 @@ def test_forked_step_equals_the_single_stream_step():
     gt = {"rgb": torch.rand((128, 3), generator=g)[None].cuda(), "mask": (torch.rand((128,), generator=g) > 0.2).float()[None, :, None].repeat(1, 1, 3).cuda()}
     res = {}
     for name, kw in (("plain", dict(sync_free=True, fork=False)), ("fork", dict(sync_free=True, fork=True)),
-                     ("graph", dict(use_graph=True, fork=False)), ("graph_fork", dict(use_graph=True))):
+                     ("graph", dict(use_graph=True)), ("graph_fork", dict(use_graph=True, fork=True))):
         model = build_model(scene)
         step = TrainStep(model, keep_grads=True, **kw)
         assert step.fork == (name in ("fork", "graph_fork"))

@@ -4,7 +4,7 @@
     python3 tools/strong_proxy.py [--out gpurun_out/strong_proxy.json] [--dense] [--steps 60]
 
 Per ray count: ms/step eager (sync-free launches), ms/step with the forward + loss + backward replayed as one hipGraph (single stream, and
-FORKED: independent passes as parallel branches — TrainStep(fork=True), the default of graphed steps since round 5), the host's time to
+FORKED: independent passes as parallel branches — TrainStep(fork=True)), the host's time to
 ENQUEUE an eager step (if that exceeds the GPU's step time the eager mode is host-bound).
 --scenes S: the configs[3] proxy — S scenes stepped round-robin on two streams (MultiSceneTrainer), every scene with rays/8 rays of its batch
 (what one rank of the 8-GPU run does), graph replays; against the same S scenes at the full batch.
@@ -73,8 +73,8 @@ def multi_scene(a, dev):
     S = a.scenes
     scenes = [syn.make_scene(10000, seed=s, prior="fitted") for s in range(S)]
     rows = []
-    for rays, kw, mode in ((1024, dict(sync_free=True), "eager"), (128, dict(sync_free=True, use_graph=True, fork=False), "graph_single_stream"),
-                           (128, dict(sync_free=True, use_graph=True), "graph")):
+    for rays, kw, mode in ((1024, dict(sync_free=True), "eager"), (128, dict(sync_free=True, use_graph=True), "graph"),
+                           (128, dict(sync_free=True, use_graph=True, fork=True), "graph_forked")):
         built = []
         for s, sc in enumerate(scenes):
             torch.manual_seed(1 + s)
@@ -135,8 +135,8 @@ def main():
     for rays in rays_list:
         batches = bench.make_batches(scene, 32, rays, 0, 1, dev)
         row = {"rays_per_rank": rays, "ranks_implied": rays_list[0] // rays}
-        for mode, kw in (("eager", dict(sync_free=True)), ("graph_single_stream", dict(sync_free=True, use_graph=True, fork=False)),
-                         ("graph", dict(sync_free=True, use_graph=True))):
+        for mode, kw in (("eager", dict(sync_free=True)), ("graph", dict(sync_free=True, use_graph=True)),
+                         ("graph_forked", dict(sync_free=True, use_graph=True, fork=True))):
             torch.manual_seed(1)
             model, step = build(scene, dev, **kw)
             ms, enq_first, enq_med, ms_settled = timed(step, batches, 12, a.steps)
@@ -151,7 +151,7 @@ def main():
         print(json.dumps(row), flush=True)
     base = rows[0]
     for r in rows:
-        for mode in ("eager", "graph_single_stream", "graph"):
+        for mode in ("eager", "graph", "graph_forked"):
             r[mode]["speedup_vs_full_batch"] = base[mode]["ms_per_step"] / r[mode]["ms_per_step"]
             r[mode]["speedup_vs_full_batch_settled"] = base[mode]["ms_per_step_settled"] / r[mode]["ms_per_step_settled"]
     res = {"what": f"strong-scaling proxy, {name} shape: one rank's share of the batch on one MI355X, optimisation step before communication "
