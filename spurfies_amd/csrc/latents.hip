@@ -72,10 +72,17 @@ __global__ void tv_backward_kernel(const float* __restrict__ feat, const int32_t
     else atomicAdd(&g_feat[(size_t)i * 32 + c], own);
 }
 
-// dst[i] += acc[i] * 2^-48 (the exact sum, rounded to fp32 once); acc[i] = 0 for the next use.  A set status word (acc[-1]: some term
-// was non-finite, common.h) turns every dst[i] into NaN; the host side clears the word behind this kernel.
+// dst[i] += acc[i] * 2^-48 (the exact sum, rounded to fp32 once); acc[i] = 0 for the next use.  A set status word (bit 0 of acc[-1]:
+// some term was non-finite, common.h) turns every dst[i] into NaN.  The word is cleared by this launch itself: every workgroup reads it
+// first, takes a ticket in its upper half when it is done, and the LAST workgroup to finish stores zero — no memset behind the kernel (a
+// hipMemsetAsync here became a memset node of a captured step; on ROCm 7.2 such a graph, replayed after a hipDeviceSynchronize, flushed NaN
+// on every later step — found by tools/soak.py's resume leg).
 __global__ void fixed_accumulate_kernel(long long* __restrict__ acc, float* __restrict__ dst, long long n) {
-    const bool poisoned = acc[-1] != 0;
+    __shared__ int s_poisoned;
+    unsigned long long* status = reinterpret_cast<unsigned long long*>(acc - 1);
+    if (threadIdx.x == 0) s_poisoned = (int)(__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1ull);
+    __syncthreads();
+    const bool poisoned = s_poisoned != 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long a = acc[i];
         if (poisoned) {
@@ -86,6 +93,11 @@ __global__ void fixed_accumulate_kernel(long long* __restrict__ acc, float* __re
             dst[i] += (fabs(d) >= 0.5 * FIXED_LIMIT) ? __builtin_nanf("") : (float)(d / FIXED_SCALE);
             acc[i] = 0;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = atomicAdd(status, 1ull << 32) >> 32;       // every workgroup has read the flag before it takes a ticket
+        if (t == (unsigned long long)gridDim.x - 1) __hip_atomic_store(status, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -137,7 +149,6 @@ int spf_fixed_accumulate(int64_t* acc, float* dst, int64_t n, void* stream) {
     if (blocks > 4096) blocks = 4096;
     fixed_accumulate_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<long long*>(acc), dst, (long long)n);
     SPF_LAUNCH_CHECK("fixed_accumulate_kernel");
-    SPF_HIP_CHECK(hipMemsetAsync(acc - 1, 0, sizeof(int64_t), (hipStream_t)stream));      // status word: clear for the next use
     return SPF_OK;
 }
 

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
+
 
 class GraphedRenderer:
     def __init__(self, model, n_rays, fast=-1):
@@ -34,7 +36,7 @@ class GraphedRenderer:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.set_rng_state(rng)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self._graph):
+        with ops.capture_guard(), torch.no_grad(), torch.cuda.graph(self._graph):
             self._out = self.model(dict(self._in, local_data=None), fast=self.fast)
         torch.set_rng_state(rng)            # the captured forward drew from the CPU generator too (ray_sampler.py:562): only __call__'s draws count
         self._flags = self.model.ray_sampler._flags
@@ -120,7 +122,7 @@ class ImageRenderer:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.set_rng_state(rng)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self._graph):
+        with ops.capture_guard(), torch.no_grad(), torch.cuda.graph(self._graph):
             self._chunk()
         # the captured _chunk() ran the forward's CPU-generator draw once more (ray_sampler.py:562): restored, so that a first or re-captured
         # image advances the generator by exactly one draw per chunk, as the eager path does (round-4 advisor finding)

@@ -37,6 +37,29 @@ def _bucket(name):
         _BUCKET_HOOK[0](name)
 
 
+# ---- hipGraph capture: nothing may free device memory while a stream is capturing --------------------------------------------------------
+class capture_guard:
+    """Around every hipGraph capture: collect Python garbage BEFORE it and keep the cyclic collector off DURING it.  A dead model left over
+    from an earlier run sits in reference cycles until the collector happens to run; if that is in the middle of a capture, its VoxelGrid's
+    destructor calls spf_grid_destroy -> hipFree, which is illegal while any stream captures and invalidates the capture (found by
+    tools/soak.py's rebuild-and-resume leg: 'operation failed due to a previous error during capture')."""
+
+    def __enter__(self):
+        import gc
+
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+
+        if self._was:
+            gc.enable()
+        return False
+
+
 # ---- who owns the scratch buffers of the launches being issued ------------------------------------------------------------------------
 # Workspaces (weight-gradient slabs, loss partials, fixed-point accumulators) are cached across steps.  Two steps that may run at the same
 # time must not share one: eager launches are told apart by their stream, but a hipGraph is captured on torch's capture stream whatever

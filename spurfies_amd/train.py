@@ -226,7 +226,7 @@ class TrainStep:
             self._graph = torch.cuda.CUDAGraph()
             self._graph_tail, self._counts = None, None
             if self.world == 1:
-                with torch.cuda.graph(self._graph):
+                with ops.capture_guard(), torch.cuda.graph(self._graph):
                     out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
                     losses = self.loss(out, self._static_gt)
                     if not self.zero_in_adam:      # else the previous step's Adam sweep left the gradient buffer zero: no fill node in the graph
@@ -244,11 +244,11 @@ class TrainStep:
                 # invisible to its peers, whose collective sequences stay aligned (round-4 advisor finding: a lone re-capture used to issue
                 # three extra all-reduces and hang the group).
                 pool = torch.cuda.graph_pool_handle()
-                with torch.cuda.graph(self._graph, pool=pool):
+                with ops.capture_guard(), torch.cuda.graph(self._graph, pool=pool):
                     out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
                     self._counts = sdist.fused_counts(out)
                 self._graph_tail = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph_tail, pool=pool):
+                with ops.capture_guard(), torch.cuda.graph(self._graph_tail, pool=pool):
                     losses = self.loss.fused_forward(out, self._static_gt, denom=self._counts, world=self.world)
                     if not self.zero_in_adam:
                         self.flat.zero_()
@@ -274,6 +274,24 @@ class TrainStep:
             sdist.all_reduce_sum(self._counts, self.group)
             self._graph_tail.replay()
         return self._static_out
+
+    # ---- whole-step state: what a run needs to CONTINUE as if it had not stopped ---------------------------------------------------
+    def state_dict(self):
+        """Model, optimiser moments, learning-rate schedule, step counter and the CPU generator the reference draws its per-step random
+        numbers from (ray_sampler.py:55,514,550,562).  The reference's own checkpoints (train.py:221-241: model + optimiser, written by
+        VolOpt.save_checkpoints in the same layout) restart the schedule and the generator; with this blob a resumed run takes the same
+        steps the uninterrupted one would have — bit for bit under ops.set_scatter_mode("fixed") (tools/soak.py, tests/test_gpu_model.py)."""
+        return {"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+                "scheduler_state_dict": self.scheduler.state_dict(), "iter_step": self.iter_step, "cpu_rng_state": torch.get_rng_state()}
+
+    def load_state_dict(self, blob):
+        self.model.load_state_dict(blob["model_state_dict"])
+        self.optimizer.load_state_dict(blob["optimizer_state_dict"])
+        self.scheduler.load_state_dict(blob["scheduler_state_dict"])
+        self.iter_step = int(blob["iter_step"])
+        torch.set_rng_state(blob["cpu_rng_state"].cpu())        # torch.load(map_location=device) moves it
+        self.flat.zero_()                  # re-attach the flat gradient views
+        self._grads_clean = False
 
     def _root_grad(self, loss):
         if self._one is None or self._one.device != loss.device:

@@ -363,6 +363,60 @@ def test_fixed_scatter_mode_makes_the_whole_step_bit_reproducible():
         np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6 * float(np.abs(b).max()), err_msg=n)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_resumed_run_continues_bit_for_bit_in_fixed_scatter_mode(tmp_path, graph):
+    """TrainStep.state_dict() (model, Adam moments, cosine schedule, step counter, the CPU generator of the reference's per-step draws —
+    ray_sampler.py:55,514,550,562) written after three steps and loaded into a REBUILT model + step: the next three steps end in exactly
+    the parameters and moments of the uninterrupted six-step run (ops.set_scatter_mode("fixed"): no summation-order noise)."""
+    from spurfies_amd import ops
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.train import TrainStep
+
+    scene = syn.make_scene(4000, seed=15, prior="fitted")
+    g = torch.Generator().manual_seed(6)
+    K = torch.from_numpy(scene["intrinsics"])[None].cuda()
+    batches = []
+    for it in range(6):
+        uv = torch.from_numpy(syn.make_pixels(256, g))[None].cuda()
+        pose = torch.from_numpy(scene["poses"][it % 3])[None].cuda()
+        batches.append(({"intrinsics": K, "uv": uv, "pose": pose, "local_data": None},
+                        {"rgb": torch.rand((256, 3), generator=g)[None].cuda(), "mask": (torch.rand((256,), generator=g) > 0.2).float()[None, :, None].repeat(1, 1, 3).cuda()}))
+
+    def flat_state(step):
+        f = step.optimizer._flat
+        return [f[k].clone() for k in ("param", "m", "v")] + [torch.tensor(step.optimizer.param_groups[1]["lr"])]
+
+    ops.set_scatter_mode("fixed")
+    try:
+        step = TrainStep(build_model(scene), sync_free=True, use_graph=graph)
+        torch.manual_seed(3)
+        for i, b in enumerate(batches):
+            step(dict(b[0]), b[1])
+            if i == 1:
+                # a device-wide synchronisation between two replays of one captured step: with a hipMemsetAsync node in the graph (the
+                # accumulators' status word used to be cleared that way) every replay after it flushed NaN on ROCm 7.2 and Adam skipped
+                torch.cuda.synchronize()
+        assert step.optimizer._flat["state"].tolist()[:2] == [6.0, 0.0], "six updates, none skipped"
+        straight = flat_state(step)
+        step = TrainStep(build_model(scene), sync_free=True, use_graph=graph)
+        torch.manual_seed(3)
+        for b in batches[:3]:
+            step(dict(b[0]), b[1])
+        torch.save(step.state_dict(), tmp_path / "state.pth")
+        del step
+        torch.manual_seed(999)                                   # a resumed process starts from some other generator state
+        step = TrainStep(build_model(scene), sync_free=True, use_graph=graph)
+        step.load_state_dict(torch.load(tmp_path / "state.pth", map_location="cuda"))
+        assert step.iter_step == 3 and step.scheduler.last_epoch == 3
+        for b in batches[3:]:
+            step(dict(b[0]), b[1])
+        resumed = flat_state(step)
+    finally:
+        ops.set_scatter_mode("atomic")
+    for name, a, b in zip(("parameters", "exp_avg", "exp_avg_sq", "lr"), straight, resumed):
+        assert torch.equal(a.cpu(), b.cpu()), f"{name} of the resumed run differ from the uninterrupted run"
+
+
 def test_graphed_step_tracks_eager_step():
     """hipGraph replay of forward + loss + backward gives the same three-step trajectory as eager launches."""
     from spurfies_amd import synthetic as syn
