@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--local", action="store_true", help="also time the DTU recipe's real step: synthetic local_data on every batch (find_surface_points + "
                     "feature-consistency loss, local_weight 0.5) -> extra record + ms_per_step_with_local")
     ap.add_argument("--gc", choices=["off", "on"], default="off", help="Python's cyclic garbage collector during the timed regions (off: collected once before them)")
-    ap.add_argument("--settle", type=float, default=1.0, help="seconds of the same step run UNTIMED behind the --warmup steps, before the timed region, so that "
+    ap.add_argument("--settle", type=float, default=2.0, help="seconds of the same step run UNTIMED behind the --warmup steps, before the timed region, so that "
                     "the chip's clock has settled under load (the 20-step region read 6.7 %% faster than the sustained one without it)")
     ap.add_argument("--points", type=int, default=10000, help="neural points (DTU-like cloud)")
     ap.add_argument("--spacing", type=float, default=0.025, help="nearest-neighbour spacing of the synthetic cloud (0.0125 = dense stress cloud)")
@@ -611,12 +611,16 @@ def measure_train(args, ctx, w):
     dt = float(tmax.item())
     sustained = None
     if n_sust > 0:        # the same step over a >= 1 s region, reported beside the contract region
-        sync()
+        if not use_graph:
+            ops.profile_start(tags=("geo",))      # the SAME instrumentation as the contract region (its events cost ~1 % of a step): the two
+        sync()                                    # figures then differ by settling only; this region's events are discarded
         t1 = time.perf_counter()
         for i in range(first + steps, first + steps + n_sust):
             run_step(i)
         sync()
         ts = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+        if not use_graph:
+            ops.profile_stop()
         if world > 1:
             torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
         sustained = float(ts.item()) / n_sust * 1e3

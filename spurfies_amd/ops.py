@@ -68,12 +68,33 @@ class capture_guard:
 _SCRATCH_OWNER = [None]
 
 
+_OWNER_TOKENS = [0]
+
+
+def _drop_owner(token):
+    """The owner died: its cached workspaces go with it (a token is never reused, unlike id(): a later step must not inherit them)."""
+    for cache in (_fixed_bufs, _wgrad_ws, _loss_ws):
+        for key in [k for k in cache if len(k) > 1 and isinstance(k[1], tuple) and k[1][:2] == ("owner", token)]:
+            del cache[key]
+    for key in [k for k in _FORK_USED if k[0] == token]:
+        del _FORK_USED[key]
+    for key in [k for k in _FORK_STREAMS if k[0] == token]:
+        del _FORK_STREAMS[key]
+
+
 class scratch_owner:
     def __init__(self, owner):
         self.owner = owner
 
     def __enter__(self):
-        self.prev, _SCRATCH_OWNER[0] = _SCRATCH_OWNER[0], id(self.owner)
+        token = getattr(self.owner, "_spf_scratch_token", None)
+        if token is None:
+            import weakref
+
+            _OWNER_TOKENS[0] += 1
+            token = self.owner._spf_scratch_token = _OWNER_TOKENS[0]
+            weakref.finalize(self.owner, _drop_owner, token)
+        self.prev, _SCRATCH_OWNER[0] = _SCRATCH_OWNER[0], token
         return self
 
     def __exit__(self, *exc):

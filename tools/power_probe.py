@@ -296,6 +296,20 @@ def main():
         print("color_bwd", row, flush=True)
     except Exception as e:                       # the C signature moves with the rounds; the other rows stand on their own
         res["loads"]["color_bwd"] = {"error": repr(e)[:300]}
+    # one weight-gradient GEMM of the colour trunk's shape (dW[256,256] += G^T A over NP rows, row-major operands, bf16-piece products)
+    try:
+        rows_w = (NP // 64) * 64
+        Gw, Aw = torch.randn((rows_w, 256), device="cuda"), torch.randn((rows_w, 256), device="cuda")
+        dW, db = torch.zeros((256, 256), device="cuda"), torch.zeros((256,), device="cuda")
+        nr = torch.tensor([rows_w], dtype=torch.int32, device="cuda")
+        row = run_for(lambda: ops.wgrad(Gw, Aw, nr, out=dW, dbias=db), a.secs, smp, "wgrad_256")
+        row.update({"what": f"spf_wgrad C = 256 (GEMM + slab reduce launches), {rows_w} rows", "tflops_algorithmic": rows_w * 2.0 * 256 * 256 / (row["ms_per_launch"] * 1e-3) / 1e12})
+        row["frac_of_peak"] = row["tflops_algorithmic"] / bench.PEAK_SPLIT_TFLOPS
+        res["loads"]["wgrad_256"] = row
+        print("wgrad_256", row, flush=True)
+        del Gw, Aw
+    except Exception as e:
+        res["loads"]["wgrad_256"] = {"error": repr(e)[:300]}
     del G, gb, gf, out, act0, act1, act2
 
     # the whole optimisation step
