@@ -544,6 +544,15 @@ def measure_train(args, ctx, w):
     # for >= args.settle seconds more (extra warm-up, whatever --warmup says) before the contract region; both figures stay in the line.
     sync()
     per = max((time.perf_counter() - t_w) / max(warmup, 1), 1e-4)
+    # Python's cyclic collector is kept out of the timed regions (a generation-2 pass over this process's ~10^6 objects takes ~0.1 s: one of
+    # them inside a 40-step region doubled its reading); collected once HERE — in front of the settle phase, not between it and the timed region:
+    # 0.1 - 0.3 s of idle GPU there let the chip drop its clock state, and the first steps of a 20-step region paid for the ramp (+2 - 3 %)
+    import gc
+
+    gc_was = gc.isenabled()
+    if args.gc == "off":
+        gc.collect()
+        gc.disable()
     settle = 0
     if args.settle > 0:
         t_s = time.perf_counter()
@@ -559,14 +568,6 @@ def measure_train(args, ctx, w):
     for _, _, st_ in scenes:
         if st_.buckets is not None:
             st_.buckets.timing = []               # an event pair around every finish(): the exposed part of the gradient exchange
-    # Python's cyclic collector is kept out of the timed regions (a generation-2 pass over this process's ~10^6 objects takes ~0.1 s: one of
-    # them inside a 40-step region doubled its reading); collected once here, re-enabled at the end of the measurement
-    import gc
-
-    gc_was = gc.isenabled()
-    if args.gc == "off":
-        gc.collect()
-        gc.disable()
     sync()
     host_max = 0.0
     t0 = time.perf_counter()

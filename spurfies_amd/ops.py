@@ -93,7 +93,7 @@ class scratch_owner:
 
             _OWNER_TOKENS[0] += 1
             token = self.owner._spf_scratch_token = _OWNER_TOKENS[0]
-            weakref.finalize(self.owner, _drop_owner, token)
+            weakref.finalize(self.owner, _drop_owner, token).atexit = False      # at interpreter exit the caches go with the process
         self.prev, _SCRATCH_OWNER[0] = _SCRATCH_OWNER[0], token
         return self
 

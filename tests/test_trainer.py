@@ -42,6 +42,31 @@ def test_checkpoint_layout_and_roundtrip_cpu(tmp_path):
     assert all(not p.requires_grad for n, p in t2.model.named_parameters() if n.startswith(("F_geometry", "T.")))
 
 
+def test_whole_step_state_roundtrip_cpu(tmp_path):
+    """TrainStep.state_dict() carries what the reference's two checkpoint files do not (train.py:221-241 saves model + optimiser): the cosine
+    schedule's position, the step counter and the CPU generator of the per-step draws — loaded into a fresh step they are all back."""
+    t, _ = _volopt(tmp_path, "cpu")
+    step = t.step
+    for _ in range(5):                                   # five schedule positions without touching the GPU path
+        step.optimizer.step()
+        step.scheduler.step()
+        step.iter_step += 1
+    with torch.no_grad():
+        step.model.neural_feats_color.add_(0.5)
+    torch.manual_seed(41)
+    torch.rand(7)
+    blob = step.state_dict()
+    expect = torch.rand(5)                               # what the run would have drawn next
+    torch.save(blob, tmp_path / "state.pth")
+    t2, _ = _volopt(tmp_path / "fresh", "cpu")
+    torch.manual_seed(0)
+    t2.step.load_state_dict(torch.load(tmp_path / "state.pth"))
+    assert t2.step.iter_step == 5 and t2.step.scheduler.last_epoch == 5
+    assert t2.step.optimizer.param_groups[1]["lr"] == step.optimizer.param_groups[1]["lr"] < 5.0e-4
+    assert torch.equal(t2.step.model.neural_feats_color, step.model.neural_feats_color)
+    assert torch.equal(torch.rand(5), expect)
+
+
 def test_resume_keeps_checkpoint_latents_over_start_values(tmp_path):
     """`init_state_dict` (runner.py: the fitted geometry latents) holds START values: on is_continue they are applied before the
     checkpoint is restored, so a resumed run keeps its trained latents (round-2 advisor finding: they were reset to step 0)."""
