@@ -756,13 +756,39 @@ def main():
                        "sustained": 0, "light": True, "strong": strong, "local": True,
                        "record": "the main workload with the DTU recipe's feature-consistency loss (local_weight 0.5) on every step"})
     res["extra"] = []
+    # The extra records must never cost the contract line: a rank that fails or hangs inside one of them (a collective its peers never reach)
+    # would leave rank 0 without anything to print.  Every rank arms the same timer; when it fires, rank 0 prints the main record with what
+    # the extras have produced so far and all ranks leave (os._exit: no second program is started, nothing waits for the stuck collective).
+    import threading
+
+    def abandon():
+        if rank == 0:
+            res["extra"].append({"record": "extras abandoned", "error": f"an extra record failed or did not finish within {limit:.0f} s (SPF_EXTRAS_TIMEOUT); "
+                                                                     "the main record above is complete"})
+            res.setdefault("cpu_baseline", None)
+            print(json.dumps(res), flush=True)
+        os._exit(0)
+
+    limit = float(os.environ.get("SPF_EXTRAS_TIMEOUT", "300"))
+    timer = threading.Timer(limit, abandon) if (extras and limit > 0) else None
+    if timer is not None:
+        timer.daemon = True
+        timer.start()
     for w in extras:
-        r, _ = measure_train(args, ctx, w)
+        try:
+            r, _ = measure_train(args, ctx, w)
+        except Exception as e:  # noqa: BLE001 — recorded in the line; at world > 1 the peers' timer ends the run if they wait for this rank
+            res["extra"].append({"record": w["record"], "error": repr(e)[:400]})
+            if world > 1:
+                abandon()              # the peers are inside collectives this rank will not join: leave now, their timers end them
+            continue
         keep = {"record": w["record"], **{k: r[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "dist", "loss_last")}}
         keep["roofline"] = None if r["roofline"] is None else {k: r["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_ms", "pairs_per_launch", "kernel")}
         res["extra"].append(keep)
         if w["local"]:
             res["ms_per_step_with_local"] = r["ms_per_step"]
+    if timer is not None:
+        timer.cancel()
     if rank == 0:
         res["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(scene, args.cpu_rays)     # N = 1 only
         print(json.dumps(res), flush=True)

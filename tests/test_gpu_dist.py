@@ -281,6 +281,18 @@ def test_bench_starts_its_own_ranks_when_called_without_a_launcher():
     assert d["finish_ms_per_step"] is not None and d["finish_ms_per_step"] >= 0.0
 
 
+def test_bench_keeps_the_contract_line_when_the_extra_records_do_not_finish():
+    """The extra records (configs[4], weak scaling) run AFTER the contract measurement; if they fail or hang, every rank's timer ends the run
+    and rank 0 still prints the complete main record (SPF_EXTRAS_TIMEOUT, here far too short for any extra to finish)."""
+    out = _bench_self_launched(["--rays", "256", "--c4-points", "6000", "--c4-rays", "512"], env_extra={"SPF_EXTRAS_TIMEOUT": "0.05"}, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["roofline"] is not None
+    assert rec["extra"] and rec["extra"][-1]["record"] == "extras abandoned" and "SPF_EXTRAS_TIMEOUT" in rec["extra"][-1]["error"]
+
+
 def test_bench_refuses_rccl_with_fewer_gpus_than_ranks_and_fails_loudly_on_a_hung_bring_up():
     if torch.cuda.device_count() < 2:
         out = _bench_self_launched(["--rays", "64"], env_extra={"SPF_DIST_BACKEND": "nccl"})
