@@ -389,11 +389,11 @@ __device__ __forceinline__ void store_quad_x3_tops(__bf16* X, int row, int f0, f
 // 0.01 h for four accumulator values (the bias is already in the accumulators)
 __device__ __forceinline__ void scale4(const f32x16& acc, int g, f32x4& v, f32x4& vs);
 
-// [64][8 * NG] tile of the planes (exactly p1 + p2 + p3 per element) -> fp32 rows in HBM, coalesced (32 B per thread, a row's
+// [ROWS][8 * NG] tile of the planes (exactly p1 + p2 + p3 per element) -> fp32 rows in HBM, coalesced (32 B per thread, a row's
 // threads are consecutive): what the weight-gradient GEMM reads.
-template <int NG, int LDP = X3_LDP>
+template <int NG, int LDP = X3_LDP, int ROWS = 64>
 __device__ __forceinline__ void store_tile_from_planes(const __bf16* X, float* __restrict__ dst, int ld_dst, int tid) {
-    for (int idx = tid; idx < 64 * NG; idx += 256) {
+    for (int idx = tid; idx < ROWS * NG; idx += 256) {
         const int row = idx / NG, gc = idx % NG;
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(X + row * LDP + 8 * gc);
         const bf16x8 b = *reinterpret_cast<const bf16x8*>(X + (64 * LDP) + row * LDP + 8 * gc);

@@ -350,7 +350,8 @@ __device__ __forceinline__ RxBias rx_load_bias(gfp bias, int wave, int lane) {
 
 // transposed epilogues (lane = row j of half n, 4 consecutive features per quad): linear (acc + b), LeakyReLU forward (sign words
 // pushed in the order (m, g, e), stored lane-major) and LeakyReLU backward (popped in the same order)
-__device__ __forceinline__ void rx_linear_epilogue(__bf16* X, const f32x16 (&acc)[2][2], const RxBias* bias, int wave, int lane) {
+template <int NT>
+__device__ __forceinline__ void rx_linear_epilogue(__bf16* X, const f32x16 (&acc)[2][NT], const RxBias* bias, int wave, int lane) {
     const int j = lane & 31, kg = lane >> 5;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -358,24 +359,26 @@ __device__ __forceinline__ void rx_linear_epilogue(__bf16* X, const f32x16 (&acc
         for (int g = 0; g < 4; ++g) {
             const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 f32x4 h = f32x4{acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
                 if (bias) h += bias->b[m][g];
                 store_quad_x3<RX_LDP>(X, 32 * n + j, f0, h);
             }
         }
 }
-template <bool STORE>
-__device__ __forceinline__ void rx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], const RxBias& bias, int wave, int lane, uint32_t* masks_l) {
+template <bool STORE, int NT>
+__device__ __forceinline__ void rx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][NT], const RxBias& bias, int wave, int lane, uint32_t* masks_l) {
     const int j = lane & 31, kg = lane >> 5;
-    uint32_t bits[2] = {0u, 0u};
+    uint32_t bits[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bits[n] = 0u;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 f32x4 h, hs, out;
                 bias_scale4(acc[m][n], g, bias.b[m][g], h, hs);
 #pragma unroll
@@ -384,20 +387,23 @@ __device__ __forceinline__ void rx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2
             }
         }
     if (STORE) {
-        masks_l[(2 * wave) * 64 + lane] = bits[0];
-        masks_l[(2 * wave + 1) * 64 + lane] = bits[1];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) masks_l[(NT * wave + n) * 64 + lane] = bits[n];
     }
 }
-__device__ __forceinline__ void rx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mw)[2]) {
+template <int NT>
+__device__ __forceinline__ void rx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2][NT], int wave, int lane, const uint32_t (&mw)[NT]) {
     const int j = lane & 31, kg = lane >> 5;
-    uint32_t bits[2] = {mw[0], mw[1]};
+    uint32_t bits[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bits[n] = mw[n];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 f32x4 v, vs, out;
                 scale4(acc[m][n], g, v, vs);
 #pragma unroll
@@ -407,44 +413,43 @@ __device__ __forceinline__ void rx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2
         }
 }
 
-template <bool STORE>
-__global__ void __launch_bounds__(256, 1)
-rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict__ ray_dirs, const int32_t* __restrict__ point_slot,
-                        const int32_t* __restrict__ n_points_dev, int max_points, int SR, const float* packed, float* __restrict__ colors,
-                        float* __restrict__ agg, float* __restrict__ direnc, float* __restrict__ act1, float* __restrict__ act2,
-                        uint32_t* __restrict__ masks) {
-    __shared__ __attribute__((aligned(16))) __bf16 X[3 * 64 * RX_LDP];
-    __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
-    __shared__ int s_row[64];
+// One workgroup's tiles.  NT = 2: tiles of 64 points (rounds 1 - 4); NT = 1 (round 5): HALF-HEIGHT tiles of 32 points — twice the tiles at ~55 % of a
+// tile's time each, taken when the launch has at most 32 points per workgroup (the 128-rays-per-GPU step: 6.5 k points were 102 tiles on 102 of 256
+// CUs, one ~45 us tile pass each).  Forward and backward make the same choice (same point count, same grid): the sign words' layout depends on it.
+template <bool STORE, int NT>
+__device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int* s_row, const float* __restrict__ agg3, const float* __restrict__ ray_dirs,
+                                                      const int32_t* __restrict__ point_slot, const int P, int SR, const float* packed,
+                                                      float* __restrict__ colors, float* __restrict__ agg, float* __restrict__ direnc,
+                                                      float* __restrict__ act1, float* __restrict__ act2, uint32_t* __restrict__ masks) {
+    constexpr int ROWS = 32 * NT, PARTS = 256 / ROWS, PW = 256 / PARTS, NV = PW / 4;      // gather: thread = (row, part): PW agg3 floats each
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
-    const int ntiles = (P + 63) / 64;
+    const int ntiles = (P + ROWS - 1) / ROWS;
     const float* packed0 = packed;
     T_DECL
-    // this thread's gather operands (row = tid >> 2, quarter = tid & 3: 64 agg3 floats; quarter 0 also the ray direction) are requested one
+    // this thread's gather operands (row = tid / PARTS, part = tid % PARTS; part 0 also the ray direction) are requested one
     // tile ahead: the slot lookup before the second GEMM, the rows right after the last GEMM's weight requests (vector-memory results
     // return in order: requested earlier, the GEMMs' weight fragments would wait behind these HBM rows; and a dependent lookup issued
-    // after them would wait for all sixteen), so they land under the last epilogue and the stores
-    f32x4 v[16];
+    // after them would wait for all of them), so they land under the last epilogue and the stores
+    f32x4 v[NV];
     float dnext[3] = {0.f, 0.f, 0.f};
     int srow_next = -1, slot_pf = -1;
     auto fetch_slot = [&](int t) {
-        const int p = t * 64 + (tid >> 2);
-        slot_pf = ((tid & 3) == 0 && t < ntiles && p < P) ? (point_slot ? point_slot[p] : p) : -1;
+        const int p = t * ROWS + tid / PARTS;
+        slot_pf = ((tid % PARTS) == 0 && t < ntiles && p < P) ? (point_slot ? point_slot[p] : p) : -1;
     };
     auto fetch_rows = [&](int t) {
-        const int row = tid >> 2, q4 = tid & 3;
-        const int p = t * 64 + row;
+        const int row = tid / PARTS, q = tid % PARTS;
+        const int p = t * ROWS + row;
         const bool ok = t < ntiles && p < P;
         srow_next = slot_pf;
         if (srow_next >= 0) {
             const float* dv = ray_dirs + (size_t)(srow_next / SR) * 3;
             dnext[0] = dv[0]; dnext[1] = dv[1]; dnext[2] = dv[2];
         }
-        const f32x4* src = reinterpret_cast<const f32x4*>(agg3 + (size_t)(ok ? p : 0) * 256 + q4 * 64);
+        const f32x4* src = reinterpret_cast<const f32x4*>(agg3 + (size_t)(ok ? p : 0) * 256 + q * PW);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = ok ? src[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NV; ++u) v[u] = ok ? src[u] : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     fetch_slot((int)blockIdx.x);
     fetch_rows((int)blockIdx.x);
@@ -457,11 +462,11 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
         gx3 w_fw2 = frag + RX_FW2 + wave * (RX_TH * 2 * 3 * 64) + lane;
         const WFrag3 fr6 = load_wfrag3(w_fw6);               // in flight during the gather
         T_MARK(0)
-        {   // gather: thread = (row, quarter): 64 agg3 floats each; quarter 0 also encodes the view direction (columns 256..287)
-            const int row = tid >> 2, q4 = tid & 3;
+        {   // gather: thread = (row, part): PW agg3 floats each; part 0 also encodes the view direction (columns 256..287)
+            const int row = tid / PARTS, q = tid % PARTS;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) store_quad_x3<RX_LDP>(X, row, q4 * 64 + 4 * u, v[u]);
-            if (q4 == 0) {
+            for (int u = 0; u < NV; ++u) store_quad_x3<RX_LDP>(X, row, q * PW + 4 * u, v[u]);
+            if (q == 0) {
                 float e[32];
 #pragma unroll
                 for (int c = 0; c < 32; ++c) e[c] = 0.f;
@@ -486,7 +491,7 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
                 if (STORE) {
 #pragma unroll
                     for (int c4 = 0; c4 < 6; ++c4)
-                        *reinterpret_cast<f32x4*>(direnc + (size_t)(tile * 64 + row) * 24 + 4 * c4) = f32x4{e[4 * c4], e[4 * c4 + 1], e[4 * c4 + 2], e[4 * c4 + 3]};
+                        *reinterpret_cast<f32x4*>(direnc + (size_t)(tile * ROWS + row) * 24 + 4 * c4) = f32x4{e[4 * c4], e[4 * c4 + 1], e[4 * c4 + 2], e[4 * c4 + 3]};
                 }
                 s_row[row] = srow;
             }
@@ -494,46 +499,48 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
         T_MARK(1)
         lds_barrier();
         T_MARK(2)
-        const size_t tb = (size_t)tile * 64 * 256;
-        uint32_t* mk = STORE ? masks + (size_t)tile * 2 * 512 : nullptr;
-        f32x16 acc[2][2];
+        const size_t tb = (size_t)tile * ROWS * 256;
+        uint32_t* mk = STORE ? masks + (size_t)tile * 2 * (256 * NT) : nullptr;       // [layer 2][wave 4][row half NT][lane 64]
+        f32x16 acc[2][NT];
         RxBias bias = rx_load_bias(pf + RO_B6, wave, lane);
-        zero_acc(acc);
-        WFrag3 nf = gemm_x3<RX_TH, false, RX_LDP>(X, w_fw6, lane, acc, fr6, w_fw1);          // F_color.6 on the weighted mean
+        WFrag3 nf = gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_fw6, lane, acc, fr6, w_fw1);          // F_color.6 on the weighted mean
         T_MARK(3)
         lds_barrier();
         T_MARK(2)
-        rx_linear_epilogue(X, acc, &bias, wave, lane);       // agg -> columns 0..255 (the dir-enc columns stay)
+        rx_linear_epilogue<NT>(X, acc, &bias, wave, lane);       // agg -> columns 0..255 (the dir-enc columns stay)
         T_MARK(4)
         lds_barrier();
         T_MARK(2)
-        if (STORE) store_tile_from_planes<32, RX_LDP>(X, agg + tb, 256, tid);              // kept for R.0's weight gradient
+        if (STORE) store_tile_from_planes<32, RX_LDP, ROWS>(X, agg + tb, 256, tid);              // kept for R.0's weight gradient
         T_MARK(5)
         bias = rx_load_bias(pf + RO_B1, wave, lane);
         fetch_slot(tile + (int)gridDim.x);
-        zero_acc(acc);
-        nf = gemm_x3<RX_T1, false, RX_LDP>(X, w_fw1, lane, acc, nf, w_fw2);
+        nf = gemm_x3<RX_T1, false, RX_LDP, NT>(X, w_fw1, lane, acc, nf, w_fw2);
         T_MARK(3)
         lds_barrier();
         T_MARK(2)
-        rx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, mk);
+        rx_fwd_epilogue<STORE, NT>(X, acc, bias, wave, lane, mk);
         T_MARK(4)
         lds_barrier();
         T_MARK(2)
-        if (STORE) store_tile_from_planes<32, RX_LDP>(X, act1 + tb, 256, tid);
+        if (STORE) store_tile_from_planes<32, RX_LDP, ROWS>(X, act1 + tb, 256, tid);
         T_MARK(5)
         bias = rx_load_bias(pf + RO_B2, wave, lane);
         const RxBias w3q0 = rx_load_bias(pf + RO_W3, wave, lane), w3q1 = rx_load_bias(pf + RO_W3 + 256, wave, lane),
                      w3q2 = rx_load_bias(pf + RO_W3 + 512, wave, lane);      // the 3 x 256 last layer, this lane's quads: ahead of the GEMM
-        zero_acc(acc);
-        gemm_x3<RX_TH, false, RX_LDP>(X, w_fw2, lane, acc, nf, nullptr);
+        gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_fw2, lane, acc, nf, nullptr);
         fetch_rows(tile + (int)gridDim.x);
         T_MARK(3)
         lds_barrier();
         T_MARK(2)
         {   // second activation (-> planes for the act2 store) and the 256 -> 3 layer from the registers: partial dot products per lane
-            uint32_t bits[2] = {0u, 0u};
-            float s[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            uint32_t bits[NT];
+            float s3[NT][3];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bits[n] = 0u;
+                s3[n][0] = s3[n][1] = s3[n][2] = 0.f;
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -541,36 +548,36 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
                     const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
                     const f32x4 w3[3] = {w3q0.b[m][g], w3q1.b[m][g], w3q2.b[m][g]};
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
+                    for (int n = 0; n < NT; ++n) {
                         f32x4 h, hs, out;
                         bias_scale4(acc[m][n], g, bias.b[m][g], h, hs);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             out[e] = lrelu_push(h[e], hs[e], bits[n]);
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) s[n][c] += w3[c][e] * out[e];
+                            for (int c = 0; c < 3; ++c) s3[n][c] += w3[c][e] * out[e];
                         }
                         if (STORE) store_quad_x3<RX_LDP>(X, 32 * n + j, f0, out);
                     }
                 }
             if (STORE) {
-                mk[512 + (2 * wave) * 64 + lane] = bits[0];
-                mk[512 + (2 * wave + 1) * 64 + lane] = bits[1];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) mk[256 * NT + (NT * wave + n) * 64 + lane] = bits[n];
             }
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float t = s[n][c] + __shfl_xor(s[n][c], 32);
+                    const float t = s3[n][c] + __shfl_xor(s3[n][c], 32);
                     if (kg == 0) red[(wave * 64 + 32 * n + j) * 4 + c] = t;
                 }
         }
         T_MARK(4)
         lds_barrier();
         T_MARK(2)
-        if (STORE) store_tile_from_planes<32, RX_LDP>(X, act2 + tb, 256, tid);
+        if (STORE) store_tile_from_planes<32, RX_LDP, ROWS>(X, act2 + tb, 256, tid);
         T_MARK(5)
-        if (tid < 64) {
+        if (tid < ROWS) {
             const int srow = s_row[tid];
             if (srow >= 0) {
 #pragma unroll
@@ -587,18 +594,33 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
     T_FLUSH
 }
 
+template <bool STORE>
 __global__ void __launch_bounds__(256, 1)
-rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __restrict__ colors, const int32_t* __restrict__ point_slot,
-                         const int32_t* __restrict__ n_points_dev, int max_points, const float* packed, const float* __restrict__ act2,
-                         const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ g_agg,
-                         float* __restrict__ g_agg3, float* __restrict__ g_w4 /* [3,256] */, float* __restrict__ g_b4 /* [3] */,
-                         long long* __restrict__ g_w4_fixed, long long* __restrict__ g_b4_fixed) {
+rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict__ ray_dirs, const int32_t* __restrict__ point_slot,
+                        const int32_t* __restrict__ n_points_dev, int max_points, int SR, const float* packed, float* __restrict__ colors,
+                        float* __restrict__ agg, float* __restrict__ direnc, float* __restrict__ act1, float* __restrict__ act2,
+                        uint32_t* __restrict__ masks) {
     __shared__ __attribute__((aligned(16))) __bf16 X[3 * 64 * RX_LDP];
-    __shared__ __attribute__((aligned(16))) float s_g3[64 * 4];
+    __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+    __shared__ int s_row[64];
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    if (P <= 32 * (int)gridDim.x)
+        rhead_forward_x3_body<STORE, 1>(X, red, s_row, agg3, ray_dirs, point_slot, P, SR, packed, colors, agg, direnc, act1, act2, masks);
+    else
+        rhead_forward_x3_body<STORE, 2>(X, red, s_row, agg3, ray_dirs, point_slot, P, SR, packed, colors, agg, direnc, act1, act2, masks);
+}
+
+template <int NT>
+__device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, const float* __restrict__ g_colors, const float* __restrict__ colors,
+                                                       const int32_t* __restrict__ point_slot, const int P, const float* packed,
+                                                       const float* __restrict__ act2, const uint32_t* __restrict__ masks, float* __restrict__ G1,
+                                                       float* __restrict__ G2, float* __restrict__ g_agg, float* __restrict__ g_agg3,
+                                                       float* __restrict__ g_w4 /* [3,256] */, float* __restrict__ g_b4 /* [3] */,
+                                                       long long* __restrict__ g_w4_fixed, long long* __restrict__ g_b4_fixed) {
+    constexpr int ROWS = 32 * NT;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
-    const int ntiles = (P + 63) / 64;
+    const int ntiles = (P + ROWS - 1) / ROWS;
     const float* packed0 = packed;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -607,10 +629,10 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
         gx3 w_bw2 = frag + RX_BW2 + wave * (RX_TH * 2 * 3 * 64) + lane;
         gx3 w_bwa = frag + RX_BWA + wave * (RX_TH * 2 * 3 * 64) + lane;
         gx3 w_bw6 = frag + RX_BW6 + wave * (RX_TH * 2 * 3 * 64) + lane;
-        const size_t tb = (size_t)tile * 64 * 256;
+        const size_t tb = (size_t)tile * ROWS * 256;
         const WFrag3 fr2 = load_wfrag3(w_bw2);               // in flight during the small last-layer stage
-        if (tid < 64) {   // dL/d(pre-sigmoid) = g_c * c (1 - c)
-            const int p = tile * 64 + tid;
+        if (tid < ROWS) {   // dL/d(pre-sigmoid) = g_c * c (1 - c)
+            const int p = tile * ROWS + tid;
             float g[3] = {0.f, 0.f, 0.f};
             if (p < P) {
                 const int srow = point_slot ? point_slot[p] : p;
@@ -623,11 +645,13 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
             *reinterpret_cast<f32x4*>(s_g3 + tid * 4) = f32x4{g[0], g[1], g[2], 0.f};
         }
         lds_barrier();
-        const uint32_t* mk = masks + (size_t)tile * 2 * 512;
-        uint32_t bits[2] = {mk[512 + (2 * wave) * 64 + lane], mk[512 + (2 * wave + 1) * 64 + lane]};    // G2 stage's sign words, ahead of the dW3 stage
+        const uint32_t* mk = masks + (size_t)tile * 2 * (256 * NT);       // the forward's layout: [layer 2][wave 4][row half NT][lane 64]
+        uint32_t bits[NT];                                                 // G2 stage's sign words, ahead of the dW3 stage
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bits[n] = mk[256 * NT + (NT * wave + n) * 64 + lane];
         {   // dW3[c][col] += sum_rows g3[row][c] a2[row][col]; db3[c] += sum_rows g3[row][c]   (thread = column)
             float a0 = 0.f, a1 = 0.f, a2v = 0.f;
-            const int rows_here = min(64, P - tile * 64);
+            const int rows_here = min(ROWS, P - tile * ROWS);
             for (int row = 0; row < rows_here; ++row) {
                 const float a = act2[tb + row * 256 + tid];
                 a0 += s_g3[row * 4] * a;
@@ -645,13 +669,15 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
             }
             if (tid < 3) {
                 float s = 0.f;
-                for (int row = 0; row < 64; ++row) s += s_g3[row * 4 + tid];
+                for (int row = 0; row < ROWS; ++row) s += s_g3[row * 4 + tid];
                 if (g_b4_fixed) fixed_add(g_b4_fixed, tid, s);
                 else atomicAdd(&g_b4[tid], s);
             }
         }
         {   // G2 = (g3 W3) * lrelu'(h2), formed in the transposed accumulator arrangement -> planes
-            const f32x4 g3[2] = {*reinterpret_cast<const f32x4*>(s_g3 + j * 4), *reinterpret_cast<const f32x4*>(s_g3 + (32 + j) * 4)};
+            f32x4 g3[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) g3[n] = *reinterpret_cast<const f32x4*>(s_g3 + (32 * n + j) * 4);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -661,7 +687,7 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
 #pragma unroll
                     for (int c = 0; c < 3; ++c) w3[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(pf + RO_W3 + c * 256 + f0);
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
+                    for (int n = 0; n < NT; ++n) {
                         f32x4 out;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -673,23 +699,22 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
                 }
         }
         lds_barrier();
-        store_tile_from_planes<32, RX_LDP>(X, G2 + tb, 256, tid);
-        f32x16 acc[2][2];
-        const uint32_t mw1[2] = {mk[(2 * wave) * 64 + lane], mk[(2 * wave + 1) * 64 + lane]};
-        zero_acc(acc);
-        WFrag3 nf = gemm_x3<RX_TH, false, RX_LDP>(X, w_bw2, lane, acc, fr2, w_bwa);
+        store_tile_from_planes<32, RX_LDP, ROWS>(X, G2 + tb, 256, tid);
+        f32x16 acc[2][NT];
+        uint32_t mw1[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) mw1[n] = mk[(NT * wave + n) * 64 + lane];
+        WFrag3 nf = gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_bw2, lane, acc, fr2, w_bwa);
         lds_barrier();
-        rx_bwd_epilogue(X, acc, wave, lane, mw1);
+        rx_bwd_epilogue<NT>(X, acc, wave, lane, mw1);
         lds_barrier();
-        store_tile_from_planes<32, RX_LDP>(X, G1 + tb, 256, tid);
-        zero_acc(acc);
-        nf = gemm_x3<RX_TH, false, RX_LDP>(X, w_bwa, lane, acc, nf, w_bw6);
+        store_tile_from_planes<32, RX_LDP, ROWS>(X, G1 + tb, 256, tid);
+        nf = gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_bwa, lane, acc, nf, w_bw6);
         lds_barrier();
-        rx_linear_epilogue(X, acc, nullptr, wave, lane);     // g_agg: operand of F_color.6's weight gradient and of the last product
+        rx_linear_epilogue<NT>(X, acc, nullptr, wave, lane);     // g_agg: operand of F_color.6's weight gradient and of the last product
         lds_barrier();
-        store_tile_from_planes<32, RX_LDP>(X, g_agg + tb, 256, tid);
-        zero_acc(acc);
-        gemm_x3<RX_TH, false, RX_LDP>(X, w_bw6, lane, acc, nf, nullptr);                     // g_agg3 = g_agg W6
+        store_tile_from_planes<32, RX_LDP, ROWS>(X, g_agg + tb, 256, tid);
+        gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_bw6, lane, acc, nf, nullptr);                 // g_agg3 = g_agg W6
         lds_barrier();
         {   // -> fp32 tile in the (now dead) plane memory -> coalesced rows in HBM
             float* XF = reinterpret_cast<float*>(X);
@@ -698,14 +723,33 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
+                    for (int n = 0; n < NT; ++n)
                         *reinterpret_cast<f32x4*>(XF + (32 * n + j) * LDA + 64 * wave + 32 * m + 8 * g + 4 * kg) =
                             f32x4{acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
             lds_barrier();
-            store_tile_256<LDA>(XF, g_agg3 + tb, tid);
+#pragma unroll 4
+            for (int u = 0; u < ROWS / 4; ++u) {           // ROWS rows of 256 floats, 16 bytes per thread
+                const int e4 = tid + 256 * u, row = e4 >> 6, c4 = e4 & 63;
+                *reinterpret_cast<f32x4*>(g_agg3 + tb + row * 256 + 4 * c4) = *reinterpret_cast<const f32x4*>(XF + row * LDA + 4 * c4);
+            }
         }
         lds_barrier();
     }
+}
+
+__global__ void __launch_bounds__(256, 1)
+rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __restrict__ colors, const int32_t* __restrict__ point_slot,
+                         const int32_t* __restrict__ n_points_dev, int max_points, const float* packed, const float* __restrict__ act2,
+                         const uint32_t* __restrict__ masks, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ g_agg,
+                         float* __restrict__ g_agg3, float* __restrict__ g_w4 /* [3,256] */, float* __restrict__ g_b4 /* [3] */,
+                         long long* __restrict__ g_w4_fixed, long long* __restrict__ g_b4_fixed) {
+    __shared__ __attribute__((aligned(16))) __bf16 X[3 * 64 * RX_LDP];
+    __shared__ __attribute__((aligned(16))) float s_g3[64 * 4];
+    const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
+    if (P <= 32 * (int)gridDim.x)        // the forward's rule (same P, same grid): the sign words were stored in the half-height layout
+        rhead_backward_x3_body<1>(X, s_g3, g_colors, colors, point_slot, P, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
+    else
+        rhead_backward_x3_body<2>(X, s_g3, g_colors, colors, point_slot, P, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
 }
 
 
@@ -745,7 +789,8 @@ int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* p
     const int tiles = spf::div_up(max_points, 64);
     const int blocks = tiles < 512 ? tiles : 512;
     if (arith == SPF_ARITH_SPLIT) {
-        const int b1 = tiles < 256 ? tiles : 256;       // one workgroup per CU
+        const int t32 = spf::div_up(max_points, 32);
+        const int b1 = t32 < 256 ? t32 : 256;           // one workgroup per CU; <= 32 points per workgroup: half-height tiles (chosen on the device)
         if (store)
             rhead_forward_x3_kernel<true><<<b1, 256, 0, (hipStream_t)stream>>>(agg3, ray_dirs, point_slot, n_points, max_points, SR, packed, colors, agg,
                                                                                direnc, act1, act2, masks);
@@ -779,7 +824,8 @@ int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t
     const int tiles = spf::div_up(max_points, 64);
     const int blocks = tiles < 512 ? tiles : 512;
     if (arith == SPF_ARITH_SPLIT) {    // g_b6 / g_b0 / g_b2 are not touched in this mode: spf_wgrad's dbias output provides them
-        const int b1 = tiles < 256 ? tiles : 256;
+        const int t32 = spf::div_up(max_points, 32);
+        const int b1 = t32 < 256 ? t32 : 256;           // the forward's grid: both kernels then choose the same tile height
         rhead_backward_x3_kernel<<<b1, 256, 0, (hipStream_t)stream>>>(g_colors, colors, point_slot, n_points, max_points, packed, act2, masks, G1, G2,
                                                                       g_agg, g_agg3, g_w4, g_b4, reinterpret_cast<long long*>(g_w4_fixed),
                                                                       reinterpret_cast<long long*>(g_b4_fixed));

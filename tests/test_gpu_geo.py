@@ -214,13 +214,15 @@ def test_color_path_forward_backward_match_oracle(color_mode, static):
         np.testing.assert_allclose(params[n].grad.cpu().numpy(), g.numpy(), rtol=2e-3, atol=2e-4 * float(g.abs().max()), err_msg=n)
 
 
-def test_rhead_forward_backward_match_torch(color_mode):
+@pytest.mark.parametrize("P_,R", [(1000, 40), (9001, 120)])
+def test_rhead_forward_backward_match_torch(color_mode, P_, R):
     """Head stage alone (F_color.6 per point + R, pointneus_disent.py:333-346) vs the oracle's torch ops: colours, d/d agg3,
-    weight and bias gradients; sparse slot rows and SR > 1."""
+    weight and bias gradients; sparse slot rows and SR > 1.  1000 points: at most 32 points per workgroup, so the bf16-piece kernels take
+    their half-height (32-point) tiles, the last one ragged; 9001 points: the 64-point tiles (round 5: both heights, chosen on the device)."""
     from spurfies_amd import ops
 
     g = torch.Generator().manual_seed(5)
-    P_, R, SR = 1000, 40, 80
+    SR = 80
     st = P.load_state(syn.make_mlp_weights(seed=3))
     names = ["F_color.6.weight", "F_color.6.bias"] + [f"R.{i}.{n}" for i in (0, 2, 4) for n in ("weight", "bias")]
     params = [st[n].detach().cuda().requires_grad_(True) for n in names]
@@ -242,10 +244,21 @@ def test_rhead_forward_backward_match_torch(color_mode):
     (col_o * coef).sum().backward()
     np.testing.assert_allclose(colors[slots.long().cuda()].detach().cpu().numpy(), col_o.detach().numpy(), rtol=2e-5, atol=2e-6)
     assert float(colors.detach().abs().sum()) == pytest.approx(float(colors[slots.long().cuda()].detach().abs().sum()))
-    np.testing.assert_allclose(agg_g.grad.cpu().numpy(), agg_o.grad.numpy(), rtol=5e-4, atol=1e-6)
+    ga, go = agg_g.grad.cpu().numpy(), agg_o.grad.numpy()
+    bad = np.abs(ga - go) > 5e-4 * np.abs(go) + 1e-6
+    # a hidden unit whose pre-activation is within rounding of zero takes the other LeakyReLU slope in one of the two evaluations: that point's
+    # whole gradient row moves by a few per cent of its scale (9001 points x 512 units: about one such point; none among 1000)
+    assert bad.mean() <= 5e-4 and float(np.abs(ga - go).max()) <= 2e-4, (int(bad.sum()), float(np.abs(ga - go).max()))
+    if P_ <= 1000:
+        np.testing.assert_allclose(ga, go, rtol=5e-4, atol=1e-6)
     for n, p_ in zip(names, params):
         gr = st[n].grad
-        np.testing.assert_allclose(p_.grad.cpu().numpy(), gr.numpy(), rtol=2e-3, atol=2e-4 * float(gr.abs().max()), err_msg=n)
+        if P_ <= 1000:
+            np.testing.assert_allclose(p_.grad.cpu().numpy(), gr.numpy(), rtol=2e-3, atol=2e-4 * float(gr.abs().max()), err_msg=n)
+        else:       # (the kink point above also moves the weight-gradient rows of its flipped unit: a handful of elements, by < 1e-3 of the largest)
+            d = np.abs(p_.grad.cpu().numpy() - gr.numpy())
+            scale = float(gr.abs().max())
+            assert (d > 2e-3 * np.abs(gr.numpy()) + 2e-4 * scale).mean() <= 1e-3 and float(d.max()) <= 2e-3 * scale, (n, float(d.max()), scale)
 
 
 def test_split_products_agree_with_fp32_mfma_kernel():
