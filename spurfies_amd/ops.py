@@ -746,6 +746,9 @@ class ColorAgg(_GradModeFunction):
                 # the three GEMMs side by side in one launch + one reduce (round 4; they were three + three) — and with them the head stage's
                 # three, deferred by RHead.backward (round 5)
                 pend = [p for ps, _ in _PENDING_WGRAD for p in ps]
+                if len(pend) + 3 > WGRAD_MAX_PROBLEMS:     # more than one head stage waiting (a model evaluated twice in one backward): own launch
+                    flush_pending_wgrad()
+                    pend = []
                 _PENDING_WGRAD.clear()
                 wgrad_batched([(G1, act0, sk[1], g_b0, 104, G64, 39, 103), (G2, act1, sk[3], g_b2, 256, G64 | AT, 0, 0),
                                (G3, act2, sk[5], g_b4, 256, G64 | AT, 0, 0)] + pend, pl.n_pairs)
@@ -1170,13 +1173,21 @@ def set_head_wgrad_merged(on=True):
     _MERGE_HEAD[0] = bool(on)
 
 
+WGRAD_MAX_PROBLEMS = 7       # spf_wgrad_batched (include/spurfies_hip.h)
+
+
 def flush_pending_wgrad():
     """Launch weight-gradient problems that were deferred to a later batched launch which never came (a backward without the colour trunk)."""
-    if _PENDING_WGRAD:
-        probs = [p for ps, _ in _PENDING_WGRAD for p in ps]
-        _PENDING_WGRAD.clear()
+    while _PENDING_WGRAD:
+        probs, _ = _PENDING_WGRAD.pop(0)
         wgrad_batched(probs, None)
         _bucket("head")
+
+
+def drop_pending_wgrad():
+    """Forget deferred weight-gradient problems WITHOUT launching them: called where a new forward starts — anything still waiting belongs to a
+    backward that was abandoned half way (an exception between the head's and the trunk's backward) and must not ride in the next step's launch."""
+    _PENDING_WGRAD.clear()
 
 
 def wgrad_batched(problems, n_rows):

@@ -140,6 +140,7 @@ class TrainStep:
     def _forward_backward_body(self, model_input, ground_truth, reduce_buckets, collectives):
         model_input = dict(model_input)
         model_input["iter_step"] = self.iter_step
+        ops.drop_pending_wgrad()                 # (left behind only by a backward that was abandoned half way)
         if self.sync_free:
             self._refresh_draws(model_input["uv"].shape[1], model_input["uv"].device)
         out = self.model(model_input, fast=1)
@@ -226,6 +227,7 @@ class TrainStep:
             self._graph = torch.cuda.CUDAGraph()
             self._graph_tail, self._counts = None, None
             if self.world == 1:
+                ops.drop_pending_wgrad()
                 with ops.capture_guard(), torch.cuda.graph(self._graph):
                     out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
                     losses = self.loss(out, self._static_gt)

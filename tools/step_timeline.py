@@ -21,6 +21,13 @@ def short(name):
 
 # a step starts at the ray set-up launch (camera_rays_kernel, or camera_uniform_kernel since round 5)
 starts = [i for i, r in enumerate(rows) if "camera_rays_kernel" in r["Kernel_Name"] or "camera_uniform_kernel" in r["Kernel_Name"]]
+# the step shown is the one with the MEDIAN period among the (up to) nine steps around index `back` from the end: a single step can be hit by an
+# outlier (one colour backward launch read 1.79 ms instead of 0.71 in a round-5 collection) and would misrepresent the sequence
+cand = [k for k in range(back - 4, back + 5) if k >= 2 and k + 1 <= len(starts) - 1]
+periods = sorted((int(rows[starts[-k]]["Start_Timestamp"]) - int(rows[starts[-k - 1]]["Start_Timestamp"]), k) for k in cand)
+if periods:
+    back = periods[len(periods) // 2][1]
+    print(f"# step {back} from the end of the trace: median period of {len(periods)} neighbouring steps ({periods[0][0] / 1e3:.1f} .. {periods[-1][0] / 1e3:.1f} us)")
 a, b = starts[-back - 1], starts[-back]
 seq = rows[a:b]
 t0 = int(seq[0]["Start_Timestamp"])
