@@ -293,7 +293,10 @@ int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const floa
 /* colors[row,3] = sigmoid(R([direnc3(ray_dirs[row / SR]) | W6 agg3[p] + b6])) for the p-th valid point, row = point_slot[p]
  * (rows of invalid points untouched: pre-fill with 0).  Training mode (direnc != NULL) stores, per point
  * (T = 64*ceil(P/64) rows): agg [T,256] (= F_color.6's output, R.0's input), direnc [T,24] (21 + 3 zeros),
- * act1, act2 [T,256], masks [T/64,2,512]. */
+ * act1, act2 [T,256], masks [T/64,2,512] (LeakyReLU sign words, 16 words per point; opaque: written and read back by this pair of entry
+ * points only).  SPF_ARITH_SPLIT, round 5: the point list is worked off in whole rounds of 64-point tiles (one tile per workgroup and round) and
+ * the remainder — less than one round — in 32-point tiles when that is at most one per workgroup; spf_rhead_backward splits the list at the
+ * same place (same count, same max_points => same grid), which is what lets it read the sign words the forward stored. */
 int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* point_slot, const int32_t* n_points,
                       int32_t max_points, int32_t SR, const float* packed, float* colors, float* agg, float* direnc,
                       float* act1, float* act2, uint32_t* masks, int32_t arith, void* stream);

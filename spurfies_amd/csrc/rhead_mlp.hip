@@ -413,18 +413,23 @@ __device__ __forceinline__ void rx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2
         }
 }
 
+// Points covered by whole rounds of 64-point tiles on a grid of G workgroups (forward and backward split the list at the same place: the
+// LeakyReLU sign words are stored per tile in the layout of the tile height that wrote them).
+__device__ __forceinline__ int rx_full_rounds_points(int P, int G) { return (P / 64 / G) * G * 64; }
+
 // One workgroup's tiles.  NT = 2: tiles of 64 points (rounds 1 - 4); NT = 1 (round 5): HALF-HEIGHT tiles of 32 points — twice the tiles at ~55 % of a
 // tile's time each, taken when the launch has at most 32 points per workgroup (the 128-rays-per-GPU step: 6.5 k points were 102 tiles on 102 of 256
 // CUs, one ~45 us tile pass each).  Forward and backward make the same choice (same point count, same grid): the sign words' layout depends on it.
 template <bool STORE, int NT>
 __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int* s_row, const float* __restrict__ agg3, const float* __restrict__ ray_dirs,
-                                                      const int32_t* __restrict__ point_slot, const int P, int SR, const float* packed,
+                                                      const int32_t* __restrict__ point_slot, const int p0, const int P, int SR, const float* packed,
                                                       float* __restrict__ colors, float* __restrict__ agg, float* __restrict__ direnc,
                                                       float* __restrict__ act1, float* __restrict__ act2, uint32_t* __restrict__ masks) {
+    // points [p0, P) of the list, p0 a multiple of 64: tile t covers points p0 + t ROWS ..
     constexpr int ROWS = 32 * NT, PARTS = 256 / ROWS, PW = 256 / PARTS, NV = PW / 4;      // gather: thread = (row, part): PW agg3 floats each
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntiles = (P + ROWS - 1) / ROWS;
+    const int ntiles = (P - p0 + ROWS - 1) / ROWS;
     const float* packed0 = packed;
     T_DECL
     // this thread's gather operands (row = tid / PARTS, part = tid % PARTS; part 0 also the ray direction) are requested one
@@ -435,12 +440,12 @@ __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int
     float dnext[3] = {0.f, 0.f, 0.f};
     int srow_next = -1, slot_pf = -1;
     auto fetch_slot = [&](int t) {
-        const int p = t * ROWS + tid / PARTS;
+        const int p = p0 + t * ROWS + tid / PARTS;
         slot_pf = ((tid % PARTS) == 0 && t < ntiles && p < P) ? (point_slot ? point_slot[p] : p) : -1;
     };
     auto fetch_rows = [&](int t) {
         const int row = tid / PARTS, q = tid % PARTS;
-        const int p = t * ROWS + row;
+        const int p = p0 + t * ROWS + row;
         const bool ok = t < ntiles && p < P;
         srow_next = slot_pf;
         if (srow_next >= 0) {
@@ -491,7 +496,7 @@ __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int
                 if (STORE) {
 #pragma unroll
                     for (int c4 = 0; c4 < 6; ++c4)
-                        *reinterpret_cast<f32x4*>(direnc + (size_t)(tile * ROWS + row) * 24 + 4 * c4) = f32x4{e[4 * c4], e[4 * c4 + 1], e[4 * c4 + 2], e[4 * c4 + 3]};
+                        *reinterpret_cast<f32x4*>(direnc + (size_t)(p0 + tile * ROWS + row) * 24 + 4 * c4) = f32x4{e[4 * c4], e[4 * c4 + 1], e[4 * c4 + 2], e[4 * c4 + 3]};
                 }
                 s_row[row] = srow;
             }
@@ -499,8 +504,8 @@ __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int
         T_MARK(1)
         lds_barrier();
         T_MARK(2)
-        const size_t tb = (size_t)tile * ROWS * 256;
-        uint32_t* mk = STORE ? masks + (size_t)tile * 2 * (256 * NT) : nullptr;       // [layer 2][wave 4][row half NT][lane 64]
+        const size_t tb = (size_t)(p0 + tile * ROWS) * 256;
+        uint32_t* mk = STORE ? masks + (size_t)(p0 + tile * ROWS) * 16 : nullptr;         // 16 words per point: [layer 2][wave 4][row half NT][lane 64] per tile
         f32x16 acc[2][NT];
         RxBias bias = rx_load_bias(pf + RO_B6, wave, lane);
         WFrag3 nf = gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_fw6, lane, acc, fr6, w_fw1);          // F_color.6 on the weighted mean
@@ -604,15 +609,20 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
     __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
     __shared__ int s_row[64];
     const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
-    if (P <= 32 * (int)gridDim.x)
-        rhead_forward_x3_body<STORE, 1>(X, red, s_row, agg3, ray_dirs, point_slot, P, SR, packed, colors, agg, direnc, act1, act2, masks);
-    else
-        rhead_forward_x3_body<STORE, 2>(X, red, s_row, agg3, ray_dirs, point_slot, P, SR, packed, colors, agg, direnc, act1, act2, masks);
+    // whole rounds of 64-point tiles first (every workgroup one tile per round); what is left — less than one round — as half-height tiles when
+    // that puts it on twice the workgroups (55 k points on 256 workgroups: 3 rounds + 186 half tiles instead of a fourth round at 36 % occupancy)
+    const int p_full = rx_full_rounds_points(P, (int)gridDim.x);
+    if (p_full > 0)
+        rhead_forward_x3_body<STORE, 2>(X, red, s_row, agg3, ray_dirs, point_slot, 0, p_full, SR, packed, colors, agg, direnc, act1, act2, masks);
+    if (P - p_full > 32 * (int)gridDim.x)
+        rhead_forward_x3_body<STORE, 2>(X, red, s_row, agg3, ray_dirs, point_slot, p_full, P, SR, packed, colors, agg, direnc, act1, act2, masks);
+    else if (P > p_full)
+        rhead_forward_x3_body<STORE, 1>(X, red, s_row, agg3, ray_dirs, point_slot, p_full, P, SR, packed, colors, agg, direnc, act1, act2, masks);
 }
 
 template <int NT>
 __device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, const float* __restrict__ g_colors, const float* __restrict__ colors,
-                                                       const int32_t* __restrict__ point_slot, const int P, const float* packed,
+                                                       const int32_t* __restrict__ point_slot, const int p0, const int P, const float* packed,
                                                        const float* __restrict__ act2, const uint32_t* __restrict__ masks, float* __restrict__ G1,
                                                        float* __restrict__ G2, float* __restrict__ g_agg, float* __restrict__ g_agg3,
                                                        float* __restrict__ g_w4 /* [3,256] */, float* __restrict__ g_b4 /* [3] */,
@@ -620,7 +630,7 @@ __device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, c
     constexpr int ROWS = 32 * NT;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntiles = (P + ROWS - 1) / ROWS;
+    const int ntiles = (P - p0 + ROWS - 1) / ROWS;             // points [p0, P), p0 a multiple of 64
     const float* packed0 = packed;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -629,10 +639,10 @@ __device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, c
         gx3 w_bw2 = frag + RX_BW2 + wave * (RX_TH * 2 * 3 * 64) + lane;
         gx3 w_bwa = frag + RX_BWA + wave * (RX_TH * 2 * 3 * 64) + lane;
         gx3 w_bw6 = frag + RX_BW6 + wave * (RX_TH * 2 * 3 * 64) + lane;
-        const size_t tb = (size_t)tile * ROWS * 256;
+        const size_t tb = (size_t)(p0 + tile * ROWS) * 256;
         const WFrag3 fr2 = load_wfrag3(w_bw2);               // in flight during the small last-layer stage
         if (tid < ROWS) {   // dL/d(pre-sigmoid) = g_c * c (1 - c)
-            const int p = tile * ROWS + tid;
+            const int p = p0 + tile * ROWS + tid;
             float g[3] = {0.f, 0.f, 0.f};
             if (p < P) {
                 const int srow = point_slot ? point_slot[p] : p;
@@ -645,13 +655,13 @@ __device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, c
             *reinterpret_cast<f32x4*>(s_g3 + tid * 4) = f32x4{g[0], g[1], g[2], 0.f};
         }
         lds_barrier();
-        const uint32_t* mk = masks + (size_t)tile * 2 * (256 * NT);       // the forward's layout: [layer 2][wave 4][row half NT][lane 64]
+        const uint32_t* mk = masks + (size_t)(p0 + tile * ROWS) * 16;       // the forward's layout: 16 words per point, [layer 2][wave 4][row half NT][lane 64] per tile
         uint32_t bits[NT];                                                 // G2 stage's sign words, ahead of the dW3 stage
 #pragma unroll
         for (int n = 0; n < NT; ++n) bits[n] = mk[256 * NT + (NT * wave + n) * 64 + lane];
         {   // dW3[c][col] += sum_rows g3[row][c] a2[row][col]; db3[c] += sum_rows g3[row][c]   (thread = column)
             float a0 = 0.f, a1 = 0.f, a2v = 0.f;
-            const int rows_here = min(ROWS, P - tile * ROWS);
+            const int rows_here = min(ROWS, P - p0 - tile * ROWS);
             for (int row = 0; row < rows_here; ++row) {
                 const float a = act2[tb + row * 256 + tid];
                 a0 += s_g3[row * 4] * a;
@@ -746,10 +756,14 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
     __shared__ __attribute__((aligned(16))) __bf16 X[3 * 64 * RX_LDP];
     __shared__ __attribute__((aligned(16))) float s_g3[64 * 4];
     const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
-    if (P <= 32 * (int)gridDim.x)        // the forward's rule (same P, same grid): the sign words were stored in the half-height layout
-        rhead_backward_x3_body<1>(X, s_g3, g_colors, colors, point_slot, P, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
-    else
-        rhead_backward_x3_body<2>(X, s_g3, g_colors, colors, point_slot, P, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
+    // the forward's split (same P, same grid): whole rounds of 64-point tiles, the rest as half-height tiles if that is at most one per workgroup
+    const int p_full = rx_full_rounds_points(P, (int)gridDim.x);
+    if (p_full > 0)
+        rhead_backward_x3_body<2>(X, s_g3, g_colors, colors, point_slot, 0, p_full, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
+    if (P - p_full > 32 * (int)gridDim.x)
+        rhead_backward_x3_body<2>(X, s_g3, g_colors, colors, point_slot, p_full, P, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
+    else if (P > p_full)
+        rhead_backward_x3_body<1>(X, s_g3, g_colors, colors, point_slot, p_full, P, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
 }
 
 
