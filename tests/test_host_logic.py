@@ -148,3 +148,68 @@ def test_mesh_route_back_half_on_an_analytic_sphere():
     assert same["accuracy"] == 0.0 and same["completeness"] == 0.0
     far = surface.chamfer_dtu(np.concatenate([gt, [[5.0, 5.0, 5.0]]]), gt, max_dist=0.2)         # outliers beyond max_dist are not averaged in
     assert far["accuracy"] == 0.0
+
+
+def test_workspace_owner_tokens_are_never_reused_and_die_with_their_owner():
+    """Scratch buffers are keyed by a per-owner token (ops.scratch_owner), not by id(owner): Python hands a dead object's id to the next
+    allocation, and a new optimisation step must not inherit (or keep alive) a dead one's workspaces; the caches are dropped with the owner."""
+    import gc
+
+    from spurfies_amd import ops
+
+    class Owner:
+        pass
+
+    a = Owner()
+    with ops.scratch_owner(a):
+        ta = ops._SCRATCH_OWNER[0]
+        with ops.scratch_owner(Owner()):                       # nested owners restore the outer one
+            assert ops._SCRATCH_OWNER[0] != ta
+        assert ops._SCRATCH_OWNER[0] == ta
+    assert ops._SCRATCH_OWNER[0] is None
+    ops._wgrad_ws[(0, ("owner", ta, None), 123)] = "workspace of a"
+    ops._fixed_bufs[(0, ("owner", ta, "geo_scatter"), "geo_latents")] = "accumulators of a"
+    with ops.scratch_owner(a):
+        assert ops._SCRATCH_OWNER[0] == ta                     # the same owner keeps its token
+    del a
+    gc.collect()
+    assert not any(k[1][:2] == ("owner", ta) for k in list(ops._wgrad_ws) + list(ops._fixed_bufs) if isinstance(k[1], tuple))
+    b = Owner()
+    with ops.scratch_owner(b):
+        assert ops._SCRATCH_OWNER[0] > ta                      # never handed out again
+
+
+def test_capture_guard_keeps_the_collector_out_and_restores_it():
+    """ops.capture_guard: collect before a hipGraph capture, cyclic collector off during it (a dead model's VoxelGrid.__del__ -> hipFree inside a
+    capture invalidates it), previous state restored afterwards — also when the body raises."""
+    import gc
+
+    from spurfies_amd import ops
+
+    assert gc.isenabled()
+    with ops.capture_guard():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    try:
+        with ops.capture_guard():
+            raise RuntimeError("capture failed")
+    except RuntimeError:
+        pass
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with ops.capture_guard():
+            assert not gc.isenabled()
+        assert not gc.isenabled()                              # it was off before: stays off
+    finally:
+        gc.enable()
+
+
+def test_deferred_weight_gradient_problems_do_not_outlive_an_abandoned_backward():
+    """The head stage's weight-gradient problems wait in ops._PENDING_WGRAD for the colour trunk's launch; if a backward is abandoned between the
+    two (an exception), the next forward drops them instead of launching stale pointers with the next step."""
+    from spurfies_amd import ops
+
+    ops._PENDING_WGRAD.append((["stale problem"], ("tensors",)))
+    ops.drop_pending_wgrad()
+    assert ops._PENDING_WGRAD == []
