@@ -543,7 +543,6 @@ def measure_train(args, ctx, w):
     # region right behind a short warm-up read 6.7 % faster than the 200-step region behind it (BENCH_r04).  So the same step runs UNTIMED
     # for >= args.settle seconds more (extra warm-up, whatever --warmup says) before the contract region; both figures stay in the line.
     sync()
-    per = max((time.perf_counter() - t_w) / max(warmup, 1), 1e-4)
     # Python's cyclic collector is kept out of the timed regions (a generation-2 pass over this process's ~10^6 objects takes ~0.1 s: one of
     # them inside a 40-step region doubled its reading); collected once HERE — in front of the settle phase, not between it and the timed region:
     # 0.1 - 0.3 s of idle GPU there let the chip drop its clock state, and the first steps of a 20-step region paid for the ramp (+2 - 3 %)
@@ -555,12 +554,23 @@ def measure_train(args, ctx, w):
         gc.disable()
     settle = 0
     if args.settle > 0:
+        # The NUMBER of settle steps must be the same on every rank (each step holds collectives at world > 1: a rank that ran one step more than
+        # its peers would wait for them forever — an earlier time-bounded loop did exactly that on two ranks): ten probe steps are timed, every rank
+        # derives a count from its own clock and the ranks agree on the largest.
+        probe = 10
         t_s = time.perf_counter()
-        while time.perf_counter() - t_s < args.settle:
-            for _ in range(max(1, int(0.05 / per))):
-                run_step(warmup + settle)
-                settle += 1
-            sync()
+        for _ in range(probe):
+            run_step(warmup + settle)
+            settle += 1
+        sync()
+        per = max((time.perf_counter() - t_s) / probe, 1e-5)
+        more = torch.tensor([max(0, int((args.settle - per * probe) / per) + 1)], device=device, dtype=torch.int64)
+        if world > 1:
+            torch.distributed.all_reduce(more, op=torch.distributed.ReduceOp.MAX)
+        for _ in range(min(int(more.item()), 100000)):
+            run_step(warmup + settle)
+            settle += 1
+        sync()
     first = warmup + settle
     ops.geo_clock(reset=True)                     # in-kernel clock counters of the dominant kernel: zeroed before the timed region
     if not use_graph:
@@ -778,6 +788,9 @@ def main():
         try:
             r, _ = measure_train(args, ctx, w)
         except Exception as e:  # noqa: BLE001 — recorded in the line; at world > 1 the peers' timer ends the run if they wait for this rank
+            import traceback
+
+            print(f"[bench] rank {rank}: extra record {w['record']!r} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
             res["extra"].append({"record": w["record"], "error": repr(e)[:400]})
             if world > 1:
                 abandon()              # the peers are inside collectives this rank will not join: leave now, their timers end them

@@ -250,7 +250,8 @@ def _bench_self_launched(extra, nproc=2, env_extra=None, timeout=600):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--points", "3000",
-           "--no-cpu-baseline", "--sustained", "0", "--settle", "0", "--ab-reps", "0", "--geo-engine", "split_w"] + extra
+           "--no-cpu-baseline", "--sustained", "0", "--settle", "0.3", "--ab-reps", "0", "--geo-engine", "split_w"] + extra
+    # (--settle > 0 on purpose: the settle phase's step count must be agreed between the ranks — a time-bounded loop per rank deadlocked two ranks)
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 
