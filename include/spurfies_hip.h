@@ -32,7 +32,7 @@ extern "C" {
 #define SPF_ENOMEM (-12)
 #define SPF_EHIP (-5)
 
-#define SPF_ABI_VERSION 5
+#define SPF_ABI_VERSION 6
 #define SPF_KMAX 8          /* neighbours per point (config/vol/dtu_pn.yaml:27, k: 8) */
 #define SPF_GEO_DIM 32      /* geometry latent width = feature_vector_size/2 (pointneus_disent.py:172) */
 #define SPF_COL_DIM 64      /* colour latent width  = feature_vector_size   (pointneus_disent.py:161) */
@@ -401,12 +401,16 @@ int spf_render_rgb_backward(const float* weights, const float* colors, const flo
  * g_acc [R] (may be NULL): gradient of acc = sum_j w_j, added to every slot's g_weights; g_pts_rendered [R,3] (may be NULL; needs
  * ray_dirs): gradient of spf_render_forward's pts_rendered, entering through dist (g_dist[r] += g_pts_rendered[r] . ray_dirs[r]).
  * g_beta_fixed (may be NULL): a one-entry fixed-point accumulator (see "Reproducible gradients" below) that receives the rays' terms
- * instead of g_beta's float atomics. */
+ * instead of g_beta's float atomics.
+ * ABI 6 — lfirst [R], lcoef [R,2] (spf_local_forward) and lscale[0] (spf_loss_backward*), all three or none: the feature-consistency
+ * term's gradient joins here, g_sdf[r, lfirst[r] + i] += lscale[0] * lcoef[r, i] for i in {0, 1} where lfirst[r] >= 0 (its backward has
+ * no launch of its own in the optimisation step). */
 int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas,
                         const float* colors, const float* beta, const float* weights, const float* g_weights,
                         const float* g_rgb, const float* g_depth, const float* g_dist, int32_t R, int32_t SR,
                         float* g_sdf, float* g_colors, float* g_beta, const float* beta_param, const float* g_acc,
-                        const float* g_pts_rendered, const float* ray_dirs, int64_t* g_beta_fixed, void* stream);
+                        const float* g_pts_rendered, const float* ray_dirs, int64_t* g_beta_fixed, const int32_t* lfirst,
+                        const float* lcoef, const float* lscale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight-gradient GEMM with a device-side row count — replaces autograd's AddmmBackward GEMMs for the
@@ -547,6 +551,39 @@ int spf_camera_uniform(const float* uv, const float* pose, const float* intrinsi
                        int32_t tv_n, int32_t tv_k, float* tv_out, const spf_prologue_packs* packs, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ABI 6 — multi-view feature-consistency ("local") term of the DTU recipe (config/ours.yaml:16, local_weight 0.5) — replaces
+ *   find_surface_points   spurfies/model/pointneus_disent.py:586-612
+ *   the surface points    spurfies/model/pointneus_disent.py:727-749
+ *   get_local_loss        spurfies/feat_utils.py:377-451 (idx_world2cam / idx_cam2img :43-55, normalize_for_grid_sample / get_in_range
+ *                         :58-77, F.grid_sample(bilinear, zeros, align_corners=False), cosine term and masks :425-437)
+ * and autograd's backward through them.  The per-view data arrives as a DESCRIPTOR IN DEVICE MEMORY, so that a captured hipGraph of the
+ * optimisation step serves every training view: the caller overwrites the descriptor's bytes between replays (one small copy).
+ * ---------------------------------------------------------------------------------------- */
+#define SPF_LOCAL_MAX_VIEWS 8   /* reference view + up to 7 source views (datasets/dtu.py:268-291 passes 2) */
+typedef struct spf_local_desc {
+    uint64_t feat[SPF_LOCAL_MAX_VIEWS];    /* device addresses of float32 [C,H,W] feature maps: [0] = local_data["feat"], [1 + s] = feat_src[s] */
+    float cam[SPF_LOCAL_MAX_VIEWS][2][16]; /* row-major 4x4 pairs {world -> camera, K in [:3,:3]}: [0] = local_data["cam"], [1 + s] = src_cams[s] */
+    float center[3];                       /* local_data["center"] */
+    float size;                            /* local_data["size"]:  p_world = p / 2 * size + center (feat_utils.py:405-408) */
+    int32_t n_src, C, H, W;                /* source views m (1 .. SPF_LOCAL_MAX_VIEWS - 1); channels; map height / width (half the image's) */
+} spf_local_desc;
+
+/* sdf, z [R,SR]: the SDF (1000 at slots without a point) and depth of every shading slot; cam_loc, ray_dirs [R,3]; desc: DEVICE pointer.
+ * Per ray: the first slot pair whose SDF goes from + to - (no crossing: lfirst = -1 and zeros), t = linearly interpolated depth of the
+ * zero, surface point cam_loc + ray_dirs t, projected into the reference and the m source views, features sampled bilinearly,
+ *   d_surface [R]  t (0 without a crossing)                         == find_surface_points' d_surface
+ *   lfirst [R]     first slot of the crossing or -1                 (>= 0 == find_surface_points' network_mask)
+ *   lsum [R]       sum over the source views of |1 - cos| where both projections are in range and |1 - cos| < 0.5
+ *   lcoef [R,2]    d lsum / d sdf[r, lfirst + {0, 1}]               (the only differentiable inputs)
+ * The reference's loss is sum_r lsum[r] / (m * #{lfirst >= 0}) (0 when no ray has a crossing); spf_loss_forward forms it. */
+int spf_local_forward(const spf_local_desc* desc, const float* sdf, const float* z, const float* cam_loc, const float* ray_dirs, int32_t R,
+                      int32_t SR, float* d_surface, int32_t* lfirst, float* lsum, float* lcoef, void* stream);
+
+/* The backward as a dense array, for callers outside the fused optimisation step: g_sdf [R,SR] = g_sum[0] * d (sum_r lsum[r]) / d sdf
+ * (zero except at the crossings; every entry is written). */
+int spf_local_backward(const int32_t* lfirst, const float* lcoef, const float* g_sum, int32_t R, int32_t SR, float* g_sdf, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Loss terms of one optimisation step — replaces VolSDFLoss.forward (spurfies/model/loss.py:42-49,
  * 51-101) and the pseudo-point term of spurfies/model/pointneus_disent.py:765-780.
  * ---------------------------------------------------------------------------------------- */
@@ -555,30 +592,40 @@ typedef struct spf_loss_weights {
     int32_t world;                         /* ranks sharing the batch (tv / constant terms are split over them) */
 } spf_loss_weights;
 
+/* ABI 6: the feature-consistency term inside the loss kernels (NULL: the term is 0).  Device pointers in a host struct, read at call time. */
+typedef struct spf_local_terms {
+    const float* lsum;           /* [R]  spf_local_forward */
+    const int32_t* lfirst;       /* [R]  spf_local_forward */
+    const spf_local_desc* desc;  /* device: n_src is read from it (count = n_src * #{lfirst >= 0}) */
+    float* lscale;               /* [1] OUT of the backward entry points: g_total * weights.local / count, for spf_render_backward */
+} spf_local_terms;
+
 int64_t spf_loss_workspace_floats(void);
 
 /* rgb, rgb_gt [R,3]; acc [R] = sum_j w_j; mask_gt[r * mask_stride], r < R; grad [rows,3] + slot_valid [rows] (d sdf/dx of the shading slots;
  * NULL skips the eikonal term) with n_points[0] = number of valid slots (device); psdf [R] SDF at the rendered points with
  * pvalid / ray_valid [R] (NULL skips the pseudo term); tv (NULL: 0) = the TV term: with n_tv = 0 a device scalar (the mean itself), with
  * n_tv > 0 spf_tv_forward's per-point array tv[n_tv], whose mean (utils.py:282) is formed here; denom = NULL or device
- * {R_total, P_total, pseudo_count_total} (global counts of a ray-sharded batch).
+ * {R_total, P_total, pseudo_count_total, local_count_total} (global counts of a ray-sharded batch); local = NULL or the
+ * feature-consistency term's per-ray values (ABI 6).
  *   total[0]  the weighted loss;   terms[8] = {loss, rgb, eikonal, tv, mask, local, pseudo, local pseudo count}
- *   den[4]    normalisers for spf_loss_backward.   workspace: spf_loss_workspace_floats() floats.
+ *   den[8]    normalisers for spf_loss_backward (five used).   workspace: spf_loss_workspace_floats() floats.
  * ABI 5: total == terms == den == NULL runs the partial-sum launch only; spf_loss_backward_finalize then forms the terms on its way (the
  * workspace must stay untouched in between). */
 int spf_loss_forward(const float* rgb, const float* rgb_gt, const float* acc, const float* mask_gt, int32_t mask_stride,
                      const float* grad, const uint8_t* slot_valid, int64_t rows, const int32_t* n_points, const float* psdf,
                      const uint8_t* pvalid, const uint8_t* ray_valid, const float* tv, int32_t n_tv, const float* denom, int32_t R,
                      const spf_loss_weights* weights, float* workspace, float* total, float* terms, float* den,
-                     void* stream);
+                     const spf_local_terms* local, void* stream);
 
 /* g_total = dL/d total (device scalar) -> g_rgb [R,3], g_acc [R], g_psdf [R] (may be NULL), g_tv[0] (may be NULL): the gradient w.r.t. the
  * TV mean (n_tv = 0) or w.r.t. every tv[i] of the per-point array (n_tv > 0: the mean's gradient / n_tv, one scalar for all points).
- * The eikonal term has no gradient w.r.t. any trainable tensor. */
+ * The eikonal term has no gradient w.r.t. any trainable tensor.  local != NULL: local->lscale[0] = g_total * weights.local /
+ * count — the feature-consistency term's gradient is applied by spf_render_backward (lfirst, lcoef, lscale). */
 int spf_loss_backward(const float* g_total, const float* den, const spf_loss_weights* weights, const float* rgb,
                       const float* rgb_gt, const float* acc, const float* mask_gt, int32_t mask_stride, const float* psdf,
                       const uint8_t* pvalid, const uint8_t* ray_valid, int32_t R, float* g_rgb, float* g_acc,
-                      float* g_psdf, float* g_tv, int32_t n_tv, void* stream);
+                      float* g_psdf, float* g_tv, int32_t n_tv, const spf_local_terms* local, void* stream);
 
 /* ABI 5: spf_loss_backward behind a partial-sums-only spf_loss_forward — every workgroup derives the normalisers from the workspace's partial
  * sums itself and the first one also writes total / terms / den (the forward's outputs), so the step has no single-block finalize launch
@@ -590,7 +637,7 @@ int spf_loss_backward_finalize(const float* g_total, const spf_loss_weights* wei
                                const uint8_t* ray_valid, int32_t R, float* g_rgb, float* g_acc, float* g_psdf, float* g_tv, int32_t n_tv,
                                const float* workspace, int64_t rows, const int32_t* n_points, const float* tv, const float* denom,
                                float* total, float* terms, float* den, const float* tv_feat, const int32_t* tv_nbr, const float* tv_w,
-                               const float* tv_norm, int32_t tv_k, float* tv_g_feat, void* stream);
+                               const float* tv_norm, int32_t tv_k, float* tv_g_feat, const spf_local_terms* local, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Parameter update — replaces the tail of the reference's train step (spurfies/train.py:359-363, 548-564):

@@ -45,6 +45,20 @@ class ProloguePacks(C.Structure):
                 [(n, C.c_void_p) for n in ("rw6", "rb6", "rw0", "rb0", "rw2", "rb2", "rw4", "rb4", "r_packed", "r_zero")] + [("r_zero_floats", C.c_int64)])
 
 
+class LocalTermsArgs(C.Structure):
+    """spf_local_terms"""
+    _fields_ = [("lsum", C.c_void_p), ("lfirst", C.c_void_p), ("desc", C.c_void_p), ("lscale", C.c_void_p)]
+
+
+LOCAL_MAX_VIEWS = 8
+
+
+class LocalDesc(C.Structure):
+    """spf_local_desc (built on the host, uploaded as bytes)"""
+    _fields_ = [("feat", C.c_uint64 * LOCAL_MAX_VIEWS), ("cam", C.c_float * (LOCAL_MAX_VIEWS * 32)), ("center", C.c_float * 3), ("size", C.c_float),
+                ("n_src", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
+
+
 SIGNATURES = {
     "spf_abi_version": (C.c_int, []),
     "spf_last_error": (C.c_char_p, []),
@@ -81,7 +95,9 @@ SIGNATURES = {
     "spf_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spf_render_rgb": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "spf_render_rgb_backward": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P]),
-    "spf_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_local_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "spf_local_backward": (C.c_int, [_P, _P, _P, _I, _I, _P, _P]),
     "spf_wgrad_workspace_floats": (C.c_int64, [_I]),
     "spf_wgrad": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "spf_wgrad_batched": (C.c_int, [C.POINTER(WgradProblem), _I, _P, _I, _P, _I, _I, _P]),
@@ -94,10 +110,11 @@ SIGNATURES = {
     "spf_adam_workspace_floats": (C.c_int64, []),
     "spf_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P, _P, _P]),
     "spf_loss_workspace_floats": (C.c_int64, []),
-    "spf_loss_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _I, _P, _I, C.POINTER(LossWeights), _P, _P, _P, _P, _P]),
+    "spf_loss_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _I, _P, _I, C.POINTER(LossWeights), _P, _P, _P, _P,
+                                   C.POINTER(LocalTermsArgs), _P]),
     "spf_loss_backward_finalize": (C.c_int, [_P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, C.c_int64, _P, _P, _P, _P, _P, _P,
-                                             _P, _P, _P, _P, _I, _P, _P]),
-    "spf_loss_backward": (C.c_int, [_P, _P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
+                                             _P, _P, _P, _P, _I, _P, C.POINTER(LocalTermsArgs), _P]),
+    "spf_loss_backward": (C.c_int, [_P, _P, C.POINTER(LossWeights), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, C.POINTER(LocalTermsArgs), _P]),
 }
 
 _lib = None

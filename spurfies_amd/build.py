@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspurfies_hip.so")
-SOURCES = ["grid.hip", "geo_mlp.hip", "color_mlp.hip", "rhead_mlp.hip", "wgrad.hip", "render.hip", "sampler.hip", "latents.hip", "camera.hip", "loss.hip", "optim.hip"]
+SOURCES = ["grid.hip", "geo_mlp.hip", "color_mlp.hip", "rhead_mlp.hip", "wgrad.hip", "render.hip", "sampler.hip", "latents.hip", "camera.hip", "loss.hip", "local.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 

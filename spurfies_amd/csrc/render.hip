@@ -162,7 +162,9 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
                                                               float* __restrict__ g_sdf, float* __restrict__ g_colors,
                                                               float* __restrict__ g_beta, const float* __restrict__ beta_param,
                                                               const float* __restrict__ g_acc, const float* __restrict__ g_pts,
-                                                              const float* __restrict__ ray_dirs, long long* __restrict__ g_beta_fixed) {
+                                                              const float* __restrict__ ray_dirs, long long* __restrict__ g_beta_fixed,
+                                                              const int32_t* __restrict__ lfirst, const float* __restrict__ lcoef,
+                                                              const float* __restrict__ lscale) {
     const int lane = threadIdx.x & 63;
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= R) return;
@@ -211,6 +213,9 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
         }
     }
     P_ = wave_sum(P_);
+    // the feature-consistency term's gradient (spf_local_forward): two entries of this ray's row
+    const int lf = lfirst ? lfirst[r] : -1;
+    const float lg0 = lf >= 0 ? *lscale * lcoef[2 * r] : 0.f, lg1 = lf >= 0 ? *lscale * lcoef[2 * r + 1] : 0.f;
     float carryE = 0.f, carryP = 0.f, gb = 0.f;
 #pragma unroll
     for (int ch = 0; ch < MAX_CH; ++ch) {
@@ -243,6 +248,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(const float* __res
                 gsd = sd != 0.f ? gsig * (-0.5f * eu / (beta * beta)) : 0.f;
                 gb += gsig * (-sig / beta + 0.5f * sd * eu / (beta * beta * beta));
             }
+            if (s == lf) gsd += lg0;
+            if (s == lf + 1 && lf >= 0) gsd += lg1;
             g_sdf[g] = gsd;
         }
     }
@@ -307,7 +314,8 @@ int spf_render_rgb_backward(const float* weights, const float* colors, const flo
 int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas, const float* colors,
                         const float* beta, const float* weights, const float* g_weights, const float* g_rgb, const float* g_depth,
                         const float* g_dist, int32_t R, int32_t SR, float* g_sdf, float* g_colors, float* g_beta, const float* beta_param,
-                        const float* g_acc, const float* g_pts_rendered, const float* ray_dirs, int64_t* g_beta_fixed, void* stream) {
+                        const float* g_acc, const float* g_pts_rendered, const float* ray_dirs, int64_t* g_beta_fixed, const int32_t* lfirst,
+                        const float* lcoef, const float* lscale, void* stream) {
     if (R < 0 || SR < 1 || SR > 64 * MAX_CH) return spf::fail(SPF_EINVAL, "spf_render_backward: need 1 <= SR <= %d", 64 * MAX_CH);
     if (R == 0) return SPF_OK;
     if (!sdf || !slot_valid || !z || !deltas || !beta || !weights || !g_sdf || !g_beta)
@@ -315,9 +323,11 @@ int spf_render_backward(const float* sdf, const uint8_t* slot_valid, const float
     if (g_rgb && (!colors || !g_colors)) return spf::fail(SPF_EINVAL, "spf_render_backward: g_rgb needs colors and g_colors");
     if (!g_rgb && g_colors) return spf::fail(SPF_EINVAL, "spf_render_backward: g_colors needs g_rgb");
     if (g_pts_rendered && !ray_dirs) return spf::fail(SPF_EINVAL, "spf_render_backward: g_pts_rendered needs ray_dirs");
+    if ((lfirst != nullptr) != (lcoef != nullptr) || (lfirst != nullptr) != (lscale != nullptr))
+        return spf::fail(SPF_EINVAL, "spf_render_backward: lfirst, lcoef and lscale are given (or left out) together");
     render_backward_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, (hipStream_t)stream>>>(
         sdf, slot_valid, z, deltas, colors, beta, weights, g_weights, g_rgb, g_depth, g_dist, R, SR, g_sdf, g_colors, g_beta, beta_param, g_acc,
-        g_pts_rendered, ray_dirs, reinterpret_cast<long long*>(g_beta_fixed));
+        g_pts_rendered, ray_dirs, reinterpret_cast<long long*>(g_beta_fixed), lfirst, lcoef, lscale);
     SPF_LAUNCH_CHECK("render_backward_kernel");
     return SPF_OK;
 }

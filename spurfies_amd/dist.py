@@ -175,7 +175,10 @@ def fused_counts(out):
     f = out["_fused"]
     dev = out["rgb_values"].device
     cnt = (f["pvalid"].bool() & f["ray_valid"].bool()).sum().float()
-    lcnt = out["local_count"] if "local_count" in out else torch.zeros((), device=dev)
+    if f.get("local") is not None:
+        lcnt = f["local"].count()
+    else:
+        lcnt = out["local_count"] if "local_count" in out else torch.zeros((), device=dev)
     return torch.stack([torch.full((), float(out["rgb_values"].shape[0]), device=dev), f["n_points"][0].float(), cnt, lcnt])
 
 

@@ -46,14 +46,15 @@ class VolSDFLoss(nn.Module):
         tv = model_outputs.get("tv_loss") if self.tv_weight > 0 else None
         psdf = f["psdf"] if self.pseudo_weight > 0 else None
         has_local = "local_sum" in model_outputs and self.local_weight > 0       # then `total` is read by an add below: no deferred finalize
+        # the feature-consistency term of the step (ops.LocalTerms): summed, normalised and weighted inside the loss kernels
         total, t = ops.FusedLoss.apply(model_outputs["rgb_values"], f["acc"], psdf, tv, f["grad"], f["slot_valid"], f["n_points"],
                                        f["pvalid"], f["ray_valid"], rgb_gt, mask, mask.stride(0), w, denom, not has_local,
-                                       f.get("tv_ctx") if self.tv_weight > 0 else None)
+                                       f.get("tv_ctx") if self.tv_weight > 0 else None, f.get("local"))
         self.iter_step += 1
         local = t[5]
         if "local_sum" in model_outputs and self.local_weight > 0:
-            # the feature-consistency term is PyTorch ops (grid_sample) upstream of the loss kernels: added here, normalised by the
-            # global hit count when rays are sharded (denom[3])
+            # the feature-consistency term came through ops.LocalLoss (a step that is sync-free but whose compositing does not carry
+            # ops.LocalTerms): added here, normalised by the global hit count when rays are sharded (denom[3])
             cnt = model_outputs["local_count"] if (denom is None or denom.numel() < 4) else denom[3]
             local = model_outputs["local_sum"] / cnt.clamp(min=1.0)
             total = total + self.local_weight * local

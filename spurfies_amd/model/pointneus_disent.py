@@ -352,6 +352,8 @@ class PointVolSDF(nn.Module):
         # forked step (ops.branch; TrainStep(fork=True), the default of graph-replayed steps): passes that do not depend on each other are
         # issued on side streams = parallel branches of the step's hipGraph.  Branch "aux": the two weight-packing launches (they only read
         # the parameters) and the TV term, beside the main pass's kNN / geometry kernel.
+        if not self.training:
+            local_data = None                                     # the feature-consistency term is a training loss (:731)
         fork = static and ops.fork_enabled() and local_data is None and ops._sink(self.density.beta) is not None
         ev_pack, tv_early = None, None
         if fork and (pre is None or tv_pre is None):
@@ -411,14 +413,20 @@ class PointVolSDF(nn.Module):
         colors = colors.view(R, SR, 3)
 
         # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------
+        local_terms = None
         if fork:
             ops.wait(ev_w)
             rgb = ops.RenderRGB.apply(weights, colors)
             ops.join(dev)                                         # the pseudo-point pass and the TV term: read by the loss kernels next
         elif static and ops._sink(self.density.beta) is not None:    # beta's gradient goes straight into its .grad buffer
             # ... and the rendered surface points o + d * dist_map of the pseudo-point loss (:765-767) come out of the same launch
+            if local_data is not None:
+                # multi-view feature consistency at the SDF zero crossings (:727-763; DTU recipe, local_weight 0.5): ONE launch (crossing search,
+                # projection into the 1 + m views, bilinear taps, cosine term, tangents); its sum joins the loss kernels' partial sums and its
+                # gradient joins g_sdf inside the compositing backward — no other launch, no host synchronisation (ops.LocalTerms)
+                local_terms = ops.local_forward(feat_utils.local_desc(local_data, dev), sdf, z_slots, cam_loc, ray_dirs)
             weights, rgb, depth, dist_map, acc, pts_rendered = ops.Render.apply(sdf, colors, self.density.get_beta_value(), q["slot_valid"], z_slots,
-                                                                                deltas, self.density.beta, cam_loc, ray_dirs)
+                                                                                deltas, self.density.beta, cam_loc, ray_dirs, local_terms)
         else:
             pts_rendered = None
             weights, rgb, depth, dist_map, acc = ops.Render.apply(sdf, colors, self.density.get_beta(), q["slot_valid"], z_slots, deltas)
@@ -428,11 +436,16 @@ class PointVolSDF(nn.Module):
                            "deltas": deltas, "sdf": sdf, "gradients": gradients, "colors": colors, "dist_map": dist_map}
 
         # ---- multi-view feature consistency at the SDF zero crossings (:727-763), DTU training only ---------
-        if local_data is not None and self.training:
-            d_surface, hit = self.find_surface_points(sdf, z_slots)
-            lsum, lcnt = feat_utils.local_loss_terms(DistPoints.apply(cam_loc, ray_dirs, d_surface), hit, local_data)
+        if local_terms is not None:
+            if self.keep_stages:
+                self.stages.update({"d_surface": local_terms.d_surface, "network_mask": local_terms.lfirst >= 0})
+        elif local_data is not None and self.training:
+            # the same launch behind an autograd.Function of its own (ops.LocalLoss): the default training mode
+            lsum, lcnt, d_surface, hit = ops.LocalLoss.apply(sdf, z_slots, cam_loc, ray_dirs, feat_utils.local_desc(local_data, dev))
             output["local_loss"] = lsum / lcnt.clamp(min=1.0)          # 0 when no ray crosses the surface, as feat_utils.py:390-391
             output["local_sum"], output["local_count"] = lsum, lcnt    # ray-sharded steps normalise by the global count
+            if self.keep_stages:
+                self.stages.update({"d_surface": d_surface, "network_mask": hit})
         if not static:          # per-slot maps the trainer never reads in an optimisation step (plots only)
             far_fill = float(conf.ray_sampler.far)
             output["depth_values"] = torch.where(ray_mask[:, None], depth, torch.ones_like(depth))
@@ -445,7 +458,7 @@ class PointVolSDF(nn.Module):
             if pr is None:
                 pr = self._sdf_points(pts_rendered if pts_rendered is not None else DistPoints.apply(cam_loc, ray_dirs, dist_map), with_grad=True, role="pseudo")
             output["_fused"] = {"acc": acc, "grad": gradients.detach(), "slot_valid": q["slot_valid"].view(-1), "n_points": pl.n_points,
-                                "psdf": pr["sdf"], "pvalid": pr["valid"], "ray_valid": q["ray_valid"]}
+                                "psdf": pr["sdf"], "pvalid": pr["valid"], "ray_valid": q["ray_valid"], "local": local_terms}
         else:
             pseudo_pts_loss = torch.zeros((), device=dev)
             pseudo_sum, pseudo_cnt = pseudo_pts_loss, pseudo_pts_loss

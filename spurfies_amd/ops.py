@@ -2,6 +2,8 @@
 arithmetic stage is a HIP kernel in libspurfies_hip.so)."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib, _prof
@@ -794,9 +796,11 @@ class Render(torch.autograd.Function):
     effective beta (a 0-dim tensor); differentiable w.r.t. all three."""
 
     @staticmethod
-    def forward(ctx, sdf, colors, beta, slot_valid, z, deltas, beta_param=None, cam_loc=None, ray_dirs=None):
+    def forward(ctx, sdf, colors, beta, slot_valid, z, deltas, beta_param=None, cam_loc=None, ray_dirs=None, local=None):
         """beta_param: the raw LaplaceDensity parameter (beta = |beta_param| + beta_min was formed from it, detached) when
         its gradient should be accumulated straight into its .grad buffer (set_grad_sinks).
+        local (LocalTerms, optional): the feature-consistency term of this step (local_forward on the same sdf rows) — its gradient w.r.t.
+        the SDF joins g_sdf inside the backward launch, scaled by the `lscale` the loss backward (FusedLoss, which runs first) leaves.
         cam_loc / ray_dirs [R,3] (optional): a sixth output pts_rendered = cam_loc + ray_dirs * dist (pointneus_disent.py:765-767; differentiable
         through dist) comes out of the same launch and its gradient goes back through the same backward launch."""
         R, SR = sdf.shape
@@ -819,6 +823,7 @@ class Render(torch.autograd.Function):
                                                      _lib.ptr(acc), _lib.ptr(loc_c), _lib.ptr(dirs_c), _lib.ptr(pts), _lib.stream_ptr()), "spf_render_forward")
         ctx.save_for_backward(sdf_c, col_c, beta_c, slot_valid, z, deltas, weights, dirs_c)
         ctx.with_pts = with_pts
+        ctx.local = local
         ctx.beta_param = beta_param.detach() if beta_param is not None else None
         ctx.beta_sink = _sink(beta_param) if beta_param is not None else None
         if beta_param is not None and ctx.beta_sink is None:
@@ -841,15 +846,19 @@ class Render(torch.autograd.Function):
         sink = ctx.beta_sink
         g_beta = sink.reshape(1) if sink is not None else torch.zeros((1,), dtype=torch.float32, device=dev)
         acc_b = _fixed_acc(g_beta, "beta") if _SCATTER["mode"] == "fixed" else None        # one term per ray: order-independent in this mode
+        lt = ctx.local
+        if lt is not None and not lt.scaled:
+            raise RuntimeError("Render(local=...): the loss backward (FusedLoss with the same LocalTerms) has not written lscale")
         with torch.cuda.device(dev), _prof.span("render_bwd", rays=R, slots=SR):
             _lib.check(_lib.lib().spf_render_backward(_lib.ptr(sdf), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(colors),
                                                       _lib.ptr(beta), _lib.ptr(weights), _lib.ptr(gw), _lib.ptr(g_rgb), _lib.ptr(g_depth),
                                                       _lib.ptr(g_dist), R, SR, _lib.ptr(g_sdf), _lib.ptr(g_col), _lib.ptr(g_beta),
                                                       _lib.ptr(ctx.beta_param), _lib.ptr(g_acc), _lib.ptr(g_pts), _lib.ptr(dirs if g_pts is not None else None),
-                                                      _lib.ptr(acc_b), _lib.stream_ptr()), "spf_render_backward")
+                                                      _lib.ptr(acc_b), _lib.ptr(None if lt is None else lt.lfirst), _lib.ptr(None if lt is None else lt.lcoef),
+                                                      _lib.ptr(None if lt is None else lt.lscale), _lib.stream_ptr()), "spf_render_backward")
         if acc_b is not None:
             _fixed_flush(acc_b, g_beta)
-        return g_sdf, g_col, (None if sink is not None else g_beta.reshape(())), None, None, None, None, None, None
+        return g_sdf, g_col, (None if sink is not None else g_beta.reshape(())), None, None, None, None, None, None, None
 
 
 class RenderW(torch.autograd.Function):
@@ -896,7 +905,8 @@ class RenderW(torch.autograd.Function):
             _lib.check(_lib.lib().spf_render_backward(_lib.ptr(sdf), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), None, _lib.ptr(beta),
                                                       _lib.ptr(weights), _lib.ptr(g_w), None, _lib.ptr(g_depth), _lib.ptr(g_dist), R, SR, _lib.ptr(g_sdf),
                                                       None, _lib.ptr(g_beta), _lib.ptr(ctx.beta_param), _lib.ptr(g_acc), _lib.ptr(g_pts),
-                                                      _lib.ptr(dirs if g_pts is not None else None), _lib.ptr(acc_b), _lib.stream_ptr()), "spf_render_backward")
+                                                      _lib.ptr(dirs if g_pts is not None else None), _lib.ptr(acc_b), None, None, None, _lib.stream_ptr()),
+                       "spf_render_backward")
         if acc_b is not None:
             _fixed_flush(acc_b, g_beta)
         return g_sdf, None, None, None, None, None, None, None
@@ -1310,6 +1320,70 @@ def set_fused_sampler(on=True):
     _FUSED_SAMPLER[0] = bool(on)
 
 
+class LocalTerms:
+    """One step's feature-consistency term as spf_local_forward leaves it: per ray d_surface [R], lfirst [R] (-1: no crossing), lsum [R],
+    lcoef [R,2], and lscale [1] — written by the loss backward (FusedLoss), read by the compositing backward (Render), which is how the term's
+    gradient reaches the SDF rows without a launch of its own.  `desc`: feat_utils.LocalDesc (device descriptor of the view)."""
+
+    def __init__(self, desc, R, dev):
+        self.desc = desc
+        self.d_surface = torch.empty((R,), dtype=torch.float32, device=dev)
+        self.lfirst = torch.empty((R,), dtype=torch.int32, device=dev)
+        self.lsum = torch.empty((R,), dtype=torch.float32, device=dev)
+        self.lcoef = torch.empty((R, 2), dtype=torch.float32, device=dev)
+        self.lscale = torch.empty((1,), dtype=torch.float32, device=dev)
+        self.scaled = False
+        self._args = None
+
+    def args(self):
+        if self._args is None:
+            self._args = _lib.LocalTermsArgs(self.lsum.data_ptr(), self.lfirst.data_ptr(), self.desc.buf.data_ptr(), self.lscale.data_ptr())
+        return ctypes.byref(self._args)
+
+    def count(self):
+        """source views x rays with a crossing: the denominator of the reference's mean (feat_utils.py:437), device float []."""
+        n_src = self.desc.buf[_lib.LocalDesc.n_src.offset: _lib.LocalDesc.n_src.offset + 4].view(torch.int32)[0]       # read on the device: a replayed
+        return (self.lfirst >= 0).sum().float() * n_src.float()                                                      # graph serves every view
+
+
+def local_forward(desc, sdf, z, cam_loc, ray_dirs) -> LocalTerms:
+    """find_surface_points (pointneus_disent.py:586-612) + the surface points (:744-749) + get_local_loss (feat_utils.py:377-451) for the
+    rays of one view: ONE launch over the dense [R,SR] SDF / depth rows (values only; see LocalTerms for the gradient's route)."""
+    R, SR = sdf.shape
+    dev = sdf.device
+    lt = LocalTerms(desc, R, dev)
+    with torch.cuda.device(dev), _prof.span("local_fwd", rays=R, slots=SR):
+        _lib.check(_lib.lib().spf_local_forward(_lib.ptr(desc.buf), _lib.ptr(sdf.detach().contiguous()), _lib.ptr(z.contiguous()),
+                                                _lib.ptr(cam_loc.detach().contiguous()), _lib.ptr(ray_dirs.detach().contiguous()), R, SR,
+                                                _lib.ptr(lt.d_surface), _lib.ptr(lt.lfirst), _lib.ptr(lt.lsum), _lib.ptr(lt.lcoef), _lib.stream_ptr()),
+                   "spf_local_forward")
+    return lt
+
+
+class LocalLoss(torch.autograd.Function):
+    """(sum, count, d_surface [R], hit bool [R]) of the feature-consistency term, differentiable w.r.t. sdf [R,SR] through `sum` — the
+    stand-alone form (default training mode, tests): the local loss is sum / max(count, 1).  The fused optimisation step does not use it
+    (LocalTerms travels through FusedLoss and Render instead: no reduction, scaling or backward launches of its own)."""
+
+    @staticmethod
+    def forward(ctx, sdf, z, cam_loc, ray_dirs, desc):
+        lt = local_forward(desc, sdf, z, cam_loc, ray_dirs)
+        ctx.lt, ctx.shape = lt, sdf.shape
+        hit, cnt = lt.lfirst >= 0, lt.count()
+        ctx.mark_non_differentiable(hit, cnt, lt.d_surface)
+        return lt.lsum.sum(), cnt, lt.d_surface, hit
+
+    @staticmethod
+    def backward(ctx, g_sum, _g_cnt, _g_d, _g_hit=None):
+        lt = ctx.lt
+        R, SR = ctx.shape
+        g_sdf = torch.empty((R, SR), dtype=torch.float32, device=lt.lsum.device)
+        with torch.cuda.device(g_sdf.device):
+            _lib.check(_lib.lib().spf_local_backward(_lib.ptr(lt.lfirst), _lib.ptr(lt.lcoef), _lib.ptr(g_sum.detach().reshape(1).contiguous().float()), R, SR,
+                                                     _lib.ptr(g_sdf), _lib.stream_ptr()), "spf_local_backward")
+        return g_sdf, None, None, None, None
+
+
 _loss_ws = {}
 
 
@@ -1330,10 +1404,12 @@ class FusedLoss(_GradModeFunction):
 
     @staticmethod
     def forward(ctx, rgb, acc, psdf, tv, grad, slot_valid, n_points, pvalid, ray_valid, rgb_gt, mask_gt, mask_stride, weights, denom, allow_defer=True,
-                tv_ctx=None):
+                tv_ctx=None, local=None):
         """allow_defer=False: `total` is read by further forward ops (the feature-consistency term is added to it): finalize in the forward.
         tv_ctx = (geometry latent parameter, TVGraph): `tv` are per-point VALUES formed outside autograd (the step's first launch); their
-        backward is this function's job — it rides in the loss backward launch and adds straight into the parameter's gradient sink."""
+        backward is this function's job — it rides in the loss backward launch and adds straight into the parameter's gradient sink.
+        local (LocalTerms): the feature-consistency term joins the partial sums (terms[5], weighted by weights.local in the total); its
+        gradient does not pass through autograd: the backward launch leaves local.lscale, which Render's backward (same LocalTerms) applies."""
         dev = rgb.device
         R = rgb.shape[0]
         rgb_c, acc_c = rgb.detach().contiguous(), acc.detach().reshape(R).contiguous()
@@ -1345,18 +1421,22 @@ class FusedLoss(_GradModeFunction):
             _loss_ws[key] = torch.empty((int(_lib.lib().spf_loss_workspace_floats()),), dtype=torch.float32, device=dev)
         total = torch.empty((), dtype=torch.float32, device=dev)
         terms = torch.empty((8,), dtype=torch.float32, device=dev)
-        den = torch.empty((4,), dtype=torch.float32, device=dev)
+        den = torch.empty((8,), dtype=torch.float32, device=dev)
         rows = 0 if grad is None else grad.shape[0]
+        if local is not None and denom is not None and denom.numel() < 4:
+            raise ValueError("FusedLoss(local=...): denom needs the global local count as its fourth entry (dist.fused_counts)")
         defer = bool(allow_defer) and _DEFER_LOSS[0] and _GradModeFunction._outer_grad_mode and any(ctx.needs_input_grad[:4])
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_loss_forward(_lib.ptr(rgb_c), _lib.ptr(rgb_gt), _lib.ptr(acc_c), _lib.ptr(mask_gt), mask_stride,
                                                    _lib.ptr(grad), _lib.ptr(slot_valid), rows, _lib.ptr(n_points), _lib.ptr(psdf_c),
                                                    _lib.ptr(pvalid), _lib.ptr(ray_valid), _lib.ptr(tv_c), n_tv, _lib.ptr(denom), R, weights,
                                                    _lib.ptr(_loss_ws[key]), None if defer else _lib.ptr(total), None if defer else _lib.ptr(terms),
-                                                   None if defer else _lib.ptr(den), _lib.stream_ptr()), "spf_loss_forward")
+                                                   None if defer else _lib.ptr(den), None if local is None else local.args(), _lib.stream_ptr()),
+                       "spf_loss_forward")
         ctx.save_for_backward(rgb_c, acc_c, psdf_c, rgb_gt, mask_gt, pvalid, ray_valid, den)
         ctx.misc = (mask_stride, weights, acc.shape, None if psdf is None else psdf.shape, tv is not None, n_tv)
         ctx.fin = (_loss_ws[key], rows, n_points, tv_c, denom, total, terms) if defer else None
+        ctx.local = local
         ctx.tv_ctx = None
         if tv_ctx is not None:
             sink = _sink(tv_ctx[0])
@@ -1373,7 +1453,9 @@ class FusedLoss(_GradModeFunction):
         mask_stride, weights, acc_shape, psdf_shape, has_tv, n_tv = ctx.misc
         R, dev = rgb.shape[0], rgb.device
         if g_total is None:
-            return (None,) * 16
+            return (None,) * 17
+        lt = ctx.local
+        largs = None if lt is None else lt.args()
         g = g_total.detach().reshape(1).contiguous()
         g_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
         g_acc = torch.empty((R,), dtype=torch.float32, device=dev)
@@ -1390,18 +1472,20 @@ class FusedLoss(_GradModeFunction):
                                                                  _lib.ptr(denom), _lib.ptr(total), _lib.ptr(terms), _lib.ptr(den), _lib.ptr(feat),
                                                                  _lib.ptr(None if graph is None else graph.nbr), _lib.ptr(None if graph is None else graph.w),
                                                                  _lib.ptr(None if graph is None else graph.norm), 1 if graph is None else graph.nbr.shape[1],
-                                                                 _lib.ptr(sink), _lib.stream_ptr()), "spf_loss_backward_finalize")
+                                                                 _lib.ptr(sink), largs, _lib.stream_ptr()), "spf_loss_backward_finalize")
             else:
                 _lib.check(_lib.lib().spf_loss_backward(_lib.ptr(g), _lib.ptr(den), weights, _lib.ptr(rgb), _lib.ptr(rgb_gt), _lib.ptr(acc),
                                                         _lib.ptr(mask_gt), mask_stride, _lib.ptr(psdf), _lib.ptr(pvalid), _lib.ptr(ray_valid), R,
-                                                        _lib.ptr(g_rgb), _lib.ptr(g_acc), _lib.ptr(g_psdf), _lib.ptr(g_tv), n_tv, _lib.stream_ptr()),
+                                                        _lib.ptr(g_rgb), _lib.ptr(g_acc), _lib.ptr(g_psdf), _lib.ptr(g_tv), n_tv, largs, _lib.stream_ptr()),
                            "spf_loss_backward")
                 if tvc is not None:          # (finalize was not deferred: the TV backward as its own launch, one gradient value for all points)
                     feat, graph, sink = tvc
                     _lib.check(_lib.lib().spf_tv_backward(_lib.ptr(feat), _lib.ptr(graph.nbr), _lib.ptr(graph.w), _lib.ptr(graph.norm), _lib.ptr(g_tv), 0, 1.0,
                                                           feat.shape[0], graph.nbr.shape[1], _lib.ptr(sink), None, _lib.stream_ptr()), "spf_tv_backward")
+        if lt is not None:
+            lt.scaled = True                  # lscale is on its way: Render's backward (later in autograd's order) may read it
         if tvc is not None:
             g_tv = None                       # the latent gradient has been accumulated: nothing for autograd
         g_tv_out = None if g_tv is None else (g_tv.expand(n_tv) if n_tv else g_tv.reshape(()))      # per-point array: one value, stride 0
         return (g_rgb, g_acc.view(acc_shape), None if g_psdf is None else g_psdf.view(psdf_shape), g_tv_out,
-                None, None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None)

@@ -45,7 +45,6 @@ class TrainStep:
         self.sync_free = sync_free
         self.use_graph = use_graph
         self._graph = None
-        self._warned_graph_local = False
         self._one = None
         self._graph_key = None
         model.sync_free = sync_free
@@ -92,25 +91,15 @@ class TrainStep:
 
     def _step(self, model_input, ground_truth):
         self.model.train()
-        if self.use_graph and model_input.get("local_data") is not None:
-            # the captured graph holds no per-view feature maps: replaying it would silently drop the feature-consistency term
-            # (local_weight 0.5).  Steps that carry local_data run the eager sync-free path (same kernels, same loss).
-            if not self._warned_graph_local:
-                import warnings
-
-                warnings.warn("TrainStep(use_graph=True): this batch carries local_data — running the eager sync-free step for it "
-                              "(the hipGraph is captured without the per-view feature maps)")
-                self._warned_graph_local = True
-            losses, out = self._forward_backward(model_input, ground_truth, reduce_buckets=True)
-        elif self.use_graph:
+        if self.use_graph:
             losses, out = self._graphed_forward_backward(model_input, ground_truth)
         else:
             losses, out = self._forward_backward(model_input, ground_truth, reduce_buckets=True)
         if self.world > 1:
             if self.buckets is not None and self.buckets.armed:
-                # the backward that just ran had the bucket hooks (eager sync-free step, also the eager fallback of a use_graph step that
-                # carries local_data): reduce the buckets nobody announced (geometry latents: last), then wait for all of them — never a
-                # second, dense reduce on top (that summed three buckets twice: round-3 advisor finding)
+                # the backward that just ran had the bucket hooks (eager sync-free step): reduce the buckets nobody announced (geometry
+                # latents: last), then wait for all of them — never a second, dense reduce on top (that summed three buckets twice:
+                # round-3 advisor finding)
                 self.buckets.finish()
             else:
                 sdist.all_reduce_sum(self.flat.buffer, self.group)
@@ -205,12 +194,21 @@ class TrainStep:
             ops.set_fork(prev_fork)
 
     def _graphed_forward_backward_body(self, model_input, ground_truth):
+        from . import feat_utils
+
         dev = model_input["uv"].device
         keys_in = ("intrinsics", "uv", "pose")
-        key = self.model.cache_key()
+        # the DTU recipe's feature-consistency term (local_data, local_weight 0.5) is part of the captured step: its kernels read the view's
+        # feature-map addresses, cameras and sizes from a DESCRIPTOR in device memory (feat_utils.LocalDesc), and each replay is preceded by a
+        # copy of the current view's descriptor into the graph's static one — one graph for all training views
+        local = model_input.get("local_data")
+        desc = None if local is None else feat_utils.local_desc(local, dev)
+        key = (self.model.cache_key(), desc is not None)
         if self._graph is None or self._static_in["uv"].shape != model_input["uv"].shape or key != self._graph_key:
             self._graph_key = key
             self._static_in = {k: model_input[k].clone() for k in keys_in}
+            self._static_desc = None if desc is None else feat_utils.LocalDesc(desc.buf.clone(), desc.n_src)
+            static_local = self._static_desc
             self._static_gt = {k: ground_truth[k].to(dev).clone() for k in ("rgb", "mask")}
             # warm-up on a side stream (builds the cell table, TV graph, workspaces, allocator pools) without touching the
             # training trajectory: parameters are restored afterwards and no optimiser step is taken
@@ -219,7 +217,7 @@ class TrainStep:
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(2):       # no collective in the warm-up: ranks may (re)capture independently of each other
-                    self._forward_backward(dict(self._static_in, local_data=None), self._static_gt, collectives=False)
+                    self._forward_backward(dict(self._static_in, local_data=static_local), self._static_gt, collectives=False)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.set_rng_state(rng)
             self._refresh_draws(model_input["uv"].shape[1], dev)      # allocates the persistent draw buffers
@@ -229,7 +227,7 @@ class TrainStep:
             if self.world == 1:
                 ops.drop_pending_wgrad()
                 with ops.capture_guard(), torch.cuda.graph(self._graph):
-                    out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
+                    out = self.model(dict(self._static_in, local_data=static_local, iter_step=0), fast=1)
                     losses = self.loss(out, self._static_gt)
                     if not self.zero_in_adam:      # else the previous step's Adam sweep left the gradient buffer zero: no fill node in the graph
                         self.flat.zero_()
@@ -247,7 +245,7 @@ class TrainStep:
                 # three extra all-reduces and hang the group).
                 pool = torch.cuda.graph_pool_handle()
                 with ops.capture_guard(), torch.cuda.graph(self._graph, pool=pool):
-                    out = self.model(dict(self._static_in, local_data=None, iter_step=0), fast=1)
+                    out = self.model(dict(self._static_in, local_data=static_local, iter_step=0), fast=1)
                     self._counts = sdist.fused_counts(out)
                 self._graph_tail = torch.cuda.CUDAGraph()
                 with ops.capture_guard(), torch.cuda.graph(self._graph_tail, pool=pool):
@@ -262,6 +260,10 @@ class TrainStep:
         # the batch -> the graph's static input buffers: ONE multi-tensor copy launch (five D2D copies were 24 us of a 1 ms step at 128 rays)
         src = [model_input[k] for k in keys_in] + [ground_truth[k] for k in ("rgb", "mask")]
         dst = [self._static_in[k] for k in keys_in] + [self._static_gt[k] for k in ("rgb", "mask")]
+        if desc is not None:
+            src.append(desc.buf)
+            dst.append(self._static_desc.buf)
+            self._static_desc.keep = desc.keep       # the maps the replay reads
         if all(a.is_cuda and a.dtype == b.dtype and a.shape == b.shape for a, b in zip(src, dst)):
             torch._foreach_copy_(dst, src)
         else:

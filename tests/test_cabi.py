@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     missing = [n for n in decl if not hasattr(lib, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert set(_lib.SIGNATURES) == decl, (set(_lib.SIGNATURES) ^ decl)
-    assert lib.spf_abi_version() == 5
+    assert lib.spf_abi_version() == 6
     assert not [n for n in decl if n.endswith("_set_mode") or n.endswith("_get_mode")], "no process-global modes in the ABI"
     assert lib.spf_geo_packed_floats() > 0 and lib.spf_color_packed_floats() > 0
 

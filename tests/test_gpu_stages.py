@@ -125,9 +125,10 @@ def test_stages_behind_the_sampler_match_reference(name):
     np.testing.assert_allclose(out["tv_loss"].item(), fx["out.tv_loss"], rtol=2e-6)
     np.testing.assert_allclose(out["pseudo_pts_loss"].item(), fx["out.pseudo_pts_loss"], rtol=2e-4, atol=1e-6)
     if "stage.d_surface" in fx:                               # find_surface_points (:586-612) + get_local_loss (feat_utils.py:377-451)
-        d_s, hit = model.find_surface_points(sg["sdf"].detach(), sg["z_slots"])
-        assert np.array_equal(hit.cpu().numpy()[ray_mask], fx["stage.network_mask"][0]) and not hit.cpu().numpy()[~ray_mask].any()
-        np.testing.assert_allclose(d_s.cpu().numpy()[ray_mask], fx["stage.d_surface"][0], rtol=1e-4, atol=1e-5)
+        for d_s, hit in (model.find_surface_points(sg["sdf"].detach(), sg["z_slots"]),          # the reference-named PyTorch form
+                         (sg["d_surface"], sg["network_mask"])):                                  # what the step's launch (spf_local_forward) left
+            assert np.array_equal(hit.cpu().numpy()[ray_mask], fx["stage.network_mask"][0]) and not hit.cpu().numpy()[~ray_mask].any()
+            np.testing.assert_allclose(d_s.cpu().numpy()[ray_mask], fx["stage.d_surface"][0], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(out["local_loss"].item(), fx["out.local_loss"], rtol=1e-3)
         assert float(fx["out.local_loss"]) > 0.01
     else:
