@@ -48,8 +48,10 @@ def parse():
     ap.add_argument("--global-rays", type=int, default=0, help="strong scaling with this many rays per step instead of --rays (kept for older command lines)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: --rays rays per GPU, the batch grows with N (no BASELINE config has such batches; "
                     "reported as an `extra` record of the default run at N > 1)")
-    ap.add_argument("--extras", choices=["auto", "on", "off"], default="auto", help="extra records in the same JSON line (`extra`): BASELINE.json configs[4] "
-                    "strong-scaled (2e5 points, 4096 rays per step) and the weak-scaling figure (1024 rays per GPU); auto = at N > 1")
+    ap.add_argument("--extras", choices=["auto", "on", "off"], default="auto", help="extra records in the same JSON line (`extra`), measured AFTER the contract "
+                    "region under a timer.  N = 1 (auto / on): the DTU recipe's real step (feature-consistency term on every batch -> ms_per_step_with_local) "
+                    "and one evaluation-render chunk (fast = -1, realised sampler iterations).  N > 1 (auto / on), N = 1 (on): BASELINE.json configs[4] "
+                    "strong-scaled (2e5 points, 4096 rays per step) and the weak-scaling figure (1024 rays per GPU)")
     ap.add_argument("--c4-points", type=int, default=200000, help="neural points of the configs[4] extra record (tests shrink it)")
     ap.add_argument("--c4-rays", type=int, default=4096, help="rays per step of the configs[4] extra record")
     ap.add_argument("--local", action="store_true", help="also time the DTU recipe's real step: synthetic local_data on every batch (find_surface_points + "
@@ -190,7 +192,7 @@ def make_batches(scene, n_steps, rays_total, rank, world, device, seed=12345, lo
     views = None
     if local:
         views = [{k: (torch.from_numpy(np.asarray(v)).to(device) if isinstance(v, (np.ndarray, np.floating)) else v)
-                  for k, v in syn.make_local_data(scene, v_, seed=0).items()} for v_ in range(len(scene["poses"]))]
+                  for k, v in syn.make_local_data(scene, v_, channels=32, seed=0).items()} for v_ in range(len(scene["poses"]))]      # 32 channels: VisMVSNet's FeatExt (feat_utils.py:347-349)
     for s in range(n_steps):
         uv = torch.from_numpy(syn.make_pixels(rays_total, g))
         rgb = torch.rand((rays_total, 3), generator=g)
@@ -229,7 +231,7 @@ def cpu_baseline(scene, n_rays):
 
     cores = min(os.cpu_count() or 1, 8)   # more intra-op threads only slow these small CPU ops down
     v_all, t_all = run(cores, n_rays, 2)
-    r1 = max(64, n_rays // 4)
+    r1 = n_rays          # the SAME batch size on one thread (round-5 verdict: no extrapolation from a quarter batch)
     v_one, t_one = run(1, r1, 1)
     torch.set_num_threads(cores)
     return {"value": v_all, "unit": "ray-samples/s", "cores": cores, "kind": "port",
@@ -505,7 +507,7 @@ def measure_train(args, ctx, w):
     torch.manual_seed(0)
     # small per-rank batches are host-bound in eager mode (the host needs ~2 ms to enqueue the ~40 launches of a step the GPU runs in ~1 ms
     # at 128 rays: profiles/r04_strong_proxy.json): forward + loss + backward replay as hipGraphs there unless --no-graph
-    use_graph = (args.graph or (rays_local <= 256 and not args.no_graph)) and not args.sync and not w["local"]
+    use_graph = (args.graph or (rays_local <= 256 and not args.no_graph)) and not args.sync
     scenes = [build_scene_step(a, seed, device, world, use_graph) for seed in range(a.scenes)]
     scene, model, step = scenes[0]
     n_batches = warmup + steps + max(n_sust, 0)
@@ -751,6 +753,7 @@ def main():
     res, scene = measure_train(args, ctx, main_w)
     extras = []
     want_extras = args.extras == "on" or (args.extras == "auto" and world > 1)
+    want_local = args.local or (args.extras != "off" and world == 1 and args.mode == "train")
     if want_extras and args.scenes == 1:
         es, ew = max(5, args.steps // 2), 2
         # BASELINE.json configs[4]: the dense cloud with 4096-ray batches, strong-scaled over the same ranks
@@ -759,25 +762,31 @@ def main():
         # the weak-scaling figure of the main workload (1024 rays PER GPU)
         extras.append({"points": args.points, "spacing": args.spacing, "scenes": 1, "rays_total": args.rays * world, "steps": es, "warmup": ew, "sustained": 0,
                        "light": True, "strong": False, "local": False, "record": "weak scaling of the main workload (--rays rays PER GPU; no BASELINE config has such batches)"})
-    if args.local and args.scenes == 1:
+    if want_local and args.scenes == 1:
         # the DTU recipe's real step (pointneus_disent.py:727-763, feat_utils.py:377-451; config/ours.yaml local_weight 0.5): find_surface_points + the
         # feature-consistency loss on synthetic per-view feature maps, every step
-        extras.append({"points": args.points, "spacing": args.spacing, "scenes": 1, "rays_total": rays_total, "steps": args.steps, "warmup": args.warmup,
-                       "sustained": 0, "light": True, "strong": strong, "local": True,
-                       "record": "the main workload with the DTU recipe's feature-consistency loss (local_weight 0.5) on every step"})
+        extras.insert(0, {"points": args.points, "spacing": args.spacing, "scenes": 1, "rays_total": rays_total, "steps": args.steps, "warmup": args.warmup,
+                          "sustained": 0, "light": True, "strong": strong, "local": True,
+                          "record": "the main workload with the DTU recipe's feature-consistency loss (local_weight 0.5) on every step: find_surface_points + "
+                                    "get_local_loss as one HIP launch inside the step (32-channel synthetic feature maps of 3 views at half resolution)"})
     res["extra"] = []
     # The extra records must never cost the contract line: a rank that fails or hangs inside one of them (a collective its peers never reach)
     # would leave rank 0 without anything to print.  Every rank arms the same timer; when it fires, rank 0 prints the main record with what
     # the extras have produced so far and all ranks leave (os._exit: no second program is started, nothing waits for the stuck collective).
     import threading
 
-    def abandon():
-        if rank == 0:
-            res["extra"].append({"record": "extras abandoned", "error": f"an extra record failed or did not finish within {limit:.0f} s (SPF_EXTRAS_TIMEOUT); "
-                                                                     "the main record above is complete"})
-            res.setdefault("cpu_baseline", None)
-            print(json.dumps(res), flush=True)
-        os._exit(0)
+    line_lock, line_done = threading.Lock(), [False]     # the JSON line is printed exactly once, by the main thread or by the timer thread
+
+    def abandon(code=0):
+        """code: 0 when the timer fired (the contract line is complete: the run counts), 3 from the rank whose own extra record raised."""
+        with line_lock:
+            if not line_done[0] and rank == 0:
+                line_done[0] = True
+                out = dict(res, extra=list(res["extra"]) + [{"record": "extras abandoned", "error": f"an extra record failed or did not finish within {limit:.0f} s "
+                                                                                                     "(SPF_EXTRAS_TIMEOUT); the main record above is complete"}])
+                out.setdefault("cpu_baseline", None)
+                print(json.dumps(out), flush=True)
+            os._exit(code)
 
     limit = float(os.environ.get("SPF_EXTRAS_TIMEOUT", "300"))
     timer = threading.Timer(limit, abandon) if (extras and limit > 0) else None
@@ -793,7 +802,7 @@ def main():
             print(f"[bench] rank {rank}: extra record {w['record']!r} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
             res["extra"].append({"record": w["record"], "error": repr(e)[:400]})
             if world > 1:
-                abandon()              # the peers are inside collectives this rank will not join: leave now, their timers end them
+                abandon(3)             # the peers are inside collectives this rank will not join: leave now (non-zero: this rank failed), their timers end them
             continue
         keep = {"record": w["record"], **{k: r[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "dist", "loss_last")}}
         keep["roofline"] = None if r["roofline"] is None else {k: r["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_ms", "pairs_per_launch", "kernel")}
@@ -804,7 +813,10 @@ def main():
         timer.cancel()
     if rank == 0:
         res["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(scene, args.cpu_rays)     # N = 1 only
-        print(json.dumps(res), flush=True)
+        with line_lock:
+            if not line_done[0]:
+                line_done[0] = True
+                print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -852,7 +852,8 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
         else return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: (C, layout) = (%d, %d) is not one of (256, 0), (256, G_TILES64 | A_TILES), "
                                           "(36..128 step 4, G_TILES64), (4..128 step 4, 0)", q, C, p.layout);
         if (kind[q] != 1 && (p.lda < C || (p.lda % 4))) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: lda >= C and a multiple of 4", q);
-        if (kind[q] != 0 && (rows_of[q] % 64)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: tiled operands need max_rows %% 64 == 0", q);
+        // (kinds 0 and 3 are row-major on both sides: any row count)
+        if ((kind[q] == 1 || kind[q] == 2) && (rows_of[q] % 64)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: tiled operands need max_rows %% 64 == 0", q);
         if (p.col_mod < 0 || p.col_mod > C || p.col_rot < 0 || (p.col_mod > 0 && p.col_rot >= p.col_mod) || (p.col_mod == 0 && p.col_rot != 0))
             return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: need 0 <= col_rot < col_mod <= C (or both 0)", q);
         if (p.ldw < (p.col_mod > 0 ? p.col_mod : C)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: problem %d: ldw too small", q);

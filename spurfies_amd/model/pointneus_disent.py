@@ -311,7 +311,7 @@ class PointVolSDF(nn.Module):
         ext = smp.draws
         n0 = smp.N_samples_eval
         # ... and the per-point TV terms of the geometry latents in the same launch (their backward rides in the loss backward launch)
-        tv_in = (ops.scatter_mode() != "fixed" and ops._sink(self.neural_feats_geometry) is not None and input.get("local_data") is None)
+        tv_in = ops.scatter_mode() != "fixed" and ops._sink(self.neural_feats_geometry) is not None
         res = ops.camera_uniform(input["uv"], input["pose"], input["intrinsics"], self.density.beta, self.density.beta_min_value, beta_fwd,
                                  smp._linspace(n0, dev), ext["t_rand"], smp.near, smp.far, tv_graph=self.tv_graph() if tv_in else None,
                                  tv_feat=self.neural_feats_geometry if tv_in else None,
