@@ -102,6 +102,15 @@ int spf_grid_query(const spf_grid* g, const float* raypos, int32_t R, int32_t D,
                    float radius_limit_scale, int32_t SR, int32_t* pidx, float* loc,
                    int32_t* slot_sample, uint8_t* slot_valid, uint8_t* ray_valid, void* stream);
 
+/* ABI 6 — front end of the mesh-extraction sweep (spurfies/utils/plots.py:249-253: get_sdf_eval over the points of a regular grid, chunk by
+ * chunk): the grid np.meshgrid(xs, ys, zs) ('xy' indexing, raveled: point i = (xs[(i / nz) % nx], ys[i / (nx nz)], zs[i % nz])) is never
+ * materialised.  For the flat indices [first, first + count): a point that fails the dilated-occupancy test spf_grid_query starts with gets
+ * fill[i - first] = fill_value (its SDF is the 1000 filler whatever else happens); the others leave compacted, in no particular order:
+ * pts[n,3], idx[n] = i, with n ADDED to counter[0] (device, zero before the first call of a sweep; pts / idx must hold the running total).
+ * The caller evaluates spf_grid_query / spf_geo_forward on pts and scatters the results to idx. */
+int spf_grid_sweep_hits(const spf_grid* grid, const float* xs, const float* ys, const float* zs, int32_t nx, int32_t ny, int32_t nz,
+                        int64_t first, int64_t count, float* fill, float fill_value, float* pts, int64_t* idx, uint64_t* counter, void* stream);
+
 /* ABI 5: the neighbour search of spf_grid_query alone, for slots that were assigned elsewhere: slot_sample [R,SR] (INPUT: sample index of
  * each slot or -1, a ray's first SR dilated-occupancy hits in sample order) and ray_valid [R] cleared to 0 come from the caller —
  * spf_sampler_train assigns the slots while it still holds the ray's sorted samples.  Same outputs as spf_grid_query. */

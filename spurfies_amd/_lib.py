@@ -68,6 +68,7 @@ SIGNATURES = {
     "spf_grid_get_info": (C.c_int, [_P, C.POINTER(GridInfo)]),
     "spf_grid_query": (C.c_int, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
     "spf_grid_knn": (C.c_int, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
+    "spf_grid_sweep_hits": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, C.c_int64, C.c_int64, _P, _F, _P, _P, _P, _P]),
     "spf_compact_points": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P]),
     "spf_compact_sync_words": (C.c_int64, [C.c_int64]),
     "spf_compact_pairs": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P]),

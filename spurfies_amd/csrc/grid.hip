@@ -722,6 +722,41 @@ void free_tables(spf_grid* g) {
     g->cursor = nullptr;
 }
 
+// ---- mesh-extraction sweep, front end (plots.py:249-253: get_sdf_eval over a regular grid): the grid's points are GENERATED from the
+//      three axes (no [M,3] array travels over PCIe or through HBM), tested against the dilated occupancy — the test every point query starts
+//      with (knn_kernel's inline_slots) — and the ones that pass leave compacted (coordinates + flat index); the others get the filler now.
+//      ~88 % of a mesh grid fails the test: the neighbour search, the compaction and the MLP kernels then only ever see the rest.
+__global__ void __launch_bounds__(256)
+sweep_hits_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs, int nx, int nz, long long first,
+                  long long count, GridDev g, float* __restrict__ fill, float fill_value, float* __restrict__ pts, long long* __restrict__ idx,
+                  unsigned long long* __restrict__ counter) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool hit = false;
+    float x = 0.f, y = 0.f, z = 0.f;
+    const long long i = first + t;
+    if (t < count) {        // np.meshgrid(x, y, z) 'xy' layout, raveled: i = (iy * nx + ix) * nz + iz
+        const long long row = i / nz;
+        x = xs[(int)(row % nx)];
+        y = ys[(int)(row / nx)];
+        z = zs[(int)(i - row * nz)];
+        hit = dil_hit(g, x, y, z);
+        if (!hit) fill[t] = fill_value;
+    }
+    const unsigned long long b = __ballot(hit);
+    if (!b) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(counter, (unsigned long long)__popcll(b));
+    base = __shfl(base, 0);                                   // (64-bit shuffle)
+    if (hit) {
+        const unsigned long long o = base + __popcll(b & ((1ull << lane) - 1ull));
+        pts[3 * o] = x;
+        pts[3 * o + 1] = y;
+        pts[3 * o + 2] = z;
+        idx[o] = i;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1037,6 +1072,20 @@ static int compact_pairs_impl(const uint8_t* slot_valid, const int32_t* nbr, int
     cp_write_kernel<<<chunks, 256, 0, stream>>>(slot_valid, nbr, nslot, k, scratch, point_slot, slot_point, pair_off, pair_point, counts, fill_sdf,
                                                 fill_value, fill_grad, gate);
     SPF_LAUNCH_CHECK("cp_write_kernel");
+    return SPF_OK;
+}
+
+int spf_grid_sweep_hits(const spf_grid* g, const float* xs, const float* ys, const float* zs, int32_t nx, int32_t ny, int32_t nz, int64_t first,
+                        int64_t count, float* fill, float fill_value, float* pts, int64_t* idx, uint64_t* counter, void* stream_) {
+    if (!g || !g->cell_start) return spf::fail(SPF_EINVAL, "spf_grid_sweep_hits: grid not built");
+    if (nx < 1 || ny < 1 || nz < 1 || first < 0 || count < 0 || first + count > (int64_t)nx * ny * nz)
+        return spf::fail(SPF_EINVAL, "spf_grid_sweep_hits: need nx, ny, nz >= 1 and [first, first + count) inside the nx * ny * nz grid");
+    if (count == 0) return SPF_OK;
+    if (!xs || !ys || !zs || !fill || !pts || !idx || !counter) return spf::fail(SPF_EINVAL, "spf_grid_sweep_hits: null pointer");
+    sweep_hits_kernel<<<spf::div_up(count, 256), 256, 0, (hipStream_t)stream_>>>(xs, ys, zs, nx, nz, first, count, spf::dev_view(g), fill, fill_value, pts,
+                                                                                   reinterpret_cast<long long*>(idx),
+                                                                                   reinterpret_cast<unsigned long long*>(counter));
+    SPF_LAUNCH_CHECK("sweep_hits_kernel");
     return SPF_OK;
 }
 

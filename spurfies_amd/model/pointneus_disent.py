@@ -14,6 +14,7 @@ What differs is HOW it runs:
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -207,6 +208,34 @@ class PointVolSDF(nn.Module):
     def get_sdf_eval(self, inputs):
         """:249-298 — mesh-extraction entry."""
         return self._sdf_points(inputs, with_grad=False)["sdf"]
+
+    def sdf_eval_grid(self, xs, ys, zs, chunk=1 << 22, span=1 << 26):
+        """get_sdf_eval over the regular grid np.meshgrid(xs, ys, zs) (plots.py:249-253 evaluates it in 100 000-point chunks of a host
+        array; chunking is not observable) -> device float32 [len(ys), len(xs), len(zs)] (the 'xy' layout), 1000 where a point has no
+        neighbour.  The points are generated on the device from the axes (cast to float32 exactly as `torch.tensor(grid, dtype=torch.float)`
+        casts them, plots.py:327-330), ~88 % of them fail the dilated-occupancy test every point query starts with and are filled at once
+        (spf_grid_sweep_hits); the rest — compacted — go through the neighbour search and the SDF kernels `chunk` points at a time and
+        are scattered back.  One host read-back (the hit count) per `span` grid points."""
+        dev = self.neural_pts.device
+        grid = self._grid()
+        ax = [torch.as_tensor(np.asarray(a)).to(torch.float32).to(dev).contiguous() for a in (xs, ys, zs)]
+        nx, ny, nz = (int(a.numel()) for a in ax)
+        M = nx * ny * nz
+        out = torch.empty((M,), dtype=torch.float32, device=dev)
+        cap = min(M, int(span))
+        pts = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+        idx = torch.empty((cap,), dtype=torch.int64, device=dev)
+        counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+        with torch.no_grad():
+            for first in range(0, M, cap):
+                cnt = min(cap, M - first)
+                counter.zero_()
+                grid.sweep_hits(ax[0], ax[1], ax[2], out[first: first + cnt], first, cnt, pts, idx, counter, fill_value=SDF_FILL)
+                n = int(counter.item())
+                for a in range(0, n, int(chunk)):
+                    b = min(n, a + int(chunk))
+                    out.index_copy_(0, idx[a:b], self._sdf_points(pts[a:b], with_grad=False)["sdf"])
+        return out.view(ny, nx, nz)
 
     def pseudo_sdf(self, inputs):
         """:423-495 — differentiable SDF of the valid rows only ([Nv,1]); a constant 1000-vector over

@@ -132,6 +132,16 @@ class VoxelGrid:
                                                    _lib.stream_ptr()), "spf_grid_knn")
         return out
 
+    def sweep_hits(self, xs, ys, zs, fill, first, count, pts, idx, counter, fill_value=1000.0):
+        """spf_grid_sweep_hits: for the flat indices [first, first + count) of np.meshgrid(xs, ys, zs) ('xy', raveled) write `fill_value` into
+        fill[: count] where the point fails the dilated-occupancy test and append the others to (pts [*,3], idx int64 [*]) at counter[0]."""
+        if self._built_for is None:
+            raise RuntimeError("VoxelGrid.sweep_hits before set_pointset")
+        with torch.cuda.device(fill.device):
+            _lib.check(_lib.lib().spf_grid_sweep_hits(self._h, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(zs), xs.numel(), ys.numel(), zs.numel(), int(first), int(count),
+                                                      _lib.ptr(fill), float(fill_value), _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(counter), _lib.stream_ptr()),
+                       "spf_grid_sweep_hits")
+
     def info(self):
         gi = _lib.GridInfo()
         _lib.check(_lib.lib().spf_grid_get_info(self._h, C.byref(gi)), "spf_grid_get_info")

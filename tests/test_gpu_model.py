@@ -637,6 +637,12 @@ def test_surface_route_grid_sweep_and_chamfer():
     st_np["T.0.bias"] = st_np["T.0.bias"] - np.float32(med)          # a prior whose level set crosses the cloud
     model.load_state_dict({"T.0.bias": torch.from_numpy(st_np["T.0.bias"])}, strict=False)
     vol = surface.sdf_volume(model.get_sdf_eval, grid, splitn=100000)
+    # the model's own sweep (points generated on the device, occupancy pre-filter, 4 M-point chunks: PointVolSDF.sdf_eval_grid) against the
+    # reference's formulation — the uploaded [M,3] array in 100 000-point chunks through get_sdf_eval: the same volume, bit for bit
+    vol_ref_form = surface.sdf_volume(lambda p: model.get_sdf_eval(p), grid, splitn=100000)
+    assert np.array_equal(vol, vol_ref_form)
+    small = model.sdf_eval_grid(*grid["xyz"], chunk=5000, span=70001).cpu().numpy()      # several spans, ragged chunks
+    assert np.array_equal(small, vol)
     pts = surface.surface_points(vol, grid)
     assert len(pts) > 2000
     st = P.load_state(st_np, requires_grad=False)
