@@ -387,11 +387,14 @@ int spf_filter_points(const float* loc, const uint8_t* slot_valid, const float* 
  * rgb = sum w c, depth = sum w z / (sum w + 1e-8), dist = sum w z / (sum w + 1e-10), acc = sum w.
  * colors [R,SR,3] must be 0 at invalid slots; beta is a DEVICE scalar (|beta_param| + beta_min).
  * pts_rendered [R,3] (may be NULL; needs cam_loc / ray_dirs [R,3]): the rendered surface points cam_loc + ray_dirs * dist the
- * pseudo-point loss queries (pointneus_disent.py:765-767), formed here instead of by a separate elementwise launch. */
+ * pseudo-point loss queries (pointneus_disent.py:765-767), formed here instead of by a separate elementwise launch.
+ * ABI 6 — evaluation outputs from the same launch (all may be NULL): grad [R,SR,3] (d sdf/d x of the slots) -> normal [R,3] =
+ * sum_j w_j grad_j / |grad_j| over the valid slots (the `normal_map` of pointneus_disent.py:797-815, 886-888); ray_valid [R]: depth[r] =
+ * depth_fill for a ray without a valid slot (the reference initialises `depth_values` with ones, :822-826). */
 int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas,
                        const float* colors, const float* beta, int32_t R, int32_t SR, float* weights,
                        float* rgb, float* depth, float* dist, float* acc, const float* cam_loc, const float* ray_dirs,
-                       float* pts_rendered, void* stream);
+                       float* pts_rendered, const float* grad, float* normal, const uint8_t* ray_valid, float depth_fill, void* stream);
 
 /* ABI 5 — the colour composite on its own.  spf_render_forward with colors == rgb == NULL is the WEIGHTS-ONLY form: everything that depends
  * on the SDF alone (weights, depth, dist, acc, pts_rendered — and with them the whole pseudo-point pass, pointneus_disent.py:765-780) can then

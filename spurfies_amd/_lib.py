@@ -93,7 +93,7 @@ SIGNATURES = {
     "spf_sampler_finish": (C.c_int, [_P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _I, _P, _P, _P, _I, _P]),
     "spf_sampler_train": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _I, _P, _I, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "spf_filter_points": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
-    "spf_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spf_render_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P]),
     "spf_render_rgb": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "spf_render_rgb_backward": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "spf_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -53,12 +53,13 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const float* __rest
                                                              int R, int SR, float* __restrict__ weights, float* __restrict__ rgb,
                                                              float* __restrict__ depth, float* __restrict__ dist, float* __restrict__ acc,
                                                              const float* __restrict__ cam_loc, const float* __restrict__ ray_dirs,
-                                                             float* __restrict__ pts_rendered) {
+                                                             float* __restrict__ pts_rendered, const float* __restrict__ grad,
+                                                             float* __restrict__ normal, const uint8_t* __restrict__ ray_valid, float depth_fill) {
     const int lane = threadIdx.x & 63;
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= R) return;
     const float beta = *beta_p;
-    float carry = 0.f, W = 0.f, N = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    float carry = 0.f, W = 0.f, N = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
     for (int base = 0; base < SR; base += 64) {
         const int s = base + lane;
         float E = 0.f, zz = 0.f;
@@ -80,10 +81,22 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const float* __rest
                 c1 += w * colors[g * 3 + 1];
                 c2 += w * colors[g * 3 + 2];
             }
+            if (grad && valid[g]) {      // evaluation: normal_map = sum_j w_j g_j / |g_j| over the valid slots (pointneus_disent.py:797-815)
+                const float gx = grad[g * 3], gy = grad[g * 3 + 1], gz = grad[g * 3 + 2];
+                const float nrm = sqrtf((gx * gx + gy * gy) + gz * gz);
+                n0 += w * (gx / nrm);
+                n1 += w * (gy / nrm);
+                n2 += w * (gz / nrm);
+            }
         }
     }
     W = wave_sum(W);
     N = wave_sum(N);
+    if (grad) {
+        n0 = wave_sum(n0);
+        n1 = wave_sum(n1);
+        n2 = wave_sum(n2);
+    }
     if (colors) {               // colors == NULL: the weights-only form (spf_render_rgb composites later, behind the colour MLPs)
         c0 = wave_sum(c0);
         c1 = wave_sum(c1);
@@ -95,7 +108,13 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const float* __rest
             rgb[3 * r + 1] = c1;
             rgb[3 * r + 2] = c2;
         }
-        depth[r] = N / (W + 1e-8f);
+        // ray_valid (evaluation outputs): a ray without any neighbour keeps the reference's initial value of `depth` (pointneus_disent.py:822-826)
+        depth[r] = (ray_valid && !ray_valid[r]) ? depth_fill : N / (W + 1e-8f);
+        if (grad) {
+            normal[3 * r] = n0;
+            normal[3 * r + 1] = n1;
+            normal[3 * r + 2] = n2;
+        }
         const float dm = N / (W + 1e-10f);
         dist[r] = dm;
         acc[r] = W;
@@ -278,16 +297,18 @@ int spf_filter_points(const float* loc, const uint8_t* slot_valid, const float* 
 
 int spf_render_forward(const float* sdf, const uint8_t* slot_valid, const float* z, const float* deltas, const float* colors,
                        const float* beta, int32_t R, int32_t SR, float* weights, float* rgb, float* depth, float* dist, float* acc,
-                       const float* cam_loc, const float* ray_dirs, float* pts_rendered, void* stream) {
+                       const float* cam_loc, const float* ray_dirs, float* pts_rendered, const float* grad, float* normal, const uint8_t* ray_valid,
+                       float depth_fill, void* stream) {
     if (R < 0 || SR < 1 || SR > 64 * MAX_CH) return spf::fail(SPF_EINVAL, "spf_render_forward: need 1 <= SR <= %d", 64 * MAX_CH);
     if (R == 0) return SPF_OK;
     if (!sdf || !slot_valid || !z || !deltas || !beta || !weights || !depth || !dist || !acc)
         return spf::fail(SPF_EINVAL, "spf_render_forward: null pointer");
     if ((colors == nullptr) != (rgb == nullptr)) return spf::fail(SPF_EINVAL, "spf_render_forward: colors and rgb are given (or left out) together");
     if (pts_rendered && (!cam_loc || !ray_dirs)) return spf::fail(SPF_EINVAL, "spf_render_forward: pts_rendered needs cam_loc and ray_dirs");
+    if ((grad == nullptr) != (normal == nullptr)) return spf::fail(SPF_EINVAL, "spf_render_forward: grad and normal are given (or left out) together");
     render_forward_kernel<<<spf::div_up((long long)R * 64, 256), 256, 0, (hipStream_t)stream>>>(sdf, slot_valid, z, deltas, colors, beta, R,
                                                                                                  SR, weights, rgb, depth, dist, acc, cam_loc,
-                                                                                                 ray_dirs, pts_rendered);
+                                                                                                 ray_dirs, pts_rendered, grad, normal, ray_valid, depth_fill);
     SPF_LAUNCH_CHECK("render_forward_kernel");
     return SPF_OK;
 }

@@ -13,11 +13,13 @@ from . import ops
 
 
 class GraphedRenderer:
-    def __init__(self, model, n_rays, fast=-1):
-        """model: PointVolSDF in eval mode on a CUDA device; n_rays: rays per chunk (every call must bring exactly that many)."""
+    def __init__(self, model, n_rays, fast=-1, keys=None):
+        """model: PointVolSDF in eval mode on a CUDA device; n_rays: rays per chunk (every call must bring exactly that many).
+        keys: None = the reference's full output dict; a tuple out of ('rgb_values', 'depth_values', 'normal_map', 'weights') = only those
+        (PointVolSDF.eval_keys: what the reference's evaluation loops read — no pseudo-point pass, TV term or plot maps in the graph)."""
         if model.training:
             raise ValueError("GraphedRenderer renders in evaluation mode: call model.eval() first")
-        self.model, self.n_rays, self.fast = model, int(n_rays), fast
+        self.model, self.n_rays, self.fast, self.keys = model, int(n_rays), fast, (None if keys is None else tuple(keys))
         self.dev = model.neural_pts.device
         self._graph = None
         self._key = None
@@ -30,14 +32,18 @@ class GraphedRenderer:
         rng = torch.get_rng_state()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side), torch.no_grad():          # warm-up: cell table, caches, allocator pools (the CPU generator is restored)
-            for _ in range(2):
-                self.model(dict(self._in, local_data=None), fast=self.fast)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.set_rng_state(rng)
-        self._graph = torch.cuda.CUDAGraph()
-        with ops.capture_guard(), torch.no_grad(), torch.cuda.graph(self._graph):
-            self._out = self.model(dict(self._in, local_data=None), fast=self.fast)
+        prev, self.model.eval_keys = self.model.eval_keys, self.keys
+        try:
+            with torch.cuda.stream(side), torch.no_grad():          # warm-up: cell table, caches, allocator pools (the CPU generator is restored)
+                for _ in range(2):
+                    self.model(dict(self._in, local_data=None), fast=self.fast)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.set_rng_state(rng)
+            self._graph = torch.cuda.CUDAGraph()
+            with ops.capture_guard(), torch.no_grad(), torch.cuda.graph(self._graph):
+                self._out = self.model(dict(self._in, local_data=None), fast=self.fast)
+        finally:
+            self.model.eval_keys = prev
         torch.set_rng_state(rng)            # the captured forward drew from the CPU generator too (ray_sampler.py:562): only __call__'s draws count
         self._flags = self.model.ray_sampler._flags
         self._key = self.model.cache_key()
@@ -106,7 +112,11 @@ class ImageRenderer:
         """One chunk at the cursor: gather uv, forward, scatter, advance — every tensor op on the device, shapes static."""
         rows = torch.minimum(self._cursor + self._lane, self._last)         # a short last chunk repeats the last pixel
         uv = self._uv.index_select(1, rows)
-        out = self.model({"uv": uv, "pose": self._pose, "intrinsics": self._K, "local_data": None}, fast=self.fast)
+        prev, self.model.eval_keys = self.model.eval_keys, self.keys          # only what the image needs (PointVolSDF.eval_keys)
+        try:
+            out = self.model({"uv": uv, "pose": self._pose, "intrinsics": self._K, "local_data": None}, fast=self.fast)
+        finally:
+            self.model.eval_keys = prev
         for k in self.keys:
             self.out[k].index_copy_(0, rows, out[k].reshape(self.n_rays, -1))
         self._cursor.add_(self.n_rays)

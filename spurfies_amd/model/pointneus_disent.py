@@ -88,6 +88,10 @@ class PointVolSDF(nn.Module):
         self.keep_stages = False
         self.stages = None
         self.sync_free = False   # training only: static shapes, no host synchronisation (spurfies_amd/train.py sets it)
+        # evaluation only: None = every output of the reference's forward (:851-892); a tuple of keys out of ("rgb_values", "depth_values",
+        # "normal_map", "weights") = the render outputs the reference's evaluation loops read (train.py:419-424, eval_spurfies.py:282-287) and
+        # nothing else — no pseudo-point pass, TV term or per-slot plot maps, composites + normals + depth fill in ONE launch (eval_graph.py)
+        self.eval_keys = None
         self._cp_sync = ops.CompactSync()     # this model's own word buffers of the one-launch compaction, one per kNN pass
 
     # ------------------------------------------------------------------ initialisation (:116-205)
@@ -306,7 +310,7 @@ class PointVolSDF(nn.Module):
 
         # one launch for the ray set-up (None for multi-view batches); in sync-free training it also forms this forward's effective
         # Laplace scale |beta| + beta_min, which the sampler and the compositing kernels read (density.get_beta_value)
-        fuse_beta = self.sync_free and self.training and self.density.beta.is_cuda
+        fuse_beta = ((self.sync_free and self.training) or (not self.training and self.eval_keys is not None)) and self.density.beta.is_cuda
         beta_fwd = torch.empty((), dtype=torch.float32, device=dev) if fuse_beta else None
         smp = self.ray_sampler
         if (fuse_beta and fast == 1 and ops._FUSED_SAMPLER[0] and smp.draws is not None and smp.N_samples_extra > 0
@@ -400,11 +404,12 @@ class PointVolSDF(nn.Module):
         # evaluation needs no exact-size training buffers either: worst-case colour buffers + device-side counts, no host read-back
         dense = static or not self.training
         # the bool forms of the two masks are read by the reference-shaped outputs only (two conversion launches)
-        valid = None if static else q["slot_valid"].bool()        # [R,SR]  == reference `mask`
-        ray_mask = None if static else q["ray_valid"].bool()      # [R]
+        light = (not self.training) and self.eval_keys is not None
+        valid = None if (static or light) else q["slot_valid"].bool()        # [R,SR]  == reference `mask`
+        ray_mask = None if (static or light) else q["ray_valid"].bool()      # [R]
         sdf_buf = torch.empty((R * SR,), dtype=torch.float32, device=dev)
         grad_buf = torch.empty((R * SR, 3), dtype=torch.float32, device=dev)
-        fuse_filter = static and ops._FUSED_SAMPLER[0]            # filter_points (:207-239) rides in the compaction launch
+        fuse_filter = (static or not self.training) and ops._FUSED_SAMPLER[0]     # filter_points (:207-239) rides in the compaction launch
         pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(R * SR, k), fill_sdf=sdf_buf, fill_grad=grad_buf,
                                      sync=self._cp_sync.get("main", dev, R * SR), filt=(q["loc"], cam_loc, ray_dirs) if fuse_filter else None)
         point_slot = pl.point_slot
@@ -440,6 +445,11 @@ class PointVolSDF(nn.Module):
                 ev_w = br.record()
                 pr = self._sdf_points(pts_rendered, with_grad=True, role="pseudo")
         colors = colors.view(R, SR, 3)
+        if light:        # the evaluation loops' outputs and nothing else: composites, normals and the depth fill in one launch
+            weights, rgb, depth_values, normal_map = ops.render_eval(sdf, colors, self.density.get_beta_value(), q["slot_valid"], z_slots, deltas,
+                                                                     gradients, q["ray_valid"], depth_fill=1.0)
+            full = {"rgb_values": rgb, "depth_values": depth_values, "normal_map": normal_map, "weights": weights}
+            return {k_: full[k_] for k_ in self.eval_keys}
 
         # ---- density + compositing (:714-723, 765-795, 894-908), one HIP kernel each way --------------
         local_terms = None

@@ -820,7 +820,8 @@ class Render(torch.autograd.Function):
         with torch.cuda.device(dev), _prof.span("render_fwd", rays=R, slots=SR):
             _lib.check(_lib.lib().spf_render_forward(_lib.ptr(sdf_c), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), _lib.ptr(col_c),
                                                      _lib.ptr(beta_c), R, SR, _lib.ptr(weights), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(dist),
-                                                     _lib.ptr(acc), _lib.ptr(loc_c), _lib.ptr(dirs_c), _lib.ptr(pts), _lib.stream_ptr()), "spf_render_forward")
+                                                     _lib.ptr(acc), _lib.ptr(loc_c), _lib.ptr(dirs_c), _lib.ptr(pts), None, None, None, 0.0, _lib.stream_ptr()),
+                       "spf_render_forward")
         ctx.save_for_backward(sdf_c, col_c, beta_c, slot_valid, z, deltas, weights, dirs_c)
         ctx.with_pts = with_pts
         ctx.local = local
@@ -861,6 +862,25 @@ class Render(torch.autograd.Function):
         return g_sdf, g_col, (None if sink is not None else g_beta.reshape(())), None, None, None, None, None, None, None
 
 
+def render_eval(sdf, colors, beta, slot_valid, z, deltas, grad, ray_valid, depth_fill=1.0):
+    """The evaluation render's composites in one launch (no autograd): (weights [R,SR], rgb [R,3], depth_values [R,1] — `depth_fill` on rays
+    without a valid slot —, normal_map [R,3] = sum_j w_j grad_j / |grad_j|): pointneus_disent.py:714-723, 782-815, 822-826, 886-888."""
+    R, SR = sdf.shape
+    dev = sdf.device
+    weights = torch.empty((R, SR), dtype=torch.float32, device=dev)
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    normal = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    scratch = torch.empty((2, R), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _prof.span("render_fwd", rays=R, slots=SR):
+        _lib.check(_lib.lib().spf_render_forward(_lib.ptr(sdf.detach().contiguous()), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas),
+                                                 _lib.ptr(colors.detach().contiguous()), _lib.ptr(beta.detach().reshape(1).contiguous()), R, SR, _lib.ptr(weights),
+                                                 _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(scratch[0]), _lib.ptr(scratch[1]), None, None, None,
+                                                 _lib.ptr(grad.detach().contiguous()), _lib.ptr(normal), _lib.ptr(ray_valid), float(depth_fill), _lib.stream_ptr()),
+                   "spf_render_forward")
+    return weights, rgb, depth, normal
+
+
 class RenderW(torch.autograd.Function):
     """The part of `Render` that depends on the SDF alone: (weights [R,SR], depth [R,1], dist_map [R], acc [R,1], pts_rendered [R,3]) —
     spf_render_forward's weights-only form.  With `RenderRGB` behind the colour MLPs it replaces `Render` in a forked optimisation step:
@@ -882,7 +902,7 @@ class RenderW(torch.autograd.Function):
         with torch.cuda.device(dev), _prof.span("render_fwd", rays=R, slots=SR):
             _lib.check(_lib.lib().spf_render_forward(_lib.ptr(sdf_c), _lib.ptr(slot_valid), _lib.ptr(z), _lib.ptr(deltas), None, _lib.ptr(beta_c), R, SR,
                                                      _lib.ptr(weights), None, _lib.ptr(depth), _lib.ptr(dist), _lib.ptr(acc), _lib.ptr(loc_c),
-                                                     _lib.ptr(dirs_c), _lib.ptr(pts), _lib.stream_ptr()), "spf_render_forward")
+                                                     _lib.ptr(dirs_c), _lib.ptr(pts), None, None, None, 0.0, _lib.stream_ptr()), "spf_render_forward")
         ctx.save_for_backward(sdf_c, beta_c, slot_valid, z, deltas, weights, dirs_c)
         ctx.beta_param = beta_param.detach()
         ctx.beta_sink = _sink(beta_param)

@@ -56,7 +56,7 @@ def test_argument_validation_without_gpu(lib):
     assert b"arith" in lib.spf_last_error()
     assert lib.spf_wgrad(None, None, 256, 256, None, 16, None, 256, None, None, 0, 2, 0, 0, None) == -22 and b"arith" in lib.spf_last_error()
     assert lib.spf_wgrad(None, None, 104, 104, None, 16, None, 103, None, None, 0, 0, 39, 200, None) == -22 and b"col_rot" in lib.spf_last_error()
-    assert lib.spf_render_forward(None, None, None, None, None, None, 4, 1000, None, None, None, None, None, None, None, None, None) == -22
+    assert lib.spf_render_forward(None, None, None, None, None, None, 4, 1000, None, None, None, None, None, None, None, None, None, None, None, 1.0, None) == -22
     lib.spf_grid_destroy(h)
 
 

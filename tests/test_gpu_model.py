@@ -104,6 +104,31 @@ def test_eval_step_matches_reference_golden():
         np.testing.assert_allclose(out[k].detach().cpu().numpy(), fx[f"out.{k}"], err_msg=k, **OUT_TOL)      # measured: 5e-6 (tools/e2e_errors.py)
 
 
+def test_eval_keys_give_the_full_forwards_render_outputs():
+    """PointVolSDF.eval_keys (what the streamed evaluation renderers ask for: the outputs the reference's evaluation loops read,
+    train.py:419-424 / eval_spurfies.py:282-287) against the full reference-shaped evaluation forward on the same rays: rgb, depth and
+    weights bit for bit (same kernels, same order), normals to round-off (composited inside the render launch instead of by torch ops) —
+    and against the reference fixture itself."""
+    fx = load_golden("step_eval_r24.npz")
+    scene = scene_of(fx)
+    model = build_model(scene, train=False)
+    inp = inputs_of(fx, scene, device="cuda")
+    torch.manual_seed(int(fx["meta.seed"]) + 7)
+    with torch.no_grad():
+        full = model(inp, fast=-1)
+    model.eval_keys = ("rgb_values", "depth_values", "normal_map", "weights")
+    torch.manual_seed(int(fx["meta.seed"]) + 7)
+    with torch.no_grad():
+        light = model(inp, fast=-1)
+    model.eval_keys = None
+    assert set(light) == {"rgb_values", "depth_values", "normal_map", "weights"}
+    for k in ("rgb_values", "depth_values", "weights"):
+        assert torch.equal(light[k].reshape(full[k].shape), full[k]), k
+    np.testing.assert_allclose(light["normal_map"].cpu().numpy(), full["normal_map"].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for k in light:
+        np.testing.assert_allclose(light[k].cpu().numpy().reshape(fx[f"out.{k}"].shape), fx[f"out.{k}"], err_msg=k, **OUT_TOL)
+
+
 def test_sdf_eval_matches_reference_golden():
     fx = load_golden("sdf_eval_grid.npz")
     scene = scene_of(fx)
