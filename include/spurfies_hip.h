@@ -357,6 +357,56 @@ int spf_sampler_finish(const float* z_samples, int32_t Ns, const float* z_vals, 
                        int32_t Ne, float near, float far, const float* cam_loc, const float* ray_dirs, int32_t R,
                        float* z_out, float* points, const int32_t* flags, int32_t it, void* stream);
 
+/* ABI 6 — ONE ITERATION of the evaluation sampler loop (ErrorBoundSampler_pn.get_z_vals with fast = -1, ray_sampler.py:397-533) behind the
+ * geometry kernel's SDF-only launch over the iteration's NEW samples (spf_geo_forward with sdf == NULL), in two launches instead of ~14
+ * (point reduce, cat, gather, beta pass, two sampling passes with three output fills, finish, index cast, two point ops, hit slots):
+ *   phase 0  "test"  the iteration's SDF row sdf_cur [R,n]: entry k comes from the previous row (sdf_prev [R,n_prev]) or from the pair scratch
+ *                    of the new samples, selected by merged_idx [R,n] (index into cat(previous z, new samples); n_prev == 0: all new);
+ *                    beta [R] by bisection (ray_sampler.py:420-445); flags[it + 1] |= 1 if any ray's beta > beta0 (the convergence test :468).
+ *   phase 1  "step"  flags[it + 1] decides.  Set: N_more samples from the error-bound pdf (u_more), z_merged / merged_out [R, n + N_more] (sorted
+ *                    merge, :532-533) and points_new [R,N_more,3] = cam_loc + s ray_dirs, the next iteration's query points.  Clear: N_fin samples
+ *                    from the weight pdf (u_fin), then spf_sampler_finish's z_out / points_out [R, N_fin + 2 + Ne(,3)] and the main pass's slot
+ *                    assignment (slot_sample [R,SR], ray_valid [R] cleared: spf_grid_knn takes them) — and NaN in points_new.
+ *   phase 2  "last"  the last iteration the loop may take (it == max_total_iters - 1): phase 0's input stage, the full bisection, then phase
+ *                    1's final branch unconditionally (:434-445, no test).
+ * Every launch returns at once when flags[it] == 0 (the loop ended earlier); all shapes are static, nothing synchronises.  u_more / u_fin
+ * are shared by all rays (torch.linspace(0, 1, N), :509-511 in evaluation).  Same arithmetic, same order as the separate launches
+ * (tests/test_gpu_sampler.py compares them bit for bit). */
+typedef struct spf_sampler_eval_args {
+    const float* z;              /* [R,n] sorted depths of this iteration */
+    int32_t n, n_prev;
+    const float* sdf_prev;       /* [R,n_prev] (n_prev > 0) */
+    const int32_t* merged_idx;   /* [R,n] (n_prev > 0) */
+    const float* pair_tmp;       /* spf_geo_forward's per-pair scratch of the n - n_prev new samples per ray */
+    const int32_t* pair_off;
+    const int32_t* slot_point;   /* [R * (n - n_prev)] */
+    float* sdf_cur;              /* [R,n] written by phases 0 / 2, read by phase 1 */
+    float* beta;                 /* [R] in (it > 0) / out */
+    const float* beta0;          /* device scalar */
+    float eps, bound_coef, add_tiny;
+    int32_t beta_iters;
+    const float* u_more;
+    int32_t N_more;
+    const float* u_fin;
+    int32_t N_fin;
+    float* z_merged;
+    int32_t* merged_out;
+    float* points_new;
+    const int32_t* sel;          /* [Ne] extra samples of the current z (:541-547) */
+    int32_t Ne;
+    float near, far;
+    const float* cam_loc;
+    const float* ray_dirs;
+    float* z_out;
+    float* points_out;
+    int32_t SR;
+    int32_t* slot_sample;
+    uint8_t* ray_valid;
+    int32_t* flags;              /* [max_total_iters + 2], flags[0] = 1, the rest zero before the first iteration */
+    int32_t it;
+} spf_sampler_eval_args;
+int spf_sampler_eval(const spf_sampler_eval_args* args, const spf_grid* grid, int32_t R, int32_t phase, void* stream);
+
 /* ABI 5 — the optimisation step's sampler pass (ErrorBoundSampler_pn.get_z_vals with fast = 1: one iteration, final sampling; ray_sampler.py:
  * 377-574) behind the SDF kernel as ONE launch, wave per ray: (i) the per-sample SDF from the geometry kernel's per-pair scratch (spf_geo_forward
  * with sdf == NULL: pair_tmp, pair_off, slot_point [R*n] = point id of a sample or -1; 1000 where a sample has no neighbour), (ii) beta by

@@ -59,6 +59,17 @@ class LocalDesc(C.Structure):
                 ("n_src", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
 
 
+class SamplerEvalArgs(C.Structure):
+    """spf_sampler_eval_args"""
+    _fields_ = [("z", C.c_void_p), ("n", C.c_int32), ("n_prev", C.c_int32), ("sdf_prev", C.c_void_p), ("merged_idx", C.c_void_p), ("pair_tmp", C.c_void_p),
+                ("pair_off", C.c_void_p), ("slot_point", C.c_void_p), ("sdf_cur", C.c_void_p), ("beta", C.c_void_p), ("beta0", C.c_void_p),
+                ("eps", C.c_float), ("bound_coef", C.c_float), ("add_tiny", C.c_float), ("beta_iters", C.c_int32), ("u_more", C.c_void_p), ("N_more", C.c_int32),
+                ("u_fin", C.c_void_p), ("N_fin", C.c_int32), ("z_merged", C.c_void_p), ("merged_out", C.c_void_p), ("points_new", C.c_void_p),
+                ("sel", C.c_void_p), ("Ne", C.c_int32), ("near", C.c_float), ("far", C.c_float), ("cam_loc", C.c_void_p), ("ray_dirs", C.c_void_p),
+                ("z_out", C.c_void_p), ("points_out", C.c_void_p), ("SR", C.c_int32), ("slot_sample", C.c_void_p), ("ray_valid", C.c_void_p),
+                ("flags", C.c_void_p), ("it", C.c_int32)]
+
+
 SIGNATURES = {
     "spf_abi_version": (C.c_int, []),
     "spf_last_error": (C.c_char_p, []),
@@ -90,6 +101,7 @@ SIGNATURES = {
     "spf_rhead_backward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "spf_sampler_uniform": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
     "spf_sampler_iter": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "spf_sampler_eval": (C.c_int, [C.POINTER(SamplerEvalArgs), _P, _I, _I, _P]),
     "spf_sampler_finish": (C.c_int, [_P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _I, _P, _P, _P, _I, _P]),
     "spf_sampler_train": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _I, _P, _I, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "spf_filter_points": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),

@@ -83,9 +83,24 @@ struct SamplerTail {
     int SR;
     int32_t* slot_sample;         // [R, SR]
     uint8_t* ray_valid;           // [R] (cleared; the kNN kernel raises it)
+    // ---- evaluation loop (spf_sampler_eval): the iteration's SDF row is gathered from the previous row and the NEW samples' pair scratch
+    const float* sdf_prev;        // [R, n_prev] SDF of the previous iteration's z (NULL: first iteration)
+    const int32_t* merged_idx;    // [R, n] index of z[k] in cat(previous z, new samples) (NULL: identity)
+    int n_prev;                   // n - (number of new samples); pair_off / slot_point describe the new samples only
+    float* sdf_cur;               // [R, n] out: this iteration's SDF row (the next launch / iteration reads it)
+    const float* u_alt;           // MODE_EVAL_STEP: u / N of the FINAL branch (the kernel's u / N are the merging branch's)
+    int N_alt;
+    float* points_new;            // [R, N, 3] o + s d of the merging branch's new samples (the next iteration's query points)
 };
 
-template <int E, bool FUSED = false>
+// MODE: what surrounds the per-ray arithmetic
+constexpr int MODE_PLAIN = 0;       // sdf_in -> samples / merge (spf_sampler_iter)
+constexpr int MODE_TRAIN = 1;       // pair scratch -> final samples -> finish + hit slots (spf_sampler_train)
+constexpr int MODE_EVAL_TEST = 2;   // pair scratch + previous row -> sdf_cur, beta, convergence flag; nothing else
+constexpr int MODE_EVAL_STEP = 3;   // sdf_cur + beta; flags[it + 1] decides: merge (+ new points) | final samples -> finish + hit slots
+constexpr int MODE_EVAL_LAST = 4;   // pair scratch + previous row -> full bisection -> final samples -> finish + hit slots
+
+template <int E, int MODE = MODE_PLAIN>
 __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restrict__ z_in, const float* __restrict__ sdf_in,
                                                            const float* __restrict__ beta_in, const float* __restrict__ beta0_p, int R, int n,
                                                            float eps, float bound_coef, int beta_iters, int more, float add_tiny,
@@ -97,11 +112,27 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
     // Every pass of iteration `it` needs flags[it]; the sampling passes are additionally tied to the convergence test of the SAME iteration,
     // flags[it + 1] ("beta.max() > beta0", ray_sampler.py:468, set below by the beta-only pass): the merging pass runs iff it is set, the final
     // pass iff it is clear.  A pass whose turn it is not returns at once.
-    if (flags) {
+    constexpr bool FUSED = MODE == MODE_TRAIN || MODE == MODE_EVAL_TEST || MODE == MODE_EVAL_LAST;     // the input stage reads the pair scratch
+    if (MODE == MODE_EVAL_STEP) {
+        const bool reached = flags[it] != 0;
+        more = reached && flags[it + 1] != 0;
+        if (!more) {
+            // no further iteration (the loop ends here, or never got here): the NEXT iteration's neighbour search still runs over points_new
+            // (only its MLP work is gated off).  NaN is outside every cell, so that search costs nothing — stale points of an earlier
+            // replay would be searched in full.
+            const int r0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+            if (tail.points_new && r0 < R)
+                for (int m = (threadIdx.x & 63); m < 3 * N; m += 64) tail.points_new[(size_t)r0 * 3 * N + m] = __builtin_nanf("");
+            if (!reached) return;
+            u = tail.u_alt;
+            N = tail.N_alt;
+        }
+    } else if (flags) {
         bool live = flags[it] != 0;
         if (N > 0) live = live && ((flags[it + 1] != 0) == (more != 0));
         if (!live) return;
     }
+    const bool tailf = MODE == MODE_TRAIN || MODE == MODE_EVAL_LAST || (MODE == MODE_EVAL_STEP && !more);
     constexpr int NMAX = 64 * E;
     __shared__ float smem[4 * (3 * NMAX + 128)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -115,8 +146,12 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
         for (int k = lane; k < n; k += 64) {
             zs[k] = z_in[(size_t)r * n + k];
             if (FUSED) {          // geo_point_reduce_kernel's weighted mean of this sample's pairs (same order of additions)
-                const int p = tail.slot_point[(size_t)r * n + k];
+                // evaluation loop: z[k] is either a sample of an earlier iteration (its SDF is in the previous row) or one of this
+                // iteration's n - n_prev new samples (ray_sampler.py:405-410: gather(cat(sdf, new), samples_idx))
+                const int src = tail.merged_idx ? tail.merged_idx[(size_t)r * n + k] : k;
+                const int p = src < tail.n_prev ? -2 : tail.slot_point[(size_t)r * (n - tail.n_prev) + (src - tail.n_prev)];
                 float v = 1000.0f;                                    // pointneus_disent.py:371 filler
+                if (p == -2) v = tail.sdf_prev[(size_t)r * tail.n_prev + src];
                 if (p >= 0) {
                     const int q0 = tail.pair_off[p], q1 = tail.pair_off[p + 1];
                     float nrm = 0.f, acc = 0.f;
@@ -128,6 +163,7 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
                     v = acc / nrm;
                 }
                 ds[k] = v;
+                if (tail.sdf_cur) tail.sdf_cur[(size_t)r * n + k] = v;
             } else {
                 ds[k] = sdf_in[(size_t)r * n + k];
             }
@@ -205,6 +241,7 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
         beta_out[r] = beta;
         if (flags && N == 0 && beta > beta0) atomicOr(&flags[it + 1], 1);      // the beta-only pass is the convergence test: another iteration follows
     }
+    if (MODE == MODE_EVAL_TEST) return;
 
     // ---- pdf over the n-1 intervals with the final beta -------------------------------------------
     float p[E];
@@ -264,10 +301,14 @@ __global__ void __launch_bounds__(256) sampler_iter_kernel(const float* __restri
             if (denom < 1e-5f) denom = 1.f;
             const float t = (uu - cdf[below]) / denom;
             const float s = zs[below] + t * (zs[above] - zs[below]);
-            if (!FUSED) samples[(size_t)r * N + m] = s;
-            if (more || FUSED) sm[m] = s;
+            if (MODE == MODE_PLAIN) samples[(size_t)r * N + m] = s;
+            if (more || tailf) sm[m] = s;
+            if (MODE == MODE_EVAL_STEP && more) {       // the next iteration's query points (ray_sampler.py:401-402)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) tail.points_new[((size_t)r * N + m) * 3 + k] = tail.cam_loc[3 * r + k] + s * tail.ray_dirs[3 * r + k];
+            }
         }
-    if (FUSED) {
+    if (tailf) {
         // ---- sampler_finish_kernel: z_final = sort([samples | near | far | z[sel]]) by rank counting, points = o + z d -----------------
         __syncthreads();                                           // cdf is dead from here on: its LDS holds the candidates
         const int M = N + 2 + tail.Ne;
@@ -430,10 +471,54 @@ int spf_sampler_train(const float* z, const float* pair_tmp, const int32_t* pair
         !slot_sample || !ray_valid)
         return spf::fail(SPF_EINVAL, "spf_sampler_train: null pointer");
     if (grid->n_in == 0) return spf::fail(SPF_EINVAL, "spf_sampler_train: the grid holds no points");
-    SamplerTail t{pair_tmp, pair_off, slot_point, sel, Ne, near, far, cam_loc, ray_dirs, z_out, points, spf::dev_view(grid), SR, slot_sample, ray_valid};
-    sampler_iter_kernel<2, true><<<spf::div_up(R, 4), 256, 0, (hipStream_t)stream>>>(z, nullptr, nullptr, beta0, R, n, eps, bound_coef, beta_iters, 0, 0.f, u, 1, N,
-                                                                                     nullptr, beta_out, nullptr, nullptr, nullptr, 0, t);
+    SamplerTail t{pair_tmp, pair_off, slot_point, sel, Ne, near, far, cam_loc, ray_dirs, z_out, points, spf::dev_view(grid), SR, slot_sample, ray_valid,
+                  nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr};
+    sampler_iter_kernel<2, MODE_TRAIN><<<spf::div_up(R, 4), 256, 0, (hipStream_t)stream>>>(z, nullptr, nullptr, beta0, R, n, eps, bound_coef, beta_iters, 0, 0.f, u, 1,
+                                                                                           N, nullptr, beta_out, nullptr, nullptr, nullptr, 0, t);
     SPF_LAUNCH_CHECK("sampler_iter_kernel<fused>");
+    return SPF_OK;
+}
+
+int spf_sampler_eval(const spf_sampler_eval_args* a, const spf_grid* grid, int32_t R, int32_t phase, void* stream) {
+    if (!a) return spf::fail(SPF_EINVAL, "spf_sampler_eval: null arguments");
+    const int n = a->n, n_new = n - a->n_prev;
+    if (R < 0 || n < 2 || n > 640 || a->n_prev < 0 || n_new < 0 || phase < 0 || phase > 2 || a->it < 0 || a->it > 30)
+        return spf::fail(SPF_EINVAL, "spf_sampler_eval: need 2 <= n <= 640, 0 <= n_prev <= n, phase in {0, 1, 2}, 0 <= it <= 30");
+    if (R == 0) return SPF_OK;
+    if (!a->z || !a->sdf_cur || !a->beta || !a->beta0 || !a->flags) return spf::fail(SPF_EINVAL, "spf_sampler_eval: null z / sdf_cur / beta / beta0 / flags");
+    const bool gathers = phase != 1, finishes = phase != 0, merges = phase == 1;
+    if (gathers && (!a->pair_tmp || !a->pair_off || !a->slot_point || (a->n_prev > 0 && (!a->sdf_prev || !a->merged_idx))))
+        return spf::fail(SPF_EINVAL, "spf_sampler_eval: phases 0 / 2 need the pair scratch of the new samples and, with n_prev > 0, sdf_prev + merged_idx");
+    if (merges && (!a->u_more || a->N_more < 1 || a->N_more > 128 || n + a->N_more > 640 || !a->z_merged || !a->merged_out || !a->points_new || !a->cam_loc || !a->ray_dirs))
+        return spf::fail(SPF_EINVAL, "spf_sampler_eval: phase 1 needs u_more, 1 <= N_more <= 128, n + N_more <= 640, z_merged, merged_out, points_new, cam_loc, ray_dirs");
+    if (finishes) {
+        if (!a->u_fin || a->N_fin < 1 || a->Ne < 0 || a->N_fin + 2 + a->Ne > 128 || (a->Ne > 0 && !a->sel) || !a->cam_loc || !a->ray_dirs || !a->z_out || !a->points_out ||
+            !a->slot_sample || !a->ray_valid || a->SR < 1 || !grid)
+            return spf::fail(SPF_EINVAL, "spf_sampler_eval: phases 1 / 2 need u_fin, N_fin + 2 + Ne <= 128, sel, cam_loc, ray_dirs, z_out, points_out, slot_sample, ray_valid, SR, grid");
+        if (grid->n_in == 0) return spf::fail(SPF_EINVAL, "spf_sampler_eval: the grid holds no points");
+    }
+    SamplerTail t{a->pair_tmp, a->pair_off, a->slot_point, a->sel, a->Ne, a->near, a->far, a->cam_loc, a->ray_dirs, a->z_out, a->points_out,
+                  finishes ? spf::dev_view(grid) : GridDev{}, a->SR, a->slot_sample, a->ray_valid,
+                  a->sdf_prev, a->n_prev > 0 ? a->merged_idx : nullptr, a->n_prev, gathers ? a->sdf_cur : nullptr, a->u_fin, a->N_fin, a->points_new};
+    const int blocks = spf::div_up(R, 4);
+    hipStream_t s = (hipStream_t)stream;
+    const bool small = n <= 128;
+#define SPF_EVAL_LAUNCH(MODE, sdf_in, beta_in, iters, more, u, N, zm, mi)                                                                                       \
+    do {                                                                                                                                                        \
+        if (small)                                                                                                                                              \
+            sampler_iter_kernel<2, MODE><<<blocks, 256, 0, s>>>(a->z, sdf_in, beta_in, a->beta0, R, n, a->eps, a->bound_coef, iters, more, a->add_tiny, u, 0, N, \
+                                                                nullptr, a->beta, zm, mi, a->flags, a->it, t);                                                   \
+        else                                                                                                                                                    \
+            sampler_iter_kernel<10, MODE><<<blocks, 256, 0, s>>>(a->z, sdf_in, beta_in, a->beta0, R, n, a->eps, a->bound_coef, iters, more, a->add_tiny, u, 0, N, \
+                                                                 nullptr, a->beta, zm, mi, a->flags, a->it, t);                                                  \
+    } while (0)
+    // beta_in: the first iteration derives its starting beta from the sample spacing (ray_sampler.py:389-395), later ones continue from the last
+    const float* beta_in = a->it == 0 ? nullptr : a->beta;
+    if (phase == 0) SPF_EVAL_LAUNCH(MODE_EVAL_TEST, nullptr, beta_in, a->beta_iters, 0, nullptr, 0, nullptr, nullptr);
+    else if (phase == 1) SPF_EVAL_LAUNCH(MODE_EVAL_STEP, a->sdf_cur, a->beta, 0, 1, a->u_more, a->N_more, a->z_merged, a->merged_out);
+    else SPF_EVAL_LAUNCH(MODE_EVAL_LAST, nullptr, beta_in, a->beta_iters, 0, a->u_fin, a->N_fin, nullptr, nullptr);
+#undef SPF_EVAL_LAUNCH
+    SPF_LAUNCH_CHECK("sampler_iter_kernel<eval>");
     return SPF_OK;
 }
 

@@ -209,6 +209,17 @@ class PointVolSDF(nn.Module):
         """sdf_importance behind a device-side gate (int32 [1]; 0 = skip the MLP work): the sampler's sync-free evaluation loop."""
         return self._sdf_points(inputs, with_grad=False, gate=gate, role="sampler")["sdf"]
 
+    def sdf_pairs_gated(self, inputs, gate):
+        """The SDF pass of one evaluation-sampler iteration WITHOUT its per-point reduction: neighbour search, compaction and the geometry
+        kernel's per-pair scratch (ops.geo_forward(reduce=False)) -> (pair_tmp, PairList); the consumer (spf_sampler_eval) reduces."""
+        grid = self._grid()
+        x = inputs.detach().contiguous()
+        q = grid.query_dense(x.unsqueeze(1), self.conf.k, self.conf.r, 1)
+        pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(-1, self.conf.k), gate=gate, sync=self._cp_sync.get("sampler", x.device, x.shape[0]))
+        tmp = ops.geo_forward(x, pl, self.neural_pts, self.neural_feats_geometry.detach(), self._packed(), float(self.conf.rbf), with_grad=False,
+                              reduce=False)["pair_tmp"]
+        return tmp, pl
+
     def get_sdf_eval(self, inputs):
         """:249-298 — mesh-extraction entry."""
         return self._sdf_points(inputs, with_grad=False)["sdf"]
@@ -320,17 +331,19 @@ class PointVolSDF(nn.Module):
                 return out
         rays = ops.camera_rays(uv, pose, intrinsics, self.density.beta, self.density.beta_min_value, beta_fwd)
         self.density._beta_forward = beta_fwd if rays is not None else None
+        slots = None
         try:
             if rays is not None:
                 ray_dirs, cam_loc, depth_scale = rays
                 self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast, iter_step)
                 points = self.ray_sampler.last_points
+                slots = self.ray_sampler.last_slots          # the evaluation loop's last launch assigned the main pass's slots on its way
             else:
                 ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
                 dirs_cam, _ = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], intrinsics)
                 depth_scale = dirs_cam[0, :, 2:]
                 points, _, cam_loc, ray_dirs = self.get_importance_rays(cam_loc, ray_dirs, self, fast, iter_step)
-            return self.render_points(points, ray_dirs, cam_loc, depth_scale, input.get("local_data"))
+            return self.render_points(points, ray_dirs, cam_loc, depth_scale, input.get("local_data"), slots=slots)
         finally:
             self.density._beta_forward = None
 

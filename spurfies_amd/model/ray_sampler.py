@@ -69,6 +69,10 @@ class ErrorBoundSampler_pn(RaySampler):
         # evaluation mode: enqueue all iterations with device-side loop control instead of one host synchronisation per iteration
         # (spf_sampler_iter: flags / it); used when the model offers `sdf_importance_gated`.  False = the reference's host-side loop.
         self.device_loop = True
+        # ... and each iteration of that loop as TWO launches behind the SDF kernel (spf_sampler_eval: test, then merge | final + finish + the
+        # main pass's slot assignment) instead of ~14; False = the separate launches (tests compare both bit for bit)
+        self.fused_eval = True
+        self.last_slots = None      # (slot_sample int32 [R,SR], ray_valid uint8 [R]) of the main pass when the fused loop assigned them
         self.shard = None   # (rank, world) for ray-sharded batches: CPU-generator draws are made for the whole batch, this rank's rows kept
         self.draws = None   # sync-free / graph mode: {'t_rand' [R,128], 'u' [R,N_samples], 'sel' int32 [N_extra]} device tensors the
         #                     caller fills from the CPU generator (same calls, same order) before every step
@@ -111,9 +115,13 @@ class ErrorBoundSampler_pn(RaySampler):
         R = ray_dirs.shape[0]
         ray_dirs, cam_loc = ray_dirs.detach().contiguous(), cam_loc.detach().contiguous()
         max_total_iters = fast if fast >= 0 else self.max_total_iters
+        self.last_slots = None
         beta0 = (model.density.get_beta_value() if hasattr(model.density, "get_beta_value") else model.density.get_beta().detach()).reshape(1).contiguous()
         n0 = self.N_samples_eval
         if (not model.training and self.device_loop and max_total_iters > 1 and hasattr(model, "sdf_importance_gated") and ray_dirs.is_cuda):
+            if (self.fused_eval and hasattr(model, "sdf_pairs_gated") and self.N_samples_eval <= 128 and self.N_samples_eval * max_total_iters <= 640
+                    and self.N_samples + 2 + self.N_samples_extra <= 128):
+                return self._z_vals_device_loop_fused(ray_dirs, cam_loc, model, max_total_iters, beta0)
             return self._z_vals_device_loop(ray_dirs, cam_loc, model, max_total_iters, beta0)
         ext = self.draws if (self.draws is not None and model.training) else None
         if ext is not None:
@@ -172,7 +180,63 @@ class ErrorBoundSampler_pn(RaySampler):
         z_samples_eik = torch.gather(z_out, 1, idx.unsqueeze(-1))
         return z_out, z_samples_eik
 
-    # ------------------------------------------------------------------ evaluation: the same loop, controlled on the device
+    # ------------------------------------------------------------------ evaluation: the device-controlled loop, two launches per iteration
+    def _z_vals_device_loop_fused(self, ray_dirs, cam_loc, model, max_iters, beta0):
+        """_z_vals_device_loop with every iteration's sampler work in two launches (spf_sampler_eval) behind the neighbour search, the
+        compaction and the SDF-only geometry launch of the iteration's NEW samples: "test" (per-sample SDF from the pair scratch and the previous
+        row, beta bisection, the batch-wide convergence flag) and "step" (the flag decides: merge + next query points, or final samples +
+        finish + the main pass's slot assignment); the last allowed iteration is one launch.  Same values as the separate launches."""
+        from .. import ops
+
+        dev, R = ray_dirs.device, ray_dirs.shape[0]
+        n0, Nf, Ne = self.N_samples_eval, self.N_samples, self.N_samples_extra
+        key = ("flags", max_iters, str(dev))
+        if key not in self._lin:
+            t = torch.zeros((max_iters + 2,), dtype=torch.int32)
+            t[0] = 1
+            self._lin[key] = t.to(dev)
+        flags = self._lin[key].clone()
+        z_vals, points = ops.sampler_uniform(self._linspace(n0, dev), None, cam_loc, ray_dirs, self.near, self.far)
+        M, SR = Nf + 2 + Ne, int(model.conf.max_shading_pts)
+        z_out = torch.empty((R, M), dtype=torch.float32, device=dev)
+        pts_out = torch.empty((R, M, 3), dtype=torch.float32, device=dev)
+        slot_sample = torch.empty((R, SR), dtype=torch.int32, device=dev)
+        ray_valid = torch.empty((R,), dtype=torch.uint8, device=dev)
+        beta = torch.empty((R,), dtype=torch.float32, device=dev)
+        grid_h = model._grid()._h
+        common = dict(beta=beta, beta0=beta0, eps=self.eps, bound_coef=self._bound_coef, add_tiny=self.add_tiny, beta_iters=self.beta_iters,
+                      u_more=self._linspace(n0, dev), N_more=n0, u_fin=self._linspace(Nf, dev), N_fin=Nf, Ne=Ne, near=self.near, far=self.far,
+                      cam_loc=cam_loc, ray_dirs=ray_dirs, z_out=z_out, points_out=pts_out, SR=SR, slot_sample=slot_sample, ray_valid=ray_valid, flags=flags)
+        sdf_prev, merged, n_prev = None, None, 0
+        for it in range(max_iters):
+            n = z_vals.shape[1]
+            with torch.no_grad():
+                tmp, pl = model.sdf_pairs_gated(points.view(-1, 3), flags[it: it + 1])
+            skey = ("sel", n, Ne, str(dev))
+            if Ne > 0 and skey not in self._lin:
+                self._lin[skey] = torch.linspace(0, n - 1, Ne).long().to(torch.int32).to(dev)
+            sdf_cur = torch.empty((R, n), dtype=torch.float32, device=dev)
+            args = dict(common, z=z_vals, n=n, n_prev=n_prev, sdf_prev=sdf_prev, merged_idx=merged, pair_tmp=tmp, pair_off=pl.pair_off,
+                        slot_point=pl.slot_point, sdf_cur=sdf_cur, sel=self._lin[skey] if Ne > 0 else None, it=it)
+            if it < max_iters - 1:
+                zm = torch.empty((R, n + n0), dtype=torch.float32, device=dev)
+                mi = torch.empty((R, n + n0), dtype=torch.int32, device=dev)
+                pn = torch.empty((R, n0, 3), dtype=torch.float32, device=dev)
+                args.update(z_merged=zm, merged_out=mi, points_new=pn)
+                ops.sampler_eval(0, grid_h, R, **args)
+                ops.sampler_eval(1, grid_h, R, **args)
+                sdf_prev, merged, n_prev, z_vals, points = sdf_cur, mi, n, zm, pn
+            else:
+                ops.sampler_eval(2, grid_h, R, **args)
+        self._flags = (flags, max_iters)
+        self.last_points = pts_out
+        self.last_slots = (slot_sample, ray_valid)
+        if torch.cuda.is_current_stream_capturing():         # hipGraph capture (eval_graph.py): the CPU-generator draw below is the replayer's job
+            return z_out, None
+        idx = torch.randint(z_out.shape[-1], (z_out.shape[0],)).to(dev)       # the eikonal sample (:562-563) consumes the generator as the reference
+        return z_out, torch.gather(z_out, 1, idx.unsqueeze(-1))
+
+    # ------------------------------------------------------------------ evaluation: the same loop as separate launches
     def _z_vals_device_loop(self, ray_dirs, cam_loc, model, max_iters, beta0):
         """get_z_vals for evaluation (:377-574, no random draws) WITHOUT the host-side convergence test of :468.  The iteration count is
         data-dependent but every iteration's shapes are static (128 (it + 1) samples per ray), so all `max_iters` iterations are enqueued and

@@ -1013,6 +1013,21 @@ def sampler_train(z, pair_tmp, pl, beta0, eps, bound_coef, beta_iters, u, sel, n
     return beta, z_out, pts, slot_sample, ray_valid
 
 
+def sampler_eval(phase, grid_handle, R, **kw):
+    """One launch of the evaluation sampler loop's iteration (include/spurfies_hip.h: spf_sampler_eval; phase 0 = test, 1 = step, 2 = last).
+    kw: the fields of spf_sampler_eval_args — tensors (or None) for the pointers, numbers for the rest."""
+    a = _lib.SamplerEvalArgs()
+    dev = kw["z"].device
+    for name, ctype in _lib.SamplerEvalArgs._fields_:
+        v = kw.get(name)
+        if ctype is ctypes.c_void_p:
+            setattr(a, name, None if v is None else v.data_ptr())
+        elif v is not None:
+            setattr(a, name, v)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().spf_sampler_eval(ctypes.byref(a), grid_handle, int(R), int(phase), _lib.stream_ptr()), "spf_sampler_eval")
+
+
 def sampler_finish(z_samples, z_vals, sel, near, far, cam_loc, ray_dirs, flags=None, it=0, out=None):
     """flags / it: runs only behind the final sampling pass of iteration `it` (spf_sampler_iter); out = (z_out, points) to write into."""
     R, Ns = z_samples.shape

@@ -93,19 +93,25 @@ def test_device_controlled_eval_loop_equals_the_host_controlled_loop(prior, expe
            "pose": torch.from_numpy(scene["poses"][1])[None].cuda(), "local_data": None}
     res = {}
     with torch.no_grad():
-        for device_loop in (False, True):
-            model.ray_sampler.device_loop = device_loop
+        # host-controlled loop; device-controlled loop as separate launches; device-controlled loop with two launches per iteration
+        # (spf_sampler_eval: per-sample SDF from the pair scratch + the previous row, test, then merge | final + finish + slot assignment)
+        for name, device_loop, fused in (("host", False, False), ("device", True, False), ("fused", True, True)):
+            model.ray_sampler.device_loop, model.ray_sampler.fused_eval = device_loop, fused
             torch.manual_seed(4)
             out = model(dict(inp), fast=-1)
-            res[device_loop] = ({k: out[k].clone() for k in ("rgb_values", "depth_values", "normal_map", "weights")},
-                                model.ray_sampler.last_points.clone(), model.ray_sampler.last_iters)
-    (o0, p0, it0), (o1, p1, it1) = res[False], res[True]
-    assert it0 == it1 and 1 <= it0 <= 5, (it0, it1)
-    assert (it0 == 5) == expect_all, (prior, it0)
+            assert (model.ray_sampler.last_slots is not None) == fused
+            res[name] = ({k: out[k].clone() for k in ("rgb_values", "depth_values", "normal_map", "weights")},
+                         model.ray_sampler.last_points.clone(), model.ray_sampler.last_iters, torch.rand(1).item())
+    (o0, p0, it0, a0) = res["host"]
     same = lambda a, b: torch.allclose(a, b, rtol=0.0, atol=0.0, equal_nan=True)      # bit-identical; a ray that never meets the shell holds NaN depths in both
-    assert same(p0, p1), "main-pass sample positions must be identical"
-    for k in o0:      # the colour path sums its weighted mean with float atomics: rendered values agree to that run-to-run noise
-        assert torch.allclose(o0[k], o1[k], rtol=1e-4, atol=1e-6, equal_nan=True), k
+    assert (it0 == 5) == expect_all, (prior, it0)
+    for name in ("device", "fused"):
+        o1, p1, it1, a1 = res[name]
+        assert it0 == it1 and 1 <= it0 <= 5, (name, it0, it1)
+        assert a0 == a1, "the CPU generator advances alike"
+        assert same(p0, p1), f"{name}: main-pass sample positions must be identical"
+        for k in o0:      # the colour path sums its weighted mean with float atomics: rendered values agree to that run-to-run noise
+            assert torch.allclose(o0[k], o1[k], rtol=1e-4, atol=1e-6, equal_nan=True), (name, k)
     assert float(o0["weights"].sum()) > 0
 
 
