@@ -278,6 +278,48 @@ def eval_cpu_baseline(scene, n_rays):
             "sample": f"one evaluation render of {n_rays} rays (fast=-1) on the same scene, {dt:.1f} s on {cores} threads", "sampler_iterations": iters}
 
 
+def eval_chunk_record(args, device, scene, steps=20, warmup=5):
+    """`extra` record of the default N = 1 line: the evaluation render (PointVolSDF.forward(fast=-1) under no_grad: the full error-bounded
+    sampler + main pass with normals + colour + compositing; train.py:399-433 / eval_spurfies.py:276-292 chunks) of --rays-pixel chunks on the
+    main record's scene, replayed as one hipGraph per chunk with the outputs those loops read (eval_graph.GraphedRenderer(keys=...))."""
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.conf import default_model_conf
+    from spurfies_amd.eval_graph import GraphedRenderer
+    from spurfies_amd.model.pointneus_disent import PointVolSDF
+
+    st = scene["state"]
+    model = PointVolSDF(default_model_conf(near=0.5, grid_ranges=list(scene["ranges"])), 24, "dtu",
+                        neural_points={"pts": st["neural_pts"], "colors": scene["colors"]}, device=device)
+    model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
+    model.eval()
+    g = torch.Generator().manual_seed(777)
+    K = torch.from_numpy(scene["intrinsics"])[None].to(device)
+    batches = [{"intrinsics": K, "uv": torch.from_numpy(syn.make_pixels(args.rays, g))[None].to(device),
+                "pose": torch.from_numpy(scene["poses"][i % len(scene["poses"])])[None].to(device)} for i in range(8)]
+    render = GraphedRenderer(model, args.rays, keys=("rgb_values", "depth_values", "normal_map"))
+    iters = []
+    with torch.no_grad():
+        for i in range(warmup):
+            render(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            render(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        for i in range(3):                       # realised sampler iterations: read back outside the timed region (one small copy per chunk)
+            render(batches[i % len(batches)])
+            iters.append(model.ray_sampler.last_iters)
+    samples = args.rays * (128 * float(np.mean(iters)) + 98)
+    return {"record": "evaluation render: one hipGraph replay per chunk, outputs rgb_values / depth_values / normal_map (what train.py:419-424 and eval_spurfies.py:282-287 read)",
+            "metric": "ray-samples/sec (kNN+SDF+render, evaluation render fast=-1)", "value": samples * steps / dt, "unit": "ray-samples/s", "n_gpus": 1, "steps": steps,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "scaling": "weak",
+            "config": {"workload": f"evaluation render of {args.rays}-ray chunks on the main record's scene ({args.points} neural points): full error-bounded sampler "
+                                   "(up to 5 iterations of 128 samples per ray) + 98 main samples per ray, SDF + normals + colour + compositing, no_grad",
+                       "mode": "eval", "rays_per_gpu": args.rays, "sampler_iterations_realised": {"mean": float(np.mean(iters)), "min": int(min(iters)), "max": int(max(iters))},
+                       "rays_per_s": args.rays * steps / dt}}
+
+
 def main_eval(args):
     """--mode eval: a step = one evaluation-render chunk of --rays rays per GPU; no collective (chunks of an image are independent)."""
     from spurfies_amd import ops
@@ -793,7 +835,7 @@ def main():
             os._exit(code)
 
     limit = float(os.environ.get("SPF_EXTRAS_TIMEOUT", "300"))
-    timer = threading.Timer(limit, abandon) if (extras and limit > 0) else None
+    timer = threading.Timer(limit, abandon) if ((extras or want_local) and limit > 0) else None
     if timer is not None:
         timer.daemon = True
         timer.start()
@@ -813,6 +855,14 @@ def main():
         res["extra"].append(keep)
         if w["local"]:
             res["ms_per_step_with_local"] = r["ms_per_step"]
+    if want_local and args.scenes == 1 and world == 1:      # (same switch: the N = 1 line's second short record)
+        try:
+            res["extra"].append(eval_chunk_record(args, device, scene))
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            print(f"[bench] the evaluation-chunk record failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+            res["extra"].append({"record": "evaluation render", "error": repr(e)[:400]})
     if timer is not None:
         timer.cancel()
     if rank == 0:

@@ -1127,7 +1127,7 @@ __device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
 template <bool WITH_JAC, int NT>
 __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                              const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off,
-                                             const int32_t* __restrict__ pair_point, const int NP, int k, const float* __restrict__ pts,
+                                             const int32_t* __restrict__ pair_point, const int NP, const int q0, int k, const float* __restrict__ pts,
                                              const float* __restrict__ feat_geo, const float* packed, float rbf, float* __restrict__ pair_tmp,
                                              float* __restrict__ jac) {
     constexpr int ROWS = 32 * NT;
@@ -1143,7 +1143,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         if ((tid >> 2) < ROWS && q < NP) {
             const int p = pair_point[q];
             srow = point_slot ? point_slot[p] : p;
-            idx = nbr[(size_t)srow * k + (q - pair_off[p])];
+            idx = nbr[(size_t)srow * k + (q + q0 - pair_off[p])];
         }
         cur = gx_fetch_row(idx, srow, tid & 3, x, pts, feat_geo);
     }
@@ -1225,7 +1225,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
-        if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
+        if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn + q0 - n_off)];
         bias = load_bias3(pf + OFF_B3, wave, lane);
 #if SPF_LEAN_EPILOGUE && SPF_LEAN_BIASC
         bias_cinit(bias, ci);
@@ -1333,10 +1333,24 @@ geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
     __shared__ float red[4][64];
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
     CLK_DECL
-    if (NP <= 32 * (int)gridDim.x)      // everything fits one pass of half-height tiles
-        geo_x3w_body<WITH_JAC, 1>(X, red, x, nbr, point_slot, pair_off, pair_point, NP, k, pts, feat_geo, packed, rbf, pair_tmp, jac);
-    else
-        geo_x3w_body<WITH_JAC, 2>(X, red, x, nbr, point_slot, pair_off, pair_point, NP, k, pts, feat_geo, packed, rbf, pair_tmp, jac);
+    // Whole rounds of 64-pair tiles first (every workgroup one tile per round); what is left — less than one round — as HALF-HEIGHT tiles
+    // when that is at most one per workgroup (a half tile takes ~55 % of a full one's time), else as full tiles.  A 128-ray step's main pass
+    // (49 k pairs = 770 tiles on 256 workgroups) was 3.01 rounds paid as 4; it is 3 rounds + one half-tile pass now.  The body sees the
+    // remainder through shifted pair arrays (q0 = its first pair: only the neighbour-column lookup needs the absolute pair number).
+    const int G = (int)gridDim.x;
+    const int q_full = (NP / (64 * G)) * (64 * G), rem = NP - q_full;
+    if (q_full > 0)
+        geo_x3w_body<WITH_JAC, 2>(X, red, x, nbr, point_slot, pair_off, pair_point, q_full, 0, k, pts, feat_geo, packed, rbf, pair_tmp, jac);
+    if (rem > 0) {
+        const int32_t* pp = pair_point + q_full;
+        float* pt = pair_tmp + (size_t)q_full * PT_STRIDE;
+        float* jc = jac ? jac + (size_t)q_full * SPF_GEO_DIM : nullptr;
+        if (q_full > 0) lds_barrier();          // (the first body's last tile is done with the planes)
+        if (rem <= 32 * G)
+            geo_x3w_body<WITH_JAC, 1>(X, red, x, nbr, point_slot, pair_off, pp, rem, q_full, k, pts, feat_geo, packed, rbf, pt, jc);
+        else
+            geo_x3w_body<WITH_JAC, 2>(X, red, x, nbr, point_slot, pair_off, pp, rem, q_full, k, pts, feat_geo, packed, rbf, pt, jc);
+    }
     CLK_FLUSH(1, WITH_JAC ? 1 : 0)
 }
 

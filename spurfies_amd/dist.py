@@ -27,8 +27,10 @@ def shard_rays(n_rays: int, group=None) -> torch.Tensor:
     return torch.arange(rank(group), n_rays, world_size(group))
 
 
-def all_reduce_sum(t: torch.Tensor, group=None):
-    if world_size(group) > 1:
+def all_reduce_sum(t: torch.Tensor, group=None, force=False):
+    """force: issue the collective even on a communicator of one (a sum over one rank: the values stay) — how a one-GPU box exercises the
+    step's collectives on RCCL's own stream (TrainStep(force_collectives=True))."""
+    if world_size(group) > 1 or (force and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -93,9 +95,10 @@ class BucketedAllReduce:
         geo_latents                              last (TV, pseudo-point and main-pass scatters all add into it) -> finish()
     Summation order inside a bucket is RCCL's; the result is the same sum as the single flat all-reduce."""
 
-    def __init__(self, flat: FlatGrads, names, group=None):
-        """names: parameter names in flat.params order (model.named_parameters() of the trainable tensors)."""
-        self.flat, self.group = flat, group
+    def __init__(self, flat: FlatGrads, names, group=None, force=False):
+        """names: parameter names in flat.params order (model.named_parameters() of the trainable tensors).
+        force: reduce also on a communicator of one (see all_reduce_sum)."""
+        self.flat, self.group, self.force = flat, group, bool(force)
         assert len(names) == len(flat.params)
         ranges = {}
         off = 0
@@ -136,7 +139,7 @@ class BucketedAllReduce:
         self.armed = bool(armed)
 
     def ready(self, name):
-        if world_size(self.group) == 1 or name in self._done or name not in self.ranges:
+        if (world_size(self.group) == 1 and not self.force) or name in self._done or name not in self.ranges:
             return
         self._done.add(name)
         self.log.append(name)
@@ -182,7 +185,7 @@ def fused_counts(out):
     return torch.stack([torch.full((), float(out["rgb_values"].shape[0]), device=dev), f["n_points"][0].float(), cnt, lcnt])
 
 
-def sharded_loss(loss_mod, out, ground_truth, group=None, reduce=True):
+def sharded_loss(loss_mod, out, ground_truth, group=None, reduce=True, force=False):
     """VolSDFLoss (spurfies/model/loss.py:51-101) on one rank's rays with GLOBAL normalisers.
 
     reduce=False: the counts stay this rank's own (no collective is issued) — for passes whose result is thrown away (graph warm-up /
@@ -196,7 +199,7 @@ def sharded_loss(loss_mod, out, ground_truth, group=None, reduce=True):
     if "_fused" in out:                          # sync-free mode: fused loss kernels with the all-reduced counts as normalisers
         counts = fused_counts(out)
         if reduce:
-            all_reduce_sum(counts, group)
+            all_reduce_sum(counts, group, force)
         return loss_mod.fused_forward(out, ground_truth, denom=counts, world=G)
     rgb_gt = ground_truth["rgb"].to(dev).reshape(-1, 3)
     mask_gt = ground_truth["mask"].to(dev).squeeze()[:, 0][..., None]
@@ -208,7 +211,7 @@ def sharded_loss(loss_mod, out, ground_truth, group=None, reduce=True):
     lcnt = out["local_count"] if "local_count" in out else torch.zeros((), device=dev)
     counts = torch.stack([torch.full((), float(R_loc), device=dev), P_loc, pseudo_cnt.float(), lcnt])
     if reduce:
-        all_reduce_sum(counts, group)
+        all_reduce_sum(counts, group, force)
     R_tot, P_tot, ps_tot = counts[0], counts[1].clamp(min=1), counts[2]
     zero = torch.zeros((), device=dev)
     res = {"rgb_loss": (out["rgb_values"] - rgb_gt).abs().sum() / (3.0 * R_tot)}

@@ -395,7 +395,7 @@ class PointVolSDF(nn.Module):
         R = ray_dirs.shape[0]
 
         static = self.sync_free and self.training                 # fused-loss mode of the optimisation step
-        # forked step (ops.branch; TrainStep(fork=True), the default of graph-replayed steps): passes that do not depend on each other are
+        # forked step (ops.branch; TrainStep(fork=True) — experimental, OFF by default: measured +-1 % on ROCm 7.2): passes that do not depend on each other are
         # issued on side streams = parallel branches of the step's hipGraph.  Branch "aux": the two weight-packing launches (they only read
         # the parameters) and the TV term, beside the main pass's kNN / geometry kernel.
         if not self.training:

@@ -1461,16 +1461,19 @@ class FusedLoss(_GradModeFunction):
         if local is not None and denom is not None and denom.numel() < 4:
             raise ValueError("FusedLoss(local=...): denom needs the global local count as its fourth entry (dist.fused_counts)")
         defer = bool(allow_defer) and _DEFER_LOSS[0] and _GradModeFunction._outer_grad_mode and any(ctx.needs_input_grad[:4])
+        # deferred: the partial sums must survive until THIS call's backward — a buffer of their own (2048 floats; a second forward under the
+        # same owner before the first backward would otherwise overwrite them: round-5 advisor finding), not the per-owner scratch
+        ws = torch.empty_like(_loss_ws[key]) if defer else _loss_ws[key]
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_loss_forward(_lib.ptr(rgb_c), _lib.ptr(rgb_gt), _lib.ptr(acc_c), _lib.ptr(mask_gt), mask_stride,
                                                    _lib.ptr(grad), _lib.ptr(slot_valid), rows, _lib.ptr(n_points), _lib.ptr(psdf_c),
                                                    _lib.ptr(pvalid), _lib.ptr(ray_valid), _lib.ptr(tv_c), n_tv, _lib.ptr(denom), R, weights,
-                                                   _lib.ptr(_loss_ws[key]), None if defer else _lib.ptr(total), None if defer else _lib.ptr(terms),
+                                                   _lib.ptr(ws), None if defer else _lib.ptr(total), None if defer else _lib.ptr(terms),
                                                    None if defer else _lib.ptr(den), None if local is None else local.args(), _lib.stream_ptr()),
                        "spf_loss_forward")
         ctx.save_for_backward(rgb_c, acc_c, psdf_c, rgb_gt, mask_gt, pvalid, ray_valid, den)
         ctx.misc = (mask_stride, weights, acc.shape, None if psdf is None else psdf.shape, tv is not None, n_tv)
-        ctx.fin = (_loss_ws[key], rows, n_points, tv_c, denom, total, terms) if defer else None
+        ctx.fin = (ws, rows, n_points, tv_c, denom, total, terms) if defer else None
         ctx.local = local
         ctx.tv_ctx = None
         if tv_ctx is not None:

@@ -26,7 +26,7 @@ class TrainStep:
     N_STAGING = 4            # pinned staging buffers for the CPU-generator draws (sync-free steps run ahead of the GPU)
 
     def __init__(self, model, loss=None, lr=5.0e-4, grad_clip=True, process_group=None, sync_free=False, use_graph=False, draws="batch", keep_grads=False,
-                 fork=None):
+                 fork=None, force_collectives=False):
         """sync_free: static shapes and device-side counts everywhere — no host synchronisation inside the step (the
         default path reads [P, n_pairs] back once per step to size the colour buffers exactly).
         use_graph (implies sync_free): forward + loss + backward (~50 kernel launches) are captured once into a hipGraph
@@ -40,6 +40,10 @@ class TrainStep:
         graph is within +-1 % of the single-stream one (0.965 vs 0.957 ms) and LOSES when several scenes' graphs already share the chip
         (11 scenes: 9.4 vs 8.3 ms per round) — what did pay was folding the independent small launches into launches that exist anyway."""
         self.model = model
+        # force_collectives (tests / bench on a one-GPU box): with an initialised process group of ONE rank the step still issues everything a
+        # ray-sharded step issues — the 16-byte count all-reduce, the bucketed async all-reduces + finish() (eager) or the two-graph form with
+        # the dense all-reduce (use_graph) — so that the step's stream semantics run on RCCL itself; the sums over one rank change nothing.
+        self.force_collectives = bool(force_collectives)
         self.fork = bool(fork) if fork is not None else False
         sync_free = sync_free or use_graph
         self.sync_free = sync_free
@@ -70,13 +74,14 @@ class TrainStep:
         self.draw_world = self.world if draws == "batch" else 1
         model.ray_sampler.shard = (self.rank, self.world) if self.draw_world > 1 else None
         self.buckets = None
-        if self.world > 1:
+        self.collective = self.world > 1 or self.force_collectives
+        if self.collective:
             # the all-reduce sums gradients only: replicas must START identical (latents and MLPs are drawn from the local
             # generators in the constructors).  Rank 0's parameters, frozen prior and cloud win.
             sdist.broadcast_model(model, self.optimizer, process_group)
             if sync_free:      # gradients go straight into the flat buffer: bucket by bucket, each all-reduced as soon as it is final
                 names = [n for n, p in model.named_parameters() if p.requires_grad]
-                self.buckets = sdist.BucketedAllReduce(self.flat, names, process_group)
+                self.buckets = sdist.BucketedAllReduce(self.flat, names, process_group, force=self.force_collectives)
         self.iter_step = 0
         self.skipped = 0
         # sync-free steps: the Adam sweep clears the flat gradient buffer behind itself (the next step's optimizer.zero_grad(), train.py:357,
@@ -95,14 +100,14 @@ class TrainStep:
             losses, out = self._graphed_forward_backward(model_input, ground_truth)
         else:
             losses, out = self._forward_backward(model_input, ground_truth, reduce_buckets=True)
-        if self.world > 1:
+        if self.collective:
             if self.buckets is not None and self.buckets.armed:
                 # the backward that just ran had the bucket hooks (eager sync-free step): reduce the buckets nobody announced (geometry
                 # latents: last), then wait for all of them — never a second, dense reduce on top (that summed three buckets twice:
                 # round-3 advisor finding)
                 self.buckets.finish()
             else:
-                sdist.all_reduce_sum(self.flat.buffer, self.group)
+                sdist.all_reduce_sum(self.flat.buffer, self.group, self.force_collectives)
         # train.py:359-363, 548-564 — clip_grad_norm_(1.0), skip the update when a gradient is not finite, Adam: one fused
         # device-side sequence (spurfies_amd/optim.py), no sync
         self.optimizer.step(max_norm=1.0 if self.grad_clip else 0.0, zero_grads=self.zero_in_adam)
@@ -133,8 +138,8 @@ class TrainStep:
         if self.sync_free:
             self._refresh_draws(model_input["uv"].shape[1], model_input["uv"].device)
         out = self.model(model_input, fast=1)
-        if self.world > 1:
-            losses = sdist.sharded_loss(self.loss, out, ground_truth, self.group, reduce=collectives)
+        if self.collective:
+            losses = sdist.sharded_loss(self.loss, out, ground_truth, self.group, reduce=collectives, force=self.force_collectives)
         else:
             losses = self.loss(out, ground_truth)
         if not self._grads_clean:                                               # else: cleared by the previous step's Adam sweep
@@ -224,7 +229,7 @@ class TrainStep:
             torch.set_rng_state(rng)
             self._graph = torch.cuda.CUDAGraph()
             self._graph_tail, self._counts = None, None
-            if self.world == 1:
+            if not self.collective:
                 ops.drop_pending_wgrad()
                 with ops.capture_guard(), torch.cuda.graph(self._graph):
                     out = self.model(dict(self._static_in, local_data=static_local, iter_step=0), fast=1)
@@ -275,7 +280,7 @@ class TrainStep:
         self._grads_clean = False
         self._graph.replay()
         if self._graph_tail is not None:
-            sdist.all_reduce_sum(self._counts, self.group)
+            sdist.all_reduce_sum(self._counts, self.group, self.force_collectives)
             self._graph_tail.replay()
         return self._static_out
 
@@ -286,14 +291,33 @@ class TrainStep:
         VolOpt.save_checkpoints in the same layout) restart the schedule and the generator; with this blob a resumed run takes the same
         steps the uninterrupted one would have — bit for bit under ops.set_scatter_mode("fixed") (tools/soak.py, tests/test_gpu_model.py)."""
         return {"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
-                "scheduler_state_dict": self.scheduler.state_dict(), "iter_step": self.iter_step, "cpu_rng_state": torch.get_rng_state()}
+                "scheduler_state_dict": self.scheduler.state_dict(), "iter_step": self.iter_step, "cpu_rng_state": torch.get_rng_state(),
+                "loss_iter_step": int(self.loss.iter_step), "skipped": int(self.skipped)}
 
     def load_state_dict(self, blob):
         self.model.load_state_dict(blob["model_state_dict"])
         self.optimizer.load_state_dict(blob["optimizer_state_dict"])
         self.scheduler.load_state_dict(blob["scheduler_state_dict"])
         self.iter_step = int(blob["iter_step"])
-        torch.set_rng_state(blob["cpu_rng_state"].cpu())        # torch.load(map_location=device) moves it
+        self.loss.iter_step = int(blob.get("loss_iter_step", blob["iter_step"]))
+        self.skipped = int(blob.get("skipped", 0))
+        self._draws = None                                      # staged draws of the abandoned trajectory are not reused
+        rng = blob["cpu_rng_state"].cpu()                       # torch.load(map_location=device) moves it
+        if self.world > 1:
+            # replicas must continue with ONE generator stream and one step count: rank 0's blob wins; a rank that loaded a different one is told
+            import torch.distributed as tdist
+
+            head = torch.tensor([self.iter_step, self.loss.iter_step], dtype=torch.int64)
+            mine = torch.cat([head, rng.to(torch.int64)])
+            ref = mine.clone().to(self.flat.buffer.device if tdist.get_backend(self.group) == "nccl" else "cpu")
+            tdist.broadcast(ref, src=0, group=self.group)
+            if not torch.equal(ref.cpu(), mine):
+                import warnings
+
+                warnings.warn(f"TrainStep.load_state_dict: rank {self.rank} loaded a different step count / generator state than rank 0 — continuing with rank 0's")
+                self.iter_step, self.loss.iter_step = int(ref[0]), int(ref[1])
+                rng = ref.cpu()[2:].to(torch.uint8)
+        torch.set_rng_state(rng)
         self.flat.zero_()                  # re-attach the flat gradient views
         self._grads_clean = False
 

@@ -175,6 +175,83 @@ def test_rccl_communicator_comes_up_and_runs_the_steps_collectives_with_one_rank
     assert backend == "nccl" and ms < 50.0, (backend, ms)
 
 
+def _rccl_step_worker(port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        from spurfies_amd import synthetic as syn
+        from spurfies_amd.conf import default_model_conf
+        from spurfies_amd.model.pointneus_disent import PointVolSDF
+        from spurfies_amd.train import TrainStep
+
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        scene = syn.make_scene(3000, seed=4, prior="fitted")
+        st = scene["state"]
+        g = torch.Generator().manual_seed(8)
+        K = torch.from_numpy(scene["intrinsics"])[None].cuda()
+        batches = []
+        for i in range(3):
+            uv = torch.from_numpy(syn.make_pixels(R_TOTAL, g))[None].cuda()
+            batches.append(({"intrinsics": K, "uv": uv, "pose": torch.from_numpy(scene["poses"][i])[None].cuda(), "local_data": None},
+                            {"rgb": torch.rand((R_TOTAL, 3), generator=g)[None].cuda(), "mask": torch.ones(R_TOTAL)[None, :, None].repeat(1, 1, 3).cuda()}))
+        out = {}
+        for name, kw in (("plain", dict(sync_free=True)), ("eager_rccl", dict(sync_free=True, force_collectives=True)),
+                         ("graph_rccl", dict(use_graph=True, force_collectives=True))):
+            model = PointVolSDF(default_model_conf(near=0.5, grid_ranges=list(scene["ranges"])), 24, "dtu",
+                                neural_points={"pts": st["neural_pts"], "colors": scene["colors"]})
+            model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in st.items()}, strict=False)
+            step = TrainStep(model, keep_grads=True, **kw)
+            if step.buckets is not None:
+                step.buckets.timing = []
+            torch.manual_seed(21)
+            losses, logs = [], []
+            for b in batches:
+                l, _ = step(*b)
+                losses.append(float(l["loss"].item()))
+                if step.buckets is not None:
+                    logs.append(list(step.buckets.log))
+            torch.cuda.synchronize()
+            exposed = step.buckets.exposed_ms() if step.buckets is not None else []
+            out[name] = (losses, step.flat.buffer.detach().cpu().numpy().copy(), torch.cat([p.detach().reshape(-1) for p in step.params]).cpu().numpy(), logs, exposed)
+        q.put(("ok", torch.distributed.get_backend(), out))
+        torch.distributed.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put(("error", traceback.format_exc()[-1500:], None))
+
+
+def test_step_runs_its_collectives_through_rccl_with_one_rank():
+    """Round-5 verdict item 6: the optimisation step itself on the "nccl" (RCCL) backend.  A communicator of ONE rank on cuda:0 and
+    TrainStep(force_collectives=True): the step issues what a ray-sharded step issues — the 16-byte count all-reduce between forward and loss
+    kernels, then (eager) the four bucketed `async_op` all-reduces announced by the backward's hooks + finish(), or (use_graph) the two
+    hipGraphs around the eager count all-reduce and the dense gradient all-reduce — on RCCL's own stream semantics.  Three steps each; losses,
+    last gradients and parameters equal the plain step's (sums over one rank) up to the float atomics of the backward."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_rccl_step_worker, args=(_free_port(), q))
+    p_.start()
+    try:
+        status, backend, out = q.get(timeout=300)
+    finally:
+        p_.join(timeout=60)
+        if p_.is_alive():
+            p_.terminate()
+    assert status == "ok", backend
+    assert backend == "nccl"
+    l0, g0, p0, _, _ = out["plain"]
+    for name in ("eager_rccl", "graph_rccl"):
+        l1, g1, p1, logs, exposed = out[name]
+        np.testing.assert_allclose(l1, l0, rtol=2e-4, err_msg=name)
+        np.testing.assert_allclose(g1, g0, rtol=5e-3, atol=2e-4 * float(np.abs(g0).max()), err_msg=name)
+        np.testing.assert_allclose(p1, p0, rtol=0, atol=2.5e-3, err_msg=name)            # three Adam steps of lr 5e-4: sign noise of ~zero gradients aside
+        assert np.mean(np.abs(p1 - p0) > 1e-5) < 0.02, name
+    # the eager step's buckets were reduced by their hooks, in the backward's order, every step — through RCCL
+    assert out["eager_rccl"][3] == [["color_latents", "head", "color_weights", "geo_latents"]] * 3
+    assert out["graph_rccl"][3] == [[]] * 3 and len(out["eager_rccl"][4]) == 3
+
+
 def test_rccl_two_ranks_on_one_gpu_if_rccl_allows_it():
     """Round-2 verdict item 8: can the RCCL leg be exercised as two processes on ONE GPU?  Tried here for real; RCCL (like NCCL) refuses two
     ranks of a communicator on the same device, in which case the test records that and skips — the 2-GPU test above stays the RCCL test."""
