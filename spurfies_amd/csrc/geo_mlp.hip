@@ -974,76 +974,12 @@ __device__ __forceinline__ Bias3 load_bias3(gfp bias, int wave, int lane) {
 
 // forward epilogue: a = lrelu(acc + b) -> planes; sign bits pushed into mask[n] in the order (m, g, e) (32 per word).
 // MODE 1 (last layer): sdf partial sums s[n] += v . a, and the planes receive the Jacobian seed v * lrelu'(h) instead.
-// SPF_LEAN_EPILOGUE (round 5 experiment, default OFF): the bias sits in the accumulators already (gemm_x3's cinit), LeakyReLU = v_max_f32, sign bits
-// four at a time from the split's top pieces (mlp_tile_x3.h: sign_push4 / lrelu_pick) — 6.75 instead of 8.5 vector instructions per element in
-// the hidden layers' epilogues (the round-4 verdict's item 2).  Measured on MI355X, same box, A B C x 3 (profiles/r05_epilogue_ab.json): the
-// main-pass launch takes 1.655 ms with all three cuts against 1.625 ms without (+1.8 %), and 1.628 ms with the v_max / sign-byte cuts alone
-// (SPF_LEAN_BIASC=0: +0.2 %, noise) at the same held clock (1.82 GHz) — fewer vector instructions did not buy time: the bias as C operand keeps
-// 32 more registers live across the first k-step (208 AGPRs instead of 122: accumulator-file traffic), and the epilogue's issue slots were not
-// what the k-loop behind it waits for.  Kept as a build switch (-DSPF_LEAN_EPILOGUE=1 [-DSPF_LEAN_BIASC=0]) with its parity tests green.
-#ifndef SPF_LEAN_EPILOGUE
-#define SPF_LEAN_EPILOGUE 0
-#endif
-#ifndef SPF_LEAN_BIASC          // sub-switch (A/B builds): the bias as the first product's C operand (1) or a packed add in the epilogue (0)
-#define SPF_LEAN_BIASC 1
-#endif
-// a layer's bias in the accumulator layout of its two feature tiles: the C operand of the GEMM's first product
-__device__ __forceinline__ void bias_cinit(const Bias3& b, f32x16 (&ci)[2]) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ci[m][4 * g + e] = b.b[m][g][e];
-}
-
+// (round 5 tried fewer vector instructions here — v_max LeakyReLU, sign bits four at a time from the top pieces, the bias as the first product's
+// C operand: a measured null result, profiles/r05_epilogue_ab.json; removed in round 6, the record stays)
 template <int MODE, bool WITH_JAC, int NT = 2>
 __device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][NT], const Bias3& bias, const Bias3& v5, int wave, int lane,
                                                 uint32_t (&mask)[NT], float (&s)[NT]) {
     const int j = lane & 31, kg = lane >> 5;
-#if SPF_LEAN_EPILOGUE
-#pragma unroll
-    for (int n = 0; n < NT; ++n) mask[n] = 0u;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
-            f32x4 vv = f32x4{0.f, 0.f, 0.f, 0.f}, vs = vv;
-            if (MODE == 1) {
-                vv = v5.b[m][g];
-                vs = vv * 0.01f;
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                f32x4 h, hs, out;
-#if SPF_LEAN_BIASC
-                scale4(acc[m][n], g, h, hs);                       // the bias is in the accumulators
-#else
-                bias_scale4(acc[m][n], g, bias.b[m][g], h, hs);
-#endif
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = lrelu_max(h[e], hs[e]);
-                    if (MODE == 1) {        // last layer: sdf partial sums, and the planes get the Jacobian seed v * lrelu'(h) (m4 is never popped)
-                        s[n] += vv[e] * a;
-                        const uint32_t neg = (uint32_t)((int)__float_as_uint(h[e]) >> 31);
-                        out[e] = __uint_as_float((neg & __float_as_uint(vs[e])) | (~neg & __float_as_uint(vv[e])));
-                    } else {
-                        out[e] = a;
-                    }
-                }
-                if (MODE == 0) {
-                    uint32_t a1, b1;
-                    store_quad_x3_tops(X, 32 * n + j, f0, out, a1, b1);
-                    sign_push4(a1, b1, mask[n]);
-                } else if (WITH_JAC) {
-                    store_quad_x3(X, 32 * n + j, f0, out);
-                }
-            }
-        }
-    return;
-#endif
 #pragma unroll
     for (int n = 0; n < NT; ++n) mask[n] = 0u;
 #pragma unroll
@@ -1082,23 +1018,6 @@ __device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
 template <int NT = 2>
 __device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][NT], int wave, int lane, const uint32_t (&mask_in)[NT]) {
     const int j = lane & 31, kg = lane >> 5;
-#if SPF_LEAN_EPILOGUE
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 64 * wave + 32 * m + 8 * g + 4 * kg;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                f32x4 v, vs, out;
-                scale4(acc[m][n], g, v, vs);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) out[e] = lrelu_pick(v[e], vs[e], mask_in[n], 4 * m + g, e);
-                store_quad_x3(X, 32 * n + j, f0, out);
-            }
-        }
-    return;
-#endif
     uint32_t mask[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) mask[n] = mask_in[n];
@@ -1192,14 +1111,8 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         gx3 w_fw4 = frag + XW_FW4 + wave * (XW_TH * 2 * 3 * 64) + lane, w_bw4 = frag + XW_BW4 + wave * (XW_TH * 2 * 3 * 64) + lane;
         gx3 w_bw3 = frag + XW_BW3 + wave * (XW_TH * 2 * 3 * 64) + lane, w_bw2 = frag + XW_BW2 + wave * (XW_TH * 2 * 3 * 64) + lane;
         Bias3 bias = load_bias3(pf + OFF_B1, wave, lane);
-        f32x16 ci[2];
         WFrag3 nf;
-#if SPF_LEAN_EPILOGUE && SPF_LEAN_BIASC
-        bias_cinit(bias, ci);
-        nf = gemm_x3<XW_T1, false, X3_LDP, NT>(X, w_fw1, lane, acc, fr1, w_fw2, ci);
-#else
         nf = gemm_x3<XW_T1, false, X3_LDP, NT>(X, w_fw1, lane, acc, fr1, w_fw2);
-#endif
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
@@ -1212,12 +1125,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
             n_off = pair_off[n_p];
         }
         bias = load_bias3(pf + OFF_B2, wave, lane);
-#if SPF_LEAN_EPILOGUE && SPF_LEAN_BIASC
-        bias_cinit(bias, ci);
-        nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw2, lane, acc, nf, w_fw3, ci);
-#else
         nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw2, lane, acc, nf, w_fw3);
-#endif
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
@@ -1227,12 +1135,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         T_MARK(5)
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn + q0 - n_off)];
         bias = load_bias3(pf + OFF_B3, wave, lane);
-#if SPF_LEAN_EPILOGUE && SPF_LEAN_BIASC
-        bias_cinit(bias, ci);
-        nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw3, lane, acc, nf, w_fw4, ci);
-#else
         nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw3, lane, acc, nf, w_fw4);
-#endif
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
@@ -1243,12 +1146,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         cur = gx_fetch_row(n_idx, n_srow, q40, x, pts, feat_geo);
         bias = load_bias3(pf + OFF_B4, wave, lane);
         const Bias3 v5q = load_bias3(pf + OFF_V5, wave, lane);       // folded last layer v = T W8, same quads: requested ahead of the GEMM too
-#if SPF_LEAN_EPILOGUE && SPF_LEAN_BIASC
-        bias_cinit(bias, ci);
-        nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr, ci);
-#else
         nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
-#endif
         T_MARK(2)
         lds_barrier();
         T_MARK(3)

@@ -56,8 +56,7 @@ struct X3Regs {
 // HALF-HEIGHT 32-row tile of round 5 (one MFMA per fragment: the k-step is 12 MFMAs = 384 cycles for the same 6 KB of fragments, i.e. at the
 // CU's L1 fill rate — twice the tiles at ~55 % of a tile's time each: for launches whose 64-row tiles would not fill the chip once).
 template <int R, bool LW, bool LX, int LN, bool SWAP = false, int LDP = X3_LDP, bool FIRST = false, int NT = 2>
-__device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 (&acc)[2][NT], X3Regs<NT>& r, WFrag3& nxt, gx3 next_wp,
-                                        const f32x16* cinit = nullptr) {
+__device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 (&acc)[2][NT], X3Regs<NT>& r, WFrag3& nxt, gx3 next_wp) {
     constexpr int R1 = (R + 1) % 3, R2 = (R + 2) % 3;
     if (LW) {
 #pragma unroll
@@ -85,10 +84,8 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
     }
     // smallest terms first; four accumulators alternate
     // (the first product of a GEMM takes C = 0 as an inline constant: no accumulator zeroing)
-    // (round 5: or C = the layer's bias, cinit[m] in the accumulator layout of feature tile m — the epilogue's packed bias add is gone; transposed
-    // products only: there a lane's 16 accumulator registers of tile m hold 16 different features, the same for both row tiles)
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const f32x16 ci0 = (FIRST && cinit) ? cinit[0] : zero16, ci1 = (FIRST && cinit) ? cinit[1] : zero16;
+    const f32x16 ci0 = zero16, ci1 = zero16;
     if constexpr (NT == 2) {
 #define SPF_X3(PW, PX, Z)                                                                                              \
     {                                                                                                                  \
@@ -154,8 +151,7 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
 }
 
 template <int T, bool SWAP = false, int LDP = X3_LDP, int NT = 2>
-__device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][NT], const WFrag3& first, gx3 next_wp,
-                                          const f32x16* cinit = nullptr) {
+__device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][NT], const WFrag3& first, gx3 next_wp) {
     static_assert(T >= 3, "gemm_x3: at least three k-steps");
     const int j = lane & 31, kg = lane >> 5;
     const __bf16* xp = X + j * LDP + 8 * kg;
@@ -175,7 +171,7 @@ __device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32
     constexpr int MAIN = T - 2, REM = MAIN % 3;        // k-steps that request weights; the last two only consume
     constexpr bool ZC = true;                          // C = 0 on the first product of the GEMM
     if (MAIN >= 3) {
-        x3_step<0, true, true, 0, SWAP, LDP, ZC, NT>(xp, wp, 0, acc, r, nxt, next_wp, cinit);
+        x3_step<0, true, true, 0, SWAP, LDP, ZC, NT>(xp, wp, 0, acc, r, nxt, next_wp);
         x3_step<1, true, true, 0, SWAP, LDP, false, NT>(xp, wp, 1, acc, r, nxt, next_wp);
         x3_step<2, true, true, 0, SWAP, LDP, false, NT>(xp, wp, 2, acc, r, nxt, next_wp);
 #pragma unroll 1
@@ -185,7 +181,7 @@ __device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32
             x3_step<2, true, true, 0, SWAP, LDP, false, NT>(xp, wp, t + 2, acc, r, nxt, next_wp);
         }
     }
-    if (REM >= 1) x3_step<0, true, true, 0, SWAP, LDP, (ZC && MAIN < 3), NT>(xp, wp, MAIN - REM, acc, r, nxt, next_wp, cinit);
+    if (REM >= 1) x3_step<0, true, true, 0, SWAP, LDP, (ZC && MAIN < 3), NT>(xp, wp, MAIN - REM, acc, r, nxt, next_wp);
     if (REM == 2) x3_step<1, true, true, 0, SWAP, LDP, false, NT>(xp, wp, MAIN - 1, acc, r, nxt, next_wp);
     if (next_wp) {
         x3_step<REM, false, true, 1, SWAP, LDP, false, NT>(xp, wp, T - 2, acc, r, nxt, next_wp);
@@ -352,42 +348,6 @@ __device__ __forceinline__ float lrelu_pop(float g, float g001, uint32_t& bits) 
     asm("v_add_co_u32_e32 %1, vcc, %1, %1\n\tv_cndmask_b32_e32 %0, %3, %2, vcc" : "=&v"(out), "+v"(bits) : "v"(g), "v"(g001) : "vcc");
     return out;
 }
-
-// ---- round 5: the forward epilogue with fewer vector instructions per element (the matrix pipe is power-limited: every VALU instruction beside it is
-// paid in watts as well as issue slots).  LeakyReLU = max(h, 0.01 h) (one v_max_f32 instead of v_cmp + v_cndmask); the sign bits are not pushed
-// one element at a time through the carry chain (v_cmp + v_addc) but taken FOUR at a time from the top bf16 pieces the split has just formed:
-// v_perm_b32 gathers the four high bytes (bit 7 = sign of the activation = sign of h) and a shift + v_bfi_b32 files them into byte lanes —
-// after the 8 quads of a word, byte e holds element e's sign of quad q at bit q.  3 instructions per quad instead of 8.
-// (h = +0.0 reads as "positive" here where the reference's `x > 0` says no: the two differ by the factor 0.01 on a gradient entry whose
-// pre-activation is exactly zero — padded rows have h = bias, real rows never hit it.)
-__device__ __forceinline__ float lrelu_max(float h, float h001) {
-    float out;
-    asm("v_max_f32_e32 %0, %1, %2" : "=v"(out) : "v"(h), "v"(h001));
-    return out;
-}
-// push the signs of a quad whose packed top pieces are (a1 = elements 0, 1; b1 = elements 2, 3)
-__device__ __forceinline__ void sign_push4(uint32_t a1, uint32_t b1, uint32_t& bits) {
-    const uint32_t t = __builtin_amdgcn_perm(b1, a1, 0x07050301u);
-    bits = (t & 0x80808080u) | ((bits >> 1) & 0x7f7f7f7fu);
-}
-// element e of quad q (the q-th push of 8) of a finished word: all-ones if negative
-__device__ __forceinline__ float lrelu_pick(float g, float g001, uint32_t bits, int q, int e) {
-    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 8 * e + q, 1);
-    return __uint_as_float((m & __float_as_uint(g001)) | (~m & __float_as_uint(g)));
-}
-// store_quad_x3 that also returns the packed top pieces (for sign_push4)
-template <int LDP = X3_LDP>
-__device__ __forceinline__ void store_quad_x3_tops(__bf16* X, int row, int f0, f32x4 v, uint32_t& a1, uint32_t& b1) {
-    uint32_t a2, a3, b2, b3;
-    split3_pair(f32x2{v[0], v[1]}, a1, a2, a3);
-    split3_pair(f32x2{v[2], v[3]}, b1, b2, b3);
-    __bf16* dst = X + row * LDP + f0;
-    *reinterpret_cast<u32x2*>(dst) = u32x2{a1, b1};
-    *reinterpret_cast<u32x2*>(dst + (64 * LDP)) = u32x2{a2, b2};
-    *reinterpret_cast<u32x2*>(dst + 2 * (64 * LDP)) = u32x2{a3, b3};
-}
-// 0.01 h for four accumulator values (the bias is already in the accumulators)
-__device__ __forceinline__ void scale4(const f32x16& acc, int g, f32x4& v, f32x4& vs);
 
 // [ROWS][8 * NG] tile of the planes (exactly p1 + p2 + p3 per element) -> fp32 rows in HBM, coalesced (32 B per thread, a row's
 // threads are consecutive): what the weight-gradient GEMM reads.
