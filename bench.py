@@ -278,6 +278,12 @@ def eval_cpu_baseline(scene, n_rays):
             "sample": f"one evaluation render of {n_rays} rays (fast=-1) on the same scene, {dt:.1f} s on {cores} threads", "sampler_iterations": iters}
 
 
+def ops_geo_is_split_w():
+    from spurfies_amd import ops
+
+    return ops.geo_mode() == "split_w"
+
+
 def eval_chunk_record(args, device, scene, steps=20, warmup=5):
     """`extra` record of the default N = 1 line: the evaluation render (PointVolSDF.forward(fast=-1) under no_grad: the full error-bounded
     sampler + main pass with normals + colour + compositing; train.py:399-433 / eval_spurfies.py:276-292 chunks) of --rays-pixel chunks on the
@@ -310,8 +316,25 @@ def eval_chunk_record(args, device, scene, steps=20, warmup=5):
         for i in range(3):                       # realised sampler iterations: read back outside the timed region (one small copy per chunk)
             render(batches[i % len(batches)])
             iters.append(model.ray_sampler.last_iters)
+    # opt-in variant, reported beside the default: the sampler's SDF-only passes with reduced products (SPF_ARITH_LITE; main pass unchanged)
+    lite = None
+    if ops_geo_is_split_w():
+        model.sampler_lite = True
+        r2 = GraphedRenderer(model, args.rays, keys=("rgb_values", "depth_values", "normal_map"))
+        with torch.no_grad():
+            for i in range(warmup):
+                r2(batches[i % len(batches)])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                r2(batches[i % len(batches)])
+            torch.cuda.synchronize()
+            lite = {"ms_per_step": (time.perf_counter() - t0) / steps * 1e3, "sampler_iterations": int(model.ray_sampler.last_iters),
+                    "what": "PointVolSDF.sampler_lite = True (OFF by default): the evaluation sampler's SDF-only passes with two bf16 pieces per operand; the "
+                            "main pass, normals and colours keep the fp32-class products (tolerance study: tests/test_gpu_sampler.py::test_reduced_product_...)"}
+        model.sampler_lite = False
     samples = args.rays * (128 * float(np.mean(iters)) + 98)
-    return {"record": "evaluation render: one hipGraph replay per chunk, outputs rgb_values / depth_values / normal_map (what train.py:419-424 and eval_spurfies.py:282-287 read)",
+    return {"reduced_product_sampler_passes": lite, "record": "evaluation render: one hipGraph replay per chunk, outputs rgb_values / depth_values / normal_map (what train.py:419-424 and eval_spurfies.py:282-287 read)",
             "metric": "ray-samples/sec (kNN+SDF+render, evaluation render fast=-1)", "value": samples * steps / dt, "unit": "ray-samples/s", "n_gpus": 1, "steps": steps,
             "warmup": warmup, "ms_per_step": dt / steps * 1e3, "scaling": "weak",
             "config": {"workload": f"evaluation render of {args.rays}-ray chunks on the main record's scene ({args.points} neural points): full error-bounded sampler "

@@ -190,6 +190,12 @@ int spf_compact_pairs_filter(const uint8_t* slot_valid, const int32_t* nbr, int3
 /* spf_geo_forward only, OR-ed into arith: the bf16-piece kernels of THIS launch stamp the held-clock counters (spf_geo_clock_read).  Without
  * the bit a launch touches no state outside its arguments. */
 #define SPF_ARITH_CLOCK 0x100
+/* ABI 6 — spf_geo_forward only, OR-ed into SPF_ARITH_SPLIT_W for an SDF-ONLY pass (grad == jac == NULL): REDUCED products — two bf16 pieces
+ * per operand, three piece products instead of six (~16 mantissa bits per product instead of fp32-class), half the matrix instructions.
+ * OPT-IN for the evaluation sampler's SDF passes (ray_sampler.py:403: values that only steer where the next samples go; the main pass
+ * re-evaluates every rendered point with the full products); never for a pass whose values are rendered, differentiated or reported.
+ * Tolerance study: tests/test_gpu_sampler.py::test_reduced_product_sampler_passes..., DESIGN.md section 5. */
+#define SPF_ARITH_LITE 0x200
 
 /* Number of floats of the packed F_geometry/T weight image. */
 

@@ -1043,7 +1043,7 @@ __device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
 // pairs — the weights stream as for a 64-row tile (the k-step becomes L1-fill-bound instead of matrix-pipe-bound: mlp_tile_x3.h), so a tile
 // takes ~55 % of a full one's time and twice as many workgroups have work: chosen by the kernel when all the launch's pairs fit ONE pass of
 // half tiles over the grid (the sampler pass and the pseudo-point pass of a 128-ray step: 64 resp. 16 full tiles on a 256-CU chip).
-template <bool WITH_JAC, int NT>
+template <bool WITH_JAC, int NT, int NPC = 3>
 __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                              const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off,
                                              const int32_t* __restrict__ pair_point, const int NP, const int q0, int k, const float* __restrict__ pts,
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         gx3 w_bw3 = frag + XW_BW3 + wave * (XW_TH * 2 * 3 * 64) + lane, w_bw2 = frag + XW_BW2 + wave * (XW_TH * 2 * 3 * 64) + lane;
         Bias3 bias = load_bias3(pf + OFF_B1, wave, lane);
         WFrag3 nf;
-        nf = gemm_x3<XW_T1, false, X3_LDP, NT>(X, w_fw1, lane, acc, fr1, w_fw2);
+        nf = gemm_x3<XW_T1, false, X3_LDP, NT, NPC>(X, w_fw1, lane, acc, fr1, w_fw2);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
@@ -1125,7 +1125,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
             n_off = pair_off[n_p];
         }
         bias = load_bias3(pf + OFF_B2, wave, lane);
-        nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw2, lane, acc, nf, w_fw3);
+        nf = gemm_x3<XW_TH, false, X3_LDP, NT, NPC>(X, w_fw2, lane, acc, nf, w_fw3);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
@@ -1135,7 +1135,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         T_MARK(5)
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn + q0 - n_off)];
         bias = load_bias3(pf + OFF_B3, wave, lane);
-        nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw3, lane, acc, nf, w_fw4);
+        nf = gemm_x3<XW_TH, false, X3_LDP, NT, NPC>(X, w_fw3, lane, acc, nf, w_fw4);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
@@ -1146,7 +1146,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         cur = gx_fetch_row(n_idx, n_srow, q40, x, pts, feat_geo);
         bias = load_bias3(pf + OFF_B4, wave, lane);
         const Bias3 v5q = load_bias3(pf + OFF_V5, wave, lane);       // folded last layer v = T W8, same quads: requested ahead of the GEMM too
-        nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
+        nf = gemm_x3<XW_TH, false, X3_LDP, NT, NPC>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
@@ -1221,7 +1221,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
     T_FLUSH
 }
 
-template <bool WITH_JAC>
+template <bool WITH_JAC, int NPC = 3>
 __global__ void __launch_bounds__(256, 1)
 geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
                     const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
@@ -1238,16 +1238,16 @@ geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
     const int G = (int)gridDim.x;
     const int q_full = (NP / (64 * G)) * (64 * G), rem = NP - q_full;
     if (q_full > 0)
-        geo_x3w_body<WITH_JAC, 2>(X, red, x, nbr, point_slot, pair_off, pair_point, q_full, 0, k, pts, feat_geo, packed, rbf, pair_tmp, jac);
+        geo_x3w_body<WITH_JAC, 2, NPC>(X, red, x, nbr, point_slot, pair_off, pair_point, q_full, 0, k, pts, feat_geo, packed, rbf, pair_tmp, jac);
     if (rem > 0) {
         const int32_t* pp = pair_point + q_full;
         float* pt = pair_tmp + (size_t)q_full * PT_STRIDE;
         float* jc = jac ? jac + (size_t)q_full * SPF_GEO_DIM : nullptr;
         if (q_full > 0) lds_barrier();          // (the first body's last tile is done with the planes)
         if (rem <= 32 * G)
-            geo_x3w_body<WITH_JAC, 1>(X, red, x, nbr, point_slot, pair_off, pp, rem, q_full, k, pts, feat_geo, packed, rbf, pt, jc);
+            geo_x3w_body<WITH_JAC, 1, NPC>(X, red, x, nbr, point_slot, pair_off, pp, rem, q_full, k, pts, feat_geo, packed, rbf, pt, jc);
         else
-            geo_x3w_body<WITH_JAC, 2>(X, red, x, nbr, point_slot, pair_off, pp, rem, q_full, k, pts, feat_geo, packed, rbf, pt, jc);
+            geo_x3w_body<WITH_JAC, 2, NPC>(X, red, x, nbr, point_slot, pair_off, pp, rem, q_full, k, pts, feat_geo, packed, rbf, pt, jc);
     }
     CLK_FLUSH(1, WITH_JAC ? 1 : 0)
 }
@@ -1291,7 +1291,10 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
                     const float* feat_geo, const float* packed, float rbf, float* sdf, float* grad, float* wn, float* jac,
                     float* pair_tmp, int32_t arith, void* stream) {
     const int clk = (arith & SPF_ARITH_CLOCK) ? 1 : 0;      // opt-in held-clock stamps (spf_geo_clock_read); ignored by the fp32-MFMA twin
-    arith &= ~SPF_ARITH_CLOCK;
+    const bool lite = (arith & SPF_ARITH_LITE) != 0;        // reduced products (two pieces per operand): SDF-only passes of the 32x32x16 engine
+    arith &= ~(SPF_ARITH_CLOCK | SPF_ARITH_LITE);
+    if (lite && (arith != SPF_ARITH_SPLIT_W || grad || jac))
+        return spf::fail(SPF_EINVAL, "spf_geo_forward: SPF_ARITH_LITE goes with SPF_ARITH_SPLIT_W and an SDF-only pass (no grad / jac): its values steer the sampler, nothing else");
     if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32 && arith != SPF_ARITH_SPLIT_W)
         return spf::fail(SPF_EINVAL, "spf_geo_forward: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_SPLIT_W (2) [| SPF_ARITH_CLOCK], got %d", arith);
     if (max_points < 0 || max_pairs < 0 || k < 1 || k > SPF_KMAX)
@@ -1319,6 +1322,9 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
         if (grad)
             geo_pairs_x3w_kernel<true><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
                                                           pair_tmp, jac, clk);
+        else if (lite)
+            geo_pairs_x3w_kernel<false, 2><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
+                                                              rbf, pair_tmp, nullptr, clk);
         else
             geo_pairs_x3w_kernel<false><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
                                                            rbf, pair_tmp, nullptr, clk);

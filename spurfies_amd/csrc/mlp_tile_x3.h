@@ -55,32 +55,35 @@ struct X3Regs {
 // NT = number of 32-row tiles of the activation operand a wave multiplies: 2 = the 64-row tile (every weight fragment feeds two MFMAs), 1 = the
 // HALF-HEIGHT 32-row tile of round 5 (one MFMA per fragment: the k-step is 12 MFMAs = 384 cycles for the same 6 KB of fragments, i.e. at the
 // CU's L1 fill rate — twice the tiles at ~55 % of a tile's time each: for launches whose 64-row tiles would not fill the chip once).
-template <int R, bool LW, bool LX, int LN, bool SWAP = false, int LDP = X3_LDP, bool FIRST = false, int NT = 2>
+// NPC = pieces per operand that take part: 3 = the fp32-class product (six piece products), 2 = the REDUCED product of round 6 (pieces 0 and 1
+// of both operands, products (1,0) (0,1) (0,0): ~16 mantissa bits, half the MFMAs and two thirds of the operand traffic) — offered to the
+// evaluation sampler's SDF-only passes only (include/spurfies_hip.h: SPF_ARITH_LITE), never to a pass whose values are rendered or differentiated.
+template <int R, bool LW, bool LX, int LN, bool SWAP = false, int LDP = X3_LDP, bool FIRST = false, int NT = 2, int NPC = 3>
 __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 (&acc)[2][NT], X3Regs<NT>& r, WFrag3& nxt, gx3 next_wp) {
     constexpr int R1 = (R + 1) % 3, R2 = (R + 2) % 3;
     if (LW) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) r.w[R2][m][p] = wp[((t + 2) * 6 + m * 3 + p) * 64];
+            for (int p = 0; p < NPC; ++p) r.w[R2][m][p] = wp[((t + 2) * 6 + m * 3 + p) * 64];
     }
     if (LN == 1) {          // the next layer's k-step 0 (second-to-last k-step) and k-step 1 (last k-step): no request of this layer left
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) nxt.w[m][p] = next_wp[(m * 3 + p) * 64];
+            for (int p = 0; p < NPC; ++p) nxt.w[m][p] = next_wp[(m * 3 + p) * 64];
     }
     if (LN == 2) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) nxt.w1[m][p] = next_wp[(6 + m * 3 + p) * 64];
+            for (int p = 0; p < NPC; ++p) nxt.w1[m][p] = next_wp[(6 + m * 3 + p) * 64];
     }
     if (LX) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) r.x[R1][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 32 * n * LDP + 16 * (t + 1));
+            for (int p = 0; p < NPC; ++p) r.x[R1][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 32 * n * LDP + 16 * (t + 1));
     }
     // smallest terms first; four accumulators alternate
     // (the first product of a GEMM takes C = 0 as an inline constant: no accumulator zeroing)
@@ -103,21 +106,25 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][1][PX], r.w[R][1][PW], c11, 0, 0, 0);             \
         }                                                                                                              \
     }
-        SPF_X3(2, 0, FIRST) SPF_X3(0, 2, false) SPF_X3(1, 1, false) SPF_X3(1, 0, false) SPF_X3(0, 1, false) SPF_X3(0, 0, false)
+        if constexpr (NPC == 3) {
+            SPF_X3(2, 0, FIRST) SPF_X3(0, 2, false) SPF_X3(1, 1, false) SPF_X3(1, 0, false) SPF_X3(0, 1, false) SPF_X3(0, 0, false)
+        } else {
+            SPF_X3(1, 0, FIRST) SPF_X3(0, 1, false) SPF_X3(0, 0, false)
+        }
 #undef SPF_X3
         // the requests ride between the MFMAs (issued in one block in front of them, their ~25 issue slots leave the matrix pipe idle
         // once per k-step): LDS reads first (needed at the start of the next k-step), then the L2 requests (needed one k-step later)
         if (LX) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 2 * NPC; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
         if (LW || LN != 0) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            for (int i = 0; i < 2 * NPC; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NPC == 3 ? 2 : 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
@@ -129,19 +136,23 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0][PW], r.x[R][0][PX], c0, 0, 0, 0);                  \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1][PW], r.x[R][0][PX], c1, 0, 0, 0);                  \
     }
-        SPF_X3H(2, 0, FIRST) SPF_X3H(0, 2, false) SPF_X3H(1, 1, false) SPF_X3H(1, 0, false) SPF_X3H(0, 1, false) SPF_X3H(0, 0, false)
+        if constexpr (NPC == 3) {
+            SPF_X3H(2, 0, FIRST) SPF_X3H(0, 2, false) SPF_X3H(1, 1, false) SPF_X3H(1, 0, false) SPF_X3H(0, 1, false) SPF_X3H(0, 0, false)
+        } else {
+            SPF_X3H(1, 0, FIRST) SPF_X3H(0, 1, false) SPF_X3H(0, 0, false)
+        }
 #undef SPF_X3H
         // 12 MFMAs carry 3 LDS reads and 6 L2 requests
         if (LX) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < NPC; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
         if (LW || LN != 0) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 2 * NPC; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
@@ -150,7 +161,7 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int T, bool SWAP = false, int LDP = X3_LDP, int NT = 2>
+template <int T, bool SWAP = false, int LDP = X3_LDP, int NT = 2, int NPC = 3>
 __device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][NT], const WFrag3& first, gx3 next_wp) {
     static_assert(T >= 3, "gemm_x3: at least three k-steps");
     const int j = lane & 31, kg = lane >> 5;
@@ -160,35 +171,35 @@ __device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPC; ++p) {
             r.w[0][m][p] = first.w[m][p];
             r.w[1][m][p] = first.w1[m][p];
         }
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) r.x[0][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 32 * n * LDP);
+        for (int p = 0; p < NPC; ++p) r.x[0][n][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 32 * n * LDP);
     constexpr int MAIN = T - 2, REM = MAIN % 3;        // k-steps that request weights; the last two only consume
     constexpr bool ZC = true;                          // C = 0 on the first product of the GEMM
     if (MAIN >= 3) {
-        x3_step<0, true, true, 0, SWAP, LDP, ZC, NT>(xp, wp, 0, acc, r, nxt, next_wp);
-        x3_step<1, true, true, 0, SWAP, LDP, false, NT>(xp, wp, 1, acc, r, nxt, next_wp);
-        x3_step<2, true, true, 0, SWAP, LDP, false, NT>(xp, wp, 2, acc, r, nxt, next_wp);
+        x3_step<0, true, true, 0, SWAP, LDP, ZC, NT, NPC>(xp, wp, 0, acc, r, nxt, next_wp);
+        x3_step<1, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, 1, acc, r, nxt, next_wp);
+        x3_step<2, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, 2, acc, r, nxt, next_wp);
 #pragma unroll 1
         for (int t = 3; t + 3 <= MAIN; t += 3) {
-            x3_step<0, true, true, 0, SWAP, LDP, false, NT>(xp, wp, t, acc, r, nxt, next_wp);
-            x3_step<1, true, true, 0, SWAP, LDP, false, NT>(xp, wp, t + 1, acc, r, nxt, next_wp);
-            x3_step<2, true, true, 0, SWAP, LDP, false, NT>(xp, wp, t + 2, acc, r, nxt, next_wp);
+            x3_step<0, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, t, acc, r, nxt, next_wp);
+            x3_step<1, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, t + 1, acc, r, nxt, next_wp);
+            x3_step<2, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, t + 2, acc, r, nxt, next_wp);
         }
     }
-    if (REM >= 1) x3_step<0, true, true, 0, SWAP, LDP, (ZC && MAIN < 3), NT>(xp, wp, MAIN - REM, acc, r, nxt, next_wp);
-    if (REM == 2) x3_step<1, true, true, 0, SWAP, LDP, false, NT>(xp, wp, MAIN - 1, acc, r, nxt, next_wp);
+    if (REM >= 1) x3_step<0, true, true, 0, SWAP, LDP, (ZC && MAIN < 3), NT, NPC>(xp, wp, MAIN - REM, acc, r, nxt, next_wp);
+    if (REM == 2) x3_step<1, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, MAIN - 1, acc, r, nxt, next_wp);
     if (next_wp) {
-        x3_step<REM, false, true, 1, SWAP, LDP, false, NT>(xp, wp, T - 2, acc, r, nxt, next_wp);
-        x3_step<(REM + 1) % 3, false, false, 2, SWAP, LDP, false, NT>(xp, wp, T - 1, acc, r, nxt, next_wp);
+        x3_step<REM, false, true, 1, SWAP, LDP, false, NT, NPC>(xp, wp, T - 2, acc, r, nxt, next_wp);
+        x3_step<(REM + 1) % 3, false, false, 2, SWAP, LDP, false, NT, NPC>(xp, wp, T - 1, acc, r, nxt, next_wp);
     } else {
-        x3_step<REM, false, true, 0, SWAP, LDP, false, NT>(xp, wp, T - 2, acc, r, nxt, next_wp);
-        x3_step<(REM + 1) % 3, false, false, 0, SWAP, LDP, false, NT>(xp, wp, T - 1, acc, r, nxt, next_wp);
+        x3_step<REM, false, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, T - 2, acc, r, nxt, next_wp);
+        x3_step<(REM + 1) % 3, false, false, 0, SWAP, LDP, false, NT, NPC>(xp, wp, T - 1, acc, r, nxt, next_wp);
     }
     return nxt;
 }

@@ -92,6 +92,9 @@ class PointVolSDF(nn.Module):
         # "normal_map", "weights") = the render outputs the reference's evaluation loops read (train.py:419-424, eval_spurfies.py:282-287) and
         # nothing else — no pseudo-point pass, TV term or per-slot plot maps, composites + normals + depth fill in ONE launch (eval_graph.py)
         self.eval_keys = None
+        # evaluation only, OPT-IN (default False): the sampler's SDF-only passes with reduced products (SPF_ARITH_LITE: ~16 mantissa bits) — their
+        # values only steer where samples go; the main pass evaluates every rendered point with the full products.  Tolerance study in DESIGN.md.
+        self.sampler_lite = False
         self._cp_sync = ops.CompactSync()     # this model's own word buffers of the one-launch compaction, one per kNN pass
 
     # ------------------------------------------------------------------ initialisation (:116-205)
@@ -217,7 +220,7 @@ class PointVolSDF(nn.Module):
         q = grid.query_dense(x.unsqueeze(1), self.conf.k, self.conf.r, 1)
         pl = ops.PairList.from_slots(q["slot_valid"], q["pidx"].view(-1, self.conf.k), gate=gate, sync=self._cp_sync.get("sampler", x.device, x.shape[0]))
         tmp = ops.geo_forward(x, pl, self.neural_pts, self.neural_feats_geometry.detach(), self._packed(), float(self.conf.rbf), with_grad=False,
-                              reduce=False)["pair_tmp"]
+                              reduce=False, lite=self.sampler_lite)["pair_tmp"]
         return tmp, pl
 
     def get_sdf_eval(self, inputs):

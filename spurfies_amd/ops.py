@@ -430,10 +430,11 @@ def pack_geometry_weights(state: dict) -> torch.Tensor:
     return packed
 
 
-def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_out=None, grad_out=None, reduce=True):
+def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_out=None, grad_out=None, reduce=True, lite=False):
     """Rows = first dim of x / nbr.  Returns dict(sdf [rows] (1000 where not a valid point), grad [rows,3] | None,
     wn [max_pairs], jac [max_pairs,32] | None).  sdf_out / grad_out: buffers already holding the filler (compact_points(fill_*)).
-    reduce=False (no grad): the per-point reduction is left to the consumer (sampler_train); the result is 'pair_tmp' [max_pairs,5]."""
+    reduce=False (no grad): the per-point reduction is left to the consumer (sampler_train); the result is 'pair_tmp' [max_pairs,5].
+    lite (no grad, 'split_w' engine only; ignored otherwise): reduced products, SPF_ARITH_LITE — for sampler passes, opt-in."""
     rows = pl.nbr.shape[0]
     dev = x.device
     if not reduce:
@@ -450,7 +451,9 @@ def geo_forward(x, pl: "PairList", pts, feat_geo, packed, rbf, with_grad, sdf_ou
         _lib.check(_lib.lib().spf_geo_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off), _lib.ptr(pl.pair_point),
                                               _lib.ptr(pl.n_points), _lib.ptr(pl.n_pairs), pl.max_points, pl.max_pairs, pl.k, _lib.ptr(pts),
                                               _lib.ptr(feat_geo), _lib.ptr(packed), float(rbf), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(wn),
-                                              _lib.ptr(jac), _lib.ptr(tmp), _ARITH["geo"] | (0x100 if _GEO_CLOCK[0] else 0), _lib.stream_ptr()), "spf_geo_forward")
+                                              _lib.ptr(jac), _lib.ptr(tmp),
+                                              _ARITH["geo"] | (0x100 if _GEO_CLOCK[0] else 0) | (0x200 if (lite and not with_grad and _ARITH["geo"] == 2) else 0),
+                                              _lib.stream_ptr()), "spf_geo_forward")
     return {"sdf": sdf, "wn": wn, "grad": grad, "jac": jac, "pair_tmp": tmp}
 
 
