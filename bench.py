@@ -84,6 +84,9 @@ def parse():
                     "section 8(d): reported separately, with the realised sampler iterations), followed by the reference-sized get_sdf_eval grid sweep")
     ap.add_argument("--image", type=int, nargs=2, default=[576, 768], metavar=("H", "W"), help="eval mode: also render ONE full image of this size as a stream of "
                     "--rays-pixel chunks (eval_graph.ImageRenderer: train.py:399-433 / eval_spurfies.py:276-292 without per-chunk host work) and report images/s; 0 0 = skip")
+    ap.add_argument("--eval-outputs", choices=["render", "reference"], default="render", help="eval mode: render = the outputs the reference's evaluation loops read "
+                    "(rgb_values, depth_values, normal_map: train.py:419-424, eval_spurfies.py:282-287; PointVolSDF.eval_keys), reference = every key of the reference's "
+                    "forward (adds the pseudo-point pass, the TV term and the per-slot plot maps)")
     ap.add_argument("--sweep-resolution", type=int, default=512, help="eval mode: samples along the shortest axis of the mesh-extraction grid (the reference: 512); 0 = skip")
     ap.add_argument("--geo-engine", choices=["auto", "split", "split_w"], default="auto", help="MFMA shape of the dominant kernel: 16x16x32 (split), 32x32x16 "
                     "(split_w), or auto = time both on this box before the warm-up steps (TrainStep.autotune_geo_engine) and keep the faster")
@@ -373,6 +376,8 @@ def main_eval(args):
     ops.geo_clock_enable(True)                    # this process is the one measuring caller of the library's held-clock counters
     iters = []
     tune = None
+    keys = ("rgb_values", "depth_values", "normal_map") if args.eval_outputs == "render" else None
+    model.eval_keys = keys
     render = lambda b: model(dict(b), fast=-1)
     with torch.no_grad():
         if args.geo_engine == "auto":          # MFMA shape of the geometry kernels: both timed on one chunk on THIS box (untimed), the faster kept
@@ -390,7 +395,7 @@ def main_eval(args):
         if args.graph:                             # one hipGraph replay per chunk (spurfies_amd/eval_graph.py)
             from spurfies_amd.eval_graph import GraphedRenderer
 
-            render = GraphedRenderer(model, args.rays)
+            render = GraphedRenderer(model, args.rays, keys=keys)
         for i in range(args.warmup):
             render(batches[i % len(batches)])
         ops.geo_clock(reset=True)
@@ -451,7 +456,7 @@ def main_eval(args):
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"evaluation render (train.py:399-472 / eval_spurfies.py:276-292 chunks): {args.points} neural points, {args.rays} rays per chunk and GPU, "
                                   f"full error-bounded sampler (up to 5 iterations of 128 samples/ray) + 98 main samples/ray, SDF + normals + colour + compositing, no_grad; prior = {args.prior}",
-                      "mode": "eval", "launch": "one hipGraph replay per chunk" if args.graph else "eager launches", "rays_per_gpu": args.rays, "neural_points": args.points, "prior": args.prior, "parallelism": f"chunk-sharded dp{world}",
+                      "mode": "eval", "outputs": args.eval_outputs, "launch": "one hipGraph replay per chunk" if args.graph else "eager launches", "rays_per_gpu": args.rays, "neural_points": args.points, "prior": args.prior, "parallelism": f"chunk-sharded dp{world}",
                       "sampler_iterations_realised": {"mean": float(np.mean(iters)), "min": int(min(iters)), "max": int(max(iters))},
                       "rays_per_s": args.rays * world * args.steps / dt,
                       "host_syncs_per_step": "none inside the forward (device-side loop control of the sampler, worst-case buffers + device counts); this bench reads the realised iteration count back once per chunk"},
