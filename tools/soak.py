@@ -28,6 +28,8 @@ _own.add_argument("--steps", type=int, default=20000)
 _own.add_argument("--block", type=int, default=1000)
 _own.add_argument("--det-steps", type=int, default=400)
 _own.add_argument("--out", default="gpurun_out/r05_soak.json")
+_own.add_argument("--local", action="store_true", help="the DTU recipe's real step: every batch carries its view's synthetic local_data (feature-consistency "
+                  "term inside the replayed graph, the view descriptor overwritten per step)")
 own, rest = _own.parse_known_args()
 sys.argv = ["bench.py", "--no-cpu-baseline", "--sustained", "0"] + rest
 import bench  # noqa: E402
@@ -65,7 +67,7 @@ def soak():
     import gc
 
     scene, model, step = build()
-    batches = bench.make_batches(scene, N_BATCH, args.rays, 0, 1, dev)
+    batches = bench.make_batches(scene, N_BATCH, args.rays, 0, 1, dev, local=own.local)
     torch.manual_seed(1)
     half = (own.steps // 2 // own.block) * own.block
     rows, resumed_at = [], None
@@ -99,7 +101,7 @@ def soak():
             print("resumed", resumed_at, flush=True)
     finite = all(np.isfinite(r["loss"]) for r in rows) and all(bool(torch.isfinite(p).all()) for p in model.parameters())
     ms = [r["ms_per_step"] for r in rows]
-    return {"steps": own.steps, "block": own.block, "mode": "sync-free, hipGraph replay, 64 batches cycled", "points": args.points, "rays": args.rays,
+    return {"steps": own.steps, "block": own.block, "mode": "sync-free, hipGraph replay, 64 batches cycled" + (", local_data (feature-consistency term) on every step, three views in turn" if own.local else ""), "points": args.points, "rays": args.rays,
             "schedule": "CosineAnnealingLR(T_max=100000, eta_min=3e-4) from 5e-4", "resume": resumed_at, "blocks": rows, "all_finite": finite,
             "ms_per_step_first_block": ms[0], "ms_per_step_last_block": ms[-1], "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
             "skipped_updates_total_since_resume": rows[-1]["skipped_updates"],
@@ -111,7 +113,7 @@ def determinism(graph):
     try:
         n, mid = own.det_steps, own.det_steps // 2
         scene, model, step = build(graph)
-        batches = bench.make_batches(scene, N_BATCH, args.rays, 0, 1, dev)
+        batches = bench.make_batches(scene, N_BATCH, args.rays, 0, 1, dev, local=own.local)
         torch.manual_seed(7)
         run_block(step, batches, 0, n)
         straight = digest(step)
