@@ -88,8 +88,10 @@ def parse():
                     "(rgb_values, depth_values, normal_map: train.py:419-424, eval_spurfies.py:282-287; PointVolSDF.eval_keys), reference = every key of the reference's "
                     "forward (adds the pseudo-point pass, the TV term and the per-slot plot maps)")
     ap.add_argument("--sweep-resolution", type=int, default=512, help="eval mode: samples along the shortest axis of the mesh-extraction grid (the reference: 512); 0 = skip")
-    ap.add_argument("--geo-engine", choices=["auto", "split", "split_w"], default="auto", help="MFMA shape of the dominant kernel: 16x16x32 (split), 32x32x16 "
-                    "(split_w), or auto = time both on this box before the warm-up steps (TrainStep.autotune_geo_engine) and keep the faster")
+    ap.add_argument("--geo-engine", choices=["auto", "split", "split_w", "h2"], default="h2", help="arithmetic / MFMA shape of the dominant kernel: six bf16 piece "
+                    "products per fp32 product on 16x16x32 (split) or 32x32x16 tiles (split_w); three fp16 piece products on 32x32x16 tiles (h2: two fp16 pieces per "
+                    "operand, 22 mantissa bits, same measured error against float64 as the fp32-MFMA kernel: tools/engine_accuracy.py — the DEFAULT since round 6); auto = "
+                    "time the two bf16 shapes on this box before the warm-up steps (TrainStep.autotune_geo_engine) and keep the faster of THOSE")
     ap.add_argument("--ab-reps", type=int, default=10, help="forward+backward passes per leg of the A B B A engine comparison after the timed region (0 = skip)")
     return ap.parse_args()
 
@@ -682,7 +684,7 @@ def measure_train(args, ctx, w):
             "finish_what": "HIP events on rank 0's compute stream around BucketedAllReduce.finish() (launch of the last bucket + wait for all): "
                            "the part of the exchange not hidden behind the backward"})
     loss_last = float(losses["loss"].item())
-    clk = ops.geo_clock(reset=True).get((engine, True))       # the clock the chip held under the dominant kernel DURING the timed region
+    clk = ops.geo_clock(reset=True).get(("split_w" if engine == "h2" else engine, True))       # the clock the chip held under the dominant kernel DURING the timed region (h2 = the 32x32x16 kernel: its counter slot)
     if use_graph and a.scenes == 1:
         # events cannot be placed inside a hipGraph replay: time the dominant kernel over eager forward+backward passes of
         # the SAME batches right after the timed region (same kernels, same inputs; no optimiser step)
@@ -735,7 +737,7 @@ def measure_train(args, ctx, w):
         elif not (rec["config"].get("points") == a.points and rec["config"].get("rays") == rays_local and rec["config"].get("prior", "kaiming") == a.prior):
             traffic_src = f"profiles/{name} is of this code but of another workload ({rec['config']}): not quoted"
         else:
-            want = "geo_pairs_x3_kernel<true>" if ops.geo_mode() == "split" else "geo_pairs_x3w_kernel<true>"
+            want = "geo_pairs_x3_kernel<true>" if ops.geo_mode() == "split" else ("geo_pairs_x3w_kernel<true, 2, true>" if ops.geo_mode() == "h2" else "geo_pairs_x3w_kernel<true, 3, false>")
             hit = [v for k, v in rec["kernels"].items() if want in k] or [v for k, v in rec["kernels"].items() if "geo_pairs_x3" in k and "<true>" in k]
             if hit:
                 traffic = hit[0]["hbm_bytes_max_corrected"]
@@ -745,14 +747,18 @@ def measure_train(args, ctx, w):
         ms = sum(p["ms"] for p in main_)
         pairs = sum(p["pairs"] for p in main_)
         ach = pairs * (F_FWD + F_JAC) / (ms * 1e-3) / 1e12
-        kname = "geo_pairs_x3_kernel<true>" if engine == "split" else "geo_pairs_x3w_kernel<true>"
-        shape = "v_mfma_f32_16x16x32_bf16" if engine == "split" else "v_mfma_f32_32x32x16_bf16"
-        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
-                "peak_basis": f"algorithmic fp32 FLOP/s; each fp32 product = 6 exact bf16 piece products on the bf16 matrix pipe (this run: {shape}), so the "
-                              "ceiling is the dense bf16 MFMA peak (2516.6 TFLOP/s) / 6; for scale, the fp32-MFMA peak is 157.3 TFLOP/s",
+        kname = "geo_pairs_x3_kernel<true>" if engine == "split" else ("geo_pairs_x3w_kernel<true, 2, true>" if engine == "h2" else "geo_pairs_x3w_kernel<true, 3, false>")
+        shape = "v_mfma_f32_16x16x32_bf16" if engine == "split" else ("v_mfma_f32_32x32x16_f16" if engine == "h2" else "v_mfma_f32_32x32x16_bf16")
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if engine == "h2" else PEAK_SPLIT_TFLOPS
+        roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "peak_basis": (f"algorithmic fp32 FLOP/s; each fp32 product = 3 exact fp16 piece products (two fp16 pieces per operand, main + cross accumulators) on the "
+                               f"matrix pipe (this run: {shape}), so the ceiling is the dense fp16 MFMA peak (2516.6 TFLOP/s) / 3; for scale, the fp32-MFMA peak is 157.3 TFLOP/s"
+                               if engine == "h2" else
+                               f"algorithmic fp32 FLOP/s; each fp32 product = 6 exact bf16 piece products on the bf16 matrix pipe (this run: {shape}), so the "
+                               "ceiling is the dense bf16 MFMA peak (2516.6 TFLOP/s) / 6; for scale, the fp32-MFMA peak is 157.3 TFLOP/s"),
                 "achieved_over_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                 "sustainable": None if light else sustainable_ceiling(ach),
-                "held_clock": held_clock(ach, clk),
+                "held_clock": held_clock(ach, clk, peak),
                 "engine": {"selected": engine, "mfma": shape, "how": ("timed both shapes on this box after 40 untimed passes, before the warm-up steps (main-pass launch; the shape alternates every pass, A B B A x 10)" if tune else ("the main record's choice" if light else "--geo-engine")),
                            "autotune_ms": tune},
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": kname + " (+ geo_point_reduce_kernel, < 1 % of the launch)",
@@ -786,7 +792,11 @@ def measure_train(args, ctx, w):
                    "settle_steps_untimed": settle, "settle_seconds": args.settle,
                    "sampler_draws": "CPU generator, reference call order" + ("" if world == 1 else ("; batch-wide per rank, own rows kept (--exact-draws)" if a.exact_draws
                                                                                                    else "; per-rank streams, own rays only")),
-                   "arithmetic": "fp32 throughout; every MLP kernel (geometry, colour trunk, per-point head) and the weight-gradient GEMMs form each fp32 product from three bf16 pieces per operand (6 exact bf16 piece products, fp32 accumulate: fp32-class, <= 2 ulp per product)",
+                   "arithmetic": ("fp32 storage and accumulation throughout. Geometry kernel (engine h2): every fp32 operand as two fp16 pieces (22 mantissa bits), each fp32 product = 3 exact "
+                                  "fp16 piece products in two fp32 accumulators (main + 2^-11 x cross) — measured error against float64 equal to the fp32-MFMA kernel's (tools/engine_accuracy.py: SDF "
+                                  "1.1e-7 rms relative for f32 / bf16 x 3 / h2 alike). " if engine == "h2" else "fp32 storage and accumulation throughout. ") +
+                                 "Colour trunk, per-point head and the weight-gradient GEMMs" + ("" if engine == "h2" else ", and the geometry kernel,") +
+                                 " form each fp32 product from three bf16 pieces per operand (6 exact bf16 piece products: fp32-class, <= 2 ulp per product)",
                    "launch": launch},
         "roofline": roof, "dist": dinfo,
         "sustained_ms_per_step": sustained, "sustained_steps": n_sust if sustained is not None else 0,
@@ -927,28 +937,31 @@ def sustainable_ceiling(achieved_tflops):
                       "(csrc sha256 matches), committed; not measured in this run"}
 
 
-def held_clock(achieved_tflops, clk):
+def held_clock(achieved_tflops, clk, peak=None):
     """The shader clock the dominant kernel HELD inside the timed region, measured by the kernel itself (s_memtime / s_memrealtime stamps
     of every workgroup, spf_geo_clock_read) in this run, and the roofline fraction at that clock."""
     if not clk:
         return None
     ghz = clk["ghz"]
-    return {"ghz": ghz, "nominal_ghz": 2.4, "peak_at_held_clock": PEAK_SPLIT_TFLOPS * ghz / 2.4, "frac_at_held_clock": achieved_tflops / (PEAK_SPLIT_TFLOPS * ghz / 2.4),
+    peak = peak or PEAK_SPLIT_TFLOPS
+    return {"ghz": ghz, "nominal_ghz": 2.4, "peak_at_held_clock": peak * ghz / 2.4, "frac_at_held_clock": achieved_tflops / (peak * ghz / 2.4),
             "workgroups": clk["workgroups"], "mean_us_per_workgroup": clk["mean_us_per_workgroup"],
             "source": "measured in this run: in-kernel s_memtime / s_memrealtime stamps of every workgroup of the dominant kernel's launches in the timed region "
                       "(spf_geo_clock_read); `frac` above stays priced at 2.4 GHz"}
 
 
 def engine_ab(step, batches, first, reps, rays_local, sync):
-    """Both MFMA shapes of the dominant kernel on the SAME batches in this process, after the timed regions: legs A B B A of `reps`
-    forward + backward passes each (no optimiser step: every leg sees the same parameters and pair counts), main-pass launch timed with HIP
-    events, clock read from the kernels' own counters."""
+    """Two arithmetic modes of the dominant kernel on the SAME batches in this process, after the timed regions — the run's own (h2: three fp16 piece
+    products per fp32 product) against the six-product bf16 kernel on the same 32x32x16 tiles, or, for a bf16 run, the two bf16 MFMA shapes: legs A B B A of
+    `reps` forward + backward passes each (no optimiser step: every leg sees the same parameters and pair counts), main-pass launch timed with HIP events,
+    clock read from the kernels' own counters."""
     from spurfies_amd import ops
 
     prev = ops.geo_mode()
-    acc = {"split": {"ms": 0.0, "pairs": 0.0, "n": 0, "cyc": 0.0, "ticks": 0.0}, "split_w": {"ms": 0.0, "pairs": 0.0, "n": 0, "cyc": 0.0, "ticks": 0.0}}
+    A, B = ("h2", "split_w") if prev == "h2" else ("split", "split_w")
+    acc = {A: {"ms": 0.0, "pairs": 0.0, "n": 0, "cyc": 0.0, "ticks": 0.0}, B: {"ms": 0.0, "pairs": 0.0, "n": 0, "cyc": 0.0, "ticks": 0.0}}
     try:
-        for mode in ("split", "split_w", "split_w", "split"):
+        for mode in (A, B, B, A):
             ops.set_geo_mode(mode)
             step._forward_backward(dict(batches[first % len(batches)][0]), batches[first % len(batches)][1])
             ops.geo_clock(reset=True)
@@ -958,7 +971,7 @@ def engine_ab(step, batches, first, reps, rays_local, sync):
                 step._forward_backward(dict(b[0]), b[1])
             sync()
             rows = [p for p in ops.profile_stop() if p["with_grad"] and p["rows"] >= 2 * rays_local]
-            c = ops.geo_clock(reset=True).get((mode, True))
+            c = ops.geo_clock(reset=True).get(("split_w" if mode == "h2" else mode, True))
             a = acc[mode]
             a["ms"] += sum(p["ms"] for p in rows)
             a["pairs"] += sum(p["pairs"] for p in rows)
@@ -969,14 +982,15 @@ def engine_ab(step, batches, first, reps, rays_local, sync):
     finally:
         ops.set_geo_mode(prev)
     out = {"order": "A B B A, %d forward+backward passes per leg on the timed batches, after the timed regions" % reps}
-    for mode, shape in (("split", "v_mfma_f32_16x16x32_bf16"), ("split_w", "v_mfma_f32_32x32x16_bf16")):
+    shapes = {"split": ("v_mfma_f32_16x16x32_bf16", 6.0), "split_w": ("v_mfma_f32_32x32x16_bf16", 6.0), "h2": ("v_mfma_f32_32x32x16_f16", 3.0)}
+    for mode in (A, B):
         a = acc[mode]
         if a["n"]:
             ach = a["pairs"] * (F_FWD + F_JAC) / (a["ms"] * 1e-3) / 1e12
-            out[mode] = {"mfma": shape, "avg_ms": a["ms"] / a["n"], "pairs_per_launch": a["pairs"] / a["n"], "achieved": ach, "frac": ach / PEAK_SPLIT_TFLOPS,
-                         "held_ghz": (a["cyc"] / a["ticks"]) if a["ticks"] else None, "launches": a["n"]}
-    if "split" in out and "split_w" in out:
-        out["faster"] = min(("split", "split_w"), key=lambda m: out[m]["avg_ms"])
+            out[mode] = {"mfma": shapes[mode][0], "piece_products_per_fp32_product": int(shapes[mode][1]), "avg_ms": a["ms"] / a["n"], "pairs_per_launch": a["pairs"] / a["n"],
+                         "achieved": ach, "frac": ach / (PEAK_BF16_MFMA_TFLOPS / shapes[mode][1]), "held_ghz": (a["cyc"] / a["ticks"]) if a["ticks"] else None, "launches": a["n"]}
+    if A in out and B in out:
+        out["faster"] = min((A, B), key=lambda m: out[m]["avg_ms"])
     return out
 
 

@@ -187,6 +187,11 @@ int spf_compact_pairs_filter(const uint8_t* slot_valid, const int32_t* nbr, int3
 #define SPF_ARITH_SPLIT 0
 #define SPF_ARITH_F32 1
 #define SPF_ARITH_SPLIT_W 2
+/* ABI 6 — spf_geo_forward only: "H2" arithmetic on v_mfma_f32_32x32x16_f16 — every fp32 operand as TWO fp16 pieces x = h1 + 2^-11 h2 (22 mantissa
+ * bits), a product = h1 g1 (main accumulator) + 2^-11 (h1 g2 + h2 g1) (second accumulator, scaled once per layer), every piece product exact in
+ * the fp32 accumulation: three matrix instructions per product instead of six.  |error| <= 3 x 2^-22 (7e-7) of a product (bf16 x 3: ~2e-7;
+ * fp32: 6e-8); operand range is fp16's (|x| < 65504; below 6e-5 an absolute accuracy of 1.5e-11).  The same kernel as SPF_ARITH_SPLIT_W otherwise. */
+#define SPF_ARITH_H2 3
 /* spf_geo_forward only, OR-ed into arith: the bf16-piece kernels of THIS launch stamp the held-clock counters (spf_geo_clock_read).  Without
  * the bit a launch touches no state outside its arguments. */
 #define SPF_ARITH_CLOCK 0x100

@@ -898,9 +898,11 @@ constexpr int XW_BW2 = XW_BW3 + XW_SZH;
 constexpr int XW_JW1 = XW_BW2 + XW_SZH;
 constexpr int XW_FRAGS = XW_JW1 + XW_SZJ;
 constexpr int XW_BASE = PACKED_FLOATS + 4 * X3_FRAGS;          // float offset of this engine's fragments inside the packed image
-constexpr int PACKED_TOTAL = XW_BASE + 4 * XW_FRAGS;
+constexpr int XH_BASE = XW_BASE + 4 * XW_FRAGS;                 // the same regions as fp16 piece pairs (H2 arithmetic): slot 2 of a triple unused
+constexpr int PACKED_TOTAL = XH_BASE + 4 * XW_FRAGS;
 
-// one thread per fragment slot (region, wave, k16, m, lane): 8 weights -> 3 x bf16x8
+// one thread per fragment slot (region, wave, k16, m, lane): 8 weights -> 3 x bf16x8, or (H2) 2 x f16x8 in the same slots
+template <bool H2>
 __global__ void geo_pack_x3w_kernel(PackArgs a, bf16x8* __restrict__ out) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr int N1 = XW_SZ1 / 3, NH = XW_SZH / 3, NJ = XW_SZJ / 3;
@@ -943,6 +945,18 @@ __global__ void geo_pack_x3w_kernel(PackArgs a, bf16x8* __restrict__ out) {
         }
         base = (size_t)XW_JW1 + (size_t)(m * XW_TH + t) * 3 * 64 + ln;
     }
+    if (H2) {
+        f16x8 h1, h2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h1[e] = (_Float16)w[e];
+            h2[e] = (_Float16)((w[e] - (float)h1[e]) * 2048.0f);
+        }
+        out[base] = __builtin_bit_cast(bf16x8, h1);
+        out[base + 64] = __builtin_bit_cast(bf16x8, h2);
+        out[base + 128] = bf16x8{};
+        return;
+    }
     bf16x8 p1, p2, p3;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -976,7 +990,7 @@ __device__ __forceinline__ Bias3 load_bias3(gfp bias, int wave, int lane) {
 // MODE 1 (last layer): sdf partial sums s[n] += v . a, and the planes receive the Jacobian seed v * lrelu'(h) instead.
 // (round 5 tried fewer vector instructions here — v_max LeakyReLU, sign bits four at a time from the top pieces, the bias as the first product's
 // C operand: a measured null result, profiles/r05_epilogue_ab.json; removed in round 6, the record stays)
-template <int MODE, bool WITH_JAC, int NT = 2>
+template <int MODE, bool WITH_JAC, int NT = 2, bool H2 = false>
 __device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][NT], const Bias3& bias, const Bias3& v5, int wave, int lane,
                                                 uint32_t (&mask)[NT], float (&s)[NT]) {
     const int j = lane & 31, kg = lane >> 5;
@@ -1009,13 +1023,13 @@ __device__ __forceinline__ void fwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
                         out[e] = lrelu_push(h[e], hs[e], mask[n]);
                     }
                 }
-                if (MODE == 0 || WITH_JAC) store_quad_x3(X, 32 * n + j, f0, out);
+                if (MODE == 0 || WITH_JAC) store_quad_xh<H2, X3_LDP>(X, 32 * n + j, f0, out);
             }
         }
 }
 
 // backward epilogue: g_h = g_a * lrelu'(h) -> planes (pops the words the forward epilogue filled, in the same order)
-template <int NT = 2>
+template <int NT = 2, bool H2 = false>
 __device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2][NT], int wave, int lane, const uint32_t (&mask_in)[NT]) {
     const int j = lane & 31, kg = lane >> 5;
     uint32_t mask[NT];
@@ -1033,7 +1047,7 @@ __device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
                 f32x4 out;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], mask[n]);
-                store_quad_x3(X, 32 * n + j, f0, out);
+                store_quad_xh<H2, X3_LDP>(X, 32 * n + j, f0, out);
             }
         }
 }
@@ -1043,7 +1057,21 @@ __device__ __forceinline__ void bwd_epilogue_x3(__bf16* X, const f32x16 (&acc)[2
 // pairs — the weights stream as for a 64-row tile (the k-step becomes L1-fill-bound instead of matrix-pipe-bound: mlp_tile_x3.h), so a tile
 // takes ~55 % of a full one's time and twice as many workgroups have work: chosen by the kernel when all the launch's pairs fit ONE pass of
 // half tiles over the grid (the sampler pass and the pseudo-point pass of a 128-ray step: 64 resp. 16 full tiles on a 256-CU chip).
-template <bool WITH_JAC, int NT, int NPC = 3>
+// a layer's GEMM on the engine the body was built for: bf16 pieces (one accumulator), or H2 (main + cross accumulators, combined here)
+template <int T, int NT, int NPC, bool H2, int NC>
+__device__ __forceinline__ WFrag3 gemm_xh(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][NT], const WFrag3& first, gx3 next_wp,
+                                          f32x16 (&accc)[2][NC]) {
+    if constexpr (H2) {
+        static_assert(NC == NT, "H2: one cross accumulator per main accumulator");
+        const WFrag3 nf = gemm_x3<T, false, X3_LDP, NT, 2, true>(X, wp, lane, acc, first, next_wp, accc);
+        h2_combine<NT>(acc, accc);
+        return nf;
+    } else {
+        return gemm_x3<T, false, X3_LDP, NT, NPC>(X, wp, lane, acc, first, next_wp);
+    }
+}
+
+template <bool WITH_JAC, int NT, int NPC = 3, bool H2 = false>
 __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                              const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off,
                                              const int32_t* __restrict__ pair_point, const int NP, const int q0, int k, const float* __restrict__ pts,
@@ -1069,7 +1097,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gfp pf = launder(packed0);
-        gx3 frag = reinterpret_cast<gx3>(pf + XW_BASE);
+        gx3 frag = reinterpret_cast<gx3>(pf + (H2 ? XH_BASE : XW_BASE));
         gx3 w_fw1 = frag + XW_FW1 + wave * (XW_T1 * 2 * 3 * 64) + lane;
         const WFrag3 fr1 = load_wfrag3(w_fw1);                  // in flight during the gather
         T_MARK(31)
@@ -1079,8 +1107,8 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         if (row0 < ROWS) {
             const int q = tile * ROWS + row0;
             const float lo[4] = {cur.f0[0], cur.f0[1], cur.f0[2], cur.f0[3]}, hi[4] = {cur.f1[0], cur.f1[1], cur.f1[2], cur.f1[3]};
-            store_quad_x3(X, row0, q40 * 8, lo);
-            store_quad_x3(X, row0, q40 * 8 + 4, hi);
+            store_quad_xh<H2, X3_LDP>(X, row0, q40 * 8, lo);
+            store_quad_xh<H2, X3_LDP>(X, row0, q40 * 8 + 4, hi);
             if (q40 == 0) {
                 float d[4] = {cur.d[0], cur.d[1], cur.d[2], 0.f};
                 if (cur.idx >= 0) {
@@ -1088,11 +1116,11 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
                     const float sc = dist * rbf;
                     pair_tmp[(size_t)q * PT_STRIDE] = expf(-(sc * sc));
                 }
-                store_quad_x3(X, row0, 32, d);
+                store_quad_xh<H2, X3_LDP>(X, row0, 32, d);
                 const float z[4] = {0.f, 0.f, 0.f, 0.f};
-                store_quad_x3(X, row0, 36, z);
-                store_quad_x3(X, row0, 40, z);
-                store_quad_x3(X, row0, 44, z);
+                store_quad_xh<H2, X3_LDP>(X, row0, 36, z);
+                store_quad_xh<H2, X3_LDP>(X, row0, 40, z);
+                store_quad_xh<H2, X3_LDP>(X, row0, 44, z);
             }
         }
         const int qn = (tile + (int)gridDim.x) * ROWS + row0;     // this thread's row in the workgroup's next tile
@@ -1102,6 +1130,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         T_MARK(1)
 
         f32x16 acc[2][NT];
+        f32x16 accc[2][H2 ? NT : 1];          // H2: the cross terms' accumulators
         uint32_t m1[NT], m2[NT], m3[NT], m4[NT];
         float ssum[NT];
 #pragma unroll
@@ -1112,11 +1141,11 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
         gx3 w_bw3 = frag + XW_BW3 + wave * (XW_TH * 2 * 3 * 64) + lane, w_bw2 = frag + XW_BW2 + wave * (XW_TH * 2 * 3 * 64) + lane;
         Bias3 bias = load_bias3(pf + OFF_B1, wave, lane);
         WFrag3 nf;
-        nf = gemm_x3<XW_T1, false, X3_LDP, NT, NPC>(X, w_fw1, lane, acc, fr1, w_fw2);
+        nf = gemm_xh<XW_T1, NT, NPC, H2>(X, w_fw1, lane, acc, fr1, w_fw2, accc);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC, NT>(X, acc, bias, bias, wave, lane, m1, ssum);
+        fwd_epilogue_x3<0, WITH_JAC, NT, H2>(X, acc, bias, bias, wave, lane, m1, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
@@ -1125,33 +1154,33 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
             n_off = pair_off[n_p];
         }
         bias = load_bias3(pf + OFF_B2, wave, lane);
-        nf = gemm_x3<XW_TH, false, X3_LDP, NT, NPC>(X, w_fw2, lane, acc, nf, w_fw3);
+        nf = gemm_xh<XW_TH, NT, NPC, H2>(X, w_fw2, lane, acc, nf, w_fw3, accc);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC, NT>(X, acc, bias, bias, wave, lane, m2, ssum);
+        fwd_epilogue_x3<0, WITH_JAC, NT, H2>(X, acc, bias, bias, wave, lane, m2, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn + q0 - n_off)];
         bias = load_bias3(pf + OFF_B3, wave, lane);
-        nf = gemm_x3<XW_TH, false, X3_LDP, NT, NPC>(X, w_fw3, lane, acc, nf, w_fw4);
+        nf = gemm_xh<XW_TH, NT, NPC, H2>(X, w_fw3, lane, acc, nf, w_fw4, accc);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        fwd_epilogue_x3<0, WITH_JAC, NT>(X, acc, bias, bias, wave, lane, m3, ssum);
+        fwd_epilogue_x3<0, WITH_JAC, NT, H2>(X, acc, bias, bias, wave, lane, m3, ssum);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
         cur = gx_fetch_row(n_idx, n_srow, q40, x, pts, feat_geo);
         bias = load_bias3(pf + OFF_B4, wave, lane);
         const Bias3 v5q = load_bias3(pf + OFF_V5, wave, lane);       // folded last layer v = T W8, same quads: requested ahead of the GEMM too
-        nf = gemm_x3<XW_TH, false, X3_LDP, NT, NPC>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr);
+        nf = gemm_xh<XW_TH, NT, NPC, H2>(X, w_fw4, lane, acc, nf, WITH_JAC ? w_bw4 : nullptr, accc);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
         // last forward layer: sdf_j = v . a4 + c from the accumulators; the planes receive the Jacobian seed v * lrelu'(h4)
-        fwd_epilogue_x3<1, WITH_JAC, NT>(X, acc, bias, v5q, wave, lane, m4, ssum);
+        fwd_epilogue_x3<1, WITH_JAC, NT, H2>(X, acc, bias, v5q, wave, lane, m4, ssum);
         {
             const int j = lane & 31, kg = lane >> 5;
 #pragma unroll
@@ -1170,36 +1199,36 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
 
         if (WITH_JAC) {
             // ---- Jacobian sweep: g_a3 = g_h4 W6 ; g_h3 = g_a3 * D3 ; ... ; J = g_h1 W0 ------------------------------------------
-                        nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_bw4, lane, acc, nf, w_bw3);
+                        nf = gemm_xh<XW_TH, NT, (H2 ? 2 : 3), H2>(X, w_bw4, lane, acc, nf, w_bw3, accc);
             T_MARK(10)
             lds_barrier();
             T_MARK(11)
-            bwd_epilogue_x3<NT>(X, acc, wave, lane, m3);
+            bwd_epilogue_x3<NT, H2>(X, acc, wave, lane, m3);
             T_MARK(12)
             lds_barrier();
             T_MARK(13)
-                        nf = gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_bw3, lane, acc, nf, w_bw2);
+                        nf = gemm_xh<XW_TH, NT, (H2 ? 2 : 3), H2>(X, w_bw3, lane, acc, nf, w_bw2, accc);
             T_MARK(10)
             lds_barrier();
             T_MARK(11)
-            bwd_epilogue_x3<NT>(X, acc, wave, lane, m2);
+            bwd_epilogue_x3<NT, H2>(X, acc, wave, lane, m2);
             T_MARK(12)
             lds_barrier();
             T_MARK(13)
-                        gemm_x3<XW_TH, false, X3_LDP, NT>(X, w_bw2, lane, acc, nf, nullptr);
+                        gemm_xh<XW_TH, NT, (H2 ? 2 : 3), H2>(X, w_bw2, lane, acc, nf, nullptr, accc);
             T_MARK(10)
             gx3 w_jw1 = frag + XW_JW1 + (wave >> 1) * (XW_TH * 3 * 64) + lane;
             const WFrag1 frj = load_wfrag1(w_jw1);
             lds_barrier();
             T_MARK(11)
-            bwd_epilogue_x3<NT>(X, acc, wave, lane, m1);
+            bwd_epilogue_x3<NT, H2>(X, acc, wave, lane, m1);
             T_MARK(12)
             lds_barrier();
             T_MARK(13)
             // last step 256 -> 35 (padded 64): wave = (feature half m, row half n), one 32x32 tile each
             if (NT == 2 || (wave & 1) == 0) {                   // (half tiles: the two waves of the second row half have nothing to multiply)
                 const int m = wave >> 1, n = wave & 1, j = lane & 31, kg = lane >> 5;
-                const f32x16 aj = gemm_x3_tile<XW_TH>(X, n, w_jw1, lane, frj);
+                const f32x16 aj = gemm_x3_tile<XW_TH, X3_LDP, H2>(X, n, w_jw1, lane, frj);
                 const int q = tile * ROWS + 32 * n + j;
                 if (q < NP) {
                     if (m == 0) {
@@ -1221,7 +1250,7 @@ __device__ __forceinline__ void geo_x3w_body(__bf16* X, float (*red)[64], const 
     T_FLUSH
 }
 
-template <bool WITH_JAC, int NPC = 3>
+template <bool WITH_JAC, int NPC = 3, bool H2 = false>
 __global__ void __launch_bounds__(256, 1)
 geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ point_slot,
                     const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point, const int32_t* __restrict__ n_pairs_dev,
@@ -1238,16 +1267,16 @@ geo_pairs_x3w_kernel(const float* __restrict__ x, const int32_t* __restrict__ nb
     const int G = (int)gridDim.x;
     const int q_full = (NP / (64 * G)) * (64 * G), rem = NP - q_full;
     if (q_full > 0)
-        geo_x3w_body<WITH_JAC, 2, NPC>(X, red, x, nbr, point_slot, pair_off, pair_point, q_full, 0, k, pts, feat_geo, packed, rbf, pair_tmp, jac);
+        geo_x3w_body<WITH_JAC, 2, NPC, H2>(X, red, x, nbr, point_slot, pair_off, pair_point, q_full, 0, k, pts, feat_geo, packed, rbf, pair_tmp, jac);
     if (rem > 0) {
         const int32_t* pp = pair_point + q_full;
         float* pt = pair_tmp + (size_t)q_full * PT_STRIDE;
         float* jc = jac ? jac + (size_t)q_full * SPF_GEO_DIM : nullptr;
         if (q_full > 0) lds_barrier();          // (the first body's last tile is done with the planes)
         if (rem <= 32 * G)
-            geo_x3w_body<WITH_JAC, 1, NPC>(X, red, x, nbr, point_slot, pair_off, pp, rem, q_full, k, pts, feat_geo, packed, rbf, pt, jc);
+            geo_x3w_body<WITH_JAC, 1, NPC, H2>(X, red, x, nbr, point_slot, pair_off, pp, rem, q_full, k, pts, feat_geo, packed, rbf, pt, jc);
         else
-            geo_x3w_body<WITH_JAC, 2, NPC>(X, red, x, nbr, point_slot, pair_off, pp, rem, q_full, k, pts, feat_geo, packed, rbf, pt, jc);
+            geo_x3w_body<WITH_JAC, 2, NPC, H2>(X, red, x, nbr, point_slot, pair_off, pp, rem, q_full, k, pts, feat_geo, packed, rbf, pt, jc);
     }
     CLK_FLUSH(1, WITH_JAC ? 1 : 0)
 }
@@ -1281,7 +1310,8 @@ int spf_geo_pack(const float* w0, const float* b0, const float* w2, const float*
     PackArgs a{w0, b0, w2, b2, w4, b4, w6, b6, w8, b8, wT, bT};
     geo_pack_kernel<<<spf::div_up(PACKED_FLOATS, 256), 256, 0, (hipStream_t)stream>>>(a, packed);
     geo_pack_x3_kernel<<<spf::div_up(X3_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + PACKED_FLOATS));
-    geo_pack_x3w_kernel<<<spf::div_up(XW_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + XW_BASE));
+    geo_pack_x3w_kernel<false><<<spf::div_up(XW_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + XW_BASE));
+    geo_pack_x3w_kernel<true><<<spf::div_up(XW_FRAGS / 3, 256), 256, 0, (hipStream_t)stream>>>(a, reinterpret_cast<bf16x8*>(packed + XH_BASE));
     SPF_LAUNCH_CHECK("geo_pack_kernel");
     return SPF_OK;
 }
@@ -1293,10 +1323,11 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
     const int clk = (arith & SPF_ARITH_CLOCK) ? 1 : 0;      // opt-in held-clock stamps (spf_geo_clock_read); ignored by the fp32-MFMA twin
     const bool lite = (arith & SPF_ARITH_LITE) != 0;        // reduced products (two pieces per operand): SDF-only passes of the 32x32x16 engine
     arith &= ~(SPF_ARITH_CLOCK | SPF_ARITH_LITE);
-    if (lite && (arith != SPF_ARITH_SPLIT_W || grad || jac))
+    if (lite && arith == SPF_ARITH_H2) {      // (H2 already takes three products per fp32 product: nothing to reduce)
+    } else if (lite && (arith != SPF_ARITH_SPLIT_W || grad || jac))
         return spf::fail(SPF_EINVAL, "spf_geo_forward: SPF_ARITH_LITE goes with SPF_ARITH_SPLIT_W and an SDF-only pass (no grad / jac): its values steer the sampler, nothing else");
-    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32 && arith != SPF_ARITH_SPLIT_W)
-        return spf::fail(SPF_EINVAL, "spf_geo_forward: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_SPLIT_W (2) [| SPF_ARITH_CLOCK], got %d", arith);
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32 && arith != SPF_ARITH_SPLIT_W && arith != SPF_ARITH_H2)
+        return spf::fail(SPF_EINVAL, "spf_geo_forward: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1), SPF_ARITH_SPLIT_W (2) or SPF_ARITH_H2 (3) [| SPF_ARITH_CLOCK], got %d", arith);
     if (max_points < 0 || max_pairs < 0 || k < 1 || k > SPF_KMAX)
         return spf::fail(SPF_EINVAL, "spf_geo_forward: bad sizes (max_points=%d max_pairs=%d k=%d)", max_points, max_pairs, k);
     if (max_points == 0 || max_pairs == 0) return SPF_OK;
@@ -1316,6 +1347,15 @@ int spf_geo_forward(const float* x, const int32_t* nbr, const int32_t* point_slo
         else
             geo_pairs_x3_kernel<false><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
                                                           rbf, pair_tmp, nullptr, clk);
+    } else if (arith == SPF_ARITH_H2) {
+        const int half = spf::div_up(max_pairs, 32);
+        const int b1 = half < 256 ? half : 256;
+        if (grad)
+            geo_pairs_x3w_kernel<true, 2, true><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed, rbf,
+                                                                   pair_tmp, jac, clk);
+        else
+            geo_pairs_x3w_kernel<false, 2, true><<<b1, 256, 0, s>>>(x, nbr, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts, feat_geo, packed,
+                                                                    rbf, pair_tmp, nullptr, clk);
     } else if (arith == SPF_ARITH_SPLIT_W) {
         const int half = spf::div_up(max_pairs, 32);          // the kernel takes half-height (32-pair) tiles when they all fit one pass
         const int b1 = half < 256 ? half : 256;

@@ -10,6 +10,15 @@ namespace spf {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef const __attribute__((address_space(1))) bf16x8* gx3;
+// ---- "H2" arithmetic (round 6): an fp32 operand as TWO fp16 pieces, x = h1 + 2^-11 h2 with h1 = fp16(x), h2 = fp16((x - h1) 2^11) (both round to
+// nearest; the difference and the scaling are exact in fp32): 22 mantissa bits instead of fp32's 24.  A product takes THREE piece products — h1 g1
+// into the main accumulator, h1 g2 + h2 g1 into a second one that is scaled by 2^-11 once per layer (every piece product is exact in the MFMA's fp32
+// accumulation: 11 x 11 bits) — i.e. HALF the matrix instructions of the six-product bf16 scheme and two thirds of its operand bytes; the dropped
+// h2 g2 is <= 2^-22 of the product.  Per product: |error| <= 3 x 2^-22 ~ 7e-7 relative (bf16 x 3: ~ 2e-7; a true fp32 product: 6e-8).  Range is
+// fp16's: operands above 65504 overflow (no MLP activation of this model comes near), operands below 6e-5 keep an ABSOLUTE accuracy of 1.5e-11
+// (fp16 subnormals are honoured by the matrix pipe).  The pieces live in the same registers / LDS planes / fragment slots as bf16 pieces 0 and 1.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float H2_EPS = 1.0f / 2048.0f;
 
 constexpr int X3_LDP = 264;                       // plane row stride in bf16 (528 B: 16-B aligned, off the 256-B bank period)
 constexpr int X3_PLANE = 64 * X3_LDP;
@@ -58,8 +67,10 @@ struct X3Regs {
 // NPC = pieces per operand that take part: 3 = the fp32-class product (six piece products), 2 = the REDUCED product of round 6 (pieces 0 and 1
 // of both operands, products (1,0) (0,1) (0,0): ~16 mantissa bits, half the MFMAs and two thirds of the operand traffic) — offered to the
 // evaluation sampler's SDF-only passes only (include/spurfies_hip.h: SPF_ARITH_LITE), never to a pass whose values are rendered or differentiated.
-template <int R, bool LW, bool LX, int LN, bool SWAP = false, int LDP = X3_LDP, bool FIRST = false, int NT = 2, int NPC = 3>
-__device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 (&acc)[2][NT], X3Regs<NT>& r, WFrag3& nxt, gx3 next_wp) {
+template <int R, bool LW, bool LX, int LN, bool SWAP = false, int LDP = X3_LDP, bool FIRST = false, int NT = 2, int NPC = 3, bool H2 = false>
+__device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 (&acc)[2][NT], X3Regs<NT>& r, WFrag3& nxt, gx3 next_wp,
+                                        f32x16 (&accc)[2][NT]) {
+    static_assert(!H2 || (NPC == 2 && !SWAP), "H2: two fp16 pieces, transposed product");
     constexpr int R1 = (R + 1) % 3, R2 = (R + 2) % 3;
     if (LW) {
 #pragma unroll
@@ -106,11 +117,25 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.x[R][1][PX], r.w[R][1][PW], c11, 0, 0, 0);             \
         }                                                                                                              \
     }
-        if constexpr (NPC == 3) {
+#define SPF_H2(PW, PX, Z, A)                                                                                           \
+    {                                                                                                                  \
+        const f32x16 c00 = (Z) ? zero16 : A[0][0], c01 = (Z) ? zero16 : A[0][1], c10 = (Z) ? zero16 : A[1][0],             \
+                     c11 = (Z) ? zero16 : A[1][1];                                                                     \
+        const f16x8 w0_ = __builtin_bit_cast(f16x8, r.w[R][0][PW]), w1_ = __builtin_bit_cast(f16x8, r.w[R][1][PW]);      \
+        const f16x8 x0_ = __builtin_bit_cast(f16x8, r.x[R][0][PX]), x1_ = __builtin_bit_cast(f16x8, r.x[R][1][PX]);      \
+        A[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0_, x0_, c00, 0, 0, 0);                                        \
+        A[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0_, x1_, c01, 0, 0, 0);                                        \
+        A[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1_, x0_, c10, 0, 0, 0);                                        \
+        A[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1_, x1_, c11, 0, 0, 0);                                        \
+    }
+        if constexpr (H2) {         // cross terms into their own accumulator (scaled by 2^-11 once per layer), the main term into `acc`
+            SPF_H2(1, 0, FIRST, accc) SPF_H2(0, 1, false, accc) SPF_H2(0, 0, FIRST, acc)
+        } else if constexpr (NPC == 3) {
             SPF_X3(2, 0, FIRST) SPF_X3(0, 2, false) SPF_X3(1, 1, false) SPF_X3(1, 0, false) SPF_X3(0, 1, false) SPF_X3(0, 0, false)
         } else {
             SPF_X3(1, 0, FIRST) SPF_X3(0, 1, false) SPF_X3(0, 0, false)
         }
+#undef SPF_H2
 #undef SPF_X3
         // the requests ride between the MFMAs (issued in one block in front of them, their ~25 issue slots leave the matrix pipe idle
         // once per k-step): LDS reads first (needed at the start of the next k-step), then the L2 requests (needed one k-step later)
@@ -136,11 +161,21 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0][PW], r.x[R][0][PX], c0, 0, 0, 0);                  \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1][PW], r.x[R][0][PX], c1, 0, 0, 0);                  \
     }
-        if constexpr (NPC == 3) {
+#define SPF_H2H(PW, PX, Z, A)                                                                                          \
+    {                                                                                                                  \
+        const f32x16 c0 = (Z) ? zero16 : A[0][0], c1 = (Z) ? zero16 : A[1][0];                                           \
+        const f16x8 x0_ = __builtin_bit_cast(f16x8, r.x[R][0][PX]);                                                     \
+        A[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, r.w[R][0][PW]), x0_, c0, 0, 0, 0);   \
+        A[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, r.w[R][1][PW]), x0_, c1, 0, 0, 0);   \
+    }
+        if constexpr (H2) {
+            SPF_H2H(1, 0, FIRST, accc) SPF_H2H(0, 1, false, accc) SPF_H2H(0, 0, FIRST, acc)
+        } else if constexpr (NPC == 3) {
             SPF_X3H(2, 0, FIRST) SPF_X3H(0, 2, false) SPF_X3H(1, 1, false) SPF_X3H(1, 0, false) SPF_X3H(0, 1, false) SPF_X3H(0, 0, false)
         } else {
             SPF_X3H(1, 0, FIRST) SPF_X3H(0, 1, false) SPF_X3H(0, 0, false)
         }
+#undef SPF_H2H
 #undef SPF_X3H
         // 12 MFMAs carry 3 LDS reads and 6 L2 requests
         if (LX) {
@@ -161,8 +196,9 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int T, bool SWAP = false, int LDP = X3_LDP, int NT = 2, int NPC = 3>
-__device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][NT], const WFrag3& first, gx3 next_wp) {
+template <int T, bool SWAP = false, int LDP = X3_LDP, int NT = 2, int NPC = 3, bool H2 = false>
+__device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][NT], const WFrag3& first, gx3 next_wp,
+                                          f32x16 (&accc)[2][NT]) {
     static_assert(T >= 3, "gemm_x3: at least three k-steps");
     const int j = lane & 31, kg = lane >> 5;
     const __bf16* xp = X + j * LDP + 8 * kg;
@@ -182,26 +218,41 @@ __device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32
     constexpr int MAIN = T - 2, REM = MAIN % 3;        // k-steps that request weights; the last two only consume
     constexpr bool ZC = true;                          // C = 0 on the first product of the GEMM
     if (MAIN >= 3) {
-        x3_step<0, true, true, 0, SWAP, LDP, ZC, NT, NPC>(xp, wp, 0, acc, r, nxt, next_wp);
-        x3_step<1, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, 1, acc, r, nxt, next_wp);
-        x3_step<2, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, 2, acc, r, nxt, next_wp);
+        x3_step<0, true, true, 0, SWAP, LDP, ZC, NT, NPC, H2>(xp, wp, 0, acc, r, nxt, next_wp, accc);
+        x3_step<1, true, true, 0, SWAP, LDP, false, NT, NPC, H2>(xp, wp, 1, acc, r, nxt, next_wp, accc);
+        x3_step<2, true, true, 0, SWAP, LDP, false, NT, NPC, H2>(xp, wp, 2, acc, r, nxt, next_wp, accc);
 #pragma unroll 1
         for (int t = 3; t + 3 <= MAIN; t += 3) {
-            x3_step<0, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, t, acc, r, nxt, next_wp);
-            x3_step<1, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, t + 1, acc, r, nxt, next_wp);
-            x3_step<2, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, t + 2, acc, r, nxt, next_wp);
+            x3_step<0, true, true, 0, SWAP, LDP, false, NT, NPC, H2>(xp, wp, t, acc, r, nxt, next_wp, accc);
+            x3_step<1, true, true, 0, SWAP, LDP, false, NT, NPC, H2>(xp, wp, t + 1, acc, r, nxt, next_wp, accc);
+            x3_step<2, true, true, 0, SWAP, LDP, false, NT, NPC, H2>(xp, wp, t + 2, acc, r, nxt, next_wp, accc);
         }
     }
-    if (REM >= 1) x3_step<0, true, true, 0, SWAP, LDP, (ZC && MAIN < 3), NT, NPC>(xp, wp, MAIN - REM, acc, r, nxt, next_wp);
-    if (REM == 2) x3_step<1, true, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, MAIN - 1, acc, r, nxt, next_wp);
+    if (REM >= 1) x3_step<0, true, true, 0, SWAP, LDP, (ZC && MAIN < 3), NT, NPC, H2>(xp, wp, MAIN - REM, acc, r, nxt, next_wp, accc);
+    if (REM == 2) x3_step<1, true, true, 0, SWAP, LDP, false, NT, NPC, H2>(xp, wp, MAIN - 1, acc, r, nxt, next_wp, accc);
     if (next_wp) {
-        x3_step<REM, false, true, 1, SWAP, LDP, false, NT, NPC>(xp, wp, T - 2, acc, r, nxt, next_wp);
-        x3_step<(REM + 1) % 3, false, false, 2, SWAP, LDP, false, NT, NPC>(xp, wp, T - 1, acc, r, nxt, next_wp);
+        x3_step<REM, false, true, 1, SWAP, LDP, false, NT, NPC, H2>(xp, wp, T - 2, acc, r, nxt, next_wp, accc);
+        x3_step<(REM + 1) % 3, false, false, 2, SWAP, LDP, false, NT, NPC, H2>(xp, wp, T - 1, acc, r, nxt, next_wp, accc);
     } else {
-        x3_step<REM, false, true, 0, SWAP, LDP, false, NT, NPC>(xp, wp, T - 2, acc, r, nxt, next_wp);
-        x3_step<(REM + 1) % 3, false, false, 0, SWAP, LDP, false, NT, NPC>(xp, wp, T - 1, acc, r, nxt, next_wp);
+        x3_step<REM, false, true, 0, SWAP, LDP, false, NT, NPC, H2>(xp, wp, T - 2, acc, r, nxt, next_wp, accc);
+        x3_step<(REM + 1) % 3, false, false, 0, SWAP, LDP, false, NT, NPC, H2>(xp, wp, T - 1, acc, r, nxt, next_wp, accc);
     }
     return nxt;
+}
+// (the six- / three-product bf16 forms: one accumulator)
+template <int T, bool SWAP = false, int LDP = X3_LDP, int NT = 2, int NPC = 3>
+__device__ __forceinline__ WFrag3 gemm_x3(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][NT], const WFrag3& first, gx3 next_wp) {
+    return gemm_x3<T, SWAP, LDP, NT, NPC, false>(X, wp, lane, acc, first, next_wp, acc);
+}
+// H2: acc = main + 2^-11 cross, the layer's result in the layout every epilogue expects
+template <int NT>
+__device__ __forceinline__ void h2_combine(f32x16 (&acc)[2][NT], const f32x16 (&accc)[2][NT]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[m][n][q] = __builtin_fmaf(accc[m][n][q], H2_EPS, acc[m][n][q]);
 }
 
 // One 32x32 output tile per wave, D[m-th 32 weight rows][n-th 32 rows of X] over T k16-steps (the narrow last products: 256 ->
@@ -221,18 +272,26 @@ __device__ __forceinline__ WFrag1 load_wfrag1(gx3 wp) {
 struct X1Regs {
     bf16x8 w[3][3], x[3][3];
 };
-template <int R, bool LW, bool LX, int LDP = X3_LDP>
+template <int R, bool LW, bool LX, int LDP = X3_LDP, bool H2 = false>
 __device__ __forceinline__ void x1_step(const __bf16* xp, gx3 wp, int t, f32x16& lo, f32x16& hi, X1Regs& r) {
+    constexpr int NPC1 = H2 ? 2 : 3;
     constexpr int R1 = (R + 1) % 3, R2 = (R + 2) % 3;
     if (LW) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) r.w[R2][p] = wp[((t + 2) * 3 + p) * 64];
+        for (int p = 0; p < NPC1; ++p) r.w[R2][p] = wp[((t + 2) * 3 + p) * 64];
     }
     if (LX) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) r.x[R1][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 16 * (t + 1));
+        for (int p = 0; p < NPC1; ++p) r.x[R1][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP) + 16 * (t + 1));
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (H2) {          // lo = cross terms (scaled by the caller), hi = main term
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, r.w[R][1]), __builtin_bit_cast(f16x8, r.x[R][0]), lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, r.w[R][0]), __builtin_bit_cast(f16x8, r.x[R][0]), hi, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, r.w[R][0]), __builtin_bit_cast(f16x8, r.x[R][1]), lo, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
     lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][2], r.x[R][0], lo, 0, 0, 0);
     hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][1], r.x[R][0], hi, 0, 0, 0);
     lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.w[R][0], r.x[R][2], lo, 0, 0, 0);
@@ -242,7 +301,7 @@ __device__ __forceinline__ void x1_step(const __bf16* xp, gx3 wp, int t, f32x16&
     __builtin_amdgcn_sched_barrier(0);
 }
 // returns the tile in the accumulator layout (row_of / column = lane & 31)
-template <int T, int LDP = X3_LDP>
+template <int T, int LDP = X3_LDP, bool H2 = false>
 __device__ __forceinline__ f32x16 gemm_x3_tile(const __bf16* X, int n, gx3 wp, int lane, const WFrag1& pre) {
     static_assert(T >= 3 && (T - 2) % 3 != 0, "gemm_x3_tile: tail phases are written for (T - 2) mod 3 in {1, 2}");
     const int j = lane & 31, kg = lane >> 5;
@@ -252,7 +311,7 @@ __device__ __forceinline__ f32x16 gemm_x3_tile(const __bf16* X, int n, gx3 wp, i
 #pragma unroll
     for (int q = 0; q < 16; ++q) lo[q] = hi[q] = 0.f;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < (H2 ? 2 : 3); ++p) {
         r.w[0][p] = pre.w[0][p];
         r.w[1][p] = pre.w[1][p];
         r.x[0][p] = *reinterpret_cast<const bf16x8*>(xp + p * (64 * LDP));
@@ -261,16 +320,16 @@ __device__ __forceinline__ f32x16 gemm_x3_tile(const __bf16* X, int n, gx3 wp, i
     int t = 0;
 #pragma unroll 1
     for (; t + 3 <= MAIN; t += 3) {
-        x1_step<0, true, true, LDP>(xp, wp, t, lo, hi, r);
-        x1_step<1, true, true, LDP>(xp, wp, t + 1, lo, hi, r);
-        x1_step<2, true, true, LDP>(xp, wp, t + 2, lo, hi, r);
+        x1_step<0, true, true, LDP, H2>(xp, wp, t, lo, hi, r);
+        x1_step<1, true, true, LDP, H2>(xp, wp, t + 1, lo, hi, r);
+        x1_step<2, true, true, LDP, H2>(xp, wp, t + 2, lo, hi, r);
     }
-    if (REM >= 1) x1_step<0, true, true, LDP>(xp, wp, MAIN - REM, lo, hi, r);
-    if (REM == 2) x1_step<1, true, true, LDP>(xp, wp, MAIN - 1, lo, hi, r);
-    x1_step<REM, false, true, LDP>(xp, wp, T - 2, lo, hi, r);
-    x1_step<(REM + 1) % 3, false, false, LDP>(xp, wp, T - 1, lo, hi, r);
+    if (REM >= 1) x1_step<0, true, true, LDP, H2>(xp, wp, MAIN - REM, lo, hi, r);
+    if (REM == 2) x1_step<1, true, true, LDP, H2>(xp, wp, MAIN - 1, lo, hi, r);
+    x1_step<REM, false, true, LDP, H2>(xp, wp, T - 2, lo, hi, r);
+    x1_step<(REM + 1) % 3, false, false, LDP, H2>(xp, wp, T - 1, lo, hi, r);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) hi[q] += lo[q];
+    for (int q = 0; q < 16; ++q) hi[q] = H2 ? __builtin_fmaf(lo[q], H2_EPS, hi[q]) : hi[q] + lo[q];
     return hi;
 }
 
@@ -317,6 +376,27 @@ __device__ __forceinline__ void split3_pair(f32x2 a, uint32_t& c1, uint32_t& c2,
     c3 = cvt_pk_bf16(r2);
 }
 
+// H2: two floats -> (h1, h1') and (h2, h2') as packed fp16 pairs (round to nearest)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h_pair(f32x2 a, uint32_t& c1, uint32_t& c2) {
+    const f16x2 h = __builtin_convertvector(a, f16x2);
+    const f32x2 r = (a - __builtin_convertvector(h, f32x2)) * f32x2{2048.0f, 2048.0f};
+    c1 = __builtin_bit_cast(uint32_t, h);
+    c2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+// 4 consecutive features of one row: the two fp16 planes (the slots of bf16 pieces 0 and 1)
+template <int LDP = X3_LDP>
+__device__ __forceinline__ void store_quad_h2(__bf16* X, int row, int f0, f32x4 v) {
+    uint32_t a1, a2, b1, b2;
+    split2h_pair(f32x2{v[0], v[1]}, a1, a2);
+    split2h_pair(f32x2{v[2], v[3]}, b1, b2);
+    __bf16* dst = X + row * LDP + f0;
+    *reinterpret_cast<u32x2*>(dst) = u32x2{a1, b1};
+    *reinterpret_cast<u32x2*>(dst + (64 * LDP)) = u32x2{a2, b2};
+}
+template <bool H2, int LDP = X3_LDP>
+__device__ __forceinline__ void store_quad_xh(__bf16* X, int row, int f0, f32x4 v);
+
 // write 4 consecutive features of one row as three bf16 quads
 template <int LDP = X3_LDP>
 __device__ __forceinline__ void store_quad_x3(__bf16* X, int row, int f0, f32x4 v) {
@@ -331,6 +411,15 @@ __device__ __forceinline__ void store_quad_x3(__bf16* X, int row, int f0, f32x4 
 template <int LDP = X3_LDP>
 __device__ __forceinline__ void store_quad_x3(__bf16* X, int row, int f0, const float (&v)[4]) {
     store_quad_x3<LDP>(X, row, f0, f32x4{v[0], v[1], v[2], v[3]});
+}
+template <bool H2, int LDP>
+__device__ __forceinline__ void store_quad_xh(__bf16* X, int row, int f0, f32x4 v) {
+    if constexpr (H2) store_quad_h2<LDP>(X, row, f0, v);
+    else store_quad_x3<LDP>(X, row, f0, v);
+}
+template <bool H2, int LDP = X3_LDP>
+__device__ __forceinline__ void store_quad_xh(__bf16* X, int row, int f0, const float (&v)[4]) {
+    store_quad_xh<H2, LDP>(X, row, f0, f32x4{v[0], v[1], v[2], v[3]});
 }
 
 // LeakyReLU sign bits travel in 32-bit words filled from the top: push appends (h > 0) below the bits already there

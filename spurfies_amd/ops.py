@@ -374,13 +374,15 @@ class PairList:
 # Arithmetic of the MLP / weight-gradient kernels (include/spurfies_hip.h: SPF_ARITH_*), chosen per call; this table is host-side
 # state of the Python layer only — the C ABI itself keeps none.  'split' (default): fp32-class products (<= 2 ulp per product) from three bf16 pieces per
 # operand on the bf16 matrix pipe; 'f32': fp32 MFMA (the verification twin).
-_ARITH = {"geo": 0, "color": 0, "rhead": 0, "wgrad": 0}
+_ARITH = {"geo": 3, "color": 0, "rhead": 0, "wgrad": 0}        # geometry: H2 (round 6); the others: bf16 x 3
 _ARITH_NAMES = {"split": 0, "f32": 1}
-_GEO_ARITH_NAMES = {"split": 0, "f32": 1, "split_w": 2}     # 'split_w': the split arithmetic on 32x32x16 MFMA tiles (SPF_ARITH_SPLIT_W)
+_GEO_ARITH_NAMES = {"split": 0, "f32": 1, "split_w": 2, "h2": 3}     # 'split_w': the split arithmetic on 32x32x16 MFMA tiles; 'h2': two fp16 pieces (SPF_ARITH_H2)
 
 
 def set_geo_mode(mode: str):
-    """'split' (default: bf16-piece products on v_mfma_f32_16x16x32_bf16), 'split_w' (the same products on v_mfma_f32_32x32x16_bf16
+    """'h2' (default since round 6: two fp16 pieces per operand, three exact piece products per fp32 product on v_mfma_f32_32x32x16_f16 — the
+    same measured error against float64 as the fp32-MFMA kernel at half the matrix instructions of the bf16 scheme, tools/engine_accuracy.py),
+    'split' (six bf16-piece products on v_mfma_f32_16x16x32_bf16), 'split_w' (the same products on v_mfma_f32_32x32x16_bf16
     tiles — bench.py times both on the box it runs on) or 'f32' (fp32 MFMA, verification twin)."""
     _ARITH["geo"] = _GEO_ARITH_NAMES[mode]
 

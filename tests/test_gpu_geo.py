@@ -12,13 +12,14 @@ from tests.helpers import assert_close_except_kinks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["split", "split_w", "f32"])
+@pytest.fixture(params=["h2", "split", "split_w", "f32"])
 def geo_mode(request):
     from spurfies_amd import ops
 
+    prev = ops.geo_mode()
     ops.set_geo_mode(request.param)
     yield request.param
-    ops.set_geo_mode("split")
+    ops.set_geo_mode(prev)
 
 # fp32 tolerance: the MFMA k-ordered fma chain and the folded last layer (v = T.W8) re-associate
 # sums of ~256 terms; values are O(0.1).  Stated in DESIGN.md §tolerances.
@@ -281,13 +282,14 @@ def test_split_products_agree_with_fp32_mfma_kernel():
     ps, _, n = ops.compact_points(q["slot_valid"])
     pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), ps, n)
     res = {}
+    prev = ops.geo_mode()
     try:
-        for mode in ("f32", "split", "split_w"):
+        for mode in ("f32", "split", "split_w", "h2"):
             ops.set_geo_mode(mode)
             out = ops.geo_forward(xt, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, cfg.rbf, with_grad=True)
             res[mode] = {k: out[k].clone().cpu().numpy() for k in ("sdf", "grad", "wn", "jac")}
     finally:
-        ops.set_geo_mode("split")
+        ops.set_geo_mode(prev)
     np.testing.assert_allclose(res["split"]["sdf"], res["f32"]["sdf"], rtol=2e-6, atol=2e-7)
     np.testing.assert_array_equal(res["split"]["wn"], res["f32"]["wn"])
     assert_close_except_kinks(res["split"]["grad"], res["f32"]["grad"], rtol=2e-5, atol=2e-8, err_msg="d sdf / dx")
@@ -297,6 +299,11 @@ def test_split_products_agree_with_fp32_mfma_kernel():
     np.testing.assert_array_equal(res["split_w"]["wn"], res["split"]["wn"])
     assert_close_except_kinks(res["split_w"]["grad"], res["split"]["grad"], rtol=2e-5, atol=2e-8, err_msg="d sdf / dx (32x32x16 tiles)")
     assert_close_except_kinks(res["split_w"]["jac"], res["split"]["jac"], rtol=2e-5, atol=2e-8, err_msg="latent Jacobian (32x32x16 tiles)")
+    # H2 (round 6, the default): two fp16 pieces per operand, three piece products — against the fp32-MFMA kernel at the SAME bounds
+    np.testing.assert_allclose(res["h2"]["sdf"], res["f32"]["sdf"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_array_equal(res["h2"]["wn"], res["f32"]["wn"])
+    assert_close_except_kinks(res["h2"]["grad"], res["f32"]["grad"], rtol=2e-5, atol=2e-8, err_msg="d sdf / dx (H2)")
+    assert_close_except_kinks(res["h2"]["jac"], res["f32"]["jac"], rtol=2e-5, atol=2e-8, err_msg="latent Jacobian (H2)")
 
 
 def test_fixed_point_scatter_reports_non_finite_terms_out_of_band():
