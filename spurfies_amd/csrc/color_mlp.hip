@@ -444,7 +444,7 @@ __device__ __forceinline__ CxBias cx_load_bias(gfp bias, int wave, int lane) {
 // STORE also writes the activations to `tile_out`, the tile's K-MAJOR image (four blocks of [256 features][16 rows] fp32) the
 // weight-gradient GEMM reads (SPF_WGRAD_*_TILES): straight from the registers — for each of a lane's four features 16 lanes cover
 // 64 contiguous bytes — instead of a second pass that rebuilds fp32 rows from the planes.
-template <bool STORE>
+template <bool STORE, bool H2 = false>
 __device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], const CxBias& bias, int wave, int lane, uint32_t* masks_l,
                                                 float* __restrict__ tile_out) {
     const int j = lane & 31, kg = lane >> 5;
@@ -461,7 +461,7 @@ __device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2
                 f32x4 out;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[e] = lrelu_push(h[e], hs[e], bits[n]);
-                store_quad_x3(X, 32 * n + j, f0, out);
+                store_quad_xh<H2, X3_LDP>(X, 32 * n + j, f0, out);
                 if (STORE) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) tile_out[(2 * n + (j >> 4)) * 4096 + (f0 + e) * 16 + (j & 15)] = out[e];
@@ -534,7 +534,20 @@ __device__ __forceinline__ CxRow cx_fetch_row(int idx, int srow, int p, int q, i
 constexpr int CX_LDS_BF16 = 3 * X3_PLANE;
 constexpr int CX_LDL = 68;
 
-template <bool STORE>
+// a layer's GEMM on the colour kernels' engine: bf16 x 3 (one accumulator) or H2 (main + cross accumulators, combined here)
+template <int T, bool SWAP, bool H2, int NC>
+__device__ __forceinline__ WFrag3 cx_gemm(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][2], const WFrag3& first, gx3 next_wp, f32x16 (&accc)[2][NC]) {
+    if constexpr (H2) {
+        static_assert(NC == 2, "H2: one cross accumulator per main accumulator");
+        const WFrag3 nf = gemm_x3<T, SWAP, X3_LDP, 2, 2, true>(X, wp, lane, acc, first, next_wp, accc);
+        h2_combine<2>(acc, accc);
+        return nf;
+    } else {
+        return gemm_x3<T, SWAP>(X, wp, lane, acc, first, next_wp);
+    }
+}
+
+template <bool STORE, bool H2 = false>
 __global__ void __launch_bounds__(256, 1)
 color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
                         const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
@@ -563,7 +576,7 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gfp pf = launder(packed0);
-        gx3 frag = reinterpret_cast<gx3>(pf + C_PACKED);
+        gx3 frag = reinterpret_cast<gx3>(pf + (H2 ? CH_OFF : C_PACKED));
         gx3 w_fw1 = frag + CX_FW1 + wave * (CX_T1 * 2 * 3 * 64) + lane;
         gx3 w_fw2 = frag + CX_FW2 + wave * (CX_TH * 2 * 3 * 64) + lane;
         gx3 w_fw3 = frag + CX_FW3 + wave * (CX_TH * 2 * 3 * 64) + lane;
@@ -580,7 +593,7 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float v[4] = {cur.f[u][0], cur.f[u][1], cur.f[u][2], cur.f[u][3]};
-                store_quad_x3(X, row, q4 * 16 + 4 * u, v);
+                store_quad_xh<H2, X3_LDP>(X, row, q4 * 16 + 4 * u, v);
                 if (STORE) *reinterpret_cast<f32x4*>(a0 + q4 * 16 + 4 * u) = cur.f[u];
             }
 #pragma unroll
@@ -594,8 +607,8 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                         sv = sinf(a);
                         cv = cosf(a);
                     }
-                    store_one_x3(X, row, 64 + 3 + 6 * l + c, sv);
-                    store_one_x3(X, row, 64 + 6 + 6 * l + c, cv);
+                    store_one_xh<H2, X3_LDP>(X, row, 64 + 3 + 6 * l + c, sv);
+                    store_one_xh<H2, X3_LDP>(X, row, 64 + 6 + 6 * l + c, cv);
                     if (STORE) {
                         a0[64 + 3 + 6 * l + c] = sv;
                         a0[64 + 6 + 6 * l + c] = cv;
@@ -603,10 +616,10 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                 }
             }
             if (q4 == 0) {
-                store_one_x3(X, row, 64, cur.d[0]);
-                store_one_x3(X, row, 65, cur.d[1]);
-                store_one_x3(X, row, 66, cur.d[2]);
-                store_one_x3(X, row, 103, 0.f);          // pad column of the 104-wide internal layout
+                store_one_xh<H2, X3_LDP>(X, row, 64, cur.d[0]);
+                store_one_xh<H2, X3_LDP>(X, row, 65, cur.d[1]);
+                store_one_xh<H2, X3_LDP>(X, row, 66, cur.d[2]);
+                store_one_xh<H2, X3_LDP>(X, row, 103, 0.f);          // pad column of the 104-wide internal layout
                 if (STORE) {
                     a0[64] = cur.d[0];
                     a0[65] = cur.d[1];
@@ -614,8 +627,8 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
                     a0[103] = 0.f;
                 }
                 const float z[4] = {0.f, 0.f, 0.f, 0.f};
-                store_quad_x3(X, row, 104, z);           // K padded to 112
-                store_quad_x3(X, row, 108, z);
+                store_quad_xh<H2, X3_LDP>(X, row, 104, z);           // K padded to 112
+                store_quad_xh<H2, X3_LDP>(X, row, 108, z);
                 s_wp[2 * row] = cur.w;
                 s_wp[2 * row + 1] = __int_as_float(idx >= 0 ? cur.p : -1);
             }
@@ -627,13 +640,14 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
         T_MARK(1)
         uint32_t* mk = STORE ? masks + (size_t)tile * 3 * 512 : nullptr;                             // [layer 3][row 64][8 words]
         f32x16 acc[2][2];
+        f32x16 accc[2][H2 ? 2 : 1];        // H2: the cross terms' accumulators
         CxBias bias = cx_load_bias(pf + CO_B1, wave, lane);
         zero_acc(acc);
-        WFrag3 nf = gemm_x3<CX_T1>(X, w_fw1, lane, acc, fr1, w_fw2);
+        WFrag3 nf = cx_gemm<CX_T1, false, H2>(X, w_fw1, lane, acc, fr1, w_fw2, accc);
         T_MARK(2)
         lds_barrier();
         T_MARK(3)
-        cx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, mk, STORE ? act1 + (size_t)tile * 64 * 256 : nullptr);
+        cx_fwd_epilogue<STORE, H2>(X, acc, bias, wave, lane, mk, STORE ? act1 + (size_t)tile * 64 * 256 : nullptr);
         T_MARK(4)
         lds_barrier();
         T_MARK(5)
@@ -643,11 +657,11 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
         }
         bias = cx_load_bias(pf + CO_B2, wave, lane);
         zero_acc(acc);
-        nf = gemm_x3<CX_TH>(X, w_fw2, lane, acc, nf, w_fw3);
+        nf = cx_gemm<CX_TH, false, H2>(X, w_fw2, lane, acc, nf, w_fw3, accc);
         T_MARK(6)
         lds_barrier();
         T_MARK(7)
-        cx_fwd_epilogue<STORE>(X, acc, bias, wave, lane, STORE ? mk + 512 : nullptr, STORE ? act2 + (size_t)tile * 64 * 256 : nullptr);
+        cx_fwd_epilogue<STORE, H2>(X, acc, bias, wave, lane, STORE ? mk + 512 : nullptr, STORE ? act2 + (size_t)tile * 64 * 256 : nullptr);
         T_MARK(8)
         lds_barrier();
         T_MARK(9)
@@ -655,7 +669,7 @@ color_forward_x3_kernel(const float* __restrict__ x, const int32_t* __restrict__
         const float bv[2] = {pf[CO_B3 + 64 * wave + (lane & 31)], pf[CO_B3 + 64 * wave + (lane & 31) + 32]};     // layer-4 biases, ahead of the GEMM
         // ---- layer 4, NON-transposed: acc[m][n] = rows 32m.., features 64w + 32n..; lane (feature j, k-half kg) ------------------
         zero_acc(acc);
-        gemm_x3<CX_TH, true>(X, w_fw3, lane, acc, nf, nullptr);
+        cx_gemm<CX_TH, true, H2>(X, w_fw3, lane, acc, nf, nullptr, accc);
         T_MARK(10)
         cur = cx_fetch_row(n_idx, n_srow, n_p, qn, tid & 3, x, pts, feat_col, wn);      // lands during the epilogue
         // ---- + bias, LeakyReLU, sign words by ballot, RBF-weighted segmented sum from the accumulators -> atomics ---------------
@@ -950,17 +964,29 @@ int spf_color_forward(const float* x, const int32_t* nbr, const float* wn, const
                       const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* pts,
                       const float* feat_color, const float* packed, float* agg3, float* act0, float* act1, float* act2, uint32_t* masks,
                       int64_t* agg3_fixed, int32_t arith, void* stream) {
-    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_color_forward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32 && arith != SPF_ARITH_H2)
+        return spf::fail(SPF_EINVAL, "spf_color_forward: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_H2 (3), got %d", arith);
     if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_forward: bad sizes");
     if (max_pairs == 0) return SPF_OK;
     if (!x || !nbr || !wn || !pair_off || !pair_point || !pts || !feat_color || !packed || !agg3)
         return spf::fail(SPF_EINVAL, "spf_color_forward: null pointer");
     const bool store = act0 != nullptr;
     if (store && (!act1 || !act2 || !masks)) return spf::fail(SPF_EINVAL, "spf_color_forward: training buffers must be given together");
-    if (agg3_fixed && arith != SPF_ARITH_SPLIT) return spf::fail(SPF_EINVAL, "spf_color_forward: the fixed-point accumulator needs SPF_ARITH_SPLIT");
+    if (agg3_fixed && arith == SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_color_forward: the fixed-point accumulator needs SPF_ARITH_SPLIT or SPF_ARITH_H2");
     long long* afx = reinterpret_cast<long long*>(agg3_fixed);
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
+    if (arith == SPF_ARITH_H2) {
+        const int b1 = tiles < 256 ? tiles : 256;
+        if (store)
+            color_forward_x3_kernel<true, true><<<b1, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, pts,
+                                                                                     feat_color, packed, agg3, act0, act1, act2, masks, afx);
+        else
+            color_forward_x3_kernel<false, true><<<b1, 256, 0, (hipStream_t)stream>>>(x, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k,
+                                                                                      pts, feat_color, packed, agg3, nullptr, nullptr, nullptr, nullptr, afx);
+        SPF_LAUNCH_CHECK("color_forward_x3_kernel<H2>");
+        return SPF_OK;
+    }
     if (arith == SPF_ARITH_SPLIT) {
         const int b1 = tiles < 256 ? tiles : 256;   // one workgroup per CU (bf16 planes: 101 KB of LDS)
         if (store)

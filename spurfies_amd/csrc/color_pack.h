@@ -85,7 +85,8 @@ constexpr int CX_BW3 = CX_FW3 + CX_SZH;
 constexpr int CX_BW2 = CX_BW3 + CX_SZH;
 constexpr int CX_BWL = CX_BW2 + CX_SZH;
 constexpr int CX_FRAGS = CX_BWL + CX_SZL;
-constexpr int C_PACKED_TOTAL = C_PACKED + 4 * CX_FRAGS;
+constexpr int CH_OFF = C_PACKED + 4 * CX_FRAGS;                  // float offset of the SAME fragment image as fp16 piece pairs (H2 arithmetic; slot 2 unused)
+constexpr int C_PACKED_TOTAL = CH_OFF + 4 * CX_FRAGS;
 
 __device__ __forceinline__ void color_pack_x3_kernel_body(const CPackArgs& a, bf16x8* __restrict__ out, int s) {
     constexpr int N1 = CX_SZ1 / 3, NH = CX_SZH / 3, NL = CX_SZL / 3;
@@ -124,15 +125,20 @@ __device__ __forceinline__ void color_pack_x3_kernel_body(const CPackArgs& a, bf
         base = (size_t)CX_BWL + (size_t)(m * CX_TH + t) * 3 * 64 + ln;
     }
     bf16x8 p1, p2, p3;
+    f16x8 h1, h2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         __bf16 x, y, z;
         split3(w[e], x, y, z);
         p1[e] = x; p2[e] = y; p3[e] = z;
+        h1[e] = (_Float16)w[e];
+        h2[e] = (_Float16)((w[e] - (float)h1[e]) * 2048.0f);
     }
     out[base] = p1;
     out[base + 64] = p2;
     out[base + 128] = p3;
+    out[CX_FRAGS + base] = __builtin_bit_cast(bf16x8, h1);          // the H2 image: the same slots, two fp16 pieces
+    out[CX_FRAGS + base + 64] = __builtin_bit_cast(bf16x8, h2);
 }
 
 // the whole packed image (fp32 image + bf16-piece fragments) + an optional buffer to clear, for thread e of `nthreads`

@@ -70,7 +70,7 @@ struct X3Regs {
 template <int R, bool LW, bool LX, int LN, bool SWAP = false, int LDP = X3_LDP, bool FIRST = false, int NT = 2, int NPC = 3, bool H2 = false>
 __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 (&acc)[2][NT], X3Regs<NT>& r, WFrag3& nxt, gx3 next_wp,
                                         f32x16 (&accc)[2][NT]) {
-    static_assert(!H2 || (NPC == 2 && !SWAP), "H2: two fp16 pieces, transposed product");
+    static_assert(!H2 || NPC == 2, "H2: two fp16 pieces");
     constexpr int R1 = (R + 1) % 3, R2 = (R + 2) % 3;
     if (LW) {
 #pragma unroll
@@ -123,10 +123,17 @@ __device__ __forceinline__ void x3_step(const __bf16* xp, gx3 wp, int t, f32x16 
                      c11 = (Z) ? zero16 : A[1][1];                                                                     \
         const f16x8 w0_ = __builtin_bit_cast(f16x8, r.w[R][0][PW]), w1_ = __builtin_bit_cast(f16x8, r.w[R][1][PW]);      \
         const f16x8 x0_ = __builtin_bit_cast(f16x8, r.x[R][0][PX]), x1_ = __builtin_bit_cast(f16x8, r.x[R][1][PX]);      \
-        A[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0_, x0_, c00, 0, 0, 0);                                        \
-        A[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0_, x1_, c01, 0, 0, 0);                                        \
-        A[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1_, x0_, c10, 0, 0, 0);                                        \
-        A[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1_, x1_, c11, 0, 0, 0);                                        \
+        if (!SWAP) {                                                                                                   \
+            A[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0_, x0_, c00, 0, 0, 0);                                    \
+            A[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0_, x1_, c01, 0, 0, 0);                                    \
+            A[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1_, x0_, c10, 0, 0, 0);                                    \
+            A[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1_, x1_, c11, 0, 0, 0);                                    \
+        } else {                                                                                                       \
+            A[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0_, w0_, c00, 0, 0, 0);                                    \
+            A[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0_, w1_, c01, 0, 0, 0);                                    \
+            A[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1_, w0_, c10, 0, 0, 0);                                    \
+            A[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1_, w1_, c11, 0, 0, 0);                                    \
+        }                                                                                                              \
     }
         if constexpr (H2) {         // cross terms into their own accumulator (scaled by 2^-11 once per layer), the main term into `acc`
             SPF_H2(1, 0, FIRST, accc) SPF_H2(0, 1, false, accc) SPF_H2(0, 0, FIRST, acc)
@@ -471,6 +478,8 @@ __device__ __forceinline__ void store_tile_from_planes(const __bf16* X, float* _
 }
 
 // one element (row, col) of the planes
+template <bool H2, int LDP = X3_LDP>
+__device__ __forceinline__ void store_one_xh(__bf16* X, int row, int col, float v);
 template <int LDP = X3_LDP>
 __device__ __forceinline__ void store_one_x3(__bf16* X, int row, int col, float v) {
     __bf16 a, b, c;
@@ -478,6 +487,16 @@ __device__ __forceinline__ void store_one_x3(__bf16* X, int row, int col, float 
     X[row * LDP + col] = a;
     X[(64 * LDP) + row * LDP + col] = b;
     X[2 * (64 * LDP) + row * LDP + col] = c;
+}
+template <bool H2, int LDP>
+__device__ __forceinline__ void store_one_xh(__bf16* X, int row, int col, float v) {
+    if constexpr (H2) {
+        const _Float16 h = (_Float16)v, g = (_Float16)((v - (float)h) * 2048.0f);
+        X[row * LDP + col] = __builtin_bit_cast(__bf16, h);
+        X[(64 * LDP) + row * LDP + col] = __builtin_bit_cast(__bf16, g);
+    } else {
+        store_one_x3<LDP>(X, row, col, v);
+    }
 }
 
 }  // namespace spf

@@ -376,6 +376,25 @@ class PairList:
 # operand on the bf16 matrix pipe; 'f32': fp32 MFMA (the verification twin).
 _ARITH = {"geo": 3, "color": 0, "rhead": 0, "wgrad": 0}        # geometry: H2 (round 6); the others: bf16 x 3
 _ARITH_NAMES = {"split": 0, "f32": 1}
+# H2 arithmetic (round 6; include/spurfies_hip.h: SPF_ARITH_H2) inside the 'split' family of the colour / head / weight-gradient kernels: per kernel,
+# the piece products are three fp16 ones (two fp16 pieces per operand, main + cross accumulators) instead of six bf16 ones; everything else of the
+# 'split' family — operand layouts, sign words, who forms the bias gradients — is unchanged, so forward and backward may differ in it.
+_H2 = {"color_fwd": True, "color_bwd": False, "rhead_fwd": False, "rhead_bwd": False, "wgrad": False}
+
+
+def set_h2(**flags):
+    """ops.set_h2(color_fwd=False, ...): switch single kernels of the 'split' family between H2 (three fp16 piece products) and the six bf16 piece
+    products (tests, same-box A/B runs).  -> the previous flags."""
+    prev = dict(_H2)
+    for k, v in flags.items():
+        if k not in _H2:
+            raise KeyError(k)
+        _H2[k] = bool(v)
+    return prev
+
+
+def _arith_of(family_arith, kernel):
+    return 3 if (family_arith == 0 and _H2[kernel]) else family_arith
 _GEO_ARITH_NAMES = {"split": 0, "f32": 1, "split_w": 2, "h2": 3}     # 'split_w': the split arithmetic on 32x32x16 MFMA tiles; 'h2': two fp16 pieces (SPF_ARITH_H2)
 
 
@@ -704,7 +723,8 @@ class ColorAgg(_GradModeFunction):
             _lib.check(_lib.lib().spf_color_forward(_lib.ptr(x), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                     _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), NP, pl.k, _lib.ptr(pts),
                                                     _lib.ptr(feat_col.detach()), _lib.ptr(packed), _lib.ptr(agg3),
-                                                    *[_lib.ptr(a) for a in bufs], _lib.ptr(acc), _ARITH["color"], _lib.stream_ptr()), "spf_color_forward")
+                                                    *[_lib.ptr(a) for a in bufs], _lib.ptr(acc), _arith_of(_ARITH["color"], "color_fwd"), _lib.stream_ptr()),
+                       "spf_color_forward")
         if acc is not None:      # the RBF-weighted mean meets up to four partial sums per entry: order-independent in this mode
             _fixed_flush(acc, agg3)
         ctx.arith = _ARITH["color"]
@@ -737,7 +757,7 @@ class ColorAgg(_GradModeFunction):
             _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g_agg3), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                      _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), ctx.NP, pl.k, _lib.ptr(packed), _lib.ptr(masks),
                                                      _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(G3), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_b4),
-                                                     _lib.ptr(g_feat), _lib.ptr(acc), ctx.arith, _lib.stream_ptr()), "spf_color_backward")
+                                                     _lib.ptr(g_feat), _lib.ptr(acc), _arith_of(ctx.arith, "color_bwd"), _lib.stream_ptr()), "spf_color_backward")
         if acc is not None:
             _fixed_flush(acc, g_feat)
         if sk is not None:
