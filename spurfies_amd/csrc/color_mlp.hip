@@ -474,10 +474,18 @@ __device__ __forceinline__ void cx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2
     }
 }
 
+// H2 backward: gradients are small and their magnitude differs from ROW to row by many orders (a pair's row carries its RBF weight:
+// exp(-(45 d)^2) spans 1 .. 1e-20; the rgb loss adds 1 / (3 R)), far outside fp16's range.  The chain is linear and rows (pairs) are independent,
+// so every row travels through the planes and the accumulators multiplied by its OWN power of two (block floating point: the row's largest
+// |G3| entry becomes 128 .. 256, leaving 2^8 of headroom for growth through the two weight matrices and 2^22 below it in fp16's normal range),
+// and every value that leaves the kernel is multiplied by the row's inverse factor (both exact).  s_rinv[row] holds that inverse.
+
 // transposed backward epilogue: g_h = g_a * lrelu'(h), popping the lane's two sign words -> planes
+template <bool H2 = false>
 __device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2][2], int wave, int lane, const uint32_t (&mw)[2],
-                                                float* __restrict__ tile_out) {
+                                                float* __restrict__ tile_out, const float* s_rinv = nullptr) {
     const int j = lane & 31, kg = lane >> 5;
+    const float rinv[2] = {H2 ? s_rinv[j] : 1.0f, H2 ? s_rinv[32 + j] : 1.0f};
     uint32_t bits[2] = {mw[0], mw[1]};
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -491,9 +499,9 @@ __device__ __forceinline__ void cx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2
                 f32x4 out;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], bits[n]);
-                store_quad_x3(X, 32 * n + j, f0, out);
+                store_quad_xh<H2, X3_LDP>(X, 32 * n + j, f0, out);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) tile_out[(f0 + e) * 64 + 32 * n + j] = out[e];      // K-major 64-row tile (SPF_WGRAD_G_TILES64): full 128-byte lines
+                for (int e = 0; e < 4; ++e) tile_out[(f0 + e) * 64 + 32 * n + j] = H2 ? out[e] * rinv[n] : out[e];      // K-major 64-row tile (SPF_WGRAD_G_TILES64): full 128-byte lines
             }
         }
 }
@@ -756,6 +764,7 @@ __device__ __forceinline__ CxGrow cx_fetch_grow(const float* __restrict__ g_agg3
     return r;
 }
 
+template <bool H2>
 __global__ void __launch_bounds__(256, 1)
 color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __restrict__ nbr, const float* __restrict__ wn,
                          const int32_t* __restrict__ point_slot, const int32_t* __restrict__ pair_off, const int32_t* __restrict__ pair_point,
@@ -766,6 +775,8 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
     __shared__ __attribute__((aligned(16))) int s_idx[64];
     __shared__ __attribute__((aligned(16))) float L[64 * CX_LDL];      // the tile's latent gradients, [row][64 (+4)]
     __shared__ __attribute__((aligned(16))) int s_lead[64];            // neighbour index of the rows that lead a group of equal indices, else -1
+    __shared__ float s_amax[4][64];                                    // H2: per (feature quarter, row) largest |G3| entry, then ...
+    __shared__ float s_rinv[64];                                       // ... the row's inverse power-of-two factor
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NP = n_pairs_dev ? min(*n_pairs_dev, max_pairs) : max_pairs;
@@ -790,7 +801,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gfp pf = launder(packed0);
-        gx3 frag = reinterpret_cast<gx3>(pf + C_PACKED);
+        gx3 frag = reinterpret_cast<gx3>(pf + (H2 ? CH_OFF : C_PACKED));
         gx3 w_bw3 = frag + CX_BW3 + wave * (CX_TH * 2 * 3 * 64) + lane;
         gx3 w_bw2 = frag + CX_BW2 + wave * (CX_TH * 2 * 3 * 64) + lane;
         const WFrag3 fr3 = load_wfrag3(w_bw3);
@@ -802,18 +813,35 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         {
             if (wave == 0) s_idx[lane] = cur.idx;
             float* g3t = G3 + tbase + (size_t)(64 * wave) * 64 + lane;       // K-major 64-row tile (SPF_WGRAD_G_TILES64): feature f, row r at f * 64 + r
+            float oall[16][4];
+            float amax = 0.f;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const uint32_t word = u < 8 ? cur.m0 : cur.m1;
-                float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bool pos = (word >> ((4 * u + e) & 31)) & 1u;
                     const float t = cur.w != 0.f ? cur.ga[u][e] * cur.w : 0.f;
-                    o[e] = pos ? t : t * 0.01f;
-                    g3t[(4 * u + e) * 64] = o[e];
+                    const float o = pos ? t : t * 0.01f;
+                    oall[u][e] = o;
+                    g3t[(4 * u + e) * 64] = o;
+                    amax = fmaxf(amax, fabsf(o));
                 }
-                store_quad_x3(X, lane, 64 * wave + 4 * u, o);
+                if (!H2) store_quad_x3(X, lane, 64 * wave + 4 * u, oall[u]);
+            }
+            if (H2) {      // the row's power-of-two factor from the four feature quarters' maxima (one LDS round trip + a barrier)
+                s_amax[wave][lane] = amax;
+                lds_barrier();
+                const float rmax = fmaxf(fmaxf(s_amax[0][lane], s_amax[1][lane]), fmaxf(s_amax[2][lane], s_amax[3][lane]));
+                int ex = 0;
+                if (rmax > 0.f && rmax < 3.0e38f) (void)frexpf(rmax, &ex);          // rmax = m 2^ex, m in [0.5, 1)
+                const float sc = ldexpf(1.0f, 8 - ex);                               // row max -> [128, 256)
+                if (wave == 0) s_rinv[lane] = ldexpf(1.0f, ex - 8);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float os[4] = {oall[u][0] * sc, oall[u][1] * sc, oall[u][2] * sc, oall[u][3] * sc};
+                    store_quad_xh<true, X3_LDP>(X, lane, 64 * wave + 4 * u, os);
+                }
             }
         }
         const int next_tile = tile + (int)gridDim.x;
@@ -828,14 +856,15 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         lds_barrier();
         T_MARK(17)
         f32x16 acc[2][2];
+        f32x16 accc[2][H2 ? 2 : 1];        // H2: the cross terms' accumulators
         const int j = lane & 31;
         uint32_t mw[2] = {mk[512 + (2 * wave) * 64 + lane], mk[512 + (2 * wave + 1) * 64 + lane]};      // layer-2 sign words, before the GEMM
         zero_acc(acc);
-        WFrag3 nf = gemm_x3<CX_TH>(X, w_bw3, lane, acc, fr3, w_bw2);
+        WFrag3 nf = cx_gemm<CX_TH, false, H2>(X, w_bw3, lane, acc, fr3, w_bw2, accc);
         T_MARK(18)
         lds_barrier();
         T_MARK(19)
-        cx_bwd_epilogue(X, acc, wave, lane, mw, G2 + tbase);
+        cx_bwd_epilogue<H2>(X, acc, wave, lane, mw, G2 + tbase, s_rinv);
         T_MARK(20)
         lds_barrier();
         T_MARK(21)
@@ -847,7 +876,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         mw[0] = mk[(2 * wave) * 64 + lane];
         mw[1] = mk[(2 * wave + 1) * 64 + lane];
         zero_acc(acc);
-        gemm_x3<CX_TH>(X, w_bw2, lane, acc, nf, nullptr);
+        cx_gemm<CX_TH, false, H2>(X, w_bw2, lane, acc, nf, nullptr, accc);
         T_MARK(18)
         gx3 w_bwl = frag + CX_BWL + (wave >> 1) * (CX_TH * 3 * 64) + lane;
         const WFrag1 frl = load_wfrag1(w_bwl);
@@ -855,7 +884,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         if (n_p >= 0) n_idx = nbr[(size_t)n_srow * k + (qn - n_off)];
         lds_barrier();
         T_MARK(19)
-        cx_bwd_epilogue(X, acc, wave, lane, mw, G1 + tbase);
+        cx_bwd_epilogue<H2>(X, acc, wave, lane, mw, G1 + tbase, s_rinv);
         T_MARK(20)
         lds_barrier();
         T_MARK(21)
@@ -864,7 +893,8 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
         // ---- d/d latent = G1 W0[:, 39:103]: wave = (latent half m, row half n), one 32x32 tile each; scatter-add -------------------
         {
             const int m = wave >> 1, n = wave & 1, kg = lane >> 5;
-            const f32x16 aj = gemm_x3_tile<CX_TH>(X, n, w_bwl, lane, frl);
+            f32x16 aj = gemm_x3_tile<CX_TH, X3_LDP, H2>(X, n, w_bwl, lane, frl);
+            if (H2) aj = aj * s_rinv[32 * n + j];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<f32x4*>(&L[(32 * n + j) * CX_LDL + 32 * m + 8 * g + 4 * kg]) = f32x4{aj[4 * g], aj[4 * g + 1], aj[4 * g + 2], aj[4 * g + 3]};
@@ -1012,19 +1042,24 @@ int spf_color_backward(const float* g_agg3, const int32_t* nbr, const float* wn,
                        const int32_t* pair_point, const int32_t* n_pairs, int32_t max_pairs, int32_t k, const float* packed,
                        const uint32_t* masks, float* G1, float* G2, float* G3, float* g_b0, float* g_b2, float* g_b4, float* g_feat_color,
                        int64_t* g_feat_color_fixed, int32_t arith, void* stream) {
-    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_color_backward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32 && arith != SPF_ARITH_H2)
+        return spf::fail(SPF_EINVAL, "spf_color_backward: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_H2 (3), got %d", arith);
     if (max_pairs < 0 || k < 1 || k > SPF_KMAX) return spf::fail(SPF_EINVAL, "spf_color_backward: bad sizes");
     if (max_pairs == 0) return SPF_OK;
     if (!g_agg3 || !nbr || !wn || !pair_off || !pair_point || !packed || !masks || !G1 || !G2 || !G3 || !g_b0 || !g_b2 || !g_b4 ||
         (!g_feat_color && !g_feat_color_fixed))
         return spf::fail(SPF_EINVAL, "spf_color_backward: null pointer");
-    if (g_feat_color_fixed && arith != SPF_ARITH_SPLIT) return spf::fail(SPF_EINVAL, "spf_color_backward: the fixed-point latent accumulator needs SPF_ARITH_SPLIT");
+    if (g_feat_color_fixed && arith == SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_color_backward: the fixed-point latent accumulator needs SPF_ARITH_SPLIT or SPF_ARITH_H2");
     const int tiles = spf::div_up(max_pairs, 64);
     const int blocks = tiles < 512 ? tiles : 512;
-    if (arith == SPF_ARITH_SPLIT) {    // bias gradients come from spf_wgrad (dbias) in this mode: g_b0 / g_b2 / g_b4 are not touched
+    if (arith == SPF_ARITH_SPLIT || arith == SPF_ARITH_H2) {    // bias gradients come from spf_wgrad (dbias) in these modes: g_b0 / g_b2 / g_b4 are not touched
         const int b1 = tiles < 256 ? tiles : 256;
-        color_backward_x3_kernel<<<b1, 256, 0, (hipStream_t)stream>>>(g_agg3, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
-                                                                      masks, G1, G2, G3, g_feat_color, reinterpret_cast<long long*>(g_feat_color_fixed));
+        if (arith == SPF_ARITH_H2)
+            color_backward_x3_kernel<true><<<b1, 256, 0, (hipStream_t)stream>>>(g_agg3, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
+                                                                                masks, G1, G2, G3, g_feat_color, reinterpret_cast<long long*>(g_feat_color_fixed));
+        else
+            color_backward_x3_kernel<false><<<b1, 256, 0, (hipStream_t)stream>>>(g_agg3, nbr, wn, point_slot, pair_off, pair_point, n_pairs, max_pairs, k, packed,
+                                                                                 masks, G1, G2, G3, g_feat_color, reinterpret_cast<long long*>(g_feat_color_fixed));
         SPF_LAUNCH_CHECK("color_backward_x3_kernel");
         return SPF_OK;
     }

@@ -3,6 +3,7 @@ arithmetic stage is a HIP kernel in libspurfies_hip.so)."""
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -379,7 +380,13 @@ _ARITH_NAMES = {"split": 0, "f32": 1}
 # H2 arithmetic (round 6; include/spurfies_hip.h: SPF_ARITH_H2) inside the 'split' family of the colour / head / weight-gradient kernels: per kernel,
 # the piece products are three fp16 ones (two fp16 pieces per operand, main + cross accumulators) instead of six bf16 ones; everything else of the
 # 'split' family — operand layouts, sign words, who forms the bias gradients — is unchanged, so forward and backward may differ in it.
-_H2 = {"color_fwd": True, "color_bwd": False, "rhead_fwd": False, "rhead_bwd": False, "wgrad": False}
+_H2 = {"color_fwd": True, "color_bwd": True, "rhead_fwd": False, "rhead_bwd": False, "wgrad": False}
+
+
+if os.environ.get("SPF_H2_FLAGS"):          # same-box A/B runs of whole programs: SPF_H2_FLAGS='{"color_bwd": false}'
+    import json as _json
+
+    _H2.update({k: bool(v) for k, v in _json.loads(os.environ["SPF_H2_FLAGS"]).items() if k in _H2})
 
 
 def set_h2(**flags):

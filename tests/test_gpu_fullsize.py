@@ -77,9 +77,12 @@ def check_against_oracle(scene, n_rays, view, seed, min_points):
         scale = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
         if pname.startswith("neural_feats"):
             # latent rows are fed by a handful of pairs each: one pair sitting on a LeakyReLU kink of the MLP behind it (a pre-activation
-            # within rounding of 0 picks slope 1 or 0.01) moves ALL entries of its row.  Counted per ROW: at most 0.5 % of the rows that
-            # received a gradient may hold an entry outside 2e-3 of the tensor's gradient scale (measured on MI355X: 12 of 5536 colour rows at
-            # 1024 rays, 1 of 5 * 10^4 geometry rows), and such a row deviates by at most 5 % of its own norm (measured: 0.2 - 2 %).
+            # within rounding of 0 picks slope 1 or 0.01) moves ALL entries of its row.  Counted per ROW: at most 1.2 % of the rows that
+            # received a gradient may hold an entry outside 2e-3 of the tensor's gradient scale, and such a row deviates by at most 5 % of its own
+            # norm (measured: 0.07 - 2 %).  The allowance is what TRUE fp32 arithmetic needs against the CPU oracle's fp32: measured on MI355X on
+            # the dense cloud (1121 colour rows touched), round 6 — the fp32-MFMA twin kernels (set_color_mode('f32')) 9 rows, the default H2
+            # kernels 10, the bf16 x 3 kernels 2 (their products are exact to 2^-24, finer than an fp32 rounding); 1024 rays: 12 of 5536 (round 3).
+            # It was 0.5 % while the bf16 x 3 kernels were the default.
             bad = ~np.isclose(got, want, rtol=GRAD_RTOL, atol=GRAD_RTOL * scale + 1e-12)
             bad_rows = bad.any(axis=1)
             touched = int((want != 0).any(axis=1).sum())
@@ -88,7 +91,7 @@ def check_against_oracle(scene, n_rays, view, seed, min_points):
                 dev = np.linalg.norm(got[bad_rows] - want[bad_rows], axis=1) / np.maximum(rn, 1e-30)
                 print(f"{pname}: {int(bad_rows.sum())} of {touched} touched rows hold an entry outside {GRAD_RTOL}; their relative row deviation "
                       f"|got - want| / |want| = {np.sort(dev)[-5:]}, entries out per bad row {np.sort(bad[bad_rows].sum(1))[-5:]}, tensor rms {scale:.3e}")
-            assert bad_rows.sum() <= max(5e-3 * touched, 2), (pname, int(bad_rows.sum()), touched)
+            assert bad_rows.sum() <= max(1.2e-2 * touched, 2), (pname, int(bad_rows.sum()), touched)
             if bad_rows.any():
                 assert float(dev.max()) <= 0.05, (pname, dev.max())
         else:
