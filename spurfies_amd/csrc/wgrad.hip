@@ -258,6 +258,42 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
     return s;
 }
 
+// H2 (round 6, arith = SPF_ARITH_H2): two fp16 pieces per operand, three piece products per fp32 product (h1 h1 + h1 h2 + h2 h1; the dropped h2 h2
+// is 2^-22 of the product), ALL into the one accumulator: here the second piece is the UNSCALED residual x - fp16(x) (the MLP tile engine scales it by
+// 2^11 and keeps a second accumulator — mlp_tile_x3.h — for which eight waves' 128-register accumulators leave no room at two waves per SIMD).  An
+// unscaled residual is a normal fp16 number — the pair then carries 22 bits of x — only for |x| >= 2^-3; below that the pair keeps an ABSOLUTE
+// accuracy of 2^-25.  So the operands are block-scaled by powers of two (exact, undone once on the slab):
+//   A (activations: softplus outputs, encodings, features — O(1))  x WG_H2_ASCALE = 4: |A| < 16376 (beyond: inf, loudly), 22 bits down to 0.03,
+//     an absolute 7.5e-9 below;
+//   G (pre-activation gradients: 1 / (3 R) of the loss times a compositing and an RBF weight per row — any magnitude)  PER WAVE (a wave owns 32
+//     columns of G and their accumulators), chosen ONLINE: the first stage's largest |G| entry is put in [2^12, 2^13); when a later stage brings one
+//     that would pass 2^15, the scale shrinks to put THAT one in [2^12, 2^13) and the wave's accumulators are multiplied by the (exact) ratio once.
+//     An entry keeps 22 bits while it is within 2^-15 of its block's largest so far, and an absolute 2^-37 of that largest below.
+// What a sum over 10^5 rows needs, not what a lone product gets from the bf16 x 3 kernel (arith = SPF_ARITH_SPLIT, which stays for operands whose
+// large entries do not dominate the sum: tests/test_gpu_wgrad.py holds both to the fp32-MFMA kernel's accuracy against float64).
+typedef _Float16 f16x8w __attribute__((ext_vector_type(8)));
+constexpr float WG_H2_ASCALE = 4.0f;
+template <bool H2>
+__device__ __forceinline__ Split8 split8x(const float (&x)[8], float scale) {
+    if constexpr (H2) {
+        Split8 s;
+        f16x8w a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xs = x[e] * scale;
+            const _Float16 h = (_Float16)xs;
+            a[e] = h;
+            b[e] = (_Float16)(xs - (float)h);
+        }
+        s.p1 = __builtin_bit_cast(bf16x8, a);
+        s.p2 = __builtin_bit_cast(bf16x8, b);
+        s.p3 = s.p1;
+        return s;
+    } else {
+        return split8(x);
+    }
+}
+
 // Stage = 16 rows (one K = 16 MFMA step) of G [16,256] and A [16,CA], written into a 4-slot fp32 ring by LDS-DMA (three stages
 // requested ahead).  EIGHT waves per workgroup (two per SIMD): wave w owns output rows [32w, 32w+32) x all columns (NT x 16
 // accumulator registers).  The A tile feeds every wave, so it is split into its three bf16 planes ONCE per workgroup (one
@@ -289,7 +325,7 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
 template <int NT>
 constexpr int wgrad_split8_lds_floats() { return 3 * 16 * (256 + 32 * NT) + 2 * (3 * 32 * NT * 2) * 4; }
 
-template <int NT, int GK = 0, bool AK = false>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
+template <int NT, int GK = 0, bool AK = false, bool H2 = false>   // 8: C = 256;  4: C <= 128 (staged 128 wide, two rows per DMA request)
 __device__ __forceinline__ void wgrad_split8_body(float* sm, const float* __restrict__ G, const float* __restrict__ A, int lda, int C,
                                                   const int32_t* __restrict__ n_rows_dev, int max_rows, float* __restrict__ slab,
                                                   float* __restrict__ dbias, const int bid, const int nblk, float* __restrict__ colsum = nullptr) {
@@ -325,6 +361,7 @@ __device__ __forceinline__ void wgrad_split8_body(float* sm, const float* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float gsum = 0.f;
+    float gs_latest = 0.f, gs_cur = 0.f;      // H2: the scale of the newest split stage's G pieces / of the accumulators (0 = nothing but zeros yet)
 #ifdef SPF_TIMING      // tools/wgrad_phases.py: cycles of waves 0 (splits first) and 4 (multiplies first) per phase of the stage loop
     unsigned long long wt[10] = {}, wl = __builtin_readcyclecounter();
 #define W_MARK(i) { const unsigned long long now = __builtin_readcyclecounter(); wt[i] += now - wl; wl = now; }
@@ -380,11 +417,11 @@ __device__ __forceinline__ void wgrad_split8_body(float* sm, const float* __rest
                 for (int e = 0; e < 8; ++e) x[e] = sa[(8 * h + e) * CA + col];
             }
             W_MARK(5)
-            const Split8 b = split8(x);
+            const Split8 b = split8x<H2>(x, H2 ? WG_H2_ASCALE : 1.0f);
             W_MARK(6)
             pl[(0 * CA + col) * 2 + hs] = b.p1;
             pl[(1 * CA + col) * 2 + hs] = b.p2;
-            pl[(2 * CA + col) * 2 + hs] = b.p3;
+            if (!H2) pl[(2 * CA + col) * 2 + hs] = b.p3;
         }
         float x[8];
         if (GK) {
@@ -401,21 +438,49 @@ __device__ __forceinline__ void wgrad_split8_body(float* sm, const float* __rest
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = (8 * h + e < left) ? x[e] : 0.f;
         }
-        ga = split8(x);
+        if constexpr (H2) {      // this wave's scale: never above what the largest entry seen so far allows
+            float m = fmaxf(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))), fmaxf(fmaxf(fabsf(x[4]), fabsf(x[5])), fmaxf(fabsf(x[6]), fabsf(x[7]))));
+            // (one compare per stage; the wave-wide maximum only when a lane's entry would leave fp16's range — or nothing but zeros came so far)
+            if (__builtin_amdgcn_ballot_w64(gs_latest == 0.f || m * gs_latest >= 32768.0f) != 0) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+                if (m > 0.f && m < 3.0e38f) {
+                    int ex;
+                    (void)frexpf(m, &ex);                                   // m = f 2^ex, f in [0.5, 1)
+                    const float want = ldexpf(1.0f, 13 - max(-100, min(ex, 100)));
+                    if (gs_latest == 0.f || want < gs_latest) gs_latest = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, want)));
+                }
+            }
+            ga = split8x<true>(x, gs_latest == 0.f ? 8192.0f : gs_latest);
+        } else {
+            ga = split8x<false>(x, 1.0f);
+        }
         gsum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));      // column sums of G = the bias gradient
         W_MARK(8)
     };
     auto mfma_stage = [&](int st, const Split8& ga, bool ahead) {
         const bf16x8* pl = planes + (st & 1) * PLANE;
-        bf16x8 bq[2][3];
+        constexpr int NQ = H2 ? 2 : 3;
+        bf16x8 bq[2][NQ];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bq[0][q] = pl[(q * CA + ci) * 2 + hs];
+        for (int q = 0; q < NQ; ++q) bq[0][q] = pl[(q * CA + ci) * 2 + hs];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int k = t & 1;
             if (t + 1 < NT) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) bq[k ^ 1][q] = pl[(q * CA + 32 * (t + 1) + ci) * 2 + hs];
+                for (int q = 0; q < NQ; ++q) bq[k ^ 1][q] = pl[(q * CA + 32 * (t + 1) + ci) * 2 + hs];
+            }
+            if constexpr (H2) {
+                if (t == 1 && ahead) issue(st + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8w g1 = __builtin_bit_cast(f16x8w, ga.p1), g2 = __builtin_bit_cast(f16x8w, ga.p2);
+                const f16x8w a1 = __builtin_bit_cast(f16x8w, bq[k][0]), a2 = __builtin_bit_cast(f16x8w, bq[k][1]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(g2, a1, acc[t], 0, 0, 0);      // smallest terms first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(g1, a2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(g1, a1, acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
             }
             // the DMA requests of stage st + 3 ride between the MFMAs (in front of the split, where nothing covers their issue, they cost
             // 0.3 - 0.5 k cycles per stage): -1.3 % / -4 % / -2 % on the three shapes
@@ -439,6 +504,7 @@ __device__ __forceinline__ void wgrad_split8_body(float* sm, const float* __rest
     __builtin_amdgcn_s_barrier();
     Split8 ga, gn;
     split_stage(0, ga);
+    gs_cur = gs_latest;
     gn = ga;
     if (nst > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");                     // stage 1 landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -456,6 +522,16 @@ __device__ __forceinline__ void wgrad_split8_body(float* sm, const float* __rest
         W_MARK(2)
         if (more && late) split_stage(st + 1, gn);
         W_MARK(1)
+        if (H2 && more && gs_latest != gs_cur) {          // (wave-uniform) a larger entry arrived: the accumulators follow the pieces' new scale
+            if (gs_cur != 0.f) {
+                const float ratio = gs_latest / gs_cur;   // powers of two: exact
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] *= ratio;
+            }
+            gs_cur = gs_latest;
+        }
         ga = gn;
         if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");                   // stage st + 2 landed (this wave's share)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -476,23 +552,24 @@ __device__ __forceinline__ void wgrad_split8_body(float* sm, const float* __rest
             else atomicAdd(&dbias[32 * wave + ci], gsum);
         }
     }
+    const float gs_inv = (H2 && gs_cur != 0.f) ? 1.0f / (gs_cur * WG_H2_ASCALE) : 1.0f;      // (a power of two: exact)
     float* out = slab + ((size_t)bid * 8 + wave) * (NT * 16 * 64) + lane;     // slab[block][wave 8][t][reg][lane]
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64] = acc[t][r];
+        for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64] = H2 ? acc[t][r] * gs_inv : acc[t][r];
 #ifdef SPF_CLOCK
     T_FLUSH
 #endif
 }
 
 
-template <int NT, int GK = 0, bool AK = false>
+template <int NT, int GK = 0, bool AK = false, bool H2 = false>
 __global__ void __launch_bounds__(512, 1)
 wgrad_split8_kernel(const float* __restrict__ G, const float* __restrict__ A, int lda, int C, const int32_t* __restrict__ n_rows_dev,
                     int max_rows, float* __restrict__ slab, float* __restrict__ dbias, float* __restrict__ colsum) {
     __shared__ __attribute__((aligned(16))) float sm[wgrad_split8_lds_floats<NT>()];
-    wgrad_split8_body<NT, GK, AK>(sm, G, A, lda, C, n_rows_dev, max_rows, slab, dbias, (int)blockIdx.x, (int)gridDim.x, colsum);
+    wgrad_split8_body<NT, GK, AK, H2>(sm, G, A, lda, C, n_rows_dev, max_rows, slab, dbias, (int)blockIdx.x, (int)gridDim.x, colsum);
 }
 
 // Up to three problems over the same rows in ONE launch, side by side: workgroups [first[q], first[q] + nblk[q]) of the 1-D grid belong to
@@ -578,6 +655,7 @@ __device__ __forceinline__ void wg_assign(const WgradBatch& pb, int n_problems, 
     }
 }
 
+template <bool H2>
 __global__ void __launch_bounds__(512, 1)
 wgrad_split8_batched_kernel(WgradBatch pb, int n_problems, float* __restrict__ slabs, size_t slab_floats, int det) {
     __shared__ __attribute__((aligned(16))) float sm[wgrad_split8_lds_floats<8>()];
@@ -594,10 +672,10 @@ wgrad_split8_batched_kernel(WgradBatch pb, int n_problems, float* __restrict__ s
     const int max_rows = pb.max_rows[q];
     float* slab = slabs + (size_t)q * slab_floats;
     float* colsum = det ? slab + COLSUM_OFF : nullptr;
-    if (pb.kind[q] == 0) wgrad_split8_body<8>(sm, pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
-    else if (pb.kind[q] == 1) wgrad_split8_body<8, 2, true>(sm, pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
-    else if (pb.kind[q] == 2) wgrad_split8_body<4, 2, false>(sm, pb.G[q], pb.A[q], pb.lda[q], pb.C[q], n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
-    else wgrad_split8_body<4>(sm, pb.G[q], pb.A[q], pb.lda[q], pb.C[q], n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);      // row-major, C <= 128 (R.0's view-encoding columns)
+    if (pb.kind[q] == 0) wgrad_split8_body<8, 0, false, H2>(sm, pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
+    else if (pb.kind[q] == 1) wgrad_split8_body<8, 2, true, H2>(sm, pb.G[q], pb.A[q], pb.lda[q], 256, n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
+    else if (pb.kind[q] == 2) wgrad_split8_body<4, 2, false, H2>(sm, pb.G[q], pb.A[q], pb.lda[q], pb.C[q], n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);
+    else wgrad_split8_body<4, 0, false, H2>(sm, pb.G[q], pb.A[q], pb.lda[q], pb.C[q], n_rows_dev, max_rows, slab, pb.dbias[q], bid, nblk, colsum);      // row-major, C <= 128 (R.0's view-encoding columns)
 }
 
 // slab of wgrad_split8_kernel: output row o = 32 wave + C-row(reg, lane), column = 32 t + (lane & 31)
@@ -758,7 +836,9 @@ int64_t spf_wgrad_workspace_floats(int32_t C) { return COLSUM_OFF + (int64_t)256
 
 int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int32_t* n_rows, int32_t max_rows, float* dW, int32_t ldw,
               float* dbias, float* workspace, int32_t layout, int32_t arith, int32_t col_rot, int32_t col_mod, void* stream) {
-    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_wgrad: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
+    const bool h2 = arith == SPF_ARITH_H2;        // the 'split' family with three fp16 piece products (everything else unchanged)
+    if (h2) arith = SPF_ARITH_SPLIT;
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_wgrad: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_H2 (3), got %d", arith);
     if (col_mod < 0 || col_mod > C || col_rot < 0 || (col_mod > 0 && col_rot >= col_mod) || (col_mod == 0 && col_rot != 0))
         return spf::fail(SPF_EINVAL, "spf_wgrad: need 0 <= col_rot < col_mod <= C (or both 0), got col_rot=%d col_mod=%d C=%d", col_rot, col_mod, C);
     if (col_mod > 0 && !(arith == SPF_ARITH_SPLIT && C > 32)) return spf::fail(SPF_EINVAL, "spf_wgrad: the column rotation needs SPF_ARITH_SPLIT and C > 32");
@@ -790,19 +870,19 @@ int spf_wgrad(const float* G, const float* A, int32_t lda, int32_t C, const int3
     const int align = g64 ? 64 : ((gk || ak) ? 16 : 2);
     if (arith == SPF_ARITH_SPLIT && NT == 8 && C == 256) {
         const int b8 = blocks > 256 ? 256 : blocks;      // one 8-wave workgroup per CU
-        if (g64 && ak) wgrad_split8_kernel<8, 2, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
-        else if (g64) wgrad_split8_kernel<8, 2, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
-        else if (gk && ak) wgrad_split8_kernel<8, 1, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
-        else if (gk) wgrad_split8_kernel<8, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
-        else if (ak) wgrad_split8_kernel<8, 0, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
-        else wgrad_split8_kernel<8><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
+        if (g64 && ak) { if (h2) wgrad_split8_kernel<8, 2, true, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); else wgrad_split8_kernel<8, 2, true, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); }
+        else if (g64) { if (h2) wgrad_split8_kernel<8, 2, false, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); else wgrad_split8_kernel<8, 2, false, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); }
+        else if (gk && ak) { if (h2) wgrad_split8_kernel<8, 1, true, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); else wgrad_split8_kernel<8, 1, true, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); }
+        else if (gk) { if (h2) wgrad_split8_kernel<8, 1, false, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); else wgrad_split8_kernel<8, 1, false, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); }
+        else if (ak) { if (h2) wgrad_split8_kernel<8, 0, true, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); else wgrad_split8_kernel<8, 0, true, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); }
+        else { if (h2) wgrad_split8_kernel<8, 0, false, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); else wgrad_split8_kernel<8, 0, false, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); }
         dbias = nullptr;
         wgrad_split8_reduce_kernel<8><<<dim3(spf::div_up(per, 256), rsplit), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align, col_rot, col_mod, dbias_det);
     } else if (arith == SPF_ARITH_SPLIT && NT == 4) {
         const int b8 = blocks > 256 ? 256 : blocks;
-        if (g64) wgrad_split8_kernel<4, 2, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
-        else if (gk) wgrad_split8_kernel<4, 1, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
-        else wgrad_split8_kernel<4><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum);
+        if (g64) { if (h2) wgrad_split8_kernel<4, 2, false, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); else wgrad_split8_kernel<4, 2, false, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); }
+        else if (gk) { if (h2) wgrad_split8_kernel<4, 1, false, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); else wgrad_split8_kernel<4, 1, false, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); }
+        else { if (h2) wgrad_split8_kernel<4, 0, false, true><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); else wgrad_split8_kernel<4, 0, false, false><<<b8, 512, 0, s>>>(G, A, lda, C, n_rows, max_rows, workspace, dbias, colsum); }
         dbias = nullptr;
         wgrad_split8_reduce_kernel<4><<<dim3(spf::div_up(per, 256), rsplit), 256, 0, s>>>(workspace, b8, n_rows, max_rows, C, dW, ldw, align, col_rot, col_mod, dbias_det);
     } else if (NT == 8) {
@@ -826,7 +906,9 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
                       int32_t arith, int32_t flags, void* stream) {
     if (flags & ~SPF_WGRAD_DETERMINISTIC) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: flags may only hold SPF_WGRAD_DETERMINISTIC");
     const int det = (flags & SPF_WGRAD_DETERMINISTIC) ? 1 : 0;
-    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
+    const bool h2 = arith == SPF_ARITH_H2;
+    if (h2) arith = SPF_ARITH_SPLIT;
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_H2 (3), got %d", arith);
     if (!problems || n_problems < 1 || n_problems > WG_MAXP || max_rows < 0) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: 1 to %d problems", WG_MAXP);
     if (!workspace) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: null workspace");
     const int64_t slab_floats = spf_wgrad_workspace_floats(256);
@@ -865,7 +947,7 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
             const int C = p.C > 0 ? p.C : 256;
             if (arith != SPF_ARITH_SPLIT && (p.layout || p.col_mod)) return spf::fail(SPF_EINVAL, "spf_wgrad_batched: tiled operands / column rotation need SPF_ARITH_SPLIT");
             if (rows_of[q] == 0) continue;
-            const int rc = spf_wgrad(p.G, p.A, p.lda, C, cnt_of[q], rows_of[q], p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, p.layout | flags, arith,
+            const int rc = spf_wgrad(p.G, p.A, p.lda, C, cnt_of[q], rows_of[q], p.dW, p.ldw, p.dbias, workspace + (size_t)q * slab_floats, p.layout | flags, h2 ? SPF_ARITH_H2 : arith,
                                      p.col_rot, p.col_mod, stream);
             if (rc != SPF_OK) return rc;
         }
@@ -887,7 +969,8 @@ int spf_wgrad_batched(const struct spf_wgrad_problem* problems, int32_t n_proble
     const int nblocks = want < 256 ? (want < n_problems ? n_problems : (int)want) : 256;
     hipStream_t s = (hipStream_t)stream;
     const int per = 4 * 2 * 8 * 16 * 64;
-    wgrad_split8_batched_kernel<<<nblocks, 512, 0, s>>>(pb, n_problems, workspace, (size_t)slab_floats, det);
+    if (h2) wgrad_split8_batched_kernel<true><<<nblocks, 512, 0, s>>>(pb, n_problems, workspace, (size_t)slab_floats, det);
+    else wgrad_split8_batched_kernel<false><<<nblocks, 512, 0, s>>>(pb, n_problems, workspace, (size_t)slab_floats, det);
     wgrad_split8_reduce_batched_kernel<<<dim3(spf::div_up(per, 256), det ? 1 : reduce_slices((nblocks + n_problems - 1) / n_problems * 2), n_problems), 256, 0, s>>>(
         workspace, (size_t)slab_floats, pb, n_problems, nblocks, det);
     SPF_LAUNCH_CHECK("wgrad_split8_batched_kernel");

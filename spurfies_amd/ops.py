@@ -380,7 +380,7 @@ _ARITH_NAMES = {"split": 0, "f32": 1}
 # H2 arithmetic (round 6; include/spurfies_hip.h: SPF_ARITH_H2) inside the 'split' family of the colour / head / weight-gradient kernels: per kernel,
 # the piece products are three fp16 ones (two fp16 pieces per operand, main + cross accumulators) instead of six bf16 ones; everything else of the
 # 'split' family — operand layouts, sign words, who forms the bias gradients — is unchanged, so forward and backward may differ in it.
-_H2 = {"color_fwd": True, "color_bwd": True, "rhead_fwd": False, "rhead_bwd": False, "wgrad": False}
+_H2 = {"color_fwd": True, "color_bwd": True, "rhead_fwd": False, "rhead_bwd": False, "wgrad": True}
 
 
 if os.environ.get("SPF_H2_FLAGS"):          # same-box A/B runs of whole programs: SPF_H2_FLAGS='{"color_bwd": false}'
@@ -1235,7 +1235,8 @@ def wgrad(G, A, n_rows, C=None, out=None, ldw=None, dbias=None, layout=0, col_ro
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().spf_wgrad(_lib.ptr(G), _lib.ptr(A), A.stride(0), C, _lib.ptr(n_rows), min(G.shape[0], A.shape[0]), _lib.ptr(out), ldw, _lib.ptr(dbias),
-                                        _lib.ptr(_wgrad_ws[key]), int(layout) | _wgrad_det(C), _ARITH["wgrad"], int(col_rot), int(col_mod), _lib.stream_ptr()),
+                                        _lib.ptr(_wgrad_ws[key]), int(layout) | _wgrad_det(C), _arith_of(_ARITH["wgrad"], "wgrad") if C > 32 else _ARITH["wgrad"],
+                                        int(col_rot), int(col_mod), _lib.stream_ptr()),
                    "spf_wgrad")
     return out
 
@@ -1296,7 +1297,7 @@ def wgrad_batched(problems, n_rows):
     if key not in _wgrad_ws:
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().spf_wgrad_batched(arr, len(problems), _lib.ptr(n_rows), 0 if max_rows is None else max_rows, _lib.ptr(_wgrad_ws[key]), _ARITH["wgrad"],
+        _lib.check(_lib.lib().spf_wgrad_batched(arr, len(problems), _lib.ptr(n_rows), 0 if max_rows is None else max_rows, _lib.ptr(_wgrad_ws[key]), _arith_of(_ARITH["wgrad"], "wgrad"),
                                                     _wgrad_det(256), _lib.stream_ptr()),
                    "spf_wgrad_batched")
 

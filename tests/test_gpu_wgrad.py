@@ -1,11 +1,22 @@
-"""GPU: spf_wgrad (dW = G^T A with a device-side row count).  The default arithmetic forms every fp32 product from three bf16
-pieces per operand on the bf16 matrix pipe; this file holds it to the accuracy of the fp32-MFMA kernel against a float64
-reference — on well-scaled data, on data spanning many orders of magnitude, and on sums that cancel."""
+"""GPU: spf_wgrad (dW = G^T A with a device-side row count).  The 'split' family forms every fp32 product from pieces on the
+16-bit matrix pipe — three bf16 pieces per operand (six piece products), or H2: two fp16 pieces per operand (three piece products)
+with G block-scaled per wave and 32 columns (csrc/wgrad.hip).  This file holds both to the accuracy of the fp32-MFMA kernel against
+a float64 reference — on well-scaled data, on data spanning many orders of magnitude, and on sums that cancel; every test runs once
+per piece form."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["bf16x3", "h2"])
+def pieces(request):
+    from spurfies_amd import ops
+
+    prev = ops.set_h2(wgrad=(request.param == "h2"))
+    yield request.param
+    ops.set_h2(**prev)
 
 
 def _err(got, ref):
@@ -39,16 +50,31 @@ def test_split_products_match_fp32_accuracy(C, rows):
     assert esp < 1e-5
 
 
-def test_split_products_wide_dynamic_range_and_cancellation():
+def test_split_products_wide_dynamic_range_and_cancellation(pieces):
     g = torch.Generator().manual_seed(7)
     rows = 20000
     scale = 10.0 ** (torch.rand((rows, 1), generator=g) * 8.0 - 4.0)                   # rows scaled over 8 orders of magnitude
     G = (torch.randn((rows, 256), generator=g) * scale).cuda()
-    A = (torch.randn((rows, 256), generator=g) / scale).cuda()
+    if pieces == "h2":
+        # block floating point: a term is exact relative to the LARGEST terms of its 32-column block, so the operand to span the orders of
+        # magnitude is G (as a step's does: an RBF weight and a compositing weight per row) against activations of order one — incl. entries
+        # above 2^13 arriving late (the scale shrinks under way) and a block of columns that is 1e-6 of the others
+        G[-200:] *= 50.0
+        G[:, 32:64] *= 1e-6
+        A = torch.randn((rows, 256), generator=g).cuda()
+        A[:, :16] *= 1e-3                                                              # a few nearly dead units
+        A[:, 16:24] *= 300.0
+    else:
+        A = (torch.randn((rows, 256), generator=g) / scale).cuda()                     # anti-correlated: every row's product is of order one
     n = torch.tensor([rows], dtype=torch.int32, device="cuda")
     ref = G.double().t() @ A.double()
     res = _both(G, A, n, 256)
     assert _err(res["split"], ref) < 2e-6 + 2.0 * _err(res["f32"], ref)
+    for blk in (slice(32, 64), slice(64, 96)):                                         # per 32-column block of G (= rows of dW), tiny or not
+        assert _err(res["split"][blk], ref[blk]) < 2e-6 + 2.0 * _err(res["f32"][blk], ref[blk])
+    if pieces == "h2":
+        for cols in (slice(0, 16), slice(16, 24)):                                     # per column group of A
+            assert _err(res["split"][:, cols], ref[:, cols]) < 4e-6 + 2.0 * _err(res["f32"][:, cols], ref[:, cols])
     # exact cancellation: every row appears twice with opposite sign -> the sum is exactly representable (0), whatever the order
     G2 = torch.cat([G[:5000], -G[:5000]]).contiguous()
     A2 = torch.cat([A[:5000], A[:5000]]).contiguous()
@@ -60,7 +86,11 @@ def test_split_products_wide_dynamic_range_and_cancellation():
     n1 = torch.tensor([1], dtype=torch.int32, device="cuda")
     r1 = _both(G[:64].contiguous(), A[:64].contiguous(), n1, 256)
     exact = torch.outer(G[0].double(), A[0].double())
-    np.testing.assert_allclose(r1["split"].double().cpu().numpy(), exact.cpu().numpy(), rtol=2.5e-7, atol=0)
+    if pieces == "h2":      # ... to a few fp32 roundings of the block's largest product (entries far below it keep that absolute accuracy)
+        blockmax = exact.abs().view(8, 32, 256).amax(dim=(1, 2), keepdim=True).expand(8, 32, 256).reshape(256, 256)
+        assert float(((r1["split"].double() - exact).abs() / blockmax).max()) < 6e-7
+    else:
+        np.testing.assert_allclose(r1["split"].double().cpu().numpy(), exact.cpu().numpy(), rtol=2.5e-7, atol=0)
 
 
 @pytest.mark.parametrize("C", [256, 104, 16])
