@@ -33,6 +33,22 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6                      # dense bf16 MFMA: 256 CUs x
 # The dominant kernel forms every fp32 product from 6 exact bf16 piece products (fp32-class accuracy): its matrix-pipe ceiling in
 # ALGORITHMIC (fp32) FLOP/s is the bf16 peak / 6.
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_H2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0          # H2: three fp16 piece products per fp32 product (the fp16 and bf16 dense MFMA peaks are equal)
+
+
+def geo_peak(engine):
+    """Ceiling of the geometry kernel's algorithmic fp32 FLOP/s for an engine name (ops.geo_mode())."""
+    return PEAK_H2_TFLOPS if engine == "h2" else PEAK_SPLIT_TFLOPS
+
+
+def family_peak(kernel):
+    """(ceiling, piece form) of a kernel of the 'split' family — 'color_fwd' | 'color_bwd' | 'wgrad' | 'rhead_fwd' | 'rhead_bwd' — as this process runs it."""
+    from spurfies_amd import ops
+
+    fam = "color" if kernel.startswith("color") else ("rhead" if kernel.startswith("rhead") else "wgrad")
+    if ops._arith_of(ops._ARITH[fam], kernel) == 3:
+        return PEAK_H2_TFLOPS, "H2: three fp16 piece products per fp32 product; ceiling = dense fp16 MFMA peak / 3"
+    return PEAK_SPLIT_TFLOPS, "six bf16 piece products per fp32 product; ceiling = dense bf16 MFMA peak / 6"
 PEAK_HBM_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 F_COLOR_FWD = 2.0 * (103 * 256 + 2 * 256 * 256)     # F_color's three activated layers, per pair (the linear fourth runs per point)
 F_COLOR_BWD = 2.0 * (2 * 256 * 256 + 256 * 64)      # data-gradient chain of the same, per pair (weight gradients: spf_wgrad)
@@ -430,25 +446,28 @@ def main_eval(args):
     if fwd:
         ms, pairs = sum(p["ms"] for p in fwd), sum(p["pairs"] for p in fwd)
         ach = pairs * F_FWD / (ms * 1e-3) / 1e12
-        ck = clk.get((engine, False))
-        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
-                "kernel": ("geo_pairs_x3_kernel<false>" if engine == "split" else "geo_pairs_x3w_kernel<false>") + " (sampler passes: SDF only)",
+        ck = clk.get(("split_w" if engine == "h2" else engine, False))
+        gpk = geo_peak(engine)
+        cpk, cform = family_peak("color_fwd")
+        roof = {"bound": "mfma", "achieved": ach, "peak": gpk, "unit": "TFLOP/s", "frac": ach / gpk,
+                "kernel": ("geo_pairs_x3_kernel<false>" if engine == "split" else ("geo_pairs_x3w_kernel<false, 2, true>" if engine == "h2" else "geo_pairs_x3w_kernel<false, 3, false>")) + " (sampler passes: SDF only)",
                 "launches": len(fwd), "avg_ms": ms / len(fwd), "pairs_per_launch": pairs / len(fwd), "flop_per_pair": F_FWD, "total_ms_per_step": ms / args.steps,
-                "held_clock": held_clock(ach, ck), "traffic": None, "timing": "HIP events over the timed region",
+                "held_clock": held_clock(ach, ck, gpk), "traffic": None, "timing": "HIP events over the timed region",
                 "engine": {"selected": engine, "autotune_ms": tune},
-                "peak_basis": "algorithmic fp32 FLOP/s against the dense bf16 MFMA peak / 6 (six exact bf16 piece products per fp32 product)"}
+                "peak_basis": ("algorithmic fp32 FLOP/s against the dense fp16 MFMA peak / 3 (H2: three exact fp16 piece products per fp32 product)" if engine == "h2" else
+                               "algorithmic fp32 FLOP/s against the dense bf16 MFMA peak / 6 (six exact bf16 piece products per fp32 product)")}
         sec = []
         if jac:
             ms2, pairs2 = sum(p["ms"] for p in jac), sum(p["pairs"] for p in jac)
             a2 = pairs2 * (F_FWD + F_JAC) / (ms2 * 1e-3) / 1e12
-            sec.append({"kernel": "geometry kernel with the Jacobian sweep (main pass: SDF + normals)", "bound": "mfma", "achieved": a2, "peak": PEAK_SPLIT_TFLOPS,
-                        "unit": "TFLOP/s", "frac": a2 / PEAK_SPLIT_TFLOPS, "avg_ms": ms2 / len(jac), "pairs_per_launch": pairs2 / len(jac), "total_ms_per_step": ms2 / args.steps})
+            sec.append({"kernel": "geometry kernel with the Jacobian sweep (main pass: SDF + normals)", "bound": "mfma", "achieved": a2, "peak": gpk,
+                        "unit": "TFLOP/s", "frac": a2 / gpk, "avg_ms": ms2 / len(jac), "pairs_per_launch": pairs2 / len(jac), "total_ms_per_step": ms2 / args.steps})
         col = [p for p in prof if p["tag"] == "color_fwd" and p["pairs"] > 0]
         if col:
             ms3, pairs3 = sum(p["ms"] for p in col), sum(p["pairs"] for p in col)
             a3 = pairs3 * F_COLOR_FWD / (ms3 * 1e-3) / 1e12
-            sec.append({"kernel": "color_forward_x3_kernel<false>", "bound": "mfma", "achieved": a3, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
-                        "frac": a3 / PEAK_SPLIT_TFLOPS, "avg_ms": ms3 / len(col), "pairs_per_launch": pairs3 / len(col), "total_ms_per_step": ms3 / args.steps})
+            sec.append({"kernel": "color_forward_x3_kernel<false>", "bound": "mfma", "achieved": a3, "peak": cpk, "peak_basis": cform, "unit": "TFLOP/s",
+                        "frac": a3 / cpk, "avg_ms": ms3 / len(col), "pairs_per_launch": pairs3 / len(col), "total_ms_per_step": ms3 / args.steps})
         knn = [p for p in prof if p["tag"] == "knn"]
         if knn:
             sec.append({"kernel": "spf_grid_query (all passes)", "bound": "hbm", "total_ms_per_step": sum(p["ms"] for p in knn) / args.steps, "launches_per_step": len(knn) / args.steps})
@@ -486,7 +505,7 @@ def main_eval(args):
                              "in HBM, `seconds_incl_d2h` = with the one pageable copy of the float32 volume to the host (PCIe-inclusive)"}
             if gp:
                 ms, pairs = sum(p["ms"] for p in gp), sum(p["pairs"] for p in gp)
-                sweep["geo_kernel"] = {"achieved": pairs * F_FWD / (ms * 1e-3) / 1e12, "frac": pairs * F_FWD / (ms * 1e-3) / 1e12 / PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
+                sweep["geo_kernel"] = {"achieved": pairs * F_FWD / (ms * 1e-3) / 1e12, "frac": pairs * F_FWD / (ms * 1e-3) / 1e12 / geo_peak(ops.geo_mode()), "unit": "TFLOP/s",
                                        "pairs": pairs, "kernel_ms_total": ms}
         res["sdf_eval_sweep"] = sweep
         image = None
@@ -717,7 +736,7 @@ def measure_train(args, ctx, w):
         gc.enable()
 
     if not use_graph and a.scenes == 1 and not light:          # the other regimes' kernels, timed over separate steps (outside both timed regions)
-        ops.profile_start(tags=("color_fwd", "color_bwd", "knn", "render_fwd", "render_bwd"))
+        ops.profile_start(tags=("color_fwd", "color_bwd", "wgrad", "knn", "render_fwd", "render_bwd"))
         for i in range(first, first + min(steps, 10)):
             run_step(i)
         prof += ops.profile_stop()
@@ -749,7 +768,7 @@ def measure_train(args, ctx, w):
         ach = pairs * (F_FWD + F_JAC) / (ms * 1e-3) / 1e12
         kname = "geo_pairs_x3_kernel<true>" if engine == "split" else ("geo_pairs_x3w_kernel<true, 2, true>" if engine == "h2" else "geo_pairs_x3w_kernel<true, 3, false>")
         shape = "v_mfma_f32_16x16x32_bf16" if engine == "split" else ("v_mfma_f32_32x32x16_f16" if engine == "h2" else "v_mfma_f32_32x32x16_bf16")
-        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if engine == "h2" else PEAK_SPLIT_TFLOPS
+        peak = geo_peak(engine)
         roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "peak_basis": (f"algorithmic fp32 FLOP/s; each fp32 product = 3 exact fp16 piece products (two fp16 pieces per operand, main + cross accumulators) on the "
                                f"matrix pipe (this run: {shape}), so the ceiling is the dense fp16 MFMA peak (2516.6 TFLOP/s) / 3; for scale, the fp32-MFMA peak is 157.3 TFLOP/s"
@@ -757,7 +776,7 @@ def measure_train(args, ctx, w):
                                f"algorithmic fp32 FLOP/s; each fp32 product = 6 exact bf16 piece products on the bf16 matrix pipe (this run: {shape}), so the "
                                "ceiling is the dense bf16 MFMA peak (2516.6 TFLOP/s) / 6; for scale, the fp32-MFMA peak is 157.3 TFLOP/s"),
                 "achieved_over_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
-                "sustainable": None if light else sustainable_ceiling(ach),
+                "sustainable": None if light else sustainable_ceiling(ach, engine),
                 "held_clock": held_clock(ach, clk, peak),
                 "engine": {"selected": engine, "mfma": shape, "how": ("timed both shapes on this box after 40 untimed passes, before the warm-up steps (main-pass launch; the shape alternates every pass, A B B A x 10)" if tune else ("the main record's choice" if light else "--geo-engine")),
                            "autotune_ms": tune},
@@ -792,11 +811,7 @@ def measure_train(args, ctx, w):
                    "settle_steps_untimed": settle, "settle_seconds": args.settle,
                    "sampler_draws": "CPU generator, reference call order" + ("" if world == 1 else ("; batch-wide per rank, own rows kept (--exact-draws)" if a.exact_draws
                                                                                                    else "; per-rank streams, own rays only")),
-                   "arithmetic": ("fp32 storage and accumulation throughout. Geometry kernel (engine h2): every fp32 operand as two fp16 pieces (22 mantissa bits), each fp32 product = 3 exact "
-                                  "fp16 piece products in two fp32 accumulators (main + 2^-11 x cross) — measured error against float64 equal to the fp32-MFMA kernel's (tools/engine_accuracy.py: SDF "
-                                  "1.1e-7 rms relative for f32 / bf16 x 3 / h2 alike). " if engine == "h2" else "fp32 storage and accumulation throughout. ") +
-                                 "Colour trunk, per-point head and the weight-gradient GEMMs" + ("" if engine == "h2" else ", and the geometry kernel,") +
-                                 " form each fp32 product from three bf16 pieces per operand (6 exact bf16 piece products: fp32-class, <= 2 ulp per product)",
+                   "arithmetic": arithmetic_text(engine),
                    "launch": launch},
         "roofline": roof, "dist": dinfo,
         "sustained_ms_per_step": sustained, "sustained_steps": n_sust if sustained is not None else 0,
@@ -914,7 +929,29 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def sustainable_ceiling(achieved_tflops):
+def arithmetic_text(engine):
+    """config.arithmetic of the contract line: which piece form every dense kernel of THIS process computes in (ops._H2 / ops._ARITH as they stand)."""
+    from spurfies_amd import ops
+
+    h2 = [k for k in ("color_fwd", "color_bwd", "wgrad", "rhead_fwd", "rhead_bwd")
+          if ops._arith_of(ops._ARITH["color" if k.startswith("color") else ("rhead" if k.startswith("rhead") else "wgrad")], k) == 3]
+    names = {"color_fwd": "colour trunk forward", "color_bwd": "colour trunk backward", "wgrad": "weight-gradient GEMMs", "rhead_fwd": "per-point head forward",
+             "rhead_bwd": "per-point head backward"}
+    b3 = [names[k] for k in names if k not in h2]
+    h2 = [names[k] for k in h2] + (["geometry kernel (engine h2)"] if engine == "h2" else [])
+    if engine != "h2":
+        b3.append(f"geometry kernel (engine {engine})")
+    txt = "fp32 storage and accumulation throughout; every fp32 product of a dense kernel is formed exactly from 16-bit pieces on the matrix pipe. "
+    if h2:
+        txt += ("H2 — two fp16 pieces per operand (22 mantissa bits), 3 exact fp16 piece products per fp32 product, fp32 accumulators (MLP tiles: main + 2^-11 x cross, "
+                "combined once per layer; gradient rows / weight-gradient operands block-scaled by powers of two): " + ", ".join(h2) + ". Measured error against float64 "
+                "equal to the fp32-MFMA twins' (tools/engine_accuracy.py, tools/color_accuracy.py, tests/test_gpu_wgrad.py). ")
+    if b3:
+        txt += "bf16 x 3 — three bf16 pieces per operand, 6 exact bf16 piece products (<= 2 ulp per product): " + ", ".join(b3) + "."
+    return txt
+
+
+def sustainable_ceiling(achieved_tflops, engine="split_w"):
     """`frac` is priced against the 2.4 GHz data-sheet peak.  What the chip SUSTAINS on this instruction mix was measured with socket power beside
     it (tools/power_probe.py -> profiles/r*_power.json; another box, labelled): every dense kernel of the step runs near the 1.40 kW cap with
     the clock pulled down to ~2.0 GHz (power-limited); the library's own GEMM loop run alone peaks at ~75 % matrix-pipe duty / full clock with
@@ -924,15 +961,16 @@ def sustainable_ceiling(achieved_tflops):
     if rec is None:
         return {"peak": None, "frac": None, "why": name}
     loads = rec.get("loads", {})
-    best = max((v.get("tflops_fp32_equiv", 0.0) for k, v in loads.items() if k.startswith("x3_loop_")), default=0.0)
+    pre = "h2_loop_" if engine == "h2" else "x3_loop_"          # the GEMM loop in the run's own piece form
+    best = max((v.get("tflops_fp32_equiv", 0.0) for k, v in loads.items() if k.startswith(pre)), default=0.0)
     if best <= 0.0:
-        return {"peak": None, "frac": None, "why": f"profiles/{name} holds no x3_loop_* load"}
-    geo = loads.get("geo_split_w", {})
+        return {"peak": None, "frac": None, "why": f"profiles/{name} holds no {pre}* load"}
+    geo = loads.get("geo_h2" if engine == "h2" else "geo_split_w", {})
     return {"peak": best, "unit": "TFLOP/s", "frac": achieved_tflops / best,
-            "what": "highest algorithmic fp32 rate the library's bf16-piece GEMM loop sustained when run ALONE (tools/micro/x3_loop_rate.hip, three epilogue "
+            "what": f"highest algorithmic fp32 rate the library's {'H2 (three fp16 piece products)' if engine == 'h2' else 'bf16-piece'} GEMM loop sustained when run ALONE (tools/micro/x3_loop_rate.hip, three epilogue "
                     "variants), with socket power sampled beside it",
             "power_cap_w": rec.get("power_cap_w"), "geo_kernel_power_w": geo.get("power_w_mean"), "geo_kernel_ghz": geo.get("ghz_in_kernel"),
-            "loop_variants": {k: {kk: v.get(kk) for kk in ("what", "tflops_fp32_equiv", "mfma_duty", "ghz", "power_w_mean")} for k, v in loads.items() if k.startswith("x3_loop_")},
+            "loop_variants": {k: {kk: v.get(kk) for kk in ("what", "tflops_fp32_equiv", "mfma_duty", "ghz", "power_w_mean")} for k, v in loads.items() if k.startswith(pre)},
             "source": f"profiles/{name} — collected on ANOTHER box (hwmon power1_input of the HIP device's PCI card, 100 Hz) on this tree's kernel sources "
                       "(csrc sha256 matches), committed; not measured in this run"}
 
@@ -1006,8 +1044,23 @@ def secondary_rooflines(prof, rays_local):
         rows = [p for p in prof if p["tag"] == tag and p["pairs"] > 0]
         if rows:
             ach = sum(p["pairs"] for p in rows) * flop / (sum(p["ms"] for p in rows) * 1e-3) / 1e12
-            out.append({"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
+            pk, form = family_peak(tag)
+            out.append({"kernel": name, "bound": "mfma", "achieved": ach, "peak": pk, "peak_basis": form, "unit": "TFLOP/s", "frac": ach / pk,
                         "avg_ms": mean(rows, "ms"), "pairs_per_launch": mean(rows, "pairs"), "flop_per_pair": flop})
+    wg = [p for p in prof if p["tag"] == "wgrad" and p.get("rows_x_c", 0) > 0 and p.get("problems", 0) >= 3]        # the colour trunk's + head's problems in one launch pair
+    if wg:
+        # dW[256, C] += G[:rows]^T A[:rows, :C] per problem: 512 rows C FLOP, and both operands are read ONCE from HBM (4 (256 + C) bytes per row) —
+        # the kernel is priced against both ceilings and bound by the nearer one
+        sec_ = sum(p["ms"] for p in wg) * 1e-3
+        tf, gbs = sum(p["rows_x_c"] for p in wg) * 512.0 / sec_ / 1e12, sum(p["operand_floats"] for p in wg) * 4.0 / sec_ / 1e9
+        pk, form = family_peak("wgrad")
+        hbm_nearer = gbs / PEAK_HBM_GBS >= tf / pk
+        out.append({"kernel": "wgrad_split8_batched_kernel (+ its slab reduce launch)", "bound": "hbm" if hbm_nearer else "mfma",
+                    "achieved": gbs if hbm_nearer else tf, "peak": PEAK_HBM_GBS if hbm_nearer else pk, "unit": "GB/s" if hbm_nearer else "TFLOP/s",
+                    "frac": max(gbs / PEAK_HBM_GBS, tf / pk), "avg_ms": mean(wg, "ms"), "problems_per_launch": mean(wg, "problems"),
+                    "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": sum(p["operand_floats"] for p in wg) * 4.0 / len(wg),
+                            "what": "operand bytes (G and A rows, fp32, each read once) / launch time"},
+                    "mfma": {"achieved": tf, "peak": pk, "unit": "TFLOP/s", "frac": tf / pk, "peak_basis": form}})
     knn = [p for p in prof if p["tag"] == "knn" and p["slots"] > 1 and p["rays"] == rays_local]        # the main pass (98 samples/ray, SR = 80)
     if knn:
         # 12 B position in + 1 B mask out per sample; per hit slot 4 k B of indices + 16 B (location, sample id) out

@@ -1276,6 +1276,7 @@ def wgrad_batched(problems, n_rows):
     dev = problems[0][0].device
     arr = (_lib.WgradProblem * len(problems))()
     max_rows = None
+    work = []                # (row count: device tensor | None = the call's, capacity, C) per problem — read by the profiler span only
     for q, prob in enumerate(problems):
         G, A, out, dbias = prob[:4]
         rest = tuple(prob[4:])
@@ -1287,6 +1288,7 @@ def wgrad_batched(problems, n_rows):
         arr[q].dW, arr[q].ldw, arr[q].dbias = _lib.ptr(out), out.stride(0), _lib.ptr(dbias)
         arr[q].C, arr[q].layout, arr[q].col_rot, arr[q].col_mod = int(C), int(layout), int(col_rot), int(col_mod)
         rows = min(G.shape[0], A.shape[0])
+        work.append((own[0] if own is not None else None, int(min(rows, own[1])) if own is not None else rows, int(C)))
         if own is not None:
             arr[q].n_rows, arr[q].max_rows = _lib.ptr(own[0]), int(min(rows, own[1]))
         else:
@@ -1296,7 +1298,12 @@ def wgrad_batched(problems, n_rows):
     key = _scratch_key(dev) + (nws,)
     if key not in _wgrad_ws:
         _wgrad_ws[key] = torch.empty((nws,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    meta = {}
+    if _prof.active():       # sum over the problems of rows x (256 + C) (operand floats read) and rows x C (x 512 = FLOP)
+        cnt = [(torch.clamp((n if n is not None else n_rows).reshape(-1)[:1].double(), max=cap) if (n is not None or n_rows is not None) else
+                torch.tensor([float(cap)], dtype=torch.float64, device=dev), C) for n, cap, C in work]
+        meta = {"rows_x_c": sum(r * C for r, C in cnt), "operand_floats": sum(r * (256 + C) for r, C in cnt), "problems": len(problems)}
+    with torch.cuda.device(dev), _prof.span("wgrad", **meta):
         _lib.check(_lib.lib().spf_wgrad_batched(arr, len(problems), _lib.ptr(n_rows), 0 if max_rows is None else max_rows, _lib.ptr(_wgrad_ws[key]), _arith_of(_ARITH["wgrad"], "wgrad"),
                                                     _wgrad_det(256), _lib.stream_ptr()),
                    "spf_wgrad_batched")

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/local_ab
 for rays in 1024 128; do
   for g in "" "--graph"; do
     tag="r${rays}$( [ -n "$g" ] && echo _graph )"
-    python bench.py --rays $rays $g --local --no-cpu-baseline --sustained 0 --ab-reps 0 --geo-engine split_w > gpurun_out/local_ab/$tag.json 2> gpurun_out/local_ab/$tag.err
+    python bench.py --rays $rays $g --local --no-cpu-baseline --sustained 0 --ab-reps 0 > gpurun_out/local_ab/$tag.json 2> gpurun_out/local_ab/$tag.err
     python - <<PY
 import json
 r = json.load(open("gpurun_out/local_ab/$tag.json"))

@@ -16,7 +16,6 @@ OUT = TAG + ("_eval" if MODE else "") + ("_dense" if DENSE else "") + "_pmc_traf
 
 POINTS, RAYS = (200000, 4096) if DENSE else (10000, 1024)
 MODE += ["--spacing", "0.0125"] if DENSE else []
-MODE += ["--geo-engine", "split_w"]
 out = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = f"gpurun_out/pmc_{ctr}"

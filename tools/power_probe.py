@@ -202,8 +202,10 @@ def main():
     # the GEMM loop alone (separate process on the same GPU; this process only samples)
     exe = os.path.join("tools", "micro", "x3_loop_rate")
     if os.path.exists(exe):
-        for mode, what in ((0, "x3 GEMM loop + barrier only"), (1, "x3 GEMM loop + split-only epilogue"), (2, "x3 GEMM loop + bias / LeakyReLU / sign words / split")):
-            label = f"x3_loop_{mode}"
+        for mode, what in ((0, "x3 GEMM loop + barrier only"), (1, "x3 GEMM loop + split-only epilogue"), (2, "x3 GEMM loop + bias / LeakyReLU / sign words / split"),
+                           (3, "H2 GEMM loop (3 fp16 piece products, main + cross accumulators, combine) + barrier only"), (4, "H2 GEMM loop + split-only epilogue"),
+                           (5, "H2 GEMM loop + bias / LeakyReLU / sign words / split")):
+            label = f"x3_loop_{mode}" if mode < 3 else f"h2_loop_{mode - 3}"
             smp.label = label + ":ramp"
             t0 = time.perf_counter()
             proc = subprocess.Popen([exe, str(mode), str(a.secs)], stdout=subprocess.PIPE, text=True)
@@ -248,18 +250,20 @@ def main():
     P, NP = pl.host_counts()
     res["pairs"], res["points"] = NP, P
 
-    for mode, shape in (("split_w", "32x32x16"), ("split", "16x16x32")):
+    for mode, shape in (("h2", "32x32x16_f16"), ("split_w", "32x32x16_bf16"), ("split", "16x16x32_bf16")):
         ops.set_geo_mode(mode)
         ops.geo_clock(reset=True)
         row = run_for(lambda: ops.geo_forward(x, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, 45.0, with_grad=True), a.secs, smp, "geo_" + mode)
-        clk = ops.geo_clock(reset=True).get((mode, True))
+        clk = ops.geo_clock(reset=True).get(("split_w" if mode == "h2" else mode, True))          # (h2 = the 32x32x16 kernel: its counter slot)
         row["every_card_power_w_right_after"] = {hw: (int(_read(os.path.join(hw, "power1_input")) or 0) / 1e6) for hw in sensors.detail.get("cards", {})}
-        row.update({"what": f"geo_pairs kernel, main-pass form (SDF + Jacobian sweep), v_mfma_f32_{shape}_bf16, {NP} pairs", "ghz_in_kernel": clk["ghz"] if clk else None,
+        row.update({"what": f"geo_pairs kernel, main-pass form (SDF + Jacobian sweep), v_mfma_f32_{shape}, {NP} pairs", "ghz_in_kernel": clk["ghz"] if clk else None,
                     "tflops_algorithmic": NP * (bench.F_FWD + bench.F_JAC) / (row["ms_per_launch"] * 1e-3) / 1e12})
-        row["frac_of_peak"] = row["tflops_algorithmic"] / bench.PEAK_SPLIT_TFLOPS
+        row["frac_of_peak"] = row["tflops_algorithmic"] / (bench.PEAK_BF16_MFMA_TFLOPS / 3.0 if mode == "h2" else bench.PEAK_SPLIT_TFLOPS)
         res["loads"]["geo_" + mode] = row
         print("geo_" + mode, row, flush=True)
-    ops.set_geo_mode("split_w")
+    ops.set_geo_mode("h2")
+    peak_c = lambda kern: bench.PEAK_BF16_MFMA_TFLOPS / 3.0 if ops._arith_of(0, kern) == 3 else bench.PEAK_SPLIT_TFLOPS      # H2 kernels: three piece products
+    pieces = lambda kern: "H2: three fp16 piece products" if ops._arith_of(0, kern) == 3 else "six bf16 piece products"
     geo = ops.geo_forward(x, pl, dev["neural_pts"], dev["neural_feats_geometry"], packed, 45.0, with_grad=True)
     fcp = [dev[f"F_color.{i}.{w}"].clone().requires_grad_(True) for i in (0, 2, 4) for w in ("weight", "bias")]
     table = dev["neural_feats_color"].clone().requires_grad_(True)
@@ -268,8 +272,8 @@ def main():
         return ops.ColorAgg.apply(table, *fcp, x, geo["wn"], pl, dev["neural_pts"], P, NP)
 
     row = run_for(fwd_train, a.secs, smp, "color_fwd")
-    row.update({"what": f"color_forward_x3_kernel<true> (+ its pack launch), {NP} pairs", "tflops_algorithmic": NP * bench.F_COLOR_FWD / (row["ms_per_launch"] * 1e-3) / 1e12})
-    row["frac_of_peak"] = row["tflops_algorithmic"] / bench.PEAK_SPLIT_TFLOPS
+    row.update({"what": f"color_forward_x3_kernel<true> (+ its pack launch), {pieces('color_fwd')}, {NP} pairs", "tflops_algorithmic": NP * bench.F_COLOR_FWD / (row["ms_per_launch"] * 1e-3) / 1e12})
+    row["frac_of_peak"] = row["tflops_algorithmic"] / peak_c("color_fwd")
     res["loads"]["color_fwd"] = row
     print("color_fwd", row, flush=True)
 
@@ -286,25 +290,25 @@ def main():
         _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                                  _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), NP, pl.k, _lib.ptr(pk), _lib.ptr(masks), _lib.ptr(G[0]),
                                                  _lib.ptr(G[1]), _lib.ptr(G[2]), _lib.ptr(gb[0]), _lib.ptr(gb[1]), _lib.ptr(gb[2]), _lib.ptr(gf), None,
-                                                 ops._ARITH["color"], _lib.stream_ptr()), "bwd")
+                                                 ops._arith_of(ops._ARITH["color"], "color_bwd"), _lib.stream_ptr()), "bwd")
 
     try:
         row = run_for(bwd_only, a.secs, smp, "color_bwd")
-        row.update({"what": f"color_backward_x3_kernel, {NP} pairs", "tflops_algorithmic": NP * bench.F_COLOR_BWD / (row["ms_per_launch"] * 1e-3) / 1e12})
-        row["frac_of_peak"] = row["tflops_algorithmic"] / bench.PEAK_SPLIT_TFLOPS
+        row.update({"what": f"color_backward_x3_kernel, {pieces('color_bwd')}, {NP} pairs", "tflops_algorithmic": NP * bench.F_COLOR_BWD / (row["ms_per_launch"] * 1e-3) / 1e12})
+        row["frac_of_peak"] = row["tflops_algorithmic"] / peak_c("color_bwd")
         res["loads"]["color_bwd"] = row
         print("color_bwd", row, flush=True)
     except Exception as e:                       # the C signature moves with the rounds; the other rows stand on their own
         res["loads"]["color_bwd"] = {"error": repr(e)[:300]}
-    # one weight-gradient GEMM of the colour trunk's shape (dW[256,256] += G^T A over NP rows, row-major operands, bf16-piece products)
+    # one weight-gradient GEMM of the colour trunk's shape (dW[256,256] += G^T A over NP rows, row-major operands)
     try:
         rows_w = (NP // 64) * 64
         Gw, Aw = torch.randn((rows_w, 256), device="cuda"), torch.randn((rows_w, 256), device="cuda")
         dW, db = torch.zeros((256, 256), device="cuda"), torch.zeros((256,), device="cuda")
         nr = torch.tensor([rows_w], dtype=torch.int32, device="cuda")
         row = run_for(lambda: ops.wgrad(Gw, Aw, nr, out=dW, dbias=db), a.secs, smp, "wgrad_256")
-        row.update({"what": f"spf_wgrad C = 256 (GEMM + slab reduce launches), {rows_w} rows", "tflops_algorithmic": rows_w * 2.0 * 256 * 256 / (row["ms_per_launch"] * 1e-3) / 1e12})
-        row["frac_of_peak"] = row["tflops_algorithmic"] / bench.PEAK_SPLIT_TFLOPS
+        row.update({"what": f"spf_wgrad C = 256 (GEMM + slab reduce launches), {pieces('wgrad')}, {rows_w} rows", "tflops_algorithmic": rows_w * 2.0 * 256 * 256 / (row["ms_per_launch"] * 1e-3) / 1e12})
+        row["frac_of_peak"] = row["tflops_algorithmic"] / peak_c("wgrad")
         res["loads"]["wgrad_256"] = row
         print("wgrad_256", row, flush=True)
         del Gw, Aw

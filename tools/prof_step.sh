@@ -17,7 +17,7 @@ name = sys.argv[1]
 bench = json.loads([l for l in open(f"gpurun_out/prof_{name}.log") if l.startswith("{")][-1])
 roof = bench.get("roofline") or {}
 f = glob.glob(f"gpurun_out/prof_{name}/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "geo_pairs_x3_kernel<true>" in r["Kernel_Name"] or "geo_pairs_x3w_kernel<true>" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "geo_pairs_x3_kernel<true>" in r["Kernel_Name"] or "geo_pairs_x3w_kernel<true" in r["Kernel_Name"]]
 json.dump(bench, open(f"gpurun_out/{name}_bench.json", "w"))
 d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
 big = [x for x in d if x > 0.3 * max(d)]

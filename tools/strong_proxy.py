@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--out", default="gpurun_out/strong_proxy.json")
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--dense", action="store_true", help="configs[4]: 2e5 points, spacing 0.0125, 4096 rays per batch")
-    ap.add_argument("--engine", default="split_w")
+    ap.add_argument("--engine", default="h2")
     ap.add_argument("--scenes", type=int, default=0, help="configs[3] proxy: this many scenes round-robin on one GPU (two streams)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
