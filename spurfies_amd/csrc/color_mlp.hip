@@ -835,6 +835,7 @@ color_backward_x3_kernel(const float* __restrict__ g_agg3, const int32_t* __rest
                 const float rmax = fmaxf(fmaxf(s_amax[0][lane], s_amax[1][lane]), fmaxf(s_amax[2][lane], s_amax[3][lane]));
                 int ex = 0;
                 if (rmax > 0.f && rmax < 3.0e38f) (void)frexpf(rmax, &ex);          // rmax = m 2^ex, m in [0.5, 1)
+                ex = max(ex, -100);      // (rows below 2^-100 — an RBF weight of 1e-20 times a vanishing upstream gradient — keep a finite factor: 2^(8 - ex) must not pass 2^127)
                 const float sc = ldexpf(1.0f, 8 - ex);                               // row max -> [128, 256)
                 if (wave == 0) s_rinv[lane] = ldexpf(1.0f, ex - 8);
 #pragma unroll

@@ -43,8 +43,9 @@ grads64 = torch.autograd.grad((agg64 * g_up.double()).sum(), [T64] + W64)
 ref = {"agg3": agg64.detach(), "latent": grads64[0], **{n_: g for n_, g in zip(names, grads64[1:])}}
 
 res = {"pairs": NP, "points": P, "upstream_gradient_scale": a.gscale, "what": __doc__}
-for mode, h2 in (("f32", {}), ("split", dict(color_fwd=False, color_bwd=False, wgrad=False)), ("h2", dict(color_fwd=True, color_bwd=True)),
-                 ("h2_fwd_only", dict(color_fwd=True, color_bwd=False)), ("h2_bwd_only", dict(color_fwd=False, color_bwd=True))):
+for mode, h2 in (("f32", {}), ("split", dict(color_fwd=False, color_bwd=False, wgrad=False)), ("h2", dict(color_fwd=True, color_bwd=True, wgrad=True)),
+                 ("h2_fwd_only", dict(color_fwd=True, color_bwd=False, wgrad=False)), ("h2_bwd_only", dict(color_fwd=False, color_bwd=True, wgrad=False)),
+                 ("h2_wgrad_only", dict(color_fwd=False, color_bwd=False, wgrad=True))):
     ops.set_color_mode("f32" if mode == "f32" else "split")
     ops.set_wgrad_mode("f32" if mode == "f32" else "split")
     prev = ops.set_h2(**h2)

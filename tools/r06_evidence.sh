@@ -67,7 +67,7 @@ pmc)
   python3 tools/pmc_mfma.py r06 > gpurun_out/r06_pmc_mfma.log 2>&1; tail -2 gpurun_out/r06_pmc_mfma.log | cut -c1-300
   ;;
 power)
-  python3 tools/power_probe.py --out gpurun_out/r06_power.json > gpurun_out/r06_power.log 2>&1; grep -E "^(geo_split_w|color_fwd|color_bwd|wgrad_256|step) " gpurun_out/r06_power.log | cut -c1-400
+  python3 tools/power_probe.py --out gpurun_out/r06_power.json > gpurun_out/r06_power.log 2>&1; grep -E "^(h2_loop_[0-2]|geo_h2|geo_split_w|color_fwd|color_bwd|wgrad_256|step) " gpurun_out/r06_power.log | cut -c1-400
   ;;
 shapes)
   bash tools/shapes_evidence.sh r06 2>&1 | tail -8
