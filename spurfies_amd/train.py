@@ -284,6 +284,14 @@ class TrainStep:
             self._graph_tail.replay()
         return self._static_out
 
+    def skipped_updates(self) -> int:
+        """Updates the device-side clip + Adam sequence SKIPPED because a gradient was not finite (the reference skips them too: train.py:548-564 —
+        but there a skipped step is visible in the loop; here nothing reads the device).  One 16-byte read: call it where the host waits anyway
+        (checkpoints, logging).  A count that keeps growing means the run is no longer learning (round 6's soak found an overflowing row factor
+        this way)."""
+        f = getattr(self.optimizer, "_flat", None)
+        return int(self.skipped) if f is None else int(f["state"][1].item())
+
     # ---- whole-step state: what a run needs to CONTINUE as if it had not stopped ---------------------------------------------------
     def state_dict(self):
         """Model, optimiser moments, learning-rate schedule, step counter and the CPU generator the reference draws its per-step random
@@ -582,6 +590,14 @@ class VolOpt:
 
     # ---- checkpoints (train.py:221-241, 293-328) -----------------------------------------------------------------
     def save_checkpoints(self, epoch, latest_only=False):
+        skipped = self.step.skipped_updates()               # (the host is about to wait for the device anyway)
+        if skipped > getattr(self, "_skipped_seen", 0):
+            import warnings
+
+            warnings.warn(f"{skipped - getattr(self, '_skipped_seen', 0)} optimisation steps since the last checkpoint had a non-finite gradient and were "
+                          f"skipped ({skipped} of {self.iter_step} in total): ops.set_h2(color_fwd=False, color_bwd=False, wgrad=False) and "
+                          "ops.set_geo_mode('split_w') select the six-product bf16 arithmetic, 'f32' the fp32-MFMA twins", RuntimeWarning)
+            self._skipped_seen = skipped
         model_blob = {"epoch": epoch, "model_state_dict": self.model.state_dict(), "iter_step": self.iter_step}
         opt_blob = {"epoch": epoch, "optimizer_state_dict": self.optimizer.state_dict()}
         names = ["latest"] if latest_only else ["latest", str(epoch)]
