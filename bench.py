@@ -776,6 +776,7 @@ def measure_train(args, ctx, w):
                                f"algorithmic fp32 FLOP/s; each fp32 product = 6 exact bf16 piece products on the bf16 matrix pipe (this run: {shape}), so the "
                                "ceiling is the dense bf16 MFMA peak (2516.6 TFLOP/s) / 6; for scale, the fp32-MFMA peak is 157.3 TFLOP/s"),
                 "achieved_over_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+                "achieved_over_bf16x3_ceiling": ach / PEAK_SPLIT_TFLOPS,          # rounds 1 - 5 priced `frac` against this (bf16 peak / 6 = 419.4): comparable across rounds
                 "sustainable": None if light else sustainable_ceiling(ach, engine),
                 "held_clock": held_clock(ach, clk, peak),
                 "engine": {"selected": engine, "mfma": shape, "how": ("timed both shapes on this box after 40 untimed passes, before the warm-up steps (main-pass launch; the shape alternates every pass, A B B A x 10)" if tune else ("the main record's choice" if light else "--geo-engine")),

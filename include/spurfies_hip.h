@@ -187,10 +187,21 @@ int spf_compact_pairs_filter(const uint8_t* slot_valid, const int32_t* nbr, int3
 #define SPF_ARITH_SPLIT 0
 #define SPF_ARITH_F32 1
 #define SPF_ARITH_SPLIT_W 2
-/* ABI 6 — spf_geo_forward only: "H2" arithmetic on v_mfma_f32_32x32x16_f16 — every fp32 operand as TWO fp16 pieces x = h1 + 2^-11 h2 (22 mantissa
- * bits), a product = h1 g1 (main accumulator) + 2^-11 (h1 g2 + h2 g1) (second accumulator, scaled once per layer), every piece product exact in
- * the fp32 accumulation: three matrix instructions per product instead of six.  |error| <= 3 x 2^-22 (7e-7) of a product (bf16 x 3: ~2e-7;
- * fp32: 6e-8); operand range is fp16's (|x| < 65504; below 6e-5 an absolute accuracy of 1.5e-11).  The same kernel as SPF_ARITH_SPLIT_W otherwise. */
+/* ABI 6 — "H2" arithmetic on v_mfma_f32_32x32x16_f16: every fp32 operand as TWO fp16 pieces (22 mantissa bits), an fp32 product = THREE exact fp16
+ * piece products (the fourth is <= 2^-22 of the product and dropped) accumulated in fp32: three matrix instructions per product instead of six.
+ * Per product |error| <= 3 x 2^-22 (bf16 x 3: ~2e-7; fp32: 6e-8); per OUTPUT of a 256-term layer the measured error against float64 equals the
+ * fp32-MFMA kernels' (profiles/r06_engine_accuracy.json, r06_color_accuracy.json).  Accepted by
+ *   spf_geo_forward                 x = h1 + 2^-11 h2; main + cross accumulators combined once per layer.  The same kernel as SPF_ARITH_SPLIT_W
+ *                                   otherwise.  Activations must lie within fp16's range (|x| < 65504; below 6e-5 an absolute accuracy of 1.5e-11).
+ *   spf_color_forward / _backward   a member of the SPF_ARITH_SPLIT family: same operand layouts, sign words and bias-gradient convention, so forward
+ *                                   and backward may differ in it (SPLIT forward + H2 backward and vice versa are valid pairs).  The backward
+ *                                   carries every gradient ROW with its own power of two (rows span 1 .. 1e-44 and zeros: all finite).
+ *   spf_wgrad / spf_wgrad_batched   (C > 32) pieces h1 = fp16(s x), h2 = fp16(s x - h1) into ONE accumulator; A scaled by 4 (|A| < 16376), G per
+ *                                   wave and 32-column block by a power of two chosen on the fly: a term is exact relative to the LARGEST
+ *                                   terms of its block (csrc/wgrad.hip, tests/test_gpu_wgrad.py).
+ * spf_rhead_* does not take it (SPF_EINVAL); the narrow (C <= 32) weight-gradient kernel is fp32 MFMA whatever `arith` says.  A value outside fp16's
+ * range becomes inf / NaN — loudly:
+ * the optimiser step's finite check (spf_adam_step) then skips and counts the update. */
 #define SPF_ARITH_H2 3
 /* spf_geo_forward only, OR-ed into arith: the bf16-piece kernels of THIS launch stamp the held-clock counters (spf_geo_clock_read).  Without
  * the bit a launch touches no state outside its arguments. */

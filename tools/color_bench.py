@@ -64,7 +64,7 @@ def bwd_only():
     _lib.check(_lib.lib().spf_color_backward(_lib.ptr(g), _lib.ptr(pl.nbr), _lib.ptr(wn), _lib.ptr(pl.point_slot), _lib.ptr(pl.pair_off),
                                              _lib.ptr(pl.pair_point), _lib.ptr(pl.n_pairs), NP, pl.k, _lib.ptr(pk), _lib.ptr(masks), _lib.ptr(G[0]),
                                              _lib.ptr(G[1]), _lib.ptr(G[2]), _lib.ptr(gb[0]), _lib.ptr(gb[1]), _lib.ptr(gb[2]), _lib.ptr(gf), None,
-                                             ops._ARITH["color"], _lib.stream_ptr()), "bwd")
+                                             ops._arith_of(ops._ARITH["color"], "color_bwd"), _lib.stream_ptr()), "bwd")
 
 
 t_b = timeit(bwd_only)
