@@ -572,6 +572,12 @@ class VolOpt:
         self.last_losses = None
         self.last_psnr = None
         self.psnr_every = int(kwargs.get("psnr_every", 50))
+        # H2 arithmetic (the default of the large kernels) has fp16's exponent range where the reference's fp32 has 2^127: a value beyond it turns the
+        # step's gradient non-finite, and the device-side guard (train.py:548-564's, on the device) skips the update — silently, unless somebody reads
+        # the counter.  Every `arith_guard` steps this trainer does (one 16-byte read), and when updates were skipped since the last look it moves the
+        # process to the bf16 x 3 kernels (fp32's range, same results to fp32 accuracy, ~1.3x the step time) — once, with a warning.  0 = never look.
+        self.arith_guard = int(kwargs.get("arith_guard", 500))
+        self._skipped_guard, self._arith_fallback = 0, False
         self._local_cache = {}
 
     # ---- data -----------------------------------------------------------------------------------------------
@@ -633,7 +639,30 @@ class VolOpt:
         self.train_dataset.change_sampling_idx(self.num_pixels)
         self.iter_step += 1
         self.total_step += 1
+        if self.arith_guard > 0 and self.total_step % self.arith_guard == 0:
+            self._guard_arithmetic()
         return losses
+
+    def _guard_arithmetic(self):
+        """See `arith_guard` in __init__.  -> True when this call switched the arithmetic."""
+        skipped = self.step.skipped_updates()
+        grew, self._skipped_guard = skipped > self._skipped_guard, skipped
+        if not grew or self._arith_fallback:
+            return False
+        from . import ops
+
+        if ops.geo_mode() != "h2" and not any(ops._H2.values()):
+            return False                                  # already on fp32-range arithmetic: the non-finite gradients are the run's own
+        import warnings
+
+        warnings.warn(f"{skipped} optimisation steps of {self.total_step} had a non-finite gradient and were skipped; switching the geometry / colour / "
+                      "weight-gradient kernels of this process from H2 (fp16 pieces: |value| < 65504) to bf16 x 3 (fp32's range) — "
+                      "ops.set_geo_mode('split_w'), ops.set_h2(color_fwd=False, color_bwd=False, wgrad=False)", RuntimeWarning)
+        ops.set_geo_mode("split_w")
+        ops.set_h2(color_fwd=False, color_bwd=False, wgrad=False, rhead_fwd=False, rhead_bwd=False)
+        self.step._graph = None                           # a captured step holds the old kernels: re-captured by the next call
+        self._arith_fallback = True
+        return True
 
     def _local_to_device(self, local, indices, dev):
         """Device copy of a view's `local_data`, cached per VIEW INDEX (the reference's DTUDataset builds a fresh dict and freshly indexed

@@ -371,3 +371,35 @@ def test_color_backward_rows_of_any_magnitude_stay_finite():
         assert bool(torch.isfinite(v).all()), k
         ref = got["bf16x3"][k]
         assert float((v - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), k      # (LeakyReLU kink rows move whole latent rows: the oracle test's allowance)
+
+
+def test_h2_values_beyond_fp16_range_are_loud_and_the_bf16_engine_carries_them():
+    """H2 holds activations as fp16 pairs: |value| < 65504 (include/spurfies_hip.h).  Latents scaled far beyond that are a different network, but the
+    contract is about HOW the limit shows: never a finite wrong number — the H2 engine returns non-finite SDFs for the affected points (the optimiser
+    step's finite check then skips and counts the update; VolOpt's arith_guard moves the run to bf16 x 3), and the bf16 x 3 engine, which has fp32's
+    range, evaluates the same inputs to the fp32-MFMA twin's values."""
+    from spurfies_amd import ops
+
+    scene, st, cfg, x, dev, grid, packed = _setup(n_points=2000, n_query=600, seed=4)
+    xt = torch.from_numpy(x).cuda()
+    q = grid.query_dense(xt.unsqueeze(1), cfg.k, cfg.r, 1)
+    ps, _, n = ops.compact_points(q["slot_valid"])
+    pl = ops.PairList(q["pidx"].reshape(-1, cfg.k), ps, n)
+    n_p, _ = pl.host_counts()
+    big = dev["neural_feats_geometry"] * 3.0e5
+    valid = ps[:n_p].long()
+    out = {}
+    prev = ops.geo_mode()
+    try:
+        for mode in ("h2", "split_w", "f32"):
+            ops.set_geo_mode(mode)
+            out[mode] = ops.geo_forward(xt, pl, dev["neural_pts"], big, packed, cfg.rbf, with_grad=False)["sdf"][valid]
+    finally:
+        ops.set_geo_mode(prev)
+    assert bool(torch.isfinite(out["f32"]).all()) and bool(torch.isfinite(out["split_w"]).all())
+    np.testing.assert_allclose(out["split_w"].cpu().numpy(), out["f32"].cpu().numpy(), rtol=1e-4, atol=1e-4 * float(out["f32"].abs().max()))
+    bad = ~torch.isfinite(out["h2"])
+    assert int(bad.sum()) > n_p // 2                                            # loud ...
+    ok = ~bad                                                                    # ... and where a point's values stayed in range, right
+    if int(ok.sum()):
+        np.testing.assert_allclose(out["h2"][ok].cpu().numpy(), out["f32"][ok].cpu().numpy(), rtol=1e-3, atol=1e-3 * float(out["f32"].abs().max()))

@@ -213,3 +213,29 @@ def test_trainer_with_local_data_optimises_the_feature_consistency_term(tmp_path
     pytest.local_loss_seen[sync_free] = local
     if len(pytest.local_loss_seen) == 2:
         np.testing.assert_allclose(pytest.local_loss_seen[True], pytest.local_loss_seen[False], rtol=1e-4)
+
+
+def test_trainer_leaves_h2_when_updates_were_skipped_as_non_finite(tmp_path):
+    """VolOpt(arith_guard=N): every N steps the trainer reads the device-side count of skipped (non-finite) updates; when it grew, the process moves
+    from H2 (fp16's exponent range) to the bf16 x 3 kernels (fp32's), once, with a warning, and a captured step is dropped for re-capture."""
+    import warnings
+
+    from spurfies_amd import ops
+
+    t, _ = _volopt(tmp_path, "cpu")
+    assert t.arith_guard == 500 and ops.geo_mode() == "h2" and ops._H2["color_bwd"] and ops._H2["wgrad"]
+    prev_h2, prev_geo = dict(ops._H2), ops.geo_mode()
+    try:
+        counts = iter([0, 3, 9])
+        t.step.skipped_updates = lambda: next(counts)
+        t.step._graph = object()
+        assert t._guard_arithmetic() is False and ops.geo_mode() == "h2" and t.step._graph is not None          # nothing skipped: nothing changes
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert t._guard_arithmetic() is True
+        assert len(w) == 1 and "non-finite" in str(w[0].message) and "3 optimisation steps" in str(w[0].message)
+        assert ops.geo_mode() == "split_w" and not any(ops._H2.values()) and t.step._graph is None
+        assert t._guard_arithmetic() is False                                                                       # once
+    finally:
+        ops.set_geo_mode(prev_geo)
+        ops.set_h2(**prev_h2)
