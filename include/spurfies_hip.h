@@ -199,8 +199,9 @@ int spf_compact_pairs_filter(const uint8_t* slot_valid, const int32_t* nbr, int3
  *   spf_wgrad / spf_wgrad_batched   (C > 32) pieces h1 = fp16(s x), h2 = fp16(s x - h1) into ONE accumulator; A scaled by 4 (|A| < 16376), G per
  *                                   wave and 32-column block by a power of two chosen on the fly: a term is exact relative to the LARGEST
  *                                   terms of its block (csrc/wgrad.hip, tests/test_gpu_wgrad.py).
- * spf_rhead_* does not take it (SPF_EINVAL); the narrow (C <= 32) weight-gradient kernel is fp32 MFMA whatever `arith` says.  A value outside fp16's
- * range becomes inf / NaN — loudly:
+ *   spf_rhead_forward / _backward   as the colour pair: a member of the SPF_ARITH_SPLIT family, forward and backward independently; the backward carries
+ *                                   every gradient row (= point) with its own power of two.
+ * The narrow (C <= 32) weight-gradient kernel is fp32 MFMA whatever `arith` says.  A value outside fp16's range becomes inf / NaN — loudly:
  * the optimiser step's finite check (spf_adam_step) then skips and counts the update. */
 #define SPF_ARITH_H2 3
 /* spf_geo_forward only, OR-ed into arith: the bf16-piece kernels of THIS launch stamp the held-clock counters (spf_geo_clock_read).  Without

@@ -477,6 +477,31 @@ __device__ __forceinline__ void store_tile_from_planes(const __bf16* X, float* _
     }
 }
 
+// the same for either piece form; H2: h1 + 2^-11 h2 per element (the 22-bit value the next GEMM consumed), optionally times a per-row factor
+// (block-scaled gradient rows: rinv[row] undoes the row's power of two, exactly)
+template <bool H2, int NG, int LDP = X3_LDP, int ROWS = 64>
+__device__ __forceinline__ void store_tile_from_planes_xh(const __bf16* X, float* __restrict__ dst, int ld_dst, int tid, const float* rinv = nullptr) {
+    if constexpr (!H2) {
+        store_tile_from_planes<NG, LDP, ROWS>(X, dst, ld_dst, tid);
+    } else {
+        for (int idx = tid; idx < ROWS * NG; idx += 256) {
+            const int row = idx / NG, gc = idx % NG;
+            const f16x8 a = *reinterpret_cast<const f16x8*>(X + row * LDP + 8 * gc);
+            const f16x8 b = *reinterpret_cast<const f16x8*>(X + (64 * LDP) + row * LDP + 8 * gc);
+            const float r = rinv ? rinv[row] : 1.0f;
+            f32x4 lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = __builtin_fmaf((float)b[e], H2_EPS, (float)a[e]) * r;
+                hi[e] = __builtin_fmaf((float)b[e + 4], H2_EPS, (float)a[e + 4]) * r;
+            }
+            float* d = dst + (size_t)row * ld_dst + 8 * gc;
+            *reinterpret_cast<f32x4*>(d) = lo;
+            *reinterpret_cast<f32x4*>(d + 4) = hi;
+        }
+    }
+}
+
 // one element (row, col) of the planes
 template <bool H2, int LDP = X3_LDP>
 __device__ __forceinline__ void store_one_xh(__bf16* X, int row, int col, float v);

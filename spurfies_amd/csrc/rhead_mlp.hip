@@ -350,7 +350,20 @@ __device__ __forceinline__ RxBias rx_load_bias(gfp bias, int wave, int lane) {
 
 // transposed epilogues (lane = row j of half n, 4 consecutive features per quad): linear (acc + b), LeakyReLU forward (sign words
 // pushed in the order (m, g, e), stored lane-major) and LeakyReLU backward (popped in the same order)
-template <int NT>
+// a layer's GEMM on the head kernels' engine: bf16 x 3 (one accumulator) or H2 (main + cross accumulators, combined here)
+template <int T, int NT, bool H2, int NC>
+__device__ __forceinline__ WFrag3 rx_gemm(const __bf16* X, gx3 wp, int lane, f32x16 (&acc)[2][NT], const WFrag3& first, gx3 next_wp, f32x16 (&accc)[2][NC]) {
+    if constexpr (H2) {
+        static_assert(NC == NT, "H2: one cross accumulator per main accumulator");
+        const WFrag3 nf = gemm_x3<T, false, RX_LDP, NT, 2, true>(X, wp, lane, acc, first, next_wp, accc);
+        h2_combine<NT>(acc, accc);
+        return nf;
+    } else {
+        return gemm_x3<T, false, RX_LDP, NT>(X, wp, lane, acc, first, next_wp);
+    }
+}
+
+template <int NT, bool H2 = false>
 __device__ __forceinline__ void rx_linear_epilogue(__bf16* X, const f32x16 (&acc)[2][NT], const RxBias* bias, int wave, int lane) {
     const int j = lane & 31, kg = lane >> 5;
 #pragma unroll
@@ -362,11 +375,11 @@ __device__ __forceinline__ void rx_linear_epilogue(__bf16* X, const f32x16 (&acc
             for (int n = 0; n < NT; ++n) {
                 f32x4 h = f32x4{acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
                 if (bias) h += bias->b[m][g];
-                store_quad_x3<RX_LDP>(X, 32 * n + j, f0, h);
+                store_quad_xh<H2, RX_LDP>(X, 32 * n + j, f0, h);
             }
         }
 }
-template <bool STORE, int NT>
+template <bool STORE, int NT, bool H2 = false>
 __device__ __forceinline__ void rx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2][NT], const RxBias& bias, int wave, int lane, uint32_t* masks_l) {
     const int j = lane & 31, kg = lane >> 5;
     uint32_t bits[NT];
@@ -383,7 +396,7 @@ __device__ __forceinline__ void rx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2
                 bias_scale4(acc[m][n], g, bias.b[m][g], h, hs);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[e] = lrelu_push(h[e], hs[e], bits[n]);
-                store_quad_x3<RX_LDP>(X, 32 * n + j, f0, out);
+                store_quad_xh<H2, RX_LDP>(X, 32 * n + j, f0, out);
             }
         }
     if (STORE) {
@@ -391,7 +404,7 @@ __device__ __forceinline__ void rx_fwd_epilogue(__bf16* X, const f32x16 (&acc)[2
         for (int n = 0; n < NT; ++n) masks_l[(NT * wave + n) * 64 + lane] = bits[n];
     }
 }
-template <int NT>
+template <int NT, bool H2 = false>
 __device__ __forceinline__ void rx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2][NT], int wave, int lane, const uint32_t (&mw)[NT]) {
     const int j = lane & 31, kg = lane >> 5;
     uint32_t bits[NT];
@@ -408,7 +421,7 @@ __device__ __forceinline__ void rx_bwd_epilogue(__bf16* X, const f32x16 (&acc)[2
                 scale4(acc[m][n], g, v, vs);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[e] = lrelu_pop(v[e], vs[e], bits[n]);
-                store_quad_x3<RX_LDP>(X, 32 * n + j, f0, out);
+                store_quad_xh<H2, RX_LDP>(X, 32 * n + j, f0, out);
             }
         }
 }
@@ -420,7 +433,7 @@ __device__ __forceinline__ int rx_full_rounds_points(int P, int G) { return (P /
 // One workgroup's tiles.  NT = 2: tiles of 64 points (rounds 1 - 4); NT = 1 (round 5): HALF-HEIGHT tiles of 32 points — twice the tiles at ~55 % of a
 // tile's time each, taken when the launch has at most 32 points per workgroup (the 128-rays-per-GPU step: 6.5 k points were 102 tiles on 102 of 256
 // CUs, one ~45 us tile pass each).  Forward and backward make the same choice (same point count, same grid): the sign words' layout depends on it.
-template <bool STORE, int NT>
+template <bool STORE, int NT, bool H2 = false>
 __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int* s_row, const float* __restrict__ agg3, const float* __restrict__ ray_dirs,
                                                       const int32_t* __restrict__ point_slot, const int p0, const int P, int SR, const float* packed,
                                                       float* __restrict__ colors, float* __restrict__ agg, float* __restrict__ direnc,
@@ -461,7 +474,7 @@ __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gfp pf = launder(packed0);
-        gx3 frag = reinterpret_cast<gx3>(pf + R_PACKED);
+        gx3 frag = reinterpret_cast<gx3>(pf + (H2 ? RH_OFF : R_PACKED));
         gx3 w_fw6 = frag + RX_FW6 + wave * (RX_TH * 2 * 3 * 64) + lane;
         gx3 w_fw1 = frag + RX_FW1 + wave * (RX_T1 * 2 * 3 * 64) + lane;
         gx3 w_fw2 = frag + RX_FW2 + wave * (RX_TH * 2 * 3 * 64) + lane;
@@ -470,7 +483,7 @@ __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int
         {   // gather: thread = (row, part): PW agg3 floats each; part 0 also encodes the view direction (columns 256..287)
             const int row = tid / PARTS, q = tid % PARTS;
 #pragma unroll
-            for (int u = 0; u < NV; ++u) store_quad_x3<RX_LDP>(X, row, q * PW + 4 * u, v[u]);
+            for (int u = 0; u < NV; ++u) store_quad_xh<H2, RX_LDP>(X, row, q * PW + 4 * u, v[u]);
             if (q == 0) {
                 float e[32];
 #pragma unroll
@@ -492,7 +505,7 @@ __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int
                     }
                 }
 #pragma unroll
-                for (int c4 = 0; c4 < 8; ++c4) store_quad_x3<RX_LDP>(X, row, 256 + 4 * c4, f32x4{e[4 * c4], e[4 * c4 + 1], e[4 * c4 + 2], e[4 * c4 + 3]});
+                for (int c4 = 0; c4 < 8; ++c4) store_quad_xh<H2, RX_LDP>(X, row, 256 + 4 * c4, f32x4{e[4 * c4], e[4 * c4 + 1], e[4 * c4 + 2], e[4 * c4 + 3]});
                 if (STORE) {
 #pragma unroll
                     for (int c4 = 0; c4 < 6; ++c4)
@@ -507,33 +520,34 @@ __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int
         const size_t tb = (size_t)(p0 + tile * ROWS) * 256;
         uint32_t* mk = STORE ? masks + (size_t)(p0 + tile * ROWS) * 16 : nullptr;         // 16 words per point: [layer 2][wave 4][row half NT][lane 64] per tile
         f32x16 acc[2][NT];
+        f32x16 accc[2][H2 ? NT : 1];      // H2: the cross terms' accumulators
         RxBias bias = rx_load_bias(pf + RO_B6, wave, lane);
-        WFrag3 nf = gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_fw6, lane, acc, fr6, w_fw1);          // F_color.6 on the weighted mean
+        WFrag3 nf = rx_gemm<RX_TH, NT, H2>(X, w_fw6, lane, acc, fr6, w_fw1, accc);          // F_color.6 on the weighted mean
         T_MARK(3)
         lds_barrier();
         T_MARK(2)
-        rx_linear_epilogue<NT>(X, acc, &bias, wave, lane);       // agg -> columns 0..255 (the dir-enc columns stay)
+        rx_linear_epilogue<NT, H2>(X, acc, &bias, wave, lane);       // agg -> columns 0..255 (the dir-enc columns stay)
         T_MARK(4)
         lds_barrier();
         T_MARK(2)
-        if (STORE) store_tile_from_planes<32, RX_LDP, ROWS>(X, agg + tb, 256, tid);              // kept for R.0's weight gradient
+        if (STORE) store_tile_from_planes_xh<H2, 32, RX_LDP, ROWS>(X, agg + tb, 256, tid);              // kept for R.0's weight gradient
         T_MARK(5)
         bias = rx_load_bias(pf + RO_B1, wave, lane);
         fetch_slot(tile + (int)gridDim.x);
-        nf = gemm_x3<RX_T1, false, RX_LDP, NT>(X, w_fw1, lane, acc, nf, w_fw2);
+        nf = rx_gemm<RX_T1, NT, H2>(X, w_fw1, lane, acc, nf, w_fw2, accc);
         T_MARK(3)
         lds_barrier();
         T_MARK(2)
-        rx_fwd_epilogue<STORE, NT>(X, acc, bias, wave, lane, mk);
+        rx_fwd_epilogue<STORE, NT, H2>(X, acc, bias, wave, lane, mk);
         T_MARK(4)
         lds_barrier();
         T_MARK(2)
-        if (STORE) store_tile_from_planes<32, RX_LDP, ROWS>(X, act1 + tb, 256, tid);
+        if (STORE) store_tile_from_planes_xh<H2, 32, RX_LDP, ROWS>(X, act1 + tb, 256, tid);
         T_MARK(5)
         bias = rx_load_bias(pf + RO_B2, wave, lane);
         const RxBias w3q0 = rx_load_bias(pf + RO_W3, wave, lane), w3q1 = rx_load_bias(pf + RO_W3 + 256, wave, lane),
                      w3q2 = rx_load_bias(pf + RO_W3 + 512, wave, lane);      // the 3 x 256 last layer, this lane's quads: ahead of the GEMM
-        gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_fw2, lane, acc, nf, nullptr);
+        rx_gemm<RX_TH, NT, H2>(X, w_fw2, lane, acc, nf, nullptr, accc);
         fetch_rows(tile + (int)gridDim.x);
         T_MARK(3)
         lds_barrier();
@@ -562,7 +576,7 @@ __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int
 #pragma unroll
                             for (int c = 0; c < 3; ++c) s3[n][c] += w3[c][e] * out[e];
                         }
-                        if (STORE) store_quad_x3<RX_LDP>(X, 32 * n + j, f0, out);
+                        if (STORE) store_quad_xh<H2, RX_LDP>(X, 32 * n + j, f0, out);
                     }
                 }
             if (STORE) {
@@ -580,7 +594,7 @@ __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int
         T_MARK(4)
         lds_barrier();
         T_MARK(2)
-        if (STORE) store_tile_from_planes<32, RX_LDP, ROWS>(X, act2 + tb, 256, tid);
+        if (STORE) store_tile_from_planes_xh<H2, 32, RX_LDP, ROWS>(X, act2 + tb, 256, tid);
         T_MARK(5)
         if (tid < ROWS) {
             const int srow = s_row[tid];
@@ -599,7 +613,7 @@ __device__ __forceinline__ void rhead_forward_x3_body(__bf16* X, float* red, int
     T_FLUSH
 }
 
-template <bool STORE>
+template <bool STORE, bool H2 = false>
 __global__ void __launch_bounds__(256, 1)
 rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict__ ray_dirs, const int32_t* __restrict__ point_slot,
                         const int32_t* __restrict__ n_points_dev, int max_points, int SR, const float* packed, float* __restrict__ colors,
@@ -613,15 +627,20 @@ rhead_forward_x3_kernel(const float* __restrict__ agg3, const float* __restrict_
     // that puts it on twice the workgroups (55 k points on 256 workgroups: 3 rounds + 186 half tiles instead of a fourth round at 36 % occupancy)
     const int p_full = rx_full_rounds_points(P, (int)gridDim.x);
     if (p_full > 0)
-        rhead_forward_x3_body<STORE, 2>(X, red, s_row, agg3, ray_dirs, point_slot, 0, p_full, SR, packed, colors, agg, direnc, act1, act2, masks);
+        rhead_forward_x3_body<STORE, 2, H2>(X, red, s_row, agg3, ray_dirs, point_slot, 0, p_full, SR, packed, colors, agg, direnc, act1, act2, masks);
     if (P - p_full > 32 * (int)gridDim.x)
-        rhead_forward_x3_body<STORE, 2>(X, red, s_row, agg3, ray_dirs, point_slot, p_full, P, SR, packed, colors, agg, direnc, act1, act2, masks);
+        rhead_forward_x3_body<STORE, 2, H2>(X, red, s_row, agg3, ray_dirs, point_slot, p_full, P, SR, packed, colors, agg, direnc, act1, act2, masks);
     else if (P > p_full)
-        rhead_forward_x3_body<STORE, 1>(X, red, s_row, agg3, ray_dirs, point_slot, p_full, P, SR, packed, colors, agg, direnc, act1, act2, masks);
+        rhead_forward_x3_body<STORE, 1, H2>(X, red, s_row, agg3, ray_dirs, point_slot, p_full, P, SR, packed, colors, agg, direnc, act1, act2, masks);
 }
 
-template <int NT>
-__device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, const float* __restrict__ g_colors, const float* __restrict__ colors,
+// H2: as in the colour trunk's backward, every gradient ROW (= point) travels through the planes and the accumulators multiplied by its own power of two
+// — a point's upstream gradient carries its compositing weight, 1 .. 1e-30 — chosen so that the row's largest |dL/d(pre-sigmoid)| lies in [1, 2): G2 =
+// g3 W3 then stays within a few units and three more weight matrices have 2^14 of headroom below fp16's 65504 (the last product leaves from the fp32
+// accumulators); every value that leaves the kernel is multiplied by the row's inverse factor (s_rinv).  The 3 x 256 layer's weight / bias gradient is
+// formed from the UNSCALED g3.
+template <int NT, bool H2 = false>
+__device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, float* s_rinv, const float* __restrict__ g_colors, const float* __restrict__ colors,
                                                        const int32_t* __restrict__ point_slot, const int p0, const int P, const float* packed,
                                                        const float* __restrict__ act2, const uint32_t* __restrict__ masks, float* __restrict__ G1,
                                                        float* __restrict__ G2, float* __restrict__ g_agg, float* __restrict__ g_agg3,
@@ -635,7 +654,7 @@ __device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, c
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gfp pf = launder(packed0);
-        gx3 frag = reinterpret_cast<gx3>(pf + R_PACKED);
+        gx3 frag = reinterpret_cast<gx3>(pf + (H2 ? RH_OFF : R_PACKED));
         gx3 w_bw2 = frag + RX_BW2 + wave * (RX_TH * 2 * 3 * 64) + lane;
         gx3 w_bwa = frag + RX_BWA + wave * (RX_TH * 2 * 3 * 64) + lane;
         gx3 w_bw6 = frag + RX_BW6 + wave * (RX_TH * 2 * 3 * 64) + lane;
@@ -652,7 +671,16 @@ __device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, c
                     g[c] = g_colors[(size_t)srow * 3 + c] * cc * (1.f - cc);
                 }
             }
-            *reinterpret_cast<f32x4*>(s_g3 + tid * 4) = f32x4{g[0], g[1], g[2], 0.f};
+            float sc = 1.0f;
+            if constexpr (H2) {
+                const float rmax = fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fabsf(g[2]));
+                int ex = 0;
+                if (rmax > 0.f && rmax < 3.0e38f) (void)frexpf(rmax, &ex);          // rmax = m 2^ex, m in [0.5, 1)
+                ex = max(ex, -100);                                                  // (the factor must stay finite: rows below 2^-100 keep 2^101)
+                sc = ldexpf(1.0f, 1 - ex);                                           // row max -> [1, 2)
+                s_rinv[tid] = ldexpf(1.0f, ex - 1);
+            }
+            *reinterpret_cast<f32x4*>(s_g3 + tid * 4) = f32x4{g[0], g[1], g[2], sc};   // [3] = the row's factor (H2), read by the G2 stage only
         }
         lds_barrier();
         const uint32_t* mk = masks + (size_t)(p0 + tile * ROWS) * 16;       // the forward's layout: 16 words per point, [layer 2][wave 4][row half NT][lane 64] per tile
@@ -701,30 +729,32 @@ __device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, c
                         f32x4 out;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = g3[n][0] * w3[0][e] + g3[n][1] * w3[1][e] + g3[n][2] * w3[2][e];
+                            float v = g3[n][0] * w3[0][e] + g3[n][1] * w3[1][e] + g3[n][2] * w3[2][e];
+                            if (H2) v *= g3[n][3];                               // the row's power of two (exact)
                             out[e] = lrelu_pop(v, v * 0.01f, bits[n]);
                         }
-                        store_quad_x3<RX_LDP>(X, 32 * n + j, f0, out);
+                        store_quad_xh<H2, RX_LDP>(X, 32 * n + j, f0, out);
                     }
                 }
         }
         lds_barrier();
-        store_tile_from_planes<32, RX_LDP, ROWS>(X, G2 + tb, 256, tid);
+        store_tile_from_planes_xh<H2, 32, RX_LDP, ROWS>(X, G2 + tb, 256, tid, s_rinv);
         f32x16 acc[2][NT];
+        f32x16 accc[2][H2 ? NT : 1];
         uint32_t mw1[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) mw1[n] = mk[(NT * wave + n) * 64 + lane];
-        WFrag3 nf = gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_bw2, lane, acc, fr2, w_bwa);
+        WFrag3 nf = rx_gemm<RX_TH, NT, H2>(X, w_bw2, lane, acc, fr2, w_bwa, accc);
         lds_barrier();
-        rx_bwd_epilogue<NT>(X, acc, wave, lane, mw1);
+        rx_bwd_epilogue<NT, H2>(X, acc, wave, lane, mw1);
         lds_barrier();
-        store_tile_from_planes<32, RX_LDP, ROWS>(X, G1 + tb, 256, tid);
-        nf = gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_bwa, lane, acc, nf, w_bw6);
+        store_tile_from_planes_xh<H2, 32, RX_LDP, ROWS>(X, G1 + tb, 256, tid, s_rinv);
+        nf = rx_gemm<RX_TH, NT, H2>(X, w_bwa, lane, acc, nf, w_bw6, accc);
         lds_barrier();
-        rx_linear_epilogue<NT>(X, acc, nullptr, wave, lane);     // g_agg: operand of F_color.6's weight gradient and of the last product
+        rx_linear_epilogue<NT, H2>(X, acc, nullptr, wave, lane);     // g_agg: operand of F_color.6's weight gradient and of the last product
         lds_barrier();
-        store_tile_from_planes<32, RX_LDP, ROWS>(X, g_agg + tb, 256, tid);
-        gemm_x3<RX_TH, false, RX_LDP, NT>(X, w_bw6, lane, acc, nf, nullptr);                 // g_agg3 = g_agg W6
+        store_tile_from_planes_xh<H2, 32, RX_LDP, ROWS>(X, g_agg + tb, 256, tid, s_rinv);
+        rx_gemm<RX_TH, NT, H2>(X, w_bw6, lane, acc, nf, nullptr, accc);                 // g_agg3 = g_agg W6
         lds_barrier();
         {   // -> fp32 tile in the (now dead) plane memory -> coalesced rows in HBM
             float* XF = reinterpret_cast<float*>(X);
@@ -740,13 +770,16 @@ __device__ __forceinline__ void rhead_backward_x3_body(__bf16* X, float* s_g3, c
 #pragma unroll 4
             for (int u = 0; u < ROWS / 4; ++u) {           // ROWS rows of 256 floats, 16 bytes per thread
                 const int e4 = tid + 256 * u, row = e4 >> 6, c4 = e4 & 63;
-                *reinterpret_cast<f32x4*>(g_agg3 + tb + row * 256 + 4 * c4) = *reinterpret_cast<const f32x4*>(XF + row * LDA + 4 * c4);
+                f32x4 o = *reinterpret_cast<const f32x4*>(XF + row * LDA + 4 * c4);
+                if (H2) o = o * s_rinv[row];
+                *reinterpret_cast<f32x4*>(g_agg3 + tb + row * 256 + 4 * c4) = o;
             }
         }
         lds_barrier();
     }
 }
 
+template <bool H2 = false>
 __global__ void __launch_bounds__(256, 1)
 rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __restrict__ colors, const int32_t* __restrict__ point_slot,
                          const int32_t* __restrict__ n_points_dev, int max_points, const float* packed, const float* __restrict__ act2,
@@ -755,15 +788,16 @@ rhead_backward_x3_kernel(const float* __restrict__ g_colors, const float* __rest
                          long long* __restrict__ g_w4_fixed, long long* __restrict__ g_b4_fixed) {
     __shared__ __attribute__((aligned(16))) __bf16 X[3 * 64 * RX_LDP];
     __shared__ __attribute__((aligned(16))) float s_g3[64 * 4];
+    __shared__ float s_rinv[64];               // H2: the rows' inverse factors
     const int P = n_points_dev ? min(*n_points_dev, max_points) : max_points;
     // the forward's split (same P, same grid): whole rounds of 64-point tiles, the rest as half-height tiles if that is at most one per workgroup
     const int p_full = rx_full_rounds_points(P, (int)gridDim.x);
     if (p_full > 0)
-        rhead_backward_x3_body<2>(X, s_g3, g_colors, colors, point_slot, 0, p_full, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
+        rhead_backward_x3_body<2, H2>(X, s_g3, s_rinv, g_colors, colors, point_slot, 0, p_full, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
     if (P - p_full > 32 * (int)gridDim.x)
-        rhead_backward_x3_body<2>(X, s_g3, g_colors, colors, point_slot, p_full, P, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
+        rhead_backward_x3_body<2, H2>(X, s_g3, s_rinv, g_colors, colors, point_slot, p_full, P, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
     else if (P > p_full)
-        rhead_backward_x3_body<1>(X, s_g3, g_colors, colors, point_slot, p_full, P, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
+        rhead_backward_x3_body<1, H2>(X, s_g3, s_rinv, g_colors, colors, point_slot, p_full, P, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4, g_b4, g_w4_fixed, g_b4_fixed);
 }
 
 
@@ -794,7 +828,9 @@ int spf_rhead_pack(const float* w6, const float* b6, const float* w0, const floa
 int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* point_slot, const int32_t* n_points, int32_t max_points,
                       int32_t SR, const float* packed, float* colors, float* agg, float* direnc, float* act1, float* act2, uint32_t* masks,
                       int32_t arith, void* stream) {
-    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_rhead_forward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
+    const bool h2 = arith == SPF_ARITH_H2;        // the 'split' family with three fp16 piece products (layouts, sign words, outputs unchanged)
+    if (h2) arith = SPF_ARITH_SPLIT;
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_rhead_forward: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_H2 (3), got %d", arith);
     if (max_points < 0 || SR < 1) return spf::fail(SPF_EINVAL, "spf_rhead_forward: bad sizes");
     if (max_points == 0) return SPF_OK;
     if (!agg3 || !ray_dirs || !packed || !colors) return spf::fail(SPF_EINVAL, "spf_rhead_forward: null pointer");
@@ -805,12 +841,12 @@ int spf_rhead_forward(const float* agg3, const float* ray_dirs, const int32_t* p
     if (arith == SPF_ARITH_SPLIT) {
         const int t32 = spf::div_up(max_points, 32);
         const int b1 = t32 < 256 ? t32 : 256;           // one workgroup per CU; <= 32 points per workgroup: half-height tiles (chosen on the device)
-        if (store)
-            rhead_forward_x3_kernel<true><<<b1, 256, 0, (hipStream_t)stream>>>(agg3, ray_dirs, point_slot, n_points, max_points, SR, packed, colors, agg,
-                                                                               direnc, act1, act2, masks);
-        else
-            rhead_forward_x3_kernel<false><<<b1, 256, 0, (hipStream_t)stream>>>(agg3, ray_dirs, point_slot, n_points, max_points, SR, packed, colors,
-                                                                                nullptr, nullptr, nullptr, nullptr, nullptr);
+        auto go = [&](auto kern) {
+            kern<<<b1, 256, 0, (hipStream_t)stream>>>(agg3, ray_dirs, point_slot, n_points, max_points, SR, packed, colors, store ? agg : nullptr,
+                                                     store ? direnc : nullptr, store ? act1 : nullptr, store ? act2 : nullptr, store ? masks : nullptr);
+        };
+        if (store) { if (h2) go(rhead_forward_x3_kernel<true, true>); else go(rhead_forward_x3_kernel<true, false>); }
+        else { if (h2) go(rhead_forward_x3_kernel<false, true>); else go(rhead_forward_x3_kernel<false, false>); }
         SPF_LAUNCH_CHECK("rhead_forward_x3_kernel");
         return SPF_OK;
     }
@@ -828,7 +864,9 @@ int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t
                        const float* packed, const float* act2, const uint32_t* masks, float* G1, float* G2, float* g_agg, float* g_agg3,
                        float* g_b6, float* g_b0, float* g_b2, float* g_w4, float* g_b4, int64_t* g_w4_fixed, int64_t* g_b4_fixed, int32_t arith,
                        void* stream) {
-    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_rhead_backward: arith must be SPF_ARITH_SPLIT (0) or SPF_ARITH_F32 (1), got %d", arith);
+    const bool h2 = arith == SPF_ARITH_H2;
+    if (h2) arith = SPF_ARITH_SPLIT;
+    if (arith != SPF_ARITH_SPLIT && arith != SPF_ARITH_F32) return spf::fail(SPF_EINVAL, "spf_rhead_backward: arith must be SPF_ARITH_SPLIT (0), SPF_ARITH_F32 (1) or SPF_ARITH_H2 (3), got %d", arith);
     if (max_points < 0) return spf::fail(SPF_EINVAL, "spf_rhead_backward: bad sizes");
     if ((g_w4_fixed || g_b4_fixed) && (arith != SPF_ARITH_SPLIT || !g_w4_fixed || !g_b4_fixed))
         return spf::fail(SPF_EINVAL, "spf_rhead_backward: the fixed-point accumulators come as a pair and need SPF_ARITH_SPLIT");
@@ -840,9 +878,11 @@ int spf_rhead_backward(const float* g_colors, const float* colors, const int32_t
     if (arith == SPF_ARITH_SPLIT) {    // g_b6 / g_b0 / g_b2 are not touched in this mode: spf_wgrad's dbias output provides them
         const int t32 = spf::div_up(max_points, 32);
         const int b1 = t32 < 256 ? t32 : 256;           // the forward's grid: both kernels then choose the same tile height
-        rhead_backward_x3_kernel<<<b1, 256, 0, (hipStream_t)stream>>>(g_colors, colors, point_slot, n_points, max_points, packed, act2, masks, G1, G2,
-                                                                      g_agg, g_agg3, g_w4, g_b4, reinterpret_cast<long long*>(g_w4_fixed),
-                                                                      reinterpret_cast<long long*>(g_b4_fixed));
+        auto go = [&](auto kern) {
+            kern<<<b1, 256, 0, (hipStream_t)stream>>>(g_colors, colors, point_slot, n_points, max_points, packed, act2, masks, G1, G2, g_agg, g_agg3, g_w4,
+                                                     g_b4, reinterpret_cast<long long*>(g_w4_fixed), reinterpret_cast<long long*>(g_b4_fixed));
+        };
+        if (h2) go(rhead_backward_x3_kernel<true>); else go(rhead_backward_x3_kernel<false>);
         SPF_LAUNCH_CHECK("rhead_backward_x3_kernel");
         return SPF_OK;
     }

@@ -83,7 +83,8 @@ constexpr int RX_BW2 = RX_FW2 + RX_SZH;
 constexpr int RX_BWA = RX_BW2 + RX_SZH;
 constexpr int RX_BW6 = RX_BWA + RX_SZH;
 constexpr int RX_FRAGS = RX_BW6 + RX_SZH;
-constexpr int R_PACKED_TOTAL = R_PACKED + 4 * RX_FRAGS;
+constexpr int RH_OFF = R_PACKED + 4 * RX_FRAGS;   // (floats) the H2 image: the same fragment order with fp16 pieces in the slots of pieces 0 and 1 (slot 2 unused)
+constexpr int R_PACKED_TOTAL = R_PACKED + 8 * RX_FRAGS;
 
 __device__ __forceinline__ void rhead_pack_x3_kernel_body(const RPackArgs& a, bf16x8* __restrict__ out, int s) {
     constexpr int N1 = RX_SZ1 / 3, NH = RX_SZH / 3;
@@ -95,7 +96,7 @@ __device__ __forceinline__ void rhead_pack_x3_kernel_body(const RPackArgs& a, bf
     const int T = region == 1 ? RX_T1 : RX_TH;
     const int ln = local & 63, i = ln & 31, kg = ln >> 5, m = (local >> 6) & 1, t = (local >> 7) % T, wv = (local >> 7) / T;
     const int f = 64 * wv + 32 * m + i;
-    bf16x8 p1, p2, p3;
+    bf16x8 p1, p2, p3, q1, q2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = 16 * t + 8 * kg + e;
@@ -111,11 +112,16 @@ __device__ __forceinline__ void rhead_pack_x3_kernel_body(const RPackArgs& a, bf
         __bf16 x, y, z;
         split3(v, x, y, z);
         p1[e] = x; p2[e] = y; p3[e] = z;
+        const _Float16 h = (_Float16)v, g = (_Float16)((v - (float)h) * 2048.0f);
+        q1[e] = __builtin_bit_cast(__bf16, h);
+        q2[e] = __builtin_bit_cast(__bf16, g);
     }
     const size_t base = (size_t)base_r + (size_t)((wv * T + t) * 2 + m) * 3 * 64 + ln;
     out[base] = p1;
     out[base + 64] = p2;
     out[base + 128] = p3;
+    out[RX_FRAGS + base] = q1;          // the H2 image (RH_OFF)
+    out[RX_FRAGS + base + 64] = q2;
 }
 
 constexpr int R_PACK_THREADS = R_PACKED > RX_FRAGS / 3 ? R_PACKED : RX_FRAGS / 3;

@@ -375,12 +375,12 @@ class PairList:
 # Arithmetic of the MLP / weight-gradient kernels (include/spurfies_hip.h: SPF_ARITH_*), chosen per call; this table is host-side
 # state of the Python layer only — the C ABI itself keeps none.  'split' (default): fp32-class products (<= 2 ulp per product) from three bf16 pieces per
 # operand on the bf16 matrix pipe; 'f32': fp32 MFMA (the verification twin).
-_ARITH = {"geo": 3, "color": 0, "rhead": 0, "wgrad": 0}        # geometry: H2 (round 6); the others: bf16 x 3
+_ARITH = {"geo": 3, "color": 0, "rhead": 0, "wgrad": 0}        # geometry: H2 (round 6); the others: the 'split' family, H2 inside it per kernel (_H2)
 _ARITH_NAMES = {"split": 0, "f32": 1}
 # H2 arithmetic (round 6; include/spurfies_hip.h: SPF_ARITH_H2) inside the 'split' family of the colour / head / weight-gradient kernels: per kernel,
 # the piece products are three fp16 ones (two fp16 pieces per operand, main + cross accumulators) instead of six bf16 ones; everything else of the
 # 'split' family — operand layouts, sign words, who forms the bias gradients — is unchanged, so forward and backward may differ in it.
-_H2 = {"color_fwd": True, "color_bwd": True, "rhead_fwd": False, "rhead_bwd": False, "wgrad": True}
+_H2 = {"color_fwd": True, "color_bwd": True, "rhead_fwd": True, "rhead_bwd": True, "wgrad": True}
 
 
 if os.environ.get("SPF_H2_FLAGS"):          # same-box A/B runs of whole programs: SPF_H2_FLAGS='{"color_bwd": false}'
@@ -1116,7 +1116,7 @@ class RHead(_GradModeFunction):
         agg3_c = agg3.detach().contiguous()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().spf_rhead_forward(_lib.ptr(agg3_c), _lib.ptr(ray_dirs), _lib.ptr(point_slot), _lib.ptr(n_points), P, int(SR),
-                                                    _lib.ptr(packed), _lib.ptr(colors), *[_lib.ptr(b) for b in bufs], _ARITH["rhead"],
+                                                    _lib.ptr(packed), _lib.ptr(colors), *[_lib.ptr(b) for b in bufs], _arith_of(_ARITH["rhead"], "rhead_fwd"),
                                                     _lib.stream_ptr()), "spf_rhead_forward")
         ctx.arith = _ARITH["rhead"]
         if train:
@@ -1145,7 +1145,7 @@ class RHead(_GradModeFunction):
             _lib.check(_lib.lib().spf_rhead_backward(_lib.ptr(g_colors), _lib.ptr(colors), _lib.ptr(point_slot), _lib.ptr(n_points), P, _lib.ptr(packed),
                                                      _lib.ptr(act2), _lib.ptr(masks), _lib.ptr(G1), _lib.ptr(G2), _lib.ptr(g_agg), _lib.ptr(g_agg3),
                                                      _lib.ptr(g_b6), _lib.ptr(g_b0), _lib.ptr(g_b2), _lib.ptr(g_w4), _lib.ptr(g_b4), _lib.ptr(acc_w),
-                                                     _lib.ptr(acc_b), ctx.arith, _lib.stream_ptr()), "spf_rhead_backward")
+                                                     _lib.ptr(acc_b), _arith_of(ctx.arith, "rhead_bwd"), _lib.stream_ptr()), "spf_rhead_backward")
         if fixed:
             _fixed_flush(acc_w, g_w4)
             _fixed_flush(acc_b, g_b4)

@@ -38,7 +38,7 @@ def oracle_step(scene, n_rays, view, seed):
     return inp, rgb_gt, mask_gt, out, losses, grads, stages
 
 
-def check_against_oracle(scene, n_rays, view, seed, min_points):
+def check_against_oracle(scene, n_rays, view, seed, min_points, weight_kink_frac=2e-4, weight_kink_rtol=None):
     from spurfies_amd import ops
     from spurfies_amd.model.loss import VolSDFLoss
     from spurfies_amd.train import TrainStep
@@ -95,7 +95,9 @@ def check_against_oracle(scene, n_rays, view, seed, min_points):
             if bad_rows.any():
                 assert float(dev.max()) <= 0.05, (pname, dev.max())
         else:
-            assert_close_except_kinks(got, want, rtol=GRAD_RTOL, atol=GRAD_RTOL * scale + 1e-12, max_frac=2e-4, err_msg=pname)
+            assert_close_except_kinks(got, want, rtol=GRAD_RTOL, atol=GRAD_RTOL * scale + 1e-12, max_frac=weight_kink_frac, err_msg=pname)
+            if weight_kink_rtol is not None:      # ... and what misses the tight bound misses it by little (a slope flip of ONE point's unit, spread over a dense gradient)
+                np.testing.assert_allclose(got, want, rtol=weight_kink_rtol, atol=weight_kink_rtol * scale + 1e-12, err_msg=pname + " (kink bound)")
         np.testing.assert_allclose(float(p.grad.norm()), float(np.linalg.norm(want.astype(np.float64))), rtol=1e-3, err_msg=pname + " l2")
     return inp, gt, olosses, model
 
@@ -124,4 +126,9 @@ def test_large_clouds_32_ray_batch_matches_oracle(n_points, spacing):
     scene = syn.make_scene(n_points, seed=21, spacing=spacing)
     assert tuple(scene["ranges"])[0] == -2.0
     scene["intrinsics"], scene["poses"] = syn.make_cameras(ring_radius=4.0)
-    check_against_oracle(scene, 32, view=0, seed=6, min_points=500)
+    # Weight tensors: with 32 rays a single point's LeakyReLU kink in the HEAD (R.0 unit 122 of one dominant point, dense cloud) moves entries of every
+    # dense weight gradient by 0.2 - 0.4 %: 15 - 121 entries per tensor (<= 0.4 %) miss the 2e-3 bound, none by more than 4.4e-3.  Measured on MI355X,
+    # round 6: the fp32-MFMA twin of the head kernels (set_rhead_mode('f32')) and the default H2 head kernels give the SAME rows and counts to the
+    # digit — they take the kink the way true fp32 arithmetic does — while the bf16 x 3 head kernels (products exact to 2^-24) side with the CPU
+    # oracle and meet 2e-4 (the allowance while they were the default).  Allowed: 0.5 % of a tensor's entries outside 2e-3, every entry within 1e-2.
+    check_against_oracle(scene, 32, view=0, seed=6, min_points=500, weight_kink_frac=5e-3, weight_kink_rtol=1e-2)
