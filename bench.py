@@ -538,7 +538,7 @@ def main_eval(args):
 
 
 def csrc_digest():
-    """sha256 over the library's sources (spurfies_amd/csrc/*, include/spurfies_hip.h): the identity of the KERNEL code of this tree.  The
+    """sha256 over the library's sources (spurfies_amd/csrc/*, include/spurfies_hip.h) and its compiler flags: the identity of the KERNEL code of this tree.  The
     counter / power collections under profiles/ record it (tools/pmc_traffic.py, tools/power_probe.py); a collection whose digest differs from
     the running tree's is stale evidence and is not quoted (round-4 verdict item 8)."""
     import hashlib
@@ -548,6 +548,9 @@ def csrc_digest():
     for path in files + [os.path.join(ROOT, "include", "spurfies_hip.h")]:
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
+    from spurfies_amd import build as _build
+
+    h.update(" ".join(_build.FLAGS).encode())          # the compiler flags are part of the kernels' identity (round 6: -amdgpu-mfma-vgpr-form)
     return h.hexdigest()
 
 

@@ -15,13 +15,22 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspurfies_hip.so")
 SOURCES = ["grid.hip", "geo_mlp.hip", "color_mlp.hip", "rhead_mlp.hip", "wgrad.hip", "render.hip", "sampler.hip", "latents.hip", "camera.hip", "loss.hip", "local.hip", "optim.hip"]
+# -amdgpu-mfma-vgpr-form (round 6): MFMA accumulators in architectural VGPRs.  The compiler's default put the H2 kernels' accumulators (main + cross:
+# 128 registers per wave tile) into AGPRs and paid a v_accvgpr_read per element in every epilogue — 21 % of the geometry kernel's vector
+# instructions, 12 - 14 % of the colour / head kernels' (static counts: geo main pass 12 445 -> 10 417 VALU, head backward 6 222 -> 5 467); the
+# kernels are VALU- and power-bound beside the matrix pipe, so the step went 3.45 -> 3.29 ms on one box (A B B A B A).  No scratch in any kernel.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
-         "-Wall", "-Wno-unused-function"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wall", "-Wno-unused-function"]
+FLAGS_STAMP = os.path.join(LIBDIR, "build_flags.txt")      # objects built with other flags are stale
+
+
+def _flags_text() -> str:
+    return " ".join(FLAGS + os.environ.get("SPF_EXTRA_HIPCC_FLAGS", "").split())
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
+    if not os.path.exists(LIB) or (os.path.exists(FLAGS_STAMP) and open(FLAGS_STAMP).read() != _flags_text()):
+        return True                                    # (a library that travelled without its stamp is taken as it is: dates decide)
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "spurfies_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
@@ -49,6 +58,8 @@ def build(force: bool = False, verbose: bool = True, incremental: bool = False) 
     if not force and not incremental and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    if incremental and not (os.path.exists(FLAGS_STAMP) and open(FLAGS_STAMP).read() == _flags_text()):
+        force = True                                   # other (or unknown) flags than the objects on disk were built with: everything again
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "spurfies_hip.h")]
@@ -66,6 +77,8 @@ def build(force: bool = False, verbose: bool = True, incremental: bool = False) 
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(_flags_text())
     return LIB
 
 
