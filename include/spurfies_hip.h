@@ -178,7 +178,8 @@ int spf_compact_pairs_filter(const uint8_t* slot_valid, const int32_t* nbr, int3
  *                    products with i + j <= 4 run on the bf16 matrix pipe with fp32 accumulation: each piece product is exact,
  *                    the three dropped ones are below 2^-24 of the product each — fp32-CLASS accuracy (<= 2 ulp per product,
  *                    tests/test_gpu_wgrad.py; results differ from SPF_ARITH_F32 by that and by summation order), at 2.7x the
- *                    matrix rate.  What the product path uses.  The geometry kernel runs it on v_mfma_f32_16x16x32_bf16.
+ *                    matrix rate.  The product path's arithmetic of rounds 1 - 5 (since round 6 the Python layer passes SPF_ARITH_H2 where a kernel
+ *                    takes it).  The geometry kernel runs it on v_mfma_f32_16x16x32_bf16.
  *   SPF_ARITH_F32    v_mfma_f32_32x32x2_f32 (verification twin).
  *   SPF_ARITH_SPLIT_W  spf_geo_forward only: SPF_ARITH_SPLIT's arithmetic on v_mfma_f32_32x32x16_bf16 tiles (same products, other
  *                    summation order) — the second MFMA shape of the dominant kernel, kept so that a benchmark can time both shapes

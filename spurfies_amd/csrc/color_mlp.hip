@@ -407,8 +407,9 @@ color_backward_kernel(const float* __restrict__ g_agg3, const int32_t* __restric
 
 
 // ==============================================================================================================================
-// The same two kernels on the bf16 matrix pipe with fp32-CLASS products (six exact bf16 piece products, <= 2 ulp per fp32 product) from three bf16 pieces per operand (the default;
-// arith = SPF_ARITH_F32 selects the fp32-MFMA kernels above).  Engine and arithmetic argument: mlp_tile_x3.h / geo_mlp.hip.
+// The same two kernels on the bf16 matrix pipe with fp32-CLASS products (six exact bf16 piece products, <= 2 ulp per fp32 product) from three bf16 pieces per operand (arith = SPF_ARITH_SPLIT; rounds 1 - 5's default)
+// or, since round 6, three exact fp16 piece products from two fp16 pieces per operand (arith = SPF_ARITH_H2: the template flag H2 below; what the Python layer
+// passes by default); arith = SPF_ARITH_F32 selects the fp32-MFMA kernels above.  Engine and arithmetic argument: mlp_tile_x3.h / geo_mlp.hip.
 //   * layers 0 and 2 run as transposed products (a lane owns 4 consecutive features of one row, the epilogue rewrites the bf16
 //     planes with 8-byte stores); layer 4 — whose output only feeds the RBF-weighted mean — runs non-transposed, so that a lane
 //     owns a column strip and takes the segmented weighted sum straight from its accumulators, as the fp32 kernel does;

@@ -498,7 +498,7 @@ __global__ void geo_pack_kernel(PackArgs a, float* __restrict__ out) {
 
 
 // ==============================================================================================================================
-// Same path with fp32-CLASS products (six exact bf16 piece products, <= 2 ulp per fp32 product) from three bf16 pieces per operand (the default; arith = SPF_ARITH_F32 selects the kernel above).
+// Same path with fp32-CLASS products (six exact bf16 piece products, <= 2 ulp per fp32 product) from three bf16 pieces per operand (arith = SPF_ARITH_SPLIT / SPF_ARITH_SPLIT_W; rounds 1 - 5's default.  Round 6's default is H2 — three exact fp16 piece products from two fp16 pieces per operand — on the 32x32x16 engine further down: SPF_ARITH_H2.  arith = SPF_ARITH_F32 selects the kernel above).
 //   x = p1 + p2 + p3, p1 = bf16(x), p2 = bf16(x - p1), p3 = bf16(x - p1 - p2): both differences are exact in fp32 and 3 x 8
 //   mantissa bits cover fp32's 24; a product of two fp32 numbers is sum_{i,j} a_i b_j, every piece product is exact in the
 //   MFMA's fp32 accumulation and the three with i + j >= 5 are below 2^-24 of the product, so the six with i + j <= 4 give the

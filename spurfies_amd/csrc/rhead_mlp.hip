@@ -327,8 +327,8 @@ rhead_backward_kernel(const float* __restrict__ g_colors, const float* __restric
 
 
 // ==============================================================================================================================
-// The same two kernels on the bf16 matrix pipe with fp32-class products (<= 2 ulp per product) from three bf16 pieces per operand (the default;
-// arith = SPF_ARITH_F32 selects the fp32-MFMA kernels above).  Engine: mlp_tile_x3.h; plane row stride 296 bf16 so that the first
+// The same two kernels on the bf16 matrix pipe with fp32-class products (<= 2 ulp per product) from three bf16 pieces per operand (arith = SPF_ARITH_SPLIT) or, since round 6
+// and by default, three exact fp16 piece products from two fp16 pieces (arith = SPF_ARITH_H2: template flag H2); arith = SPF_ARITH_F32 selects the fp32-MFMA kernels above.  Engine: mlp_tile_x3.h; plane row stride 296 bf16 so that the first
 // head layer's 288-wide input ([agg 256 | dir-enc 21 | 0]) is one GEMM.  One workgroup per CU (113.7 KB of planes).
 // Bias gradients of the three 256-wide layers are column sums of g_agg / G1 / G2 and come from spf_wgrad (dbias) in this mode.
 // ==============================================================================================================================

@@ -8,7 +8,8 @@
 // K-huge / MN-tiny shape: every workgroup owns a slice of the rows and the FULL 256 x C output in accumulators, streams G and A
 // from HBM exactly once through an LDS ring filled by LDS-DMA and leaves its partial in a slab; a second small kernel sums the
 // slabs (16 slices, float atomics) into dW.  Kernels in this file, newest first:
-//   wgrad_split8_kernel   default for C > 32: fp32-class products (<= 2 ulp per product) from three bf16 pieces per operand on the bf16 matrix pipe
+//   wgrad_split8_kernel   C > 32: fp32-class products from 16-bit pieces on the matrix pipe — three bf16 pieces per operand (SPF_ARITH_SPLIT, <= 2 ulp per product)
+//                         or two block-scaled fp16 pieces (SPF_ARITH_H2, round 6: what the Python layer passes by default)
 //   wgrad_dma_kernel      fp32 MFMA, LDS-DMA staged (arith = SPF_ARITH_F32; the verification twin of the above)
 //   wgrad_lds_kernel      fp32 MFMA, register-staged (C in (128, 256) that is not 256)
 //   wgrad_narrow_kernel   fp32 MFMA, direct loads (C <= 32)
