@@ -239,3 +239,56 @@ def test_trainer_leaves_h2_when_updates_were_skipped_as_non_finite(tmp_path):
     finally:
         ops.set_geo_mode(prev_geo)
         ops.set_h2(**prev_h2)
+
+
+@pytest.mark.gpu
+def test_graph_trainer_survives_the_arithmetic_fallback(tmp_path):
+    """VolOpt(use_graph=True, arith_guard=2): the guard's look after step 2 reports skipped updates (injected), the process moves from H2 to the
+    bf16 x 3 kernels, the captured step is dropped and RE-CAPTURED by the next call — training continues with finite losses that track the run it
+    would have been (same scene, same draws: the two piece forms agree to fp32 accuracy), and the kernels that run afterwards are the bf16 x 3 ones."""
+    import warnings
+
+    from spurfies_amd import ops
+    from spurfies_amd import synthetic as syn
+    from spurfies_amd.conf import Conf
+    from spurfies_amd.train import SyntheticDataset, VolOpt
+
+    scene = syn.make_scene(3000, seed=6, prior="fitted")
+    prior = {k: torch.from_numpy(np.asarray(v)) for k, v in scene["state"].items() if k.startswith(("F_geometry", "T."))}
+    prev_h2, prev_geo = dict(ops._H2), ops.geo_mode()
+    runs = {}
+    try:
+        for name, inject in (("plain", False), ("fallback", True)):
+            ops.set_geo_mode(prev_geo)
+            ops.set_h2(**prev_h2)
+            args = Conf(exps_folder="exps", grad_clip=True, vol=Conf(train=Conf(expname="ours", num_pixels=256, checkpoint_freq=0), dataset=Conf(data_dir="dtu")))
+            torch.manual_seed(4)
+            t = VolOpt(args=args, batch_size=1, scan="scan24", root=str(tmp_path / name), scene=scene, dataset=SyntheticDataset(scene, local=True),
+                       neural_points={"pts": scene["state"]["neural_pts"], "colors": scene["colors"]}, prior_state_dict=prior, device="cuda",
+                       init_state_dict={"neural_feats_geometry": torch.from_numpy(scene["state"]["neural_feats_geometry"])}, use_graph=True,
+                       arith_guard=2 if inject else 0)
+            t.gen_dataset(2)
+            if inject:
+                real = t.step.skipped_updates
+                t.step.skipped_updates = lambda: real() + 1          # "one update was skipped since the last look"
+            torch.manual_seed(0)
+            losses = []
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                for i in range(5):
+                    t.train_dataset.change_sampling_idx(256)
+                    batch = t.train_dataset.collate_fn([t.train_dataset[i % 3]])
+                    losses.append(float(t.train_step(batch)["loss"].item()))
+            runs[name] = losses
+            if inject:
+                assert t._arith_fallback and ops.geo_mode() == "split_w" and not any(ops._H2.values())
+                assert sum("non-finite" in str(x.message) for x in w) == 1
+                assert t.step._graph is not None                      # re-captured after the switch
+                assert real() == 0                                    # nothing was actually skipped: every update of the five ran
+            else:
+                assert ops.geo_mode() == "h2"
+        assert all(np.isfinite(v) for v in runs["fallback"])
+        np.testing.assert_allclose(runs["fallback"], runs["plain"], rtol=2e-3)
+    finally:
+        ops.set_geo_mode(prev_geo)
+        ops.set_h2(**prev_h2)
